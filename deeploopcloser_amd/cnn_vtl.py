@@ -1,0 +1,135 @@
+"""CnnVtl encoder with the reference's call surface, running on MI355X.
+
+Mirrors src/cnn_vtl/network/cnn_vtl.py: ctor (:13-17), model (:28-128),
+transform (:130-133).  Each convolution is im2col + one fp64 MFMA GEMM with the
+bias / ReLU fused (dlc_gemm_bias_act); pooling, per-row min/max, the 0..255
+scaling, the int8 cast and the column gather are HIP kernels too.
+
+The reference's weights (bvlc_alexnet.npy, cnn_vtl.py:137-149) are a git-LFS
+pointer upstream, so weights here are seeded synthetic AlexNet-shaped tensors
+unless set_weights()/load_alexnet_npy() is used.  The reference's column mask
+is drawn from the unseeded global NumPy RNG (:118-128); here the same draw
+takes an explicit ``mask_seed``.
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+from .engine import default_engine
+from .math_utils import MathUtils
+
+# (name, kh, kw, cin, cout, stride, padding, relu, pool_after) -- cnn_vtl.py:33-93
+_LAYERS = (
+    ("conv1", 11, 11, 3, 96, 4, "VALID", True, True),
+    ("conv2", 5, 5, 96, 256, 1, "SAME", True, True),
+    ("conv3", 3, 3, 256, 384, 1, "SAME", True, False),
+    ("conv4", 3, 3, 384, 384, 1, "SAME", True, False),
+    ("conv5", 3, 3, 384, 256, 1, "SAME", False, False),
+)
+
+
+def _out_size(n, k, s, padding):
+    if padding == "VALID":
+        return (n - k) // s + 1, 0
+    o = -(-n // s)
+    pad = max((o - 1) * s + k - n, 0)
+    return o, pad // 2
+
+
+class CnnVtl:
+    def __init__(self, input_shape=(1, 224, 224, 3), batch_size: int = 10, compress_factor: float = 99.59,
+                 seed=0, mask_seed=0, device=None, frame_chunk=128):
+        if len(input_shape) != 4 or any(int(v) <= 0 for v in input_shape) or input_shape[3] != 3:
+            raise ValueError("input_shape must be [N, H, W, 3] with positive entries")
+        if not (0 <= compress_factor <= 100):
+            raise ValueError("compress_factor must be between 0 and 100")        # v8n rule, cnn_vtl.py:22
+        self.input_shape = list(input_shape)
+        self.batch_size = batch_size
+        self.compress_factor = compress_factor
+        self.frame_chunk = int(frame_chunk)
+        self.engine = default_engine(device)
+        self._define_model(seed, mask_seed)
+
+    def _define_model(self, seed, mask_seed):
+        h, w = self.input_shape[1], self.input_shape[2]
+        self._geom, self.layer_sizes = [], []
+        for name, kh, kw, cin, cout, s, pad, relu, pool in _LAYERS:
+            oh, ph = _out_size(h, kh, s, pad)
+            ow, pw = _out_size(w, kw, s, pad)
+            self._geom.append((kh, kw, cin, cout, s, ph, pw, oh, ow, relu, pool))
+            self.layer_sizes.append(oh * ow * cout)
+            h, w = oh, ow
+            if pool:
+                h, w = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        rng = np.random.RandomState(seed)
+        ws, bs = [], []
+        for _, kh, kw, cin, cout, _, _, _, _ in _LAYERS:
+            ws.append(rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin))
+            bs.append(rng.standard_normal(cout) * 0.1)
+        self.set_weights(ws, bs)
+        # column mask, cnn_vtl.py:118-128 (choice WITH replacement, union)
+        mrng = np.random.RandomState(mask_seed)
+        mask = np.zeros(int(np.sum(self.layer_sizes)), dtype=bool)
+        start = 0
+        for size in self.layer_sizes:
+            idx = mrng.choice(np.arange(start, start + size), size=MathUtils.compressed_size(size, self.compress_factor))
+            start += size
+            mask[idx] = True
+        self.set_columns(np.nonzero(mask)[0])
+
+    def set_columns(self, columns):
+        columns = np.asarray(columns, dtype=np.int64)
+        total = int(np.sum(self.layer_sizes))
+        if columns.ndim != 1 or columns.size == 0 or columns.min() < 0 or columns.max() >= total:
+            raise ValueError("columns must be a non-empty 1-D index list into the %d-wide descriptor" % total)
+        self.columns = columns
+        self._columns_dev = torch.from_numpy(columns).to(self.engine.device)
+
+    def set_weights(self, weights, biases):
+        """HWIO kernels + biases for conv1..conv5."""
+        ws, bs = [], []
+        for (name, kh, kw, cin, cout, *_), w, b in zip(_LAYERS, weights, biases):
+            w = np.asarray(w, dtype=np.float64)
+            if w.shape != (kh, kw, cin, cout):
+                raise ValueError("%s kernel must be %s, got %s" % (name, (kh, kw, cin, cout), w.shape))
+            ws.append(self.engine.to_device(w.reshape(kh * kw * cin, cout), torch.float64))
+            bs.append(self.engine.to_device(np.asarray(b, dtype=np.float64).reshape(cout), torch.float64))
+        self._w, self._b = ws, bs
+
+    def load_alexnet_npy(self, path):
+        """The {layer: [W, b]} dict layout of bvlc_alexnet.npy (cnn_vtl.py:137-149), fc6-8 skipped."""
+        d = np.load(path, encoding="bytes", allow_pickle=True).item()
+        names = [l[0] for l in _LAYERS]
+        self.set_weights([d[n][0] for n in names], [d[n][1] for n in names])
+
+    def _features(self, x):
+        """conv1..conv5 outputs of a frame chunk: list of [n, oh, ow, cout] fp64 tensors."""
+        e = self.engine
+        outs = []
+        h = x
+        n = x.shape[0]
+        for (kh, kw, cin, cout, s, ph, pw, oh, ow, relu, pool), w, b in zip(self._geom, self._w, self._b):
+            cols = e.im2col(h, kh, kw, s, ph, pw, oh, ow)
+            y = e.gemm_bias_act(cols, w, b, act=L.DLC_ACT_RELU if relu else L.DLC_ACT_NONE)
+            del cols
+            y = y.reshape(n, oh, ow, cout)
+            outs.append(y)
+            h = e.maxpool3x3s2(y) if pool else y
+        return outs
+
+    def transform_tensor(self, x):
+        x = self.engine.to_device(x, torch.float64)
+        if x.dim() != 4 or list(x.shape[1:]) != list(self.input_shape[1:]):
+            raise ValueError("expected input of shape [N, %d, %d, 3], got %s" %
+                             (self.input_shape[1], self.input_shape[2], tuple(x.shape)))
+        parts = []
+        for lo in range(0, x.shape[0], self.frame_chunk):
+            outs = self._features(x[lo:lo + self.frame_chunk].contiguous())
+            parts.append(self.engine.minmax_quant_gather(outs, self._columns_dev))
+        if not parts:
+            return torch.empty((0, self.columns.size), dtype=torch.int8, device=self.engine.device)
+        return torch.cat(parts, dim=0)
+
+    def transform(self, x):
+        """CnnVtl.transform (cnn_vtl.py:130-133): frames [N,H,W,3] -> int8 [N, D']."""
+        return self.transform_tensor(x).cpu().numpy()

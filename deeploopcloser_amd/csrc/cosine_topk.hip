@@ -1,0 +1,656 @@
+// Cosine-similarity + top-k match for gfx950 (MI355X).
+//
+// Pipeline of one dlc_cosine_topk() call (all on the caller's stream):
+//   1. score_gemm_kernel   S~ = DB . Q^T on the bf16/f16 MFMA (fp32 accumulate).
+//      The score tile never leaves the accumulators: the epilogue keeps, per
+//      query, the maximum of every aligned block of 16 database rows
+//      ("group", gmax) and of every 128 rows ("half tile", tmax).  The
+//      database is streamed from HBM exactly once.
+//   2. select_groups_kernel  per query: the kg = k + SLACK half tiles with the
+//      largest tmax, then the kg groups with the largest gmax inside them.
+//      Every member of the exact top-k lies in one of those groups (the k-th
+//      largest group maximum is a lower bound of the k-th largest score).
+//   3. rescore_kernel      exact fp32 dot products for the 16 rows of each
+//      selected group (a gather of kg*16 rows per query).
+//   4. final_topk_kernel   top-k of the kg*16 candidates, score descending,
+//      ties toward the lower database index.
+// dlc_topk_merge() is step 4 on an all-gather of per-shard results.
+//
+// MFMA operand roles: A = database rows, B = queries, so that in the 16x16 C/D
+// layout (col = lane&15, row = 4*(lane>>4)+reg) a lane holds ONE query and
+// FOUR database rows per tile: the per-group maximum is an in-lane v_max chain.
+// The A fragment's row i of MFMA tile tt is mapped to database row
+// 16*(i>>2) + 4*tt + (i&3) of the wave's 64-row half, which makes each lane's
+// 16 accumulators (4 tiles x 4 regs) one CONTIGUOUS block of 16 database rows.
+#include "dlc_internal.h"
+
+namespace {
+
+constexpr int BM = 256;          // database rows per workgroup tile
+constexpr int BNQ = 256;         // queries per workgroup tile
+constexpr int BK = 64;           // K step (elements); rows of the LDS image are 128 B
+constexpr int NTHREADS = 512;    // 8 waves: 2 (database halves of 128 rows) x 4 (64 queries)
+constexpr int TILE_BYTES = 256 * BK * 2;   // 32 KiB: one operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;  // A tile + B tile
+constexpr int LDS_BYTES = 2 * BUF_BYTES;   // double buffered: 128 KiB
+constexpr int GROUP = 16;        // database rows per group
+constexpr int HALF = 128;        // database rows per half tile
+constexpr int SLACK = 8;         // extra groups kept beyond k (fp32 re-score vs MFMA order)
+constexpr int MAX_KG = DLC_MAX_K + SLACK;
+
+template <typename Tag> struct Mfma16;
+template <> struct Mfma16<dlc_bf16_tag> {
+    static __device__ __forceinline__ f32x4_t run(uint4 a, uint4 b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                       __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(unsigned short h) { return dlc_bf16_bits_to_f32(h); }
+};
+template <> struct Mfma16<dlc_f16_tag> {
+    static __device__ __forceinline__ f32x4_t run(uint4 a, uint4 b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                      __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(unsigned short h) { return dlc_f16_bits_to_f32(h); }
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+// LDS image of an operand tile: 256 rows x 128 B, 16-B chunk `ch` of row `r`
+// lives in slot ch ^ f(r).  f is chosen so that each ds_read_b128 lane group of
+// a fragment read covers 16 distinct slots of the 256-B bank row:
+//   A (database, permuted fragment rows): f = bit1(r) | bits5:4(r) << 1
+//   B (queries, consecutive fragment rows): f = bits3:1(r)
+__device__ __forceinline__ int swz_a(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }
+__device__ __forceinline__ int swz_b(int r) { return (r >> 1) & 7; }
+
+struct GemmArgs {
+    const char* Q;      // [q, ldq] elements of 2 bytes
+    const char* DB;     // [n, lddb]
+    long long ldq_b;    // row strides in BYTES
+    long long lddb_b;
+    int q;
+    long long n;
+    int nk;             // d / 64
+    float* gmax;        // [q, ldg]
+    long long ldg;
+    float* tmax;        // [q, ldt]
+    long long ldt;
+    long long ng;       // ceil(n/16)
+    long long nh;       // ceil(n/128)
+    float* S;           // dense mode: [q, lds]
+    long long lds;
+};
+
+template <typename Tag, bool DENSE>
+__global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2;   // database half (128 rows)
+    const int wc = wid & 3;    // query block (64 queries)
+    const long long tile = blockIdx.x;
+    const int qblk = blockIdx.y;
+
+    // ---- staging addresses: wave `wid` stages LDS rows 32*wid .. 32*wid+31 of both tiles
+    const char* srcA[4];
+    const char* srcB[4];
+    const int slot = lane & 7;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int R = 32 * wid + 8 * ii + (lane >> 3);
+        long long dbrow = tile * BM + R;
+        if (dbrow > p.n - 1) dbrow = p.n - 1;
+        srcA[ii] = p.DB + dbrow * p.lddb_b + ((slot ^ swz_a(R)) << 4);
+        int qrow = qblk * BNQ + R;
+        if (qrow > p.q - 1) qrow = p.q - 1;
+        srcB[ii] = p.Q + (long long)qrow * p.ldq_b + ((slot ^ swz_b(R)) << 4);
+    }
+    const int lds_stage = (32 * wid) * 128;   // + ii * 1024
+
+    // ---- fragment read offsets
+    const int i = lane & 15;
+    const int kq = lane >> 4;
+    const int fa = ((i >> 1) & 1) | ((i >> 2) << 1);
+    const int fb = (i >> 1) & 7;
+    const int rowA0 = wr * 128 + 16 * (i >> 2) + (i & 3);
+    const int rowB0 = wc * 64 + i;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        offA[ks] = rowA0 * 128 + (((4 * ks + kq) ^ fa) << 4);
+        offB[ks] = TILE_BYTES + rowB0 * 128 + (((4 * ks + kq) ^ fb) << 4);
+    }
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: stage K tile 0 into buffer 0
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        glds16(srcA[ii], smem + lds_stage + ii * 1024);
+        glds16(srcB[ii], smem + TILE_BYTES + lds_stage + ii * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // LDS-DMA drained by every wave, then visible to all
+
+    for (int kt = 0; kt < p.nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < p.nk) {
+            char* nb = smem + (cur ^ 1) * BUF_BYTES + lds_stage;
+            const long long ko = (long long)(kt + 1) * 128;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                glds16(srcA[ii] + ko, nb + ii * 1024);
+                glds16(srcB[ii] + ko, nb + TILE_BYTES + ii * 1024);
+            }
+        }
+        const char* base = smem + cur * BUF_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 b[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = *(const uint4*)(base + offB[ks] + c * 2048);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint4 a = *(const uint4*)(base + offA[ks] + (t >> 2) * 8192 + (t & 3) * 512);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t][c] = Mfma16<Tag>::run(a, b[c], acc[t][c]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // next tile landed; everyone done reading `cur`
+    }
+
+    // ---- epilogue
+    const int lg = lane >> 4;
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int qidx = qblk * BNQ + wc * 64 + c * 16 + i;
+            if (qidx >= p.q) continue;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const long long row0 = tile * BM + wr * 128 + (t >> 2) * 64 + 16 * lg + 4 * (t & 3);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < p.n) p.S[(long long)qidx * p.lds + row0 + r] = acc[t][c][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int qidx = qblk * BNQ + wc * 64 + c * 16 + i;
+            float hm[2];
+#pragma unroll
+            for (int th = 0; th < 2; ++th) {
+                float m = acc[th * 4][c][0];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[th * 4 + tt][c][r]);
+                hm[th] = m;
+                const long long g = tile * (BM / GROUP) + wr * 8 + th * 4 + lg;
+                if (qidx < p.q && g < p.ng) p.gmax[(long long)qidx * p.ldg + g] = m;
+            }
+            float h = fmaxf(hm[0], hm[1]);
+            h = fmaxf(h, __shfl_xor(h, 16));
+            h = fmaxf(h, __shfl_xor(h, 32));
+            const long long ht = tile * 2 + wr;
+            if (lg == 0 && qidx < p.q && ht < p.nh) p.tmax[(long long)qidx * p.ldt + ht] = h;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// selection helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f32_key(float x) {   // monotone: larger float -> larger key
+    unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// true if candidate (sa, ia) sorts before (sb, ib): score descending, id ascending.
+__device__ __forceinline__ bool before(float sa, long long ia, float sb, long long ib) {
+    return (sa > sb) || (sa == sb && ia < ib);
+}
+
+// Workgroup (256 threads) radix select: writes into sel[0..kt) the indices of
+// the kt largest of vals[0..m) (ties at the threshold -> lower index first).
+// The result SET is deterministic; its order is (greater-than part in index
+// order, then threshold ties in index order).  Requires 1 <= kt <= m.
+__device__ void wg_select_topk_indices(const float* __restrict__ vals, int m, int kt, int* sel,
+                                       unsigned* hist /*[256]*/, int* scratch /*[16]*/) {
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, mask = 0;
+    int remaining = kt;
+    for (int pass = 3; pass >= 0; --pass) {
+        const int sh = pass * 8;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int e = tid; e < m; e += blockDim.x) {
+            const unsigned k = f32_key(vals[e]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, b = 255;
+            for (; b > 0; --b) {
+                const int h = (int)hist[b];
+                if (cum + h >= remaining) break;
+                cum += h;
+            }
+            scratch[0] = b;
+            scratch[1] = remaining - cum;
+        }
+        __syncthreads();
+        prefix |= ((unsigned)scratch[0]) << sh;
+        mask |= 255u << sh;
+        remaining = scratch[1];
+        __syncthreads();
+    }
+    const unsigned T = prefix;          // key of the kt-th largest value
+    const int n_gt = kt - remaining;    // values strictly above T
+    // ordered compaction, 256 elements per step
+    const int lane = tid & 63, w = tid >> 6;
+    int* wsum = scratch + 2;            // [4 waves][2]
+    int base_gt = 0, base_eq = 0;
+    for (int e0 = 0; e0 < m; e0 += 256) {
+        const int e = e0 + tid;
+        unsigned k = 0;
+        bool gt = false, eq = false;
+        if (e < m) {
+            k = f32_key(vals[e]);
+            gt = k > T;
+            eq = k == T;
+        }
+        const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+        const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int pg = __popcll(bg & lower), pe = __popcll(be & lower);
+        if (lane == 0) { wsum[w * 2] = __popcll(bg); wsum[w * 2 + 1] = __popcll(be); }
+        __syncthreads();
+        int og = base_gt, oe = base_eq, tg = 0, te = 0;
+        for (int ww = 0; ww < 4; ++ww) {
+            if (ww < w) { og += wsum[ww * 2]; oe += wsum[ww * 2 + 1]; }
+            tg += wsum[ww * 2];
+            te += wsum[ww * 2 + 1];
+        }
+        if (gt) sel[og + pg] = e;
+        if (eq && (oe + pe) < remaining) sel[n_gt + oe + pe] = e;
+        base_gt += tg;
+        base_eq += te;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void select_groups_kernel(const float* __restrict__ tmax, long long ldt,
+                                                            int nh, const float* __restrict__ gmax,
+                                                            long long ldg, long long ng, int kg,
+                                                            int* __restrict__ glist /*[q, kg]*/) {
+    __shared__ unsigned hist[256];
+    __shared__ int scratch[16];
+    __shared__ int s_tiles[MAX_KG];
+    __shared__ float cv[MAX_KG * 8];
+    __shared__ int cid[MAX_KG * 8];
+    const int qi = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int kt = min(kg, nh);
+    wg_select_topk_indices(tmax + (long long)qi * ldt, nh, kt, s_tiles, hist, scratch);
+    __syncthreads();
+    const int m2 = kt * 8;
+    for (int e = tid; e < m2; e += blockDim.x) {
+        const long long g = (long long)s_tiles[e >> 3] * 8 + (e & 7);
+        const bool ok = g < ng;
+        cv[e] = ok ? gmax[(long long)qi * ldg + g] : -INFINITY;
+        cid[e] = ok ? (int)g : 0x7fffffff;
+    }
+    __syncthreads();
+    for (int e = tid; e < kg; e += blockDim.x) glist[(long long)qi * kg + e] = -1;
+    __syncthreads();
+    for (int e = tid; e < m2; e += blockDim.x) {
+        const float s = cv[e];
+        const int id = cid[e];
+        if (id == 0x7fffffff) continue;
+        int rank = 0;
+        for (int j = 0; j < m2; ++j) rank += before(cv[j], cid[j], s, id) ? 1 : 0;
+        if (rank < kg) glist[(long long)qi * kg + rank] = id;
+    }
+}
+
+// One wave per (query, selected group): 16 exact fp32 dot products.
+template <typename Tag>
+__global__ __launch_bounds__(256) void rescore_kernel(const char* __restrict__ Q, long long ldq_b,
+                                                      const char* __restrict__ DB, long long lddb_b,
+                                                      long long n, int d, const int* __restrict__ glist, int kg,
+                                                      float* __restrict__ cand /*[q, kg*16]*/) {
+    const int qi = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= kg) return;
+    const int g = glist[(long long)qi * kg + s];
+    float* out = cand + ((long long)qi * kg + s) * GROUP;
+    if (g < 0) {
+        if (lane < GROUP) out[lane] = -INFINITY;
+        return;
+    }
+    const long long row0 = (long long)g * GROUP;
+    const char* qrow = Q + (long long)qi * ldq_b;
+    const char* rows[GROUP];
+#pragma unroll
+    for (int r = 0; r < GROUP; ++r) {
+        long long rr = row0 + r;
+        if (rr > n - 1) rr = n - 1;
+        rows[r] = DB + rr * lddb_b;
+    }
+    float acc[GROUP];
+#pragma unroll
+    for (int r = 0; r < GROUP; ++r) acc[r] = 0.f;
+    for (int d0 = lane * 8; d0 < d; d0 += 512) {
+        const uint4 qv = *(const uint4*)(qrow + (long long)d0 * 2);
+        uint4 rv[GROUP];
+#pragma unroll
+        for (int r = 0; r < GROUP; ++r) rv[r] = *(const uint4*)(rows[r] + (long long)d0 * 2);
+        const unsigned qw[4] = {qv.x, qv.y, qv.z, qv.w};
+        float qf[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qf[2 * e] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu));
+            qf[2 * e + 1] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16));
+        }
+#pragma unroll
+        for (int r = 0; r < GROUP; ++r) {
+            const unsigned w4[4] = {rv[r].x, rv[r].y, rv[r].z, rv[r].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[r] = fmaf(qf[2 * e], Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc[r]);
+                acc[r] = fmaf(qf[2 * e + 1], Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < GROUP; ++r) {
+        float v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        acc[r] = v;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < GROUP; ++r) out[r] = (row0 + r < n) ? acc[r] : -INFINITY;
+    }
+}
+
+// Top-k of m candidates per query (rank by counting, m <= a few thousand).
+// mode 0: candidates are cand[q, kg*16] with id = glist[q, e/16]*16 + e%16
+// mode 1: candidates are scores/idx [parts, q, k] (all-gather layout), idx < 0 = empty
+__global__ __launch_bounds__(256) void final_topk_kernel(int mode, const float* __restrict__ cand,
+                                                         const int* __restrict__ glist, int kg,
+                                                         const float* __restrict__ pscores,
+                                                         const long long* __restrict__ pidx, int parts,
+                                                         long long nq, int k, long long row_offset,
+                                                         float* __restrict__ out_s, long long* __restrict__ out_i) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int qi = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int m = mode == 0 ? kg * GROUP : parts * k;
+    float* cs = (float*)dsm;
+    long long* ci = (long long*)(dsm + dlc::align_up((size_t)m * 4, 16));
+    for (int e = tid; e < m; e += blockDim.x) {
+        float s;
+        long long id;
+        if (mode == 0) {
+            const int g = glist[(long long)qi * kg + (e >> 4)];
+            s = cand[(long long)qi * kg * GROUP + e];
+            id = (g < 0 || s == -INFINITY) ? 0x7fffffffffffffffll : (long long)g * GROUP + (e & 15) + row_offset;
+            if (g < 0) s = -INFINITY;
+        } else {
+            const long long o = ((long long)(e / k) * nq + qi) * k + (e % k);
+            id = pidx[o];
+            s = pscores[o];
+            if (id < 0) { id = 0x7fffffffffffffffll; s = -INFINITY; }
+        }
+        cs[e] = s;
+        ci[e] = id;
+    }
+    for (int e = tid; e < k; e += blockDim.x) {
+        out_s[(long long)qi * k + e] = -INFINITY;
+        out_i[(long long)qi * k + e] = -1;
+    }
+    __syncthreads();
+    for (int e = tid; e < m; e += blockDim.x) {
+        const float s = cs[e];
+        const long long id = ci[e];
+        if (id == 0x7fffffffffffffffll) continue;
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += before(cs[j], ci[j], s, id) ? 1 : 0;
+        if (rank < k) {
+            out_s[(long long)qi * k + rank] = s;
+            out_i[(long long)qi * k + rank] = id;
+        }
+    }
+}
+
+// Row L2 normalisation into the stored descriptor format.
+template <typename Src, typename Tag>
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const Src* __restrict__ src, long long lds, int d,
+                                                           int center, unsigned short* __restrict__ dst,
+                                                           long long ldd) {
+    __shared__ double red[8];
+    const long long row = blockIdx.x;
+    const Src* x = src + row * lds;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double mean = 0.0;
+    if (center) {
+        double s = 0.0;
+        for (int e = tid; e < d; e += 256) s += (double)x[e];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        mean = (red[0] + red[1] + red[2] + red[3]) / (double)d;
+        __syncthreads();
+    }
+    double ss = 0.0;
+    for (int e = tid; e < d; e += 256) {
+        const double v = (double)x[e] - mean;
+        ss += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) red[4 + w] = ss;
+    __syncthreads();
+    const double nrm = sqrt(red[4] + red[5] + red[6] + red[7]);
+    const double inv = nrm > 0.0 ? 1.0 / nrm : 1.0;
+    for (int e = tid; e < (int)ldd; e += 256) {
+        unsigned short bits = 0;
+        if (e < d) {
+            const float v = (float)(((double)x[e] - mean) * inv);
+            if constexpr (__is_same(Tag, dlc_bf16_tag)) {
+                bits = __builtin_bit_cast(unsigned short, (__bf16)v);
+            } else {
+                bits = __builtin_bit_cast(unsigned short, (_Float16)v);
+            }
+        }
+        dst[row * ldd + e] = bits;
+    }
+}
+
+struct WsLayout {
+    size_t gmax, tmax, glist, cand, total;
+    long long ldg, ldt;
+    int kg;
+};
+
+WsLayout ws_layout(int64_t q, int64_t n, int k) {
+    WsLayout w;
+    const int64_t ntiles = dlc::cdiv(n, BM);
+    w.ldg = ntiles * (BM / GROUP);
+    w.ldt = ntiles * 2;
+    w.kg = k + SLACK;
+    size_t o = 0;
+    w.gmax = o; o += dlc::align_up((size_t)q * w.ldg * 4, 256);
+    w.tmax = o; o += dlc::align_up((size_t)q * w.ldt * 4, 256);
+    w.glist = o; o += dlc::align_up((size_t)q * w.kg * 4, 256);
+    w.cand = o; o += dlc::align_up((size_t)q * w.kg * GROUP * 4, 256);
+    w.total = o;
+    return w;
+}
+
+int check_operands(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB, int64_t n,
+                   int64_t lddb, int64_t d) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (dtype != DLC_BF16 && dtype != DLC_F16)
+        return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "cosine match: dtype %d (need DLC_BF16 or DLC_F16)", dtype);
+    if (!Q || !DB || q < 1 || n < 1 || d < 1) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine match: null/empty operand");
+    if (d % BK != 0) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: d=%lld must be a multiple of %d", (long long)d, BK);
+    if (ldq < d || lddb < d || (ldq % 8) || (lddb % 8))
+        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: row strides must be >= d and multiples of 8 elements");
+    if (((uintptr_t)Q & 15) || ((uintptr_t)DB & 15))
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine match: operands must be 16-byte aligned");
+    if (q > 0x7fffff00ll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: q too large");
+    if (n / GROUP > 0x7ffffff0ll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: n too large for one shard");
+    return DLC_OK;
+}
+
+template <typename Tag, bool DENSE>
+int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
+    auto kern = score_gemm_kernel<Tag, DENSE>;
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)dlc::cdiv(a.n, BM), (unsigned)dlc::cdiv(a.q, BNQ));
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), LDS_BYTES, st, a);
+    DLC_LAUNCH_CHECK(ctx, "score_gemm_kernel");
+    return DLC_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dlc_cosine_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int k) {
+    (void)d;
+    if (q < 1 || n < 1 || k < 1 || k > DLC_MAX_K) return 0;
+    return ws_layout(q, n, k).total;
+}
+
+extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                               int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, float* out_scores,
+                               int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_operands(ctx, dtype, Q, q, ldq, DB, n, lddb, d);
+    if (rc != DLC_OK) return rc;
+    if (k < 1 || k > DLC_MAX_K) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk: k=%d outside 1..%d", k, DLC_MAX_K);
+    if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk: null output");
+    const WsLayout w = ws_layout(q, n, k);
+    if (!workspace || workspace_bytes < w.total)
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "cosine_topk: workspace %zu < %zu bytes", workspace_bytes, w.total);
+    if (((uintptr_t)workspace & 255)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk: workspace must be 256-byte aligned");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+
+    GemmArgs a;
+    a.Q = (const char*)Q; a.DB = (const char*)DB;
+    a.ldq_b = ldq * 2; a.lddb_b = lddb * 2;
+    a.q = (int)q; a.n = n; a.nk = (int)(d / BK);
+    a.gmax = (float*)(ws + w.gmax); a.ldg = w.ldg;
+    a.tmax = (float*)(ws + w.tmax); a.ldt = w.ldt;
+    a.ng = dlc::cdiv(n, GROUP); a.nh = dlc::cdiv(n, HALF);
+    a.S = nullptr; a.lds = 0;
+
+    ctx->have_gemm_events = 0;
+    if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_gemm_start, st));
+    rc = (dtype == DLC_BF16) ? launch_gemm<dlc_bf16_tag, false>(ctx, a, st) : launch_gemm<dlc_f16_tag, false>(ctx, a, st);
+    if (rc != DLC_OK) return rc;
+    if (ctx->profiling) {
+        DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_gemm_stop, st));
+        ctx->have_gemm_events = 1;
+    }
+
+    int* glist = (int*)(ws + w.glist);
+    float* cand = (float*)(ws + w.cand);
+    hipLaunchKernelGGL(select_groups_kernel, dim3((unsigned)q), dim3(256), 0, st, a.tmax, a.ldt, (int)a.nh, a.gmax,
+                       a.ldg, a.ng, w.kg, glist);
+    DLC_LAUNCH_CHECK(ctx, "select_groups_kernel");
+    dim3 rgrid((unsigned)dlc::cdiv(w.kg, 4), (unsigned)q);
+    if (dtype == DLC_BF16)
+        hipLaunchKernelGGL(rescore_kernel<dlc_bf16_tag>, rgrid, dim3(256), 0, st, a.Q, a.ldq_b, a.DB, a.lddb_b, n, (int)d,
+                           glist, w.kg, cand);
+    else
+        hipLaunchKernelGGL(rescore_kernel<dlc_f16_tag>, rgrid, dim3(256), 0, st, a.Q, a.ldq_b, a.DB, a.lddb_b, n, (int)d,
+                           glist, w.kg, cand);
+    DLC_LAUNCH_CHECK(ctx, "rescore_kernel");
+    const int m = w.kg * GROUP;
+    const size_t dsm = dlc::align_up((size_t)m * 4, 16) + (size_t)m * 8;
+    hipLaunchKernelGGL(final_topk_kernel, dim3((unsigned)q), dim3(256), dsm, st, 0, cand, glist, w.kg,
+                       (const float*)nullptr, (const long long*)nullptr, 0, (long long)q, k, (long long)row_offset,
+                       out_scores, (long long*)out_idx);
+    DLC_LAUNCH_CHECK(ctx, "final_topk_kernel");
+    return DLC_OK;
+}
+
+extern "C" int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* idx, int parts, int64_t q, int k,
+                              float* out_scores, int64_t* out_idx, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!scores || !idx || !out_scores || !out_idx || parts < 1 || q < 1 || k < 1 || k > DLC_MAX_K)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "topk_merge: bad argument");
+    const size_t m = (size_t)parts * k;
+    const size_t dsm = dlc::align_up(m * 4, 16) + m * 8;
+    if (dsm > 60000) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "topk_merge: parts*k=%zu too large", m);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipLaunchKernelGGL(final_topk_kernel, dim3((unsigned)q), dim3(256), dsm, (hipStream_t)stream, 1,
+                       (const float*)nullptr, (const int*)nullptr, 0, scores, (const long long*)idx, parts,
+                       (long long)q, k, 0ll, out_scores, (long long*)out_idx);
+    DLC_LAUNCH_CHECK(ctx, "final_topk_kernel(merge)");
+    return DLC_OK;
+}
+
+extern "C" int dlc_cosine_scores(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                                 int64_t n, int64_t lddb, int64_t d, float* S, int64_t lds, void* stream) {
+    int rc = check_operands(ctx, dtype, Q, q, ldq, DB, n, lddb, d);
+    if (rc != DLC_OK) return rc;
+    if (!S || lds < n) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_scores: bad output");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    GemmArgs a;
+    a.Q = (const char*)Q; a.DB = (const char*)DB;
+    a.ldq_b = ldq * 2; a.lddb_b = lddb * 2;
+    a.q = (int)q; a.n = n; a.nk = (int)(d / BK);
+    a.gmax = nullptr; a.ldg = 0; a.tmax = nullptr; a.ldt = 0; a.ng = 0; a.nh = 0;
+    a.S = S; a.lds = lds;
+    return (dtype == DLC_BF16) ? launch_gemm<dlc_bf16_tag, true>(ctx, a, (hipStream_t)stream)
+                               : launch_gemm<dlc_f16_tag, true>(ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* src, int64_t n, int64_t d, int64_t lds,
+                                     int center, int dst_dtype, void* dst, int64_t ldd, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!src || !dst || n < 1 || d < 1 || lds < d || ldd < d)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "l2_normalize_rows: bad argument");
+    if (ldd % BK) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "l2_normalize_rows: ldd=%lld must be a multiple of %d", (long long)ldd, BK);
+    if (ldd > 0x7fffffff) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "l2_normalize_rows: ldd too large");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)n), block(256);
+    unsigned short* o = (unsigned short*)dst;
+#define DLC_NORM(SRC, TAG) \
+    hipLaunchKernelGGL((l2_normalize_kernel<SRC, TAG>), grid, block, 0, st, (const SRC*)src, (long long)lds, (int)d, center, o, (long long)ldd)
+    if (src_dtype == DLC_F32 && dst_dtype == DLC_BF16) DLC_NORM(float, dlc_bf16_tag);
+    else if (src_dtype == DLC_F32 && dst_dtype == DLC_F16) DLC_NORM(float, dlc_f16_tag);
+    else if (src_dtype == DLC_F64 && dst_dtype == DLC_BF16) DLC_NORM(double, dlc_bf16_tag);
+    else if (src_dtype == DLC_F64 && dst_dtype == DLC_F16) DLC_NORM(double, dlc_f16_tag);
+    else return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "l2_normalize_rows: dtype pair %d -> %d", src_dtype, dst_dtype);
+#undef DLC_NORM
+    DLC_LAUNCH_CHECK(ctx, "l2_normalize_kernel");
+    return DLC_OK;
+}

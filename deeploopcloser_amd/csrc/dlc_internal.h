@@ -1,0 +1,80 @@
+// Internal helpers shared by the HIP translation units behind include/dlc.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dlc.h"
+
+struct dlc_ctx {
+    int device;
+    char err[512];
+    int profiling;
+    hipEvent_t ev_gemm_start;
+    hipEvent_t ev_gemm_stop;
+    int have_gemm_events;   // events recorded by the last cosine_topk call
+};
+
+namespace dlc {
+
+inline int fail(dlc_ctx* ctx, int status, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return status;
+}
+
+#define DLC_HIP_CHECK(ctx, expr)                                                              \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return dlc::fail((ctx), DLC_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                             hipGetErrorString(e__), __FILE__, __LINE__);                     \
+    } while (0)
+
+#define DLC_LAUNCH_CHECK(ctx, what)                                                           \
+    do {                                                                                      \
+        hipError_t e__ = hipGetLastError();                                                   \
+        if (e__ != hipSuccess)                                                                \
+            return dlc::fail((ctx), DLC_ERR_HIP, "launch of %s failed: %s", (what),           \
+                             hipGetErrorString(e__));                                         \
+    } while (0)
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// RAII-free device guard: the C ABI is re-entrant per context and each context
+// is bound to one device.
+struct DeviceGuard {
+    int prev;
+    bool ok;
+    explicit DeviceGuard(int dev) : prev(-1), ok(true) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace dlc
+
+// ---- device-side vector types ------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) double f64x4_t;
+
+struct dlc_bf16_tag {};
+struct dlc_f16_tag {};
+
+__device__ __forceinline__ float dlc_bf16_bits_to_f32(unsigned short h) {
+    return __uint_as_float(((unsigned)h) << 16);
+}
+__device__ __forceinline__ float dlc_f16_bits_to_f32(unsigned short h) {
+    _Float16 v = __builtin_bit_cast(_Float16, h);
+    return (float)v;
+}

@@ -1,0 +1,263 @@
+// Dense GEMM with fused bias + activation on the fp64 / fp32-input MFMA of
+// gfx950: the SDAV / DA layers (sigmoid(x.W + b)) and the CnnVtl convolutions
+// (im2col . HWIO + b, ReLU) in the reference's own arithmetic type.
+//
+//   fp64: v_mfma_f64_16x16x4_f64   C/D row = (lane>>4) + 4*reg, col = lane&15
+//   fp32: v_mfma_f32_16x16x4_f32   C/D row = 4*(lane>>4) + reg, col = lane&15
+//   A operand: lane holds A[row = lane&15][k = lane>>4]; B: B[k = lane>>4][col = lane&15]
+//
+// Workgroup tile 128 x 128, K step 16, 4 waves (2 x 2), each wave 64 x 64 =
+// 4 x 4 MFMA tiles.  Operands are staged global -> registers -> LDS (padded
+// rows, so arbitrary M/N/K and odd leading dimensions such as 1681 work with
+// plain predicated loads); the next K tile's global loads are issued before
+// the current tile's MFMAs.
+#include "dlc_internal.h"
+
+namespace dlc_gemm {
+
+constexpr int TM = 128, TN = 128, TK = 16;
+constexpr int LDA_S = TK + 1;      // A tile [128][17]: conflict-free column-of-rows reads
+constexpr int LDB_KN = TN + 16;    // B tile [16][144] for B stored [K,N]
+constexpr int LDB_NK = TK + 1;     // B tile [128][17] for B stored [N,K]
+
+template <typename T> struct Mma;
+template <> struct Mma<double> {
+    typedef f64x4_t acc_t;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mma<float> {
+    typedef f32x4_t acc_t;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+template <typename T>
+__device__ __forceinline__ T apply_act(T z, int act) {
+    if (act == DLC_ACT_SIGMOID) return (T)1 / ((T)1 + exp(-z));   // tf.nn.sigmoid
+    if (act == DLC_ACT_RELU) return z > (T)0 ? z : (T)0;
+    return z;
+}
+
+template <typename T>
+struct Args {
+    const T* A; long long lda;
+    const T* B; long long ldb;
+    const T* bias;
+    T* C; long long ldc;
+    long long M, N, K;
+    int act;
+};
+
+template <typename T, int BLAYOUT>
+__global__ __launch_bounds__(256) void gemm_bias_act_kernel(Args<T> p) {
+    constexpr int LDB_S = BLAYOUT == DLC_B_KN ? LDB_KN : LDB_NK;
+    constexpr int B_ELEMS = BLAYOUT == DLC_B_KN ? TK * LDB_KN : TN * LDB_NK;
+    __shared__ T As[TM * LDA_S];
+    __shared__ T Bs[B_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const long long m0 = (long long)blockIdx.x * TM, n0 = (long long)blockIdx.y * TN;
+
+    // staging coordinates
+    const int a_row = tid >> 1, a_k = (tid & 1) * 8;            // A: 2 threads per row, 8 k each
+    const int bkn_k = tid >> 4, bkn_n = (tid & 15) * 8;         // B[K,N]: 16 threads per k row, 8 n each
+    T ra[8], rb[8];
+
+    auto load_tile = [&](long long k0) {
+        const long long gm = m0 + a_row;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long long gk = k0 + a_k + e;
+            ra[e] = (gm < p.M && gk < p.K) ? p.A[gm * p.lda + gk] : (T)0;
+        }
+        if constexpr (BLAYOUT == DLC_B_KN) {
+            const long long gk = k0 + bkn_k;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long long gn = n0 + bkn_n + e;
+                rb[e] = (gk < p.K && gn < p.N) ? p.B[gk * p.ldb + gn] : (T)0;
+            }
+        } else {
+            const long long gn = n0 + a_row;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long long gk = k0 + a_k + e;
+                rb[e] = (gn < p.N && gk < p.K) ? p.B[gn * p.ldb + gk] : (T)0;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) As[a_row * LDA_S + a_k + e] = ra[e];
+        if constexpr (BLAYOUT == DLC_B_KN) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Bs[bkn_k * LDB_S + bkn_n + e] = rb[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Bs[a_row * LDB_S + a_k + e] = rb[e];
+        }
+    };
+
+    typename Mma<T>::acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (typename Mma<T>::acc_t){0, 0, 0, 0};
+
+    const int fr = lane & 15, fk = lane >> 4;
+    const long long nkt = (p.K + TK - 1) / TK;
+    load_tile(0);
+    for (long long kt = 0; kt < nkt; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile((kt + 1) * TK);
+#pragma unroll
+        for (int kk = 0; kk < TK / 4; ++kk) {
+            T a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[(wr * 64 + i * 16 + fr) * LDA_S + kk * 4 + fk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (BLAYOUT == DLC_B_KN) b[j] = Bs[(kk * 4 + fk) * LDB_S + wc * 64 + j * 16 + fr];
+                else b[j] = Bs[(wc * 64 + j * 16 + fr) * LDB_S + kk * 4 + fk];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long gn = n0 + wc * 64 + j * 16 + fr;
+        if (gn >= p.N) continue;
+        const T bv = p.bias ? p.bias[gn] : (T)0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long gm = m0 + wr * 64 + i * 16 + Mma<T>::row(lane, r);
+                if (gm < p.M) p.C[gm * p.ldc + gn] = apply_act<T>(acc[i][j][r] + bv, p.act);
+            }
+    }
+}
+
+template <typename T>
+int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+           const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st) {
+    Args<T> a;
+    a.A = (const T*)A; a.lda = lda; a.B = (const T*)B; a.ldb = ldb; a.bias = (const T*)bias;
+    a.C = (T*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
+    if (dlc::cdiv(N, TN) > 65535 || dlc::cdiv(M, TM) > 0x7fffffffll)
+        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "gemm: M or N too large for one launch");
+    dim3 grid((unsigned)dlc::cdiv(M, TM), (unsigned)dlc::cdiv(N, TN));
+    if (blayout == DLC_B_KN) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_NK>), grid, dim3(256), 0, st, a);
+    DLC_LAUNCH_CHECK(ctx, "gemm_bias_act_kernel");
+    return DLC_OK;
+}
+
+int gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A,
+                  int64_t lda, const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "gemm: null/empty operand");
+    if (blayout != DLC_B_KN && blayout != DLC_B_NK) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "gemm: blayout %d", blayout);
+    if (act < DLC_ACT_NONE || act > DLC_ACT_RELU) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "gemm: act %d", act);
+    if (lda < K || ldc < N || (blayout == DLC_B_KN ? ldb < N : ldb < K))
+        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "gemm: leading dimension smaller than the row");
+    if (dtype == DLC_F64) return launch<double>(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st);
+    if (dtype == DLC_F32) return launch<float>(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st);
+    return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "gemm: dtype %d (need DLC_F64 or DLC_F32)", dtype);
+}
+
+}  // namespace dlc_gemm
+
+extern "C" int dlc_gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int64_t N, int64_t K,
+                                 const void* A, int64_t lda, const void* B, int64_t ldb, const void* bias, void* C,
+                                 int64_t ldc, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    return dlc_gemm::gemm_bias_act(ctx, dtype, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, (hipStream_t)stream);
+}
+
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_kernel(const T* __restrict__ A, long long lda, const T* __restrict__ bias,
+                                                       T* __restrict__ C, long long ldc, long long M, long long N,
+                                                       int act) {
+    const long long total = M * N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / N, c = e - r * N;
+        const T z = A[r * lda + c] + (bias ? bias[c] : (T)0);
+        C[r * ldc + c] = dlc_gemm::apply_act<T>(z, act);
+    }
+}
+}  // namespace
+
+extern "C" int dlc_bias_act(dlc_ctx* ctx, int dtype, int act, int64_t M, int64_t N, const void* A, int64_t lda,
+                            const void* bias, void* C, int64_t ldc, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!A || !C || M < 1 || N < 1 || lda < N || ldc < N) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "bias_act: bad argument");
+    if (act < DLC_ACT_NONE || act > DLC_ACT_RELU) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "bias_act: act %d", act);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    long long blocks = dlc::cdiv(M * N, 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (dtype == DLC_F64)
+        hipLaunchKernelGGL(bias_act_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const double*)A, (long long)lda, (const double*)bias, (double*)C, (long long)ldc,
+                           (long long)M, (long long)N, act);
+    else if (dtype == DLC_F32)
+        hipLaunchKernelGGL(bias_act_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)A, (long long)lda, (const float*)bias, (float*)C, (long long)ldc, (long long)M,
+                           (long long)N, act);
+    else
+        return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "bias_act: dtype %d", dtype);
+    DLC_LAUNCH_CHECK(ctx, "bias_act_kernel");
+    return DLC_OK;
+}
+
+static size_t elem_size(int dtype) { return dtype == DLC_F64 ? 8 : (dtype == DLC_F32 ? 4 : 0); }
+
+extern "C" size_t dlc_sdav_encode_workspace_bytes(int64_t rows, const int64_t* dims, int n_layers, int dtype) {
+    if (rows < 1 || !dims || n_layers < 1 || elem_size(dtype) == 0) return 0;
+    int64_t wmax = 0;
+    for (int l = 1; l < n_layers; ++l) wmax = dims[l] > wmax ? dims[l] : wmax;   // widths of the hidden hand-offs
+    if (n_layers == 1) return 256;
+    return 2 * dlc::align_up((size_t)rows * (size_t)wmax * elem_size(dtype), 256);
+}
+
+extern "C" int dlc_sdav_encode(dlc_ctx* ctx, int dtype, int64_t rows, int n_layers, const int64_t* dims, const void* x,
+                               const void* const* W, const void* const* b, void* out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!dims || !x || !W || !out || rows < 1 || n_layers < 1)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_encode: null/empty argument");
+    if (elem_size(dtype) == 0) return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "sdav_encode: dtype %d", dtype);
+    for (int l = 0; l <= n_layers; ++l)
+        if (dims[l] < 1) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_encode: dims[%d] = %lld", l, (long long)dims[l]);
+    const size_t need = dlc_sdav_encode_workspace_bytes(rows, dims, n_layers, dtype);
+    if (n_layers > 1 && (!workspace || workspace_bytes < need))
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "sdav_encode: workspace %zu < %zu bytes", workspace_bytes, need);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    char* ping[2] = {(char*)workspace, (char*)workspace + need / 2};
+    const void* in = x;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!W[l]) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_encode: W[%d] is null", l);
+        void* o = (l == n_layers - 1) ? out : (void*)ping[l & 1];
+        int rc = dlc_gemm::gemm_bias_act(ctx, dtype, DLC_B_KN, DLC_ACT_SIGMOID, rows, dims[l + 1], dims[l], in, dims[l],
+                                         W[l], dims[l + 1], b ? b[l] : nullptr, o, dims[l + 1], (hipStream_t)stream);
+        if (rc != DLC_OK) return rc;
+        in = o;
+    }
+    return DLC_OK;
+}

@@ -1,0 +1,280 @@
+// Reference-semantics match kernels:
+//   * cnn_vtl distance matrix: sum_k popcount(|a_k ^ b_k|) on signed int8
+//     (src/cnn_vtl/similarity/DistanceCalculator.py:4-12, loop of
+//     src/cnn_vtl/create_distance_matrix.py:30-36).  HBM/VALU-bound byte work:
+//     LDS-tiled 64x64 output blocks, 4 bytes per VALU op (SWAR |x|, v_bcnt).
+//   * SDAV similarity matrix (src/sdav/similarity/SimilarityCalculator.py:12-49,
+//     loop of src/sdav/create_similarity_matrix.py:29-38): patch-to-patch
+//     distances from one fp64 MFMA Gram GEMM (||a||^2+||b||^2-2a.b), then one
+//     wave per frame pair for argmin / weighted distance / log-sum.
+#include "dlc_internal.h"
+
+namespace dlc_gemm {
+int gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A,
+                  int64_t lda, const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st);
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// cnn_vtl distance
+// ---------------------------------------------------------------------------
+// popcount(|x|) for the four signed bytes of w:  |x| = (x ^ m) + s with m = 0xFF
+// and s = 1 for negative bytes (~x <= 127, so the +1 never carries out of a byte;
+// -128 -> 128 -> 1 bit, as bin(-128) has).
+__device__ __forceinline__ int popabs4(unsigned w) {
+    const unsigned s = (w >> 7) & 0x01010101u;
+    const unsigned m = (s << 8) - s;   // 0xFF in every negative byte
+    return __popc((w ^ m) + s);
+}
+
+constexpr int DT = 64;      // output tile (frames x frames)
+constexpr int DCH = 64;     // descriptor bytes per step (16 words)
+
+__global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __restrict__ desc, long long n, long long d,
+                                                              long long ldd, long long* __restrict__ out) {
+    __shared__ unsigned As[DT][DCH / 4 + 1];
+    __shared__ unsigned Bs[DT][DCH / 4 + 1];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const long long i0 = (long long)blockIdx.y * DT, j0 = (long long)blockIdx.x * DT;
+    int acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0;
+    const int lrow = tid >> 2, lw0 = (tid & 3) * 4;   // 4 threads per row, 4 words each
+    for (long long k0 = 0; k0 < d; k0 += DCH) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned va = 0, vb = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long k = k0 + (lw0 + w) * 4 + e;
+                if (k < d) {
+                    if (i0 + lrow < n) va |= ((unsigned)(unsigned char)desc[(i0 + lrow) * ldd + k]) << (8 * e);
+                    if (j0 + lrow < n) vb |= ((unsigned)(unsigned char)desc[(j0 + lrow) * ldd + k]) << (8 * e);
+                }
+            }
+            As[lrow][lw0 + w] = va;
+            Bs[lrow][lw0 + w] = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < DCH / 4; ++w) {
+            unsigned a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = As[ty * 4 + r][w]; b[r] = Bs[tx * 4 + r][w]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] += popabs4(a[r] ^ b[c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long i = i0 + ty * 4 + r, j = j0 + tx * 4 + c;
+            if (i < n && j < n) out[i * n + j] = (long long)acc[r][c];
+        }
+}
+
+// ---------------------------------------------------------------------------
+// SDAV similarity
+// ---------------------------------------------------------------------------
+// Column mean of desc viewed as [rows, H], summed row by row in order (what
+// np.average(axis=0) does on a C-contiguous array, SimilarityCalculator.py:20-23),
+// then the distinctive score exp(-(avg-mu)^2 / (2 sigma^2)) (:25-27).
+__global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __restrict__ desc, long long rows, int H,
+                                                                double mu, double sigma, double* __restrict__ score) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    double s = 0.0;
+    for (long long r = 0; r < rows; ++r) s += desc[r * H + c];
+    const double avg = s / (double)rows;
+    const double e = -((avg - mu) * (avg - mu)) / (2.0 * sigma * sigma);
+    score[c] = exp(e);
+}
+
+// Per patch row: squared norm and p = dot(score, row).  One wave per row.
+__global__ __launch_bounds__(256) void row_stats_kernel(const double* __restrict__ desc, long long rows, int H,
+                                                        const double* __restrict__ score, double* __restrict__ nrm2,
+                                                        double* __restrict__ proj) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const double* x = desc + r * H;
+    double n2 = 0.0, p = 0.0;
+    for (int k = lane; k < H; k += 64) {
+        const double v = x[k];
+        n2 = fma(v, v, n2);
+        p = fma(score[k], v, p);
+    }
+    for (int o = 32; o > 0; o >>= 1) { n2 += __shfl_xor(n2, o); p += __shfl_xor(p, o); }
+    if (lane == 0) { nrm2[r] = n2; proj[r] = p; }
+}
+
+__device__ __forceinline__ long long f64_to_i64_trunc(double v) {
+    if (!(fabs(v) < 9.2233720368547758e18)) return (long long)0x8000000000000000ull;   // inf / nan / overflow
+    return (long long)v;   // truncation toward zero
+}
+
+// One wave per frame pair (i, j), i in [i_lo, i_hi), j in (i, N).  G is the Gram
+// block  desc[i_lo*P .. i_hi*P) . desc[col0 ..)^T  with leading dimension ldg.
+__global__ __launch_bounds__(256) void pair_score_kernel(const double* __restrict__ desc, const double* __restrict__ G,
+                                                         long long ldg, long long col0, const double* __restrict__ nrm2,
+                                                         const double* __restrict__ proj,
+                                                         const double* __restrict__ score, long long N, int P, int H,
+                                                         long long i_lo, long long i_hi, double ca, double cb,
+                                                         double* __restrict__ out_f64, long long* __restrict__ out_i64) {
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long i = i_lo + blockIdx.y;
+    if (i >= i_hi || j >= N || j <= i) return;
+    double term = 0.0;
+    if (lane < P) {
+        const long long ra = i * P + lane;
+        const double* grow = G + (ra - i_lo * P) * ldg + (j * P - col0);
+        const double na = nrm2[ra];
+        double best = 0.0;
+        int bi = 0;
+        for (int b = 0; b < P; ++b) {
+            double d2 = na + nrm2[j * P + b] - 2.0 * grow[b];
+            d2 = d2 > 0.0 ? d2 : 0.0;
+            const double dist = sqrt(d2);                       // np.linalg.norm, :34
+            if (b == 0 || dist < best) { best = dist; bi = b; } // np.argmin: first minimum
+        }
+        const long long rb = j * P + bi;
+        double wd = fabs(proj[ra] - proj[rb]);                  // |dot(score, m_i - m_j*)|, :42-43
+        if (wd < 1e-6 * (fabs(proj[ra]) + fabs(proj[rb]))) {    // cancellation: evaluate the difference directly
+            const double* xa = desc + ra * H;
+            const double* xb = desc + rb * H;
+            double s = 0.0;
+            for (int k = 0; k < H; ++k) s = fma(score[k], xa[k] - xb[k], s);
+            wd = fabs(s);
+        }
+        term = ca + cb * log(wd);                               // :48
+    }
+    for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o);
+    if (lane == 0) {
+        out_f64[i * N + j] = term;
+        out_f64[j * N + i] = term;
+        if (out_i64) {
+            const long long t = f64_to_i64_trunc(term);
+            out_i64[i * N + j] = t;
+            out_i64[j * N + i] = t;
+        }
+    }
+}
+
+__global__ void fill_diag_kernel(long long N, double* out_f64, long long* out_i64) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    out_f64[i * N + i] = -1.0;
+    if (out_i64) out_i64[i * N + i] = -1;
+}
+
+struct SimWs {
+    size_t nrm2, proj, gram, total;
+    long long chunk_frames;
+};
+
+SimWs sim_ws(int64_t N, int64_t P, int64_t H) {
+    SimWs w;
+    size_t o = 0;
+    (void)H;
+    w.nrm2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
+    w.proj = o; o += dlc::align_up((size_t)N * P * 8, 256);
+    // Gram row chunk: at most ~1 GiB, at least one frame
+    const size_t row_bytes = (size_t)N * P * 8;
+    long long cf = (long long)((1ull << 30) / (row_bytes * (size_t)P));
+    if (cf < 1) cf = 1;
+    if (cf > N) cf = N;
+    w.chunk_frames = cf;
+    w.gram = o; o += dlc::align_up((size_t)cf * P * row_bytes, 256);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int dlc_cnnvtl_distance_matrix(dlc_ctx* ctx, const int8_t* desc, int64_t N, int64_t D, int64_t ldd,
+                                          int64_t* out, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!desc || !out || N < 1 || D < 1 || ldd < D) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "distance_matrix: bad argument");
+    if (D > (1ll << 28)) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "distance_matrix: D too large for int32 accumulation");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    const unsigned t = (unsigned)dlc::cdiv(N, DT);
+    if (t > 65535) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "distance_matrix: N too large");
+    hipLaunchKernelGGL(distance_matrix_kernel, dim3(t, t), dim3(256), 0, (hipStream_t)stream, desc, (long long)N,
+                       (long long)D, (long long)ldd, (long long*)out);
+    DLC_LAUNCH_CHECK(ctx, "distance_matrix_kernel");
+    return DLC_OK;
+}
+
+extern "C" size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int64_t H) {
+    if (N < 1 || P < 1 || H < 1) return 0;
+    return sim_ws(N, P, H).total;
+}
+
+extern "C" int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows, int64_t H, double mu,
+                                         double sigma, double* score, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!dataset || !score || rows < 1 || H < 1 || H > 0x7fffffff)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "distinctive_score: bad argument");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipLaunchKernelGGL(distinctive_score_kernel, dim3((unsigned)dlc::cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dataset, (long long)rows, (int)H, mu, sigma, score);
+    DLC_LAUNCH_CHECK(ctx, "distinctive_score_kernel");
+    return DLC_OK;
+}
+
+extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H,
+                                          const double* score, double a, double b, double* out_f64, int64_t* out_i64,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!desc || !score || !out_f64 || N < 1 || P < 1 || H < 1)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "similarity_matrix: bad argument");
+    if (P > 64) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "similarity_matrix: P=%lld patches per frame > 64", (long long)P);
+    if (H > 0x7fffffff || N > 65535) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "similarity_matrix: N or H too large");
+    const SimWs w = sim_ws(N, P, H);
+    if (!workspace || workspace_bytes < w.total)
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "similarity_matrix: workspace %zu < %zu bytes", workspace_bytes, w.total);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    double* nrm2 = (double*)(ws + w.nrm2);
+    double* proj = (double*)(ws + w.proj);
+    double* gram = (double*)(ws + w.gram);
+    const long long rows = N * P;
+
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)dlc::cdiv(rows, 4)), dim3(256), 0, st, desc, rows, (int)H, score,
+                       nrm2, proj);
+    DLC_LAUNCH_CHECK(ctx, "row_stats_kernel");
+    hipLaunchKernelGGL(fill_diag_kernel, dim3((unsigned)dlc::cdiv(N, 256)), dim3(256), 0, st, (long long)N, out_f64,
+                       (long long*)out_i64);
+    DLC_LAUNCH_CHECK(ctx, "fill_diag_kernel");
+
+    for (long long i_lo = 0; i_lo + 1 < N; i_lo += w.chunk_frames) {
+        long long i_hi = i_lo + w.chunk_frames;
+        if (i_hi > N - 1) i_hi = N - 1;          // the last frame has no j > i
+        if (i_hi <= i_lo) break;
+        // columns: frames j > i_lo, i.e. from frame i_lo+1 on
+        const long long col0 = (i_lo + 1) * P;
+        const long long ncols = rows - col0;
+        const long long mrows = (i_hi - i_lo) * P;
+        int rc = dlc_gemm::gemm_bias_act(ctx, DLC_F64, DLC_B_NK, DLC_ACT_NONE, mrows, ncols, H, desc + i_lo * P * H, H,
+                                         desc + col0 * H, H, nullptr, gram, ncols, st);
+        if (rc != DLC_OK) return rc;
+        dim3 grid((unsigned)dlc::cdiv(N, 4), (unsigned)(i_hi - i_lo));
+        hipLaunchKernelGGL(pair_score_kernel, grid, dim3(256), 0, st, desc, gram, ncols, col0, nrm2, proj, score,
+                           (long long)N, (int)P, (int)H, i_lo, i_hi, a, b, out_f64, (long long*)out_i64);
+        DLC_LAUNCH_CHECK(ctx, "pair_score_kernel");
+    }
+    return DLC_OK;
+}

@@ -1,0 +1,289 @@
+"""Thin host layer over the C ABI: holds tensors in PyTorch-ROCm, passes raw
+device pointers + the current HIP stream to libdlc_hip.so.  PyTorch is used for
+device memory, streams and torch.distributed only; every computation below
+runs in the hand-written HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_TORCH_TO_DLC = {torch.bfloat16: L.DLC_BF16, torch.float16: L.DLC_F16, torch.float32: L.DLC_F32,
+                 torch.float64: L.DLC_F64, torch.int8: L.DLC_I8}
+_NAME_TO_TORCH = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f16": torch.float16, "fp16": torch.float16,
+                  "float16": torch.float16, "f32": torch.float32, "float32": torch.float32, "f64": torch.float64,
+                  "float64": torch.float64}
+
+K_STEP = 64   # the score GEMM's K step: stored descriptor rows are padded to a multiple of it
+
+
+def torch_dtype(name):
+    if isinstance(name, torch.dtype):
+        return name
+    try:
+        return _NAME_TO_TORCH[str(name).lower()]
+    except KeyError:
+        raise ValueError("unknown dtype %r" % (name,))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    """One engine per device / rank (wraps a dlc_ctx)."""
+
+    def __init__(self, device=None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("deeploopcloser_amd needs a visible MI355X (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        ctx = C.c_void_p()
+        rc = self.lib.dlc_create(self.device.index, C.byref(ctx))
+        if rc != L.DLC_OK:
+            raise L.DlcError("dlc_create(%d) failed: %s" % (self.device.index, self.lib.dlc_status_string(rc).decode()))
+        self.ctx = ctx
+        self._ws = {}
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.dlc_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers -------------------------------------------------------------
+    def _check(self, rc):
+        L.raise_for_status(self.lib, self.ctx, rc)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, key, nbytes):
+        nbytes = max(int(nbytes), 256)
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def to_device(self, x, dtype=None):
+        if isinstance(x, torch.Tensor):
+            t = x.to(self.device)
+            if dtype is not None and t.dtype != dtype:
+                t = t.to(dtype)
+            return t.contiguous()
+        a = np.ascontiguousarray(np.asarray(x))
+        t = torch.from_numpy(a).to(self.device)
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t
+
+    # ---- dense layers -----------------------------------------------------------
+    def gemm_bias_act(self, a, b, bias=None, act=L.DLC_ACT_NONE, blayout=L.DLC_B_KN, out=None):
+        """out[M,N] = act(a[M,K] . b + bias) in a's dtype (float64 / float32)."""
+        if a.dim() != 2 or b.dim() != 2:
+            raise ValueError("gemm_bias_act: operands must be 2-D")
+        if a.dtype not in (torch.float64, torch.float32) or b.dtype != a.dtype:
+            raise ValueError("gemm_bias_act: float64 or float32 operands of one dtype")
+        a, b = a.contiguous(), b.contiguous()
+        m, k = a.shape
+        n = b.shape[1] if blayout == L.DLC_B_KN else b.shape[0]
+        kb = b.shape[0] if blayout == L.DLC_B_KN else b.shape[1]
+        if kb != k:
+            raise ValueError("gemm_bias_act: inner dimensions differ (%d vs %d)" % (k, kb))
+        if bias is not None:
+            bias = bias.contiguous()
+            if bias.numel() != n or bias.dtype != a.dtype:
+                raise ValueError("gemm_bias_act: bias must be [N] of the operand dtype")
+        if out is None:
+            out = torch.empty((m, n), dtype=a.dtype, device=self.device)
+        self._check(self.lib.dlc_gemm_bias_act(self.ctx, _TORCH_TO_DLC[a.dtype], blayout, act, m, n, k, _ptr(a),
+                                                a.stride(0), _ptr(b), b.stride(0), _ptr(bias), _ptr(out),
+                                                out.stride(0), self._stream()))
+        return out
+
+    def bias_act(self, a, bias=None, act=L.DLC_ACT_NONE):
+        a = a.contiguous()
+        a2 = a.reshape(-1, a.shape[-1])
+        out = torch.empty_like(a2)
+        if bias is not None:
+            bias = bias.to(a.dtype).contiguous()
+            if bias.numel() != a2.shape[1]:
+                raise ValueError("bias_act: bias must have the row width")
+        self._check(self.lib.dlc_bias_act(self.ctx, _TORCH_TO_DLC[a.dtype], act, a2.shape[0], a2.shape[1], _ptr(a2),
+                                           a2.stride(0), _ptr(bias), _ptr(out), out.stride(0), self._stream()))
+        return out.reshape(a.shape)
+
+    def sdav_encode(self, x2d, weights, biases):
+        """sigmoid chain on x2d [rows, K0]; weights[l] is [dims[l], dims[l+1]]."""
+        dt = x2d.dtype
+        if dt not in (torch.float64, torch.float32):
+            raise ValueError("sdav_encode: float64 or float32")
+        x2d = x2d.contiguous()
+        n_layers = len(weights)
+        dims = [x2d.shape[1]] + [w.shape[1] for w in weights]
+        for l, w in enumerate(weights):
+            if w.dtype != dt or w.shape[0] != dims[l] or not w.is_contiguous():
+                raise ValueError("sdav_encode: W[%d] must be a contiguous [%d, *] %s tensor" % (l, dims[l], dt))
+        rows = x2d.shape[0]
+        dims_c = (C.c_int64 * (n_layers + 1))(*dims)
+        w_c = (C.c_void_p * n_layers)(*[w.data_ptr() for w in weights])
+        b_c = (C.c_void_p * n_layers)(*[(b.data_ptr() if b is not None else 0) for b in biases])
+        need = self.lib.dlc_sdav_encode_workspace_bytes(rows, dims_c, n_layers, _TORCH_TO_DLC[dt])
+        ws = self.workspace("sdav", need)
+        out = torch.empty((rows, dims[-1]), dtype=dt, device=self.device)
+        self._check(self.lib.dlc_sdav_encode(self.ctx, _TORCH_TO_DLC[dt], rows, n_layers, dims_c, _ptr(x2d), w_c, b_c,
+                                              _ptr(out), _ptr(ws), ws.numel(), self._stream()))
+        return out
+
+    # ---- CnnVtl pieces ---------------------------------------------------------------
+    def im2col(self, x, kh, kw, stride, pad_top, pad_left, oh, ow):
+        n, h, w, c = x.shape
+        cols = torch.empty((n * oh * ow, kh * kw * c), dtype=torch.float64, device=self.device)
+        self._check(self.lib.dlc_im2col_nhwc_f64(self.ctx, _ptr(x), n, h, w, c, kh, kw, stride, pad_top, pad_left, oh,
+                                                  ow, _ptr(cols), self._stream()))
+        return cols
+
+    def maxpool3x3s2(self, x):
+        n, h, w, c = x.shape
+        y = torch.empty((n, (h - 3) // 2 + 1, (w - 3) // 2 + 1, c), dtype=torch.float64, device=self.device)
+        self._check(self.lib.dlc_maxpool3x3s2_nhwc_f64(self.ctx, _ptr(x), n, h, w, c, _ptr(y), self._stream()))
+        return y
+
+    def minmax_quant_gather(self, segments, columns):
+        n = segments[0].shape[0]
+        segs = [s.reshape(n, -1).contiguous() for s in segments]
+        ptrs = (C.c_void_p * len(segs))(*[s.data_ptr() for s in segs])
+        sizes = (C.c_int64 * len(segs))(*[s.shape[1] for s in segs])
+        minmax = torch.empty((n, 2), dtype=torch.float64, device=self.device)
+        out = torch.empty((n, columns.numel()), dtype=torch.int8, device=self.device)
+        self._check(self.lib.dlc_minmax_quant_gather_i8(self.ctx, ptrs, sizes, len(segs), n, _ptr(columns),
+                                                         columns.numel(), _ptr(minmax), _ptr(out), self._stream()))
+        return out
+
+    # ---- reference-semantics match ---------------------------------------------------
+    def distinctive_score(self, dataset, mu, sigma):
+        d2 = dataset.reshape(-1, dataset.shape[-1]).contiguous()
+        score = torch.empty(d2.shape[1], dtype=torch.float64, device=self.device)
+        self._check(self.lib.dlc_sdav_distinctive_score(self.ctx, _ptr(d2), d2.shape[0], d2.shape[1], float(mu),
+                                                         float(sigma), _ptr(score), self._stream()))
+        return score
+
+    def sdav_similarity_matrix(self, desc, score, a=10.0, b=-10.0, want_int64=True):
+        desc = desc.contiguous()
+        n, p, h = desc.shape
+        out = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        out_i = torch.empty((n, n), dtype=torch.int64, device=self.device) if want_int64 else None
+        need = self.lib.dlc_sdav_similarity_workspace_bytes(n, p, h)
+        ws = self.workspace("sim", need)
+        self._check(self.lib.dlc_sdav_similarity_matrix(self.ctx, _ptr(desc), n, p, h, _ptr(score), float(a), float(b),
+                                                         _ptr(out), _ptr(out_i), _ptr(ws), ws.numel(), self._stream()))
+        return out, out_i
+
+    def cnnvtl_distance_matrix(self, desc):
+        desc = desc.contiguous()
+        n, d = desc.shape
+        out = torch.empty((n, n), dtype=torch.int64, device=self.device)
+        self._check(self.lib.dlc_cnnvtl_distance_matrix(self.ctx, _ptr(desc), n, d, desc.stride(0), _ptr(out),
+                                                         self._stream()))
+        return out
+
+    # ---- cosine + top-k -----------------------------------------------------------------
+    def normalize(self, x, dtype="bf16", center=False):
+        """Rows of x [n,d] (float32/float64) -> stored descriptors [n, d_pad]
+        (bf16/fp16, L2-normalised, zero-padded to a multiple of 64)."""
+        dt = torch_dtype(dtype)
+        if dt not in (torch.bfloat16, torch.float16):
+            raise ValueError("stored descriptor dtype must be bf16 or fp16")
+        if x.dtype not in (torch.float32, torch.float64):
+            raise ValueError("normalize: float32 or float64 input")
+        x = x.contiguous()
+        n, d = x.shape
+        ldd = (d + K_STEP - 1) // K_STEP * K_STEP
+        out = torch.empty((n, ldd), dtype=dt, device=self.device)
+        self._check(self.lib.dlc_l2_normalize_rows(self.ctx, _TORCH_TO_DLC[x.dtype], _ptr(x), n, d, x.stride(0),
+                                                    1 if center else 0, _TORCH_TO_DLC[dt], _ptr(out), ldd,
+                                                    self._stream()))
+        return out
+
+    def _check_stored(self, q, db):
+        if q.dim() != 2 or db.dim() != 2 or q.shape[1] != db.shape[1]:
+            raise ValueError("stored descriptors must be 2-D with one width")
+        if q.dtype != db.dtype or q.dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("stored descriptors must both be bf16 or both fp16")
+        if q.stride(1) != 1 or db.stride(1) != 1:
+            raise ValueError("stored descriptor rows must be contiguous")
+
+    def match_topk(self, q, db, k, row_offset=0, out=None):
+        """Top-k cosine match of stored queries q [Q,d] against stored db [N,d].
+        Returns (scores [Q,k] float32, idx [Q,k] int64 with row_offset added)."""
+        self._check_stored(q, db)
+        nq, d = q.shape
+        n = db.shape[0]
+        need = self.lib.dlc_cosine_topk_workspace_bytes(nq, n, d, k)
+        if need == 0:
+            raise ValueError("match_topk: k=%d outside 1..%d (or empty operand)" % (k, L.DLC_MAX_K))
+        ws = self.workspace("topk", need)
+        if out is None:
+            scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            idx = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        else:
+            scores, idx = out
+        self._check(self.lib.dlc_cosine_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
+                                              db.stride(0), d, k, row_offset, _ptr(scores), _ptr(idx), _ptr(ws),
+                                              ws.numel(), self._stream()))
+        return scores, idx
+
+    def topk_merge(self, scores, idx, out=None):
+        """Merge [parts, Q, k] per-shard results into the global [Q, k]."""
+        scores, idx = scores.contiguous(), idx.contiguous()
+        parts, nq, k = scores.shape
+        if out is None:
+            o_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            o_i = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        else:
+            o_s, o_i = out
+        self._check(self.lib.dlc_topk_merge(self.ctx, _ptr(scores), _ptr(idx), parts, nq, k, _ptr(o_s), _ptr(o_i),
+                                             self._stream()))
+        return o_s, o_i
+
+    def cosine_scores(self, q, db):
+        self._check_stored(q, db)
+        nq, d = q.shape
+        n = db.shape[0]
+        s = torch.empty((nq, n), dtype=torch.float32, device=self.device)
+        self._check(self.lib.dlc_cosine_scores(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
+                                                db.stride(0), d, _ptr(s), s.stride(0), self._stream()))
+        return s
+
+    # ---- profiling hooks for bench.py ---------------------------------------------------
+    def set_profiling(self, enabled):
+        self._check(self.lib.dlc_set_profiling(self.ctx, 1 if enabled else 0))
+
+    def last_gemm_ms(self):
+        return float(self.lib.dlc_last_gemm_ms(self.ctx))
+
+
+_default = {}
+
+
+def default_engine(device=None):
+    """Process-wide engine for the current (or given) device."""
+    if device is None:
+        if not torch.cuda.is_available():
+            L.load()   # raises ImportError first if the library itself is missing
+            raise RuntimeError("deeploopcloser_amd needs a visible MI355X; there is no CPU fallback")
+        device = torch.cuda.current_device()
+    if device not in _default:
+        _default[device] = Engine(device)
+    return _default[device]

@@ -1,0 +1,164 @@
+"""SDAV / DA encoders with the reference's call surface, running on MI355X.
+
+Mirrors src/sdav/network/SDAV.py (class SDAV: ctor :14, hyper-parameters
+:30-39, transform :293-302) and src/sdav/network/DenoisingAutoencoderVariant.py
+(class DA: ctor :15-26, transform :254-259).  The forward chain is one C-ABI
+call (dlc_sdav_encode): five fp64 MFMA GEMMs with fused bias + sigmoid,
+weights resident in HBM instead of a checkpoint restore / re-initialisation on
+every call (SDAV.py:232-240).
+
+Differences a caller can see, all deliberate:
+  * weights are drawn ONCE at construction (seeded N(0,1), the reference's
+    initialiser SDAV.py:189-217) or loaded with load_weights(); the reference
+    re-draws them on every transform() when no checkpoint exists;
+  * fit / fit_dataset / get_dataset (training) are not part of
+    this hot path and raise NotImplementedError.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .engine import default_engine
+
+
+def _init_weights(dims, seed, dtype, device, scale="reference"):
+    rng = np.random.RandomState(seed)
+    ws, bs = [], []
+    for k, n in zip(dims[:-1], dims[1:]):
+        w = rng.standard_normal((k, n))
+        if scale == "fan_in":
+            w = w / np.sqrt(k)
+        ws.append(torch.from_numpy(w).to(device=device, dtype=dtype).contiguous())
+        bs.append(torch.zeros(n, dtype=dtype, device=device))
+    return ws, bs
+
+
+class SDAV:
+    def __init__(self, verbosity=logging.WARNING, seed=0, dtype="float64", device=None, weight_scale="reference"):
+        self.logger = logging.getLogger()
+        self.logger.setLevel(verbosity)
+        self._define_params()
+        self.losses = []
+        self.engine = default_engine(device)
+        self.dtype = {"float64": torch.float64, "float32": torch.float32}[dtype]
+        dims = [self.input_shape[1]] + list(self.hidden_units)
+        self._weights, self._biases = _init_weights(dims, seed, self.dtype, self.engine.device, weight_scale)
+        logging.info("Done initializing sdav")
+
+    def _define_params(self):                      # SDAV.py:30-39
+        self.input_shape = [30, 1681]
+        self.hidden_units = [2500, 2500, 2500, 2500, 2500]
+        self.default_batch_size = 10
+        self.sparse_level = 0.05
+        self.sparse_penalty = 1.0
+        self.consecutive_penalty = 0.2
+        self.learning_rate = 0.1
+        self.epochs = 100
+        self.corruption_level = 0.3
+
+    def get_layer_input_shape(self, layer_n):      # SDAV.py:165-169
+        if layer_n == 0:
+            return self.input_shape
+        return [self.input_shape[0], self.hidden_units[layer_n - 1]]
+
+    def get_layers_input_shapes(self):             # SDAV.py:290-291
+        return list(map(self.get_layer_input_shape, range(1, 6)))
+
+    # ---- weights ------------------------------------------------------------------
+    def set_weights(self, weights, biases=None):
+        """weights: list of 5 arrays [in,out] (W_le of SDAV.py:188-217)."""
+        dims = [self.input_shape[1]] + list(self.hidden_units)
+        if len(weights) != len(self.hidden_units):
+            raise ValueError("expected %d weight matrices" % len(self.hidden_units))
+        ws, bs = [], []
+        for l, w in enumerate(weights):
+            w = self.engine.to_device(w, self.dtype)
+            if tuple(w.shape) != (dims[l], dims[l + 1]):
+                raise ValueError("W[%d] must be %s, got %s" % (l, (dims[l], dims[l + 1]), tuple(w.shape)))
+            b = biases[l] if biases is not None else np.zeros(dims[l + 1])
+            b = self.engine.to_device(b, self.dtype)
+            if b.numel() != dims[l + 1]:
+                raise ValueError("b[%d] must have %d entries" % (l, dims[l + 1]))
+            ws.append(w)
+            bs.append(b)
+        self._weights, self._biases = ws, bs
+
+    def get_weights(self):
+        return [w.cpu().numpy() for w in self._weights], [b.cpu().numpy() for b in self._biases]
+
+    def load_weights(self, path):
+        """.npz with w0..w4 / b0..b4 (our own format; TF-1 checkpoints are unreadable here)."""
+        z = np.load(path)
+        n = len(self.hidden_units)
+        self.set_weights([z["w%d" % l] for l in range(n)], [z["b%d" % l] for l in range(n)])
+
+    def save_weights(self, path):
+        ws, bs = self.get_weights()
+        np.savez(path, **{"w%d" % l: w for l, w in enumerate(ws)}, **{"b%d" % l: b for l, b in enumerate(bs)})
+
+    # ---- encode ---------------------------------------------------------------------
+    def transform_tensor(self, x):
+        """x: [B,30,1681] on any device -> torch tensor [B*30, 2500] on the GPU."""
+        x = self.engine.to_device(x, self.dtype)
+        if x.dim() != 3 or list(x.shape[1:]) != list(self.input_shape):
+            raise ValueError("expected input of shape [B, %d, %d], got %s" %
+                             (self.input_shape[0], self.input_shape[1], tuple(x.shape)))
+        if x.shape[0] == 0:
+            return torch.empty((0, self.hidden_units[-1]), dtype=self.dtype, device=self.engine.device)
+        x2 = x.reshape(x.shape[0] * x.shape[1], x.shape[2])      # flat_batch, TensorflowWrapper.py:13-15
+        return self.engine.sdav_encode(x2, self._weights, self._biases)
+
+    def transform(self, x):
+        """SDAV.transform (SDAV.py:293-302): numpy in, numpy FLAT [B*30, 2500] float64 out."""
+        return self.transform_tensor(x).to(torch.float64).cpu().numpy()
+
+    # ---- training surface: outside this hot path --------------------------------------
+    def get_dataset(self, file_pattern):
+        raise NotImplementedError("SDAV.get_dataset (SURF patch front-end, SURVEY.md section 8f-1) is not part of the "
+                                  "MI355X hot path")
+
+    def fit_dataset(self, dataset):
+        raise NotImplementedError("SDAV training (SURVEY.md section 8f-2) is not part of the MI355X hot path")
+
+    def fit(self, x):
+        raise NotImplementedError("SDAV training (SURVEY.md section 8f-2) is not part of the MI355X hot path")
+
+
+class DA:
+    """One denoising-autoencoder layer; only the transform path
+    (DenoisingAutoencoderVariant.py:116-119, 254-259)."""
+
+    def __init__(self, input_shape, hidden_units, sparse_level=0.05, sparse_penalty=1.0, consecutive_penalty=0.2,
+                 batch_size=10, learning_rate=0.1, epochs=100, layer_n=0, corruption_level=0.3, seed=0,
+                 dtype="float64", device=None):
+        if (not isinstance(input_shape, (list, tuple)) or len(input_shape) != 2 or
+                any((not isinstance(v, (int, np.integer))) or v <= 0 for v in input_shape)):
+            raise ValueError("input_shape must be a list of two positive ints")      # v8n rule, :89-90
+        if not isinstance(hidden_units, (int, np.integer)) or hidden_units <= 0:
+            raise ValueError("hidden_units must be a positive int")                  # :83-84
+        self.input_shape = list(input_shape)
+        self.hidden_units = int(hidden_units)
+        self.sparse_level, self.sparse_penalty = sparse_level, sparse_penalty
+        self.consecutive_penalty, self.batch_size = consecutive_penalty, batch_size
+        self.learning_rate, self.epochs = learning_rate, epochs
+        self.corruption_level, self.layer_n = corruption_level, layer_n
+        self.engine = default_engine(device)
+        self.dtype = {"float64": torch.float64, "float32": torch.float32}[dtype]
+        ws, bs = _init_weights([self.input_shape[1], self.hidden_units], seed, self.dtype, self.engine.device)
+        self._w0, self._b0 = ws[0], bs[0]
+
+    def set_weights(self, w, b=None):
+        w = self.engine.to_device(w, self.dtype)
+        if tuple(w.shape) != (self.input_shape[1], self.hidden_units):
+            raise ValueError("W must be %s" % ((self.input_shape[1], self.hidden_units),))
+        self._w0 = w
+        self._b0 = self.engine.to_device(b if b is not None else np.zeros(self.hidden_units), self.dtype)
+
+    def transform(self, x, batch_n: int = -1):
+        x = self.engine.to_device(x, self.dtype)
+        if list(x.shape) != self.input_shape:
+            raise ValueError("expected input of shape %s, got %s" % (self.input_shape, tuple(x.shape)))
+        h = self.engine.gemm_bias_act(x, self._w0, self._b0, act=L.DLC_ACT_SIGMOID)
+        return h.to(torch.float64).cpu().numpy()

@@ -1,0 +1,224 @@
+/*
+ * dlc.h -- C ABI of the MI355X-native loop-closure descriptor-and-match engine.
+ *
+ * This is the drop-in boundary for ONE path of nschejtman/deepLoopCloser:
+ *     encode (SDAV / DA / CnnVtl forward) -> all-vs-all similarity / distance
+ *     -> top-k match.
+ * The reference has no FFI of its own (it is pure Python on TensorFlow-1 and
+ * NumPy); each entry point below names the reference interface (file:line,
+ * relative to the reference repo) whose arithmetic it replaces.  The Python
+ * classes in deeploopcloser_amd/ keep the reference's names and signatures and
+ * bind these symbols through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) owned by the caller unless the
+ *     parameter is documented as host; nothing is allocated or freed here,
+ *     callers pass a workspace whose size the *_workspace_bytes() functions
+ *     give;
+ *   - every call is asynchronous on the caller's hipStream_t (`stream`,
+ *     passed as void*; NULL = the null stream) and never synchronises;
+ *   - matrices are row-major with explicit leading dimensions in ELEMENTS;
+ *   - return value: DLC_OK (0) or a negative dlc_status; dlc_last_error()
+ *     returns a human-readable message for the last failure on that context.
+ *   - a context is bound to one device; use one context per GPU / rank.
+ */
+#ifndef DLC_H_
+#define DLC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLC_ABI_VERSION 1
+
+typedef struct dlc_ctx dlc_ctx;
+
+typedef enum dlc_status {
+    DLC_OK = 0,
+    DLC_ERR_BAD_ARG = -1,      /* null pointer, negative size, unknown enum     */
+    DLC_ERR_BAD_SHAPE = -2,    /* shape the kernels cannot take (see each call) */
+    DLC_ERR_UNSUPPORTED = -3,  /* dtype / mode not implemented                  */
+    DLC_ERR_HIP = -4,          /* a HIP runtime call failed                     */
+    DLC_ERR_WORKSPACE = -5     /* workspace too small                           */
+} dlc_status;
+
+typedef enum dlc_dtype {
+    DLC_BF16 = 0,
+    DLC_F16 = 1,
+    DLC_F32 = 2,
+    DLC_F64 = 3,
+    DLC_I8 = 4
+} dlc_dtype;
+
+typedef enum dlc_act {
+    DLC_ACT_NONE = 0,
+    DLC_ACT_SIGMOID = 1,       /* tf.nn.sigmoid, TensorflowWrapper.py:77-78 */
+    DLC_ACT_RELU = 2           /* tf.nn.relu,    cnn_vtl.py:37             */
+} dlc_act;
+
+typedef enum dlc_blayout {
+    DLC_B_KN = 0,              /* B stored [K,N] (weights, HWIO conv kernels) */
+    DLC_B_NK = 1               /* B stored [N,K] (C = A . B^T)                */
+} dlc_blayout;
+
+/* ---- context --------------------------------------------------------- */
+int dlc_abi_version(void);
+int dlc_create(int device, dlc_ctx** out);
+int dlc_destroy(dlc_ctx* ctx);
+const char* dlc_last_error(const dlc_ctx* ctx);      /* host string, never NULL */
+const char* dlc_status_string(int status);
+
+/* ---- encode: dense layers -------------------------------------------- */
+/*
+ * C[M,N] = act(A[M,K] . B + bias[N]).
+ * Replaces TensorWrapper.matmul/.add/.sigmoid (src/utils/TensorflowWrapper.py:57-78)
+ * as used by SDAV._define_model (src/sdav/network/SDAV.py:129-157), DA's
+ * sigmoid(x @ W + b) (src/sdav/network/DenoisingAutoencoderVariant.py:119) and,
+ * with DLC_ACT_RELU/NONE on an im2col matrix, tf.layers.conv2d
+ * (src/cnn_vtl/network/cnn_vtl.py:33-93).
+ * dtype: DLC_F64 (the reference's arithmetic; v_mfma_f64_16x16x4_f64) or
+ * DLC_F32 (v_mfma_f32_16x16x4_f32).  bias may be NULL.  Any M,N,K >= 1.
+ */
+int dlc_gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act,
+                      int64_t M, int64_t N, int64_t K,
+                      const void* A, int64_t lda, const void* B, int64_t ldb,
+                      const void* bias, void* C, int64_t ldc, void* stream);
+
+/*
+ * Elementwise C[M,N] = act(A[M,N] + bias[N]) in fp64 / fp32: TensorWrapper.add
+ * and .sigmoid (src/utils/TensorflowWrapper.py:69-71,77-78) when they are not
+ * fused behind a matmul.  bias may be NULL.  In place (C == A) is allowed.
+ */
+int dlc_bias_act(dlc_ctx* ctx, int dtype, int act, int64_t M, int64_t N,
+                 const void* A, int64_t lda, const void* bias, void* C, int64_t ldc, void* stream);
+
+/*
+ * SDAV.transform (src/sdav/network/SDAV.py:293-302): the n_layers-deep chain
+ * h_l = sigmoid(h_{l-1} . W_l + b_l) on x[rows = B*P, dims[0]], corruption
+ * level 0 (mask == 1, TensorflowWrapper.py:148-156, skipped).  W / b are HOST
+ * arrays of n_layers DEVICE pointers, W_l is [dims[l], dims[l+1]] row-major,
+ * b_l is [dims[l+1]] (may be NULL); dims is a HOST array of n_layers+1 widths.
+ * out is the FLAT [rows, dims[n_layers]] array the reference returns (:163).
+ * Workspace: dlc_sdav_encode_workspace_bytes(rows, dims, n_layers, dtype).
+ */
+size_t dlc_sdav_encode_workspace_bytes(int64_t rows, const int64_t* dims, int n_layers, int dtype);
+int dlc_sdav_encode(dlc_ctx* ctx, int dtype, int64_t rows, int n_layers, const int64_t* dims,
+                    const void* x, const void* const* W, const void* const* b,
+                    void* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- encode: CnnVtl pieces (src/cnn_vtl/network/cnn_vtl.py:28-133) ------ */
+/*
+ * im2col for tf.layers.conv2d on NHWC fp64 (cnn_vtl.py:33-93): x[n,h,w,c] ->
+ * cols[n*oh*ow, kh*kw*c] with column order (kh,kw,c) == HWIO kernel reshaped
+ * to [kh*kw*c, cout].  pad_top/pad_left are TF's SAME pads (0 for VALID).
+ * src_dtype DLC_F64 or DLC_I8 is not needed: the reference feeds uint8 pixels
+ * as fp64 (create_distance_matrix.py:23,27); x here is fp64.
+ */
+int dlc_im2col_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c,
+                        int kh, int kw, int stride, int pad_top, int pad_left, int oh, int ow,
+                        double* cols, void* stream);
+/* tf.layers.max_pooling2d(3x3, stride 2, VALID) on NHWC fp64 (cnn_vtl.py:42-45,58-61). */
+int dlc_maxpool3x3s2_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c,
+                              double* y, void* stream);
+/*
+ * cnn_vtl.py:106-128: the descriptor d[n, width] is the concatenation, per
+ * frame, of the n_segs flattened conv outputs (segs[g] is [n, seg_sizes[g]]
+ * fp64, contiguous; HOST arrays of DEVICE pointers / sizes, at most 8).  Per row:
+ * min/max over all segments, (d-min)*(255/(max-min)), cast to int8 (truncate
+ * toward zero, wrap modulo 256), and gather of the n_cols selected columns
+ * (`cols`: DEVICE int64 indices into the concatenated row -- the boolean mask of
+ * :118-128 as a sorted list).  minmax is a [n,2] fp64 DEVICE scratch the call
+ * fills (min,max per row); out is [n, n_cols] int8.  n <= 65535 per call.
+ */
+int dlc_minmax_quant_gather_i8(dlc_ctx* ctx, const double* const* segs, const int64_t* seg_sizes, int n_segs,
+                               int64_t n, const int64_t* cols, int64_t n_cols, double* minmax,
+                               int8_t* out, void* stream);
+
+/* ---- match: reference semantics --------------------------------------- */
+/*
+ * Distinctive score of a descriptor dataset viewed as [rows, H] fp64:
+ * SimilarityCalculator._average_response + _distinctive_score
+ * (src/sdav/similarity/SimilarityCalculator.py:20-27): column mean (rows
+ * summed in order, as np.average does), then exp(-(avg-mu)^2 / (2 sigma^2)).
+ * The reference recomputes this for every pair (:13-14); it is hoisted here.
+ */
+int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows, int64_t H,
+                               double mu, double sigma, double* score, void* stream);
+/*
+ * All-vs-all SDAV similarity: SimilarityCalculator.similarity_score
+ * (src/sdav/similarity/SimilarityCalculator.py:12-49) for every frame pair
+ * i<j (score(h_i, h_j)), mirrored, diagonal = -1
+ * (src/sdav/create_similarity_matrix.py:29-38).  desc is [N,P,H] fp64, P <= 64;
+ * score [H] comes from dlc_sdav_distinctive_score.  out_f64 [N,N] receives the
+ * float scores (+inf where a matched pair is identical); out_i64 (may be NULL)
+ * the reference's int64 matrix (truncation toward zero, non-finite -> INT64_MIN).
+ */
+size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int64_t H);
+int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H,
+                               const double* score, double a, double b,
+                               double* out_f64, int64_t* out_i64,
+                               void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * All-vs-all cnn_vtl distance: DistanceCalculator.calculate_distance
+ * (src/cnn_vtl/similarity/DistanceCalculator.py:4-12) = sum_k popcount(|a_k ^ b_k|)
+ * on signed int8, for the full N x N loop incl. the diagonal
+ * (src/cnn_vtl/create_distance_matrix.py:30-36).  desc [N, D] int8 (row stride ldd).
+ */
+int dlc_cnnvtl_distance_matrix(dlc_ctx* ctx, const int8_t* desc, int64_t N, int64_t D, int64_t ldd,
+                               int64_t* out, void* stream);
+
+/* ---- match: cosine similarity + top-k (BASELINE.json north_star; not in the reference) */
+/*
+ * Row L2-normalisation (optional mean-centring first) of src[n,d] (DLC_F32 or
+ * DLC_F64, row stride lds) into the stored descriptor format dst[n, ldd]
+ * (DLC_BF16 or DLC_F16), columns d..ldd-1 zero-filled.  ldd must be a multiple
+ * of 64 (the GEMM's K step).
+ */
+int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* src, int64_t n, int64_t d, int64_t lds,
+                          int center, int dst_dtype, void* dst, int64_t ldd, void* stream);
+/*
+ * Top-k cosine match of q query rows against n database rows of width d
+ * (both stored normalised in `dtype` = DLC_BF16 / DLC_F16, row strides
+ * ldq / lddb in elements, d a multiple of 64, rows 16-byte aligned).
+ * Scores are fp32-accumulated dot products of the stored rows; per query the k
+ * best (score descending, ties -> lower index) go to out_scores[q,k] (fp32) and
+ * out_idx[q,k] (int64, row_offset added -- the shard's first global row).
+ * Slots past min(k,n) get -inf / -1.  1 <= k <= DLC_MAX_K.
+ */
+#define DLC_MAX_K 128
+size_t dlc_cosine_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int k);
+int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
+                    const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
+                    float* out_scores, int64_t* out_idx,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * Merge `parts` per-shard results ([parts, q, k], as an all-gather leaves
+ * them) into the global top-k with the same ordering rule.
+ */
+int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* idx, int parts, int64_t q, int k,
+                   float* out_scores, int64_t* out_idx, void* stream);
+/*
+ * Dense score block S[q, n] (fp32) = Q . DB^T for the all-vs-all cosine
+ * matrix of config 2 (small N); same operand rules as dlc_cosine_topk.
+ */
+int dlc_cosine_scores(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
+                      const void* DB, int64_t n, int64_t lddb, int64_t d,
+                      float* S, int64_t lds, void* stream);
+
+/* ---- introspection used by bench.py (kernel-only timing with HIP events) -- */
+/*
+ * Time of the dominant kernel (the MFMA score GEMM) of the LAST dlc_cosine_topk
+ * call on this context, in milliseconds, measured with hipEvents recorded on
+ * the call's stream around that launch.  Blocks until those events complete.
+ * Enabled by dlc_set_profiling(ctx, 1); returns < 0 when disabled / no call.
+ */
+int dlc_set_profiling(dlc_ctx* ctx, int enabled);
+float dlc_last_gemm_ms(dlc_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLC_H_ */

@@ -22,9 +22,21 @@ def scores(q, db):
     return np.asarray(q, dtype=np.float64) @ np.asarray(db, dtype=np.float64).T
 
 
+_TIE_Q = 2.0 ** 40
+
+
+def order_key(s):
+    """Ordering key of fp64 scores: quantised to 2^-40 so that BLAS rounding noise
+    (identical database rows can get dot products 1 ulp apart, depending on
+    where they sit in a block) cannot break an exact tie the wrong way.  2^-40
+    is ~5 orders below fp32 resolution and ~4 above fp64 noise for |s| <= 1."""
+    return np.round(np.asarray(s, dtype=np.float64) * _TIE_Q) / _TIE_Q
+
+
 def topk_from_scores(s, k, row_offset=0):
     """Top-k per row: score descending, ties -> lower index."""
     q, n = s.shape
+    s_raw, s = s, order_key(s)
     k = min(k, n)
     out_s = np.empty((q, k), dtype=np.float64)
     out_i = np.empty((q, k), dtype=np.int64)
@@ -38,7 +50,7 @@ def topk_from_scores(s, k, row_offset=0):
             cand = np.arange(n)
         order = np.lexsort((cand, -row[cand]))[:k]
         out_i[r] = cand[order] + row_offset
-        out_s[r] = row[cand[order]]
+        out_s[r] = s_raw[r][cand[order]]
     return out_s, out_i
 
 
@@ -62,8 +74,9 @@ def merge_topk(cand_s, cand_i, k):
     k = min(k, cand_s.shape[1])
     out_s = np.empty((q, k), dtype=cand_s.dtype)
     out_i = np.empty((q, k), dtype=np.int64)
+    key = order_key(cand_s)
     for r in range(q):
-        order = np.lexsort((cand_i[r], -cand_s[r]))[:k]
+        order = np.lexsort((cand_i[r], -key[r]))[:k]
         out_s[r] = cand_s[r][order]
         out_i[r] = cand_i[r][order]
     return out_s, out_i

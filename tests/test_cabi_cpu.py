@@ -1,0 +1,82 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/dlc.h declares; host-only entry points work; the
+product path fails loudly without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from deeploopcloser_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "deeploopcloser_amd", "csrc"), "-j4"])
+    return _lib.load()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "dlc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dlc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_python_binds(lib):
+    from deeploopcloser_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 20
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+
+
+def test_host_only_entry_points(lib):
+    from deeploopcloser_amd import _lib
+    assert lib.dlc_abi_version() == 1
+    assert lib.dlc_status_string(0) == b"ok"
+    assert lib.dlc_status_string(_lib.DLC_ERR_WORKSPACE) == b"workspace too small"
+    # workspace sizes are pure host arithmetic
+    w = lib.dlc_cosine_topk_workspace_bytes(256, 1_000_000, 4096, 20)
+    assert w > 256 * (1_000_000 // 16) * 4 and w % 256 == 0
+    assert lib.dlc_cosine_topk_workspace_bytes(256, 1000, 4096, 0) == 0
+    assert lib.dlc_cosine_topk_workspace_bytes(256, 1000, 4096, _lib.DLC_MAX_K + 1) == 0
+    dims = (C.c_int64 * 6)(1681, 2500, 2500, 2500, 2500, 2500)
+    assert lib.dlc_sdav_encode_workspace_bytes(300, dims, 5, _lib.DLC_F64) >= 2 * 300 * 2500 * 8
+    assert lib.dlc_sdav_similarity_workspace_bytes(20, 30, 2500) > 0
+    assert lib.dlc_last_error(None) == b"null context"
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_fails_loudly(lib):
+    import deeploopcloser_amd as dlc
+    ctx = C.c_void_p()
+    assert lib.dlc_create(0, C.byref(ctx)) < 0 and not ctx.value
+    for make in (lambda: dlc.SDAV(), lambda: dlc.CnnVtl(), lambda: dlc.DistanceCalculator.calculate_distance([1], [2]),
+                 lambda: dlc.match_topk([[1.0]], [[1.0]], 1)):
+        with pytest.raises(RuntimeError):
+            make()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "deeploopcloser_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_math_utils_matches_golden(golden):
+    from deeploopcloser_amd import MathUtils
+    g = golden("mathutils.npz")
+    got = [MathUtils.compressed_size(int(v), float(g["compression"])) for v in g["values"]]
+    assert got == g["sizes"].tolist()
