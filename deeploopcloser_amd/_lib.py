@@ -44,7 +44,7 @@ SIGNATURES = {
     "dlc_topk_merge": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp]),
     "dlc_cosine_scores": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dlc_set_profiling": (_int, [_vp, _int]),
-    "dlc_last_gemm_ms": (_flt, [_vp]),
+    "dlc_profile_gemm_ms": (_int, [_vp, C.POINTER(_flt), _int]),
 }
 
 _lib = None

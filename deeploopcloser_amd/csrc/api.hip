@@ -28,9 +28,15 @@ extern "C" int dlc_create(int device, dlc_ctx** out) {
     memset(c, 0, sizeof(*c));
     c->device = device;
     dlc::DeviceGuard guard(device);
-    if (!guard.ok || hipEventCreate(&c->ev_gemm_start) != hipSuccess || hipEventCreate(&c->ev_gemm_stop) != hipSuccess) {
+    if (!guard.ok) {
         delete c;
         return DLC_ERR_HIP;
+    }
+    for (int i = 0; i < DLC_PROFILE_RING; ++i) {
+        if (hipEventCreate(&c->ev_start[i]) != hipSuccess || hipEventCreate(&c->ev_stop[i]) != hipSuccess) {
+            delete c;   // a few leaked events on this failure path are acceptable
+            return DLC_ERR_HIP;
+        }
     }
     *out = c;
     return DLC_OK;
@@ -40,8 +46,10 @@ extern "C" int dlc_destroy(dlc_ctx* ctx) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     {
         dlc::DeviceGuard guard(ctx->device);
-        (void)hipEventDestroy(ctx->ev_gemm_start);
-        (void)hipEventDestroy(ctx->ev_gemm_stop);
+        for (int i = 0; i < DLC_PROFILE_RING; ++i) {
+            (void)hipEventDestroy(ctx->ev_start[i]);
+            (void)hipEventDestroy(ctx->ev_stop[i]);
+        }
     }
     delete ctx;
     return DLC_OK;
@@ -52,15 +60,24 @@ extern "C" const char* dlc_last_error(const dlc_ctx* ctx) { return ctx ? ctx->er
 extern "C" int dlc_set_profiling(dlc_ctx* ctx, int enabled) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     ctx->profiling = enabled ? 1 : 0;
-    ctx->have_gemm_events = 0;
+    ctx->prof_calls = 0;
     return DLC_OK;
 }
 
-extern "C" float dlc_last_gemm_ms(dlc_ctx* ctx) {
-    if (!ctx || !ctx->profiling || !ctx->have_gemm_events) return -1.0f;
+extern "C" int dlc_profile_gemm_ms(dlc_ctx* ctx, float* out_ms, int capacity) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!out_ms || capacity < 1) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "profile_gemm_ms: bad output");
     dlc::DeviceGuard guard(ctx->device);
-    if (hipEventSynchronize(ctx->ev_gemm_stop) != hipSuccess) return -1.0f;
-    float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, ctx->ev_gemm_start, ctx->ev_gemm_stop) != hipSuccess) return -1.0f;
-    return ms;
+    long long n = ctx->prof_calls;
+    if (n > DLC_PROFILE_RING) n = DLC_PROFILE_RING;
+    if (n > capacity) n = capacity;
+    for (long long i = 0; i < n; ++i) {
+        const long long call = ctx->prof_calls - n + i;
+        const int slot = (int)(call % DLC_PROFILE_RING);
+        DLC_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_stop[slot]));
+        float ms = 0.f;
+        DLC_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
+        out_ms[i] = ms;
+    }
+    return (int)n;
 }

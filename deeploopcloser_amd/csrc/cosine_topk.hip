@@ -566,13 +566,13 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
     a.ng = dlc::cdiv(n, GROUP); a.nh = dlc::cdiv(n, HALF);
     a.S = nullptr; a.lds = 0;
 
-    ctx->have_gemm_events = 0;
-    if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_gemm_start, st));
+    const int slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
+    if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[slot], st));
     rc = (dtype == DLC_BF16) ? launch_gemm<dlc_bf16_tag, false>(ctx, a, st) : launch_gemm<dlc_f16_tag, false>(ctx, a, st);
     if (rc != DLC_OK) return rc;
     if (ctx->profiling) {
-        DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_gemm_stop, st));
-        ctx->have_gemm_events = 1;
+        DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[slot], st));
+        ctx->prof_calls++;
     }
 
     int* glist = (int*)(ws + w.glist);

@@ -12,9 +12,9 @@ struct dlc_ctx {
     int device;
     char err[512];
     int profiling;
-    hipEvent_t ev_gemm_start;
-    hipEvent_t ev_gemm_stop;
-    int have_gemm_events;   // events recorded by the last cosine_topk call
+    long long prof_calls;                       // cosine_topk calls recorded since profiling was enabled
+    hipEvent_t ev_start[DLC_PROFILE_RING];
+    hipEvent_t ev_stop[DLC_PROFILE_RING];
 };
 
 namespace dlc {

@@ -270,8 +270,14 @@ class Engine:
     def set_profiling(self, enabled):
         self._check(self.lib.dlc_set_profiling(self.ctx, 1 if enabled else 0))
 
-    def last_gemm_ms(self):
-        return float(self.lib.dlc_last_gemm_ms(self.ctx))
+    def profile_gemm_ms(self, capacity=256):
+        """Durations (ms) of the score-GEMM launches of the last calls, from HIP events
+        recorded on the launch stream (blocks until they complete)."""
+        buf = (C.c_float * capacity)()
+        n = self.lib.dlc_profile_gemm_ms(self.ctx, buf, capacity)
+        if n < 0:
+            self._check(n)
+        return [float(buf[i]) for i in range(n)]
 
 
 _default = {}

@@ -210,13 +210,17 @@ int dlc_cosine_scores(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t
 
 /* ---- introspection used by bench.py (kernel-only timing with HIP events) -- */
 /*
- * Time of the dominant kernel (the MFMA score GEMM) of the LAST dlc_cosine_topk
- * call on this context, in milliseconds, measured with hipEvents recorded on
- * the call's stream around that launch.  Blocks until those events complete.
- * Enabled by dlc_set_profiling(ctx, 1); returns < 0 when disabled / no call.
+ * With profiling enabled every dlc_cosine_topk call records a hipEvent pair on
+ * the call's stream around its dominant kernel (the MFMA score GEMM), into a
+ * ring of DLC_PROFILE_RING slots.  dlc_profile_gemm_ms() waits for the recorded
+ * events and writes the durations (milliseconds, oldest first) of the last
+ * min(calls, capacity, DLC_PROFILE_RING) calls to the HOST array out_ms; it
+ * returns how many it wrote (negative dlc_status on error).  Enabling resets
+ * the ring.
  */
+#define DLC_PROFILE_RING 256
 int dlc_set_profiling(dlc_ctx* ctx, int enabled);
-float dlc_last_gemm_ms(dlc_ctx* ctx);
+int dlc_profile_gemm_ms(dlc_ctx* ctx, float* out_ms, int capacity);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,411 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs and against the committed golden fixtures.
+
+Tolerances (stated here, used below):
+  * integer / byte / index work (cnn_vtl distance, int8 descriptors, top-k
+    indices on planted-margin data, argmin-driven similarity): bit-exact;
+  * fp64 kernels (SDAV / DA / conv GEMMs, SDAV similarity): the reference is
+    fp64 and so are the kernels; only the summation order differs -> abs 1e-10
+    on sigmoid outputs, rel 1e-9 on similarity scores;
+  * cosine scores: fp32 accumulation of bf16/fp16 products vs the fp64 oracle
+    on the SAME stored values -> abs 2e-5 (north_star asks 1e-4).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dlc():
+    import deeploopcloser_amd as d
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    d.default_engine()          # raises loudly if libdlc_hip.so is missing
+    return d
+
+
+@pytest.fixture(scope="module")
+def eng(dlc):
+    return dlc.default_engine()
+
+
+# --------------------------------------------------------------------------- cosine + top-k
+def stored(eng, x, dtype):
+    return eng.normalize(torch.from_numpy(np.ascontiguousarray(x)).to(eng.device), dtype)
+
+
+def assert_topk_matches(s, i, q_st, db_st, k, row_offset=0, exact=False):
+    """Compare a GPU top-k with the fp64 oracle on the stored values.  Positions may
+    differ only where the oracle's own scores are closer than fp32 can resolve."""
+    from oracle import cosine as ocos
+    qn, dbn = q_st.float().cpu().numpy().astype(np.float64), db_st.float().cpu().numpy().astype(np.float64)
+    es, ei = ocos.cosine_topk(qn, dbn, k, row_offset=row_offset)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    kk = es.shape[1]
+    assert np.all(i[:, kk:] == -1) and np.all(np.isneginf(s[:, kk:]))
+    s, i = s[:, :kk], i[:, :kk]
+    assert np.abs(s - es).max() < 2e-5
+    if exact:
+        assert np.array_equal(i, ei)
+        return
+    diff = i != ei
+    if diff.any():
+        full = qn @ dbn.T
+        rows, cols = np.nonzero(diff)
+        got_true = full[rows, i[rows, cols] - row_offset]
+        assert np.abs(got_true - es[rows, cols]).max() < 2e-6, "index differs where scores are not tied"
+        assert diff.mean() < 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("nq,n,d,k", [(5, 1000, 64, 10), (256, 5000, 512, 20), (300, 777, 128, 7),
+                                      (1, 1, 64, 1), (3, 15, 64, 20), (17, 4097, 192, 128), (64, 20000, 4096, 20)])
+def test_cosine_topk_vs_oracle(eng, dtype, nq, n, d, k):
+    rng = np.random.RandomState(nq * 31 + n)
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    db_st, q_st = stored(eng, db, dtype), stored(eng, q, dtype)
+    s, i = eng.match_topk(q_st, db_st, k, row_offset=1000)
+    torch.cuda.synchronize()
+    assert_topk_matches(s, i, q_st, db_st, k, row_offset=1000)
+
+
+def test_cosine_topk_planted_neighbours_exact(eng):
+    """Planted-margin data: indices must be IDENTICAL to the oracle's."""
+    rng = np.random.RandomState(7)
+    n, d, nq, k = 30000, 1024, 256, 20
+    db = rng.uniform(0, 1, (n, d)).astype(np.float32)
+    db -= db.mean(axis=1, keepdims=True)
+    pi = rng.choice(n, nq, replace=False)
+    q = db[pi] + 0.12 * rng.standard_normal((nq, d)).astype(np.float32)
+    db_st, q_st = stored(eng, db, "bf16"), stored(eng, q, "bf16")
+    s, i = eng.match_topk(q_st, db_st, k)
+    assert np.array_equal(i[:, 0].cpu().numpy(), pi)           # recall@1 == 1
+    assert_topk_matches(s, i, q_st, db_st, k)
+
+
+def test_cosine_topk_duplicates_break_ties_to_lower_index(eng):
+    """Collisions: many identical key-frames (a robot standing still)."""
+    rng = np.random.RandomState(3)
+    n, d = 6000, 128
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    dup = np.array([5, 17, 300, 301, 1023, 1024, 2047, 2048, 2049, 3000, 3001, 3002, 3003, 4000, 4500, 4999, 5000,
+                    5100, 5200, 5300, 5400, 5500, 5600, 5700, 5800, 5900, 5999])
+    db[dup] = db[dup[0]]
+    q = np.stack([db[5], db[100]])
+    db_st, q_st = stored(eng, db, "bf16"), stored(eng, q, "bf16")
+    s, i = eng.match_topk(q_st, db_st, 20)
+    assert i[0].cpu().tolist() == sorted(dup.tolist())[:20]
+    assert_topk_matches(s, i, q_st, db_st, 20, exact=True)
+    # whole database identical: top-k must be rows 0..k-1
+    same = np.repeat(db[:1], 3000, axis=0)
+    st = stored(eng, same, "bf16")
+    s, i = eng.match_topk(st[:4], st, 33)
+    assert i.cpu().tolist() == [list(range(33))] * 4
+
+
+def test_cosine_topk_row_stride_and_padding(eng):
+    """d not a multiple of 64 is zero-padded by normalize(); a strided view works."""
+    rng = np.random.RandomState(11)
+    db = rng.standard_normal((2500, 100)).astype(np.float32)
+    q = rng.standard_normal((9, 100)).astype(np.float32)
+    db_st, q_st = stored(eng, db, "bf16"), stored(eng, q, "bf16")
+    assert db_st.shape[1] == 128 and torch.all(db_st[:, 100:] == 0)
+    big = torch.zeros((2500, 256), dtype=torch.bfloat16, device=eng.device)
+    big[:, :128] = db_st
+    s, i = eng.match_topk(q_st, big[:, :128], 10)
+    assert_topk_matches(s, i, q_st, db_st, 10)
+
+
+def test_cosine_scores_dense_vs_oracle(eng):
+    from oracle import cosine as ocos
+    rng = np.random.RandomState(2)
+    x = rng.standard_normal((333, 320)).astype(np.float32)
+    st = stored(eng, x, "bf16")
+    s = eng.cosine_scores(st[:70], st).cpu().numpy()
+    ref = ocos.scores(st[:70].float().cpu().numpy(), st.float().cpu().numpy())
+    assert s.shape == (70, 333) and np.abs(s - ref).max() < 2e-5
+
+
+def test_topk_merge_vs_oracle(eng):
+    from oracle import cosine as ocos
+    rng = np.random.RandomState(4)
+    parts, nq, k = 8, 50, 20
+    s = rng.standard_normal((parts, nq, k)).astype(np.float32)
+    s[3, :, 5] = s[1, :, 2]
+    i = rng.permutation(parts * nq * k).reshape(parts, nq, k).astype(np.int64)
+    i[7, :, -3:] = -1
+    ms, mi = eng.topk_merge(torch.from_numpy(s).to(eng.device), torch.from_numpy(i).to(eng.device))
+    cs = np.transpose(s, (1, 0, 2)).reshape(nq, parts * k).astype(np.float64)
+    ci = np.transpose(i, (1, 0, 2)).reshape(nq, parts * k)
+    cs = np.where(ci < 0, -np.inf, cs)
+    es, ei = ocos.merge_topk(cs, np.where(ci < 0, np.iinfo(np.int64).max, ci), k)
+    assert np.array_equal(mi.cpu().numpy(), ei) and np.array_equal(ms.cpu().numpy(), es.astype(np.float32))
+
+
+def test_sharded_equals_unsharded(eng, dlc):
+    """Size-independent property: 4 row shards + merge == one shard."""
+    rng = np.random.RandomState(9)
+    n, d, nq, k = 40000, 256, 128, 20
+    db_st = stored(eng, rng.standard_normal((n, d)).astype(np.float32), "bf16")
+    q_st = stored(eng, rng.standard_normal((nq, d)).astype(np.float32), "bf16")
+    s0, i0 = eng.match_topk(q_st, db_st, k)
+    ps, pi = [], []
+    for r in range(4):
+        lo, hi = dlc.shard_bounds(n, 4, r)
+        s, i = eng.match_topk(q_st, db_st[lo:hi], k, row_offset=lo)
+        ps.append(s.clone()), pi.append(i.clone())
+    ms, mi = eng.topk_merge(torch.stack(ps), torch.stack(pi))
+    assert torch.equal(mi, i0) and torch.equal(ms, s0)
+
+
+def test_match_errors(eng):
+    q = torch.zeros((4, 64), dtype=torch.bfloat16, device=eng.device)
+    with pytest.raises(ValueError):
+        eng.match_topk(q, q, 0)
+    with pytest.raises(ValueError):
+        eng.match_topk(q, q, 129)
+    with pytest.raises(ValueError):
+        eng.match_topk(q[:, :32], q[:, :32], 2)                     # d not a multiple of 64
+    with pytest.raises(ValueError):
+        eng.match_topk(q, q.to(torch.float16), 2)
+    with pytest.raises(ValueError):
+        eng.normalize(torch.zeros((2, 8), dtype=torch.int32, device=eng.device))
+
+
+def test_normalize_rows(eng):
+    rng = np.random.RandomState(1)
+    x = rng.standard_normal((37, 100))
+    for center in (False, True):
+        got = eng.normalize(torch.from_numpy(x).to(eng.device), "bf16", center).float().cpu().numpy()
+        y = x - x.mean(1, keepdims=True) if center else x
+        ref = y / np.linalg.norm(y, axis=1, keepdims=True)
+        ref_bf = torch.from_numpy(ref.astype(np.float32)).to(torch.bfloat16).float().numpy()
+        assert np.abs(got[:, :100] - ref_bf).max() <= 2.0 ** -8 * np.abs(ref).max() and np.all(got[:, 100:] == 0)
+        assert (got[:, :100] == ref_bf).mean() > 0.999
+
+
+# --------------------------------------------------------------------------- dense layers / SDAV
+@pytest.mark.parametrize("m,n,k", [(37, 53, 29), (128, 128, 16), (600, 2500, 1681), (1, 1, 1), (130, 384, 3456)])
+@pytest.mark.parametrize("blayout", [0, 1])
+def test_gemm_bias_act_f64(eng, m, n, k, blayout):
+    from oracle import tensor_ops
+    rng = np.random.RandomState(m + n + k)
+    a = rng.standard_normal((m, k))
+    b = rng.standard_normal((k, n)) / np.sqrt(k)
+    bias = rng.standard_normal(n)
+    bt = torch.from_numpy(np.ascontiguousarray(b if blayout == 0 else b.T)).to(eng.device)
+    for act, fn in ((0, lambda z: z), (1, tensor_ops.sigmoid), (2, lambda z: np.maximum(z, 0))):
+        got = eng.gemm_bias_act(torch.from_numpy(a).to(eng.device), bt, torch.from_numpy(bias).to(eng.device),
+                                act=act, blayout=blayout).cpu().numpy()
+        ref = fn(a @ b + bias)
+        assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_bias_act_f32(eng):
+    rng = np.random.RandomState(0)
+    a = rng.standard_normal((300, 777)).astype(np.float32)
+    b = (rng.standard_normal((777, 200)) / 28).astype(np.float32)
+    got = eng.gemm_bias_act(torch.from_numpy(a).to(eng.device), torch.from_numpy(b).to(eng.device), None, act=1)
+    ref = 1 / (1 + np.exp(-(a.astype(np.float64) @ b.astype(np.float64))))
+    assert np.abs(got.cpu().numpy() - ref).max() < 2e-6
+
+
+@pytest.mark.parametrize("scale", ["reference", "fan_in"])
+def test_sdav_transform_vs_oracle(dlc, scale):
+    """SDAV.transform (SDAV.py:293-302), both weight regimes of SURVEY section 7 'hard parts'."""
+    from oracle import sdav as osdav
+    rng = np.random.RandomState(5)
+    net = dlc.SDAV(seed=11, weight_scale=scale)
+    x = rng.uniform(0, 1, size=(7, 30, 1681))
+    h = net.transform(x)
+    ws, bs = net.get_weights()
+    ow, ob = osdav.init_weights(11, scale=scale)
+    assert all(np.array_equal(a, b) for a, b in zip(ws, ow))
+    ref = osdav.transform(x, ws, bs)
+    assert h.shape == (210, 2500) and h.dtype == np.float64
+    assert np.abs(h - ref).max() < 1e-10
+    l2 = np.linalg.norm(h - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert l2.max() < 1e-10                                          # north_star: descriptor L2 within 1e-4
+
+
+def test_sdav_transform_fp32_mode_within_north_star_tolerance(dlc):
+    from oracle import sdav as osdav
+    rng = np.random.RandomState(6)
+    net = dlc.SDAV(seed=12, dtype="float32", weight_scale="fan_in")
+    x = rng.uniform(0, 1, size=(3, 30, 1681))
+    h = net.transform(x)
+    ws, bs = net.get_weights()
+    ref = osdav.transform(x, [w.astype(np.float64) for w in ws], [b.astype(np.float64) for b in bs])
+    l2 = np.linalg.norm(h - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert l2.max() < 1e-4
+
+
+def test_sdav_surface(dlc):
+    net = dlc.SDAV()
+    assert net.input_shape == [30, 1681] and net.hidden_units == [2500] * 5 and net.default_batch_size == 10
+    assert net.get_layers_input_shapes() == [[30, 2500]] * 5
+    assert net.transform(np.zeros((0, 30, 1681))).shape == (0, 2500)
+    with pytest.raises(ValueError):
+        net.transform(np.zeros((2, 30, 100)))
+    with pytest.raises(NotImplementedError):
+        net.fit(np.zeros((1, 30, 1681)))
+
+
+def test_da_transform_vs_oracle(dlc):
+    from oracle import sdav as osdav
+    rng = np.random.RandomState(8)
+    da = dlc.DA([30, 1681], 2500, seed=4)
+    x = rng.uniform(0, 1, size=(30, 1681))
+    w = da._w0.cpu().numpy()
+    assert np.abs(da.transform(x) - osdav.da_transform(x, w, np.zeros(2500))).max() < 1e-11
+    with pytest.raises(ValueError):
+        dlc.DA([30], 10)
+
+
+def test_tensor_wrapper_reference_known_answer(dlc, golden):
+    """test/TensorflowWrapperTest.py:11-21 run through the MI355X TensorWrapper."""
+    tw = dlc.tensor_wrapper
+    g = golden("tensorwrapper_test_example.npz")
+    x = tw.constant(g["x"])
+    w = tw.constant(g["w"])
+    y = x.matmul(w.to_tf()).to_tf()
+    assert np.array_equal(g["expected"], y.cpu().numpy()) and y.dtype == torch.float64
+    # fused matmul.add.sigmoid chain == oracle layer
+    from oracle import tensor_ops
+    rng = np.random.RandomState(0)
+    xb, wb, bb = rng.uniform(0, 1, (3, 30, 40)), rng.standard_normal((40, 25)), rng.standard_normal(25)
+    h = tw.constant(xb).corrupt(0).matmul(tw.constant(wb)).add(tw.constant(bb)).sigmoid()
+    ref = tensor_ops.sigmoid(tensor_ops.tw_matmul(xb, wb) + bb)
+    assert h.shape() == [3, 30, 25] and np.abs(h.numpy() - ref).max() < 1e-12
+    assert np.abs(tw.constant(xb).add(tw.constant(xb[0, 0])).sigmoid().numpy() -
+                  tensor_ops.sigmoid(xb + xb[0, 0])).max() < 1e-15
+    m = tw.random_mask([30, 40], 0.3).numpy()
+    assert m.shape == (30, 40) and int((m == 0).sum()) == 360
+
+
+# --------------------------------------------------------------------------- reference-semantics match
+SIM_CASES = ["n6_h8", "n6_h64", "n4_h2500", "n5_h32_params", "n5_p7_h16"]
+
+
+def sim_dataset(g, name):
+    if name + "/dataset" in g:
+        return g[name + "/dataset"]
+    seed, n, p, h = g[name + "/dataset_seed_uniform01"]
+    return np.random.RandomState(int(seed)).uniform(0.0, 1.0, size=(int(n), int(p), int(h)))
+
+
+@pytest.mark.parametrize("name", SIM_CASES)
+def test_similarity_vs_reference_fixture(dlc, golden, name):
+    """GPU similarity against the outputs of the reference's own SimilarityCalculator."""
+    from oracle import similarity as osim
+    g = golden("similarity.npz")
+    ds = sim_dataset(g, name)
+    mu, sigma, a, b = g[name + "/params"]
+    calc = dlc.SimilarityCalculator(ds, mu=mu, sigma=sigma, a=a, b=b)
+    want = g[name + "/scores"]
+    n = ds.shape[0]
+    np.testing.assert_allclose(calc._score.cpu().numpy(), g[name + "/distinctive_score"], rtol=1e-13)
+    mf = calc.similarity_matrix(as_int64=False)
+    mi = calc.similarity_matrix(as_int64=True)
+    assert mi.dtype == np.int64
+    for i in range(n):
+        assert mf[i, i] == -1 and mi[i, i] == -1
+        for j in range(i + 1, n):
+            if np.isinf(want[i, j]):
+                assert mf[i, j] == want[i, j] and mi[i, j] == osim.INT64_MIN
+            else:
+                assert abs(mf[i, j] - want[i, j]) <= 1e-9 * abs(want[i, j])
+                assert mi[i, j] == int(np.trunc(want[i, j])) or abs(want[i, j] - round(want[i, j])) < 1e-7
+            assert mf[j, i] == mf[i, j] and mi[j, i] == mi[i, j]        # mirrored upper triangle
+    # the per-pair entry keeps the reference's asymmetry
+    for (i, j) in [(0, 1), (1, 0), (2, 3)]:
+        got = calc.similarity_score(ds[i], ds[j])
+        assert (np.isinf(want[i, j]) and got == want[i, j]) or abs(got - want[i, j]) <= 1e-9 * abs(want[i, j])
+
+
+def test_similarity_matrix_vs_oracle_larger(dlc):
+    from oracle import similarity as osim
+    rng = np.random.RandomState(3)
+    ds = rng.uniform(0, 1, size=(23, 30, 300))
+    ds[9] = ds[2]
+    got = dlc.SimilarityCalculator(ds).similarity_matrix(as_int64=False)
+    ref = osim.similarity_matrix_f64(ds)
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isposinf(got), np.isposinf(ref))
+    assert np.abs(got[fin] - ref[fin]).max() < 1e-9 * np.abs(ref[fin]).max()
+
+
+def test_distance_vs_reference_fixture(dlc, golden):
+    g = golden("distance.npz")
+    dc = dlc.DistanceCalculator
+    assert dc.calculate_distance(g["probe/a"], g["probe/b"]) == 6
+    per = [dc.calculate_distance([v], [np.int8(0)]) for v in g["all/a"][::17]]
+    assert per == g["all/per_element"][::17].tolist()
+    for name in ("n7_d2243", "n9_d37", "n3_d1"):
+        m = dc.distance_matrix(g[name + "/desc"])
+        assert m.dtype == np.int64 and np.array_equal(m, g[name + "/matrix"])
+
+
+def test_distance_matrix_vs_oracle_larger(dlc):
+    from oracle import distance as odist
+    rng = np.random.RandomState(13)
+    desc = rng.randint(-128, 128, size=(203, 2243)).astype(np.int8)
+    desc[50] = desc[3]
+    got = dlc.DistanceCalculator.distance_matrix(desc)
+    assert np.array_equal(got, odist.distance_matrix(desc))
+    assert got[50, 3] == 0 and np.array_equal(got, got.T)
+
+
+# --------------------------------------------------------------------------- CnnVtl
+def test_cnn_vtl_pieces_vs_oracle(eng):
+    from oracle import cnn_vtl as ocnn
+    rng = np.random.RandomState(0)
+    x = rng.uniform(0, 255, size=(2, 23, 31, 5))
+    xt = torch.from_numpy(x).to(eng.device)
+    assert np.array_equal(eng.maxpool3x3s2(xt).cpu().numpy(), ocnn.maxpool3x3s2(x))
+    w = rng.standard_normal((3, 3, 5, 7))
+    b = rng.standard_normal(7)
+    for stride, pad in ((1, "SAME"), (2, "VALID"), (2, "SAME")):
+        oh, ph = ocnn._out_size(23, 3, stride, pad)
+        ow, pw = ocnn._out_size(31, 3, stride, pad)
+        cols = eng.im2col(xt, 3, 3, stride, ph, pw, oh, ow)
+        y = eng.gemm_bias_act(cols, torch.from_numpy(w.reshape(45, 7)).to(eng.device), torch.from_numpy(b).to(eng.device),
+                              act=2).reshape(2, oh, ow, 7).cpu().numpy()
+        ref = ocnn.conv2d_nhwc(x, w, b, stride, pad, True)
+        assert y.shape == ref.shape and np.abs(y - ref).max() < 1e-10
+
+
+def test_cnn_vtl_transform_vs_oracle(dlc):
+    """CnnVtl.transform at the reference's 192x240 frame size, seeded weights + mask."""
+    from oracle import cnn_vtl as ocnn
+    rng = np.random.RandomState(2)
+    x = rng.randint(0, 256, size=(3, 192, 240, 3)).astype(np.float64)      # uint8 pixels fed as fp64
+    net = dlc.CnnVtl(input_shape=[3, 192, 240, 3], seed=5, mask_seed=9)
+    assert net.layer_sizes == [256128, 157696, 49920, 49920, 33280] == ocnn.layer_sizes((192, 240))
+    cols = ocnn.column_indices(net.layer_sizes, 99.59, seed=9)
+    assert np.array_equal(net.columns, cols) and cols.size <= 2243
+    ws, bs = ocnn.init_weights(5)
+    got = net.transform(x)
+    ref = ocnn.transform(x, ws, bs, cols)
+    assert got.dtype == np.int8 and got.shape == ref.shape == (3, cols.size)
+    diff = (got.astype(np.int16) - ref.astype(np.int16)) % 256
+    bad = np.count_nonzero(diff)
+    # fp64 on both sides, different summation order: a value within ~1e-11 of an integer may
+    # truncate differently.  Expect none; allow 2 off-by-one elements out of ~6700.
+    assert bad <= 2 and np.all((diff == 0) | (diff == 1) | (diff == 255))
+    assert (ref < 0).any() and (ref > 0).any()                       # the wrap (>127 -> negative) is exercised
+
+
+def test_cnn_vtl_surface(dlc):
+    net = dlc.CnnVtl()                                               # reference default 224x224
+    assert net.input_shape == [1, 224, 224, 3] and net.compress_factor == 99.59
+    assert net.layer_sizes == [279936, 173056, 55296, 55296, 36864]
+    y1 = net.transform(np.ones((1, 224, 224, 3)))                    # basic_example.py:6-13
+    y2 = y1.copy()
+    y2[0, 0] = 23
+    d = dlc.DistanceCalculator.calculate_distance(y1[0], y2[0])
+    assert y1.shape == (1, net.columns.size) and d >= 0
+    with pytest.raises(ValueError):
+        net.transform(np.ones((1, 100, 100, 3)))
