@@ -40,14 +40,14 @@ constexpr int MAX_KG = DLC_MAX_K + SLACK;
 
 template <typename Tag> struct Mfma16;
 template <> struct Mfma16<dlc_bf16_tag> {
-    static __device__ __forceinline__ f32x4_t run(uint4 a, uint4 b, f32x4_t c) {
+    static __device__ __forceinline__ f32x4_t run(u32x4_t a, u32x4_t b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                        __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ float to_f32(unsigned short h) { return dlc_bf16_bits_to_f32(h); }
 };
 template <> struct Mfma16<dlc_f16_tag> {
-    static __device__ __forceinline__ f32x4_t run(uint4 a, uint4 b, f32x4_t c) {
+    static __device__ __forceinline__ f32x4_t run(u32x4_t a, u32x4_t b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
                                                       __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
@@ -87,6 +87,45 @@ struct GemmArgs {
     long long lds;
 };
 
+// ---- LDS image (128 KiB): two K-tile buffers of 64 KiB; in a buffer four 16-KiB
+// half tiles A0 | A1 | B0 | B1, each 128 rows x 128 B:
+//   A half h, row r = wr*64 + rr   <->  tile database row  wr*128 + h*64 + rr
+//   B half h, row r = wc*32 + rr   <->  query row          wc*64  + h*32 + rr
+// A wave computes its 128 x 64 block as four 64 x 32 quadrants (A half, B half),
+// each in two 32-wide k-slices: 8 mini-phases of 8 MFMAs per K tile.
+constexpr int HALF_BYTES = 128 * 128;
+constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
+
+// Two LDS-DMA wave-instructions (2 x 1 KiB = this wave's share of one half tile).
+// Issued from inline asm so that hipcc does not count them: it would otherwise
+// put s_waitcnt vmcnt(0) in front of every ds_read and serialise the pipeline.
+// M0 carries the LDS destination (wave-uniform); saved and restored because the
+// compiler owns it.  s_nop 4 covers an SGPR operand freshly written by a VALU.
+__device__ __forceinline__ void dma_half(unsigned voff0, unsigned voff1, const char* sbase, unsigned lds0) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, %4, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff0), "v"(voff1), "s"(sbase), "s"(lds0)
+        : "memory", "scc");
+}
+
+#define DLC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define DLC_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <typename Tag, bool DENSE>
 __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,79 +136,141 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     const int wc = wid & 3;    // query block (64 queries)
     const long long tile = blockIdx.x;
     const int qblk = blockIdx.y;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem;
 
-    // ---- staging addresses: wave `wid` stages LDS rows 32*wid .. 32*wid+31 of both tiles
-    const char* srcA[4];
-    const char* srcB[4];
-    const int slot = lane & 7;
+    // ---- DMA source offsets (bytes from the tile's / query block's first row), per half, per DMA
+    const char* a_base = p.DB + tile * BM * p.lddb_b;
+    const char* b_base = p.Q + (long long)qblk * BNQ * p.ldq_b;
+    unsigned voffA[2][2], voffB[2][2];
+    {
+        const int slot = lane & 7;
+        const long long arows = p.n - tile * BM;          // valid rows in this tile (>= 1)
+        const long long brows = (long long)p.q - (long long)qblk * BNQ;
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
-        const int R = 32 * wid + 8 * ii + (lane >> 3);
-        long long dbrow = tile * BM + R;
-        if (dbrow > p.n - 1) dbrow = p.n - 1;
-        srcA[ii] = p.DB + dbrow * p.lddb_b + ((slot ^ swz_a(R)) << 4);
-        int qrow = qblk * BNQ + R;
-        if (qrow > p.q - 1) qrow = p.q - 1;
-        srcB[ii] = p.Q + (long long)qrow * p.ldq_b + ((slot ^ swz_b(R)) << 4);
+        for (int j = 0; j < 2; ++j) {
+            const int r = 16 * wid + 8 * j + (lane >> 3);             // row inside the half
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                long long ar = (r >> 6) * 128 + h * 64 + (r & 63);
+                if (ar > arows - 1) ar = arows - 1;
+                voffA[h][j] = (unsigned)(ar * p.lddb_b + ((slot ^ swz_a(r)) << 4));
+                long long br = (r >> 5) * 64 + h * 32 + (r & 31);
+                if (br > brows - 1) br = brows - 1;
+                voffB[h][j] = (unsigned)(br * p.ldq_b + ((slot ^ swz_b(r)) << 4));
+            }
+        }
     }
-    const int lds_stage = (32 * wid) * 128;   // + ii * 1024
+    const unsigned lds_stage = lds_base + (unsigned)(16 * wid) * 128;   // this wave's rows of a half
+    const int nk = p.nk;
 
-    // ---- fragment read offsets
+    // ---- fragment read offsets (bytes inside a half)
     const int i = lane & 15;
     const int kq = lane >> 4;
     const int fa = ((i >> 1) & 1) | ((i >> 2) << 1);
     const int fb = (i >> 1) & 7;
-    const int rowA0 = wr * 128 + 16 * (i >> 2) + (i & 3);
-    const int rowB0 = wc * 64 + i;
-    int offA[2], offB[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        offA[ks] = rowA0 * 128 + (((4 * ks + kq) ^ fa) << 4);
-        offB[ks] = TILE_BYTES + rowB0 * 128 + (((4 * ks + kq) ^ fb) << 4);
-    }
+    typedef const __attribute__((address_space(3))) u32x4_t* lds_u4p;
+    typedef const __attribute__((address_space(3))) char* lds_cp;
+    const lds_cp lbase = (lds_cp)(lptr_t)smem;
+    // byte offsets of this lane's fragment rows in the CURRENT buffer; toggled with ^BUF_BYTES
+    // (the two buffers are 64 KiB apart and the dynamic LDS segment starts at offset 0)
+    unsigned rdA0 = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((0 + kq) ^ fa) << 4);   // + tt*512
+    unsigned rdA1 = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((4 + kq) ^ fa) << 4);
+    unsigned rdB0 = (wc * 32 + i) * 128 + (((0 + kq) ^ fb) << 4);                         // + c*2048
+    unsigned rdB1 = (wc * 32 + i) * 128 + (((4 + kq) ^ fb) << 4);
+    unsigned lds_cur = lds_stage;        // this wave's DMA rows in the current buffer
 
     f32x4_t acc[8][4];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // Fragment registers: one k-slice (32 wide) of one half: A 4 tiles, B 2 tiles.
+    u32x4_t faX[4], faY[4], fbX[2], fbY[2];
 
-    // ---- prologue: stage K tile 0 into buffer 0
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
-        glds16(srcA[ii], smem + lds_stage + ii * 1024);
-        glds16(srcB[ii], smem + TILE_BYTES + lds_stage + ii * 1024);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // LDS-DMA drained by every wave, then visible to all
+#define DLC_READ_A(DST, RD, OFF)                      \
+    _Pragma("unroll") for (int tt = 0; tt < 4; ++tt)  \
+        DST[tt] = *(lds_u4p)(lbase + (RD) + (OFF) + tt * 512)
+#define DLC_READ_B(DST, RD, OFF)                      \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)     \
+        DST[c] = *(lds_u4p)(lbase + (RD) + (OFF) + c * 2048)
+#define DLC_MFMA(FA, FB, AH, BH)                                                                     \
+    do {                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) _Pragma("unroll") for (int c = 0; c < 2; ++c) \
+            acc[(AH) * 4 + tt][(BH) * 2 + c] =                                                       \
+                Mfma16<Tag>::run(FA[tt], FB[c], acc[(AH) * 4 + tt][(BH) * 2 + c]);                   \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+    } while (0)
+#define DLC_RELEASE()    \
+    DLC_WAIT_LGKM0();    \
+    wg_barrier()
+    // DMA of half OFF of K tile t2 into the CURRENT buffer (K offset clamped past the end: the
+    // redundant DMA lands in a dead half and keeps the vmcnt bookkeeping uniform)
+#define DLC_ISSUE(LDS, OFF, VOFF, BASE, t2)                                                          \
+    do {                                                                                             \
+        int kk_ = (t2) < nk ? (t2) : nk - 1;                                                         \
+        dma_half(VOFF[0], VOFF[1], (BASE) + (long long)kk_ * 128, (LDS) + (OFF));                    \
+    } while (0)
 
-    for (int kt = 0; kt < p.nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < p.nk) {
-            char* nb = smem + (cur ^ 1) * BUF_BYTES + lds_stage;
-            const long long ko = (long long)(kt + 1) * 128;
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                glds16(srcA[ii] + ko, nb + ii * 1024);
-                glds16(srcB[ii] + ko, nb + TILE_BYTES + ii * 1024);
-            }
-        }
-        const char* base = smem + cur * BUF_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 b[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) b[c] = *(const uint4*)(base + offB[ks] + c * 2048);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const uint4 a = *(const uint4*)(base + offA[ks] + (t >> 2) * 8192 + (t & 3) * 512);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[t][c] = Mfma16<Tag>::run(a, b[c], acc[t][c]);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // next tile landed; everyone done reading `cur`
+    // ---- prologue: K tiles 0 and 1 issued (tile 1 clamps to tile 0 when nk == 1)
+    DLC_ISSUE(lds_cur, OFF_A1, voffA[1], a_base, 0);
+    DLC_ISSUE(lds_cur, OFF_B0, voffB[0], b_base, 0);
+    DLC_ISSUE(lds_cur, OFF_B1, voffB[1], b_base, 0);
+    DLC_ISSUE(lds_cur, OFF_A0, voffA[0], a_base, 0);
+    DLC_ISSUE(lds_cur ^ BUF_BYTES, OFF_A1, voffA[1], a_base, 1);
+    DLC_ISSUE(lds_cur ^ BUF_BYTES, OFF_B0, voffB[0], b_base, 1);
+    DLC_ISSUE(lds_cur ^ BUF_BYTES, OFF_B1, voffB[1], b_base, 1);
+    DLC_ISSUE(lds_cur ^ BUF_BYTES, OFF_A0, voffA[0], a_base, 1);
+    DLC_WAIT_VMCNT(8);            // K tile 0 landed
+    wg_barrier();
+    DLC_READ_A(faX, rdA0, OFF_A0);
+    DLC_READ_B(fbX, rdB0, OFF_B0);
+
+    // One K tile = 8 mini-phases of 8 MFMAs, k-slice outer, quadrants in snake order so that
+    // exactly one operand changes per step and every LDS fragment is read once:
+    //   m1 (A0,B0,k0) m2 (A0,B1,k0) m3 (A1,B1,k0) m4 (A1,B0,k0)
+    //   m5 (A1,B0,k1) m6 (A1,B1,k1) m7 (A0,B1,k1) m8 (A0,B0,k1)
+    // Mini-phase m issues the reads of m+1 first, then its own MFMAs.  A half of the current
+    // buffer is dead once its k1 slice has been read (A1 after m3, B0 after m4, B1 after m5, A0
+    // after m6): a barrier there, then the DMA of K tile t+2 into it.  Per-tile DMA order
+    // A1,B0,B1,A0; the single vmcnt(6) at the end of m6 leaves the three youngest halves in flight
+    // and retires all of K tile t+1, whose first slices are read in m7 / m8.
+    for (int t = 0; t < nk; ++t) {
+        DLC_READ_B(fbY, rdB0, OFF_B1);
+        DLC_MFMA(faX, fbX, 0, 0);                                  // m1
+        DLC_READ_A(faY, rdA0, OFF_A1);
+        DLC_MFMA(faX, fbY, 0, 1);                                  // m2
+        DLC_READ_A(faX, rdA1, OFF_A1);
+        DLC_MFMA(faY, fbY, 1, 1);                                  // m3
+        DLC_RELEASE();                                             // A1 read by everyone
+        DLC_READ_B(fbY, rdB1, OFF_B0);
+        DLC_ISSUE(lds_cur, OFF_A1, voffA[1], a_base, t + 2);
+        DLC_MFMA(faY, fbX, 1, 0);                                  // m4
+        DLC_RELEASE();                                             // B0
+        DLC_READ_B(fbX, rdB1, OFF_B1);
+        DLC_ISSUE(lds_cur, OFF_B0, voffB[0], b_base, t + 2);
+        DLC_MFMA(faX, fbY, 1, 0);                                  // m5
+        DLC_RELEASE();                                             // B1
+        DLC_READ_A(faY, rdA1, OFF_A0);
+        DLC_ISSUE(lds_cur, OFF_B1, voffB[1], b_base, t + 2);
+        DLC_MFMA(faX, fbX, 1, 1);                                  // m6
+        DLC_WAIT_VMCNT(6);                                         // K tile t+1 landed (this wave's share)
+        DLC_RELEASE();                                             // A0; and t+1 visible to all
+        DLC_ISSUE(lds_cur, OFF_A0, voffA[0], a_base, t + 2);
+        rdA0 ^= BUF_BYTES; rdA1 ^= BUF_BYTES; rdB0 ^= BUF_BYTES; rdB1 ^= BUF_BYTES;   // next tile's buffer
+        lds_cur ^= BUF_BYTES;
+        DLC_READ_A(faX, rdA0, OFF_A0);
+        DLC_MFMA(faY, fbX, 0, 1);                                  // m7
+        DLC_READ_B(fbX, rdB0, OFF_B0);
+        DLC_MFMA(faY, fbY, 0, 0);                                  // m8
     }
+    DLC_WAIT_VMCNT(0);   // the clamped tail DMAs must not outlive the workgroup's LDS
+    DLC_WAIT_LGKM0();
+#undef DLC_ISSUE
+#undef DLC_READ_A
+#undef DLC_READ_B
+#undef DLC_MFMA
+#undef DLC_RELEASE
 
     // ---- epilogue
     const int lg = lane >> 4;

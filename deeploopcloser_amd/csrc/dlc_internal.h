@@ -67,6 +67,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) double f64x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 struct dlc_bf16_tag {};
 struct dlc_f16_tag {};
