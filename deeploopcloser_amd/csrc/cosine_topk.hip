@@ -3,25 +3,27 @@
 // Pipeline of one dlc_cosine_topk() call (all on the caller's stream):
 //   1. score_gemm_kernel   S~ = DB . Q^T on the bf16/f16 MFMA (fp32 accumulate).
 //      The score tile never leaves the accumulators: the epilogue keeps, per
-//      query, the maximum of every aligned block of 16 database rows
+//      query, the maximum of every aligned block of 8 database rows
 //      ("group", gmax) and of every 128 rows ("half tile", tmax).  The
 //      database is streamed from HBM exactly once.
-//   2. select_groups_kernel  per query: the kg = k + SLACK half tiles with the
-//      largest tmax, then the kg groups with the largest gmax inside them.
-//      Every member of the exact top-k lies in one of those groups (the k-th
-//      largest group maximum is a lower bound of the k-th largest score).
-//   3. rescore_kernel      exact fp32 dot products for the 16 rows of each
-//      selected group (a gather of kg*16 rows per query).
-//   4. final_topk_kernel   top-k of the kg*16 candidates, score descending,
-//      ties toward the lower database index.
-// dlc_topk_merge() is step 4 on an all-gather of per-shard results.
+//   2. finish_topk_kernel  one workgroup per query:
+//      a. the kg = k + SLACK half tiles with the largest tmax, then the kg groups
+//         with the largest gmax inside them.  Every member of the exact top-k
+//         lies in one of those groups (the k-th largest group maximum is a
+//         lower bound of the k-th largest score);
+//      b. exact fp32 dot products for the 8 rows of each selected group (a
+//         gather of kg*8 rows per query);
+//      c. top-k of the kg*8 candidates, score descending, ties toward the
+//         lower database index.
+// dlc_topk_merge() is step 2c on an all-gather of per-shard results.
 //
 // MFMA operand roles: A = database rows, B = queries, so that in the 16x16 C/D
 // layout (col = lane&15, row = 4*(lane>>4)+reg) a lane holds ONE query and
 // FOUR database rows per tile: the per-group maximum is an in-lane v_max chain.
 // The A fragment's row i of MFMA tile tt is mapped to database row
 // 16*(i>>2) + 4*tt + (i&3) of the wave's 64-row half, which makes each lane's
-// 16 accumulators (4 tiles x 4 regs) one CONTIGUOUS block of 16 database rows.
+// 16 accumulators (4 tiles x 4 regs) one CONTIGUOUS block of 16 database rows
+// (two groups of 8).
 #include "dlc_internal.h"
 
 namespace {
@@ -33,9 +35,10 @@ constexpr int NTHREADS = 512;    // 8 waves: 2 (database halves of 128 rows) x 4
 constexpr int TILE_BYTES = 256 * BK * 2;   // 32 KiB: one operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;  // A tile + B tile
 constexpr int LDS_BYTES = 2 * BUF_BYTES;   // double buffered: 128 KiB
-constexpr int GROUP = 16;        // database rows per group
+constexpr int GROUP = 8;         // database rows per group
 constexpr int HALF = 128;        // database rows per half tile
-constexpr int SLACK = 8;         // extra groups kept beyond k (fp32 re-score vs MFMA order)
+constexpr int GROUPS_PER_HALF = HALF / GROUP;
+constexpr int SLACK = 4;         // extra groups kept beyond k (fp32 re-score order vs MFMA order)
 constexpr int MAX_KG = DLC_MAX_K + SLACK;
 
 template <typename Tag> struct Mfma16;
@@ -294,14 +297,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
             float hm[2];
 #pragma unroll
             for (int th = 0; th < 2; ++th) {
-                float m = acc[th * 4][c][0];
+                // this lane's 16 rows of the half are two groups of 8: MFMA tiles {0,1} and {2,3}
+                float m0 = acc[th * 4][c][0], m1 = acc[th * 4 + 2][c][0];
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[th * 4 + tt][c][r]);
-                hm[th] = m;
-                const long long g = tile * (BM / GROUP) + wr * 8 + th * 4 + lg;
-                if (qidx < p.q && g < p.ng) p.gmax[(long long)qidx * p.ldg + g] = m;
+                    for (int r = 0; r < 4; ++r) {
+                        m0 = fmaxf(m0, acc[th * 4 + tt][c][r]);
+                        m1 = fmaxf(m1, acc[th * 4 + 2 + tt][c][r]);
+                    }
+                hm[th] = fmaxf(m0, m1);
+                const long long g = tile * (BM / GROUP) + wr * 16 + th * 8 + lg * 2;
+                if (qidx < p.q) {
+                    float* dst = p.gmax + (long long)qidx * p.ldg + g;
+                    if (g + 1 < p.ng) *(float2*)dst = make_float2(m0, m1);
+                    else if (g < p.ng) dst[0] = m0;
+                }
             }
             float h = fmaxf(hm[0], hm[1]);
             h = fmaxf(h, __shfl_xor(h, 16));
@@ -313,230 +324,202 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------
-// selection helpers
+// selection: iterative block arg-max (score descending, id ascending)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned f32_key(float x) {   // monotone: larger float -> larger key
-    unsigned u = __float_as_uint(x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-// true if candidate (sa, ia) sorts before (sb, ib): score descending, id ascending.
+// true if candidate (sa, ia) sorts before (sb, ib)
 __device__ __forceinline__ bool before(float sa, long long ia, float sb, long long ib) {
     return (sa > sb) || (sa == sb && ia < ib);
 }
 
-// Workgroup (256 threads) radix select: writes into sel[0..kt) the indices of
-// the kt largest of vals[0..m) (ties at the threshold -> lower index first).
-// The result SET is deterministic; its order is (greater-than part in index
-// order, then threshold ties in index order).  Requires 1 <= kt <= m.
-__device__ void wg_select_topk_indices(const float* __restrict__ vals, int m, int kt, int* sel,
-                                       unsigned* hist /*[256]*/, int* scratch /*[16]*/) {
-    const int tid = threadIdx.x;
-    unsigned prefix = 0, mask = 0;
-    int remaining = kt;
-    for (int pass = 3; pass >= 0; --pass) {
-        const int sh = pass * 8;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        for (int e = tid; e < m; e += blockDim.x) {
-            const unsigned k = f32_key(vals[e]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> sh) & 255u], 1u);
+constexpr int FIN_THREADS = 512;            // finish / merge workgroup
+constexpr long long ID_NONE = 0x7fffffffffffffffll;
+
+// Workgroup selection of the `k` best of m candidates held in LDS (val[e], and an id given by
+// idf(e); candidates with val == -inf are empty).  Result, in order, in out_e[0..k) (element
+// index, or -1 when fewer than k candidates exist).  Thread `tid` owns elements tid, tid+T, ...
+// and caches its best one; an iteration is one wave reduction + one barrier + the winner's
+// rescan of its own elements, so the cost is k * O(m/T + log T), independent of ties.
+template <typename IdF>
+__device__ void block_topk(float* val, int m, int k, IdF idf, int* out_e, float* red_v, long long* red_i,
+                           int* red_e) {
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
+    float bv = -INFINITY;
+    long long bi = ID_NONE;
+    int be = -1;
+    auto rescan = [&]() {
+        bv = -INFINITY; bi = ID_NONE; be = -1;
+        for (int e = tid; e < m; e += T) {
+            const float v = val[e];
+            if (v == -INFINITY) continue;
+            const long long id = idf(e);
+            if (be < 0 || before(v, id, bv, bi)) { bv = v; bi = id; be = e; }
         }
-        __syncthreads();
-        if (tid == 0) {
-            int cum = 0, b = 255;
-            for (; b > 0; --b) {
-                const int h = (int)hist[b];
-                if (cum + h >= remaining) break;
-                cum += h;
-            }
-            scratch[0] = b;
-            scratch[1] = remaining - cum;
+    };
+    rescan();
+    for (int it = 0; it < k; ++it) {
+        float v = bv; long long i = bi; int e = be;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(v, o);
+            const long long i2 = __shfl_xor(i, o);
+            const int e2 = __shfl_xor(e, o);
+            if (e2 >= 0 && (e < 0 || before(v2, i2, v, i))) { v = v2; i = i2; e = e2; }
         }
+        const int slot = (it & 1) * 16;
+        if (lane == 0) { red_v[slot + w] = v; red_i[slot + w] = i; red_e[slot + w] = e; }
         __syncthreads();
-        prefix |= ((unsigned)scratch[0]) << sh;
-        mask |= 255u << sh;
-        remaining = scratch[1];
-        __syncthreads();
+        v = red_v[slot]; i = red_i[slot]; e = red_e[slot];
+        for (int ww = 1; ww < nw; ++ww) {
+            const float v2 = red_v[slot + ww];
+            const long long i2 = red_i[slot + ww];
+            const int e2 = red_e[slot + ww];
+            if (e2 >= 0 && (e < 0 || before(v2, i2, v, i))) { v = v2; i = i2; e = e2; }
+        }
+        if (tid == 0) out_e[it] = e;
+        if (e >= 0 && (e % T) == tid) {          // the owner retires the winner and finds its next best
+            val[e] = -INFINITY;
+            rescan();
+        }
     }
-    const unsigned T = prefix;          // key of the kt-th largest value
-    const int n_gt = kt - remaining;    // values strictly above T
-    // ordered compaction, 256 elements per step
-    const int lane = tid & 63, w = tid >> 6;
-    int* wsum = scratch + 2;            // [4 waves][2]
-    int base_gt = 0, base_eq = 0;
-    for (int e0 = 0; e0 < m; e0 += 256) {
-        const int e = e0 + tid;
-        unsigned k = 0;
-        bool gt = false, eq = false;
-        if (e < m) {
-            k = f32_key(vals[e]);
-            gt = k > T;
-            eq = k == T;
-        }
-        const unsigned long long bg = __ballot(gt), be = __ballot(eq);
-        const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const int pg = __popcll(bg & lower), pe = __popcll(be & lower);
-        if (lane == 0) { wsum[w * 2] = __popcll(bg); wsum[w * 2 + 1] = __popcll(be); }
-        __syncthreads();
-        int og = base_gt, oe = base_eq, tg = 0, te = 0;
-        for (int ww = 0; ww < 4; ++ww) {
-            if (ww < w) { og += wsum[ww * 2]; oe += wsum[ww * 2 + 1]; }
-            tg += wsum[ww * 2];
-            te += wsum[ww * 2 + 1];
-        }
-        if (gt) sel[og + pg] = e;
-        if (eq && (oe + pe) < remaining) sel[n_gt + oe + pe] = e;
-        base_gt += tg;
-        base_eq += te;
-        __syncthreads();
-    }
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void select_groups_kernel(const float* __restrict__ tmax, long long ldt,
-                                                            int nh, const float* __restrict__ gmax,
-                                                            long long ldg, long long ng, int kg,
-                                                            int* __restrict__ glist /*[q, kg]*/) {
-    __shared__ unsigned hist[256];
-    __shared__ int scratch[16];
-    __shared__ int s_tiles[MAX_KG];
-    __shared__ float cv[MAX_KG * 8];
-    __shared__ int cid[MAX_KG * 8];
-    const int qi = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int kt = min(kg, nh);
-    wg_select_topk_indices(tmax + (long long)qi * ldt, nh, kt, s_tiles, hist, scratch);
-    __syncthreads();
-    const int m2 = kt * 8;
-    for (int e = tid; e < m2; e += blockDim.x) {
-        const long long g = (long long)s_tiles[e >> 3] * 8 + (e & 7);
-        const bool ok = g < ng;
-        cv[e] = ok ? gmax[(long long)qi * ldg + g] : -INFINITY;
-        cid[e] = ok ? (int)g : 0x7fffffff;
-    }
-    __syncthreads();
-    for (int e = tid; e < kg; e += blockDim.x) glist[(long long)qi * kg + e] = -1;
-    __syncthreads();
-    for (int e = tid; e < m2; e += blockDim.x) {
-        const float s = cv[e];
-        const int id = cid[e];
-        if (id == 0x7fffffff) continue;
-        int rank = 0;
-        for (int j = 0; j < m2; ++j) rank += before(cv[j], cid[j], s, id) ? 1 : 0;
-        if (rank < kg) glist[(long long)qi * kg + rank] = id;
-    }
-}
-
-// One wave per (query, selected group): 16 exact fp32 dot products.
+// One workgroup per query: half-tile selection -> group selection -> exact fp32 re-score of
+// the selected groups' rows -> final top-k.
 template <typename Tag>
-__global__ __launch_bounds__(256) void rescore_kernel(const char* __restrict__ Q, long long ldq_b,
-                                                      const char* __restrict__ DB, long long lddb_b,
-                                                      long long n, int d, const int* __restrict__ glist, int kg,
-                                                      float* __restrict__ cand /*[q, kg*16]*/) {
-    const int qi = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= kg) return;
-    const int g = glist[(long long)qi * kg + s];
-    float* out = cand + ((long long)qi * kg + s) * GROUP;
-    if (g < 0) {
-        if (lane < GROUP) out[lane] = -INFINITY;
-        return;
+__global__ __launch_bounds__(FIN_THREADS) void finish_topk_kernel(
+    float* __restrict__ tmax, long long ldt, int nh, int tv_in_lds, const float* __restrict__ gmax, long long ldg,
+    long long ng, int kg, const char* __restrict__ Q, long long ldq_b, const char* __restrict__ DB, long long lddb_b, long long n,
+    int d, int k, long long row_offset, float* __restrict__ out_s, long long* __restrict__ out_i) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    __shared__ float red_v[32];
+    __shared__ long long red_i[32];
+    __shared__ int red_e[32];
+    __shared__ int sel[MAX_KG];               // selected half tiles, then selected groups
+    __shared__ int sel2[MAX_KG];
+    __shared__ float cval[MAX_KG * GROUPS_PER_HALF];   // level-2 candidates / re-scored rows
+    constexpr int GPH = GROUPS_PER_HALF;
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // [nh] half-tile maxima of this query: staged in LDS, or (very large shards) consumed in
+    // place in the workspace row, which the next GEMM rewrites anyway
+    float* tv = tv_in_lds ? (float*)dsm : tmax + (long long)qi * ldt;
+
+    // ---- level 1: the kt half tiles with the largest maximum (ties -> lower tile)
+    if (tv_in_lds)
+        for (int e = tid; e < nh; e += FIN_THREADS) tv[e] = tmax[(long long)qi * ldt + e];
+    __syncthreads();
+    const int kt = min(kg, nh);
+    block_topk(tv, nh, kt, [](int e) { return (long long)e; }, sel, red_v, red_i, red_e);
+
+    // ---- level 2: among their groups, the kg2 groups with the largest maximum
+    const int m2 = kt * GPH;
+    for (int e = tid; e < m2; e += FIN_THREADS) {
+        const long long g = (long long)sel[e / GPH] * GPH + (e % GPH);
+        cval[e] = (g < ng) ? gmax[(long long)qi * ldg + g] : -INFINITY;
     }
-    const long long row0 = (long long)g * GROUP;
+    __syncthreads();
+    const int kg2 = min(kg, m2);
+    block_topk(cval, m2, kg2, [&](int e) { return (long long)sel[e / GPH] * GPH + (e % GPH); }, sel2, red_v, red_i,
+               red_e);
+    // group ids of the winners (sel2 holds candidate slots); -1 = none
+    if (tid < kg2) {
+        const int e = sel2[tid];
+        sel2[tid] = e < 0 ? -1 : (int)((long long)sel[e / GPH] * GPH + (e % GPH));
+    }
+    __syncthreads();
+
+    // ---- re-score: wave w takes groups w, w+8, ...; GROUP exact fp32 dot products each
     const char* qrow = Q + (long long)qi * ldq_b;
-    const char* rows[GROUP];
+    for (int s = w; s < kg2; s += FIN_THREADS / 64) {
+        const int g = sel2[s];
+        if (g < 0) {
+            if (lane < GROUP) cval[s * GROUP + lane] = -INFINITY;
+            continue;
+        }
+        const long long row0 = (long long)g * GROUP;
+        const char* rows[GROUP];
 #pragma unroll
-    for (int r = 0; r < GROUP; ++r) {
-        long long rr = row0 + r;
-        if (rr > n - 1) rr = n - 1;
-        rows[r] = DB + rr * lddb_b;
-    }
-    float acc[GROUP];
+        for (int r = 0; r < GROUP; ++r) {
+            long long rr = row0 + r;
+            if (rr > n - 1) rr = n - 1;
+            rows[r] = DB + rr * lddb_b;
+        }
+        float acc[GROUP];
 #pragma unroll
-    for (int r = 0; r < GROUP; ++r) acc[r] = 0.f;
-    for (int d0 = lane * 8; d0 < d; d0 += 512) {
-        const uint4 qv = *(const uint4*)(qrow + (long long)d0 * 2);
-        uint4 rv[GROUP];
+        for (int r = 0; r < GROUP; ++r) acc[r] = 0.f;
+        for (int d0 = lane * 8; d0 < d; d0 += 512) {
+            const uint4 qv = *(const uint4*)(qrow + (long long)d0 * 2);
+            uint4 rv[GROUP];
 #pragma unroll
-        for (int r = 0; r < GROUP; ++r) rv[r] = *(const uint4*)(rows[r] + (long long)d0 * 2);
-        const unsigned qw[4] = {qv.x, qv.y, qv.z, qv.w};
-        float qf[8];
+            for (int r = 0; r < GROUP; ++r) rv[r] = *(const uint4*)(rows[r] + (long long)d0 * 2);
+            const unsigned qw[4] = {qv.x, qv.y, qv.z, qv.w};
+            float qf[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            qf[2 * e] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu));
-            qf[2 * e + 1] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16));
+            for (int e = 0; e < 4; ++e) {
+                qf[2 * e] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu));
+                qf[2 * e + 1] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16));
+            }
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r) {
+                const unsigned w4[4] = {rv[r].x, rv[r].y, rv[r].z, rv[r].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[r] = fmaf(qf[2 * e], Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc[r]);
+                    acc[r] = fmaf(qf[2 * e + 1], Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc[r]);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < GROUP; ++r) {
-            const unsigned w4[4] = {rv[r].x, rv[r].y, rv[r].z, rv[r].w};
+            float v = acc[r];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[r] = fmaf(qf[2 * e], Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc[r]);
-                acc[r] = fmaf(qf[2 * e + 1], Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc[r]);
-            }
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == r) cval[s * GROUP + r] = (row0 + r < n) ? v : -INFINITY;
         }
     }
-#pragma unroll
-    for (int r = 0; r < GROUP; ++r) {
-        float v = acc[r];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        acc[r] = v;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < GROUP; ++r) out[r] = (row0 + r < n) ? acc[r] : -INFINITY;
+    __syncthreads();
+
+    // ---- final top-k of the kg2*GROUP re-scored rows (id = database row)
+    const int m3 = kg2 * GROUP;
+    tv = (float*)dsm;
+    for (int e = tid; e < m3; e += FIN_THREADS) tv[e] = cval[e];     // keep the scores: block_topk retires them
+    __syncthreads();
+    block_topk(cval, m3, min(k, m3), [&](int e) { return (long long)sel2[e / GROUP] * GROUP + (e % GROUP); }, sel,
+               red_v, red_i, red_e);
+    for (int e = tid; e < k; e += FIN_THREADS) {
+        const int c = e < min(k, m3) ? sel[e] : -1;
+        out_s[(long long)qi * k + e] = c < 0 ? -INFINITY : tv[c];
+        out_i[(long long)qi * k + e] = c < 0 ? -1 : (long long)sel2[c / GROUP] * GROUP + (c % GROUP) + row_offset;
     }
 }
 
-// Top-k of m candidates per query (rank by counting, m <= a few thousand).
-// mode 0: candidates are cand[q, kg*16] with id = glist[q, e/16]*16 + e%16
-// mode 1: candidates are scores/idx [parts, q, k] (all-gather layout), idx < 0 = empty
-__global__ __launch_bounds__(256) void final_topk_kernel(int mode, const float* __restrict__ cand,
-                                                         const int* __restrict__ glist, int kg,
-                                                         const float* __restrict__ pscores,
-                                                         const long long* __restrict__ pidx, int parts,
-                                                         long long nq, int k, long long row_offset,
-                                                         float* __restrict__ out_s, long long* __restrict__ out_i) {
+// Global top-k from [parts, q, k] per-shard results (the all-gather layout); idx < 0 = empty slot.
+__global__ __launch_bounds__(FIN_THREADS) void merge_topk_kernel(const float* __restrict__ pscores,
+                                                                 const long long* __restrict__ pidx, int parts,
+                                                                 long long nq, int k, float* __restrict__ out_s,
+                                                                 long long* __restrict__ out_i) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    const int qi = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int m = mode == 0 ? kg * GROUP : parts * k;
+    __shared__ float red_v[32];
+    __shared__ long long red_i[32];
+    __shared__ int red_e[32];
+    __shared__ int sel[DLC_MAX_K];
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    const int m = parts * k;
     float* cs = (float*)dsm;
-    long long* ci = (long long*)(dsm + dlc::align_up((size_t)m * 4, 16));
-    for (int e = tid; e < m; e += blockDim.x) {
-        float s;
-        long long id;
-        if (mode == 0) {
-            const int g = glist[(long long)qi * kg + (e >> 4)];
-            s = cand[(long long)qi * kg * GROUP + e];
-            id = (g < 0 || s == -INFINITY) ? 0x7fffffffffffffffll : (long long)g * GROUP + (e & 15) + row_offset;
-            if (g < 0) s = -INFINITY;
-        } else {
-            const long long o = ((long long)(e / k) * nq + qi) * k + (e % k);
-            id = pidx[o];
-            s = pscores[o];
-            if (id < 0) { id = 0x7fffffffffffffffll; s = -INFINITY; }
-        }
-        cs[e] = s;
-        ci[e] = id;
-    }
-    for (int e = tid; e < k; e += blockDim.x) {
-        out_s[(long long)qi * k + e] = -INFINITY;
-        out_i[(long long)qi * k + e] = -1;
+    float* keep = cs + m;
+    long long* ci = (long long*)(dsm + dlc::align_up((size_t)m * 8, 16));
+    for (int e = tid; e < m; e += FIN_THREADS) {
+        const long long o = ((long long)(e / k) * nq + qi) * k + (e % k);
+        const long long id = pidx[o];
+        const float s = id < 0 ? -INFINITY : pscores[o];
+        cs[e] = s; keep[e] = s; ci[e] = id;
     }
     __syncthreads();
-    for (int e = tid; e < m; e += blockDim.x) {
-        const float s = cs[e];
-        const long long id = ci[e];
-        if (id == 0x7fffffffffffffffll) continue;
-        int rank = 0;
-        for (int j = 0; j < m; ++j) rank += before(cs[j], ci[j], s, id) ? 1 : 0;
-        if (rank < k) {
-            out_s[(long long)qi * k + rank] = s;
-            out_i[(long long)qi * k + rank] = id;
-        }
+    block_topk(cs, m, min(k, m), [&](int e) { return ci[e]; }, sel, red_v, red_i, red_e);
+    for (int e = tid; e < k; e += FIN_THREADS) {
+        const int c = e < min(k, m) ? sel[e] : -1;
+        out_s[(long long)qi * k + e] = c < 0 ? -INFINITY : keep[c];
+        out_i[(long long)qi * k + e] = c < 0 ? -1 : ci[c];
     }
 }
 
@@ -584,7 +567,7 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const Src* __restrict
 }
 
 struct WsLayout {
-    size_t gmax, tmax, glist, cand, total;
+    size_t gmax, tmax, total;
     long long ldg, ldt;
     int kg;
 };
@@ -598,8 +581,6 @@ WsLayout ws_layout(int64_t q, int64_t n, int k) {
     size_t o = 0;
     w.gmax = o; o += dlc::align_up((size_t)q * w.ldg * 4, 256);
     w.tmax = o; o += dlc::align_up((size_t)q * w.ldt * 4, 256);
-    w.glist = o; o += dlc::align_up((size_t)q * w.kg * 4, 256);
-    w.cand = o; o += dlc::align_up((size_t)q * w.kg * GROUP * 4, 256);
     w.total = o;
     return w;
 }
@@ -676,25 +657,20 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
         ctx->prof_calls++;
     }
 
-    int* glist = (int*)(ws + w.glist);
-    float* cand = (float*)(ws + w.cand);
-    hipLaunchKernelGGL(select_groups_kernel, dim3((unsigned)q), dim3(256), 0, st, a.tmax, a.ldt, (int)a.nh, a.gmax,
-                       a.ldg, a.ng, w.kg, glist);
-    DLC_LAUNCH_CHECK(ctx, "select_groups_kernel");
-    dim3 rgrid((unsigned)dlc::cdiv(w.kg, 4), (unsigned)q);
-    if (dtype == DLC_BF16)
-        hipLaunchKernelGGL(rescore_kernel<dlc_bf16_tag>, rgrid, dim3(256), 0, st, a.Q, a.ldq_b, a.DB, a.lddb_b, n, (int)d,
-                           glist, w.kg, cand);
-    else
-        hipLaunchKernelGGL(rescore_kernel<dlc_f16_tag>, rgrid, dim3(256), 0, st, a.Q, a.ldq_b, a.DB, a.lddb_b, n, (int)d,
-                           glist, w.kg, cand);
-    DLC_LAUNCH_CHECK(ctx, "rescore_kernel");
-    const int m = w.kg * GROUP;
-    const size_t dsm = dlc::align_up((size_t)m * 4, 16) + (size_t)m * 8;
-    hipLaunchKernelGGL(final_topk_kernel, dim3((unsigned)q), dim3(256), dsm, st, 0, cand, glist, w.kg,
-                       (const float*)nullptr, (const long long*)nullptr, 0, (long long)q, k, (long long)row_offset,
-                       out_scores, (long long*)out_idx);
-    DLC_LAUNCH_CHECK(ctx, "final_topk_kernel");
+    // LDS for the half-tile maxima (reused for the re-scored rows)
+    size_t dsm = (size_t)w.kg * GROUP * 4;
+    const int tv_in_lds = (size_t)a.nh * 4 <= 96 * 1024;
+    if (tv_in_lds && dsm < (size_t)a.nh * 4) dsm = (size_t)a.nh * 4;
+    dsm = dlc::align_up(dsm, 16);
+    {
+        auto fk = (dtype == DLC_BF16) ? finish_topk_kernel<dlc_bf16_tag> : finish_topk_kernel<dlc_f16_tag>;
+        if (dsm > 48 * 1024)
+            DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm));
+        hipLaunchKernelGGL(fk, dim3((unsigned)q), dim3(FIN_THREADS), dsm, st, a.tmax, a.ldt, (int)a.nh, tv_in_lds, a.gmax, a.ldg, a.ng,
+                           w.kg, a.Q, a.ldq_b, a.DB, a.lddb_b, (long long)n, (int)d, k, (long long)row_offset, out_scores,
+                           (long long*)out_idx);
+    }
+    DLC_LAUNCH_CHECK(ctx, "finish_topk_kernel");
     return DLC_OK;
 }
 
@@ -704,14 +680,13 @@ extern "C" int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* 
     if (!scores || !idx || !out_scores || !out_idx || parts < 1 || q < 1 || k < 1 || k > DLC_MAX_K)
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "topk_merge: bad argument");
     const size_t m = (size_t)parts * k;
-    const size_t dsm = dlc::align_up(m * 4, 16) + m * 8;
-    if (dsm > 60000) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "topk_merge: parts*k=%zu too large", m);
+    const size_t dsm = dlc::align_up(m * 8, 16) + m * 8;
+    if (dsm > 48 * 1024) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "topk_merge: parts*k=%zu too large", m);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    hipLaunchKernelGGL(final_topk_kernel, dim3((unsigned)q), dim3(256), dsm, (hipStream_t)stream, 1,
-                       (const float*)nullptr, (const int*)nullptr, 0, scores, (const long long*)idx, parts,
-                       (long long)q, k, 0ll, out_scores, (long long*)out_idx);
-    DLC_LAUNCH_CHECK(ctx, "final_topk_kernel(merge)");
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)q), dim3(FIN_THREADS), dsm, (hipStream_t)stream, scores,
+                       (const long long*)idx, parts, (long long)q, k, out_scores, (long long*)out_idx);
+    DLC_LAUNCH_CHECK(ctx, "merge_topk_kernel");
     return DLC_OK;
 }
 
