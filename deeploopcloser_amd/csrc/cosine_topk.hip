@@ -324,64 +324,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------
-// selection: iterative block arg-max (score descending, id ascending)
+// selection on packed 64-bit keys: (monotone score key << 32) | ~id32, so "larger key" ==
+// "higher score, then lower id".  key 0 = empty.
 // ---------------------------------------------------------------------------
-// true if candidate (sa, ia) sorts before (sb, ib)
-__device__ __forceinline__ bool before(float sa, long long ia, float sb, long long ib) {
-    return (sa > sb) || (sa == sb && ia < ib);
+__device__ __forceinline__ unsigned f32_key(float x) {   // monotone: larger float -> larger key
+    unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long pack_key(float score, unsigned id) {
+    return ((unsigned long long)f32_key(score) << 32) | (unsigned long long)(~id);
+}
+__device__ __forceinline__ unsigned key_id(unsigned long long key) { return ~(unsigned)key; }
+
+// wave-wide unsigned max through DPP (row_shr 1,2,4,8 + row_bcast 15 / 31), result in every lane
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define DLC_DPP_MAX(ctrl, rmask) \
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false))
+    DLC_DPP_MAX(0x111, 0xf);
+    DLC_DPP_MAX(0x112, 0xf);
+    DLC_DPP_MAX(0x114, 0xf);
+    DLC_DPP_MAX(0x118, 0xf);
+    DLC_DPP_MAX(0x142, 0xa);
+    DLC_DPP_MAX(0x143, 0xc);
+#undef DLC_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 constexpr int FIN_THREADS = 512;            // finish / merge workgroup
-constexpr long long ID_NONE = 0x7fffffffffffffffll;
+constexpr int FIN_WAVES = FIN_THREADS / 64;
+constexpr int MAX_CAND = MAX_KG * GROUPS_PER_HALF;   // >= FIN_WAVES * MAX_KG and >= MAX_KG * GROUP
 
-// Workgroup selection of the `k` best of m candidates held in LDS (val[e], and an id given by
-// idf(e); candidates with val == -inf are empty).  Result, in order, in out_e[0..k) (element
-// index, or -1 when fewer than k candidates exist).  Thread `tid` owns elements tid, tid+T, ...
-// and caches its best one; an iteration is one wave reduction + one barrier + the winner's
-// rescan of its own elements, so the cost is k * O(m/T + log T), independent of ties.
-template <typename IdF>
-__device__ void block_topk(float* val, int m, int k, IdF idf, int* out_e, float* red_v, long long* red_i,
-                           int* red_e) {
-    const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, w = tid >> 6, nw = T >> 6;
-    float bv = -INFINITY;
-    long long bi = ID_NONE;
-    int be = -1;
-    auto rescan = [&]() {
-        bv = -INFINITY; bi = ID_NONE; be = -1;
-        for (int e = tid; e < m; e += T) {
-            const float v = val[e];
-            if (v == -INFINITY) continue;
-            const long long id = idf(e);
-            if (be < 0 || before(v, id, bv, bi)) { bv = v; bi = id; be = e; }
-        }
-    };
-    rescan();
-    for (int it = 0; it < k; ++it) {
-        float v = bv; long long i = bi; int e = be;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float v2 = __shfl_xor(v, o);
-            const long long i2 = __shfl_xor(i, o);
-            const int e2 = __shfl_xor(e, o);
-            if (e2 >= 0 && (e < 0 || before(v2, i2, v, i))) { v = v2; i = i2; e = e2; }
-        }
-        const int slot = (it & 1) * 16;
-        if (lane == 0) { red_v[slot + w] = v; red_i[slot + w] = i; red_e[slot + w] = e; }
-        __syncthreads();
-        v = red_v[slot]; i = red_i[slot]; e = red_e[slot];
-        for (int ww = 1; ww < nw; ++ww) {
-            const float v2 = red_v[slot + ww];
-            const long long i2 = red_i[slot + ww];
-            const int e2 = red_e[slot + ww];
-            if (e2 >= 0 && (e < 0 || before(v2, i2, v, i))) { v = v2; i = i2; e = e2; }
-        }
-        if (tid == 0) out_e[it] = e;
-        if (e >= 0 && (e % T) == tid) {          // the owner retires the winner and finds its next best
-            val[e] = -INFINITY;
-            rescan();
-        }
+// Rank-by-counting on unique keys in LDS: out[rank] = element index, for rank < k.
+// Every thread walks the keys in the same order (LDS broadcast reads).
+__device__ __forceinline__ void rank_select(const unsigned long long* keys, int m, int k, int* out) {
+    for (int e = threadIdx.x; e < m; e += blockDim.x) {
+        const unsigned long long ke = keys[e];
+        if (ke == 0ull) continue;
+        int rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < m; ++j) rank += keys[j] > ke ? 1 : 0;
+        if (rank < k) out[rank] = e;
     }
-    __syncthreads();
 }
 
 // One workgroup per query: half-tile selection -> group selection -> exact fp32 re-score of
@@ -389,48 +372,74 @@ __device__ void block_topk(float* val, int m, int k, IdF idf, int* out_e, float*
 template <typename Tag>
 __global__ __launch_bounds__(FIN_THREADS) void finish_topk_kernel(
     float* __restrict__ tmax, long long ldt, int nh, int tv_in_lds, const float* __restrict__ gmax, long long ldg,
-    long long ng, int kg, const char* __restrict__ Q, long long ldq_b, const char* __restrict__ DB, long long lddb_b, long long n,
-    int d, int k, long long row_offset, float* __restrict__ out_s, long long* __restrict__ out_i) {
+    long long ng, int kg, const char* __restrict__ Q, long long ldq_b, const char* __restrict__ DB, long long lddb_b,
+    long long n, int d, int k, long long row_offset, float* __restrict__ out_s, long long* __restrict__ out_i) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    __shared__ float red_v[32];
-    __shared__ long long red_i[32];
-    __shared__ int red_e[32];
-    __shared__ int sel[MAX_KG];               // selected half tiles, then selected groups
-    __shared__ int sel2[MAX_KG];
-    __shared__ float cval[MAX_KG * GROUPS_PER_HALF];   // level-2 candidates / re-scored rows
+    __shared__ unsigned long long ckey[MAX_CAND];
+    __shared__ int sel[MAX_KG];               // selected half tiles; later the final winners
+    __shared__ int sel2[MAX_KG];              // selected groups
+    __shared__ float cval[MAX_KG * GROUP];    // re-scored rows
     constexpr int GPH = GROUPS_PER_HALF;
     const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // [nh] half-tile maxima of this query: staged in LDS, or (very large shards) consumed in
     // place in the workspace row, which the next GEMM rewrites anyway
     float* tv = tv_in_lds ? (float*)dsm : tmax + (long long)qi * ldt;
-
-    // ---- level 1: the kt half tiles with the largest maximum (ties -> lower tile)
     if (tv_in_lds)
         for (int e = tid; e < nh; e += FIN_THREADS) tv[e] = tmax[(long long)qi * ldt + e];
+    for (int e = tid; e < MAX_KG; e += FIN_THREADS) { sel[e] = -1; sel2[e] = -1; }
     __syncthreads();
+
+    // ---- level 1: the kt half tiles with the largest maximum (ties -> lower tile).
+    // Each wave extracts the kt best of its slice by repeated wave arg-max (DPP, no barrier);
+    // the FIN_WAVES * kt survivors are ranked together.
     const int kt = min(kg, nh);
-    block_topk(tv, nh, kt, [](int e) { return (long long)e; }, sel, red_v, red_i, red_e);
+    {
+        const int chunk = (nh + FIN_WAVES - 1) / FIN_WAVES;
+        const int lo_e = w * chunk, hi_e = min(nh, lo_e + chunk);
+        unsigned bh = 0, bl = 0;               // this lane's best key (hi, lo); 0,0 = none
+        auto rescan = [&]() {
+            bh = 0; bl = 0;
+            for (int e = lo_e + lane; e < hi_e; e += 64) {
+                const float v = tv[e];
+                if (v == -INFINITY) continue;
+                const unsigned h = f32_key(v), l = ~(unsigned)e;
+                if (h > bh || (h == bh && l > bl)) { bh = h; bl = l; }
+            }
+        };
+        rescan();
+        for (int it = 0; it < kt; ++it) {
+            const unsigned mh = wave_max_u32(bh);
+            const unsigned ml = wave_max_u32(bh == mh ? bl : 0u);
+            if (lane == 0) ckey[w * kt + it] = mh == 0u ? 0ull : (((unsigned long long)mh << 32) | ml);
+            if (mh != 0u && bh == mh && bl == ml) {      // the owner retires it and finds its next best
+                tv[~ml] = -INFINITY;
+                rescan();
+            }
+        }
+    }
+    __syncthreads();
+    rank_select(ckey, FIN_WAVES * kt, kt, sel);          // sel[rank] = slot in ckey
+    __syncthreads();
+    if (tid < kt) { const int c = sel[tid]; sel[tid] = c < 0 ? -1 : (int)key_id(ckey[c]); }   // -> half-tile index
+    __syncthreads();
 
     // ---- level 2: among their groups, the kg2 groups with the largest maximum
     const int m2 = kt * GPH;
     for (int e = tid; e < m2; e += FIN_THREADS) {
-        const long long g = (long long)sel[e / GPH] * GPH + (e % GPH);
-        cval[e] = (g < ng) ? gmax[(long long)qi * ldg + g] : -INFINITY;
+        const int ht = sel[e / GPH];
+        const long long g = (long long)ht * GPH + (e % GPH);
+        ckey[e] = (ht >= 0 && g < ng) ? pack_key(gmax[(long long)qi * ldg + g], (unsigned)g) : 0ull;
     }
     __syncthreads();
     const int kg2 = min(kg, m2);
-    block_topk(cval, m2, kg2, [&](int e) { return (long long)sel[e / GPH] * GPH + (e % GPH); }, sel2, red_v, red_i,
-               red_e);
-    // group ids of the winners (sel2 holds candidate slots); -1 = none
-    if (tid < kg2) {
-        const int e = sel2[tid];
-        sel2[tid] = e < 0 ? -1 : (int)((long long)sel[e / GPH] * GPH + (e % GPH));
-    }
+    rank_select(ckey, m2, kg2, sel2);
+    __syncthreads();
+    if (tid < kg2) { const int c = sel2[tid]; sel2[tid] = c < 0 ? -1 : (int)key_id(ckey[c]); }   // -> group index
     __syncthreads();
 
     // ---- re-score: wave w takes groups w, w+8, ...; GROUP exact fp32 dot products each
     const char* qrow = Q + (long long)qi * ldq_b;
-    for (int s = w; s < kg2; s += FIN_THREADS / 64) {
+    for (int s = w; s < kg2; s += FIN_WAVES) {
         const int g = sel2[s];
         if (g < 0) {
             if (lane < GROUP) cval[s * GROUP + lane] = -INFINITY;
@@ -477,49 +486,70 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_topk_kernel(
             if (lane == r) cval[s * GROUP + r] = (row0 + r < n) ? v : -INFINITY;
         }
     }
+    for (int e = tid; e < k; e += FIN_THREADS) {          // defaults for slots past the candidates
+        out_s[(long long)qi * k + e] = -INFINITY;
+        out_i[(long long)qi * k + e] = -1;
+        if (e < MAX_KG) sel[e] = -1;
+    }
     __syncthreads();
 
-    // ---- final top-k of the kg2*GROUP re-scored rows (id = database row)
+    // ---- final top-k of the kg2*GROUP re-scored rows (id = database row inside the shard)
     const int m3 = kg2 * GROUP;
-    tv = (float*)dsm;
-    for (int e = tid; e < m3; e += FIN_THREADS) tv[e] = cval[e];     // keep the scores: block_topk retires them
+    for (int e = tid; e < m3; e += FIN_THREADS) {
+        const float v = cval[e];
+        const int g = sel2[e / GROUP];
+        ckey[e] = (g < 0 || v == -INFINITY) ? 0ull : pack_key(v, (unsigned)((long long)g * GROUP + (e % GROUP)));
+    }
     __syncthreads();
-    block_topk(cval, m3, min(k, m3), [&](int e) { return (long long)sel2[e / GROUP] * GROUP + (e % GROUP); }, sel,
-               red_v, red_i, red_e);
+    rank_select(ckey, m3, k, sel);
+    __syncthreads();
     for (int e = tid; e < k; e += FIN_THREADS) {
-        const int c = e < min(k, m3) ? sel[e] : -1;
-        out_s[(long long)qi * k + e] = c < 0 ? -INFINITY : tv[c];
-        out_i[(long long)qi * k + e] = c < 0 ? -1 : (long long)sel2[c / GROUP] * GROUP + (c % GROUP) + row_offset;
+        const int c = sel[e];
+        if (c >= 0) {
+            out_s[(long long)qi * k + e] = cval[c];
+            out_i[(long long)qi * k + e] = (long long)key_id(ckey[c]) + row_offset;
+        }
     }
 }
 
 // Global top-k from [parts, q, k] per-shard results (the all-gather layout); idx < 0 = empty slot.
+// Rank-by-counting on (score key, id): ids are unique, so the order is total.
 __global__ __launch_bounds__(FIN_THREADS) void merge_topk_kernel(const float* __restrict__ pscores,
                                                                  const long long* __restrict__ pidx, int parts,
                                                                  long long nq, int k, float* __restrict__ out_s,
                                                                  long long* __restrict__ out_i) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    __shared__ float red_v[32];
-    __shared__ long long red_i[32];
-    __shared__ int red_e[32];
-    __shared__ int sel[DLC_MAX_K];
     const int qi = blockIdx.x, tid = threadIdx.x;
     const int m = parts * k;
-    float* cs = (float*)dsm;
-    float* keep = cs + m;
-    long long* ci = (long long*)(dsm + dlc::align_up((size_t)m * 8, 16));
+    long long* ci = (long long*)dsm;
+    unsigned* sk = (unsigned*)(dsm + (size_t)m * 8);
+    float* cs = (float*)(dsm + (size_t)m * 12);
     for (int e = tid; e < m; e += FIN_THREADS) {
         const long long o = ((long long)(e / k) * nq + qi) * k + (e % k);
         const long long id = pidx[o];
-        const float s = id < 0 ? -INFINITY : pscores[o];
-        cs[e] = s; keep[e] = s; ci[e] = id;
+        const float s = pscores[o];
+        ci[e] = id; cs[e] = s;
+        sk[e] = id < 0 ? 0u : f32_key(s);
+    }
+    for (int e = tid; e < k; e += FIN_THREADS) {
+        out_s[(long long)qi * k + e] = -INFINITY;
+        out_i[(long long)qi * k + e] = -1;
     }
     __syncthreads();
-    block_topk(cs, m, min(k, m), [&](int e) { return ci[e]; }, sel, red_v, red_i, red_e);
-    for (int e = tid; e < k; e += FIN_THREADS) {
-        const int c = e < min(k, m) ? sel[e] : -1;
-        out_s[(long long)qi * k + e] = c < 0 ? -INFINITY : keep[c];
-        out_i[(long long)qi * k + e] = c < 0 ? -1 : ci[c];
+    for (int e = tid; e < m; e += FIN_THREADS) {
+        const unsigned se = sk[e];
+        const long long ie = ci[e];
+        if (ie < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < m; ++j) {
+            const unsigned sj = sk[j];
+            const long long ij = ci[j];
+            rank += (ij >= 0 && (sj > se || (sj == se && ij < ie))) ? 1 : 0;
+        }
+        if (rank < k) {
+            out_s[(long long)qi * k + rank] = cs[e];
+            out_i[(long long)qi * k + rank] = ie;
+        }
     }
 }
 
@@ -597,7 +627,7 @@ int check_operands(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ld
     if (((uintptr_t)Q & 15) || ((uintptr_t)DB & 15))
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine match: operands must be 16-byte aligned");
     if (q > 0x7fffff00ll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: q too large");
-    if (n / GROUP > 0x7ffffff0ll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: n too large for one shard");
+    if (n > 0x7ffffff0ll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: more than 2^31 rows in one shard");
     return DLC_OK;
 }
 
@@ -680,7 +710,7 @@ extern "C" int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* 
     if (!scores || !idx || !out_scores || !out_idx || parts < 1 || q < 1 || k < 1 || k > DLC_MAX_K)
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "topk_merge: bad argument");
     const size_t m = (size_t)parts * k;
-    const size_t dsm = dlc::align_up(m * 8, 16) + m * 8;
+    const size_t dsm = m * 16;
     if (dsm > 48 * 1024) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "topk_merge: parts*k=%zu too large", m);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
