@@ -33,8 +33,16 @@ constexpr int BNQ = 256;         // queries per workgroup tile
 constexpr int BK = 64;           // K step (elements); rows of the LDS image are 128 B
 constexpr int NTHREADS = 512;    // 8 waves: 2 (database halves of 128 rows) x 4 (64 queries)
 constexpr int TILE_BYTES = 256 * BK * 2;   // 32 KiB: one operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;  // A tile + B tile
-constexpr int LDS_BYTES = 2 * BUF_BYTES;   // double buffered: 128 KiB
+constexpr int A_TILE = TILE_BYTES;         // ring strides
+constexpr int B_TILE = TILE_BYTES;
+constexpr int B_RING = 3 * A_TILE;         // A ring: 3 K tiles (96 KiB), then B ring: 2 K tiles (64 KiB)
+constexpr int LDS_BYTES = 3 * A_TILE + 2 * B_TILE;   // 160 KiB: the whole LDS of a CU
+#ifndef DLC_STAGGER_SLEEP
+#define DLC_STAGGER_SLEEP 127    // s_sleep units of 64 cycles per stagger step (~4 us)
+#endif
+#ifndef DLC_STAGGER_PHASES
+#define DLC_STAGGER_PHASES 16
+#endif
 constexpr int GROUP = 8;         // database rows per group
 constexpr int HALF = 128;        // database rows per half tile
 constexpr int GROUPS_PER_HALF = HALF / GROUP;
@@ -90,34 +98,39 @@ struct GemmArgs {
     long long lds;
 };
 
-// ---- LDS image (128 KiB): two K-tile buffers of 64 KiB; in a buffer four 16-KiB
-// half tiles A0 | A1 | B0 | B1, each 128 rows x 128 B:
+// ---- LDS image (160 KiB): a ring of 3 K tiles of the database operand (A, streamed from HBM)
+// followed by a ring of 2 K tiles of the query operand (B, re-read from L2).  A K tile of an
+// operand is two 16-KiB half tiles of 128 rows x 128 B:
 //   A half h, row r = wr*64 + rr   <->  tile database row  wr*128 + h*64 + rr
 //   B half h, row r = wc*32 + rr   <->  query row          wc*64  + h*32 + rr
 // A wave computes its 128 x 64 block as four 64 x 32 quadrants (A half, B half),
 // each in two 32-wide k-slices: 8 mini-phases of 8 MFMAs per K tile.
 constexpr int HALF_BYTES = 128 * 128;
-constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
 
-// Two LDS-DMA wave-instructions (2 x 1 KiB = this wave's share of one half tile).
-// Issued from inline asm so that hipcc does not count them: it would otherwise
-// put s_waitcnt vmcnt(0) in front of every ds_read and serialise the pipeline.
-// M0 carries the LDS destination (wave-uniform); saved and restored because the
-// compiler owns it.  s_nop 4 covers an SGPR operand freshly written by a VALU.
-__device__ __forceinline__ void dma_half(unsigned voff0, unsigned voff1, const char* sbase, unsigned lds0) {
+// Four LDS-DMA wave-instructions (4 x 1 KiB: 32 rows of one half tile).  Issued from inline asm
+// so that hipcc does not count them: it would otherwise put s_waitcnt vmcnt(0) in front of every
+// ds_read and serialise the pipeline.  M0 carries the LDS destination (wave-uniform); saved and
+// restored because the compiler owns it.  s_nop 4 covers an SGPR operand freshly written by a VALU.
+__device__ __forceinline__ void dma4(const unsigned (&voff)[4], const char* sbase, unsigned lds0) {
     unsigned keep;
     asm volatile(
         "s_nop 4\n\t"
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\t"
+        "s_mov_b32 m0, %6\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "s_add_u32 m0, %4, 0x400\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, %6, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %3\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_add_u32 m0, %6, 0x800\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %5\n\t"
+        "s_add_u32 m0, %6, 0xc00\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %5\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff0), "v"(voff1), "s"(sbase), "s"(lds0)
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase), "s"(lds0)
         : "memory", "scc");
 }
 
@@ -141,29 +154,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     const int qblk = blockIdx.y;
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem;
 
-    // ---- DMA source offsets (bytes from the tile's / query block's first row), per half, per DMA
+    // ---- DMA roles: waves 0-3 stream the database (A) halves from HBM, waves 4-7 the query
+    // (B) halves from L2.  vmcnt counts per wave and in order, so with one stream per wave the A
+    // waves can keep three halves (48 KiB per CU) in flight regardless of the B traffic.
+    const bool is_a = wid < 4;
+    const int ridx = wid & 3;                               // this wave stages rows 32*ridx .. +31 of a half
     const char* a_base = p.DB + tile * BM * p.lddb_b;
     const char* b_base = p.Q + (long long)qblk * BNQ * p.ldq_b;
-    unsigned voffA[2][2], voffB[2][2];
+    unsigned voff[2][4];                                    // [half][dma]: byte offset of this lane's 16 B
     {
         const int slot = lane & 7;
-        const long long arows = p.n - tile * BM;          // valid rows in this tile (>= 1)
+        const long long arows = p.n - tile * BM;            // valid rows in this tile (>= 1)
         const long long brows = (long long)p.q - (long long)qblk * BNQ;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = 16 * wid + 8 * j + (lane >> 3);             // row inside the half
+        for (int j = 0; j < 4; ++j) {
+            const int r = 32 * ridx + 8 * j + (lane >> 3);  // row inside the half
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 long long ar = (r >> 6) * 128 + h * 64 + (r & 63);
                 if (ar > arows - 1) ar = arows - 1;
-                voffA[h][j] = (unsigned)(ar * p.lddb_b + ((slot ^ swz_a(r)) << 4));
                 long long br = (r >> 5) * 64 + h * 32 + (r & 31);
                 if (br > brows - 1) br = brows - 1;
-                voffB[h][j] = (unsigned)(br * p.ldq_b + ((slot ^ swz_b(r)) << 4));
+                voff[h][j] = is_a ? (unsigned)(ar * p.lddb_b + ((slot ^ swz_a(r)) << 4))
+                                  : (unsigned)(br * p.ldq_b + ((slot ^ swz_b(r)) << 4));
             }
         }
     }
-    const unsigned lds_stage = lds_base + (unsigned)(16 * wid) * 128;   // this wave's rows of a half
+    const unsigned lds_stage = lds_base + (unsigned)(32 * ridx) * 128;   // this wave's rows of a half
     const int nk = p.nk;
 
     // ---- fragment read offsets (bytes inside a half)
@@ -174,13 +191,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     typedef const __attribute__((address_space(3))) u32x4_t* lds_u4p;
     typedef const __attribute__((address_space(3))) char* lds_cp;
     const lds_cp lbase = (lds_cp)(lptr_t)smem;
-    // byte offsets of this lane's fragment rows in the CURRENT buffer; toggled with ^BUF_BYTES
-    // (the two buffers are 64 KiB apart and the dynamic LDS segment starts at offset 0)
-    unsigned rdA0 = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((0 + kq) ^ fa) << 4);   // + tt*512
-    unsigned rdA1 = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((4 + kq) ^ fa) << 4);
-    unsigned rdB0 = (wc * 32 + i) * 128 + (((0 + kq) ^ fb) << 4);                         // + c*2048
-    unsigned rdB1 = (wc * 32 + i) * 128 + (((4 + kq) ^ fb) << 4);
-    unsigned lds_cur = lds_stage;        // this wave's DMA rows in the current buffer
+    const unsigned rdA0_l = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((0 + kq) ^ fa) << 4);   // + tt*512
+    const unsigned rdA1_l = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((4 + kq) ^ fa) << 4);
+    const unsigned rdB0_l = B_RING + (wc * 32 + i) * 128 + (((0 + kq) ^ fb) << 4);                // + c*2048
+    const unsigned rdB1_l = B_RING + (wc * 32 + i) * 128 + (((4 + kq) ^ fb) << 4);
+    // ring positions of the CURRENT K tile (bytes): A ring of 3 tiles, B ring of 2
+    unsigned aoff = 0, boff = 0;
+    unsigned rdA0 = rdA0_l, rdA1 = rdA1_l, rdB0 = rdB0_l, rdB1 = rdB1_l;
 
     f32x4_t acc[8][4];
 #pragma unroll
@@ -207,69 +224,91 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
 #define DLC_RELEASE()    \
     DLC_WAIT_LGKM0();    \
     wg_barrier()
-    // DMA of half OFF of K tile t2 into the CURRENT buffer (K offset clamped past the end: the
+    // DMA of half H of K tile t2 into ring position POS (K offset clamped past the end: the
     // redundant DMA lands in a dead half and keeps the vmcnt bookkeeping uniform)
-#define DLC_ISSUE(LDS, OFF, VOFF, BASE, t2)                                                          \
+#define DLC_ISSUE_A(POS, H, t2)                                                                      \
     do {                                                                                             \
-        int kk_ = (t2) < nk ? (t2) : nk - 1;                                                         \
-        dma_half(VOFF[0], VOFF[1], (BASE) + (long long)kk_ * 128, (LDS) + (OFF));                    \
+        if (is_a) {                                                                                  \
+            int kk_ = (t2) < nk ? (t2) : nk - 1;                                                     \
+            dma4(voff[H], a_base + (long long)kk_ * 128, lds_stage + (POS) + (H) * HALF_BYTES);      \
+        }                                                                                            \
+    } while (0)
+#define DLC_ISSUE_B(POS, H, t2)                                                                      \
+    do {                                                                                             \
+        if (!is_a) {                                                                                 \
+            int kk_ = (t2) < nk ? (t2) : nk - 1;                                                     \
+            dma4(voff[H], b_base + (long long)kk_ * 128, lds_stage + B_RING + (POS) + (H) * HALF_BYTES); \
+        }                                                                                            \
     } while (0)
 
-    // ---- prologue: K tiles 0 and 1 issued (tile 1 clamps to tile 0 when nk == 1)
-    DLC_ISSUE(lds_cur, OFF_A1, voffA[1], a_base, 0);
-    DLC_ISSUE(lds_cur, OFF_B0, voffB[0], b_base, 0);
-    DLC_ISSUE(lds_cur, OFF_B1, voffB[1], b_base, 0);
-    DLC_ISSUE(lds_cur, OFF_A0, voffA[0], a_base, 0);
-    DLC_ISSUE(lds_cur ^ BUF_BYTES, OFF_A1, voffA[1], a_base, 1);
-    DLC_ISSUE(lds_cur ^ BUF_BYTES, OFF_B0, voffB[0], b_base, 1);
-    DLC_ISSUE(lds_cur ^ BUF_BYTES, OFF_B1, voffB[1], b_base, 1);
-    DLC_ISSUE(lds_cur ^ BUF_BYTES, OFF_A0, voffA[0], a_base, 1);
-    DLC_WAIT_VMCNT(8);            // K tile 0 landed
+    // Workgroups of one round would otherwise walk K in lockstep, all CUs touching the same
+    // 128-byte column of their rows at the same time; a small start stagger of the FIRST round
+    // (later rounds inherit it) spreads them over K without changing any result.
+    if (tile < 256) {
+        const int steps = (int)((tile >> 3) % DLC_STAGGER_PHASES);
+        for (int s_ = 0; s_ < steps; ++s_) __builtin_amdgcn_s_sleep(DLC_STAGGER_SLEEP);
+    }
+    // ---- prologue: A tiles 0,1,2 and B tiles 0,1 issued (per-tile order A1,A0 / B0,B1, as the
+    // steady state issues them); then wait for tile 0.
+    DLC_ISSUE_A(0 * A_TILE, 1, 0);
+    DLC_ISSUE_A(0 * A_TILE, 0, 0);
+    DLC_ISSUE_A(1 * A_TILE, 1, 1);
+    DLC_ISSUE_A(1 * A_TILE, 0, 1);
+    DLC_ISSUE_A(2 * A_TILE, 1, 2);
+    DLC_ISSUE_A(2 * A_TILE, 0, 2);
+    DLC_ISSUE_B(0 * B_TILE, 0, 0);
+    DLC_ISSUE_B(0 * B_TILE, 1, 0);
+    DLC_ISSUE_B(1 * B_TILE, 0, 1);
+    DLC_ISSUE_B(1 * B_TILE, 1, 1);
+    if (is_a) DLC_WAIT_VMCNT(16); else DLC_WAIT_VMCNT(8);   // K tile 0 landed (this wave's share)
     wg_barrier();
-    DLC_READ_A(faX, rdA0, OFF_A0);
-    DLC_READ_B(fbX, rdB0, OFF_B0);
+    DLC_READ_A(faX, rdA0, 0);
+    DLC_READ_B(fbX, rdB0, 0);
 
     // One K tile = 8 mini-phases of 8 MFMAs, k-slice outer, quadrants in snake order so that
     // exactly one operand changes per step and every LDS fragment is read once:
     //   m1 (A0,B0,k0) m2 (A0,B1,k0) m3 (A1,B1,k0) m4 (A1,B0,k0)
     //   m5 (A1,B0,k1) m6 (A1,B1,k1) m7 (A0,B1,k1) m8 (A0,B0,k1)
     // Mini-phase m issues the reads of m+1 first, then its own MFMAs.  A half of the current
-    // buffer is dead once its k1 slice has been read (A1 after m3, B0 after m4, B1 after m5, A0
-    // after m6): a barrier there, then the DMA of K tile t+2 into it.  Per-tile DMA order
-    // A1,B0,B1,A0; the single vmcnt(6) at the end of m6 leaves the three youngest halves in flight
-    // and retires all of K tile t+1, whose first slices are read in m7 / m8.
+    // tile is dead once its k1 slice has been read (A1 after m3, B0 after m4, B1 after m5, A0
+    // after m6): a barrier there, then the DMA that refills it -- A halves with K tile t+3, B
+    // halves with t+2.  At the end of m6 each wave waits for its own stream: an A wave leaves
+    // A1(t+2), A0(t+2), A1(t+3) in flight (vmcnt 12), a B wave B0(t+2), B1(t+2) (vmcnt 8); K
+    // tile t+1, whose first slices are read in m7 / m8, has then landed.
     for (int t = 0; t < nk; ++t) {
-        DLC_READ_B(fbY, rdB0, OFF_B1);
+        DLC_READ_B(fbY, rdB0, HALF_BYTES);
         DLC_MFMA(faX, fbX, 0, 0);                                  // m1
-        DLC_READ_A(faY, rdA0, OFF_A1);
+        DLC_READ_A(faY, rdA0, HALF_BYTES);
         DLC_MFMA(faX, fbY, 0, 1);                                  // m2
-        DLC_READ_A(faX, rdA1, OFF_A1);
+        DLC_READ_A(faX, rdA1, HALF_BYTES);
         DLC_MFMA(faY, fbY, 1, 1);                                  // m3
         DLC_RELEASE();                                             // A1 read by everyone
-        DLC_READ_B(fbY, rdB1, OFF_B0);
-        DLC_ISSUE(lds_cur, OFF_A1, voffA[1], a_base, t + 2);
+        DLC_READ_B(fbY, rdB1, 0);
+        DLC_ISSUE_A(aoff, 1, t + 3);
         DLC_MFMA(faY, fbX, 1, 0);                                  // m4
         DLC_RELEASE();                                             // B0
-        DLC_READ_B(fbX, rdB1, OFF_B1);
-        DLC_ISSUE(lds_cur, OFF_B0, voffB[0], b_base, t + 2);
+        DLC_READ_B(fbX, rdB1, HALF_BYTES);
+        DLC_ISSUE_B(boff, 0, t + 2);
         DLC_MFMA(faX, fbY, 1, 0);                                  // m5
         DLC_RELEASE();                                             // B1
-        DLC_READ_A(faY, rdA1, OFF_A0);
-        DLC_ISSUE(lds_cur, OFF_B1, voffB[1], b_base, t + 2);
+        DLC_READ_A(faY, rdA1, 0);
+        DLC_ISSUE_B(boff, 1, t + 2);
         DLC_MFMA(faX, fbX, 1, 1);                                  // m6
-        DLC_WAIT_VMCNT(6);                                         // K tile t+1 landed (this wave's share)
+        if (is_a) DLC_WAIT_VMCNT(12); else DLC_WAIT_VMCNT(8);      // K tile t+1 landed (this wave's share)
         DLC_RELEASE();                                             // A0; and t+1 visible to all
-        DLC_ISSUE(lds_cur, OFF_A0, voffA[0], a_base, t + 2);
-        rdA0 ^= BUF_BYTES; rdA1 ^= BUF_BYTES; rdB0 ^= BUF_BYTES; rdB1 ^= BUF_BYTES;   // next tile's buffer
-        lds_cur ^= BUF_BYTES;
-        DLC_READ_A(faX, rdA0, OFF_A0);
+        DLC_ISSUE_A(aoff, 0, t + 3);
+        aoff = aoff == 2 * A_TILE ? 0u : aoff + A_TILE;            // ring positions of K tile t+1
+        boff ^= B_TILE;
+        rdA0 = rdA0_l + aoff; rdA1 = rdA1_l + aoff; rdB0 = rdB0_l + boff; rdB1 = rdB1_l + boff;
+        DLC_READ_A(faX, rdA0, 0);
         DLC_MFMA(faY, fbX, 0, 1);                                  // m7
-        DLC_READ_B(fbX, rdB0, OFF_B0);
+        DLC_READ_B(fbX, rdB0, 0);
         DLC_MFMA(faY, fbY, 0, 0);                                  // m8
     }
     DLC_WAIT_VMCNT(0);   // the clamped tail DMAs must not outlive the workgroup's LDS
     DLC_WAIT_LGKM0();
-#undef DLC_ISSUE
+#undef DLC_ISSUE_A
+#undef DLC_ISSUE_B
 #undef DLC_READ_A
 #undef DLC_READ_B
 #undef DLC_MFMA
@@ -456,25 +495,37 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_topk_kernel(
         float acc[GROUP];
 #pragma unroll
         for (int r = 0; r < GROUP; ++r) acc[r] = 0.f;
-        for (int d0 = lane * 8; d0 < d; d0 += 512) {
-            const uint4 qv = *(const uint4*)(qrow + (long long)d0 * 2);
-            uint4 rv[GROUP];
+        // RS_UNROLL chunks of 512 elements per trip: all their row loads are issued before the
+        // first use, so RS_UNROLL * GROUP + RS_UNROLL 16-byte loads are in flight per lane.
+        constexpr int RS_UNROLL = 4;
+        for (int d0 = lane * 8; d0 < d; d0 += 512 * RS_UNROLL) {
+            uint4 qv[RS_UNROLL], rv[RS_UNROLL][GROUP];
 #pragma unroll
-            for (int r = 0; r < GROUP; ++r) rv[r] = *(const uint4*)(rows[r] + (long long)d0 * 2);
-            const unsigned qw[4] = {qv.x, qv.y, qv.z, qv.w};
-            float qf[8];
+            for (int u = 0; u < RS_UNROLL; ++u) {
+                const int dd = d0 + u * 512;
+                const bool ok = dd < d;
+                qv[u] = ok ? *(const uint4*)(qrow + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                qf[2 * e] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu));
-                qf[2 * e + 1] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16));
+                for (int r = 0; r < GROUP; ++r)
+                    rv[u][r] = ok ? *(const uint4*)(rows[r] + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < GROUP; ++r) {
-                const unsigned w4[4] = {rv[r].x, rv[r].y, rv[r].z, rv[r].w};
+            for (int u = 0; u < RS_UNROLL; ++u) {
+                const unsigned qw[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
+                float qf[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[r] = fmaf(qf[2 * e], Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc[r]);
-                    acc[r] = fmaf(qf[2 * e + 1], Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc[r]);
+                    qf[2 * e] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu));
+                    qf[2 * e + 1] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16));
+                }
+#pragma unroll
+                for (int r = 0; r < GROUP; ++r) {
+                    const unsigned w4[4] = {rv[u][r].x, rv[u][r].y, rv[u][r].z, rv[u][r].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[r] = fmaf(qf[2 * e], Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc[r]);
+                        acc[r] = fmaf(qf[2 * e + 1], Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc[r]);
+                    }
                 }
             }
         }
@@ -677,6 +728,9 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
     a.tmax = (float*)(ws + w.tmax); a.ldt = w.ldt;
     a.ng = dlc::cdiv(n, GROUP); a.nh = dlc::cdiv(n, HALF);
     a.S = nullptr; a.lds = 0;
+#ifdef DLC_EXPERIMENT_ALIAS_ROWS   // perf experiment build only (scripts/): every database row aliases row 0
+    a.lddb_b = 0;
+#endif
 
     const int slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[slot], st));
