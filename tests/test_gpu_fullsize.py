@@ -1,0 +1,108 @@
+"""BASELINE.json full sizes on the GPU, through size-independent properties (the
+fp64 oracle cannot finish these in seconds): batch invariance, symmetry, agreement
+of the all-vs-all kernels with the per-pair entry points and with the oracle on
+sampled entries, planted-neighbour recall, sharded == unsharded."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N_FRAMES = 1063            # outdoor_kennedylong (configs[1], configs[2])
+
+
+@pytest.fixture(scope="module")
+def dlc():
+    import deeploopcloser_amd as d
+    d.default_engine()
+    return d
+
+
+@pytest.fixture(scope="module")
+def descriptors(dlc):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42)
+    x = torch.rand((N_FRAMES, 30, 1681), generator=g, device="cuda", dtype=torch.float64)
+    net = dlc.SDAV(seed=2)
+    h = net.transform_tensor(x)
+    return net, x, h
+
+
+def test_sdav_encode_kennedylong_batch_invariance(dlc, descriptors):
+    """1063 frames in one call == the same frames in chunks (bit-exact), + oracle on one frame."""
+    from oracle import sdav as osdav
+    net, x, h = descriptors
+    assert h.shape == (N_FRAMES * 30, 2500)
+    for lo, hi in ((0, 1), (500, 517), (1050, 1063)):
+        part = net.transform_tensor(x[lo:hi])
+        assert torch.equal(part, h[lo * 30:hi * 30])
+    ws, bs = net.get_weights()
+    ref = osdav.transform(x[777:778].cpu().numpy(), ws, bs)
+    assert np.abs(h[777 * 30:778 * 30].cpu().numpy() - ref).max() < 1e-10
+    assert torch.isfinite(h).all() and float(h.min()) >= 0.0 and float(h.max()) <= 1.0
+
+
+def test_similarity_matrix_kennedylong_properties(dlc, descriptors):
+    from oracle import similarity as osim
+    _, _, h = descriptors
+    ds = h.reshape(N_FRAMES, 30, 2500)
+    calc = dlc.SimilarityCalculator(ds)
+    mf = calc.similarity_matrix(as_int64=False)
+    mi = calc.similarity_matrix(as_int64=True)
+    assert mf.shape == (N_FRAMES, N_FRAMES) and np.array_equal(mf, mf.T) and np.array_equal(mi, mi.T)
+    assert np.all(np.diag(mf) == -1) and np.all(np.diag(mi) == -1)
+    fin = np.isfinite(mf)
+    assert np.array_equal(mi[fin], np.trunc(mf[fin]).astype(np.int64))
+    dsn = ds.cpu().numpy()
+    score = osim.distinctive_score(osim.average_response(dsn))
+    np.testing.assert_allclose(calc._score.cpu().numpy(), score, rtol=1e-12)
+    rng = np.random.RandomState(0)
+    for _ in range(12):
+        i, j = sorted(rng.choice(N_FRAMES, 2, replace=False))
+        idx = osim.match_features(dsn[i], dsn[j])
+        d = osim.weighted_distances(dsn[i], dsn[j], idx, score)
+        with np.errstate(divide="ignore"):
+            want = np.sum(10 - 10 * np.log(d))
+        assert (np.isinf(want) and mf[i, j] == want) or abs(mf[i, j] - want) <= 1e-9 * abs(want)
+        assert calc.similarity_score(dsn[i], dsn[j]) == mf[i, j]          # per-pair entry == matrix entry
+
+
+def test_distance_matrix_kennedylong_properties(dlc):
+    from oracle import distance as odist
+    rng = np.random.RandomState(1)
+    desc = rng.randint(-128, 128, size=(N_FRAMES, 2243)).astype(np.int8)
+    m = dlc.DistanceCalculator.distance_matrix(desc)
+    assert m.shape == (N_FRAMES, N_FRAMES) and np.array_equal(m, m.T) and np.all(np.diag(m) == 0)
+    for _ in range(50):
+        i, j = rng.randint(0, N_FRAMES, 2)
+        assert m[i, j] == odist.calculate_distance(desc[i], desc[j])
+    assert m.max() <= 8 * 2243
+
+
+def test_cosine_config4_shape_properties(dlc):
+    """configs[3]: 100k x 4096 DB, 256 queries: recall@1 on planted neighbours, self-match,
+    8 row shards + merge == one shard."""
+    eng = dlc.default_engine()
+    n, d, nq, k = 100_000, 4096, 256, 20
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    x = torch.rand((n, d), generator=g, device="cuda", dtype=torch.float32)
+    db = eng.normalize(x, "bf16", center=True)
+    pi = torch.randperm(n, generator=g, device="cuda")[:nq]
+    q = eng.normalize(x[pi] + 0.17 * torch.randn((nq, d), generator=g, device="cuda"), "bf16", center=True)
+    del x
+    s, i = eng.match_topk(q, db, k)
+    assert torch.equal(i[:, 0], pi)                                     # recall@1 = 1
+    assert torch.all(s[:, :-1] >= s[:, 1:])                             # sorted
+    s_self, i_self = eng.match_topk(db[pi], db, 1)
+    assert torch.equal(i_self[:, 0], pi) and float((s_self - 1).abs().max()) < 5e-3
+    ps, pidx = [], []
+    for r in range(8):
+        lo, hi = dlc.shard_bounds(n, 8, r)
+        a, b = eng.match_topk(q, db[lo:hi], k, row_offset=lo)
+        ps.append(a.clone()), pidx.append(b.clone())
+    ms, mi = eng.topk_merge(torch.stack(ps), torch.stack(pidx))
+    assert torch.equal(mi, i) and torch.equal(ms, s)
+    # exact scores of the returned rows, recomputed in fp64 on the host
+    rows = db[i[:8].reshape(-1)].double().reshape(8, k, d)
+    ref = torch.einsum("qkd,qd->qk", rows, q[:8].double())
+    assert float((ref - s[:8].double()).abs().max()) < 2e-5
