@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu rehearses the N>1 path with several ranks on ONE GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one stream, no overlap of a batch's selection / all-gather with the next batch's GEMM")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     return ap.parse_args()
 
@@ -103,10 +108,15 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import deeploopcloser_amd as dlc
     from deeploopcloser_amd.engine import torch_dtype
@@ -127,10 +137,18 @@ def main():
     queries = eng.normalize(planted + sigma * noise, dt, center=True)
     db = dlc.KeyframeDatabase(rows, dtype=dt, row_offset=lo, stored=True)
     sharded = dlc.ShardedKeyframeDatabase.from_database(db)
+    pipe = None if args.no_pipeline else dlc.MatchPipeline(db, k, depth=2)
     torch.cuda.synchronize()
+    last = [None]
 
     def step():
-        return sharded.match_topk(queries, k)
+        # one query batch against the whole (sharded) database.  Pipelined mode: the batch's
+        # GEMM is enqueued now; its selection / all-gather / merge run on the second stream
+        # and complete before the closing fence (torch.cuda.synchronize waits for all streams).
+        if pipe is None:
+            return sharded.match_topk(queries, k)
+        last[0] = pipe.submit(queries)
+        return None
 
     def fence():
         torch.cuda.synchronize()
@@ -144,9 +162,10 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        scores, idx = step()
+        res = step()
     fence()
     t1 = time.perf_counter()
+    scores, idx = res if pipe is None else pipe.result(last[0])
     gemm_ms = eng.profile_gemm_ms(min(args.steps, 256))
     eng.set_profiling(False)
 
@@ -178,7 +197,8 @@ def main():
             "config": {"workload": "%d-keyframe synthetic %d-d descriptor DB (%s, L2-normalised), batch=%d queries, "
                                    "top-%d cosine match; DB row-sharded over %d GPU(s), RCCL all-gather of per-shard "
                                    "top-k (BASELINE configs[4] shape, bf16 per north_star)" % (n, d, args.dtype, nq, k, world),
-                       "db_rows": n, "dim": d, "queries_per_step": nq, "k": k, "rows_per_gpu": shard_rows},
+                       "db_rows": n, "dim": d, "queries_per_step": nq, "k": k, "rows_per_gpu": shard_rows,
+                       "pipelined": pipe is not None},
             "recall_at_1": recall1,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,

@@ -22,10 +22,10 @@ from .sdav import SDAV, DA
 from .cnn_vtl import CnnVtl
 from .similarity import SimilarityCalculator
 from .distance import DistanceCalculator
-from .matching import encode, match, match_topk, KeyframeDatabase, flatten_frame_descriptors
+from .matching import encode, match, match_topk, KeyframeDatabase, MatchPipeline, flatten_frame_descriptors
 from .dist import ShardedKeyframeDatabase, shard_bounds, merge_topk_torch
 from . import tensor_wrapper
 
 __all__ = ["SDAV", "DA", "CnnVtl", "SimilarityCalculator", "DistanceCalculator", "MathUtils", "tensor_wrapper",
-           "encode", "match", "match_topk", "KeyframeDatabase", "ShardedKeyframeDatabase", "Engine",
+           "encode", "match", "match_topk", "KeyframeDatabase", "MatchPipeline", "ShardedKeyframeDatabase", "Engine",
            "default_engine", "shard_bounds", "merge_topk_torch", "flatten_frame_descriptors"]

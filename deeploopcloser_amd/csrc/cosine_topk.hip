@@ -35,8 +35,12 @@ constexpr int NTHREADS = 512;    // 8 waves: 2 (database halves of 128 rows) x 4
 constexpr int TILE_BYTES = 256 * BK * 2;   // 32 KiB: one operand tile
 constexpr int A_TILE = TILE_BYTES;         // ring strides
 constexpr int B_TILE = TILE_BYTES;
-constexpr int B_RING = 3 * A_TILE;         // A ring: 3 K tiles (96 KiB), then B ring: 2 K tiles (64 KiB)
-constexpr int LDS_BYTES = 3 * A_TILE + 2 * B_TILE;   // 160 KiB: the whole LDS of a CU
+#ifndef DLC_A_STAGES
+#define DLC_A_STAGES 2                     // depth of the database-operand ring (2 -> 128 KiB LDS, 3 -> 160 KiB)
+#endif
+constexpr int A_STAGES = DLC_A_STAGES;
+constexpr int B_RING = A_STAGES * A_TILE;  // A ring first, then the B ring of 2 K tiles (64 KiB)
+constexpr int LDS_BYTES = A_STAGES * A_TILE + 2 * B_TILE;
 #ifndef DLC_STAGGER_SLEEP
 #define DLC_STAGGER_SLEEP 127    // s_sleep units of 64 cycles per stagger step (~4 us)
 #endif
@@ -47,7 +51,6 @@ constexpr int GROUP = 8;         // database rows per group
 constexpr int HALF = 128;        // database rows per half tile
 constexpr int GROUPS_PER_HALF = HALF / GROUP;
 constexpr int SLACK = 4;         // extra groups kept beyond k (fp32 re-score order vs MFMA order)
-constexpr int MAX_KG = DLC_MAX_K + SLACK;
 
 template <typename Tag> struct Mfma16;
 template <> struct Mfma16<dlc_bf16_tag> {
@@ -250,17 +253,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     }
     // ---- prologue: A tiles 0,1,2 and B tiles 0,1 issued (per-tile order A1,A0 / B0,B1, as the
     // steady state issues them); then wait for tile 0.
-    DLC_ISSUE_A(0 * A_TILE, 1, 0);
-    DLC_ISSUE_A(0 * A_TILE, 0, 0);
-    DLC_ISSUE_A(1 * A_TILE, 1, 1);
-    DLC_ISSUE_A(1 * A_TILE, 0, 1);
-    DLC_ISSUE_A(2 * A_TILE, 1, 2);
-    DLC_ISSUE_A(2 * A_TILE, 0, 2);
+#pragma unroll
+    for (int s_ = 0; s_ < A_STAGES; ++s_) {
+        DLC_ISSUE_A(s_ * A_TILE, 1, s_);
+        DLC_ISSUE_A(s_ * A_TILE, 0, s_);
+    }
     DLC_ISSUE_B(0 * B_TILE, 0, 0);
     DLC_ISSUE_B(0 * B_TILE, 1, 0);
     DLC_ISSUE_B(1 * B_TILE, 0, 1);
     DLC_ISSUE_B(1 * B_TILE, 1, 1);
-    if (is_a) DLC_WAIT_VMCNT(16); else DLC_WAIT_VMCNT(8);   // K tile 0 landed (this wave's share)
+    if (is_a) { if constexpr (A_STAGES == 3) DLC_WAIT_VMCNT(16); else DLC_WAIT_VMCNT(8); }
+    else DLC_WAIT_VMCNT(8);                                 // K tile 0 landed (this wave's share)
     wg_barrier();
     DLC_READ_A(faX, rdA0, 0);
     DLC_READ_B(fbX, rdB0, 0);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
         DLC_MFMA(faY, fbY, 1, 1);                                  // m3
         DLC_RELEASE();                                             // A1 read by everyone
         DLC_READ_B(fbY, rdB1, 0);
-        DLC_ISSUE_A(aoff, 1, t + 3);
+        DLC_ISSUE_A(aoff, 1, t + A_STAGES);
         DLC_MFMA(faY, fbX, 1, 0);                                  // m4
         DLC_RELEASE();                                             // B0
         DLC_READ_B(fbX, rdB1, HALF_BYTES);
@@ -294,10 +297,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
         DLC_READ_A(faY, rdA1, 0);
         DLC_ISSUE_B(boff, 1, t + 2);
         DLC_MFMA(faX, fbX, 1, 1);                                  // m6
-        if (is_a) DLC_WAIT_VMCNT(12); else DLC_WAIT_VMCNT(8);      // K tile t+1 landed (this wave's share)
+        if (is_a) { if constexpr (A_STAGES == 3) DLC_WAIT_VMCNT(12); else DLC_WAIT_VMCNT(4); }
+        else DLC_WAIT_VMCNT(8);                                    // K tile t+1 landed (this wave's share)
         DLC_RELEASE();                                             // A0; and t+1 visible to all
-        DLC_ISSUE_A(aoff, 0, t + 3);
-        aoff = aoff == 2 * A_TILE ? 0u : aoff + A_TILE;            // ring positions of K tile t+1
+        DLC_ISSUE_A(aoff, 0, t + A_STAGES);
+        aoff = aoff == (A_STAGES - 1) * A_TILE ? 0u : aoff + A_TILE;   // ring positions of K tile t+1
         boff ^= B_TILE;
         rdA0 = rdA0_l + aoff; rdA1 = rdA1_l + aoff; rdB0 = rdB0_l + boff; rdB1 = rdB1_l + boff;
         DLC_READ_A(faX, rdA0, 0);
@@ -389,9 +393,9 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-constexpr int FIN_THREADS = 512;            // finish / merge workgroup
-constexpr int FIN_WAVES = FIN_THREADS / 64;
-constexpr int MAX_CAND = MAX_KG * GROUPS_PER_HALF;   // >= FIN_WAVES * MAX_KG and >= MAX_KG * GROUP
+constexpr int FIN_THREADS = 512;            // merge workgroup; finish workgroup of the stand-alone variant
+// finish kernel LDS carve (bytes) for kg selected groups: keys | re-scored rows | two index lists
+__host__ __device__ inline size_t fin_lds_fixed(int kg) { return (size_t)kg * (GROUPS_PER_HALF * 8 + GROUP * 4 + 8); }
 
 // Rank-by-counting on unique keys in LDS: out[rank] = element index, for rank < k.
 // Every thread walks the keys in the same order (LDS broadcast reads).
@@ -408,24 +412,30 @@ __device__ __forceinline__ void rank_select(const unsigned long long* keys, int 
 
 // One workgroup per query: half-tile selection -> group selection -> exact fp32 re-score of
 // the selected groups' rows -> final top-k.
-template <typename Tag>
-__global__ __launch_bounds__(FIN_THREADS) void finish_topk_kernel(
+// THREADS / RS_UNROLL pick the footprint: (512, 4) is the fastest stand-alone form (246 VGPRs);
+// (256, 1) needs ~70 VGPRs and a few KiB of LDS so that its workgroups can share a CU with a
+// resident score-GEMM workgroup (128 KiB LDS, 2 x 198 VGPRs per SIMD) when the two run on
+// different streams.
+template <typename Tag, int THREADS, int RS_UNROLL>
+__global__ __launch_bounds__(THREADS) void finish_topk_kernel(
     float* __restrict__ tmax, long long ldt, int nh, int tv_in_lds, const float* __restrict__ gmax, long long ldg,
     long long ng, int kg, const char* __restrict__ Q, long long ldq_b, const char* __restrict__ DB, long long lddb_b,
     long long n, int d, int k, long long row_offset, float* __restrict__ out_s, long long* __restrict__ out_i) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
-    __shared__ unsigned long long ckey[MAX_CAND];
-    __shared__ int sel[MAX_KG];               // selected half tiles; later the final winners
-    __shared__ int sel2[MAX_KG];              // selected groups
-    __shared__ float cval[MAX_KG * GROUP];    // re-scored rows
+    constexpr int FIN_WAVES = THREADS / 64;
+    constexpr int FIN_THREADS = THREADS;      // shadows the namespace constant inside this kernel
     constexpr int GPH = GROUPS_PER_HALF;
+    unsigned long long* ckey = (unsigned long long*)dsm;                       // [kg * GPH]
+    float* cval = (float*)(dsm + (size_t)kg * GPH * 8);                        // [kg * GROUP] re-scored rows
+    int* sel = (int*)(dsm + (size_t)kg * (GPH * 8 + GROUP * 4));               // [kg] half tiles; later the winners
+    int* sel2 = sel + kg;                                                      // [kg] selected groups
     const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // [nh] half-tile maxima of this query: staged in LDS, or (very large shards) consumed in
-    // place in the workspace row, which the next GEMM rewrites anyway
-    float* tv = tv_in_lds ? (float*)dsm : tmax + (long long)qi * ldt;
+    // [nh] half-tile maxima of this query: staged in LDS, or consumed in place in the workspace
+    // row (which the next GEMM rewrites anyway) when LDS is to be kept small or the shard is huge
+    float* tv = tv_in_lds ? (float*)(dsm + fin_lds_fixed(kg)) : tmax + (long long)qi * ldt;
     if (tv_in_lds)
         for (int e = tid; e < nh; e += FIN_THREADS) tv[e] = tmax[(long long)qi * ldt + e];
-    for (int e = tid; e < MAX_KG; e += FIN_THREADS) { sel[e] = -1; sel2[e] = -1; }
+    for (int e = tid; e < kg; e += FIN_THREADS) { sel[e] = -1; sel2[e] = -1; }
     __syncthreads();
 
     // ---- level 1: the kt half tiles with the largest maximum (ties -> lower tile).
@@ -497,7 +507,6 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_topk_kernel(
         for (int r = 0; r < GROUP; ++r) acc[r] = 0.f;
         // RS_UNROLL chunks of 512 elements per trip: all their row loads are issued before the
         // first use, so RS_UNROLL * GROUP + RS_UNROLL 16-byte loads are in flight per lane.
-        constexpr int RS_UNROLL = 4;
         for (int d0 = lane * 8; d0 < d; d0 += 512 * RS_UNROLL) {
             uint4 qv[RS_UNROLL], rv[RS_UNROLL][GROUP];
 #pragma unroll
@@ -540,8 +549,8 @@ __global__ __launch_bounds__(FIN_THREADS) void finish_topk_kernel(
     for (int e = tid; e < k; e += FIN_THREADS) {          // defaults for slots past the candidates
         out_s[(long long)qi * k + e] = -INFINITY;
         out_i[(long long)qi * k + e] = -1;
-        if (e < MAX_KG) sel[e] = -1;
     }
+    for (int e = tid; e < kg; e += FIN_THREADS) sel[e] = -1;
     __syncthreads();
 
     // ---- final top-k of the kg2*GROUP re-scored rows (id = database row inside the shard)
@@ -704,58 +713,118 @@ extern "C" size_t dlc_cosine_topk_workspace_bytes(int64_t q, int64_t n, int64_t 
     return ws_layout(q, n, k).total;
 }
 
-extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
-                               int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, float* out_scores,
-                               int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+
+struct MatchCall {
+    GemmArgs a;
+    WsLayout w;
+};
+
+int prepare_match(dlc_ctx* ctx, const char* what, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                  int64_t n, int64_t lddb, int64_t d, int k, void* workspace, size_t workspace_bytes, MatchCall* mc) {
     int rc = check_operands(ctx, dtype, Q, q, ldq, DB, n, lddb, d);
     if (rc != DLC_OK) return rc;
-    if (k < 1 || k > DLC_MAX_K) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk: k=%d outside 1..%d", k, DLC_MAX_K);
-    if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk: null output");
-    const WsLayout w = ws_layout(q, n, k);
-    if (!workspace || workspace_bytes < w.total)
-        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "cosine_topk: workspace %zu < %zu bytes", workspace_bytes, w.total);
-    if (((uintptr_t)workspace & 255)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk: workspace must be 256-byte aligned");
-    dlc::DeviceGuard guard(ctx->device);
-    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    hipStream_t st = (hipStream_t)stream;
+    if (k < 1 || k > DLC_MAX_K) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "%s: k=%d outside 1..%d", what, k, DLC_MAX_K);
+    mc->w = ws_layout(q, n, k);
+    if (!workspace || workspace_bytes < mc->w.total)
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, workspace_bytes, mc->w.total);
+    if (((uintptr_t)workspace & 255)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "%s: workspace must be 256-byte aligned", what);
     char* ws = (char*)workspace;
-
-    GemmArgs a;
+    GemmArgs& a = mc->a;
     a.Q = (const char*)Q; a.DB = (const char*)DB;
     a.ldq_b = ldq * 2; a.lddb_b = lddb * 2;
     a.q = (int)q; a.n = n; a.nk = (int)(d / BK);
-    a.gmax = (float*)(ws + w.gmax); a.ldg = w.ldg;
-    a.tmax = (float*)(ws + w.tmax); a.ldt = w.ldt;
+    a.gmax = (float*)(ws + mc->w.gmax); a.ldg = mc->w.ldg;
+    a.tmax = (float*)(ws + mc->w.tmax); a.ldt = mc->w.ldt;
     a.ng = dlc::cdiv(n, GROUP); a.nh = dlc::cdiv(n, HALF);
     a.S = nullptr; a.lds = 0;
-#ifdef DLC_EXPERIMENT_ALIAS_ROWS   // perf experiment build only (scripts/): every database row aliases row 0
-    a.lddb_b = 0;
-#endif
+    return DLC_OK;
+}
 
+int run_score(dlc_ctx* ctx, int dtype, MatchCall& mc, hipStream_t st) {
+#ifdef DLC_EXPERIMENT_ALIAS_ROWS   // perf experiment build only (scripts/): every database row aliases row 0
+    mc.a.lddb_b = 0;
+#endif
     const int slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[slot], st));
-    rc = (dtype == DLC_BF16) ? launch_gemm<dlc_bf16_tag, false>(ctx, a, st) : launch_gemm<dlc_f16_tag, false>(ctx, a, st);
+    int rc = (dtype == DLC_BF16) ? launch_gemm<dlc_bf16_tag, false>(ctx, mc.a, st) : launch_gemm<dlc_f16_tag, false>(ctx, mc.a, st);
     if (rc != DLC_OK) return rc;
     if (ctx->profiling) {
         DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[slot], st));
         ctx->prof_calls++;
     }
+    return DLC_OK;
+}
 
-    // LDS for the half-tile maxima (reused for the re-scored rows)
-    size_t dsm = (size_t)w.kg * GROUP * 4;
-    const int tv_in_lds = (size_t)a.nh * 4 <= 96 * 1024;
-    if (tv_in_lds && dsm < (size_t)a.nh * 4) dsm = (size_t)a.nh * 4;
+template <typename Tag, int THREADS, int RS_UNROLL>
+int launch_finish(dlc_ctx* ctx, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
+                  float* out_scores, int64_t* out_idx, bool small_lds, hipStream_t st) {
+    const GemmArgs& a = mc.a;
+    size_t dsm = fin_lds_fixed(mc.w.kg);
+    const int tv_in_lds = !small_lds && (size_t)a.nh * 4 <= 96 * 1024;
+    if (tv_in_lds) dsm += (size_t)a.nh * 4;
     dsm = dlc::align_up(dsm, 16);
-    {
-        auto fk = (dtype == DLC_BF16) ? finish_topk_kernel<dlc_bf16_tag> : finish_topk_kernel<dlc_f16_tag>;
-        if (dsm > 48 * 1024)
-            DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm));
-        hipLaunchKernelGGL(fk, dim3((unsigned)q), dim3(FIN_THREADS), dsm, st, a.tmax, a.ldt, (int)a.nh, tv_in_lds, a.gmax, a.ldg, a.ng,
-                           w.kg, a.Q, a.ldq_b, a.DB, a.lddb_b, (long long)n, (int)d, k, (long long)row_offset, out_scores,
-                           (long long*)out_idx);
-    }
+    auto fk = finish_topk_kernel<Tag, THREADS, RS_UNROLL>;
+    if (dsm > 48 * 1024)
+        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm));
+    hipLaunchKernelGGL(fk, dim3((unsigned)q), dim3(THREADS), dsm, st, a.tmax, a.ldt, (int)a.nh, tv_in_lds, a.gmax, a.ldg,
+                       a.ng, mc.w.kg, a.Q, a.ldq_b, a.DB, a.lddb_b, (long long)n, (int)d, k, (long long)row_offset,
+                       out_scores, (long long*)out_idx);
     DLC_LAUNCH_CHECK(ctx, "finish_topk_kernel");
     return DLC_OK;
+}
+
+int run_select(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
+               float* out_scores, int64_t* out_idx, int flags, hipStream_t st) {
+    const bool coop = (flags & DLC_SELECT_COOP) != 0;
+    if (dtype == DLC_BF16)
+        return coop ? launch_finish<dlc_bf16_tag, 256, 1>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, true, st)
+                    : launch_finish<dlc_bf16_tag, 512, 4>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, false, st);
+    return coop ? launch_finish<dlc_f16_tag, 256, 1>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, true, st)
+                : launch_finish<dlc_f16_tag, 512, 4>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, false, st);
+}
+
+}  // namespace
+
+extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                               int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, float* out_scores,
+                               int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk: null output");
+    MatchCall mc;
+    int rc = prepare_match(ctx, "cosine_topk", dtype, Q, q, ldq, DB, n, lddb, d, k, workspace, workspace_bytes, &mc);
+    if (rc != DLC_OK) return rc;
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    rc = run_score(ctx, dtype, mc, (hipStream_t)stream);
+    if (rc != DLC_OK) return rc;
+    return run_select(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, 0, (hipStream_t)stream);
+}
+
+extern "C" int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                                       int64_t n, int64_t lddb, int64_t d, int k, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    MatchCall mc;
+    int rc = prepare_match(ctx, "cosine_score_groups", dtype, Q, q, ldq, DB, n, lddb, d, k, workspace, workspace_bytes, &mc);
+    if (rc != DLC_OK) return rc;
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    return run_score(ctx, dtype, mc, (hipStream_t)stream);
+}
+
+extern "C" int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                                      int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, float* out_scores,
+                                      int64_t* out_idx, void* workspace, size_t workspace_bytes, int flags,
+                                      void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_select_topk: null output");
+    MatchCall mc;
+    int rc = prepare_match(ctx, "cosine_select_topk", dtype, Q, q, ldq, DB, n, lddb, d, k, workspace, workspace_bytes, &mc);
+    if (rc != DLC_OK) return rc;
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    return run_select(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, flags, (hipStream_t)stream);
 }
 
 extern "C" int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* idx, int parts, int64_t q, int k,

@@ -244,6 +244,28 @@ class Engine:
                                               ws.numel(), self._stream()))
         return scores, idx
 
+    def topk_workspace_bytes(self, nq, n, d, k):
+        need = self.lib.dlc_cosine_topk_workspace_bytes(nq, n, d, k)
+        if need == 0:
+            raise ValueError("k=%d outside 1..%d (or empty operand)" % (k, L.DLC_MAX_K))
+        return need
+
+    def score_groups(self, q, db, k, ws, stream=None):
+        """Stage 1 of match_topk (the MFMA score GEMM) into the caller's workspace tensor."""
+        self._check_stored(q, db)
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        self._check(self.lib.dlc_cosine_score_groups(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
+                                                      _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, _ptr(ws),
+                                                      ws.numel(), st))
+
+    def select_topk(self, q, db, k, ws, scores, idx, row_offset=0, coop=False, stream=None):
+        """Stage 2 of match_topk (selection, exact re-score, final top-k) from the workspace."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        self._check(self.lib.dlc_cosine_select_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
+                                                     _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, row_offset,
+                                                     _ptr(scores), _ptr(idx), _ptr(ws), ws.numel(),
+                                                     L.DLC_SELECT_COOP if coop else 0, st))
+
     def topk_merge(self, scores, idx, out=None):
         """Merge [parts, Q, k] per-shard results into the global [Q, k]."""
         scores, idx = scores.contiguous(), idx.contiguous()

@@ -62,6 +62,86 @@ class KeyframeDatabase:
         return self.engine.cosine_scores(self.prepare_queries(queries), self.rows)
 
 
+class MatchPipeline:
+    """Two-stream pipelined top-k match against one resident shard.
+
+    The score GEMM of batch i+1 runs on the submitting stream while the selection /
+    re-score / final top-k of batch i (and, when sharded, the RCCL all-gather of the
+    per-shard results and the merge) run on a second stream: the selection is a
+    latency-bound gather whose small-footprint kernel shares the CUs with the GEMM, and
+    the collective's latency leaves the critical path.  `depth` batches are in flight,
+    each with its own workspace and output buffers; submit() returns a ticket,
+    result(ticket) waits for that batch only.  A result must be fetched before `depth`
+    further batches are submitted (its buffers are then reused).
+    """
+
+    def __init__(self, db, k, depth=2, group=None, queries_per_batch=None):
+        import torch.distributed as dist
+        self.db, self.k, self.depth = db, int(k), int(depth)
+        self.engine = db.engine
+        dev = self.engine.device
+        self.s_select = torch.cuda.Stream(device=dev)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._slots = []
+        self._count = 0
+        self._nq = queries_per_batch
+
+    def _slot(self, i, nq, d):
+        while len(self._slots) <= i:
+            self._slots.append(None)
+        s = self._slots[i]
+        if s is None or s["nq"] != nq:
+            dev = self.engine.device
+            need = self.engine.topk_workspace_bytes(nq, len(self.db), d, self.k)
+            s = {"nq": nq, "ws": torch.empty(need, dtype=torch.uint8, device=dev),
+                 "scores": torch.empty((nq, self.k), dtype=torch.float32, device=dev),
+                 "idx": torch.empty((nq, self.k), dtype=torch.int64, device=dev),
+                 "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "q": None}
+            if self.world > 1:
+                s["g_scores"] = torch.empty((self.world, nq, self.k), dtype=torch.float32, device=dev)
+                s["g_idx"] = torch.empty((self.world, nq, self.k), dtype=torch.int64, device=dev)
+                s["m_scores"] = torch.empty((nq, self.k), dtype=torch.float32, device=dev)
+                s["m_idx"] = torch.empty((nq, self.k), dtype=torch.int64, device=dev)
+            self._slots[i] = s
+        return s
+
+    def submit(self, queries):
+        import torch.distributed as dist
+        q = self.db.prepare_queries(queries)
+        eng = self.engine
+        i = self._count % self.depth
+        s = self._slot(i, q.shape[0], q.shape[1])
+        main = torch.cuda.current_stream(eng.device)
+        if s["busy"]:
+            main.wait_event(s["done"])          # the workspace / outputs of this slot are free again
+        s["q"] = q                              # keep the stored queries alive until the batch is done
+        eng.score_groups(q, self.db.rows, self.k, s["ws"], stream=main)
+        s["scored"].record(main)
+        self.s_select.wait_event(s["scored"])
+        with torch.cuda.stream(self.s_select):
+            eng.select_topk(q, self.db.rows, self.k, s["ws"], s["scores"], s["idx"], row_offset=self.db.row_offset,
+                            coop=True, stream=self.s_select)
+            if self.world > 1:
+                dist.all_gather_into_tensor(s["g_scores"].view(-1, self.k), s["scores"], group=self.group)
+                dist.all_gather_into_tensor(s["g_idx"].view(-1, self.k), s["idx"], group=self.group)
+                eng.topk_merge(s["g_scores"], s["g_idx"], out=(s["m_scores"], s["m_idx"]))
+            s["done"].record(self.s_select)
+        s["busy"] = True
+        self._count += 1
+        return self._count - 1
+
+    def result(self, ticket):
+        s = self._slots[ticket % self.depth]
+        s["done"].synchronize()
+        if self.world > 1:
+            return s["m_scores"], s["m_idx"]
+        return s["scores"], s["idx"]
+
+    def drain(self):
+        self.s_select.synchronize()
+
+
 def match(desc_q, desc_db, dtype="bf16", center=False):
     """Dense cosine-similarity matrix [Q, N] (float32 numpy)."""
     db = KeyframeDatabase(desc_db, dtype=dtype, center=center)

@@ -195,6 +195,26 @@ int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t l
                     float* out_scores, int64_t* out_idx,
                     void* workspace, size_t workspace_bytes, void* stream);
 /*
+ * The two stages of dlc_cosine_topk as separate calls, for callers that pipeline batches
+ * over two streams (stage 2 of batch i overlapping stage 1 of batch i+1, each batch with its
+ * own workspace):
+ *   dlc_cosine_score_groups  -- the MFMA score GEMM; fills the workspace (per-query maxima of
+ *                               every 8 / 128 database rows), reads Q and DB;
+ *   dlc_cosine_select_topk   -- group selection, exact fp32 re-score, final top-k; reads the
+ *                               workspace (and consumes it), Q and DB.
+ * Same operand rules, same workspace size (dlc_cosine_topk_workspace_bytes), same results.
+ * flags: DLC_SELECT_COOP selects a small-footprint kernel (256 threads, ~70 VGPRs, a few KiB
+ * of LDS) whose workgroups can share a CU with a running score GEMM.
+ */
+#define DLC_SELECT_COOP 1
+int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
+                            const void* DB, int64_t n, int64_t lddb, int64_t d, int k,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
+                           const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
+                           float* out_scores, int64_t* out_idx,
+                           void* workspace, size_t workspace_bytes, int flags, void* stream);
+/*
  * Merge `parts` per-shard results ([parts, q, k], as an all-gather leaves
  * them) into the global top-k with the same ordering rule.
  */

@@ -409,3 +409,28 @@ def test_cnn_vtl_surface(dlc):
     assert y1.shape == (1, net.columns.size) and d >= 0
     with pytest.raises(ValueError):
         net.transform(np.ones((1, 100, 100, 3)))
+
+
+def test_pipeline_and_coop_select_equal_one_shot(eng, dlc):
+    """Two-stream MatchPipeline (cooperative select kernel) == the one-shot call, batch after batch."""
+    rng = np.random.RandomState(21)
+    n, d, nq, k = 70000, 512, 200, 20
+    db = dlc.KeyframeDatabase(rng.standard_normal((n, d)).astype(np.float32), dtype="bf16", row_offset=5)
+    batches = [db.prepare_queries(rng.standard_normal((nq, d)).astype(np.float32)) for _ in range(5)]
+    want = [tuple(t.clone() for t in db.match_topk(q, k)) for q in batches]
+    pipe = dlc.MatchPipeline(db, k, depth=2)
+    tickets, got = [], []
+    for j, q in enumerate(batches):
+        tickets.append(pipe.submit(q))
+        if j >= 1:                                   # fetch with one batch of lag, as a server would
+            got.append(tuple(t.clone() for t in pipe.result(tickets[j - 1])))
+    got.append(tuple(t.clone() for t in pipe.result(tickets[-1])))
+    for (ws, wi), (gs, gi) in zip(want, got):
+        assert torch.equal(wi, gi) and torch.equal(ws, gs)
+    # stage-wise C ABI with the cooperative kernel on ONE stream as well
+    ws_buf = torch.empty(eng.topk_workspace_bytes(nq, n, d, k), dtype=torch.uint8, device=eng.device)
+    s = torch.empty((nq, k), dtype=torch.float32, device=eng.device)
+    i = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
+    eng.score_groups(batches[0], db.rows, k, ws_buf)
+    eng.select_topk(batches[0], db.rows, k, ws_buf, s, i, row_offset=5, coop=True)
+    assert torch.equal(i, want[0][1]) and torch.equal(s, want[0][0])
