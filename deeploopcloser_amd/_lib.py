@@ -45,6 +45,12 @@ SIGNATURES = {
     "dlc_cosine_score_groups": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _vp, _sz, _vp]),
     "dlc_cosine_select_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _sz,
                                      _int, _vp]),
+    "dlc_cosine_groups_per_query": (_int, [_int]),
+    "dlc_cosine_select_groups": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _vp, _sz, _vp, _vp, _int,
+                                       _vp]),
+    "dlc_cosine_rescore_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _int,
+                                      _vp, _vp, _int, _vp]),
+    "dlc_topk_merge_strided": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp]),
     "dlc_topk_merge": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp]),
     "dlc_cosine_scores": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "dlc_set_profiling": (_int, [_vp, _int]),

@@ -416,11 +416,29 @@ __device__ __forceinline__ void rank_select(const unsigned long long* keys, int 
 // (256, 1) needs ~70 VGPRs and a few KiB of LDS so that its workgroups can share a CU with a
 // resident score-GEMM workgroup (128 KiB LDS, 2 x 198 VGPRs per SIMD) when the two run on
 // different streams.
-template <typename Tag, int THREADS, int RS_UNROLL>
+// MODE: FIN_FUSED  all of it;
+//       FIN_GROUPS stops after the group selection and writes the kg selected groups of every query
+//                  (grp_ids, -1 = none; grp_max, their maxima, in rank order);
+//       FIN_RESCORE starts from such a list.  With parts > 0 it first drops every own group that
+//                  cannot be among the kg best groups of the WHOLE database: all_max holds the
+//                  lists of all `parts` shards ([parts, q, kg], an all-gather of grp_max), and a
+//                  group with kg or more strictly larger maxima anywhere is out.  Each shard then
+//                  re-scores ~kg/parts groups per query instead of kg.
+enum { FIN_FUSED = 0, FIN_GROUPS = 1, FIN_RESCORE = 2 };
+struct FinishExtra {
+    int* grp_ids;             // [q, kg]
+    float* grp_max;           // [q, kg]
+    const float* all_max;     // [parts, q, kg] or null
+    int parts;
+    long long nq;
+};
+
+template <typename Tag, int THREADS, int RS_UNROLL, int MODE>
 __global__ __launch_bounds__(THREADS) void finish_topk_kernel(
     float* __restrict__ tmax, long long ldt, int nh, int tv_in_lds, const float* __restrict__ gmax, long long ldg,
     long long ng, int kg, const char* __restrict__ Q, long long ldq_b, const char* __restrict__ DB, long long lddb_b,
-    long long n, int d, int k, long long row_offset, float* __restrict__ out_s, long long* __restrict__ out_i) {
+    long long n, int d, int k, long long row_offset, float* __restrict__ out_s, long long* __restrict__ out_i,
+    FinishExtra x) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int FIN_WAVES = THREADS / 64;
     constexpr int FIN_THREADS = THREADS;      // shadows the namespace constant inside this kernel
@@ -437,7 +455,8 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(
         for (int e = tid; e < nh; e += FIN_THREADS) tv[e] = tmax[(long long)qi * ldt + e];
     for (int e = tid; e < kg; e += FIN_THREADS) { sel[e] = -1; sel2[e] = -1; }
     __syncthreads();
-
+    int kg2;
+    if constexpr (MODE != FIN_RESCORE) {
     // ---- level 1: the kt half tiles with the largest maximum (ties -> lower tile).
     // Each wave extracts the kt best of its slice by repeated wave arg-max (DPP, no barrier);
     // the FIN_WAVES * kt survivors are ranked together.
@@ -480,11 +499,37 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(
         ckey[e] = (ht >= 0 && g < ng) ? pack_key(gmax[(long long)qi * ldg + g], (unsigned)g) : 0ull;
     }
     __syncthreads();
-    const int kg2 = min(kg, m2);
+    kg2 = min(kg, m2);
     rank_select(ckey, m2, kg2, sel2);
     __syncthreads();
+    if constexpr (MODE == FIN_GROUPS) {
+        for (int e = tid; e < kg; e += FIN_THREADS) {
+            const int c = e < kg2 ? sel2[e] : -1;
+            x.grp_ids[(long long)qi * kg + e] = c < 0 ? -1 : (int)key_id(ckey[c]);
+            x.grp_max[(long long)qi * kg + e] = c < 0 ? -INFINITY : gmax[(long long)qi * ldg + key_id(ckey[c])];
+        }
+        return;
+    }
     if (tid < kg2) { const int c = sel2[tid]; sel2[tid] = c < 0 ? -1 : (int)key_id(ckey[c]); }   // -> group index
     __syncthreads();
+    } else {
+        // ---- start from a group list; optionally filter it against the other shards' maxima
+        kg2 = kg;
+        for (int e = tid; e < kg; e += FIN_THREADS) {
+            int g = x.grp_ids[(long long)qi * kg + e];
+            if (g >= 0 && x.parts > 0) {
+                const float v = x.grp_max[(long long)qi * kg + e];
+                int greater = 0;
+                for (int pp = 0; pp < x.parts; ++pp) {
+                    const float* av = x.all_max + ((long long)pp * x.nq + qi) * kg;
+                    for (int j = 0; j < kg; ++j) greater += av[j] > v ? 1 : 0;
+                }
+                if (greater >= kg) g = -1;
+            }
+            sel2[e] = g;
+        }
+        __syncthreads();
+    }
 
     // ---- re-score: wave w takes groups w, w+8, ...; GROUP exact fp32 dot products each
     const char* qrow = Q + (long long)qi * ldq_b;
@@ -575,8 +620,10 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(
 // Global top-k from [parts, q, k] per-shard results (the all-gather layout); idx < 0 = empty slot.
 // Rank-by-counting on (score key, id): ids are unique, so the order is total.
 __global__ __launch_bounds__(FIN_THREADS) void merge_topk_kernel(const float* __restrict__ pscores,
-                                                                 const long long* __restrict__ pidx, int parts,
-                                                                 long long nq, int k, float* __restrict__ out_s,
+                                                                 long long s_stride,
+                                                                 const long long* __restrict__ pidx,
+                                                                 long long i_stride, int parts, long long nq, int k,
+                                                                 float* __restrict__ out_s,
                                                                  long long* __restrict__ out_i) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     const int qi = blockIdx.x, tid = threadIdx.x;
@@ -585,9 +632,9 @@ __global__ __launch_bounds__(FIN_THREADS) void merge_topk_kernel(const float* __
     unsigned* sk = (unsigned*)(dsm + (size_t)m * 8);
     float* cs = (float*)(dsm + (size_t)m * 12);
     for (int e = tid; e < m; e += FIN_THREADS) {
-        const long long o = ((long long)(e / k) * nq + qi) * k + (e % k);
-        const long long id = pidx[o];
-        const float s = pscores[o];
+        const long long o = (long long)qi * k + (e % k);
+        const long long id = pidx[(long long)(e / k) * i_stride + o];
+        const float s = pscores[(long long)(e / k) * s_stride + o];
         ci[e] = id; cs[e] = s;
         sk[e] = id < 0 ? 0u : f32_key(s);
     }
@@ -756,32 +803,33 @@ int run_score(dlc_ctx* ctx, int dtype, MatchCall& mc, hipStream_t st) {
     return DLC_OK;
 }
 
-template <typename Tag, int THREADS, int RS_UNROLL>
+template <typename Tag, int THREADS, int RS_UNROLL, int MODE>
 int launch_finish(dlc_ctx* ctx, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
-                  float* out_scores, int64_t* out_idx, bool small_lds, hipStream_t st) {
+                  float* out_scores, int64_t* out_idx, bool small_lds, const FinishExtra& x, hipStream_t st) {
     const GemmArgs& a = mc.a;
     size_t dsm = fin_lds_fixed(mc.w.kg);
-    const int tv_in_lds = !small_lds && (size_t)a.nh * 4 <= 96 * 1024;
+    const int tv_in_lds = MODE != FIN_RESCORE && !small_lds && (size_t)a.nh * 4 <= 96 * 1024;
     if (tv_in_lds) dsm += (size_t)a.nh * 4;
     dsm = dlc::align_up(dsm, 16);
-    auto fk = finish_topk_kernel<Tag, THREADS, RS_UNROLL>;
+    auto fk = finish_topk_kernel<Tag, THREADS, RS_UNROLL, MODE>;
     if (dsm > 48 * 1024)
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm));
     hipLaunchKernelGGL(fk, dim3((unsigned)q), dim3(THREADS), dsm, st, a.tmax, a.ldt, (int)a.nh, tv_in_lds, a.gmax, a.ldg,
                        a.ng, mc.w.kg, a.Q, a.ldq_b, a.DB, a.lddb_b, (long long)n, (int)d, k, (long long)row_offset,
-                       out_scores, (long long*)out_idx);
+                       out_scores, (long long*)out_idx, x);
     DLC_LAUNCH_CHECK(ctx, "finish_topk_kernel");
     return DLC_OK;
 }
 
+template <int MODE>
 int run_select(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
-               float* out_scores, int64_t* out_idx, int flags, hipStream_t st) {
+               float* out_scores, int64_t* out_idx, int flags, const FinishExtra& x, hipStream_t st) {
     const bool coop = (flags & DLC_SELECT_COOP) != 0;
     if (dtype == DLC_BF16)
-        return coop ? launch_finish<dlc_bf16_tag, 256, 1>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, true, st)
-                    : launch_finish<dlc_bf16_tag, 512, 4>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, false, st);
-    return coop ? launch_finish<dlc_f16_tag, 256, 1>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, true, st)
-                : launch_finish<dlc_f16_tag, 512, 4>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, false, st);
+        return coop ? launch_finish<dlc_bf16_tag, 256, 1, MODE>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, true, x, st)
+                    : launch_finish<dlc_bf16_tag, 512, 4, MODE>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, false, x, st);
+    return coop ? launch_finish<dlc_f16_tag, 256, 1, MODE>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, true, x, st)
+                : launch_finish<dlc_f16_tag, 512, 4, MODE>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, false, x, st);
 }
 
 }  // namespace
@@ -798,7 +846,7 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     rc = run_score(ctx, dtype, mc, (hipStream_t)stream);
     if (rc != DLC_OK) return rc;
-    return run_select(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, 0, (hipStream_t)stream);
+    return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, 0, FinishExtra{}, (hipStream_t)stream);
 }
 
 extern "C" int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
@@ -824,13 +872,58 @@ extern "C" int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, in
     if (rc != DLC_OK) return rc;
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    return run_select(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, flags, (hipStream_t)stream);
+    return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, flags, FinishExtra{}, (hipStream_t)stream);
 }
 
-extern "C" int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* idx, int parts, int64_t q, int k,
-                              float* out_scores, int64_t* out_idx, void* stream) {
+extern "C" int dlc_cosine_groups_per_query(int k) { return (k < 1 || k > DLC_MAX_K) ? 0 : k + SLACK; }
+
+extern "C" int dlc_cosine_select_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                                        int64_t n, int64_t lddb, int64_t d, int k, void* workspace,
+                                        size_t workspace_bytes, int32_t* group_ids, float* group_max, int flags,
+                                        void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
-    if (!scores || !idx || !out_scores || !out_idx || parts < 1 || q < 1 || k < 1 || k > DLC_MAX_K)
+    if (!group_ids || !group_max) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_select_groups: null output");
+    MatchCall mc;
+    int rc = prepare_match(ctx, "cosine_select_groups", dtype, Q, q, ldq, DB, n, lddb, d, k, workspace, workspace_bytes, &mc);
+    if (rc != DLC_OK) return rc;
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    FinishExtra x{};
+    x.grp_ids = group_ids; x.grp_max = group_max; x.nq = q;
+    return run_select<FIN_GROUPS>(ctx, dtype, mc, k, n, d, q, 0, nullptr, nullptr, flags, x, (hipStream_t)stream);
+}
+
+extern "C" int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                                       int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
+                                       const int32_t* group_ids, const float* group_max, const float* all_group_max,
+                                       int parts, float* out_scores, int64_t* out_idx, int flags, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!out_scores || !out_idx || !group_ids || !group_max || parts < 0 || (parts > 0 && !all_group_max))
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_rescore_topk: bad argument");
+    int rc = check_operands(ctx, dtype, Q, q, ldq, DB, n, lddb, d);
+    if (rc != DLC_OK) return rc;
+    if (k < 1 || k > DLC_MAX_K) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_rescore_topk: k=%d outside 1..%d", k, DLC_MAX_K);
+    MatchCall mc;                                   // no workspace needed: only the operands and kg
+    mc.w = ws_layout(q, n, k);
+    mc.a = GemmArgs{};
+    mc.a.Q = (const char*)Q; mc.a.DB = (const char*)DB;
+    mc.a.ldq_b = ldq * 2; mc.a.lddb_b = lddb * 2;
+    mc.a.q = (int)q; mc.a.n = n; mc.a.nk = (int)(d / BK);
+    mc.a.ng = dlc::cdiv(n, GROUP); mc.a.nh = dlc::cdiv(n, HALF);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    FinishExtra x{};
+    x.grp_ids = const_cast<int32_t*>(group_ids); x.grp_max = const_cast<float*>(group_max);
+    x.all_max = all_group_max; x.parts = parts; x.nq = q;
+    return run_select<FIN_RESCORE>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, flags, x, (hipStream_t)stream);
+}
+
+extern "C" int dlc_topk_merge_strided(dlc_ctx* ctx, const float* scores, int64_t score_part_stride, const int64_t* idx,
+                                      int64_t idx_part_stride, int parts, int64_t q, int k, float* out_scores,
+                                      int64_t* out_idx, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!scores || !idx || !out_scores || !out_idx || parts < 1 || q < 1 || k < 1 || k > DLC_MAX_K ||
+        score_part_stride < q * k || idx_part_stride < q * k)
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "topk_merge: bad argument");
     const size_t m = (size_t)parts * k;
     const size_t dsm = m * 16;
@@ -838,9 +931,15 @@ extern "C" int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* 
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)q), dim3(FIN_THREADS), dsm, (hipStream_t)stream, scores,
-                       (const long long*)idx, parts, (long long)q, k, out_scores, (long long*)out_idx);
+                       (long long)score_part_stride, (const long long*)idx, (long long)idx_part_stride, parts,
+                       (long long)q, k, out_scores, (long long*)out_idx);
     DLC_LAUNCH_CHECK(ctx, "merge_topk_kernel");
     return DLC_OK;
+}
+
+extern "C" int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* idx, int parts, int64_t q, int k,
+                              float* out_scores, int64_t* out_idx, void* stream) {
+    return dlc_topk_merge_strided(ctx, scores, q * k, idx, q * k, parts, q, k, out_scores, out_idx, stream);
 }
 
 extern "C" int dlc_cosine_scores(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,

@@ -266,6 +266,43 @@ class Engine:
                                                      _ptr(scores), _ptr(idx), _ptr(ws), ws.numel(),
                                                      L.DLC_SELECT_COOP if coop else 0, st))
 
+    def groups_per_query(self, k):
+        kg = self.lib.dlc_cosine_groups_per_query(k)
+        if kg == 0:
+            raise ValueError("k=%d outside 1..%d" % (k, L.DLC_MAX_K))
+        return kg
+
+    def select_groups(self, q, db, k, ws, grp_ids, grp_max, coop=False, stream=None):
+        """Stage 2a: the kg best groups of every query (shard-local ids + their maxima)."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        self._check(self.lib.dlc_cosine_select_groups(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
+                                                       _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, _ptr(ws),
+                                                       ws.numel(), _ptr(grp_ids), _ptr(grp_max),
+                                                       L.DLC_SELECT_COOP if coop else 0, st))
+
+    def rescore_topk(self, q, db, k, grp_ids, grp_max, scores, idx, all_max=None, row_offset=0, coop=False, stream=None):
+        """Stage 2b: exact re-score of the listed groups (filtered against all shards' maxima
+        when all_max [parts, Q, kg] is given) and the shard's top-k."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        parts = 0 if all_max is None else all_max.shape[0]
+        self._check(self.lib.dlc_cosine_rescore_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
+                                                      _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, row_offset,
+                                                      _ptr(grp_ids), _ptr(grp_max), _ptr(all_max), parts, _ptr(scores),
+                                                      _ptr(idx), L.DLC_SELECT_COOP if coop else 0, st))
+
+    def topk_merge_packed(self, gathered, nq, k, out):
+        """Merge an all-gather of packed per-shard results: gathered is uint8 [parts, nq*k*12],
+        each part = int64 idx [nq,k] followed by float32 scores [nq,k]."""
+        parts = gathered.shape[0]
+        if (nq * k) % 2:
+            raise ValueError("packed merge needs an even nq*k")
+        base = gathered.data_ptr()
+        o_s, o_i = out
+        self._check(self.lib.dlc_topk_merge_strided(self.ctx, C.c_void_p(base + nq * k * 8), nq * k * 3,
+                                                     C.c_void_p(base), nq * k * 3 // 2, parts, nq, k, _ptr(o_s),
+                                                     _ptr(o_i), self._stream()))
+        return o_s, o_i
+
     def topk_merge(self, scores, idx, out=None):
         """Merge [parts, Q, k] per-shard results into the global [Q, k]."""
         scores, idx = scores.contiguous(), idx.contiguous()

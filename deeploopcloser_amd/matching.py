@@ -69,7 +69,10 @@ class MatchPipeline:
     re-score / final top-k of batch i (and, when sharded, the RCCL all-gather of the
     per-shard results and the merge) run on a second stream: the selection is a
     latency-bound gather whose small-footprint kernel shares the CUs with the GEMM, and
-    the collective's latency leaves the critical path.  `depth` batches are in flight,
+    the collectives' latency leaves the critical path.  Sharded: the ranks first all-gather the
+    maxima of their selected groups (Q*kg floats each) so that each rank re-scores only the
+    groups that can be among the best of the whole database, then all-gather the packed
+    per-shard top-k ([Q,k] int64 + fp32, one collective) and merge.  `depth` batches are in flight,
     each with its own workspace and output buffers; submit() returns a ticket,
     result(ticket) waits for that batch only.  A result must be fetched before `depth`
     further batches are submitted (its buffers are then reused).
@@ -99,8 +102,15 @@ class MatchPipeline:
                  "idx": torch.empty((nq, self.k), dtype=torch.int64, device=dev),
                  "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "q": None}
             if self.world > 1:
-                s["g_scores"] = torch.empty((self.world, nq, self.k), dtype=torch.float32, device=dev)
-                s["g_idx"] = torch.empty((self.world, nq, self.k), dtype=torch.int64, device=dev)
+                kg = self.engine.groups_per_query(self.k)
+                nb = nq * self.k * 12                      # packed result: int64 idx [nq,k] | float32 scores [nq,k]
+                s["pack"] = torch.empty(nb, dtype=torch.uint8, device=dev)
+                s["idx"] = s["pack"][:nq * self.k * 8].view(torch.int64).view(nq, self.k)
+                s["scores"] = s["pack"][nq * self.k * 8:].view(torch.float32).view(nq, self.k)
+                s["g_pack"] = torch.empty((self.world, nb), dtype=torch.uint8, device=dev)
+                s["grp_ids"] = torch.empty((nq, kg), dtype=torch.int32, device=dev)
+                s["grp_max"] = torch.empty((nq, kg), dtype=torch.float32, device=dev)
+                s["g_max"] = torch.empty((self.world, nq, kg), dtype=torch.float32, device=dev)
                 s["m_scores"] = torch.empty((nq, self.k), dtype=torch.float32, device=dev)
                 s["m_idx"] = torch.empty((nq, self.k), dtype=torch.int64, device=dev)
             self._slots[i] = s
@@ -120,12 +130,19 @@ class MatchPipeline:
         s["scored"].record(main)
         self.s_select.wait_event(s["scored"])
         with torch.cuda.stream(self.s_select):
-            eng.select_topk(q, self.db.rows, self.k, s["ws"], s["scores"], s["idx"], row_offset=self.db.row_offset,
-                            coop=True, stream=self.s_select)
-            if self.world > 1:
-                dist.all_gather_into_tensor(s["g_scores"].view(-1, self.k), s["scores"], group=self.group)
-                dist.all_gather_into_tensor(s["g_idx"].view(-1, self.k), s["idx"], group=self.group)
-                eng.topk_merge(s["g_scores"], s["g_idx"], out=(s["m_scores"], s["m_idx"]))
+            if self.world == 1:
+                eng.select_topk(q, self.db.rows, self.k, s["ws"], s["scores"], s["idx"],
+                                row_offset=self.db.row_offset, coop=True, stream=self.s_select)
+            else:
+                # exchange the selected groups' maxima first, so that every shard re-scores only the
+                # groups that can be among the best of the WHOLE database (~kg/world per query)
+                eng.select_groups(q, self.db.rows, self.k, s["ws"], s["grp_ids"], s["grp_max"], coop=True,
+                                  stream=self.s_select)
+                dist.all_gather_into_tensor(s["g_max"].view(-1, s["g_max"].shape[-1]), s["grp_max"], group=self.group)
+                eng.rescore_topk(q, self.db.rows, self.k, s["grp_ids"], s["grp_max"], s["scores"], s["idx"],
+                                 all_max=s["g_max"], row_offset=self.db.row_offset, coop=True, stream=self.s_select)
+                dist.all_gather_into_tensor(s["g_pack"].view(-1), s["pack"], group=self.group)
+                eng.topk_merge_packed(s["g_pack"], q.shape[0], self.k, out=(s["m_scores"], s["m_idx"]))
             s["done"].record(self.s_select)
         s["busy"] = True
         self._count += 1

@@ -215,11 +215,39 @@ int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, in
                            float* out_scores, int64_t* out_idx,
                            void* workspace, size_t workspace_bytes, int flags, void* stream);
 /*
+ * Stage 2 split once more, for a database sharded over several GPUs.  Each shard would
+ * otherwise re-score its own kg = dlc_cosine_groups_per_query(k) best groups per query, whatever
+ * the shard size; exchanging the groups' MAXIMA first lets every shard skip the groups that
+ * cannot be among the kg best of the whole database:
+ *   dlc_cosine_select_groups -- from the workspace: group_ids [q,kg] (int32 shard-local group
+ *                               index, -1 = none) and group_max [q,kg] (fp32), in rank order;
+ *   (caller: all-gather group_max over the `parts` shards -> all_group_max [parts,q,kg])
+ *   dlc_cosine_rescore_topk  -- drops every own group with >= kg strictly larger maxima in
+ *                               all_group_max (parts = 0: no filter), re-scores the rest in
+ *                               exact fp32 and returns the shard's top-k as dlc_cosine_topk does.
+ * The union of the shards' results still contains the global top-k (merge with dlc_topk_merge).
+ */
+int dlc_cosine_groups_per_query(int k);
+int dlc_cosine_select_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
+                             const void* DB, int64_t n, int64_t lddb, int64_t d, int k,
+                             void* workspace, size_t workspace_bytes,
+                             int32_t* group_ids, float* group_max, int flags, void* stream);
+int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
+                            const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
+                            const int32_t* group_ids, const float* group_max,
+                            const float* all_group_max, int parts,
+                            float* out_scores, int64_t* out_idx, int flags, void* stream);
+/*
  * Merge `parts` per-shard results ([parts, q, k], as an all-gather leaves
  * them) into the global top-k with the same ordering rule.
  */
 int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* idx, int parts, int64_t q, int k,
                    float* out_scores, int64_t* out_idx, void* stream);
+/* Same with explicit distances (in elements) between consecutive parts, for results that were
+ * gathered as one packed buffer per shard. */
+int dlc_topk_merge_strided(dlc_ctx* ctx, const float* scores, int64_t score_part_stride,
+                           const int64_t* idx, int64_t idx_part_stride, int parts, int64_t q, int k,
+                           float* out_scores, int64_t* out_idx, void* stream);
 /*
  * Dense score block S[q, n] (fp32) = Q . DB^T for the all-vs-all cosine
  * matrix of config 2 (small N); same operand rules as dlc_cosine_topk.

@@ -434,3 +434,53 @@ def test_pipeline_and_coop_select_equal_one_shot(eng, dlc):
     eng.score_groups(batches[0], db.rows, k, ws_buf)
     eng.select_topk(batches[0], db.rows, k, ws_buf, s, i, row_offset=5, coop=True)
     assert torch.equal(i, want[0][1]) and torch.equal(s, want[0][0])
+
+
+def test_group_exchange_protocol_equals_unsharded(eng, dlc):
+    """The sharded protocol of MatchPipeline, emulated with 4 shards on one GPU: select groups per
+    shard, 'all-gather' their maxima, filtered re-score per shard, packed merge == one shard."""
+    rng = np.random.RandomState(33)
+    n, d, nq, k, parts = 50000, 256, 96, 20, 4
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[[100, 20000, 20001, 40000]] = x[7]                       # exact ties across shards
+    db = stored(eng, x, "bf16")
+    q = stored(eng, np.concatenate([x[[7, 9]], rng.standard_normal((nq - 2, d)).astype(np.float32)]), "bf16")
+    want_s, want_i = eng.match_topk(q, db, k)
+    kg = eng.groups_per_query(k)
+    ids, mx, shards = [], [], []
+    for r in range(parts):
+        lo, hi = dlc.shard_bounds(n, parts, r)
+        ws = torch.empty(eng.topk_workspace_bytes(nq, hi - lo, d, k), dtype=torch.uint8, device=eng.device)
+        gi = torch.empty((nq, kg), dtype=torch.int32, device=eng.device)
+        gm = torch.empty((nq, kg), dtype=torch.float32, device=eng.device)
+        eng.score_groups(q, db[lo:hi], k, ws)
+        eng.select_groups(q, db[lo:hi], k, ws, gi, gm, coop=(r % 2 == 1))
+        ids.append(gi), mx.append(gm), shards.append((lo, hi))
+    all_max = torch.stack(mx)
+    gathered = torch.empty((parts, nq * k * 12), dtype=torch.uint8, device=eng.device)
+    kept = 0
+    for r, (lo, hi) in enumerate(shards):
+        idx = gathered[r, :nq * k * 8].view(torch.int64).view(nq, k)
+        sc = gathered[r, nq * k * 8:].view(torch.float32).view(nq, k)
+        eng.rescore_topk(q, db[lo:hi], k, ids[r], mx[r], sc, idx, all_max=all_max, row_offset=lo, coop=(r % 2 == 0))
+        # no returned row may come from a group the filter must drop, and the filter must bite
+        grp = torch.div(idx - lo, 8, rounding_mode="floor")                                 # [nq, k]
+        pos = (ids[r].long().unsqueeze(1) == grp.unsqueeze(2))                              # [nq, k, kg]
+        valid = idx >= 0                                                                    # empty slots: too few survivors
+        assert bool((pos.any(dim=2) | ~valid).all())
+        gval = (mx[r].unsqueeze(1) * pos).sum(dim=2)                                        # that group's maximum
+        greater = (all_max.permute(1, 0, 2).reshape(nq, 1, -1) > gval.unsqueeze(2)).sum(dim=2)
+        assert bool(((greater < kg) | ~valid).all())
+        own = (all_max.permute(1, 0, 2).reshape(nq, 1, -1) > mx[r].unsqueeze(2)).sum(dim=2) < kg   # [nq, kg]
+        kept += int(own.sum())
+        # unfiltered re-score of the same list == the fused one-shot result of that shard
+        s2 = torch.empty((nq, k), dtype=torch.float32, device=eng.device)
+        i2 = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
+        eng.rescore_topk(q, db[lo:hi], k, ids[r], mx[r], s2, i2, all_max=None, row_offset=lo)
+        s1, i1 = eng.match_topk(q, db[lo:hi], k, row_offset=lo)
+        assert torch.equal(i1, i2) and torch.equal(s1, s2)
+    o_s = torch.empty((nq, k), dtype=torch.float32, device=eng.device)
+    o_i = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
+    eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i))
+    assert torch.equal(o_i, want_i) and torch.equal(o_s, want_s)
+    assert kept <= nq * (kg + 4) and kept < parts * nq * kg * 0.5        # ~kg groups survive per query in total
