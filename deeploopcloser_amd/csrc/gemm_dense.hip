@@ -54,7 +54,7 @@ struct Args {
 };
 
 template <typename T, int BLAYOUT>
-__global__ __launch_bounds__(256) void gemm_bias_act_kernel(Args<T> p) {
+__global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     constexpr int LDB_S = BLAYOUT == DLC_B_KN ? LDB_KN : LDB_NK;
     constexpr int B_ELEMS = BLAYOUT == DLC_B_KN ? TK * LDB_KN : TN * LDB_NK;
     __shared__ T As[TM * LDA_S];
@@ -68,26 +68,48 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(Args<T> p) {
     const int bkn_k = tid >> 4, bkn_n = (tid & 15) * 8;         // B[K,N]: 16 threads per k row, 8 n each
     T ra[8], rb[8];
 
+    // interior tiles (the common case) load without per-element predicates
+    const bool rows_full = (m0 + TM <= p.M);
+    const bool cols_full = (n0 + TN <= p.N);
     auto load_tile = [&](long long k0) {
+        const bool k_full = (k0 + TK <= p.K);
         const long long gm = m0 + a_row;
+        if (rows_full && k_full) {
+            const T* src = p.A + gm * p.lda + k0 + a_k;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const long long gk = k0 + a_k + e;
-            ra[e] = (gm < p.M && gk < p.K) ? p.A[gm * p.lda + gk] : (T)0;
-        }
-        if constexpr (BLAYOUT == DLC_B_KN) {
-            const long long gk = k0 + bkn_k;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const long long gn = n0 + bkn_n + e;
-                rb[e] = (gk < p.K && gn < p.N) ? p.B[gk * p.ldb + gn] : (T)0;
-            }
+            for (int e = 0; e < 8; ++e) ra[e] = src[e];
         } else {
-            const long long gn = n0 + a_row;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const long long gk = k0 + a_k + e;
-                rb[e] = (gn < p.N && gk < p.K) ? p.B[gn * p.ldb + gk] : (T)0;
+                ra[e] = (gm < p.M && gk < p.K) ? p.A[gm * p.lda + gk] : (T)0;
+            }
+        }
+        if constexpr (BLAYOUT == DLC_B_KN) {
+            const long long gk = k0 + bkn_k;
+            if (cols_full && k_full) {
+                const T* src = p.B + gk * p.ldb + n0 + bkn_n;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rb[e] = src[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const long long gn = n0 + bkn_n + e;
+                    rb[e] = (gk < p.K && gn < p.N) ? p.B[gk * p.ldb + gn] : (T)0;
+                }
+            }
+        } else {
+            const long long gn = n0 + a_row;
+            if (cols_full && k_full) {
+                const T* src = p.B + gn * p.ldb + k0 + a_k;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rb[e] = src[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const long long gk = k0 + a_k + e;
+                    rb[e] = (gn < p.N && gk < p.K) ? p.B[gn * p.ldb + gk] : (T)0;
+                }
             }
         }
     };
