@@ -6,6 +6,7 @@ include/dlc.h, with the reference's Python call surface on top:
 
     SDAV, DA                      (src/sdav/network)
     CnnVtl                        (src/cnn_vtl/network)
+    CvInputParser                 (src/sdav/input; key-points supplied by the caller)
     SimilarityCalculator          (src/sdav/similarity)
     DistanceCalculator            (src/cnn_vtl/similarity)
     MathUtils                     (src/utils/MathUtils.py)
@@ -24,8 +25,10 @@ from .similarity import SimilarityCalculator
 from .distance import DistanceCalculator
 from .matching import encode, match, match_topk, KeyframeDatabase, MatchPipeline, flatten_frame_descriptors
 from .dist import ShardedKeyframeDatabase, shard_bounds, merge_topk_torch
+from .input import CvInputParser, grid_key_points, read_ppm
 from . import tensor_wrapper
 
-__all__ = ["SDAV", "DA", "CnnVtl", "SimilarityCalculator", "DistanceCalculator", "MathUtils", "tensor_wrapper",
+__all__ = ["SDAV", "DA", "CnnVtl", "SimilarityCalculator", "DistanceCalculator", "MathUtils", "tensor_wrapper", "CvInputParser",
+           "grid_key_points", "read_ppm",
            "encode", "match", "match_topk", "KeyframeDatabase", "MatchPipeline", "ShardedKeyframeDatabase", "Engine",
            "default_engine", "shard_bounds", "merge_topk_torch", "flatten_frame_descriptors"]

@@ -83,6 +83,8 @@ class Engine:
                 t = t.to(dtype)
             return t.contiguous()
         a = np.ascontiguousarray(np.asarray(x))
+        if not a.flags.writeable:
+            a = a.copy()
         t = torch.from_numpy(a).to(self.device)
         if dtype is not None and t.dtype != dtype:
             t = t.to(dtype)
@@ -144,6 +146,25 @@ class Engine:
         out = torch.empty((rows, dims[-1]), dtype=dt, device=self.device)
         self._check(self.lib.dlc_sdav_encode(self.ctx, _TORCH_TO_DLC[dt], rows, n_layers, dims_c, _ptr(x2d), w_c, b_c,
                                               _ptr(out), _ptr(ws), ws.numel(), self._stream()))
+        return out
+
+    # ---- SDAV patch front-end --------------------------------------------------------------
+    def rgb_to_gray(self, rgb):
+        rgb = rgb.contiguous()
+        if rgb.dtype != torch.uint8 or rgb.shape[-1] != 3:
+            raise ValueError("rgb_to_gray: uint8 [..., 3] expected")
+        gray = torch.empty(rgb.shape[:-1], dtype=torch.uint8, device=self.device)
+        self._check(self.lib.dlc_rgb_to_gray_u8(self.ctx, _ptr(rgb), gray.numel(), _ptr(gray), self._stream()))
+        return gray
+
+    def extract_patches(self, gray, key_points, patch_size, dtype=torch.float64):
+        """gray uint8 [F,H,W], key_points int32 [F,P,2] -> [F,P,patch_size^2] pixel/255."""
+        gray, key_points = gray.contiguous(), key_points.contiguous()
+        f, h, w = gray.shape
+        p = key_points.shape[1]
+        out = torch.empty((f, p, patch_size * patch_size), dtype=dtype, device=self.device)
+        self._check(self.lib.dlc_extract_patches(self.ctx, _ptr(gray), f, h, w, _ptr(key_points), p, patch_size,
+                                                  _TORCH_TO_DLC[dtype], _ptr(out), self._stream()))
         return out
 
     # ---- CnnVtl pieces ---------------------------------------------------------------

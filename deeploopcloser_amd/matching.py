@@ -46,6 +46,23 @@ class KeyframeDatabase:
     def __len__(self):
         return self.rows.shape[0]
 
+    # ---- on-disk format: one .npz per shard ---------------------------------
+    def save(self, path):
+        """Stored rows as raw 16-bit words + what is needed to query them again."""
+        np.savez(path, rows_u16=self.rows.view(torch.int16).cpu().numpy().view(np.uint16),
+                 dtype=np.array(str(self.dtype).replace("torch.", "")), center=np.array(bool(self.center)),
+                 row_offset=np.array(self.row_offset, dtype=np.int64), format=np.array("dlc-keyframes-v1"))
+
+    @classmethod
+    def load(cls, path, device=None, row_offset=None):
+        z = np.load(path)
+        if str(z["format"]) != "dlc-keyframes-v1":
+            raise ValueError("%s is not a dlc-keyframes-v1 file" % path)
+        dt = torch_dtype(str(z["dtype"]))
+        rows = torch.from_numpy(z["rows_u16"].view(np.int16).copy()).view(dt)
+        return cls(rows, dtype=dt, center=bool(z["center"]), device=device, stored=True,
+                   row_offset=int(z["row_offset"]) if row_offset is None else row_offset)
+
     def prepare_queries(self, queries):
         x = self.engine.to_device(queries)
         if x.dtype in (torch.bfloat16, torch.float16):

@@ -109,6 +109,25 @@ int dlc_sdav_encode(dlc_ctx* ctx, int dtype, int64_t rows, int n_layers, const i
                     const void* x, const void* const* W, const void* const* b,
                     void* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- encode: SDAV patch front-end after key-point detection -------------------------------- */
+/*
+ * cv2.imread(path, IMREAD_GRAYSCALE) of a colour frame (src/sdav/input/CvInputParser.py:32):
+ * OpenCV's fixed-point BT.601, (R*4899 + G*9617 + B*1868 + 8192) >> 14, on interleaved uint8 RGB.
+ */
+int dlc_rgb_to_gray_u8(dlc_ctx* ctx, const uint8_t* rgb, int64_t n_pixels, uint8_t* gray, void* stream);
+/*
+ * CvInputParser.parse after get_top_n_key_points (CvInputParser.py:19-28, 49-123): for each of
+ * the P key-points of each frame a patch_size x patch_size window centred on it, shifted to
+ * stay inside the image (:74-86), flattened row-major and divided by 255.0.  gray is uint8
+ * [frames, H, W]; key_points int32 [frames, P, 2] holds (round(kp.pt[0]), round(kp.pt[1])) --
+ * as in the reference the first coordinate walks image dimension 0 (:111-119).  out is
+ * [frames, P, patch_size^2] in out_dtype (DLC_F64 or DLC_F32).  SURF itself (:36-46) is
+ * non-free OpenCV-contrib code and is not part of this library: key-points are an input.
+ */
+int dlc_extract_patches(dlc_ctx* ctx, const uint8_t* gray, int64_t frames, int H, int W,
+                        const int32_t* key_points, int P, int patch_size, int out_dtype, void* out,
+                        void* stream);
+
 /* ---- encode: CnnVtl pieces (src/cnn_vtl/network/cnn_vtl.py:28-133) ------ */
 /*
  * im2col for tf.layers.conv2d on NHWC fp64 (cnn_vtl.py:33-93): x[n,h,w,c] ->

@@ -21,4 +21,4 @@ Pinning status (see DESIGN.md "Oracle"):
   * cosine.py (cosine + top-k)              -- PARITY UNPINNED: the function does
     not exist in the reference; it is defined by BASELINE.json's north_star.
 """
-from . import tensor_ops, sdav, cnn_vtl, similarity, distance, cosine, math_utils  # noqa: F401
+from . import tensor_ops, sdav, cnn_vtl, similarity, distance, cosine, math_utils, patches  # noqa: F401

@@ -1,0 +1,111 @@
+"""Patch front-end and the config-1 plumbing on the reference's own frames
+(tests/golden/frames/*.ppm are data files of the reference's datasets/test)."""
+import glob
+import os
+from collections import namedtuple
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import patches as opatch
+
+FRAMES = sorted(glob.glob(os.path.join(GOLDEN, "frames", "*.ppm")))
+KP = namedtuple("KP", "pt response")
+
+
+def test_oracle_window_rule():
+    """get_1d_boundaries (CvInputParser.py:49-89): shift forward below 0, back above dim-1."""
+    c = np.array([[0, 0], [20, 20], [5, 235], [191, 239], [100, 120]])
+    lo, hi = opatch.get_1d_boundaries((192, 240), c, 41, 0)
+    assert lo.tolist() == [0, 0, 0, 151, 80] and hi.tolist() == [40, 40, 40, 191, 120]
+    lo, hi = opatch.get_1d_boundaries((192, 240), c, 41, 1)
+    assert lo.tolist() == [0, 0, 199, 199, 100] and hi.tolist() == [40, 40, 239, 239, 140]
+    with pytest.raises(ValueError):
+        opatch.get_1d_boundaries((192, 240), c, 40, 0)
+    with pytest.raises(ValueError):
+        opatch.get_1d_boundaries((192, 240), np.zeros((3, 3)), 41, 0)
+
+
+def test_oracle_reads_reference_frames():
+    assert len(FRAMES) == 3
+    img = opatch.read_ppm(FRAMES[0])
+    assert img.shape == (192, 240, 3) and img.dtype == np.uint8
+    g = opatch.bgr2gray_opencv(img)
+    assert g.shape == (192, 240) and 0 < g.mean() < 255
+    p = opatch.parse(g, [(96.5, 120.5), (0, 0)], 41)
+    assert p.shape == (2, 1681) and np.array_equal(p[1], (g[0:41, 0:41].reshape(-1) / 255.0))
+    assert np.array_equal(p[0], g[76:117, 100:141].reshape(-1) / 255.0)      # round(96.5)=96, round(120.5)=120
+
+
+@pytest.mark.gpu
+def test_patch_frontend_vs_oracle():
+    import deeploopcloser_amd as dlc
+    parser = dlc.CvInputParser()
+    rng = np.random.RandomState(0)
+    for path in FRAMES:
+        rgb = opatch.read_ppm(path)
+        gray = opatch.bgr2gray_opencv(rgb)
+        assert np.array_equal(dlc.default_engine().rgb_to_gray(torch.from_numpy(rgb.copy()).cuda()).cpu().numpy(), gray)
+        pts = dlc.grid_key_points(gray.shape, 24) + [(-3.2, 500.0), (191.5, 239.5), (0.5, 1.5), (2.5, 3.5), (95.49, 10), (10, 229.51)]
+        got = parser.parse(gray, pts)
+        assert got.dtype == np.float64 and got.shape == (30, 1681)
+        assert np.array_equal(got, opatch.parse(gray, pts, 41))
+        assert np.array_equal(parser.parse_from_path(path, pts), got)             # RGB file -> grey on the GPU
+        # cv2.KeyPoint-like objects: descending response, top n (CvInputParser.py:45-46)
+        kps = [KP(pt=(float(rng.uniform(0, 191)), float(rng.uniform(0, 239))), response=float(rng.rand())) for _ in range(50)]
+        want = opatch.parse(gray, [k.pt for k in sorted(kps, key=lambda k: -k.response)[:30]], 41)
+        assert np.array_equal(parser.parse(gray, kps), want)
+    assert parser.parse(gray, []).shape == (0, 1681)
+    with pytest.raises(ValueError):
+        dlc.CvInputParser(patch_size=40).parse(gray, pts)
+
+
+@pytest.mark.gpu
+def test_config1_plumbing_frames_to_matrices():
+    """configs[0]: reference frames -> patches -> SDAV descriptors -> cosine matrix + SDAV
+    similarity matrix, GPU vs oracle end to end."""
+    import deeploopcloser_amd as dlc
+    from oracle import sdav as osdav, similarity as osim, cosine as ocos
+    parser = dlc.CvInputParser()
+    net = dlc.SDAV(seed=4)
+    ws, bs = net.get_weights()
+    x = np.stack([parser.parse_from_path(p, dlc.grid_key_points((192, 240), 30)) for p in FRAMES])
+    xo = np.stack([opatch.parse(opatch.bgr2gray_opencv(opatch.read_ppm(p)), dlc.grid_key_points((192, 240), 30)) for p in FRAMES])
+    assert np.array_equal(x, xo) and x.shape == (3, 30, 1681)
+    h = dlc.encode(x, net)
+    ho = osdav.transform(xo, ws, bs)
+    assert h.shape == (90, 2500) and np.abs(h - ho).max() < 1e-10
+    frame_desc = dlc.flatten_frame_descriptors(h).numpy()                 # [3, 75000]
+    s = dlc.match(frame_desc, frame_desc)                                 # cosine 3x3 (bf16 storage)
+    so = ocos.scores(ocos.l2_normalize(frame_desc), ocos.l2_normalize(frame_desc))
+    assert s.shape == (3, 3) and np.abs(s - so).max() < 5e-3              # bf16 rounding of the stored rows
+    ts, ti = dlc.match_topk(frame_desc, frame_desc, 2)
+    assert ti[:, 0].tolist() == [0, 1, 2]
+    m = dlc.SimilarityCalculator(h.reshape(3, 30, 2500)).similarity_matrix()
+    assert np.array_equal(m, osim.similarity_matrix(ho.reshape(3, 30, 2500)))
+
+
+@pytest.mark.gpu
+def test_drivers_and_database_file(tmp_path):
+    import deeploopcloser_amd as dlc
+    from deeploopcloser_amd import drivers
+    frames_dir = os.path.join(GOLDEN, "frames")
+    sim = drivers.create_similarity_matrix(frames_dir, out_png=str(tmp_path / "sim.png"), network=dlc.SDAV(seed=4))
+    assert sim.shape == (3, 3) and sim.dtype == np.int64 and np.all(np.diag(sim) == -1) and np.array_equal(sim, sim.T)
+    dist = drivers.create_distance_matrix(frames_dir, out_png=str(tmp_path / "dist.png"))
+    assert dist.shape == (3, 3) and np.all(np.diag(dist) == 0) and np.array_equal(dist, dist.T) and dist.max() > 0
+    from PIL import Image
+    assert Image.open(tmp_path / "sim.png").size == (3, 3) and Image.open(tmp_path / "dist.png").size == (3, 3)
+    img = drivers.distance_image(dist)
+    assert img.max() == 255 and img.min() == 0
+    # key-frame DB shard round trip
+    rng = np.random.RandomState(0)
+    db = dlc.KeyframeDatabase(rng.standard_normal((500, 100)).astype(np.float32), dtype="f16", center=True, row_offset=77)
+    db.save(str(tmp_path / "shard.npz"))
+    db2 = dlc.KeyframeDatabase.load(str(tmp_path / "shard.npz"))
+    assert torch.equal(db.rows, db2.rows) and db2.row_offset == 77 and db2.center and db2.dtype == torch.float16
+    q = rng.standard_normal((5, 100)).astype(np.float32)
+    a, b = db.match_topk(q, 3), db2.match_topk(q, 3)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
