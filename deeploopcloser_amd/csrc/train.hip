@@ -1,0 +1,306 @@
+// One SGD step of SDAV layer `layer` (src/sdav/network/SDAV.py:126-159 forward, :171-186 loss,
+// :223-226 plain gradient descent; `optimizer.minimize(loss_l)` reaches every variable the loss
+// depends on, so the encoders of layers 0..layer-1 move too).  fp64 like the reference.
+// All matrix products go through the fp64 MFMA GEMM (gemm_dense.hip); the loss gradients are
+// row / elementwise HIP kernels.  Restated (and pinned by finite differences) in
+// oracle/sdav_train.py.
+#include "dlc_internal.h"
+
+namespace dlc_gemm {
+int gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A,
+                  int64_t lda, const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st);
+}
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* red) {   // 256 threads
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// x_tilde[r, c] = x[r, c] * mask[r % P, c]     (TensorWrapper.corrupt, TensorflowWrapper.py:34-38)
+__global__ __launch_bounds__(256) void mask_rows_kernel(const double* __restrict__ x, const double* __restrict__ mask,
+                                                        long long rows, int P, long long cols, double* __restrict__ out) {
+    const long long total = rows * cols;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / cols, c = e - r * cols;
+        out[e] = x[e] * mask[(r % P) * cols + c];
+    }
+}
+
+// softmax_cross_entropy_with_logits_v2(labels, logits = y) per row (SDAV.py:172), mean over rows.
+// dz2 = d(cd)/d(y) * y(1-y);  dlab (optional) = d(cd)/d(labels) = -log_softmax(y)/rows.
+__global__ __launch_bounds__(256) void xent_grad_kernel(const double* __restrict__ y, const double* __restrict__ lab,
+                                                        long long rows, int cols, double* __restrict__ dz2,
+                                                        double* __restrict__ dlab, double* __restrict__ acc) {
+    __shared__ double red[4];
+    const long long r = blockIdx.x;
+    const double* yr = y + r * cols;
+    const double* lr = lab + r * cols;
+    double mx = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmax(mx, yr[c]);
+    mx = block_max(mx, red);
+    double se = 0.0, sl = 0.0;
+    for (int c = threadIdx.x; c < cols; c += 256) { se += exp(yr[c] - mx); sl += lr[c]; }
+    se = block_sum(se, red);
+    sl = block_sum(sl, red);
+    const double lse = log(se), inv_rows = 1.0 / (double)rows;
+    double cd = 0.0;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const double yv = yr[c], lv = lr[c];
+        const double logsm = yv - mx - lse;
+        cd -= lv * logsm;
+        const double dy = (exp(logsm) * sl - lv) * inv_rows;
+        dz2[r * cols + c] = dy * yv * (1.0 - yv);
+        if (dlab) dlab[r * cols + c] = -logsm * inv_rows;
+    }
+    cd = block_sum(cd, red);
+    if (threadIdx.x == 0) atomicAdd(&acc[0], cd * inv_rows);
+}
+
+// n_t = || H_t - H_{t+1} ||_F over a frame's P x N block (SDAV.py:176-183); also cs (:174)
+__global__ __launch_bounds__(256) void frame_norm_kernel(const double* __restrict__ h, int batch, long long frame_elems,
+                                                         double sparse_level, long long rows, double* __restrict__ nrm,
+                                                         double* __restrict__ acc) {
+    __shared__ double red[4];
+    const int t = blockIdx.x;                                   // 0 .. batch-1
+    const double* a = h + (long long)t * frame_elems;
+    double s2 = 0.0, l1 = 0.0;
+    for (long long e = threadIdx.x; e < frame_elems; e += 256) {
+        const double v = a[e];
+        l1 += fabs(v - sparse_level);
+        if (t + 1 < batch) { const double dlt = v - a[frame_elems + e]; s2 += dlt * dlt; }
+    }
+    s2 = block_sum(s2, red);
+    l1 = block_sum(l1, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[1], l1 / (double)rows);
+        if (t + 1 < batch) {
+            const double n = sqrt(s2);
+            nrm[t] = n;
+            atomicAdd(&acc[2], n / (double)(batch - 1));
+        }
+    }
+}
+
+// dh += sparse_penalty*sign(h - s)/rows + consecutive term;  dz1 = dh * h(1-h)
+__global__ __launch_bounds__(256) void hidden_grad_kernel(const double* __restrict__ h, const double* __restrict__ dh_in,
+                                                          const double* __restrict__ nrm, int batch,
+                                                          long long frame_elems, long long rows, double sparse_level,
+                                                          double sparse_penalty, double consecutive_penalty,
+                                                          double* __restrict__ dz1) {
+    const long long total = (long long)batch * frame_elems;
+    const double ccs = consecutive_penalty / (double)(batch - 1), sps = sparse_penalty / (double)rows;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long f = e / frame_elems;
+        const double hv = h[e];
+        double g = dh_in[e];
+        const double d = hv - sparse_level;
+        g += sps * (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));
+        if (f + 1 < batch) g += ccs * (hv - h[e + frame_elems]) / nrm[f];
+        if (f > 0) g -= ccs * (h[e - frame_elems] - hv) / nrm[f - 1];
+        dz1[e] = g * hv * (1.0 - hv);
+    }
+}
+
+// dz1_prev = (dxt [+ dlab]) * mask[r % P] * h_prev(1-h_prev)
+__global__ __launch_bounds__(256) void backprop_input_kernel(const double* __restrict__ dxt, const double* __restrict__ dlab,
+                                                             const double* __restrict__ mask,
+                                                             const double* __restrict__ h_prev, long long rows, int P,
+                                                             long long cols, double* __restrict__ dz1_prev) {
+    const long long total = rows * cols;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / cols, c = e - r * cols;
+        double g = dxt[e];
+        if (dlab) g += dlab[e];
+        const double hv = h_prev[e];
+        dz1_prev[e] = g * mask[(r % P) * cols + c] * hv * (1.0 - hv);
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, long long rows, long long cols,
+                                                        double* __restrict__ out) {
+    __shared__ double tile[32][33];
+    const long long r0 = (long long)blockIdx.y * 32, c0 = (long long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+// out[c] = sum_r in[r, c]   (rows are few hundred: one thread per column, coalesced across columns)
+__global__ __launch_bounds__(256) void colsum_kernel(const double* __restrict__ in, long long rows, long long cols,
+                                                     double* __restrict__ out) {
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    double s = 0.0;
+    for (long long r = 0; r < rows; ++r) s += in[r * cols + c];
+    out[c] = s;
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(double* __restrict__ p, const double* __restrict__ g1,
+                                                  const double* __restrict__ g2, long long n, double lr) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256)
+        p[e] -= lr * (g2 ? g1[e] + g2[e] : g1[e]);
+}
+
+__global__ void finalize_loss_kernel(const double* acc, double sparse_penalty, double consecutive_penalty,
+                                     double* loss_out) {
+    loss_out[0] = acc[0] + sparse_penalty * acc[1] + consecutive_penalty * acc[2];
+    loss_out[1] = acc[0];
+    loss_out[2] = acc[1];
+    loss_out[3] = acc[2];
+}
+
+inline unsigned grid_for(long long n) {
+    long long b = dlc::cdiv(n, 256);
+    return (unsigned)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b));
+}
+
+struct TrainWs {
+    size_t xt[8], h[8], gw[8], gbe[8];     // per layer 0..layer
+    size_t y, dz2, dlab, dh, dz1a, dz1b, dxt, tr, gw2, gbd, nrm, acc, total;
+};
+
+TrainWs train_ws(int64_t rows, int batch, const int64_t* dims, int layer) {
+    TrainWs w;
+    size_t o = 0;
+    auto take = [&](size_t elems) { size_t at = o; o += dlc::align_up(elems * 8, 256); return at; };
+    int64_t wmax = 0;
+    for (int l = 0; l <= layer + 1; ++l) wmax = dims[l] > wmax ? dims[l] : wmax;
+    for (int l = 0; l <= layer; ++l) {
+        w.xt[l] = take((size_t)rows * dims[l]);
+        w.h[l] = take((size_t)rows * dims[l + 1]);
+        w.gw[l] = take((size_t)dims[l] * dims[l + 1]);
+        w.gbe[l] = take((size_t)dims[l + 1]);
+    }
+    w.y = take((size_t)rows * dims[layer]);
+    w.dz2 = take((size_t)rows * dims[layer]);
+    w.dlab = take((size_t)rows * dims[layer]);
+    w.dh = take((size_t)rows * wmax);
+    w.dz1a = take((size_t)rows * wmax);
+    w.dz1b = take((size_t)rows * wmax);
+    w.dxt = take((size_t)rows * wmax);
+    w.tr = take((size_t)rows * wmax);
+    w.gw2 = take((size_t)dims[layer] * dims[layer + 1]);
+    w.gbd = take((size_t)dims[layer]);
+    w.nrm = take((size_t)batch);
+    w.acc = take(4);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t dlc_sdav_train_workspace_bytes(int64_t batch, int64_t patches, const int64_t* dims, int n_layers,
+                                                 int layer) {
+    if (batch < 2 || patches < 1 || !dims || n_layers < 1 || n_layers > 8 || layer < 0 || layer >= n_layers) return 0;
+    return train_ws(batch * patches, (int)batch, dims, layer).total;
+}
+
+extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64_t patches, int n_layers,
+                                   const int64_t* dims, const double* x, const double* const* masks, double* const* W,
+                                   double* const* b_enc, double* b_dec, double sparse_level, double sparse_penalty,
+                                   double consecutive_penalty, double learning_rate, double* loss_out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!dims || !x || !masks || !W || !b_enc || !b_dec || n_layers < 1 || n_layers > 8 || layer < 0 || layer >= n_layers ||
+        patches < 1)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_train_step: bad argument");
+    if (batch < 2)
+        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_train_step: a batch needs >= 2 frames (consecutive-frame term, SDAV.py:176-183)");
+    if (batch * patches > 0x7fffffffll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_train_step: batch too large");
+    if (dims[1] != dims[layer + 1])
+        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_train_step: hidden_units[0] != hidden_units[layer] (the slice of SDAV.py:178-181 needs equal widths)");
+    for (int l = 0; l <= layer; ++l)
+        if (!masks[l] || !W[l] || !b_enc[l]) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_train_step: null parameter of layer %d", l);
+    const long long rows = batch * patches;
+    const TrainWs w = train_ws(rows, (int)batch, dims, layer);
+    if (!workspace || workspace_bytes < w.total)
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "sdav_train_step: workspace %zu < %zu bytes", workspace_bytes, w.total);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    auto P = [&](size_t off) { return (double*)(ws + off); };
+    const int Pn = (int)patches;
+#define GEMM(bl, act, M, N, K, A, lda, B, ldb, bias, C, ldc)                                                     \
+    do {                                                                                                        \
+        int rc_ = dlc_gemm::gemm_bias_act(ctx, DLC_F64, bl, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st);     \
+        if (rc_ != DLC_OK) return rc_;                                                                          \
+    } while (0)
+
+    // ---- forward through layers 0..layer (old parameters everywhere)
+    const double* cur = x;
+    for (int l = 0; l <= layer; ++l) {
+        hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(rows * dims[l])), dim3(256), 0, st, cur, masks[l], rows, Pn,
+                           (long long)dims[l], P(w.xt[l]));
+        GEMM(DLC_B_KN, DLC_ACT_SIGMOID, rows, dims[l + 1], dims[l], P(w.xt[l]), dims[l], W[l], dims[l + 1], b_enc[l],
+             P(w.h[l]), dims[l + 1]);
+        cur = P(w.h[l]);
+    }
+    const long long K = dims[layer], N = dims[layer + 1];
+    const double* h = P(w.h[layer]);
+    GEMM(DLC_B_NK, DLC_ACT_SIGMOID, rows, K, N, h, N, W[layer], N, b_dec, P(w.y), K);            // y = sigmoid(h W^T + b_d)
+    const double* labels = layer == 0 ? x : P(w.xt[layer]);
+
+    // ---- loss pieces and the gradient at the trained layer
+    DLC_HIP_CHECK(ctx, hipMemsetAsync(P(w.acc), 0, 32, st));
+    hipLaunchKernelGGL(xent_grad_kernel, dim3((unsigned)rows), dim3(256), 0, st, P(w.y), labels, rows, (int)K, P(w.dz2),
+                       layer > 0 ? P(w.dlab) : (double*)nullptr, P(w.acc));
+    hipLaunchKernelGGL(frame_norm_kernel, dim3((unsigned)batch), dim3(256), 0, st, h, (int)batch, (long long)patches * N,
+                       sparse_level, rows, P(w.nrm), P(w.acc));
+    GEMM(DLC_B_KN, DLC_ACT_NONE, rows, N, K, P(w.dz2), K, W[layer], N, nullptr, P(w.dh), N);      // dh = dz2 W
+    hipLaunchKernelGGL(hidden_grad_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, h, P(w.dh), P(w.nrm), (int)batch,
+                       (long long)patches * N, rows, sparse_level, sparse_penalty, consecutive_penalty, P(w.dz1a));
+    // decoder use of the tied weight: gw2 = dz2^T h ; b_dec gradient
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0, st,
+                       P(w.dz2), rows, K, P(w.tr));
+    GEMM(DLC_B_KN, DLC_ACT_NONE, K, N, rows, P(w.tr), rows, h, N, nullptr, P(w.gw2), N);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)dlc::cdiv(K, 256)), dim3(256), 0, st, P(w.dz2), rows, K, P(w.gbd));
+
+    // ---- backward through the encoders layer .. 0
+    double* dz1 = P(w.dz1a);
+    double* dz1_other = P(w.dz1b);
+    for (int l = layer; l >= 0; --l) {
+        const long long Kl = dims[l], Nl = dims[l + 1];
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(Kl, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0,
+                           st, P(w.xt[l]), rows, Kl, P(w.tr));
+        GEMM(DLC_B_KN, DLC_ACT_NONE, Kl, Nl, rows, P(w.tr), rows, dz1, Nl, nullptr, P(w.gw[l]), Nl);   // x~^T dz1
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)dlc::cdiv(Nl, 256)), dim3(256), 0, st, dz1, rows, Nl, P(w.gbe[l]));
+        if (l == 0) break;
+        GEMM(DLC_B_NK, DLC_ACT_NONE, rows, Kl, Nl, dz1, Nl, W[l], Nl, nullptr, P(w.dxt), Kl);          // dz1 W^T
+        hipLaunchKernelGGL(backprop_input_kernel, dim3(grid_for(rows * Kl)), dim3(256), 0, st, P(w.dxt),
+                           l == layer ? P(w.dlab) : (const double*)nullptr, masks[l], P(w.h[l - 1]), rows, Pn, Kl,
+                           dz1_other);
+        double* t = dz1; dz1 = dz1_other; dz1_other = t;
+    }
+
+    // ---- plain gradient descent on everything the loss reached (SDAV.py:223-226)
+    for (int l = 0; l <= layer; ++l) {
+        hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(dims[l] * dims[l + 1])), dim3(256), 0, st, W[l], P(w.gw[l]),
+                           l == layer ? P(w.gw2) : (const double*)nullptr, (long long)(dims[l] * dims[l + 1]), learning_rate);
+        hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(dims[l + 1])), dim3(256), 0, st, b_enc[l], P(w.gbe[l]),
+                           (const double*)nullptr, (long long)dims[l + 1], learning_rate);
+    }
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(K)), dim3(256), 0, st, b_dec, P(w.gbd), (const double*)nullptr, K,
+                       learning_rate);
+    if (loss_out)
+        hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, st, P(w.acc), sparse_penalty, consecutive_penalty,
+                           loss_out);
+#undef GEMM
+    DLC_LAUNCH_CHECK(ctx, "sdav_train_step kernels");
+    return DLC_OK;
+}

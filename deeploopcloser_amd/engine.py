@@ -148,6 +148,27 @@ class Engine:
                                               _ptr(out), _ptr(ws), ws.numel(), self._stream()))
         return out
 
+    def sdav_train_step(self, layer, x2d, batch, patches, masks, weights, b_enc, b_dec, sparse_level, sparse_penalty,
+                        consecutive_penalty, learning_rate, loss_out=None):
+        """One in-place SGD step of `layer` (fp64 tensors on this device); loss_out: 4 doubles."""
+        n_layers = len(weights)
+        dims = [weights[0].shape[0]] + [w.shape[1] for w in weights]
+        dims_c = (C.c_int64 * (n_layers + 1))(*dims)
+        for t in [x2d] + list(masks[:layer + 1]) + list(weights[:layer + 1]) + list(b_enc[:layer + 1]) + [b_dec]:
+            if t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError("sdav_train_step: contiguous float64 tensors expected")
+        m_c = (C.c_void_p * n_layers)(*[(masks[l].data_ptr() if l <= layer else 0) for l in range(n_layers)])
+        w_c = (C.c_void_p * n_layers)(*[w.data_ptr() for w in weights])
+        b_c = (C.c_void_p * n_layers)(*[b.data_ptr() for b in b_enc])
+        need = self.lib.dlc_sdav_train_workspace_bytes(batch, patches, dims_c, n_layers, layer)
+        if need == 0:
+            raise ValueError("sdav_train_step: batch must be >= 2 frames, layer in range")
+        ws = self.workspace("train", need)
+        self._check(self.lib.dlc_sdav_train_step(self.ctx, layer, batch, patches, n_layers, dims_c, _ptr(x2d), m_c, w_c,
+                                                  b_c, _ptr(b_dec), float(sparse_level), float(sparse_penalty),
+                                                  float(consecutive_penalty), float(learning_rate), _ptr(loss_out),
+                                                  _ptr(ws), ws.numel(), self._stream()))
+
     # ---- SDAV patch front-end --------------------------------------------------------------
     def rgb_to_gray(self, rgb):
         rgb = rgb.contiguous()

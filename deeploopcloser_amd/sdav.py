@@ -11,8 +11,12 @@ Differences a caller can see, all deliberate:
   * weights are drawn ONCE at construction (seeded N(0,1), the reference's
     initialiser SDAV.py:189-217) or loaded with load_weights(); the reference
     re-draws them on every transform() when no checkpoint exists;
-  * fit / fit_dataset / get_dataset (training) are not part of
-    this hot path and raise NotImplementedError.
+  * fit / fit_dataset run the reference's per-layer SGD
+    (SDAV.py:242-288) through dlc_sdav_train_step; the masking noise comes from a seeded
+    torch generator; checkpoints are .npz files (save_weights), not TF checkpoints;
+    a batch of a single frame (NaN loss in the reference) is rejected / skipped;
+  * get_dataset needs key-points: the reference's SURF detector is not available, the
+    default is a fixed grid (input.grid_key_points) unless key_points_fn is given.
 """
 import logging
 
@@ -45,6 +49,11 @@ class SDAV:
         self.dtype = {"float64": torch.float64, "float32": torch.float32}[dtype]
         dims = [self.input_shape[1]] + list(self.hidden_units)
         self._weights, self._biases = _init_weights(dims, seed, self.dtype, self.engine.device, weight_scale)
+        self._biases_dec = [torch.zeros(k, dtype=self.dtype, device=self.engine.device) for k in dims[:-1]]   # :193-217
+        self._mask_gen = torch.Generator(device=self.engine.device)
+        self._mask_gen.manual_seed(int(seed) + 1)
+        self.global_step = 0
+        self.checkpoint_file = None                 # set to a path prefix to save after each layer (:273-275)
         logging.info("Done initializing sdav")
 
     def _define_params(self):                      # SDAV.py:30-39
@@ -93,10 +102,15 @@ class SDAV:
         z = np.load(path)
         n = len(self.hidden_units)
         self.set_weights([z["w%d" % l] for l in range(n)], [z["b%d" % l] for l in range(n)])
+        if "bd0" in z:
+            self._biases_dec = [self.engine.to_device(z["bd%d" % l], self.dtype) for l in range(n)]
+            self.global_step = int(z["global_step"])
 
     def save_weights(self, path):
         ws, bs = self.get_weights()
-        np.savez(path, **{"w%d" % l: w for l, w in enumerate(ws)}, **{"b%d" % l: b for l, b in enumerate(bs)})
+        np.savez(path, **{"w%d" % l: w for l, w in enumerate(ws)}, **{"b%d" % l: b for l, b in enumerate(bs)},
+                 **{"bd%d" % l: b.cpu().numpy() for l, b in enumerate(self._biases_dec)},
+                 global_step=np.array(self.global_step))
 
     # ---- encode ---------------------------------------------------------------------
     def transform_tensor(self, x):
@@ -114,16 +128,80 @@ class SDAV:
         """SDAV.transform (SDAV.py:293-302): numpy in, numpy FLAT [B*30, 2500] float64 out."""
         return self.transform_tensor(x).to(torch.float64).cpu().numpy()
 
-    # ---- training surface: outside this hot path --------------------------------------
-    def get_dataset(self, file_pattern):
-        raise NotImplementedError("SDAV.get_dataset (SURF patch front-end, SURVEY.md section 8f-1) is not part of the "
-                                  "MI355X hot path")
+    # ---- training (SDAV.py:242-288) ---------------------------------------------------------------
+    def _mask(self, layer_n):
+        """random_mask (TensorflowWrapper.py:148-156): round(P*K*level) zeros, shuffled, [P, K]."""
+        p, k = self.get_layer_input_shape(layer_n)
+        n = p * k
+        n_zeros = int(np.round(n * float(self.corruption_level)))
+        m = torch.ones(n, dtype=torch.float64, device=self.engine.device)
+        perm = torch.randperm(n, generator=self._mask_gen, device=self.engine.device)
+        m[perm[:n_zeros]] = 0.0
+        return m.reshape(p, k)
+
+    def train_step(self, layer_n, x, masks=None):
+        """One sess.run(self.train_steps[layer_n]) (SDAV.py:262) on batch x [B,30,1681]; returns
+        {loss, cd, cs, cc} (GPU tensor of 4 doubles) evaluated before the update."""
+        if self.dtype != torch.float64:
+            raise ValueError("training runs in float64, like the reference")
+        x = self.engine.to_device(x, torch.float64)
+        if x.dim() != 3 or list(x.shape[1:]) != list(self.input_shape):
+            raise ValueError("expected input of shape [B, %d, %d]" % tuple(self.input_shape))
+        if x.shape[0] < 2:
+            raise ValueError("a training batch needs at least 2 frames (the consecutive-frame loss term)")
+        if masks is None:
+            masks = [self._mask(l) for l in range(layer_n + 1)]
+        masks = [self.engine.to_device(m, torch.float64) for m in masks]
+        loss = torch.empty(4, dtype=torch.float64, device=self.engine.device)
+        self.engine.sdav_train_step(layer_n, x.reshape(-1, x.shape[2]), x.shape[0], x.shape[1], masks, self._weights,
+                                    self._biases, self._biases_dec[layer_n], self.sparse_level, self.sparse_penalty,
+                                    self.consecutive_penalty, self.learning_rate, loss_out=loss)
+        self.global_step += 1
+        return loss
+
+    def get_dataset(self, file_pattern: str, key_points_fn=None):
+        """Generator of parsed frames [30, 1681] (SDAV.py:219-221, InputGenerator.py:17-27)."""
+        from glob import glob
+        from .input import CvInputParser, grid_key_points, read_ppm
+        files = glob(file_pattern)
+        if len(files) == 0:
+            logging.getLogger().error("Specified dataset is empty or could not find dataset")   # InputGenerator.py:21-23
+        parser = CvInputParser(self.input_shape[0], int(round(np.sqrt(self.input_shape[1]))))
+        kp = key_points_fn or (lambda shape: grid_key_points(shape, self.input_shape[0]))
+
+        def gen():
+            for f in files:
+                img = read_ppm(f)
+                yield parser.parse(img, kp(img.shape[:2]))
+        return gen()
 
     def fit_dataset(self, dataset):
-        raise NotImplementedError("SDAV training (SURVEY.md section 8f-2) is not part of the MI355X hot path")
+        """SDAV.fit_dataset (:242-275): batches of default_batch_size frames; for each layer, for
+        each batch, `epochs` SGD steps on that layer's loss; a checkpoint after each layer."""
+        frames = [np.asarray(f, dtype=np.float64) for f in dataset]
+        bs = self.default_batch_size
+        batches = [np.stack(frames[i:i + bs]) for i in range(0, len(frames), bs)]
+        for i in range(len(self.hidden_units)):
+            logging.info("Fitting layer %d" % i)
+            for batch_n, b in enumerate(batches):
+                if b.shape[0] < 2:
+                    logging.warning("skipping a batch of %d frame(s): the loss needs >= 2" % b.shape[0])
+                    continue
+                xb = self.engine.to_device(b, torch.float64)
+                for step in range(self.epochs):
+                    loss = self.train_step(i, xb)
+                    if self.logger.isEnabledFor(logging.INFO):
+                        logging.info("    Layer:%d Batch:%d fit, Epoch:%d/%d, Loss:%s" %
+                                     (i, batch_n, step + 1, self.epochs, float(loss[0].item())))
+            if self.checkpoint_file:
+                self.save_weights("%s-%d.npz" % (self.checkpoint_file, self.global_step))
 
     def fit(self, x):
-        raise NotImplementedError("SDAV training (SURVEY.md section 8f-2) is not part of the MI355X hot path")
+        """SDAV.fit (:277-288): the whole array as one batch, `epochs` steps per layer."""
+        xb = self.engine.to_device(x, torch.float64)
+        for i in range(len(self.hidden_units)):
+            for step in range(self.epochs):
+                self.train_step(i, xb)
 
 
 class DA:

@@ -109,6 +109,25 @@ int dlc_sdav_encode(dlc_ctx* ctx, int dtype, int64_t rows, int n_layers, const i
                     const void* x, const void* const* W, const void* const* b,
                     void* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- SDAV training step (the surface train.py drives: SDAV.fit / fit_dataset) ----------------- */
+/*
+ * One `sess.run(train_steps[layer])` (src/sdav/network/SDAV.py:223-226,257-263): forward of
+ * layers 0..layer with masking noise (:126-159; masks[l] is the [P, dims[l]] 0/1 mask of
+ * TensorflowWrapper.py:148-156, shared by the frames of the batch), tied-weight decoder of
+ * `layer`, loss cd + sparse_penalty*cs + consecutive_penalty*cc (:171-186), gradients with
+ * respect to every variable the loss reaches (W_0..W_layer, b_enc_0..b_enc_layer, b_dec of
+ * `layer`) and plain gradient descent with `learning_rate`, in place.  fp64.
+ * x is [batch*P, dims[0]] (batch >= 2 frames); W / b_enc / masks are HOST arrays of DEVICE
+ * pointers (entries 0..layer used); loss_out (DEVICE, 4 doubles, may be NULL) receives
+ * {loss, cd, cs, cc} evaluated BEFORE the update.
+ */
+size_t dlc_sdav_train_workspace_bytes(int64_t batch, int64_t patches, const int64_t* dims, int n_layers, int layer);
+int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64_t patches, int n_layers, const int64_t* dims,
+                        const double* x, const double* const* masks, double* const* W, double* const* b_enc,
+                        double* b_dec, double sparse_level, double sparse_penalty, double consecutive_penalty,
+                        double learning_rate, double* loss_out, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 /* ---- encode: SDAV patch front-end after key-point detection -------------------------------- */
 /*
  * cv2.imread(path, IMREAD_GRAYSCALE) of a colour frame (src/sdav/input/CvInputParser.py:32):
