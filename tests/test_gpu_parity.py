@@ -249,8 +249,8 @@ def test_sdav_surface(dlc):
     assert net.transform(np.zeros((0, 30, 1681))).shape == (0, 2500)
     with pytest.raises(ValueError):
         net.transform(np.zeros((2, 30, 100)))
-    with pytest.raises(NotImplementedError):
-        net.fit(np.zeros((1, 30, 1681)))
+    with pytest.raises(ValueError):
+        net.fit(np.zeros((1, 30, 1681)))           # one frame: the consecutive-frame term needs two
 
 
 def test_da_transform_vs_oracle(dlc):
@@ -484,3 +484,37 @@ def test_group_exchange_protocol_equals_unsharded(eng, dlc):
     eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i))
     assert torch.equal(o_i, want_i) and torch.equal(o_s, want_s)
     assert kept <= nq * (kg + 4) and kept < parts * nq * kg * 0.5        # ~kg groups survive per query in total
+
+
+def test_error_paths_raise_value_error(eng, dlc):
+    """Bad arguments come back as negative status codes from the C ABI and surface as ValueError
+    (the reference raises ValueError / validation errors); nothing is silently clamped."""
+    f64 = lambda *s: torch.zeros(s, dtype=torch.float64, device=eng.device)
+    with pytest.raises(ValueError):
+        eng.gemm_bias_act(f64(4, 5), f64(6, 7))                                   # inner dimensions differ
+    with pytest.raises(ValueError):
+        eng.gemm_bias_act(f64(4, 5), f64(5, 7), bias=f64(3))                      # bias width
+    with pytest.raises(ValueError):
+        eng.gemm_bias_act(f64(4, 5).float(), f64(5, 7))                           # mixed dtypes
+    with pytest.raises(ValueError):
+        eng.sdav_similarity_matrix(f64(3, 65, 8), f64(8))                         # P > 64 patches
+    with pytest.raises(ValueError):
+        dlc.SimilarityCalculator(np.zeros((3, 30)))                               # dataset must be [N,P,H]
+    with pytest.raises(ValueError):
+        dlc.DistanceCalculator.distance_matrix(np.zeros((3,), dtype=np.int8))
+    with pytest.raises(ValueError):
+        dlc.CnnVtl(input_shape=[1, 224, 224, 1])
+    with pytest.raises(ValueError):
+        dlc.CnnVtl(compress_factor=120.0)
+    with pytest.raises(ValueError):
+        eng.groups_per_query(0)
+    q = torch.zeros((4, 64), dtype=torch.bfloat16, device=eng.device)
+    ws = torch.empty(eng.topk_workspace_bytes(4, 4, 64, 2), dtype=torch.uint8, device=eng.device)
+    with pytest.raises(L_ERRORS):
+        eng.score_groups(q, q, 2, ws[:128])                                       # workspace too small
+    assert dlc.DistanceCalculator.calculate_distance([], []) == 0                 # zip of empties (reference: 0)
+    assert dlc.DistanceCalculator.calculate_distance([1, 2, 3], [1]) == 0         # zip stops at the shorter one
+
+
+from deeploopcloser_amd._lib import DlcError as _DlcError   # noqa: E402
+L_ERRORS = (_DlcError, ValueError)
