@@ -9,7 +9,8 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 OURS = ("score_gemm_kernel", "finish_topk_kernel", "merge_topk_kernel", "l2_normalize_kernel")
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+stats = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 with open(stats) as f, open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w") as g:
     for i, line in enumerate(f):
         if i == 0 or any(k in line for k in OURS):
@@ -23,11 +24,11 @@ for row in csv.DictReader(open(stats)):
             summary["kernels"].setdefault(k, {})["avg_ns"] = float(row["AverageNs"])
             summary["kernels"][k]["calls"] = int(row["Calls"])
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    f = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
-    if not f:
+    if not glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")):
         continue
+    f = newest(os.path.join(src, sub, "*", "*counter_collection.csv"))
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(f)):
         for k in OURS:
             if k in r["Kernel_Name"]:
                 agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
