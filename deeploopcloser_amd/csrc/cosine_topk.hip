@@ -42,7 +42,7 @@ constexpr int A_STAGES = DLC_A_STAGES;
 constexpr int B_RING = A_STAGES * A_TILE;  // A ring first, then the B ring of 2 K tiles (64 KiB)
 constexpr int LDS_BYTES = A_STAGES * A_TILE + 2 * B_TILE;
 #ifndef DLC_STAGGER_SLEEP
-#define DLC_STAGGER_SLEEP 127    // s_sleep units of 64 cycles per stagger step (~4 us)
+#define DLC_STAGGER_SLEEP 31     // s_sleep units of 64 cycles per stagger step (~1 us); x stagger_mult
 #endif
 #ifndef DLC_STAGGER_PHASES
 #define DLC_STAGGER_PHASES 16
@@ -99,6 +99,7 @@ struct GemmArgs {
     long long nh;       // ceil(n/128)
     float* S;           // dense mode: [q, lds]
     long long lds;
+    int stagger_mult;   // first-round start stagger: phase * mult * DLC_STAGGER_SLEEP * 64 cycles
 };
 
 // ---- LDS image (160 KiB): a ring of 3 K tiles of the database operand (A, streamed from HBM)
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     // 128-byte column of their rows at the same time; a small start stagger of the FIRST round
     // (later rounds inherit it) spreads them over K without changing any result.
     if (tile < 256) {
-        const int steps = (int)((tile >> 3) % DLC_STAGGER_PHASES);
+        const int steps = (int)((tile >> 3) % DLC_STAGGER_PHASES) * p.stagger_mult;
         for (int s_ = 0; s_ < steps; ++s_) __builtin_amdgcn_s_sleep(DLC_STAGGER_SLEEP);
     }
     // ---- prologue: A tiles 0,1,2 and B tiles 0,1 issued (per-tile order A1,A0 / B0,B1, as the
@@ -747,7 +748,10 @@ int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid((unsigned)dlc::cdiv(a.n, BM), (unsigned)dlc::cdiv(a.q, BNQ));
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), LDS_BYTES, st, a);
+    // measured: 0-60 us of stagger pays from ~4 dispatch rounds on, 0-15 us below (scripts/exp_rows.py)
+    GemmArgs b = a;
+    b.stagger_mult = ((long long)grid.x * grid.y >= 3 * 256) ? 4 : 1;
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), LDS_BYTES, st, b);
     DLC_LAUNCH_CHECK(ctx, "score_gemm_kernel");
     return DLC_OK;
 }
