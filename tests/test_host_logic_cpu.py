@@ -1,0 +1,58 @@
+"""Host-side logic of the Python mirror that runs without a GPU."""
+import glob
+import os
+from collections import namedtuple
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import patches as opatch
+
+FRAMES = sorted(glob.glob(os.path.join(GOLDEN, "frames", "*.ppm")))
+
+
+def test_read_ppm_matches_oracle_reader():
+    from deeploopcloser_amd.input import read_ppm
+    for f in FRAMES:
+        a = read_ppm(f)
+        assert a.shape == (192, 240, 3) and np.array_equal(a, opatch.read_ppm(f))
+    with pytest.raises(ValueError):
+        read_ppm(os.path.join(GOLDEN, "similarity.npz"))
+
+
+def test_key_point_ordering_and_rounding():
+    """CvInputParser.py:45-46 (descending response, top n) and :111 (Python round, half to even)."""
+    from deeploopcloser_amd.input import _centres, grid_key_points
+    KP = namedtuple("KP", "pt response")
+    kps = [KP((10.5, 20.5), 0.1), KP((11.5, 21.5), 0.9), KP((0.49, 239.51), 0.5), KP((5, 5), 0.7)]
+    c = _centres(kps, 3)
+    assert c.tolist() == [[12, 22], [5, 5], [0, 240]] and c.dtype == np.int32
+    assert _centres([(1.5, 2.5), (3.5, 4.5)], 30).tolist() == [[2, 2], [4, 4]]
+    assert _centres([], 30).shape == (0, 2)
+    g = grid_key_points((192, 240), 30)
+    assert len(g) == 30 and len(set(g)) == 30
+    assert all(0 <= x < 192 and 0 <= y < 240 for x, y in g)
+
+
+def test_driver_image_formulas():
+    """create_similarity_matrix.py:41-45 and create_distance_matrix.py:40."""
+    from deeploopcloser_amd.drivers import similarity_image, distance_image
+    m = np.array([[-1, 30, 10], [30, -1, 50], [10, 50, -1]], dtype=np.int64)
+    img = similarity_image(m)
+    move = 0 - m.min()
+    assert np.allclose(img, 255 * ((m + move) / (m.max() + move))) and img.min() == 0 and img.max() == 255
+    d = np.array([[0, 5], [5, 0]], dtype=np.int64)
+    assert np.array_equal(distance_image(d), np.array([[255.0, 0.0], [0.0, 255.0]]))
+
+
+def test_flatten_frame_descriptors_and_dtype_names():
+    import torch
+    from deeploopcloser_amd.matching import flatten_frame_descriptors
+    from deeploopcloser_amd.engine import torch_dtype
+    h = np.arange(2 * 30 * 4, dtype=np.float64).reshape(60, 4)
+    f = flatten_frame_descriptors(h)
+    assert tuple(f.shape) == (2, 120) and np.array_equal(f[1].numpy(), h[30:].reshape(-1))
+    assert torch_dtype("bf16") == torch.bfloat16 and torch_dtype("fp16") == torch.float16
+    with pytest.raises(ValueError):
+        torch_dtype("int3")
