@@ -137,7 +137,7 @@ def main():
     queries = eng.normalize(planted + sigma * noise, dt, center=True)
     db = dlc.KeyframeDatabase(rows, dtype=dt, row_offset=lo, stored=True)
     sharded = dlc.ShardedKeyframeDatabase.from_database(db)
-    pipe = None if args.no_pipeline else dlc.MatchPipeline(db, k, depth=2)
+    pipe = None if args.no_pipeline else dlc.MatchPipeline(db, k, depth=2 if world == 1 else 3)
     torch.cuda.synchronize()
     last = [None]
 
