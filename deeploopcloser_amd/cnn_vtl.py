@@ -1,8 +1,9 @@
 """CnnVtl encoder with the reference's call surface, running on MI355X.
 
 Mirrors src/cnn_vtl/network/cnn_vtl.py: ctor (:13-17), model (:28-128),
-transform (:130-133).  Each convolution is im2col + one fp64 MFMA GEMM with the
-bias / ReLU fused (dlc_gemm_bias_act); pooling, per-row min/max, the 0..255
+transform (:130-133).  Each convolution is one fp64 MFMA GEMM with the bias / ReLU fused:
+conv2..conv5 as an implicit GEMM (dlc_conv2d_nhwc_f64: the A-tile loader gathers input
+pixels, no im2col matrix), conv1 (3 input channels) as im2col + dlc_gemm_bias_act; pooling, per-row min/max, the 0..255
 scaling, the int8 cast and the column gather are HIP kernels too.
 
 The reference's weights (bvlc_alexnet.npy, cnn_vtl.py:137-149) are a git-LFS
@@ -109,10 +110,7 @@ class CnnVtl:
         h = x
         n = x.shape[0]
         for (kh, kw, cin, cout, s, ph, pw, oh, ow, relu, pool), w, b in zip(self._geom, self._w, self._b):
-            cols = e.im2col(h, kh, kw, s, ph, pw, oh, ow)
-            y = e.gemm_bias_act(cols, w, b, act=L.DLC_ACT_RELU if relu else L.DLC_ACT_NONE)
-            del cols
-            y = y.reshape(n, oh, ow, cout)
+            y = e.conv2d(h, w, b, kh, kw, s, ph, pw, oh, ow, L.DLC_ACT_RELU if relu else L.DLC_ACT_NONE)
             outs.append(y)
             h = e.maxpool3x3s2(y) if pool else y
         return outs

@@ -58,14 +58,30 @@ struct Segs {
     int n;
 };
 
-// per-row min / max over all segments; one workgroup per row
-__global__ __launch_bounds__(256) void row_minmax_kernel(Segs s, double* __restrict__ minmax) {
+// Order-preserving 64-bit key of a double (for atomicMin / atomicMax on unsigned long long).
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_unkey(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+__global__ void minmax_init_kernel(unsigned long long* __restrict__ keys, long long n) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r < n) { keys[r * 2] = ~0ull; keys[r * 2 + 1] = 0ull; }
+}
+
+// per-row min / max over all segments: blockIdx.y = row, blockIdx.x = slice of the row, so that a
+// handful of rows still fills the chip; partial results meet in ordered-key atomics.
+__global__ __launch_bounds__(256) void row_minmax_kernel(Segs s, unsigned long long* __restrict__ keys) {
     __shared__ double smin[4], smax[4];
-    const long long r = blockIdx.x;
+    const long long r = blockIdx.y;
     double mn = INFINITY, mx = -INFINITY;
     for (int g = 0; g < s.n; ++g) {
         const double* p = s.ptr[g] + r * s.size[g];
-        for (long long e = threadIdx.x; e < s.size[g]; e += 256) {
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < s.size[g]; e += (long long)gridDim.x * 256) {
             const double v = p[e];
             mn = fmin(mn, v);
             mx = fmax(mx, v);
@@ -76,9 +92,18 @@ __global__ __launch_bounds__(256) void row_minmax_kernel(Segs s, double* __restr
     if (lane == 0) { smin[w] = mn; smax[w] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        minmax[r * 2] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
-        minmax[r * 2 + 1] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+        mn = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+        mx = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+        if (mn <= mx) {                                         // this slice saw at least one element
+            atomicMin(&keys[r * 2], f64_key(mn));
+            atomicMax(&keys[r * 2 + 1], f64_key(mx));
+        }
     }
+}
+
+__global__ void minmax_decode_kernel(const unsigned long long* __restrict__ keys, long long n, double* __restrict__ minmax) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e < 2 * n) minmax[e] = f64_unkey(keys[e]);
 }
 
 // out[r, j] = int8( trunc( (d[r, cols[j]] - min_r) * (255 / (max_r - min_r)) ) ), wrap mod 256
@@ -154,7 +179,18 @@ extern "C" int dlc_minmax_quant_gather_i8(dlc_ctx* ctx, const double* const* seg
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(row_minmax_kernel, dim3((unsigned)n), dim3(256), 0, st, s, minmax);
+    // minmax doubles as the key scratch: [n,2] u64 keys first, decoded in place afterwards
+    unsigned long long* keys = (unsigned long long*)minmax;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((unsigned)dlc::cdiv(n, 256)), dim3(256), 0, st, keys, (long long)n);
+    long long width = 0;
+    for (int g = 0; g < n_segs; ++g) width += seg_sizes[g];
+    long long slices = dlc::cdiv(width, 256 * 16);              // >= 16 elements per thread
+    const long long want = dlc::cdiv(256 * 8, n);               // ~8 workgroups per CU over all rows
+    if (slices > want) slices = want;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL(row_minmax_kernel, dim3((unsigned)slices, (unsigned)n), dim3(256), 0, st, s, keys);
+    hipLaunchKernelGGL(minmax_decode_kernel, dim3((unsigned)dlc::cdiv(2 * n, 256)), dim3(256), 0, st, keys, (long long)n,
+                       minmax);
     DLC_LAUNCH_CHECK(ctx, "row_minmax_kernel");
     hipLaunchKernelGGL(quant_gather_kernel, dim3((unsigned)dlc::cdiv(n_cols, 256), (unsigned)n), dim3(256), 0, st, s,
                        (const long long*)cols, (long long)n_cols, (const double*)minmax, out);

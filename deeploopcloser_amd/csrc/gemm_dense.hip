@@ -43,6 +43,14 @@ __device__ __forceinline__ T apply_act(T z, int act) {
     return z;
 }
 
+// Implicit im2col (tf.layers.conv2d on NHWC, src/cnn_vtl/network/cnn_vtl.py:33-93): row m of the
+// A operand is output pixel (img, oy, ox), column k is (ky, kx, c) with c fastest; A then points
+// at the NHWC input and lda is unused.  Needs C % 8 == 0 (a thread's 8 consecutive k stay inside
+// one input pixel).
+struct ConvGeom {
+    int H, W, C, KW, stride, pad_t, pad_l, OH, OW;
+};
+
 template <typename T>
 struct Args {
     const T* A; long long lda;
@@ -51,9 +59,10 @@ struct Args {
     T* C; long long ldc;
     long long M, N, K;
     int act;
+    ConvGeom cv;
 };
 
-template <typename T, int BLAYOUT>
+template <typename T, int BLAYOUT, bool CONV = false>
 __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     constexpr int LDB_S = BLAYOUT == DLC_B_KN ? LDB_KN : LDB_NK;
     constexpr int B_ELEMS = BLAYOUT == DLC_B_KN ? TK * LDB_KN : TN * LDB_NK;
@@ -71,10 +80,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     // interior tiles (the common case) load without per-element predicates
     const bool rows_full = (m0 + TM <= p.M);
     const bool cols_full = (n0 + TN <= p.N);
+    // implicit im2col: this thread's output pixel (fixed for the whole K loop)
+    long long cv_img_base = 0;
+    int cv_iy0 = 0, cv_ix0 = 0;
+    if constexpr (CONV) {
+        const long long gm = m0 + a_row;
+        const long long gmc = gm < p.M ? gm : p.M - 1;
+        const long long img = gmc / ((long long)p.cv.OH * p.cv.OW);
+        const int rem = (int)(gmc - img * p.cv.OH * p.cv.OW);
+        const int oy = rem / p.cv.OW, ox = rem - oy * p.cv.OW;
+        cv_iy0 = oy * p.cv.stride - p.cv.pad_t;
+        cv_ix0 = ox * p.cv.stride - p.cv.pad_l;
+        cv_img_base = img * (long long)p.cv.H * p.cv.W * p.cv.C;
+    }
     auto load_tile = [&](long long k0) {
         const bool k_full = (k0 + TK <= p.K);
         const long long gm = m0 + a_row;
-        if (rows_full && k_full) {
+        if constexpr (CONV) {
+            const long long gk = k0 + a_k;                       // multiple of 8; 8 channels of one input pixel
+            const int t = (int)(gk / p.cv.C), c = (int)(gk - (long long)t * p.cv.C);
+            const int ky = t / p.cv.KW, kx = t - ky * p.cv.KW;
+            const int iy = cv_iy0 + ky, ix = cv_ix0 + kx;
+            const bool ok = gm < p.M && gk < p.K && iy >= 0 && iy < p.cv.H && ix >= 0 && ix < p.cv.W;
+            if (ok) {
+                const T* src = p.A + cv_img_base + ((long long)iy * p.cv.W + ix) * p.cv.C + c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ra[e] = src[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ra[e] = (T)0;
+            }
+        } else if (rows_full && k_full) {
             const T* src = p.A + gm * p.lda + k0 + a_k;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ra[e] = src[e];
@@ -173,10 +209,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
 
 template <typename T>
 int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
-           const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st) {
+           const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st,
+           const ConvGeom* cv = nullptr) {
     Args<T> a;
     a.A = (const T*)A; a.lda = lda; a.B = (const T*)B; a.ldb = ldb; a.bias = (const T*)bias;
     a.C = (T*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
+    a.cv = cv ? *cv : ConvGeom{};
+    if (cv) {
+        if (dlc::cdiv(N, TN) > 65535 || dlc::cdiv(M, TM) > 0x7fffffffll)
+            return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "conv: too large for one launch");
+        dim3 cgrid((unsigned)dlc::cdiv(M, TM), (unsigned)dlc::cdiv(N, TN));
+        hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, true>), cgrid, dim3(256), 0, st, a);
+        DLC_LAUNCH_CHECK(ctx, "gemm_bias_act_kernel(conv)");
+        return DLC_OK;
+    }
     if (dlc::cdiv(N, TN) > 65535 || dlc::cdiv(M, TM) > 0x7fffffffll)
         return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "gemm: M or N too large for one launch");
     dim3 grid((unsigned)dlc::cdiv(M, TM), (unsigned)dlc::cdiv(N, TN));
@@ -199,7 +245,30 @@ int gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int6
     return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "gemm: dtype %d (need DLC_F64 or DLC_F32)", dtype);
 }
 
+int conv2d_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, const double* x, const double* w,
+               const double* bias, double* out, const ConvGeom& cv, hipStream_t st) {
+    return launch<double>(ctx, DLC_B_KN, act, M, N, K, x, 0, w, N, bias, out, N, st, &cv);
+}
+
 }  // namespace dlc_gemm
+
+extern "C" int dlc_conv2d_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c, const double* kernel,
+                                   const double* bias, int kh, int kw, int cout, int stride, int pad_top, int pad_left,
+                                   int oh, int ow, int act, double* out, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!x || !kernel || !out || n < 1 || h < 1 || w < 1 || c < 1 || kh < 1 || kw < 1 || cout < 1 || stride < 1 ||
+        pad_top < 0 || pad_left < 0 || oh < 1 || ow < 1)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "conv2d: bad argument");
+    if (act < DLC_ACT_NONE || act > DLC_ACT_RELU) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "conv2d: act %d", act);
+    if (c % 8 != 0)
+        return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "conv2d: the implicit-GEMM loader needs C %% 8 == 0 (C=%d): use "
+                                                   "dlc_im2col_nhwc_f64 + dlc_gemm_bias_act", c);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    dlc_gemm::ConvGeom cv{h, w, c, kw, stride, pad_top, pad_left, oh, ow};
+    return dlc_gemm::conv2d_f64(ctx, act, n * oh * ow, cout, (int64_t)kh * kw * c, x, kernel, bias, out, cv,
+                                (hipStream_t)stream);
+}
 
 extern "C" int dlc_gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int64_t N, int64_t K,
                                  const void* A, int64_t lda, const void* B, int64_t ldb, const void* bias, void* C,

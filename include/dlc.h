@@ -158,6 +158,16 @@ int dlc_extract_patches(dlc_ctx* ctx, const uint8_t* gray, int64_t frames, int H
 int dlc_im2col_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c,
                         int kh, int kw, int stride, int pad_top, int pad_left, int oh, int ow,
                         double* cols, void* stream);
+/*
+ * tf.layers.conv2d (NHWC fp64, HWIO kernel reshaped [kh*kw*c, cout]) + bias + activation as an
+ * IMPLICIT GEMM: the A-tile loader of the fp64 MFMA GEMM gathers input pixels directly, the
+ * im2col matrix is never written.  Needs c %% 8 == 0 (conv2..conv5 of cnn_vtl.py:49-93); conv1
+ * (c = 3) goes through dlc_im2col_nhwc_f64 + dlc_gemm_bias_act.  out is [n, oh, ow, cout].
+ */
+int dlc_conv2d_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c,
+                        const double* kernel, const double* bias, int kh, int kw, int cout,
+                        int stride, int pad_top, int pad_left, int oh, int ow, int act,
+                        double* out, void* stream);
 /* tf.layers.max_pooling2d(3x3, stride 2, VALID) on NHWC fp64 (cnn_vtl.py:42-45,58-61). */
 int dlc_maxpool3x3s2_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c,
                               double* y, void* stream);

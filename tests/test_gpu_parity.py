@@ -377,6 +377,29 @@ def test_cnn_vtl_pieces_vs_oracle(eng):
         assert y.shape == ref.shape and np.abs(y - ref).max() < 1e-10
 
 
+def test_conv2d_implicit_gemm_vs_oracle(eng):
+    """dlc_conv2d_nhwc_f64 (no im2col matrix) for the cnn_vtl layer shapes with C % 8 == 0."""
+    from oracle import cnn_vtl as ocnn
+    rng = np.random.RandomState(4)
+    for (h, w, c, kh, cout, stride, pad, relu) in ((22, 28, 96, 5, 256, 1, "SAME", True), (10, 13, 256, 3, 384, 1, "SAME", True),
+                                                   (10, 13, 384, 3, 256, 1, "SAME", False), (17, 19, 8, 3, 5, 2, "VALID", True),
+                                                   (9, 9, 16, 5, 130, 2, "SAME", False)):
+        x = rng.standard_normal((3, h, w, c))
+        wk = rng.standard_normal((kh, kh, c, cout)) / np.sqrt(kh * kh * c)
+        b = rng.standard_normal(cout)
+        oh, ph = ocnn._out_size(h, kh, stride, pad)
+        ow, pw = ocnn._out_size(w, kh, stride, pad)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+        got = eng.conv2d(dev(x), dev(wk.reshape(-1, cout)), dev(b), kh, kh, stride, ph, pw, oh, ow, 2 if relu else 0)
+        ref = ocnn.conv2d_nhwc(x, wk, b, stride, pad, relu)
+        assert tuple(got.shape) == ref.shape and np.abs(got.cpu().numpy() - ref).max() < 1e-10
+        cols = eng.im2col(dev(x), kh, kh, stride, ph, pw, oh, ow)                  # explicit path: bit-identical sums
+        alt = eng.gemm_bias_act(cols, dev(wk.reshape(-1, cout)), dev(b), act=2 if relu else 0).reshape(got.shape)
+        assert torch.equal(alt, got)
+    with pytest.raises(ValueError):
+        eng.lib and eng._check(eng.lib.dlc_conv2d_nhwc_f64(eng.ctx, 1, 1, 4, 4, 3, 1, 1, 3, 3, 2, 1, 0, 0, 2, 2, 0, 1, None))
+
+
 def test_cnn_vtl_transform_vs_oracle(dlc):
     """CnnVtl.transform at the reference's 192x240 frame size, seeded weights + mask."""
     from oracle import cnn_vtl as ocnn
