@@ -127,3 +127,22 @@ def test_select_kernel_large_shard_paths(dlc, n):
     p = dlc.MatchPipeline(dlc.KeyframeDatabase(db, stored=True), 5)     # cooperative kernel: always the global path
     s2, i2 = p.result(p.submit(q))
     assert torch.equal(i2, i) and torch.equal(s2, s)
+
+
+def test_score_gemm_every_element_repeated(dlc):
+    """Race screen for the LDS-DMA pipeline of the score GEMM: the dense epilogue exposes EVERY
+    accumulator (256 queries x 20 k rows, K = 4096 = 64 K tiles), checked against an fp64 product,
+    for several launches on fresh random data (a mis-ordered wait shows up as rare wrong tiles)."""
+    eng = dlc.default_engine()
+    g = torch.Generator(device="cuda")
+    for rep in range(5):
+        g.manual_seed(100 + rep)
+        n = 20000 + 37 * rep if rep < 4 else 131072 + 5      # the last one: two full dispatch rounds under load
+        db = torch.randn((n, 4096), generator=g, device="cuda").to(torch.bfloat16)
+        q = torch.randn((256 - rep, 4096), generator=g, device="cuda").to(torch.bfloat16)
+        s = eng.cosine_scores(q, db)
+        ref = q.double() @ db.double().T
+        err = (s.double() - ref).abs().max().item()
+        assert err < 2e-3 * 64 ** 0.5, err              # |x| ~ N(0,1): fp32 accumulation of 4096 products
+        rel = ((s.double() - ref).abs() / (ref.abs() + 64.0)).max().item()
+        assert rel < 1e-5, rel
