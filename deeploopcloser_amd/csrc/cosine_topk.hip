@@ -102,8 +102,9 @@ struct GemmArgs {
     int stagger_mult;   // first-round start stagger: phase * mult * DLC_STAGGER_SLEEP * 64 cycles
 };
 
-// ---- LDS image (160 KiB): a ring of 3 K tiles of the database operand (A, streamed from HBM)
-// followed by a ring of 2 K tiles of the query operand (B, re-read from L2).  A K tile of an
+// ---- LDS image (128 KiB): a ring of A_STAGES = 2 K tiles of the database operand (A, streamed
+// from HBM; a 3-deep / 160 KiB ring measured the same) followed by a ring of 2 K tiles of the
+// query operand (B, re-read from L2).  A K tile of an
 // operand is two 16-KiB half tiles of 128 rows x 128 B:
 //   A half h, row r = wr*64 + rr   <->  tile database row  wr*128 + h*64 + rr
 //   B half h, row r = wc*32 + rr   <->  query row          wc*64  + h*32 + rr
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem;
 
     // ---- DMA roles: waves 0-3 stream the database (A) halves from HBM, waves 4-7 the query
-    // (B) halves from L2.  vmcnt counts per wave and in order, so with one stream per wave the A
-    // waves can keep three halves (48 KiB per CU) in flight regardless of the B traffic.
+    // (B) halves from L2.  vmcnt counts per wave and in order, so with one stream per wave the
+    // depth of the A prefetch does not depend on the B traffic.
     const bool is_a = wid < 4;
     const int ridx = wid & 3;                               // this wave stages rows 32*ridx .. +31 of a half
     const char* a_base = p.DB + tile * BM * p.lddb_b;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     const unsigned rdA1_l = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((4 + kq) ^ fa) << 4);
     const unsigned rdB0_l = B_RING + (wc * 32 + i) * 128 + (((0 + kq) ^ fb) << 4);                // + c*2048
     const unsigned rdB1_l = B_RING + (wc * 32 + i) * 128 + (((4 + kq) ^ fb) << 4);
-    // ring positions of the CURRENT K tile (bytes): A ring of 3 tiles, B ring of 2
+    // ring positions of the CURRENT K tile (bytes) in the A ring (A_STAGES tiles) and the B ring (2)
     unsigned aoff = 0, boff = 0;
     unsigned rdA0 = rdA0_l, rdA1 = rdA1_l, rdB0 = rdB0_l, rdB1 = rdB1_l;
 
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
         const int steps = (int)((tile >> 3) % DLC_STAGGER_PHASES) * p.stagger_mult;
         for (int s_ = 0; s_ < steps; ++s_) __builtin_amdgcn_s_sleep(DLC_STAGGER_SLEEP);
     }
-    // ---- prologue: A tiles 0,1,2 and B tiles 0,1 issued (per-tile order A1,A0 / B0,B1, as the
+    // ---- prologue: A tiles 0..A_STAGES-1 and B tiles 0,1 issued (per-tile order A1,A0 / B0,B1, as the
     // steady state issues them); then wait for tile 0.
 #pragma unroll
     for (int s_ = 0; s_ < A_STAGES; ++s_) {
@@ -275,9 +276,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     //   m5 (A1,B0,k1) m6 (A1,B1,k1) m7 (A0,B1,k1) m8 (A0,B0,k1)
     // Mini-phase m issues the reads of m+1 first, then its own MFMAs.  A half of the current
     // tile is dead once its k1 slice has been read (A1 after m3, B0 after m4, B1 after m5, A0
-    // after m6): a barrier there, then the DMA that refills it -- A halves with K tile t+3, B
+    // after m6): a barrier there, then the DMA that refills it -- A halves with K tile t+A_STAGES, B
     // halves with t+2.  At the end of m6 each wave waits for its own stream: an A wave leaves
-    // A1(t+2), A0(t+2), A1(t+3) in flight (vmcnt 12), a B wave B0(t+2), B1(t+2) (vmcnt 8); K
+    // A1(t+2) in flight (vmcnt 4; three halves / vmcnt 12 with a 3-deep ring), a B wave B0(t+2), B1(t+2) (vmcnt 8); K
     // tile t+1, whose first slices are read in m7 / m8, has then landed.
     for (int t = 0; t < nk; ++t) {
         DLC_READ_B(fbY, rdB0, HALF_BYTES);
