@@ -27,8 +27,9 @@ from .matching import encode, match, match_topk, KeyframeDatabase, MatchPipeline
 from .dist import ShardedKeyframeDatabase, shard_bounds, merge_topk_torch
 from .input import CvInputParser, grid_key_points, read_ppm
 from . import tensor_wrapper
+from .loop_closure import LoopClosureDetector
 
-__all__ = ["SDAV", "DA", "CnnVtl", "SimilarityCalculator", "DistanceCalculator", "MathUtils", "tensor_wrapper", "CvInputParser",
+__all__ = ["LoopClosureDetector", "SDAV", "DA", "CnnVtl", "SimilarityCalculator", "DistanceCalculator", "MathUtils", "tensor_wrapper", "CvInputParser",
            "grid_key_points", "read_ppm",
            "encode", "match", "match_topk", "KeyframeDatabase", "MatchPipeline", "ShardedKeyframeDatabase", "Engine",
            "default_engine", "shard_bounds", "merge_topk_torch", "flatten_frame_descriptors"]

@@ -255,9 +255,14 @@ class Engine:
         return out
 
     # ---- cosine + top-k -----------------------------------------------------------------
-    def normalize(self, x, dtype="bf16", center=False):
+    @staticmethod
+    def stored_width(d):
+        """Width of a stored descriptor row: d zero-padded to a multiple of 64."""
+        return (d + K_STEP - 1) // K_STEP * K_STEP
+
+    def normalize(self, x, dtype="bf16", center=False, out=None):
         """Rows of x [n,d] (float32/float64) -> stored descriptors [n, d_pad]
-        (bf16/fp16, L2-normalised, zero-padded to a multiple of 64)."""
+        (bf16/fp16, L2-normalised, zero-padded to a multiple of 64), into `out` if given."""
         dt = torch_dtype(dtype)
         if dt not in (torch.bfloat16, torch.float16):
             raise ValueError("stored descriptor dtype must be bf16 or fp16")
@@ -265,8 +270,13 @@ class Engine:
             raise ValueError("normalize: float32 or float64 input")
         x = x.contiguous()
         n, d = x.shape
-        ldd = (d + K_STEP - 1) // K_STEP * K_STEP
-        out = torch.empty((n, ldd), dtype=dt, device=self.device)
+        ldd = self.stored_width(d)
+        if out is None:
+            out = torch.empty((n, ldd), dtype=dt, device=self.device)
+        elif out.shape != (n, ldd) or out.dtype != dt or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("normalize: out must be a contiguous [%d, %d] %s tensor on %s" % (n, ldd, dt, self.device))
+        if n == 0:
+            return out
         self._check(self.lib.dlc_l2_normalize_rows(self.ctx, _TORCH_TO_DLC[x.dtype], _ptr(x), n, d, x.stride(0),
                                                     1 if center else 0, _TORCH_TO_DLC[dt], _ptr(out), ldd,
                                                     self._stream()))
@@ -405,6 +415,8 @@ def default_engine(device=None):
             L.load()   # raises ImportError first if the library itself is missing
             raise RuntimeError("deeploopcloser_amd needs a visible MI355X; there is no CPU fallback")
         device = torch.cuda.current_device()
+    elif not isinstance(device, int):
+        device = torch.device(device).index or 0      # one engine per GPU, whatever names it
     if device not in _default:
         _default[device] = Engine(device)
     return _default[device]

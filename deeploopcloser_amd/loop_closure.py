@@ -1,0 +1,179 @@
+"""Streaming loop-closure queries over the resident top-k engine.
+
+The reference stops at the all-vs-all matrices (create_similarity_matrix.py:29-38,
+create_distance_matrix.py:30-36); what a SLAM front-end asks is the streaming form of the same
+comparison: "does the frame that just arrived look like a place seen a while ago?".  A
+LoopClosureDetector keeps every key-frame's descriptor resident in HBM (KeyframeDatabase.append),
+matches each new frame against the key-frames more than `exclusion` frames older with the MFMA
+top-k path and reports the candidates whose cosine score reaches `threshold`.
+
+    python -m deeploopcloser_amd.loop_closure DATASET_DIR --network cnn_vtl --k 5 --threshold 0.9
+
+Batching never changes a result: a batch of B frames is matched against the longest prefix any
+of its frames may see, with k+B-1 candidates per frame, and each frame then keeps its first k
+candidates that are old enough (at most B-1 of the extra rows are too recent for it).
+"""
+import argparse
+import glob
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .matching import KeyframeDatabase
+
+
+def first_k_eligible(scores, idx, limit, k):
+    """Rows of (scores, idx) [B, kk] sorted best-first -> the first k entries per row whose id is
+    below that row's limit [B], order kept; missing slots are (-inf, -1)."""
+    ok = (idx >= 0) & (idx < limit.unsqueeze(1))
+    order = torch.argsort((~ok).to(torch.int8), dim=1, stable=True)[:, :k]
+    s, i, ok = scores.gather(1, order), idx.gather(1, order), ok.gather(1, order)
+    s = torch.where(ok, s, torch.full_like(s, float("-inf")))
+    i = torch.where(ok, i, torch.full_like(i, -1))
+    if s.shape[1] < k:                                   # fewer candidates than k were requested
+        pad = k - s.shape[1]
+        s = torch.cat([s, s.new_full((s.shape[0], pad), float("-inf"))], 1)
+        i = torch.cat([i, i.new_full((i.shape[0], pad), -1)], 1)
+    return s, i
+
+
+class LoopClosureDetector:
+    def __init__(self, dim, k=5, threshold=0.9, exclusion=30, dtype="bf16", center=False, capacity=4096,
+                 device=None):
+        if not 1 <= k <= L.DLC_MAX_K:
+            raise ValueError("k=%d outside 1..%d" % (k, L.DLC_MAX_K))
+        if exclusion < 0:
+            raise ValueError("exclusion must be >= 0")
+        self.k, self.threshold, self.exclusion = int(k), float(threshold), int(exclusion)
+        self.db = KeyframeDatabase.empty(dim, capacity=capacity, dtype=dtype, center=center, device=device)
+
+    def __len__(self):
+        return len(self.db)
+
+    @property
+    def max_batch(self):
+        """Largest number of frames one engine call can take (k + B - 1 <= DLC_MAX_K)."""
+        return L.DLC_MAX_K - self.k + 1
+
+    def query_and_insert(self, descriptors):
+        """The next B frames' descriptors [B, dim] (ids len(self) .. len(self)+B-1) ->
+        (scores [B,k] float32, ids [B,k] int64) on the device, best first, (-inf, -1) where fewer
+        than k key-frames are old enough; the frames are then key-frames themselves."""
+        x = self.db._as_float(descriptors)
+        if x.dim() != 2:
+            raise ValueError("descriptors must be [B, dim]")
+        out_s, out_i = [], []
+        for lo in range(0, x.shape[0], self.max_batch):
+            s, i = self._step(x[lo:lo + self.max_batch])
+            out_s.append(s)
+            out_i.append(i)
+        if not out_s:
+            dev = self.db.engine.device
+            return (torch.empty((0, self.k), dtype=torch.float32, device=dev),
+                    torch.empty((0, self.k), dtype=torch.int64, device=dev))
+        return torch.cat(out_s), torch.cat(out_i)
+
+    def _step(self, x):
+        db, k = self.db, self.k
+        b = x.shape[0]
+        g0, _ = db.append(x)                               # normalised once, used as query and as key-frame
+        g0 -= db.row_offset
+        q = db.rows[g0:g0 + b]
+        n_search = g0 + b - 1 - self.exclusion             # what the newest frame of the batch may see
+        dev = db.engine.device
+        if n_search <= 0:
+            return (torch.full((b, k), float("-inf"), dtype=torch.float32, device=dev),
+                    torch.full((b, k), -1, dtype=torch.int64, device=dev))
+        s, i = db.engine.match_topk(q, db.rows[:n_search], min(k + b - 1, L.DLC_MAX_K))
+        limit = torch.arange(g0 - self.exclusion, g0 - self.exclusion + b, device=dev)
+        return first_k_eligible(s, i, limit, k)
+
+    def loops(self, scores, ids, first_id):
+        """[(frame id, matched key-frame id, score)] of the candidates at or above the threshold."""
+        s, i = scores.cpu().numpy(), ids.cpu().numpy()
+        out = []
+        for r in range(s.shape[0]):
+            for c in range(s.shape[1]):
+                if i[r, c] >= 0 and s[r, c] >= self.threshold:
+                    out.append((first_id + r, int(i[r, c]), float(s[r, c])))
+        return out
+
+
+def _frame_files(dataset_path, pattern):
+    files = sorted(glob.glob(os.path.join(dataset_path, pattern)))
+    if not files:
+        raise ValueError("Specified dataset is empty or could not find dataset")        # InputGenerator.py:21-23
+    return files
+
+
+def describe_sdav(files, network=None, key_points_fn=None):
+    """Frames -> one [30*2500] place descriptor per frame (patches -> SDAV.transform, flattened)."""
+    from .input import CvInputParser, grid_key_points, read_ppm
+    from .sdav import SDAV
+    network = network or SDAV()
+    p = network.input_shape[0]
+    parser = CvInputParser(p, int(round(np.sqrt(network.input_shape[1]))))
+    kp = key_points_fn or (lambda shape: grid_key_points(shape, p))
+    frames = [read_ppm(f) for f in files]
+    x = np.stack([parser.parse(fr, kp(fr.shape[:2])) for fr in frames])
+    h = network.transform(x)
+    return h.reshape(len(files), p * h.shape[1])
+
+
+def describe_cnn_vtl(files, network=None):
+    """Frames -> CnnVtl int8 descriptors [B, D'] (as float for the cosine engine)."""
+    from .cnn_vtl import CnnVtl
+    from .input import read_ppm
+    frames = np.stack([read_ppm(f)[..., ::-1] for f in files])           # BGR, as create_distance_matrix.py:23
+    network = network or CnnVtl(input_shape=[len(files)] + list(frames.shape[1:]))
+    return network.transform(frames).astype(np.float32)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="stream the frames of a dataset through the loop-closure detector")
+    ap.add_argument("dataset_path")
+    ap.add_argument("--pattern", default="*.ppm")
+    ap.add_argument("--network", choices=["sdav", "cnn_vtl"], default="cnn_vtl")
+    ap.add_argument("--weights", help=".npz written by SDAV.save_weights (sdav) / AlexNet .npy blob (cnn_vtl)")
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--threshold", type=float, default=0.9)
+    ap.add_argument("--exclusion", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=16, help="frames encoded and matched per step")
+    ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16")
+    args = ap.parse_args(argv)
+
+    files = _frame_files(args.dataset_path, args.pattern)
+    if args.network == "sdav":
+        from .sdav import SDAV
+        net = SDAV()
+        if args.weights:
+            net.load_weights(args.weights)
+        describe = lambda fs: describe_sdav(fs, net)
+    else:
+        from .cnn_vtl import CnnVtl
+        from .input import read_ppm
+        shape = read_ppm(files[0]).shape
+        net = CnnVtl(input_shape=[args.batch] + list(shape))
+        if args.weights:
+            net.load_alexnet_npy(args.weights)
+        describe = lambda fs: describe_cnn_vtl(fs, net)
+    det = None
+    for lo in range(0, len(files), args.batch):
+        chunk = files[lo:lo + args.batch]
+        desc = describe(chunk)
+        if det is None:
+            det = LoopClosureDetector(desc.shape[1], k=args.k, threshold=args.threshold, exclusion=args.exclusion,
+                                      dtype=args.dtype, center=True, capacity=max(4096, len(files)))
+        s, i = det.query_and_insert(desc)
+        for frame, match, score in det.loops(s, i, lo):
+            print("loop\t%d\t%s\t%d\t%s\t%.4f" % (frame, os.path.basename(files[frame]), match,
+                                                 os.path.basename(files[match]), score))
+    print("frames\t%d\tkey-frames\t%d" % (len(files), len(det)), file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

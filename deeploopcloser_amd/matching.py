@@ -25,9 +25,15 @@ def flatten_frame_descriptors(h, patches=30):
 
 
 class KeyframeDatabase:
-    """A shard of stored (L2-normalised bf16 / fp16) key-frame descriptors resident in HBM."""
+    """A shard of stored (L2-normalised bf16 / fp16) key-frame descriptors resident in HBM.
 
-    def __init__(self, descriptors, dtype="bf16", center=False, row_offset=0, device=None, stored=False):
+    The rows live in a capacity-reserved buffer so that a running loop-closure session can
+    append() key-frames without re-uploading the shard: `rows` is the view of the first
+    len(db) rows, growth doubles the reservation (sized against 288 GB of HBM, a 4096-d bf16
+    key-frame is 8 KiB)."""
+
+    def __init__(self, descriptors, dtype="bf16", center=False, row_offset=0, device=None, stored=False,
+                 capacity=None):
         self.engine = default_engine(device)
         self.dtype = torch_dtype(dtype)
         self.center = center
@@ -36,15 +42,72 @@ class KeyframeDatabase:
             d = descriptors.to(self.engine.device)
             if d.dtype != self.dtype:
                 raise ValueError("stored descriptors have dtype %s, expected %s" % (d.dtype, self.dtype))
-            self.rows = d
+            rows = d
         else:
-            x = self.engine.to_device(descriptors)
-            if x.dtype not in (torch.float32, torch.float64):
-                x = x.to(torch.float32)
-            self.rows = self.engine.normalize(x, self.dtype, center)
+            rows = self.engine.normalize(self._as_float(descriptors), self.dtype, center)
+        self._n = rows.shape[0]
+        if capacity is not None and capacity > self._n:
+            self._store = torch.empty((int(capacity), rows.shape[1]), dtype=self.dtype, device=self.engine.device)
+            self._store[:self._n] = rows
+        else:
+            self._store = rows
+
+    @classmethod
+    def empty(cls, dim, capacity=4096, dtype="bf16", center=False, row_offset=0, device=None):
+        """A database of `dim`-wide descriptors with no key-frames yet and room for `capacity`."""
+        if dim < 1 or capacity < 1:
+            raise ValueError("KeyframeDatabase.empty: dim and capacity must be positive")
+        eng = default_engine(device)
+        dt = torch_dtype(dtype)
+        if dt not in (torch.bfloat16, torch.float16):
+            raise ValueError("stored descriptor dtype must be bf16 or fp16")
+        none = torch.empty((0, eng.stored_width(dim)), dtype=dt, device=eng.device)
+        return cls(none, dtype=dt, center=center, row_offset=row_offset, device=device, stored=True, capacity=capacity)
+
+    def _as_float(self, descriptors):
+        x = self.engine.to_device(descriptors)
+        if x.dtype not in (torch.float32, torch.float64):
+            x = x.to(torch.float32)
+        return x
+
+    @property
+    def rows(self):
+        return self._store[:self._n]
+
+    @property
+    def capacity(self):
+        return self._store.shape[0]
 
     def __len__(self):
-        return self.rows.shape[0]
+        return self._n
+
+    def reserve(self, capacity):
+        """Room for at least `capacity` key-frames (one device-to-device copy when it grows)."""
+        if capacity > self.capacity:
+            grown = torch.empty((int(capacity), self._store.shape[1]), dtype=self.dtype, device=self.engine.device)
+            grown[:self._n] = self._store[:self._n]
+            self._store = grown
+
+    def append(self, descriptors):
+        """Normalise and store further key-frames [B, dim]; returns their global ids (first, last+1).
+        Stream-ordered on the current stream, like every other call."""
+        x = self._as_float(descriptors)
+        if x.dim() != 2 or self.engine.stored_width(x.shape[1]) != self._store.shape[1]:
+            raise ValueError("append: descriptors must be [B, dim] with the database's width")
+        b = x.shape[0]
+        if self._n + b > self.capacity:
+            self.reserve(max(2 * self.capacity, self._n + b))
+        self.engine.normalize(x, self.dtype, self.center, out=self._store[self._n:self._n + b])
+        first = self.row_offset + self._n
+        self._n += b
+        return first, first + b
+
+    def prefix(self, n):
+        """The first n key-frames as a database that shares this one's storage (no copy)."""
+        if not 0 <= n <= self._n:
+            raise ValueError("prefix: n=%d outside 0..%d" % (n, self._n))
+        return KeyframeDatabase(self._store[:n], dtype=self.dtype, center=self.center, row_offset=self.row_offset,
+                                device=self.engine.device, stored=True)
 
     # ---- on-disk format (SURVEY section 8f-3): one .npz per shard ---------------------------------
     def save(self, path):
@@ -67,9 +130,7 @@ class KeyframeDatabase:
         x = self.engine.to_device(queries)
         if x.dtype in (torch.bfloat16, torch.float16):
             return x
-        if x.dtype not in (torch.float32, torch.float64):
-            x = x.to(torch.float32)
-        return self.engine.normalize(x, self.dtype, self.center)
+        return self.engine.normalize(self._as_float(x), self.dtype, self.center)
 
     def match_topk(self, queries, k, out=None):
         q = self.prepare_queries(queries)

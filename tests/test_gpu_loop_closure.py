@@ -1,0 +1,119 @@
+"""GPU parity of the streaming loop-closure queries and of the growable
+key-frame database they run on, against oracle/loop_closure.py on the rows as stored.
+Indices are compared exactly except where the oracle's own scores are closer than fp32 can
+resolve (2e-6); scores to 2e-5 as for every cosine test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dlc():
+    import deeploopcloser_amd as d
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    d.default_engine()
+    return d
+
+
+def revisiting_sequence(t, d, period, seed):
+    """A trajectory that returns to each place every `period` frames (plus noise)."""
+    rng = np.random.RandomState(seed)
+    places = rng.standard_normal((period, d)).astype(np.float32)
+    return places[np.arange(t) % period] + 0.3 * rng.standard_normal((t, d)).astype(np.float32)
+
+
+def check_against_oracle(det, s, i, k, exclusion):
+    from oracle import loop_closure as oloop
+    rows = det.db.rows.float().cpu().numpy().astype(np.float64)
+    es, ei = oloop.stream_topk(rows, k, exclusion)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    assert s.shape == es.shape and i.dtype == np.int64
+    assert np.array_equal(i == -1, ei == -1) and np.array_equal(np.isneginf(s), np.isneginf(es))
+    ok = ei >= 0
+    assert np.abs(s[ok] - es[ok]).max() < 2e-5
+    diff = ok & (i != ei)
+    if diff.any():
+        r, c = np.nonzero(diff)
+        true = np.einsum("nd,nd->n", rows[r], rows[i[r, c]])
+        assert np.abs(true - es[r, c]).max() < 2e-6, "index differs where scores are not tied"
+        assert diff.mean() < 1e-3
+
+
+@pytest.mark.parametrize("batch,exclusion,k,dtype", [(1, 0, 3, "bf16"), (7, 3, 5, "bf16"), (50, 40, 5, "f16"),
+                                                     (200, 10, 20, "bf16"), (64, 0, 128, "bf16")])
+def test_stream_equals_oracle_for_any_batching(dlc, batch, exclusion, k, dtype):
+    t, d = 330, 192
+    x = revisiting_sequence(t, d, 97, seed=batch)
+    det = dlc.LoopClosureDetector(d, k=k, threshold=0.5, exclusion=exclusion, dtype=dtype, capacity=16)
+    out_s, out_i = [], []
+    for lo in range(0, t, batch):
+        s, i = det.query_and_insert(x[lo:lo + batch])
+        out_s.append(s)
+        out_i.append(i)
+    s, i = torch.cat(out_s), torch.cat(out_i)
+    assert len(det) == t and det.db.capacity >= t              # grew from 16 by doubling
+    check_against_oracle(det, s, i, k, exclusion)
+    # every frame old enough to have seen its place before finds that earlier visit first
+    first = i[:, 0].cpu().numpy()
+    for g in range(97 + exclusion + 1, t):
+        assert first[g] % 97 == g % 97
+    loops = det.loops(s, i, 0)
+    assert loops and all(sc >= 0.5 and m < g - exclusion for g, m, sc in loops)
+
+
+def test_empty_batch_and_errors(dlc):
+    det = dlc.LoopClosureDetector(64, k=4, exclusion=2)
+    s, i = det.query_and_insert(np.zeros((0, 64), dtype=np.float32))
+    assert s.shape == (0, 4) and i.shape == (0, 4) and len(det) == 0
+    with pytest.raises(ValueError):
+        det.query_and_insert(np.zeros((3, 200), dtype=np.float32))      # wrong width
+    with pytest.raises(ValueError):
+        dlc.LoopClosureDetector(64, k=0)
+    with pytest.raises(ValueError):
+        dlc.LoopClosureDetector(64, k=129)
+    with pytest.raises(ValueError):
+        dlc.LoopClosureDetector(64, exclusion=-1)
+
+
+def test_appended_database_equals_one_built_at_once(dlc):
+    rng = np.random.RandomState(5)
+    x = rng.standard_normal((1000, 100)).astype(np.float32)
+    q = rng.standard_normal((9, 100)).astype(np.float32)
+    whole = dlc.KeyframeDatabase(x, dtype="bf16", center=True, row_offset=50)
+    grown = dlc.KeyframeDatabase.empty(100, capacity=3, dtype="bf16", center=True, row_offset=50)
+    ids = [grown.append(x[lo:lo + 333]) for lo in range(0, 1000, 333)]
+    assert ids == [(50, 383), (383, 716), (716, 1049), (1049, 1050)]
+    assert len(grown) == 1000 and torch.equal(grown.rows, whole.rows)
+    s0, i0 = whole.match_topk(q, 10)
+    s1, i1 = grown.match_topk(q, 10)
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    part = grown.prefix(400)
+    assert len(part) == 400 and part.rows.data_ptr() == grown.rows.data_ptr()
+    s2, i2 = part.match_topk(q, 10)
+    s3, i3 = dlc.KeyframeDatabase(x[:400], dtype="bf16", center=True, row_offset=50).match_topk(q, 10)
+    assert torch.equal(i2, i3) and torch.equal(s2, s3)
+    with pytest.raises(ValueError):
+        grown.prefix(1001)
+    with pytest.raises(ValueError):
+        grown.append(np.zeros((2, 300), dtype=np.float32))
+
+
+def test_cli_streams_the_reference_frames(dlc, capsys):
+    from deeploopcloser_amd import loop_closure
+    rc = loop_closure.main([os.path.join(GOLDEN, "frames"), "--network", "cnn_vtl", "--k", "2", "--exclusion", "0",
+                            "--threshold", "-1", "--batch", "2"])
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0
+    # frame 1 sees frame 0; frame 2 sees frames 0 and 1 -> three candidate lines
+    got = sorted((int(l.split("\t")[1]), int(l.split("\t")[3])) for l in out)
+    assert got == [(1, 0), (2, 0), (2, 1)] and all(l.startswith("loop\t") for l in out)
+    rc = loop_closure.main([os.path.join(GOLDEN, "frames"), "--network", "sdav", "--k", "1", "--exclusion", "0",
+                            "--threshold", "-1", "--batch", "3"])
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 2

@@ -56,3 +56,26 @@ def test_flatten_frame_descriptors_and_dtype_names():
     assert torch_dtype("bf16") == torch.bfloat16 and torch_dtype("fp16") == torch.float16
     with pytest.raises(ValueError):
         torch_dtype("int3")
+
+
+def test_loop_closure_candidate_filter_and_oracle():
+    """first_k_eligible keeps, per frame, the first k candidates that are old enough; the
+    oracle's streaming rule on a hand-made sequence."""
+    import torch
+    from deeploopcloser_amd.loop_closure import first_k_eligible
+    from oracle import loop_closure as oloop
+    s = torch.tensor([[0.9, 0.8, 0.7, 0.6], [0.5, 0.4, float("-inf"), float("-inf")]])
+    i = torch.tensor([[7, 2, 9, 1], [3, 0, -1, -1]])
+    fs, fi = first_k_eligible(s, i, torch.tensor([8, 3]), 3)
+    assert fi.tolist() == [[7, 2, 1], [0, -1, -1]]
+    assert fs[0].tolist() == pytest.approx([0.9, 0.8, 0.6]) and fs[1, 0].item() == pytest.approx(0.4)
+    assert torch.isneginf(fs[1, 1:]).all()
+    fs, fi = first_k_eligible(s[:, :2], i[:, :2], torch.tensor([8, 3]), 3)       # fewer candidates than k
+    assert fi.tolist() == [[7, 2, -1], [0, -1, -1]]
+
+    e = np.eye(4)
+    rows = np.stack([e[0], e[1], e[2], e[0], e[1], e[3], e[0]])            # places 0 1 2 0 1 3 0
+    es, ei = oloop.stream_topk(rows, k=2, exclusion=1)
+    assert ei[:2].tolist() == [[-1, -1], [-1, -1]]                          # nothing old enough yet
+    assert ei[3].tolist() == [0, 1] and es[3].tolist() == [1.0, 0.0]        # frame 3 sees 0..1, revisits place 0
+    assert ei[4, 0] == 1 and ei[6].tolist() == [0, 3]                       # ties -> lower id
