@@ -147,79 +147,6 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
-#ifdef DLC_LIFE   // perf experiment build only: shader-clock and 100-MHz stamps around one workgroup's life
-__device__ unsigned long long dlc_dbg_life[4 * 8];
-#define DLC_LIFE_BEGIN()                                                            \
-    const unsigned long long life_c0 = __builtin_amdgcn_s_memtime();                \
-    const unsigned long long life_r0 = __builtin_amdgcn_s_memrealtime()
-#define DLC_LIFE_END()                                                              \
-    do {                                                                            \
-        const unsigned long long life_c1 = __builtin_amdgcn_s_memtime();            \
-        const unsigned long long life_r1 = __builtin_amdgcn_s_memrealtime();        \
-        if ((blockIdx.x & 511) == 300 && blockIdx.y == 0 && threadIdx.x == 0) {     \
-            const int sl_ = (int)(blockIdx.x >> 9) & 7;                             \
-            dlc_dbg_life[sl_ * 4 + 0] = life_c0; dlc_dbg_life[sl_ * 4 + 1] = life_c1; \
-            dlc_dbg_life[sl_ * 4 + 2] = life_r0; dlc_dbg_life[sl_ * 4 + 3] = life_r1; \
-        }                                                                           \
-    } while (0)
-#else
-#define DLC_LIFE_BEGIN() (void)0
-#define DLC_LIFE_END() (void)0
-#endif
-
-// Epilogue shared by the score kernels: acc[t][c] holds, for query  qblk*256 + wc*64 + c*16 + (lane&15),
-// the database rows  tile*256 + wr*128 + (t>>2)*64 + 16*(lane>>4) + 4*(t&3) + 0..3.
-template <bool DENSE>
-__device__ __forceinline__ void score_epilogue(const f32x4_t (&acc)[8][4], const GemmArgs& p, long long tile, int qblk,
-                                               int wr, int wc, int lane) {
-    const int i = lane & 15;
-    const int lg = lane >> 4;
-    if constexpr (DENSE) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int qidx = qblk * BNQ + wc * 64 + c * 16 + i;
-            if (qidx >= p.q) continue;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const long long row0 = tile * BM + wr * 128 + (t >> 2) * 64 + 16 * lg + 4 * (t & 3);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + r < p.n) p.S[(long long)qidx * p.lds + row0 + r] = acc[t][c][r];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int qidx = qblk * BNQ + wc * 64 + c * 16 + i;
-            float hm[2];
-#pragma unroll
-            for (int th = 0; th < 2; ++th) {
-                // this lane's 16 rows of the half are two groups of 8: MFMA tiles {0,1} and {2,3}
-                float m0 = acc[th * 4][c][0], m1 = acc[th * 4 + 2][c][0];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        m0 = fmaxf(m0, acc[th * 4 + tt][c][r]);
-                        m1 = fmaxf(m1, acc[th * 4 + 2 + tt][c][r]);
-                    }
-                hm[th] = fmaxf(m0, m1);
-                const long long g = tile * (BM / GROUP) + wr * 16 + th * 8 + lg * 2;
-                if (qidx < p.q) {
-                    float* dst = p.gmax + (long long)qidx * p.ldg + g;
-                    if (g + 1 < p.ng) *(float2*)dst = make_float2(m0, m1);
-                    else if (g < p.ng) dst[0] = m0;
-                }
-            }
-            float h = fmaxf(hm[0], hm[1]);
-            h = fmaxf(h, __shfl_xor(h, 16));
-            h = fmaxf(h, __shfl_xor(h, 32));
-            const long long ht = tile * 2 + wr;
-            if (lg == 0 && qidx < p.q && ht < p.nh) p.tmax[(long long)qidx * p.ldt + ht] = h;
-        }
-    }
-}
-
 template <typename Tag, bool DENSE>
 __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,7 +158,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     const long long tile = blockIdx.x;
     const int qblk = blockIdx.y;
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem;
-    DLC_LIFE_BEGIN();
 
     // ---- DMA roles: waves 0-3 stream the database (A) halves from HBM, waves 4-7 the query
     // (B) halves from L2.  vmcnt counts per wave and in order, so with one stream per wave the
@@ -286,17 +212,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     // Fragment registers: one k-slice (32 wide) of one half: A 4 tiles, B 2 tiles.
     u32x4_t faX[4], faY[4], fbX[2], fbY[2];
 
-#ifdef DLC_EXP_READS_ONCE  // energy experiment: fragments are read during the first K tile only
-#define DLC_RD_ON (t < 1)
-    int t = 0;
-#else
-#define DLC_RD_ON true
-#endif
 #define DLC_READ_A(DST, RD, OFF)                      \
-    if (DLC_RD_ON) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt)  \
+    _Pragma("unroll") for (int tt = 0; tt < 4; ++tt)  \
         DST[tt] = *(lds_u4p)(lbase + (RD) + (OFF) + tt * 512)
 #define DLC_READ_B(DST, RD, OFF)                      \
-    if (DLC_RD_ON) _Pragma("unroll") for (int c = 0; c < 2; ++c)     \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)     \
         DST[c] = *(lds_u4p)(lbase + (RD) + (OFF) + c * 2048)
 #define DLC_MFMA(FA, FB, AH, BH)                                                                     \
     do {                                                                                             \
@@ -318,14 +238,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
             dma4(voff[H], a_base + (long long)kk_ * 128, lds_stage + (POS) + (H) * HALF_BYTES);      \
         }                                                                                            \
     } while (0)
-#ifdef DLC_EXP_B_ONCE      // energy experiment: the query tiles are staged by the prologue only
-#define DLC_B_ON(t2) ((t2) < 2)
-#else
-#define DLC_B_ON(t2) true
-#endif
 #define DLC_ISSUE_B(POS, H, t2)                                                                      \
     do {                                                                                             \
-        if (!is_a && DLC_B_ON(t2)) {                                                                     \
+        if (!is_a) {                                                                                 \
             int kk_ = (t2) < nk ? (t2) : nk - 1;                                                     \
             dma4(voff[H], b_base + (long long)kk_ * 128, lds_stage + B_RING + (POS) + (H) * HALF_BYTES); \
         }                                                                                            \
@@ -365,11 +280,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     // halves with t+2.  At the end of m6 each wave waits for its own stream: an A wave leaves
     // A1(t+2) in flight (vmcnt 4; three halves / vmcnt 12 with a 3-deep ring), a B wave B0(t+2), B1(t+2) (vmcnt 8); K
     // tile t+1, whose first slices are read in m7 / m8, has then landed.
-#ifdef DLC_EXP_READS_ONCE
-    for (t = 0; t < nk; ++t) {
-#else
     for (int t = 0; t < nk; ++t) {
-#endif
         DLC_READ_B(fbY, rdB0, HALF_BYTES);
         DLC_MFMA(faX, fbX, 0, 0);                                  // m1
         DLC_READ_A(faY, rdA0, HALF_BYTES);
@@ -409,206 +320,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
 #undef DLC_MFMA
 #undef DLC_RELEASE
 
-    DLC_LIFE_END();
-    score_epilogue<DENSE>(acc, p, tile, qblk, wr, wc, lane);
-}
-
-// ---------------------------------------------------------------------------
-// score_gemm_pp_kernel: the same tile, operand images of A, accumulation order (bit-identical
-// results) and epilogue as score_gemm_kernel, scheduled as a two-group ping-pong: the waves of a
-// SIMD (w and w+4) alternate a COMPUTE segment (the 32 MFMAs of one 32-wide k-slice, operands in
-// registers) with a LOAD segment (the 12 fragment reads of the next k-slice + 4 DMA pieces),
-// one segment apart, so that each SIMD's matrix pipe sees one back-to-back MFMA stream while the
-// partner wave is on the LDS / vector-memory paths.  One s_barrier per segment.
-//
-// Segment n of a wave: n = 4t + 2s -> L(t,s) loads k-slice s of K tile t, n + 1 -> C(t,s).
-// Group 0 (waves 0-3) runs segment n in slot n, group 1 (waves 4-7) in slot n + 1.
-//
-// LDS (144 KiB): A ring of 3 K tiles (the 128-B-row image of score_gemm_kernel, 32 KiB each),
-// B ring of 3 k-SLICES (256 query rows x 64 B, 16 KiB each; 16-B chunk kq of row r in slot
-// kq ^ F[(r>>2)&3], F = {0,2,3,1}: conflict-free for the fragment reads).
-//   A tile t is read in slots 4t .. 4t+3 and refilled with tile t+3; waves 0-3 issue tile t+2
-//   into the buffer of tile t-1 during their L(t,0), L(t,1) (slots 4t, 4t+2 > 4t-1) and wait at the
-//   end of L(t,1) with that tile's 8 pieces still in flight: tile t+1 has landed (vmcnt counts in
-//   order) and the barrier ending slot 4t+2 publishes it before slot 4t+4 reads it.
-//   B slice j (= 2t+s) is read in slots 2j, 2j+1 and refilled with slice j+3; waves 4-7 issue slice
-//   j+2 into the buffer of slice j-1 during their L(j) (slot 2j+1 > 2j-1) and then wait with those
-//   4 pieces in flight: slice j+1 has landed, published by the barrier ending slot 2j+1, read
-//   from slot 2j+2 on.
-// ---------------------------------------------------------------------------
-#ifdef DLC_STAMPS   // perf experiment build only: load-segment-end time stamps of one workgroup
-__device__ unsigned dlc_dbg_stamps[8 * 16];
-#define DLC_STAMP_TILE 1000
-#define DLC_STAMP_T0 30
-#endif
-#ifdef DLC_EXP_TILED
-#define DLC_A_KSTRIDE 32768
-#else
-#define DLC_A_KSTRIDE 128
-#endif
-constexpr int PP_A_STAGES = 3;
-constexpr int PP_B_SLICE = 256 * 64;                      // 16 KiB
-constexpr int PP_B_RING = PP_A_STAGES * A_TILE;
-constexpr int PP_LDS_BYTES = PP_A_STAGES * A_TILE + 3 * PP_B_SLICE;
-__device__ __forceinline__ int swz_pp_b(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }   // {0,2,3,1}
-
-template <typename Tag, bool DENSE>
-__global__ __launch_bounds__(NTHREADS, 2) void score_gemm_pp_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2;   // database half (128 rows); also the ping-pong group
-    const int wc = wid & 3;    // query block (64 queries)
-    const long long tile = blockIdx.x;
-    const int qblk = blockIdx.y;
-    const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem;
-    DLC_LIFE_BEGIN();
-
-    // ---- DMA roles: waves 0-3 stream the database (A) from HBM, 32 rows of each half per wave;
-    // waves 4-7 the query slices (B) from L2, 64 rows per wave.
-    const bool is_a = wid < 4;
-    const int ridx = wid & 3;
-    const char* a_base = p.DB + tile * BM * p.lddb_b;
-    const char* b_base = p.Q + (long long)qblk * BNQ * p.ldq_b;
-    unsigned voff[2][4];                                    // A: [half][piece]; B: [0][piece]
-    {
-        const long long arows = p.n - tile * BM;            // valid rows in this tile (>= 1)
-        const long long brows = (long long)p.q - (long long)qblk * BNQ;
+    // ---- epilogue
+    const int lg = lane >> 4;
+    if constexpr (DENSE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = 32 * ridx + 8 * j + (lane >> 3);  // A: row inside the half, 8 rows x 128 B per piece
-            const int rb = 64 * ridx + 16 * j + (lane >> 2);   // B: query row, 16 rows x 64 B per piece
-            long long br = rb > brows - 1 ? brows - 1 : rb;
+        for (int c = 0; c < 4; ++c) {
+            const int qidx = qblk * BNQ + wc * 64 + c * 16 + i;
+            if (qidx >= p.q) continue;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                long long ar = (r >> 6) * 128 + h * 64 + (r & 63);
-                if (ar > arows - 1) ar = arows - 1;
-#ifdef DLC_EXP_TILED   // timing experiment: database stored as [tile][K tile][256 rows][128 B]
-                voff[h][j] = is_a ? (unsigned)(ar * 128 + (((lane & 7) ^ swz_a(r)) << 4))
-#else
-                voff[h][j] = is_a ? (unsigned)(ar * p.lddb_b + (((lane & 7) ^ swz_a(r)) << 4))
-#endif
-                                  : (unsigned)(br * p.ldq_b + (((lane & 3) ^ swz_pp_b(rb)) << 4));
+            for (int t = 0; t < 8; ++t) {
+                const long long row0 = tile * BM + wr * 128 + (t >> 2) * 64 + 16 * lg + 4 * (t & 3);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < p.n) p.S[(long long)qidx * p.lds + row0 + r] = acc[t][c][r];
             }
         }
-    }
-    const unsigned lds_stage_a = lds_base + (unsigned)(32 * ridx) * 128;
-    const unsigned lds_stage_b = lds_base + PP_B_RING + (unsigned)(64 * ridx) * 64;
-    const int nk = p.nk;
-
-    // ---- fragment read offsets
-    const int i = lane & 15;
-    const int kq = lane >> 4;
-    const int fa = ((i >> 1) & 1) | ((i >> 2) << 1);
-    typedef const __attribute__((address_space(3))) u32x4_t* lds_u4p;
-    typedef const __attribute__((address_space(3))) char* lds_cp;
-    const lds_cp lbase = (lds_cp)(lptr_t)smem;
-    // A: bytes inside a K tile image; slice s adds the chunk offset, half h HALF_BYTES, MFMA tile tt 512
-    const unsigned rdA_s0 = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((0 + kq) ^ fa) << 4);
-    const unsigned rdA_s1 = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((4 + kq) ^ fa) << 4);
-    // B: bytes inside a slice image; query tile c adds 16 rows = 1024
-    const unsigned rdB = PP_B_RING + (wc * 64 + i) * 64 + ((kq ^ swz_pp_b(i)) << 4);
-    unsigned aoff = 0;                 // ring position of the CURRENT K tile (bytes)
-    unsigned afill = 2 * A_TILE;       // ring position that K tile t+2 goes to
-    unsigned bcur = 0;                 // ring position of the CURRENT B slice
-    unsigned bfill = 2 * PP_B_SLICE;   // ring position that slice j+2 goes to
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    u32x4_t fA[8], fB[4];              // one k-slice of the wave's 128 x 64 block
-#ifdef DLC_STAMPS
-    unsigned stamp[16];
-#pragma unroll
-    for (int j_ = 0; j_ < 16; ++j_) stamp[j_] = 0;
-#endif
-
-    // this wave's DMA share for the load segment of slice S of K tile T: A waves half S of tile T+2
-    // (k offset clamped past the end: the redundant DMA lands in a dead buffer and keeps the vmcnt
-    // bookkeeping uniform), B waves slice S of tile T+1
-#define DLC_PP_ISSUE(T, S)                                                                                \
-    do {                                                                                                  \
-        if (is_a) {                                                                                       \
-            const int kk_ = (T) + 2 < nk ? (T) + 2 : nk - 1;                                              \
-            dma4(voff[S], a_base + (long long)kk_ * DLC_A_KSTRIDE, lds_stage_a + afill + (S) * HALF_BYTES); \
-        } else {                                                                                          \
-            const int kk_ = (T) + 1 < nk ? (T) + 1 : nk - 1;                                              \
-            dma4(voff[0], b_base + (long long)kk_ * 128 + (S) * 64, lds_stage_b + bfill);                 \
-        }                                                                                                 \
-    } while (0)
-
-    if (tile < 256) {                  // first-round start stagger, as in score_gemm_kernel
-        const int steps = (int)((tile >> 3) % DLC_STAGGER_PHASES) * p.stagger_mult;
-        for (int s_ = 0; s_ < steps; ++s_) __builtin_amdgcn_s_sleep(DLC_STAGGER_SLEEP);
-    }
-    // ---- prologue: A tiles 0, 1 and B slices 0, 1 (= K tile 0); wait for tile 0 / slice 0
-    if (is_a) {
-        dma4(voff[0], a_base, lds_stage_a);
-        dma4(voff[1], a_base, lds_stage_a + HALF_BYTES);
-        const int k1 = nk > 1 ? 1 : 0;
-        dma4(voff[0], a_base + (long long)k1 * DLC_A_KSTRIDE, lds_stage_a + A_TILE);
-        dma4(voff[1], a_base + (long long)k1 * DLC_A_KSTRIDE, lds_stage_a + A_TILE + HALF_BYTES);
-        DLC_WAIT_VMCNT(8);
     } else {
-        dma4(voff[0], b_base, lds_stage_b);
-        dma4(voff[0], b_base + 64, lds_stage_b + PP_B_SLICE);
-        DLC_WAIT_VMCNT(4);
-    }
-    wg_barrier();
-    if (wr == 1) wg_barrier();         // group 1 runs one segment behind
-
-    for (int t = 0; t < nk; ++t) {
 #pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_) {
-            // ---- L(t, s_)
-            const unsigned ra = (s_ ? rdA_s1 : rdA_s0) + aoff;
+        for (int c = 0; c < 4; ++c) {
+            const int qidx = qblk * BNQ + wc * 64 + c * 16 + i;
+            float hm[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int th = 0; th < 2; ++th) {
+                // this lane's 16 rows of the half are two groups of 8: MFMA tiles {0,1} and {2,3}
+                float m0 = acc[th * 4][c][0], m1 = acc[th * 4 + 2][c][0];
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) fA[h * 4 + tt] = *(lds_u4p)(lbase + ra + h * HALF_BYTES + tt * 512);
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) fB[c] = *(lds_u4p)(lbase + rdB + bcur + c * 1024);
-            DLC_PP_ISSUE(t, s_);
-            if (is_a) { if (s_ == 1) DLC_WAIT_VMCNT(8); }
-            else DLC_WAIT_VMCNT(4);
-            bcur = bcur == 2 * PP_B_SLICE ? 0u : bcur + PP_B_SLICE;
-            bfill = bfill == 2 * PP_B_SLICE ? 0u : bfill + PP_B_SLICE;
-#ifdef DLC_STAMPS
-            {
-                const unsigned long long st_ = __builtin_amdgcn_s_memtime();
-                DLC_WAIT_LGKM0();
-                if (t >= DLC_STAMP_T0 && t < DLC_STAMP_T0 + 8) stamp[(t - DLC_STAMP_T0) * 2 + s_] = (unsigned)st_;
+                    for (int r = 0; r < 4; ++r) {
+                        m0 = fmaxf(m0, acc[th * 4 + tt][c][r]);
+                        m1 = fmaxf(m1, acc[th * 4 + 2 + tt][c][r]);
+                    }
+                hm[th] = fmaxf(m0, m1);
+                const long long g = tile * (BM / GROUP) + wr * 16 + th * 8 + lg * 2;
+                if (qidx < p.q) {
+                    float* dst = p.gmax + (long long)qidx * p.ldg + g;
+                    if (g + 1 < p.ng) *(float2*)dst = make_float2(m0, m1);
+                    else if (g < p.ng) dst[0] = m0;
+                }
             }
-#endif
-            DLC_WAIT_LGKM0();
-            wg_barrier();
-            // ---- C(t, s_)
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[tt][c] = Mfma16<Tag>::run(fA[tt], fB[c], acc[tt][c]);
-            __builtin_amdgcn_s_setprio(0);
-            wg_barrier();
+            float h = fmaxf(hm[0], hm[1]);
+            h = fmaxf(h, __shfl_xor(h, 16));
+            h = fmaxf(h, __shfl_xor(h, 32));
+            const long long ht = tile * 2 + wr;
+            if (lg == 0 && qidx < p.q && ht < p.nh) p.tmax[(long long)qidx * p.ldt + ht] = h;
         }
-        aoff = aoff == 2 * A_TILE ? 0u : aoff + A_TILE;
-        afill = afill == 2 * A_TILE ? 0u : afill + A_TILE;
     }
-#undef DLC_PP_ISSUE
-    if (wr == 0) wg_barrier();         // the barrier of group 1's last segment
-    DLC_WAIT_VMCNT(0);                 // the clamped tail DMAs must not outlive the workgroup's LDS
-    DLC_WAIT_LGKM0();
-#ifdef DLC_STAMPS
-    if (tile == DLC_STAMP_TILE && qblk == 0 && lane == 0) {
-#pragma unroll
-        for (int j_ = 0; j_ < 16; ++j_) dlc_dbg_stamps[wid * 16 + j_] = stamp[j_];
-    }
-#endif
-    DLC_LIFE_END();
-    score_epilogue<DENSE>(acc, p, tile, qblk, wr, wc, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -985,23 +742,17 @@ int check_operands(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ld
 
 template <typename Tag, bool DENSE>
 int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
-#ifdef DLC_PINGPONG
-    auto kern = score_gemm_pp_kernel<Tag, DENSE>;
-    constexpr int lds_bytes = PP_LDS_BYTES;
-#else
     auto kern = score_gemm_kernel<Tag, DENSE>;
-    constexpr int lds_bytes = LDS_BYTES;
-#endif
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
-        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     dim3 grid((unsigned)dlc::cdiv(a.n, BM), (unsigned)dlc::cdiv(a.q, BNQ));
     // measured: 0-60 us of stagger pays from ~4 dispatch rounds on, 0-15 us below (scripts/exp_rows.py)
     GemmArgs b = a;
     b.stagger_mult = ((long long)grid.x * grid.y >= 3 * 256) ? 4 : 1;
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds_bytes, st, b);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), LDS_BYTES, st, b);
     DLC_LAUNCH_CHECK(ctx, "score_gemm_kernel");
     return DLC_OK;
 }
@@ -1236,15 +987,3 @@ extern "C" int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* sr
     DLC_LAUNCH_CHECK(ctx, "l2_normalize_kernel");
     return DLC_OK;
 }
-
-#ifdef DLC_STAMPS
-extern "C" int dlc_debug_stamps(unsigned* host128) {
-    return (int)hipMemcpyFromSymbol(host128, HIP_SYMBOL(dlc_dbg_stamps), sizeof(unsigned) * 128);
-}
-#endif
-
-#ifdef DLC_LIFE
-extern "C" int dlc_debug_life(unsigned long long* host32) {
-    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(dlc_dbg_life), sizeof(unsigned long long) * 32);
-}
-#endif
