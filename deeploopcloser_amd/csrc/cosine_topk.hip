@@ -100,6 +100,8 @@ struct GemmArgs {
     float* S;           // dense mode: [q, lds]
     long long lds;
     int stagger_mult;   // first-round start stagger: phase * mult * DLC_STAGGER_SLEEP * 64 cycles
+    int nqb;            // query blocks of 256 (grid mapping below)
+    long long ntiles;   // database tiles of 256 rows
 };
 
 // ---- LDS image (128 KiB): a ring of A_STAGES = 2 K tiles of the database operand (A, streamed
@@ -155,8 +157,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2;   // database half (128 rows)
     const int wc = wid & 3;    // query block (64 queries)
-    const long long tile = blockIdx.x;
-    const int qblk = blockIdx.y;
+    // Workgroup id -> (tile, query block).  Ids go round-robin to the 8 XCDs, each with its own
+    // L2: within a run of 8*nqb ids, id j works on tile 8g + (j & 7) for query block j >> 3, so the
+    // nqb workgroups that stream the same database tile sit on ONE XCD, 8 ids apart in dispatch
+    // order -- the tile comes from HBM once and the others hit that XCD's L2.  (A tile-major grid
+    // re-read the whole database per query block: Q = 512 cost exactly 2x Q = 256.)
+    const unsigned wg = blockIdx.x;
+    const unsigned run = 8u * (unsigned)p.nqb;
+    const int j_ = (int)(wg % run);
+    const long long tile = (long long)(wg / run) * 8 + (j_ & 7);
+    const int qblk = j_ >> 3;
+    if (tile >= p.ntiles) return;      // padding of the last run (before any barrier)
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem;
 
     // ---- DMA roles: waves 0-3 stream the database (A) halves from HBM, waves 4-7 the query
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     // Workgroups of one round would otherwise walk K in lockstep, all CUs touching the same
     // 128-byte column of their rows at the same time; a small start stagger of the FIRST round
     // (later rounds inherit it) spreads them over K without changing any result.
-    if (tile < 256) {
+    if (wg < 256) {
         const int steps = (int)((tile >> 3) % DLC_STAGGER_PHASES) * p.stagger_mult;
         for (int s_ = 0; s_ < steps; ++s_) __builtin_amdgcn_s_sleep(DLC_STAGGER_SLEEP);
     }
@@ -748,10 +759,14 @@ int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
-    dim3 grid((unsigned)dlc::cdiv(a.n, BM), (unsigned)dlc::cdiv(a.q, BNQ));
-    // measured: 0-60 us of stagger pays from ~4 dispatch rounds on, 0-15 us below (scripts/exp_rows.py)
     GemmArgs b = a;
-    b.stagger_mult = ((long long)grid.x * grid.y >= 3 * 256) ? 4 : 1;
+    b.ntiles = dlc::cdiv(a.n, BM);
+    b.nqb = (int)dlc::cdiv(a.q, BNQ);
+    const long long nwg = dlc::cdiv(b.ntiles, 8) * 8 * b.nqb;
+    if (nwg > 0x7fffffffll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: %lld workgroups exceed the grid limit", nwg);
+    dim3 grid((unsigned)nwg);
+    // measured: 0-60 us of stagger pays from ~4 dispatch rounds on, 0-15 us below (scripts/exp_rows.py)
+    b.stagger_mult = (nwg >= 3 * 256) ? 4 : 1;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), LDS_BYTES, st, b);
     DLC_LAUNCH_CHECK(ctx, "score_gemm_kernel");
     return DLC_OK;

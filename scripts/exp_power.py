@@ -23,7 +23,7 @@ for path in sys.argv[1:]:
     L.LIB_PATH = os.path.abspath(path)
     dlc.engine._default.clear()
     eng = dlc.Engine(0)
-    n, d, nq, k = 1_000_000, 4096, 256, 20
+    n, d, nq, k = 1_000_000, 4096, int(os.environ.get("DLC_EXP_Q", "256")), 20
     db = torch.randn((n, d), device=eng.device, dtype=torch.float32).to(torch.bfloat16)
     q = torch.randn((nq, d), device=eng.device, dtype=torch.float32).to(torch.bfloat16)
     ws = torch.empty(eng.topk_workspace_bytes(nq, n, d, k), dtype=torch.uint8, device=eng.device)
@@ -44,7 +44,7 @@ for path in sys.argv[1:]:
     stop.set()
     th.join()
     good = [o for o in out[1:] if o[0] > 0]
-    print("%-32s %.3f ms/launch back-to-back; samples (W, sclk MHz, mclk MHz): %s" % (os.path.basename(path), dt, good), flush=True)
+    print("Q=%d %-32s %.3f ms/launch back-to-back; samples (W, sclk MHz, mclk MHz): %s" % (nq, os.path.basename(path), dt, good), flush=True)
     del db, q, ws
     eng.close()
     time.sleep(3)
