@@ -28,6 +28,17 @@ for dt in ("float64", "float32"):
                       "tflops": flops / t / 1e12}), flush=True)
 h64 = dlc.SDAV(seed=1).transform_tensor(x).reshape(N, 30, 2500)
 
+# --- config 2: cosine matrix + top-k over the flattened [30*2500] place descriptors, bf16
+place = h64.reshape(N, 30 * 2500)
+db = dlc.KeyframeDatabase(place, dtype="bf16", center=True)
+qs = db.rows
+t, s = timed(lambda: eng.cosine_scores(qs, db.rows))
+print(json.dumps({"path": "cosine matrix (flattened SDAV descriptors)", "frames": N, "dim": place.shape[1],
+                  "ms": t * 1e3, "pairs_per_s": N * N / t, "tflops": 2.0 * N * N * db.rows.shape[1] / t / 1e12}), flush=True)
+t, _ = timed(lambda: eng.match_topk(qs, db.rows, 20))
+print(json.dumps({"path": "cosine top-20 (flattened SDAV descriptors)", "frames": N, "ms": t * 1e3}), flush=True)
+del db, qs, s, place
+
 # --- SDAV similarity matrix (reference semantics), fp64
 calc = dlc.SimilarityCalculator(h64)
 t, m = timed(lambda: eng.sdav_similarity_matrix(calc._dataset_dev, calc._score, 10.0, -10.0), reps=2)
