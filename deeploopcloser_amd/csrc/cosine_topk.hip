@@ -26,6 +26,8 @@
 // (two groups of 8).
 #include "dlc_internal.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int BM = 256;          // database rows per workgroup tile
@@ -102,7 +104,15 @@ struct GemmArgs {
     int stagger_mult;   // first-round start stagger: phase * mult * DLC_STAGGER_SLEEP * 64 cycles
     int nqb;            // query blocks of 256 (grid mapping below)
     long long ntiles;   // database tiles of 256 rows
+    int nsplit;         // split-K: chunks of kchunk K tiles, one workgroup each (1 = whole K in one)
+    int kchunk;
+    float* P;           // split-K partial scores [nsplit][q][ldp], ldp = ntiles * 256
+    long long ldp;
 };
+
+constexpr int GEMM_GROUPS = 0;   // epilogue: group / half-tile maxima (top-k path)
+constexpr int GEMM_DENSE = 1;    //           the score tile itself
+constexpr int GEMM_PARTIAL = 2;  //           this K chunk's partial score tile (split-K)
 
 // ---- LDS image (128 KiB): a ring of A_STAGES = 2 K tiles of the database operand (A, streamed
 // from HBM; a 3-deep / 160 KiB ring measured the same) followed by a ring of 2 K tiles of the
@@ -149,7 +159,7 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <typename Tag, bool DENSE>
+template <typename Tag, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -162,7 +172,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     // nqb workgroups that stream the same database tile sit on ONE XCD, 8 ids apart in dispatch
     // order -- the tile comes from HBM once and the others hit that XCD's L2.  (A tile-major grid
     // re-read the whole database per query block: Q = 512 cost exactly 2x Q = 256.)
-    const unsigned wg = blockIdx.x;
+    // Split-K (MODE == GEMM_PARTIAL; few tiles, long rows): the K chunk is the fastest index.
+    const unsigned chunk = MODE == GEMM_PARTIAL ? blockIdx.x % (unsigned)p.nsplit : 0u;
+    const unsigned wg = MODE == GEMM_PARTIAL ? blockIdx.x / (unsigned)p.nsplit : blockIdx.x;
     const unsigned run = 8u * (unsigned)p.nqb;
     const int j_ = (int)(wg % run);
     const long long tile = (long long)(wg / run) * 8 + (j_ & 7);
@@ -175,8 +187,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     // depth of the A prefetch does not depend on the B traffic.
     const bool is_a = wid < 4;
     const int ridx = wid & 3;                               // this wave stages rows 32*ridx .. +31 of a half
-    const char* a_base = p.DB + tile * BM * p.lddb_b;
-    const char* b_base = p.Q + (long long)qblk * BNQ * p.ldq_b;
+    const int k_begin = MODE == GEMM_PARTIAL ? (int)chunk * p.kchunk : 0;
+    const char* a_base = p.DB + tile * BM * p.lddb_b + (long long)k_begin * 128;
+    const char* b_base = p.Q + (long long)qblk * BNQ * p.ldq_b + (long long)k_begin * 128;
     unsigned voff[2][4];                                    // [half][dma]: byte offset of this lane's 16 B
     {
         const int slot = lane & 7;
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
         }
     }
     const unsigned lds_stage = lds_base + (unsigned)(32 * ridx) * 128;   // this wave's rows of a half
-    const int nk = p.nk;
+    const int nk = MODE == GEMM_PARTIAL ? min(p.kchunk, p.nk - k_begin) : p.nk;   // K tiles of this workgroup
 
     // ---- fragment read offsets (bytes inside a half)
     const int i = lane & 15;
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     // Workgroups of one round would otherwise walk K in lockstep, all CUs touching the same
     // 128-byte column of their rows at the same time; a small start stagger of the FIRST round
     // (later rounds inherit it) spreads them over K without changing any result.
-    if (wg < 256) {
+    if (MODE != GEMM_PARTIAL && wg < 256) {
         const int steps = (int)((tile >> 3) % DLC_STAGGER_PHASES) * p.stagger_mult;
         for (int s_ = 0; s_ < steps; ++s_) __builtin_amdgcn_s_sleep(DLC_STAGGER_SLEEP);
     }
@@ -333,7 +346,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
 
     // ---- epilogue
     const int lg = lane >> 4;
-    if constexpr (DENSE) {
+    if constexpr (MODE == GEMM_PARTIAL) {
+        float* part = p.P + (long long)chunk * p.q * p.ldp;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int qidx = qblk * BNQ + wc * 64 + c * 16 + i;
+            if (qidx >= p.q) continue;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const long long row0 = tile * BM + wr * 128 + (t >> 2) * 64 + 16 * lg + 4 * (t & 3);
+                *(f32x4_t*)(part + (long long)qidx * p.ldp + row0) = acc[t][c];   // ldp covers whole tiles
+            }
+        }
+    } else if constexpr (MODE == GEMM_DENSE) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int qidx = qblk * BNQ + wc * 64 + c * 16 + i;
@@ -716,13 +741,80 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const Src* __restrict
     }
 }
 
+// Split-K second pass.  Sums the chunk partials in chunk order (deterministic) and applies the
+// epilogue of the one-pass kernel: GROUPS -> gmax / tmax, DENSE -> the score matrix.
+// grid (q, ceil(groups / 256)), 256 threads: one thread per group of 8 rows.
+__global__ __launch_bounds__(256) void splitk_groups_kernel(const float* __restrict__ P, long long ldp, int q, int nsplit,
+                                                            float* __restrict__ gmax, long long ldg, long long ng,
+                                                            float* __restrict__ tmax, long long ldt, long long nh) {
+    const int qi = blockIdx.x;
+    const long long g = (long long)blockIdx.y * 256 + threadIdx.x;
+    float m = -INFINITY;
+    if (g < ng) {
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        const float* src = P + (long long)qi * ldp + g * GROUP;
+        for (int c = 0; c < nsplit; ++c) {
+            a += *(const f32x4_t*)(src);
+            b += *(const f32x4_t*)(src + 4);
+            src += (long long)q * ldp;
+        }
+        m = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+        gmax[(long long)qi * ldg + g] = m;
+    }
+    // the 16 groups of a half tile sit in 16 consecutive lanes
+    m = fmaxf(m, __shfl_xor(m, 1));
+    m = fmaxf(m, __shfl_xor(m, 2));
+    m = fmaxf(m, __shfl_xor(m, 4));
+    m = fmaxf(m, __shfl_xor(m, 8));
+    const long long ht = g / GROUPS_PER_HALF;
+    if ((threadIdx.x & 15) == 0 && ht < nh) tmax[(long long)qi * ldt + ht] = m;
+}
+
+// grid (q, ceil(n / 1024)), 256 threads: four consecutive rows per thread.
+__global__ __launch_bounds__(256) void splitk_dense_kernel(const float* __restrict__ P, long long ldp, int q, int nsplit,
+                                                           float* __restrict__ S, long long lds, long long n) {
+    const int qi = blockIdx.x;
+    const long long r0 = ((long long)blockIdx.y * 256 + threadIdx.x) * 4;
+    if (r0 >= n) return;
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+    const float* src = P + (long long)qi * ldp + r0;
+    for (int c = 0; c < nsplit; ++c) {
+        a += *(const f32x4_t*)src;
+        src += (long long)q * ldp;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (r0 + r < n) S[(long long)qi * lds + r0 + r] = a[r];
+}
+
+// Split-K plan: when the (tile, query block) grid would leave most CUs idle and the rows are long,
+// K is cut into chunks of >= 8 K tiles so that about two dispatch rounds of workgroups exist.
+struct SplitPlan {
+    int nsplit, kchunk;
+};
+SplitPlan split_plan(int64_t q, int64_t n, int64_t d) {
+    const int64_t base = dlc::cdiv(n, BM) * dlc::cdiv(q, BNQ);
+    const int64_t nk = d / BK;
+    SplitPlan sp{1, (int)nk};
+    if (base >= 128 || nk < 16) return sp;
+    int64_t want = std::min<int64_t>(dlc::cdiv((int64_t)512, base), nk / 8);
+    // partial scores are nsplit * q * (tiles * 256) floats: keep them under 1 GiB
+    const int64_t per_chunk = q * dlc::cdiv(n, BM) * BM * 4;
+    want = std::min<int64_t>(want, (int64_t)(1ll << 30) / std::max<int64_t>(per_chunk, 1));
+    if (want < 2) return sp;
+    sp.kchunk = (int)dlc::cdiv(nk, want);
+    sp.nsplit = (int)dlc::cdiv(nk, (int64_t)sp.kchunk);
+    return sp;
+}
+
 struct WsLayout {
-    size_t gmax, tmax, total;
-    long long ldg, ldt;
+    size_t gmax, tmax, part, total;
+    long long ldg, ldt, ldp;
     int kg;
+    SplitPlan sp;
 };
 
-WsLayout ws_layout(int64_t q, int64_t n, int k) {
+WsLayout ws_layout(int64_t q, int64_t n, int64_t d, int k) {
     WsLayout w;
     const int64_t ntiles = dlc::cdiv(n, BM);
     w.ldg = ntiles * (BM / GROUP);
@@ -731,6 +823,10 @@ WsLayout ws_layout(int64_t q, int64_t n, int k) {
     size_t o = 0;
     w.gmax = o; o += dlc::align_up((size_t)q * w.ldg * 4, 256);
     w.tmax = o; o += dlc::align_up((size_t)q * w.ldt * 4, 256);
+    w.sp = split_plan(q, n, d);
+    w.ldp = ntiles * BM;
+    w.part = o;
+    if (w.sp.nsplit > 1) o += dlc::align_up((size_t)w.sp.nsplit * q * w.ldp * 4, 256);
     w.total = o;
     return w;
 }
@@ -751,9 +847,9 @@ int check_operands(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ld
     return DLC_OK;
 }
 
-template <typename Tag, bool DENSE>
+template <typename Tag, int MODE>
 int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
-    auto kern = score_gemm_kernel<Tag, DENSE>;
+    auto kern = score_gemm_kernel<Tag, MODE>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -762,7 +858,8 @@ int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
     GemmArgs b = a;
     b.ntiles = dlc::cdiv(a.n, BM);
     b.nqb = (int)dlc::cdiv(a.q, BNQ);
-    const long long nwg = dlc::cdiv(b.ntiles, 8) * 8 * b.nqb;
+    if (MODE != GEMM_PARTIAL) { b.nsplit = 1; b.kchunk = a.nk; }
+    const long long nwg = dlc::cdiv(b.ntiles, 8) * 8 * b.nqb * b.nsplit;
     if (nwg > 0x7fffffffll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: %lld workgroups exceed the grid limit", nwg);
     dim3 grid((unsigned)nwg);
     // measured: 0-60 us of stagger pays from ~4 dispatch rounds on, 0-15 us below (scripts/exp_rows.py)
@@ -772,12 +869,32 @@ int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
     return DLC_OK;
 }
 
+// The score pass of a match: one kernel, or split-K partials + the reducing second pass.
+// dense: write S instead of the group maxima.
+template <typename Tag>
+int launch_scores(dlc_ctx* ctx, const GemmArgs& a, bool dense, hipStream_t st) {
+    if (a.nsplit <= 1) return dense ? launch_gemm<Tag, GEMM_DENSE>(ctx, a, st) : launch_gemm<Tag, GEMM_GROUPS>(ctx, a, st);
+    int rc = launch_gemm<Tag, GEMM_PARTIAL>(ctx, a, st);
+    if (rc != DLC_OK) return rc;
+    if (dense) {
+        dim3 grid((unsigned)a.q, (unsigned)dlc::cdiv(a.n, (int64_t)1024));
+        hipLaunchKernelGGL(splitk_dense_kernel, grid, dim3(256), 0, st, a.P, a.ldp, a.q, a.nsplit, a.S, a.lds, a.n);
+        DLC_LAUNCH_CHECK(ctx, "splitk_dense_kernel");
+    } else {
+        const long long groups = dlc::cdiv(a.n, BM) * (BM / GROUP);    // whole tiles: every lane of a half-tile reduction is live
+        dim3 grid((unsigned)a.q, (unsigned)dlc::cdiv(groups, (long long)256));
+        hipLaunchKernelGGL(splitk_groups_kernel, grid, dim3(256), 0, st, a.P, a.ldp, a.q, a.nsplit, a.gmax, a.ldg, a.ng,
+                           a.tmax, a.ldt, a.nh);
+        DLC_LAUNCH_CHECK(ctx, "splitk_groups_kernel");
+    }
+    return DLC_OK;
+}
+
 }  // namespace
 
 extern "C" size_t dlc_cosine_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int k) {
-    (void)d;
-    if (q < 1 || n < 1 || k < 1 || k > DLC_MAX_K) return 0;
-    return ws_layout(q, n, k).total;
+    if (q < 1 || n < 1 || d < BK || k < 1 || k > DLC_MAX_K) return 0;
+    return ws_layout(q, n, d, k).total;
 }
 
 namespace {
@@ -792,7 +909,7 @@ int prepare_match(dlc_ctx* ctx, const char* what, int dtype, const void* Q, int6
     int rc = check_operands(ctx, dtype, Q, q, ldq, DB, n, lddb, d);
     if (rc != DLC_OK) return rc;
     if (k < 1 || k > DLC_MAX_K) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "%s: k=%d outside 1..%d", what, k, DLC_MAX_K);
-    mc->w = ws_layout(q, n, k);
+    mc->w = ws_layout(q, n, d, k);
     if (!workspace || workspace_bytes < mc->w.total)
         return dlc::fail(ctx, DLC_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, workspace_bytes, mc->w.total);
     if (((uintptr_t)workspace & 255)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "%s: workspace must be 256-byte aligned", what);
@@ -805,6 +922,8 @@ int prepare_match(dlc_ctx* ctx, const char* what, int dtype, const void* Q, int6
     a.tmax = (float*)(ws + mc->w.tmax); a.ldt = mc->w.ldt;
     a.ng = dlc::cdiv(n, GROUP); a.nh = dlc::cdiv(n, HALF);
     a.S = nullptr; a.lds = 0;
+    a.nsplit = mc->w.sp.nsplit; a.kchunk = mc->w.sp.kchunk;
+    a.P = (float*)(ws + mc->w.part); a.ldp = mc->w.ldp;
     return DLC_OK;
 }
 
@@ -814,7 +933,7 @@ int run_score(dlc_ctx* ctx, int dtype, MatchCall& mc, hipStream_t st) {
 #endif
     const int slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[slot], st));
-    int rc = (dtype == DLC_BF16) ? launch_gemm<dlc_bf16_tag, false>(ctx, mc.a, st) : launch_gemm<dlc_f16_tag, false>(ctx, mc.a, st);
+    int rc = (dtype == DLC_BF16) ? launch_scores<dlc_bf16_tag>(ctx, mc.a, false, st) : launch_scores<dlc_f16_tag>(ctx, mc.a, false, st);
     if (rc != DLC_OK) return rc;
     if (ctx->profiling) {
         DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[slot], st));
@@ -924,7 +1043,7 @@ extern "C" int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, i
     if (rc != DLC_OK) return rc;
     if (k < 1 || k > DLC_MAX_K) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_rescore_topk: k=%d outside 1..%d", k, DLC_MAX_K);
     MatchCall mc;                                   // no workspace needed: only the operands and kg
-    mc.w = ws_layout(q, n, k);
+    mc.w = ws_layout(q, n, d, k);
     mc.a = GemmArgs{};
     mc.a.Q = (const char*)Q; mc.a.DB = (const char*)DB;
     mc.a.ldq_b = ldq * 2; mc.a.lddb_b = lddb * 2;
@@ -962,21 +1081,34 @@ extern "C" int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* 
     return dlc_topk_merge_strided(ctx, scores, q * k, idx, q * k, parts, q, k, out_scores, out_idx, stream);
 }
 
+extern "C" size_t dlc_cosine_scores_workspace_bytes(int64_t q, int64_t n, int64_t d) {
+    if (q < 1 || n < 1 || d < BK) return 0;
+    const SplitPlan sp = split_plan(q, n, d);
+    return sp.nsplit > 1 ? dlc::align_up((size_t)sp.nsplit * q * dlc::cdiv(n, BM) * BM * 4, 256) : 0;
+}
+
 extern "C" int dlc_cosine_scores(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
-                                 int64_t n, int64_t lddb, int64_t d, float* S, int64_t lds, void* stream) {
+                                 int64_t n, int64_t lddb, int64_t d, float* S, int64_t lds, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
     int rc = check_operands(ctx, dtype, Q, q, ldq, DB, n, lddb, d);
     if (rc != DLC_OK) return rc;
     if (!S || lds < n) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_scores: bad output");
+    const SplitPlan sp = split_plan(q, n, d);
+    const size_t need = dlc_cosine_scores_workspace_bytes(q, n, d);
+    if (need && (!workspace || workspace_bytes < need))
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "cosine_scores: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (need && ((uintptr_t)workspace & 255)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_scores: workspace must be 256-byte aligned");
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    GemmArgs a;
+    GemmArgs a{};
     a.Q = (const char*)Q; a.DB = (const char*)DB;
     a.ldq_b = ldq * 2; a.lddb_b = lddb * 2;
     a.q = (int)q; a.n = n; a.nk = (int)(d / BK);
-    a.gmax = nullptr; a.ldg = 0; a.tmax = nullptr; a.ldt = 0; a.ng = 0; a.nh = 0;
     a.S = S; a.lds = lds;
-    return (dtype == DLC_BF16) ? launch_gemm<dlc_bf16_tag, true>(ctx, a, (hipStream_t)stream)
-                               : launch_gemm<dlc_f16_tag, true>(ctx, a, (hipStream_t)stream);
+    a.nsplit = sp.nsplit; a.kchunk = sp.kchunk;
+    a.P = (float*)workspace; a.ldp = dlc::cdiv(n, BM) * BM;
+    return (dtype == DLC_BF16) ? launch_scores<dlc_bf16_tag>(ctx, a, true, (hipStream_t)stream)
+                               : launch_scores<dlc_f16_tag>(ctx, a, true, (hipStream_t)stream);
 }
 
 extern "C" int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* src, int64_t n, int64_t d, int64_t lds,

@@ -387,8 +387,11 @@ class Engine:
         nq, d = q.shape
         n = db.shape[0]
         s = torch.empty((nq, n), dtype=torch.float32, device=self.device)
+        need = self.lib.dlc_cosine_scores_workspace_bytes(nq, n, d)          # split-K partials; 0 for most shapes
+        ws = self.workspace("scores", need) if need else None
         self._check(self.lib.dlc_cosine_scores(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
-                                                db.stride(0), d, _ptr(s), s.stride(0), self._stream()))
+                                                db.stride(0), d, _ptr(s), s.stride(0), _ptr(ws) if need else None,
+                                                need, self._stream()))
         return s
 
     # ---- profiling hooks for bench.py ---------------------------------------------------

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DLC_ABI_VERSION 1
+#define DLC_ABI_VERSION 2
 
 typedef struct dlc_ctx dlc_ctx;
 
@@ -299,10 +299,16 @@ int dlc_topk_merge_strided(dlc_ctx* ctx, const float* scores, int64_t score_part
 /*
  * Dense score block S[q, n] (fp32) = Q . DB^T for the all-vs-all cosine
  * matrix of config 2 (small N); same operand rules as dlc_cosine_topk.
+ * Few rows with long descriptors (config 2: 1063 x 75 000) are scored split-K: the partial
+ * score tiles go through a caller-provided workspace of dlc_cosine_scores_workspace_bytes()
+ * bytes (0 when the shape is scored in one pass; workspace may then be NULL), 256-byte aligned,
+ * and are summed in chunk order (deterministic).  dlc_cosine_topk does the same inside its own
+ * workspace.
  */
+size_t dlc_cosine_scores_workspace_bytes(int64_t q, int64_t n, int64_t d);
 int dlc_cosine_scores(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
                       const void* DB, int64_t n, int64_t lddb, int64_t d,
-                      float* S, int64_t lds, void* stream);
+                      float* S, int64_t lds, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- introspection used by bench.py (kernel-only timing with HIP events) -- */
 /*

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_host_only_entry_points(lib):
     from deeploopcloser_amd import _lib
-    assert lib.dlc_abi_version() == 1
+    assert lib.dlc_abi_version() == 2
     assert lib.dlc_status_string(0) == b"ok"
     assert lib.dlc_status_string(_lib.DLC_ERR_WORKSPACE) == b"workspace too small"
     # workspace sizes are pure host arithmetic

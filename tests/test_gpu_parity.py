@@ -71,6 +71,36 @@ def test_cosine_topk_vs_oracle(eng, dtype, nq, n, d, k):
     assert_topk_matches(s, i, q_st, db_st, k, row_offset=1000)
 
 
+@pytest.mark.parametrize("nq,n,d,k", [(5, 1000, 8192, 10), (300, 700, 4160, 7), (1, 1063, 75008, 20), (2, 257, 1088, 3)])
+def test_cosine_topk_split_k_vs_oracle(eng, nq, n, d, k):
+    """Few rows with long descriptors (the reference's own scale: 1063 frames x 75 000) are scored
+    split-K: partial tiles + a reducing pass.  Includes ragged last chunks (65 and 17 K tiles)."""
+    assert eng.topk_workspace_bytes(nq, n, d, k) > eng.topk_workspace_bytes(nq, n, 64, k)     # split-K partials planned
+    rng = np.random.RandomState(n + d)
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[0] = db[n // 3] + 0.2 * q[0]
+    db[n - 1] = db[n // 3]                                     # a duplicate in another tile: tie -> lower index
+    db_st, q_st = stored(eng, db, "bf16"), stored(eng, q, "bf16")
+    s, i = eng.match_topk(q_st, db_st, k, row_offset=7)
+    torch.cuda.synchronize()
+    assert i[0, 0].item() == n // 3 + 7 and (k < 2 or i[0, 1].item() == n - 1 + 7)
+    assert_topk_matches(s, i, q_st, db_st, k, row_offset=7)
+
+
+def test_cosine_scores_split_k_vs_oracle(eng):
+    from oracle import cosine as ocos
+    rng = np.random.RandomState(12)
+    x = rng.standard_normal((333, 20000)).astype(np.float32)
+    st = stored(eng, x, "f16")
+    assert eng.lib.dlc_cosine_scores_workspace_bytes(333, 333, st.shape[1]) > 0
+    s = eng.cosine_scores(st[:100], st)
+    ref = ocos.scores(st[:100].float().cpu().numpy(), st.float().cpu().numpy())
+    assert s.shape == (100, 333) and np.abs(s.cpu().numpy() - ref).max() < 2e-5
+    s2 = eng.cosine_scores(st[:100], st)
+    assert torch.equal(s, s2)                                  # chunk-ordered reduction: bit-reproducible
+
+
 def test_cosine_topk_planted_neighbours_exact(eng):
     """Planted-margin data: indices must be IDENTICAL to the oracle's."""
     rng = np.random.RandomState(7)
