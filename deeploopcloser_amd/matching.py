@@ -172,10 +172,10 @@ class MatchPipeline:
         while len(self._slots) <= i:
             self._slots.append(None)
         s = self._slots[i]
-        if s is None or s["nq"] != nq:
+        if s is None or s["nq"] != nq or s["n"] != len(self.db):       # the database may have grown (append)
             dev = self.engine.device
             need = self.engine.topk_workspace_bytes(nq, len(self.db), d, self.k)
-            s = {"nq": nq, "ws": torch.empty(need, dtype=torch.uint8, device=dev),
+            s = {"nq": nq, "n": len(self.db), "ws": torch.empty(need, dtype=torch.uint8, device=dev),
                  "scores": torch.empty((nq, self.k), dtype=torch.float32, device=dev),
                  "idx": torch.empty((nq, self.k), dtype=torch.int64, device=dev),
                  "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "q": None}
