@@ -173,6 +173,8 @@ class MatchPipeline:
             self._slots.append(None)
         s = self._slots[i]
         if s is None or s["nq"] != nq or s["n"] != len(self.db):       # the database may have grown (append)
+            if s is not None and s["busy"]:
+                s["done"].synchronize()             # its buffers are still in use on the second stream
             dev = self.engine.device
             need = self.engine.topk_workspace_bytes(nq, len(self.db), d, self.k)
             s = {"nq": nq, "n": len(self.db), "ws": torch.empty(need, dtype=torch.uint8, device=dev),
