@@ -787,24 +787,37 @@ __global__ __launch_bounds__(256) void splitk_dense_kernel(const float* __restri
         if (r0 + r < n) S[(long long)qi * lds + r0 + r] = a[r];
 }
 
-// Split-K plan: when the (tile, query block) grid would leave most CUs idle and the rows are long,
-// K is cut into chunks of >= 8 K tiles so that about two dispatch rounds of workgroups exist.
+// Split-K plan.  A workgroup walks its K tiles one after the other (~1.6 us each) and a launch with
+// fewer workgroups than CUs leaves the rest idle, so few tiles x long rows are cut along K; the
+// price is the partial score tiles written and read back (nsplit * q * rows * 4 bytes each way)
+// and a second launch.  The plan minimises a small cost model of the two (calibrated with
+// scripts/exp_split.py); nsplit = 1 means one pass.
 struct SplitPlan {
     int nsplit, kchunk;
 };
 SplitPlan split_plan(int64_t q, int64_t n, int64_t d) {
-    const int64_t base = dlc::cdiv(n, BM) * dlc::cdiv(q, BNQ);
+    const int64_t ntiles = dlc::cdiv(n, BM);
+    const int64_t base = dlc::cdiv(ntiles, (int64_t)8) * 8 * dlc::cdiv(q, BNQ);   // workgroups of one pass
     const int64_t nk = d / BK;
-    SplitPlan sp{1, (int)nk};
-    if (base >= 128 || nk < 16) return sp;
-    int64_t want = std::min<int64_t>(dlc::cdiv((int64_t)512, base), nk / 8);
-    // partial scores are nsplit * q * (tiles * 256) floats: keep them under 1 GiB
-    const int64_t per_chunk = q * dlc::cdiv(n, BM) * BM * 4;
-    want = std::min<int64_t>(want, (int64_t)(1ll << 30) / std::max<int64_t>(per_chunk, 1));
-    if (want < 2) return sp;
-    sp.kchunk = (int)dlc::cdiv(nk, want);
-    sp.nsplit = (int)dlc::cdiv(nk, (int64_t)sp.kchunk);
-    return sp;
+    SplitPlan best{1, (int)nk};
+#ifdef DLC_EXPERIMENT_NO_SPLIT   // perf experiment build only (scripts/)
+    return best;
+#endif
+    if (base >= 256 || nk < 8) return best;
+    const double t_k = 1.6, t_fix = 8.0, t_launch = 5.0, bytes_per_us = 3.0e6;
+    const double part_bytes = (double)q * (double)ntiles * BM * 4.0;             // one chunk's partial scores
+    double best_t = (double)dlc::cdiv(base, (int64_t)256) * ((double)nk * t_k + t_fix);
+    for (int64_t ns = 2; ns <= nk / 4; ns = ns < 8 ? ns + 1 : ns + ns / 4) {
+        const int64_t kc = dlc::cdiv(nk, ns), ns_eff = dlc::cdiv(nk, kc);
+        if ((double)ns_eff * part_bytes > (double)(1ll << 30)) break;
+        const double t = (double)dlc::cdiv(base * ns_eff, (int64_t)256) * ((double)kc * t_k + t_fix) +
+                         2.0 * (double)ns_eff * part_bytes / bytes_per_us + t_launch;
+        if (t < best_t * 0.9) {                                                   // split only for a clear gain
+            best_t = t;
+            best = SplitPlan{(int)ns_eff, (int)kc};
+        }
+    }
+    return best;
 }
 
 struct WsLayout {
