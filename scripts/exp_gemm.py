@@ -9,6 +9,9 @@ from deeploopcloser_amd import _lib as L
 def run(libpath, label, n=1_000_000, d=4096, nq=256, k=20, iters=10):
     L._lib = None
     L.LIB_PATH = libpath
+    if os.environ.get("DLC_EXP_OLD_ABI") and label != "shipped":       # libraries built before ABI 2
+        L.SIGNATURES.pop("dlc_cosine_scores_workspace_bytes", None)
+        L.SIGNATURES.pop("dlc_cosine_scores", None)
     dlc.engine._default.clear()
     eng = dlc.Engine(0)
     db = torch.randn((n, d), device=eng.device, dtype=torch.float32).to(torch.bfloat16)
