@@ -16,6 +16,7 @@ DLC_BF16, DLC_F16, DLC_F32, DLC_F64, DLC_I8 = 0, 1, 2, 3, 4
 DLC_ACT_NONE, DLC_ACT_SIGMOID, DLC_ACT_RELU = 0, 1, 2
 DLC_B_KN, DLC_B_NK = 0, 1
 DLC_MAX_K = 128
+DLC_ABI_VERSION = 2          # include/dlc.h; load() refuses a library built from another header
 DLC_SELECT_COOP = 1
 
 _vp, _i64, _int, _sz, _dbl, _flt = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_double, C.c_float
@@ -87,6 +88,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.dlc_abi_version() != DLC_ABI_VERSION:
+        raise ImportError("deeploopcloser_amd: %s has ABI %d, these bindings are for ABI %d -- rebuild it"
+                          % (LIB_PATH, lib.dlc_abi_version(), DLC_ABI_VERSION))
     _lib = lib
     return lib
 

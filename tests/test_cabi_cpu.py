@@ -40,7 +40,9 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_host_only_entry_points(lib):
     from deeploopcloser_amd import _lib
-    assert lib.dlc_abi_version() == 2
+    assert lib.dlc_abi_version() == _lib.DLC_ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "dlc.h")).read()
+    assert "#define DLC_ABI_VERSION %d\n" % _lib.DLC_ABI_VERSION in header
     assert lib.dlc_status_string(0) == b"ok"
     assert lib.dlc_status_string(_lib.DLC_ERR_WORKSPACE) == b"workspace too small"
     # workspace sizes are pure host arithmetic
