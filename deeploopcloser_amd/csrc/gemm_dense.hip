@@ -93,15 +93,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
         cv_ix0 = ox * p.cv.stride - p.cv.pad_l;
         cv_img_base = img * (long long)p.cv.H * p.cv.W * p.cv.C;
     }
+    // (ky, kx, c) of this thread's 8 channels in the NEXT tile to load: load_tile is called with
+    // k0 = 0, TK, 2 TK, ... and steps them instead of dividing by C and KW in every K step
+    int cv_c = 0, cv_kx = 0, cv_ky = 0;
+    if constexpr (CONV) {
+        const int t = a_k / p.cv.C;
+        cv_c = a_k - t * p.cv.C;
+        cv_ky = t / p.cv.KW;
+        cv_kx = t - cv_ky * p.cv.KW;
+    }
     auto load_tile = [&](long long k0) {
         const bool k_full = (k0 + TK <= p.K);
         const long long gm = m0 + a_row;
         if constexpr (CONV) {
             const long long gk = k0 + a_k;                       // multiple of 8; 8 channels of one input pixel
-            const int t = (int)(gk / p.cv.C), c = (int)(gk - (long long)t * p.cv.C);
-            const int ky = t / p.cv.KW, kx = t - ky * p.cv.KW;
-            const int iy = cv_iy0 + ky, ix = cv_ix0 + kx;
+            const int iy = cv_iy0 + cv_ky, ix = cv_ix0 + cv_kx;
             const bool ok = gm < p.M && gk < p.K && iy >= 0 && iy < p.cv.H && ix >= 0 && ix < p.cv.W;
+            const int c = cv_c;
+            cv_c += TK;
+            while (cv_c >= p.cv.C) {
+                cv_c -= p.cv.C;
+                if (++cv_kx == p.cv.KW) { cv_kx = 0; ++cv_ky; }
+            }
             if (ok) {
                 const T* src = p.A + cv_img_base + ((long long)iy * p.cv.W + ix) * p.cv.C + c;
 #pragma unroll

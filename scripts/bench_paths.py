@@ -53,9 +53,9 @@ print(json.dumps({"path": "cnn_vtl distance matrix", "frames": N, "ms": t * 1e3,
                   "byte_pairs_per_s": N * N * 2243 / t}), flush=True)
 
 # --- CnnVtl encode (192x240 frames)
-nf = min(N, 256)
+nf = N
 frames = torch.randint(0, 256, (nf, 192, 240, 3), generator=g, device=eng.device).to(torch.float64)
-cnn = dlc.CnnVtl(input_shape=[nf, 192, 240, 3], frame_chunk=128)
+cnn = dlc.CnnVtl(input_shape=[nf, 192, 240, 3])
 t, d8 = timed(lambda: cnn.transform_tensor(frames), reps=2)
 print(json.dumps({"path": "CnnVtl.transform", "frames": nf, "ms": t * 1e3, "frames_per_s": nf / t,
                   "tflops_f64": 1.748e9 * nf / t / 1e12}), flush=True)
