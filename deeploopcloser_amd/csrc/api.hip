@@ -57,6 +57,15 @@ extern "C" int dlc_destroy(dlc_ctx* ctx) {
 
 extern "C" const char* dlc_last_error(const dlc_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
+extern "C" int dlc_set_scratch(dlc_ctx* ctx, void* scratch, size_t bytes) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if ((scratch && bytes == 0) || ((uintptr_t)scratch & 255))
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "set_scratch: need a 256-byte aligned buffer (or NULL, 0)");
+    ctx->scratch = scratch;
+    ctx->scratch_bytes = scratch ? bytes : 0;
+    return DLC_OK;
+}
+
 extern "C" int dlc_set_profiling(dlc_ctx* ctx, int enabled) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     ctx->profiling = enabled ? 1 : 0;

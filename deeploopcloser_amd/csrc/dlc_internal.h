@@ -15,6 +15,8 @@ struct dlc_ctx {
     long long prof_calls;                       // cosine_topk calls recorded since profiling was enabled
     hipEvent_t ev_start[DLC_PROFILE_RING];
     hipEvent_t ev_stop[DLC_PROFILE_RING];
+    void* scratch;                              // caller-owned split-K scratch (dlc_set_scratch), may be null
+    size_t scratch_bytes;
 };
 
 namespace dlc {

@@ -13,6 +13,8 @@
 // the current tile's MFMAs.
 #include "dlc_internal.h"
 
+#include <algorithm>
+
 namespace dlc_gemm {
 
 constexpr int TM = 128, TN = 128, TK = 16;
@@ -60,6 +62,8 @@ struct Args {
     long long M, N, K;
     int act;
     ConvGeom cv;
+    long long kchunk;   // split-K: elements of K per chunk (a multiple of TK; >= K when one pass), chunk = blockIdx.z
+    T* P;               // split-K partial results [chunks][M][N] (null when one pass)
 };
 
 template <typename T, int BLAYOUT, bool CONV = false>
@@ -71,6 +75,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const long long m0 = (long long)blockIdx.x * TM, n0 = (long long)blockIdx.y * TN;
+    const long long kb = (long long)blockIdx.z * p.kchunk;          // this workgroup's K range [kb, kend)
+    const long long kend = kb + p.kchunk < p.K ? kb + p.kchunk : p.K;
 
     // staging coordinates
     const int a_row = tid >> 1, a_k = (tid & 1) * 8;            // A: 2 threads per row, 8 k each
@@ -97,10 +103,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     // k0 = 0, TK, 2 TK, ... and steps them instead of dividing by C and KW in every K step
     int cv_c = 0, cv_kx = 0, cv_ky = 0;
     if constexpr (CONV) {
-        const int t = a_k / p.cv.C;
-        cv_c = a_k - t * p.cv.C;
-        cv_ky = t / p.cv.KW;
-        cv_kx = t - cv_ky * p.cv.KW;
+        const long long t = (kb + a_k) / p.cv.C;
+        cv_c = (int)(kb + a_k - t * p.cv.C);
+        cv_ky = (int)(t / p.cv.KW);
+        cv_kx = (int)(t - (long long)cv_ky * p.cv.KW);
     }
     auto load_tile = [&](long long k0) {
         const bool k_full = (k0 + TK <= p.K);
@@ -181,12 +187,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (typename Mma<T>::acc_t){0, 0, 0, 0};
 
     const int fr = lane & 15, fk = lane >> 4;
-    const long long nkt = (p.K + TK - 1) / TK;
-    load_tile(0);
+    const long long nkt = (kend - kb + TK - 1) / TK;
+    load_tile(kb);
     for (long long kt = 0; kt < nkt; ++kt) {
         store_tile();
         __syncthreads();
-        if (kt + 1 < nkt) load_tile((kt + 1) * TK);
+        if (kt + 1 < nkt) load_tile(kb + (kt + 1) * TK);
 #pragma unroll
         for (int kk = 0; kk < TK / 4; ++kk) {
             T a[4], b[4];
@@ -205,6 +211,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
         __syncthreads();
     }
 
+    if (p.P) {                                  // split-K: this chunk's raw partial tile
+        T* part = p.P + (long long)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long gn = n0 + wc * 64 + j * 16 + fr;
+            if (gn >= p.N) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long gm = m0 + wr * 64 + i * 16 + Mma<T>::row(lane, r);
+                    if (gm < p.M) part[gm * p.N + gn] = acc[i][j][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long long gn = n0 + wc * 64 + j * 16 + fr;
@@ -220,6 +242,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     }
 }
 
+// Split-K second pass: C = act(sum over chunks, in chunk order, + bias).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_bias_act_kernel(const T* __restrict__ P, int chunks, const T* __restrict__ bias,
+                                                              T* __restrict__ C, long long ldc, long long M, long long N,
+                                                              int act) {
+    const long long total = M * N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / N, c = e - r * N;
+        T z = P[e];
+        for (int s_ = 1; s_ < chunks; ++s_) z += P[(long long)s_ * total + e];
+        C[r * ldc + c] = apply_act<T>(z + (bias ? bias[c] : (T)0), act);
+    }
+}
+
+// Chunks of K for a launch that would otherwise put fewer workgroups than CUs on a long K
+// (single-frame latency mode); 1 = one pass.  Needs the context's scratch (dlc_set_scratch).
+template <typename T>
+int plan_split(const dlc_ctx* ctx, int64_t M, int64_t N, int64_t K, long long* kchunk) {
+    const int64_t wgs = dlc::cdiv(M, TM) * dlc::cdiv(N, TN), ksteps = dlc::cdiv(K, TK);
+    *kchunk = ksteps * TK;
+    if (!ctx->scratch || wgs >= 128 || ksteps < 16) return 1;
+    int64_t want = std::min<int64_t>(dlc::cdiv((int64_t)512, wgs), ksteps / 8);
+    const int64_t fit = (int64_t)(ctx->scratch_bytes / ((size_t)M * (size_t)N * sizeof(T)));
+    want = std::min(want, fit);
+    if (want < 2) return 1;
+    const int64_t steps = dlc::cdiv(ksteps, want);
+    *kchunk = steps * TK;
+    return (int)dlc::cdiv(ksteps, steps);
+}
+
 template <typename T>
 int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
            const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st,
@@ -228,20 +280,22 @@ int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, 
     a.A = (const T*)A; a.lda = lda; a.B = (const T*)B; a.ldb = ldb; a.bias = (const T*)bias;
     a.C = (T*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
     a.cv = cv ? *cv : ConvGeom{};
-    if (cv) {
-        if (dlc::cdiv(N, TN) > 65535 || dlc::cdiv(M, TM) > 0x7fffffffll)
-            return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "conv: too large for one launch");
-        dim3 cgrid((unsigned)dlc::cdiv(M, TM), (unsigned)dlc::cdiv(N, TN));
-        hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, true>), cgrid, dim3(256), 0, st, a);
-        DLC_LAUNCH_CHECK(ctx, "gemm_bias_act_kernel(conv)");
-        return DLC_OK;
-    }
     if (dlc::cdiv(N, TN) > 65535 || dlc::cdiv(M, TM) > 0x7fffffffll)
         return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "gemm: M or N too large for one launch");
-    dim3 grid((unsigned)dlc::cdiv(M, TM), (unsigned)dlc::cdiv(N, TN));
-    if (blayout == DLC_B_KN) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN>), grid, dim3(256), 0, st, a);
+    const int chunks = plan_split<T>(ctx, M, N, K, &a.kchunk);
+    a.P = chunks > 1 ? (T*)ctx->scratch : nullptr;
+    dim3 grid((unsigned)dlc::cdiv(M, TM), (unsigned)dlc::cdiv(N, TN), (unsigned)chunks);
+    if (cv) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, true>), grid, dim3(256), 0, st, a);
+    else if (blayout == DLC_B_KN) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_NK>), grid, dim3(256), 0, st, a);
     DLC_LAUNCH_CHECK(ctx, "gemm_bias_act_kernel");
+    if (chunks > 1) {
+        long long blocks = dlc::cdiv(M * N, (int64_t)256);
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL(splitk_bias_act_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)a.P, chunks,
+                           (const T*)bias, (T*)C, (long long)ldc, (long long)M, (long long)N, act);
+        DLC_LAUNCH_CHECK(ctx, "splitk_bias_act_kernel");
+    }
     return DLC_OK;
 }
 

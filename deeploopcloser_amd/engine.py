@@ -16,6 +16,7 @@ _NAME_TO_TORCH = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f16": tor
                   "float16": torch.float16, "f32": torch.float32, "float32": torch.float32, "f64": torch.float64,
                   "float64": torch.float64}
 
+SCRATCH_BYTES = 256 << 20   # default split-K scratch per engine (Engine.set_scratch)
 K_STEP = 64   # the score GEMM's K step: stored descriptor rows are padded to a multiple of it
 
 
@@ -49,11 +50,23 @@ class Engine:
             raise L.DlcError("dlc_create(%d) failed: %s" % (self.device.index, self.lib.dlc_status_string(rc).decode()))
         self.ctx = ctx
         self._ws = {}
+        self._scratch = None
+
+    def set_scratch(self, nbytes=SCRATCH_BYTES):
+        """Latency mode: lend the context `nbytes` of HBM for the split-K form of the dense GEMMs
+        (a single frame: SDAV layers with 30 rows, conv3-5 with 130 output pixels -- 5-8x lower
+        encode latency); 0 turns it off.  OFF by default: one-pass GEMMs make an encode bit-identical
+        whatever the batch it is part of, split-K changes the summation order (by ~1e-16 relative)."""
+        torch.cuda.synchronize(self.device)         # nothing in flight may still use the old buffer
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device) if nbytes else None
+        self._check(self.lib.dlc_set_scratch(self.ctx, _ptr(t) if t is not None else None, int(nbytes)))
+        self._scratch = t              # keeps the previous buffer alive until the context has the new one
 
     def close(self):
         if getattr(self, "ctx", None):
             self.lib.dlc_destroy(self.ctx)
             self.ctx = None
+            self._scratch = None
 
     def __del__(self):
         try:

@@ -143,9 +143,16 @@ def main(argv=None):
     ap.add_argument("--exclusion", type=int, default=30)
     ap.add_argument("--batch", type=int, default=16, help="frames encoded and matched per step")
     ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16")
+    ap.add_argument("--no-latency-mode", action="store_true",
+                    help="keep the one-pass GEMMs (bit-identical to a large-batch encode) for small batches too")
     args = ap.parse_args(argv)
 
     files = _frame_files(args.dataset_path, args.pattern)
+    from .engine import default_engine
+    eng = default_engine()
+    latency = args.batch <= 16 and not args.no_latency_mode
+    if latency:
+        eng.set_scratch()                        # split-K encode GEMMs: ~8x lower latency per frame
     if args.network == "sdav":
         from .sdav import SDAV
         net = SDAV()
@@ -171,6 +178,8 @@ def main(argv=None):
         for frame, match, score in det.loops(s, i, lo):
             print("loop\t%d\t%s\t%d\t%s\t%.4f" % (frame, os.path.basename(files[frame]), match,
                                                  os.path.basename(files[match]), score))
+    if latency:
+        eng.set_scratch(0)
     print("frames\t%d\tkey-frames\t%d" % (len(files), len(det)), file=sys.stderr)
     return 0
 

@@ -310,6 +310,20 @@ int dlc_cosine_scores(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t
                       const void* DB, int64_t n, int64_t lddb, int64_t d,
                       float* S, int64_t lds, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- split-K scratch of the dense GEMMs ------------------------------------- */
+/*
+ * Latency mode (a single frame: SDAV layers with M = 30 rows, conv3-5 with M = 130 output
+ * pixels) leaves a 128x128-tiled GEMM with a handful of workgroups walking a long K.  When
+ * the caller lends the context a scratch buffer, dlc_gemm_bias_act / dlc_conv2d_nhwc_f64 /
+ * dlc_sdav_encode cut K into chunks for such shapes (partial tiles in the scratch, summed in
+ * chunk order by a second kernel that applies bias + activation): deterministic, results
+ * equal to the one-pass kernel up to the summation order.  The buffer stays caller-owned
+ * (device memory, 256-byte aligned, >= a few MiB to be useful; NULL / 0 turns the mode off)
+ * and must outlive every call that may use it; calls sharing one context's scratch must be
+ * stream-ordered with respect to each other.
+ */
+int dlc_set_scratch(dlc_ctx* ctx, void* scratch, size_t bytes);
+
 /* ---- introspection used by bench.py (kernel-only timing with HIP events) -- */
 /*
  * With profiling enabled every dlc_cosine_topk call records a hipEvent pair on

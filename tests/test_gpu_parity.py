@@ -233,6 +233,53 @@ def test_gemm_bias_act_f64(eng, m, n, k, blayout):
         assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("m,n,k,blayout", [(30, 2500, 2500, "kn"), (130, 384, 3456, "kn"), (60, 300, 1681, "nk"), (1, 129, 4000, "kn")])
+def test_gemm_split_k_latency_mode(eng, m, n, k, blayout):
+    """Few rows x long K (one frame's SDAV layer / conv3-5) run split-K through the engine's scratch:
+    same result as one pass up to the summation order, bit-reproducible, 1e-10 from NumPy."""
+    from deeploopcloser_amd import _lib as L
+    rng = np.random.RandomState(m + n)
+    a = rng.standard_normal((m, k)) / np.sqrt(k)
+    b = rng.standard_normal((k, n)) if blayout == "kn" else rng.standard_normal((n, k))
+    bias = rng.standard_normal(n)
+    ref = 1.0 / (1.0 + np.exp(-(a @ (b if blayout == "kn" else b.T) + bias)))
+    ta, tb, tbias = (torch.from_numpy(v).to(eng.device) for v in (a, b, bias))
+    lay = L.DLC_B_KN if blayout == "kn" else L.DLC_B_NK
+    one_pass = eng.gemm_bias_act(ta, tb, tbias, act=L.DLC_ACT_SIGMOID, blayout=lay)
+    eng.set_scratch()
+    try:
+        split = eng.gemm_bias_act(ta, tb, tbias, act=L.DLC_ACT_SIGMOID, blayout=lay)
+        again = eng.gemm_bias_act(ta, tb, tbias, act=L.DLC_ACT_SIGMOID, blayout=lay)
+    finally:
+        eng.set_scratch(0)
+    assert torch.equal(split, again)
+    assert np.abs(split.cpu().numpy() - ref).max() < 1e-10
+    assert np.abs(one_pass.cpu().numpy() - ref).max() < 1e-10
+    assert (split - one_pass).abs().max().item() < 1e-12
+
+
+def test_latency_mode_encoders_vs_oracle(dlc, eng):
+    """Single-frame SDAV and CnnVtl encodes with the split-K scratch on: same oracle tolerances."""
+    from oracle import sdav as osdav, cnn_vtl as ocnn
+    rng = np.random.RandomState(21)
+    x = rng.uniform(0, 1, (1, 30, 1681))
+    frame = rng.randint(0, 256, (1, 192, 240, 3)).astype(np.float64)
+    net = dlc.SDAV(seed=5)
+    cnn = dlc.CnnVtl(input_shape=[1, 192, 240, 3], seed=3, mask_seed=4)
+    eng.set_scratch()
+    try:
+        h = net.transform(x)
+        d = cnn.transform(frame)
+    finally:
+        eng.set_scratch(0)
+    ws, bs = net.get_weights()
+    assert np.abs(h - osdav.transform(x, ws, bs)).max() < 1e-10
+    cw, cb = ocnn.init_weights(3)
+    ref = ocnn.transform(frame, cw, cb, ocnn.column_indices(cnn.layer_sizes, 99.59, seed=4))
+    diff = (d.astype(np.int16) - ref.astype(np.int16)) % 256      # a value on a truncation boundary may flip by one
+    assert d.dtype == np.int8 and np.count_nonzero(diff) <= 2 and np.all((diff == 0) | (diff == 1) | (diff == 255))
+
+
 def test_gemm_bias_act_f32(eng):
     rng = np.random.RandomState(0)
     a = rng.standard_normal((300, 777)).astype(np.float32)
