@@ -3,6 +3,7 @@ device pointers + the current HIP stream to libdlc_hip.so.  PyTorch is used for
 device memory, streams and torch.distributed only; every computation below
 runs in the hand-written HIP kernels.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -61,6 +62,18 @@ class Engine:
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device) if nbytes else None
         self._check(self.lib.dlc_set_scratch(self.ctx, _ptr(t) if t is not None else None, int(nbytes)))
         self._scratch = t              # keeps the previous buffer alive until the context has the new one
+
+    @contextlib.contextmanager
+    def latency_mode(self, nbytes=SCRATCH_BYTES):
+        """`with engine.latency_mode():` -- split-K scratch on inside the block (no-op if already on)."""
+        if self._scratch is not None:
+            yield
+            return
+        self.set_scratch(nbytes)
+        try:
+            yield
+        finally:
+            self.set_scratch(0)
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -14,6 +14,7 @@ of its frames may see, with k+B-1 candidates per frame, and each frame then keep
 candidates that are old enough (at most B-1 of the extra rows are too recent for it).
 """
 import argparse
+import contextlib
 import glob
 import os
 import sys
@@ -150,9 +151,12 @@ def main(argv=None):
     files = _frame_files(args.dataset_path, args.pattern)
     from .engine import default_engine
     eng = default_engine()
-    latency = args.batch <= 16 and not args.no_latency_mode
-    if latency:
-        eng.set_scratch()                        # split-K encode GEMMs: ~8x lower latency per frame
+    latency = args.batch <= 16 and not args.no_latency_mode      # split-K encode GEMMs: ~8x lower latency per frame
+    with (eng.latency_mode() if latency else contextlib.nullcontext()):
+        return _stream(args, files)
+
+
+def _stream(args, files):
     if args.network == "sdav":
         from .sdav import SDAV
         net = SDAV()
@@ -178,8 +182,6 @@ def main(argv=None):
         for frame, match, score in det.loops(s, i, lo):
             print("loop\t%d\t%s\t%d\t%s\t%.4f" % (frame, os.path.basename(files[frame]), match,
                                                  os.path.basename(files[match]), score))
-    if latency:
-        eng.set_scratch(0)
     print("frames\t%d\tkey-frames\t%d" % (len(files), len(det)), file=sys.stderr)
     return 0
 

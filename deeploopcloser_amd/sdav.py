@@ -181,27 +181,30 @@ class SDAV:
         frames = [np.asarray(f, dtype=np.float64) for f in dataset]
         bs = self.default_batch_size
         batches = [np.stack(frames[i:i + bs]) for i in range(0, len(frames), bs)]
-        for i in range(len(self.hidden_units)):
-            logging.info("Fitting layer %d" % i)
-            for batch_n, b in enumerate(batches):
-                if b.shape[0] < 2:
-                    logging.warning("skipping a batch of %d frame(s): the loss needs >= 2" % b.shape[0])
-                    continue
-                xb = self.engine.to_device(b, torch.float64)
-                for step in range(self.epochs):
-                    loss = self.train_step(i, xb)
-                    if self.logger.isEnabledFor(logging.INFO):
-                        logging.info("    Layer:%d Batch:%d fit, Epoch:%d/%d, Loss:%s" %
-                                     (i, batch_n, step + 1, self.epochs, float(loss[0].item())))
-            if self.checkpoint_file:
-                self.save_weights("%s-%d.npz" % (self.checkpoint_file, self.global_step))
+        # a 10-frame batch is 300 rows: the step's GEMMs are latency-bound without split-K (6.0 -> 2.8 ms)
+        with self.engine.latency_mode():
+            for i in range(len(self.hidden_units)):
+                logging.info("Fitting layer %d" % i)
+                for batch_n, b in enumerate(batches):
+                    if b.shape[0] < 2:
+                        logging.warning("skipping a batch of %d frame(s): the loss needs >= 2" % b.shape[0])
+                        continue
+                    xb = self.engine.to_device(b, torch.float64)
+                    for step in range(self.epochs):
+                        loss = self.train_step(i, xb)
+                        if self.logger.isEnabledFor(logging.INFO):
+                            logging.info("    Layer:%d Batch:%d fit, Epoch:%d/%d, Loss:%s" %
+                                         (i, batch_n, step + 1, self.epochs, float(loss[0].item())))
+                if self.checkpoint_file:
+                    self.save_weights("%s-%d.npz" % (self.checkpoint_file, self.global_step))
 
     def fit(self, x):
         """SDAV.fit (:277-288): the whole array as one batch, `epochs` steps per layer."""
         xb = self.engine.to_device(x, torch.float64)
-        for i in range(len(self.hidden_units)):
-            for step in range(self.epochs):
-                self.train_step(i, xb)
+        with self.engine.latency_mode():
+            for i in range(len(self.hidden_units)):
+                for step in range(self.epochs):
+                    self.train_step(i, xb)
 
 
 class DA:
