@@ -469,6 +469,8 @@ struct FinishExtra {
     const float* all_max;     // [parts, q, kg] or null
     int parts;
     long long nq;
+    int gparts;               // FIN_RESCORE: > 1 = grid.y workgroups per query, workgroup y re-scores the listed
+                              // groups e with e % gparts == y and writes its top-k at [y][q][k]
 };
 
 template <typename Tag, int THREADS, int RS_UNROLL, int MODE>
@@ -564,6 +566,7 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(
                 }
                 if (greater >= kg) g = -1;
             }
+            if (x.gparts > 1 && e % x.gparts != (int)blockIdx.y) g = -1;
             sel2[e] = g;
         }
         __syncthreads();
@@ -629,9 +632,10 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(
             if (lane == r) cval[s * GROUP + r] = (row0 + r < n) ? v : -INFINITY;
         }
     }
+    const long long oq = (long long)blockIdx.y * x.nq + qi;      // blockIdx.y > 0 only with gparts > 1
     for (int e = tid; e < k; e += FIN_THREADS) {          // defaults for slots past the candidates
-        out_s[(long long)qi * k + e] = -INFINITY;
-        out_i[(long long)qi * k + e] = -1;
+        out_s[oq * k + e] = -INFINITY;
+        out_i[oq * k + e] = -1;
     }
     for (int e = tid; e < kg; e += FIN_THREADS) sel[e] = -1;
     __syncthreads();
@@ -649,8 +653,8 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(
     for (int e = tid; e < k; e += FIN_THREADS) {
         const int c = sel[e];
         if (c >= 0) {
-            out_s[(long long)qi * k + e] = cval[c];
-            out_i[(long long)qi * k + e] = (long long)key_id(ckey[c]) + row_offset;
+            out_s[oq * k + e] = cval[c];
+            out_i[oq * k + e] = (long long)key_id(ckey[c]) + row_offset;
         }
     }
 }
@@ -821,11 +825,19 @@ SplitPlan split_plan(int64_t q, int64_t n, int64_t d) {
 }
 
 struct WsLayout {
-    size_t gmax, tmax, part, total;
+    size_t gmax, tmax, part, rs_ids, rs_max, rs_scores, rs_idx, total;
     long long ldg, ldt, ldp;
     int kg;
     SplitPlan sp;
+    int rparts;     // > 1: dlc_cosine_topk re-scores with this many workgroups per query (few queries, long rows)
 };
+
+// One workgroup per query gathers kg * 8 rows: with a handful of queries and long rows (1 query x
+// 75 000-d: 29 MB through one CU, 300 us) the re-score is spread over one workgroup per selected group.
+int rescore_parts(int64_t q, int64_t d, int kg, int k) {
+    if (q > 32 || (int64_t)kg * GROUP * d * 2 < (2 << 20)) return 1;
+    return std::min(kg, 3072 / k);            // the merge of the parts keeps parts * k 16-byte keys in 48 KiB of LDS
+}
 
 WsLayout ws_layout(int64_t q, int64_t n, int64_t d, int k) {
     WsLayout w;
@@ -840,6 +852,14 @@ WsLayout ws_layout(int64_t q, int64_t n, int64_t d, int k) {
     w.ldp = ntiles * BM;
     w.part = o;
     if (w.sp.nsplit > 1) o += dlc::align_up((size_t)w.sp.nsplit * q * w.ldp * 4, 256);
+    w.rparts = rescore_parts(q, d, w.kg, k);
+    w.rs_ids = w.rs_max = w.rs_scores = w.rs_idx = o;
+    if (w.rparts > 1) {
+        w.rs_ids = o; o += dlc::align_up((size_t)q * w.kg * 4, 256);
+        w.rs_max = o; o += dlc::align_up((size_t)q * w.kg * 4, 256);
+        w.rs_scores = o; o += dlc::align_up((size_t)w.rparts * q * k * 4, 256);
+        w.rs_idx = o; o += dlc::align_up((size_t)w.rparts * q * k * 8, 256);
+    }
     w.total = o;
     return w;
 }
@@ -966,7 +986,7 @@ int launch_finish(dlc_ctx* ctx, const MatchCall& mc, int k, int64_t n, int64_t d
     auto fk = finish_topk_kernel<Tag, THREADS, RS_UNROLL, MODE>;
     if (dsm > 48 * 1024)
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm));
-    hipLaunchKernelGGL(fk, dim3((unsigned)q), dim3(THREADS), dsm, st, a.tmax, a.ldt, (int)a.nh, tv_in_lds, a.gmax, a.ldg,
+    hipLaunchKernelGGL(fk, dim3((unsigned)q, (unsigned)(MODE == FIN_RESCORE && x.gparts > 1 ? x.gparts : 1)), dim3(THREADS), dsm, st, a.tmax, a.ldt, (int)a.nh, tv_in_lds, a.gmax, a.ldg,
                        a.ng, mc.w.kg, a.Q, a.ldq_b, a.DB, a.lddb_b, (long long)n, (int)d, k, (long long)row_offset,
                        out_scores, (long long*)out_idx, x);
     DLC_LAUNCH_CHECK(ctx, "finish_topk_kernel");
@@ -998,7 +1018,20 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     rc = run_score(ctx, dtype, mc, (hipStream_t)stream);
     if (rc != DLC_OK) return rc;
-    return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, 0, FinishExtra{}, (hipStream_t)stream);
+    if (mc.w.rparts <= 1)
+        return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, 0, FinishExtra{}, (hipStream_t)stream);
+    // few queries, long rows: group selection, re-score with one workgroup per selected group, merge
+    char* ws = (char*)workspace;
+    FinishExtra x{};
+    x.grp_ids = (int*)(ws + mc.w.rs_ids); x.grp_max = (float*)(ws + mc.w.rs_max); x.nq = q;
+    rc = run_select<FIN_GROUPS>(ctx, dtype, mc, k, n, d, q, 0, nullptr, nullptr, 0, x, (hipStream_t)stream);
+    if (rc != DLC_OK) return rc;
+    x.gparts = mc.w.rparts;
+    float* ps = (float*)(ws + mc.w.rs_scores);
+    int64_t* pi = (int64_t*)(ws + mc.w.rs_idx);
+    rc = run_select<FIN_RESCORE>(ctx, dtype, mc, k, n, d, q, row_offset, ps, pi, DLC_SELECT_COOP, x, (hipStream_t)stream);
+    if (rc != DLC_OK) return rc;
+    return dlc_topk_merge_strided(ctx, ps, q * k, pi, q * k, mc.w.rparts, q, k, out_scores, out_idx, stream);
 }
 
 extern "C" int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,

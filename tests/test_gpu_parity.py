@@ -71,7 +71,8 @@ def test_cosine_topk_vs_oracle(eng, dtype, nq, n, d, k):
     assert_topk_matches(s, i, q_st, db_st, k, row_offset=1000)
 
 
-@pytest.mark.parametrize("nq,n,d,k", [(5, 1000, 8192, 10), (300, 700, 4160, 7), (1, 1063, 75008, 20), (2, 257, 1088, 3)])
+@pytest.mark.parametrize("nq,n,d,k", [(5, 1000, 8192, 10), (300, 700, 4160, 7), (1, 1063, 75008, 20), (2, 257, 1088, 3),
+                                      (3, 2000, 16384, 128), (32, 5000, 8192, 1)])
 def test_cosine_topk_split_k_vs_oracle(eng, nq, n, d, k):
     """Few rows with long descriptors (the reference's own scale: 1063 frames x 75 000) are scored
     split-K: partial tiles + a reducing pass.  Includes ragged last chunks (65 and 17 K tiles)."""
