@@ -33,3 +33,36 @@ for B in (1, 16, 128):
     dt = time.perf_counter() - t0
     print(json.dumps({"batch": B, "latency_mode": B <= 16, "frames": T, "frames_per_s": T / dt, "ms_per_batch": dt / ((T + B - 1) // B) * 1e3,
                       "revisits_matched_top1": found, "revisits": max(0, T - period - 50)}), flush=True)
+
+
+# ---- the same stream through the SDAV path: patches (GPU front-end, fixed grid) -> SDAV fp64 ->
+# flattened 75 000-d place descriptor -> detector
+from deeploopcloser_amd.input import grid_key_points, _centres
+T2 = 512
+kp = torch.from_numpy(_centres(grid_key_points((192, 240), 30), 30)).to(eng.device)
+net = dlc.SDAV(seed=1)
+for B in (1, 16):
+    eng.set_scratch(dlc.engine.SCRATCH_BYTES)
+    det = None
+    found = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for lo in range(0, T2, B):
+        ids = torch.arange(lo, min(lo + B, T2), device=eng.device) % 200
+        noise = torch.randint(0, 8, (ids.numel(), 192, 240, 3), generator=g, device=eng.device, dtype=torch.uint8)
+        rgb = places[ids] // 2 + noise
+        gray = eng.rgb_to_gray(rgb)
+        x = eng.extract_patches(gray, kp.unsqueeze(0).expand(ids.numel(), -1, -1).contiguous(), 41)
+        h = net.transform_tensor(x)
+        desc = h.reshape(ids.numel(), -1).to(torch.float32)
+        if det is None:
+            det = dlc.LoopClosureDetector(desc.shape[1], k=5, threshold=0.5, exclusion=20, center=True, capacity=1024)
+        s, i = det.query_and_insert(desc)
+        fid = torch.arange(lo, lo + ids.numel(), device=eng.device)
+        found += int(((fid >= 220) & (i[:, 0] >= 0) & (i[:, 0] % 200 == ids)).sum().item())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"network": "sdav", "batch": B, "latency_mode": True, "frames": T2, "frames_per_s": T2 / dt,
+                      "ms_per_batch": dt / ((T2 + B - 1) // B) * 1e3, "revisits_matched_top1": found,
+                      "revisits": T2 - 220}), flush=True)
+eng.set_scratch(0)
