@@ -39,7 +39,7 @@ def _out_size(n, k, s, padding):
 
 class CnnVtl:
     def __init__(self, input_shape=(1, 224, 224, 3), batch_size: int = 10, compress_factor: float = 99.59,
-                 seed=0, mask_seed=0, device=None, frame_chunk=512):
+                 seed=0, mask_seed=0, device=None, frame_chunk=504):
         if len(input_shape) != 4 or any(int(v) <= 0 for v in input_shape) or input_shape[3] != 3:
             raise ValueError("input_shape must be [N, H, W, 3] with positive entries")
         if not (0 <= compress_factor <= 100):
