@@ -40,8 +40,8 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=1_000_000, help="key-frames in the WHOLE database")
     ap.add_argument("--dim", type=int, default=4096)
     ap.add_argument("--queries", type=int, default=256)
