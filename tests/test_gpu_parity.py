@@ -613,6 +613,17 @@ def test_error_paths_raise_value_error(eng, dlc):
     ws = torch.empty(eng.topk_workspace_bytes(4, 4, 64, 2), dtype=torch.uint8, device=eng.device)
     with pytest.raises(L_ERRORS):
         eng.score_groups(q, q, 2, ws[:128])                                       # workspace too small
+    import ctypes as C
+    buf = torch.empty(1024, dtype=torch.uint8, device=eng.device)
+    rc = eng.lib.dlc_set_scratch(eng.ctx, C.c_void_p(buf.data_ptr() + 8), 512)    # not 256-byte aligned
+    assert rc == dlc._lib.DLC_ERR_BAD_ARG and b"aligned" in eng.lib.dlc_last_error(eng.ctx)
+    long_rows = torch.zeros((8, 20032), dtype=torch.bfloat16, device=eng.device)
+    s_out = torch.empty((8, 8), dtype=torch.float32, device=eng.device)
+    assert eng.lib.dlc_cosine_scores_workspace_bytes(8, 8, 20032) > 0
+    rc = eng.lib.dlc_cosine_scores(eng.ctx, dlc._lib.DLC_BF16, C.c_void_p(long_rows.data_ptr()), 8, 20032,
+                                   C.c_void_p(long_rows.data_ptr()), 8, 20032, 20032, C.c_void_p(s_out.data_ptr()), 8,
+                                   None, 0, None)
+    assert rc == dlc._lib.DLC_ERR_WORKSPACE                                       # split-K shape without its workspace
     assert dlc.DistanceCalculator.calculate_distance([], []) == 0                 # zip of empties (reference: 0)
     assert dlc.DistanceCalculator.calculate_distance([1, 2, 3], [1]) == 0         # zip stops at the shorter one
 
