@@ -25,11 +25,11 @@ from .similarity import SimilarityCalculator
 from .distance import DistanceCalculator
 from .matching import encode, match, match_topk, KeyframeDatabase, MatchPipeline, flatten_frame_descriptors
 from .dist import ShardedKeyframeDatabase, shard_bounds, merge_topk_torch
-from .input import CvInputParser, grid_key_points, read_ppm
+from .input import CvInputParser, KeyPoint, grid_key_points, harris_key_points, read_ppm
 from . import tensor_wrapper
 from .loop_closure import LoopClosureDetector
 
 __all__ = ["LoopClosureDetector", "SDAV", "DA", "CnnVtl", "SimilarityCalculator", "DistanceCalculator", "MathUtils", "tensor_wrapper", "CvInputParser",
-           "grid_key_points", "read_ppm",
+           "grid_key_points", "harris_key_points", "KeyPoint", "read_ppm",
            "encode", "match", "match_topk", "KeyframeDatabase", "MatchPipeline", "ShardedKeyframeDatabase", "Engine",
            "default_engine", "shard_bounds", "merge_topk_torch", "flatten_frame_descriptors"]

@@ -39,7 +39,142 @@ __global__ __launch_bounds__(256) void extract_patches_kernel(const unsigned cha
     }
 }
 
+// ---- key-point detector (NOT in the reference: it uses OpenCV-contrib's non-free SURF,
+// CvInputParser.py:36-46; SURVEY section 8f-1 asks for "a simple GPU detector" instead) ----------------
+// Harris corners in exact integer arithmetic: Sobel 3x3 gradients Ix, Iy (int32), structure
+// tensor summed over the 5x5 window (Sxx, Syy, Sxy), response R16 = 16*(Sxx*Syy - Sxy^2) -
+// (Sxx+Syy)^2 (k = 1/16, int64).  Defined for pixels at least 3 away from the border, 0 elsewhere.
+__device__ __forceinline__ int px(const uint8_t* g, int W, int r, int c) { return (int)g[(long long)r * W + c]; }
+
+__global__ __launch_bounds__(256) void harris_response_kernel(const uint8_t* __restrict__ gray, int H, int W,
+                                                              long long* __restrict__ resp) {
+    const long long frame = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int r = p / W, c = p - r * W;
+    long long out = 0;
+    if (r >= 3 && r < H - 3 && c >= 3 && c < W - 3) {
+        const uint8_t* g = gray + frame * H * W;
+        long long sxx = 0, syy = 0, sxy = 0;
+        for (int dr = -2; dr <= 2; ++dr)
+            for (int dc = -2; dc <= 2; ++dc) {
+                const int rr = r + dr, cc = c + dc;
+                const int ix = (px(g, W, rr - 1, cc + 1) + 2 * px(g, W, rr, cc + 1) + px(g, W, rr + 1, cc + 1)) -
+                               (px(g, W, rr - 1, cc - 1) + 2 * px(g, W, rr, cc - 1) + px(g, W, rr + 1, cc - 1));
+                const int iy = (px(g, W, rr + 1, cc - 1) + 2 * px(g, W, rr + 1, cc) + px(g, W, rr + 1, cc + 1)) -
+                               (px(g, W, rr - 1, cc - 1) + 2 * px(g, W, rr - 1, cc) + px(g, W, rr - 1, cc + 1));
+                sxx += ix * ix; syy += iy * iy; sxy += ix * iy;
+            }
+        out = 16 * (sxx * syy - sxy * sxy) - (sxx + syy) * (sxx + syy);
+    }
+    resp[frame * H * W + p] = out;
+}
+
+// Non-maximum suppression over the 3x3 neighbourhood; equal responses: the lower linear index wins.
+__global__ __launch_bounds__(256) void harris_nms_kernel(const long long* __restrict__ resp, int H, int W,
+                                                         long long* __restrict__ cand) {
+    const long long frame = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const long long* R = resp + frame * H * W;
+    const long long v = R[p];
+    bool keep = v > 0;
+    if (keep) {
+        const int r = p / W, c = p - r * W;       // v > 0 only inside the margin: all 8 neighbours exist
+        for (int dr = -1; dr <= 1 && keep; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                if (dr == 0 && dc == 0) continue;
+                const int q = (r + dr) * W + (c + dc);
+                const long long u = R[q];
+                if (u > v || (u == v && q < p)) { keep = false; break; }
+            }
+    }
+    cand[frame * H * W + p] = keep ? v : 0;
+}
+
+// The n strongest candidates of a frame, response descending, ties toward the lower linear
+// index: n rounds of a block-wide arg-max, the winner is cleared.  One workgroup per frame.
+__global__ __launch_bounds__(1024) void harris_select_kernel(long long* __restrict__ cand, int H, int W, int n,
+                                                             int* __restrict__ pts, long long* __restrict__ resp_out,
+                                                             int* __restrict__ count) {
+    __shared__ long long sv[1024];
+    __shared__ int si[1024];
+    const long long frame = blockIdx.x;
+    long long* C = cand + frame * H * W;
+    const int tid = threadIdx.x, total = H * W;
+    int found = n;
+    for (int j = 0; j < n; ++j) {
+        long long bv = 0;
+        int bi = 0x7fffffff;
+        for (int p = tid; p < total; p += 1024) {
+            const long long v = C[p];
+            if (v > bv) { bv = v; bi = p; }      // p ascending per thread: the first maximum is the lowest index
+        }
+        sv[tid] = bv; si[tid] = bi;
+        __syncthreads();
+        for (int s_ = 512; s_ > 0; s_ >>= 1) {
+            if (tid < s_) {
+                const long long ov = sv[tid + s_];
+                const int oi = si[tid + s_];
+                if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) { sv[tid] = ov; si[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        const long long wv = sv[0];
+        const int wi = si[0];
+        __syncthreads();
+        if (wv <= 0) { found = j; break; }       // uniform: every thread reads the same sv[0]
+        if (tid == 0) {
+            pts[(frame * n + j) * 2 + 0] = wi % W;               // cv2.KeyPoint.pt = (x = column, y = row)
+            pts[(frame * n + j) * 2 + 1] = wi / W;
+            resp_out[frame * n + j] = wv;
+            C[wi] = 0;
+            __threadfence_block();
+        }
+        __syncthreads();
+    }
+    for (int j = found + tid; j < n; j += 1024) {
+        pts[(frame * n + j) * 2 + 0] = -1;
+        pts[(frame * n + j) * 2 + 1] = -1;
+        resp_out[frame * n + j] = 0;
+    }
+    if (tid == 0) count[frame] = found;
+}
+
 }  // namespace
+
+extern "C" size_t dlc_harris_keypoints_workspace_bytes(int64_t frames, int H, int W) {
+    if (frames < 1 || H < 7 || W < 7) return 0;
+    return 2 * dlc::align_up((size_t)frames * H * W * 8, 256);
+}
+
+extern "C" int dlc_harris_keypoints_u8(dlc_ctx* ctx, const uint8_t* gray, int64_t frames, int H, int W, int n,
+                                       int32_t* points, int64_t* responses, int32_t* counts, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!gray || !points || !responses || !counts || frames < 1 || n < 1)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "harris_keypoints: bad argument");
+    if (H < 7 || W < 7 || (long long)H * W > 0x7fffffffll || frames > 65535)
+        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "harris_keypoints: %lld frames of %dx%d unsupported", (long long)frames, H, W);
+    const size_t need = dlc_harris_keypoints_workspace_bytes(frames, H, W);
+    if (!workspace || workspace_bytes < need)
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "harris_keypoints: workspace %zu < %zu bytes", workspace_bytes, need);
+    if ((uintptr_t)workspace & 255) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "harris_keypoints: workspace must be 256-byte aligned");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    long long* resp = (long long*)workspace;
+    long long* cand = (long long*)((char*)workspace + need / 2);
+    dim3 grid((unsigned)dlc::cdiv((int64_t)H * W, (int64_t)256), (unsigned)frames);
+    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(256), 0, st, gray, H, W, resp);
+    DLC_LAUNCH_CHECK(ctx, "harris_response_kernel");
+    hipLaunchKernelGGL(harris_nms_kernel, grid, dim3(256), 0, st, (const long long*)resp, H, W, cand);
+    DLC_LAUNCH_CHECK(ctx, "harris_nms_kernel");
+    hipLaunchKernelGGL(harris_select_kernel, dim3((unsigned)frames), dim3(1024), 0, st, cand, H, W, n, (int*)points,
+                       (long long*)responses, (int*)counts);
+    DLC_LAUNCH_CHECK(ctx, "harris_select_kernel");
+    return DLC_OK;
+}
 
 extern "C" int dlc_rgb_to_gray_u8(dlc_ctx* ctx, const uint8_t* rgb, int64_t n_pixels, uint8_t* gray, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;

@@ -9,7 +9,7 @@ import numpy as np
 
 from .cnn_vtl import CnnVtl
 from .distance import DistanceCalculator
-from .input import CvInputParser, grid_key_points, read_ppm
+from .input import CvInputParser, read_ppm
 from .sdav import SDAV
 from .similarity import SimilarityCalculator
 
@@ -35,15 +35,14 @@ def distance_image(distance_matrix):
 def create_similarity_matrix(dataset_path, out_png=None, network=None, key_points_fn=None, pattern="*"):
     """Frames of `dataset_path` -> patches -> SDAV descriptors -> int64 similarity matrix
     (create_similarity_matrix.py:23-38) [-> PNG].  key_points_fn(gray_shape) supplies the patch
-    centres (the reference uses SURF; default: a fixed grid)."""
+    centres (the reference uses SURF; default: the build's Harris detector)."""
     files = sorted(glob.glob(os.path.join(dataset_path, pattern)))
     if not files:
         raise ValueError("Specified dataset is empty or could not find dataset")        # InputGenerator.py:21-23
     network = network or SDAV()
     parser = CvInputParser(network.input_shape[0], int(round(np.sqrt(network.input_shape[1]))))
-    kp = key_points_fn or (lambda shape: grid_key_points(shape, network.input_shape[0]))
     frames = [read_ppm(f) for f in files]
-    x = np.stack([parser.parse(fr, kp(fr.shape[:2])) for fr in frames])
+    x = np.stack([parser.parse(fr, key_points_fn(fr.shape[:2]) if key_points_fn else None) for fr in frames])
     h = network.transform(x)
     desc = h.reshape(len(files), network.input_shape[0], h.shape[1])
     matrix = SimilarityCalculator(desc).similarity_matrix()

@@ -204,6 +204,24 @@ class Engine:
         self._check(self.lib.dlc_rgb_to_gray_u8(self.ctx, _ptr(rgb), gray.numel(), _ptr(gray), self._stream()))
         return gray
 
+    def harris_keypoints(self, gray, n):
+        """gray uint8 [F,H,W] -> (points int32 [F,n,2] as cv2-style (x = column, y = row), responses int64
+        [F,n], counts int32 [F]); (-1,-1) / 0 past a frame's count.  The build's stand-in for SURF."""
+        gray = gray.contiguous()
+        if gray.dtype != torch.uint8 or gray.dim() != 3:
+            raise ValueError("harris_keypoints: uint8 [F, H, W] expected")
+        f, h, w = gray.shape
+        need = self.lib.dlc_harris_keypoints_workspace_bytes(f, h, w)
+        if need == 0 or n < 1:
+            raise ValueError("harris_keypoints: needs n >= 1 and frames of at least 7x7 pixels")
+        ws = self.workspace("harris", need)
+        pts = torch.empty((f, n, 2), dtype=torch.int32, device=self.device)
+        resp = torch.empty((f, n), dtype=torch.int64, device=self.device)
+        cnt = torch.empty((f,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.dlc_harris_keypoints_u8(self.ctx, _ptr(gray), f, h, w, n, _ptr(pts), _ptr(resp), _ptr(cnt),
+                                                      _ptr(ws), ws.numel(), self._stream()))
+        return pts, resp, cnt
+
     def extract_patches(self, gray, key_points, patch_size, dtype=torch.float64):
         """gray uint8 [F,H,W], key_points int32 [F,P,2] -> [F,P,patch_size^2] pixel/255."""
         gray, key_points = gray.contiguous(), key_points.contiguous()

@@ -3,12 +3,16 @@
 
 The reference picks the patch centres with OpenCV's SURF detector (:36-46), which is
 non-free opencv-contrib code, unavailable here and deliberately NOT re-implemented.
-Key-points are therefore an argument: any sequence of objects with ``.pt`` (and optionally
+Key-points are an argument: any sequence of objects with ``.pt`` (and optionally
 ``.response``, as cv2.KeyPoint has) or of (x, y) pairs.  With responses the reference's
 ordering is applied (descending response, top n); everything after that -- rounding, the
-clamp-inside-the-image window, flattening, /255.0 -- runs in the HIP kernel.
+clamp-inside-the-image window, flattening, /255.0 -- runs in the HIP kernel.  Without
+key-points the build's own detector supplies them: Harris corners in exact integer arithmetic
+(``harris_key_points``, ``CvInputParser.parse_batch``; HIP kernels, oracle/keypoints.py).
 ``grid_key_points`` is a deterministic stand-in for plumbing tests, not a detector.
 """
+from collections import namedtuple
+
 import numpy as np
 import torch
 
@@ -57,29 +61,64 @@ def _centres(key_points, n):
     return np.array([[int(round(float(p[0]))), int(round(float(p[1])))] for p in pts], dtype=np.int32).reshape(-1, 2)
 
 
+KeyPoint = namedtuple("KeyPoint", "pt response")      # the two cv2.KeyPoint fields the reference reads
+
+
+def _gray(engine, image):
+    img = engine.to_device(image)
+    if img.dim() == 3 and img.shape[-1] == 3:
+        img = engine.rgb_to_gray(img.to(torch.uint8))
+    if img.dim() != 2:
+        raise ValueError("image must be [H, W] grey or [H, W, 3] RGB")
+    return img.to(torch.uint8)
+
+
+def harris_key_points(image, n, device=None):
+    """The n strongest Harris corners of one image as cv2-style KeyPoint(pt=(x, y), response), strongest
+    first: the build's stand-in for the reference's SURF detector (include/dlc.h, dlc_harris_keypoints_u8)."""
+    e = default_engine(device)
+    pts, resp, cnt = e.harris_keypoints(_gray(e, image).unsqueeze(0), n)
+    c = int(cnt[0].item())
+    pts, resp = pts[0, :c].cpu().numpy(), resp[0, :c].cpu().numpy()
+    return [KeyPoint((float(x), float(y)), float(r)) for (x, y), r in zip(pts, resp)]
+
+
 class CvInputParser:
     def __init__(self, n_patches: int = 30, patch_size: int = 41, device=None):
         self.n_patches = n_patches
         self.patch_size = patch_size
         self.engine = default_engine(device)
 
-    def parse_tensor(self, image, key_points):
+    def parse_batch(self, frames):
+        """frames uint8 [F,H,W,3] RGB or [F,H,W] grey -> [F, n_patches, patch_size^2] float64 on the GPU:
+        grey conversion, Harris key-points, patch gather, nothing through the host.  A frame with
+        fewer than n_patches corners is topped up with grid points (the network needs the shape)."""
         e = self.engine
-        img = e.to_device(image)
-        if img.dim() == 3 and img.shape[-1] == 3:
-            img = e.rgb_to_gray(img.to(torch.uint8))
-        if img.dim() != 2:
-            raise ValueError("image must be [H, W] grey or [H, W, 3] RGB")
+        fr = e.to_device(frames)
+        gray = e.rgb_to_gray(fr.to(torch.uint8)) if fr.dim() == 4 else fr.to(torch.uint8)
+        if gray.dim() != 3:
+            raise ValueError("frames must be [F, H, W, 3] RGB or [F, H, W] grey")
+        pts, _, _ = e.harris_keypoints(gray, self.n_patches)
+        grid = torch.from_numpy(_centres(grid_key_points(gray.shape[1:], self.n_patches), self.n_patches)).to(e.device)
+        pts = torch.where(pts < 0, grid.unsqueeze(0).expand_as(pts), pts)
+        return e.extract_patches(gray, pts, self.patch_size)
+
+    def parse_tensor(self, image, key_points=None):
+        e = self.engine
+        img = _gray(e, image)
+        if key_points is None:                 # the build's detector instead of SURF
+            return self.parse_batch(img.unsqueeze(0))[0]
         kp = _centres(key_points, self.n_patches)
         if kp.shape[0] == 0:
             return torch.empty((0, self.patch_size ** 2), dtype=torch.float64, device=e.device)
         kpt = torch.from_numpy(kp).to(e.device).unsqueeze(0)
         return e.extract_patches(img.to(torch.uint8).unsqueeze(0), kpt, self.patch_size)[0]
 
-    def parse(self, image, key_points):
-        """CvInputParser.parse (:19-28): float64 [number of key-points (<= n_patches), patch_size^2]."""
+    def parse(self, image, key_points=None):
+        """CvInputParser.parse (:19-28): float64 [number of key-points (<= n_patches), patch_size^2].
+        key_points=None: the n_patches strongest Harris corners (the reference: SURF)."""
         return self.parse_tensor(image, key_points).cpu().numpy()
 
-    def parse_from_path(self, image_path, key_points):
+    def parse_from_path(self, image_path, key_points=None):
         """CvInputParser.parse_from_path (:30-33) for PPM frames; grey conversion as cv2.imread does it."""
         return self.parse(read_ppm(str(image_path)), key_points)

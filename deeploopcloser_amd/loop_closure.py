@@ -112,14 +112,16 @@ def _frame_files(dataset_path, pattern):
 
 def describe_sdav(files, network=None, key_points_fn=None):
     """Frames -> one [30*2500] place descriptor per frame (patches -> SDAV.transform, flattened)."""
-    from .input import CvInputParser, grid_key_points, read_ppm
+    from .input import CvInputParser, read_ppm
     from .sdav import SDAV
     network = network or SDAV()
     p = network.input_shape[0]
     parser = CvInputParser(p, int(round(np.sqrt(network.input_shape[1]))))
-    kp = key_points_fn or (lambda shape: grid_key_points(shape, p))
     frames = [read_ppm(f) for f in files]
-    x = np.stack([parser.parse(fr, kp(fr.shape[:2])) for fr in frames])
+    if key_points_fn:
+        x = np.stack([parser.parse(fr, key_points_fn(fr.shape[:2])) for fr in frames])
+    else:                                                    # grey, Harris key-points, patches: all on the GPU
+        x = parser.parse_batch(np.stack(frames))
     h = network.transform(x)
     return h.reshape(len(files), p * h.shape[1])
 

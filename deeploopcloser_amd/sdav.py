@@ -16,7 +16,7 @@ Differences a caller can see, all deliberate:
     torch generator; checkpoints are .npz files (save_weights), not TF checkpoints;
     a batch of a single frame (NaN loss in the reference) is rejected / skipped;
   * get_dataset needs key-points: the reference's SURF detector is not available, the
-    default is a fixed grid (input.grid_key_points) unless key_points_fn is given.
+    default is the build's Harris detector (input.harris_key_points) unless key_points_fn(shape) is given.
 """
 import logging
 
@@ -162,17 +162,16 @@ class SDAV:
     def get_dataset(self, file_pattern: str, key_points_fn=None):
         """Generator of parsed frames [30, 1681] (SDAV.py:219-221, InputGenerator.py:17-27)."""
         from glob import glob
-        from .input import CvInputParser, grid_key_points, read_ppm
+        from .input import CvInputParser, read_ppm
         files = glob(file_pattern)
         if len(files) == 0:
             logging.getLogger().error("Specified dataset is empty or could not find dataset")   # InputGenerator.py:21-23
         parser = CvInputParser(self.input_shape[0], int(round(np.sqrt(self.input_shape[1]))))
-        kp = key_points_fn or (lambda shape: grid_key_points(shape, self.input_shape[0]))
 
         def gen():
             for f in files:
                 img = read_ppm(f)
-                yield parser.parse(img, kp(img.shape[:2]))
+                yield parser.parse(img, key_points_fn(img.shape[:2]) if key_points_fn else None)
         return gen()
 
     def fit_dataset(self, dataset):

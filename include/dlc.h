@@ -147,6 +147,23 @@ int dlc_extract_patches(dlc_ctx* ctx, const uint8_t* gray, int64_t frames, int H
                         const int32_t* key_points, int P, int patch_size, int out_dtype, void* out,
                         void* stream);
 
+/*
+ * Key-point detector for the patch front-end.  NOT the reference's: it takes the n strongest SURF
+ * key-points (CvInputParser.py:36-46), and SURF is non-free OpenCV-contrib code that is neither
+ * available nor re-implemented.  This is a Harris corner detector in exact integer arithmetic
+ * (so the result is a function of the pixels alone): Sobel 3x3 gradients, structure tensor over
+ * the 5x5 window, response 16*det - trace^2 (k = 1/16) for pixels >= 3 from the border, 3x3
+ * non-maximum suppression, the n largest responses per frame (ties: lower row-major index).
+ * gray uint8 [frames, H, W]; points int32 [frames, n, 2] = (x = column, y = row) as
+ * cv2.KeyPoint.pt, (-1, -1) past the frame's count; responses int64 [frames, n]; counts int32
+ * [frames].  Feed `points` to dlc_extract_patches as they are: like the reference it then uses
+ * pt[0] along image dimension 0 (CvInputParser.py:111-119).
+ */
+size_t dlc_harris_keypoints_workspace_bytes(int64_t frames, int H, int W);
+int dlc_harris_keypoints_u8(dlc_ctx* ctx, const uint8_t* gray, int64_t frames, int H, int W, int n,
+                            int32_t* points, int64_t* responses, int32_t* counts, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* ---- encode: CnnVtl pieces (src/cnn_vtl/network/cnn_vtl.py:28-133) ------ */
 /*
  * im2col for tf.layers.conv2d on NHWC fp64 (cnn_vtl.py:33-93): x[n,h,w,c] ->

@@ -109,3 +109,57 @@ def test_drivers_and_database_file(tmp_path):
     q = rng.standard_normal((5, 100)).astype(np.float32)
     a, b = db.match_topk(q, 3), db2.match_topk(q, 3)
     assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+
+
+@pytest.mark.gpu
+def test_harris_keypoints_bit_exact_vs_oracle():
+    """The build's detector (stand-in for SURF) is integer arithmetic: points, responses and counts
+    equal the oracle's exactly -- reference frames, noise, a symmetric pattern full of ties, flat."""
+    import deeploopcloser_amd as dlc
+    from oracle import keypoints as okp
+    eng = dlc.default_engine()
+    rng = np.random.RandomState(8)
+    frames = [opatch.bgr2gray_opencv(opatch.read_ppm(p)) for p in FRAMES]
+    frames.append(rng.randint(0, 256, (192, 240)).astype(np.uint8))
+    tie = np.zeros((192, 240), dtype=np.uint8)
+    tie[::16, :] = 255
+    tie[:, ::16] = 255                                                       # a lattice: hundreds of equal corners
+    frames.append(tie)
+    frames.append(np.full((192, 240), 90, dtype=np.uint8))                    # flat: no key-point
+    sq = np.zeros((192, 240), dtype=np.uint8)
+    sq[50:90, 60:140] = 180                                                   # 4 corners only: count < n
+    frames.append(sq)
+    g = torch.from_numpy(np.stack(frames)).to(eng.device)
+    for n in (30, 7):
+        pts, resp, cnt = eng.harris_keypoints(g, n)
+        for f, img in enumerate(frames):
+            ep, er, ec = okp.key_points(img, n)
+            assert int(cnt[f]) == ec
+            assert np.array_equal(pts[f].cpu().numpy(), ep) and np.array_equal(resp[f].cpu().numpy(), er)
+    assert int(cnt[5]) == 0 and 0 < int(eng.harris_keypoints(g, 30)[2][6]) < 30
+    with pytest.raises(ValueError):
+        eng.harris_keypoints(g[:, :5, :5].contiguous(), 3)
+
+
+@pytest.mark.gpu
+def test_parser_default_detector_and_batch():
+    """parse(image) without key-points = Harris key-points through the reference's patch rule;
+    parse_batch does the same for a stack of frames on the GPU, topping up with grid points."""
+    import deeploopcloser_amd as dlc
+    parser = dlc.CvInputParser(30, 41)
+    rgb = [opatch.read_ppm(p) for p in FRAMES]
+    batch = parser.parse_batch(np.stack(rgb)).cpu().numpy()
+    for f, img in enumerate(rgb):
+        kps = dlc.harris_key_points(img, 30)
+        assert len(kps) == 30 and all(a.response >= b.response for a, b in zip(kps, kps[1:]))
+        one = parser.parse(img)
+        assert one.shape == (30, 1681) and np.array_equal(one, parser.parse(img, kps)) and np.array_equal(one, batch[f])
+        assert np.array_equal(one, opatch.parse(opatch.bgr2gray_opencv(img), [kp.pt for kp in kps], 41))
+    sq = np.zeros((192, 240), dtype=np.uint8)
+    sq[50:90, 60:140] = 180
+    few = dlc.harris_key_points(sq, 30)
+    x = parser.parse(sq)
+    grid = dlc.grid_key_points((192, 240), 30)
+    assert 0 < len(few) < 30 and x.shape == (30, 1681)
+    assert np.array_equal(x[:len(few)], parser.parse(sq, few))
+    assert np.array_equal(x[len(few):], parser.parse(sq, grid)[len(few):])

@@ -79,3 +79,20 @@ def test_loop_closure_candidate_filter_and_oracle():
     assert ei[:2].tolist() == [[-1, -1], [-1, -1]]                          # nothing old enough yet
     assert ei[3].tolist() == [0, 1] and es[3].tolist() == [1.0, 0.0]        # frame 3 sees 0..1, revisits place 0
     assert ei[4, 0] == 1 and ei[6].tolist() == [0, 3]                       # ties -> lower id
+
+
+def test_keypoint_oracle_on_a_square():
+    """oracle/keypoints.py: the four strongest Harris corners of a bright square are its corners;
+    mirror-symmetric responses tie and the lower row-major index comes first; a flat image has none."""
+    from oracle import keypoints as okp
+    img = np.zeros((40, 48), dtype=np.uint8)
+    img[12:28, 16:36] = 200
+    pts, resp, count = okp.key_points(img, 6)
+    assert count >= 4 and resp[0] == resp[1] == resp[2] == resp[3] > 0
+    corners = {(16, 12), (35, 12), (16, 27), (35, 27)}                       # (x = column, y = row)
+    for x, y in pts[:4]:
+        assert min(abs(x - cx) + abs(y - cy) for cx, cy in corners) <= 2
+    lin = [int(y) * 48 + int(x) for x, y in pts[:4]]
+    assert lin == sorted(lin)                                                # equal responses: ascending index
+    assert okp.key_points(np.full((20, 20), 7, dtype=np.uint8), 5)[2] == 0
+    assert okp.response(img)[:3].max() == 0 and okp.response(img)[:, -3:].max() == 0   # undefined margin is 0
