@@ -103,13 +103,19 @@ __global__ __launch_bounds__(1024) void harris_select_kernel(long long* __restri
     long long* C = cand + frame * H * W;
     const int tid = threadIdx.x, total = H * W;
     int found = n;
-    for (int j = 0; j < n; ++j) {
-        long long bv = 0;
-        int bi = 0x7fffffff;
+    // every thread keeps the best candidate of its own pixels (p = tid, tid + 1024, ...); only the
+    // owner of a round's winner clears it and rescans
+    long long bv = 0;
+    int bi = 0x7fffffff;
+    auto rescan = [&]() {
+        bv = 0; bi = 0x7fffffff;
         for (int p = tid; p < total; p += 1024) {
             const long long v = C[p];
-            if (v > bv) { bv = v; bi = p; }      // p ascending per thread: the first maximum is the lowest index
+            if (v > bv) { bv = v; bi = p; }      // p ascending: the first maximum is the lowest index
         }
+    };
+    rescan();
+    for (int j = 0; j < n; ++j) {
         sv[tid] = bv; si[tid] = bi;
         __syncthreads();
         for (int s_ = 512; s_ > 0; s_ >>= 1) {
@@ -128,10 +134,11 @@ __global__ __launch_bounds__(1024) void harris_select_kernel(long long* __restri
             pts[(frame * n + j) * 2 + 0] = wi % W;               // cv2.KeyPoint.pt = (x = column, y = row)
             pts[(frame * n + j) * 2 + 1] = wi / W;
             resp_out[frame * n + j] = wv;
-            C[wi] = 0;
-            __threadfence_block();
         }
-        __syncthreads();
+        if ((wi & 1023) == tid) {
+            C[wi] = 0;
+            rescan();
+        }
     }
     for (int j = found + tid; j < n; j += 1024) {
         pts[(frame * n + j) * 2 + 0] = -1;

@@ -88,6 +88,7 @@ class CvInputParser:
         self.n_patches = n_patches
         self.patch_size = patch_size
         self.engine = default_engine(device)
+        self._grid = {}
 
     def parse_batch(self, frames):
         """frames uint8 [F,H,W,3] RGB or [F,H,W] grey -> [F, n_patches, patch_size^2] float64 on the GPU:
@@ -99,8 +100,10 @@ class CvInputParser:
         if gray.dim() != 3:
             raise ValueError("frames must be [F, H, W, 3] RGB or [F, H, W] grey")
         pts, _, _ = e.harris_keypoints(gray, self.n_patches)
-        grid = torch.from_numpy(_centres(grid_key_points(gray.shape[1:], self.n_patches), self.n_patches)).to(e.device)
-        pts = torch.where(pts < 0, grid.unsqueeze(0).expand_as(pts), pts)
+        shape = tuple(gray.shape[1:])
+        if shape not in self._grid:                        # resident top-up points per frame size
+            self._grid[shape] = torch.from_numpy(_centres(grid_key_points(shape, self.n_patches), self.n_patches)).to(e.device)
+        pts = torch.where(pts < 0, self._grid[shape].unsqueeze(0).expand_as(pts), pts)
         return e.extract_patches(gray, pts, self.patch_size)
 
     def parse_tensor(self, image, key_points=None):

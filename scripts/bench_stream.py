@@ -35,11 +35,10 @@ for B in (1, 16, 128):
                       "revisits_matched_top1": found, "revisits": max(0, T - period - 50)}), flush=True)
 
 
-# ---- the same stream through the SDAV path: patches (GPU front-end, fixed grid) -> SDAV fp64 ->
+# ---- the same stream through the SDAV path: patches (GPU front-end, Harris key-points) -> SDAV fp64 ->
 # flattened 75 000-d place descriptor -> detector
-from deeploopcloser_amd.input import grid_key_points, _centres
 T2 = 512
-kp = torch.from_numpy(_centres(grid_key_points((192, 240), 30), 30)).to(eng.device)
+parser = dlc.CvInputParser(30, 41)
 net = dlc.SDAV(seed=1)
 for B in (1, 16):
     eng.set_scratch(dlc.engine.SCRATCH_BYTES)
@@ -51,8 +50,7 @@ for B in (1, 16):
         ids = torch.arange(lo, min(lo + B, T2), device=eng.device) % 200
         noise = torch.randint(0, 8, (ids.numel(), 192, 240, 3), generator=g, device=eng.device, dtype=torch.uint8)
         rgb = places[ids] // 2 + noise
-        gray = eng.rgb_to_gray(rgb)
-        x = eng.extract_patches(gray, kp.unsqueeze(0).expand(ids.numel(), -1, -1).contiguous(), 41)
+        x = parser.parse_batch(rgb)                        # grey, Harris key-points, 30 patches per frame
         h = net.transform_tensor(x)
         desc = h.reshape(ids.numel(), -1).to(torch.float32)
         if det is None:
