@@ -256,20 +256,30 @@ __global__ __launch_bounds__(256) void splitk_bias_act_kernel(const T* __restric
     }
 }
 
-// Chunks of K for a launch that would otherwise put fewer workgroups than CUs on a long K
-// (single-frame latency mode); 1 = one pass.  Needs the context's scratch (dlc_set_scratch).
+// Chunks of K (latency mode, needs the context's scratch; 1 = one pass).  A K step is 64 MFMAs per
+// wave (1.9 us in fp64, 1.0 us in fp32) and one workgroup per CU already keeps the matrix pipes
+// busy, so a launch costs about ceil(workgroups / 256) x K steps of that; fewer workgroups than
+// CUs, or a little more than a whole number of rounds, waste the difference.  The plan minimises
+// rounds x (K steps per chunk x t_step + 6 us) + the partial tiles written and read back + the
+// second launch, and splits only for a clear gain.
 template <typename T>
 int plan_split(const dlc_ctx* ctx, int64_t M, int64_t N, int64_t K, long long* kchunk) {
     const int64_t wgs = dlc::cdiv(M, TM) * dlc::cdiv(N, TN), ksteps = dlc::cdiv(K, TK);
     *kchunk = ksteps * TK;
-    if (!ctx->scratch || wgs >= 128 || ksteps < 16) return 1;
-    int64_t want = std::min<int64_t>(dlc::cdiv((int64_t)512, wgs), ksteps / 8);
+    if (!ctx->scratch || wgs >= 1024 || ksteps < 16) return 1;
+    const double t_step = sizeof(T) == 8 ? 1.9 : 1.0, t_fix = 6.0, t_launch = 5.0, bytes_per_us = 3.0e6;
+    const double part_bytes = (double)M * (double)N * sizeof(T);
     const int64_t fit = (int64_t)(ctx->scratch_bytes / ((size_t)M * (size_t)N * sizeof(T)));
-    want = std::min(want, fit);
-    if (want < 2) return 1;
-    const int64_t steps = dlc::cdiv(ksteps, want);
-    *kchunk = steps * TK;
-    return (int)dlc::cdiv(ksteps, steps);
+    double best_t = (double)dlc::cdiv(wgs, (int64_t)256) * ((double)ksteps * t_step + t_fix);
+    int64_t best_steps = ksteps;
+    for (int64_t s_ = 2; s_ <= std::min<int64_t>(std::min<int64_t>(ksteps / 8, fit), 64); ++s_) {
+        const int64_t steps = dlc::cdiv(ksteps, s_), chunks = dlc::cdiv(ksteps, steps);
+        const double t = (double)dlc::cdiv(wgs * chunks, (int64_t)256) * ((double)steps * t_step + t_fix) +
+                         2.0 * (double)chunks * part_bytes / bytes_per_us + t_launch;
+        if (t < best_t * 0.9) { best_t = t; best_steps = steps; }
+    }
+    *kchunk = best_steps * TK;
+    return (int)dlc::cdiv(ksteps, best_steps);
 }
 
 template <typename T>

@@ -26,7 +26,7 @@ mode = os.environ.get("DLC_LATENCY_MODE", "0") == "1"
 if mode:
     eng.set_scratch()
 print("latency mode (split-K scratch):", mode)
-for b in (1, 4, 16):
+for b in (1, 4, 16, 64, 128):
     frames = torch.randint(0, 256, (b, 192, 240, 3), generator=g, device=eng.device).to(torch.float64)
     cnn = dlc.CnnVtl(input_shape=[b, 192, 240, 3])
     measure("CnnVtl B=%d" % b, lambda: cnn.transform_tensor(frames))
