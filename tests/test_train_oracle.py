@@ -68,3 +68,35 @@ def test_corruption_mask_counts():
     m = corruption_mask((30, 1681), 0.3, rng)
     assert m.shape == (30, 1681) and int((m == 0).sum()) == int(np.round(30 * 1681 * 0.3))
     assert corruption_mask((30, 1681), 0, rng).all()
+
+
+@pytest.mark.parametrize("layer", [0, 1, 2])
+def test_analytic_gradients_match_torch_autograd(layer):
+    """Independent check: the same graph written with torch ops (SDAV.py:126-159 forward, :171-186
+    loss, tied decoder :192-216) and differentiated by autograd -- including the gradient that
+    softmax_cross_entropy_with_logits_v2 sends into its labels for layers >= 1."""
+    import torch
+    x, masks, ws, b_encs, b_dec = setup(layer, seed=3)
+    loss, _, g_ws, g_bes, g_bd = ot.loss_and_grads(layer, x, masks, ws, b_encs, b_dec)
+    tw = [torch.tensor(w, requires_grad=True) for w in ws]
+    tb = [torch.tensor(b, requires_grad=True) for b in b_encs]
+    tbd = torch.tensor(b_dec, requires_grad=True)
+    batch, patches, _ = x.shape
+    cur = torch.tensor(x)
+    for l in range(layer + 1):
+        xt = (cur * torch.tensor(masks[l])[None]).reshape(batch * patches, -1)
+        h = torch.sigmoid(xt @ tw[l] + tb[l])
+        cur = h.reshape(batch, patches, -1)
+    y = torch.sigmoid(h @ tw[layer].T + tbd)                                 # tied decoder weights
+    labels = torch.tensor(x).reshape(batch * patches, -1) if layer == 0 else xt
+    cd = (-(labels * torch.log_softmax(y, dim=1)).sum(1)).mean()
+    cs = (h - 0.05).abs().sum(1).mean()
+    hb = h.reshape(batch, patches, -1)
+    cc = ((hb[:-1] - hb[1:]) ** 2).sum((1, 2)).sqrt().mean()
+    tl = cd + 1.0 * cs + 0.2 * cc
+    tl.backward()
+    assert abs(float(tl.detach()) - loss) < 1e-12
+    for l in range(layer + 1):
+        np.testing.assert_allclose(g_ws[l], tw[l].grad.numpy(), rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(g_bes[l], tb[l].grad.numpy(), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(g_bd, tbd.grad.numpy(), rtol=1e-10, atol=1e-13)
