@@ -252,6 +252,10 @@ int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* src, int64_t 
  * best (score descending, ties -> lower index) go to out_scores[q,k] (fp32) and
  * out_idx[q,k] (int64, row_offset added -- the shard's first global row).
  * Slots past min(k,n) get -inf / -1.  1 <= k <= DLC_MAX_K.
+ * The call picks its plan from the shape (same results, the workspace size reflects it): one
+ * score pass for databases of >= 256 tiles of 256 rows; split-K partial score tiles + a reducing
+ * pass for few rows with long descriptors; for <= 32 queries with long rows the exact re-score is
+ * spread over one workgroup per selected group and merged.
  */
 #define DLC_MAX_K 128
 size_t dlc_cosine_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int k);
