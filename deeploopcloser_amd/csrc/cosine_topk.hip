@@ -159,7 +159,10 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <typename Tag, int MODE>
+// MASKQ: instantiation for a last query block with fewer than 193 queries -- waves whose 64-query
+// column block lies entirely past q skip their fragment reads and MFMAs (they still stage and
+// synchronise), so 5..192 queries do not pay, at the power cap, for 256 queries' matrix work.
+template <typename Tag, int MODE, bool MASKQ>
 __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -236,14 +239,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     // Fragment registers: one k-slice (32 wide) of one half: A 4 tiles, B 2 tiles.
     u32x4_t faX[4], faY[4], fbX[2], fbY[2];
 
+    const bool active = !MASKQ || (qblk * BNQ + wc * 64 < p.q);
 #define DLC_READ_A(DST, RD, OFF)                      \
-    _Pragma("unroll") for (int tt = 0; tt < 4; ++tt)  \
+    if (!MASKQ || active) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt)  \
         DST[tt] = *(lds_u4p)(lbase + (RD) + (OFF) + tt * 512)
 #define DLC_READ_B(DST, RD, OFF)                      \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c)     \
+    if (!MASKQ || active) _Pragma("unroll") for (int c = 0; c < 2; ++c)     \
         DST[c] = *(lds_u4p)(lbase + (RD) + (OFF) + c * 2048)
 #define DLC_MFMA(FA, FB, AH, BH)                                                                     \
-    do {                                                                                             \
+    if (!MASKQ || active) do {                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                               \
         _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) _Pragma("unroll") for (int c = 0; c < 2; ++c) \
             acc[(AH) * 4 + tt][(BH) * 2 + c] =                                                       \
@@ -402,6 +406,103 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
             if (lg == 0 && qidx < p.q && ht < p.nh) p.tmax[(long long)qidx * p.ldt + ht] = h;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// score_gemv_kernel: the score pass for a HANDFUL of queries (q <= 4: a single camera frame).
+// The 256-query MFMA tile would do 64-256x the needed matrix work -- at the power cap, where
+// that work is what sets the time -- so few queries take a bandwidth kernel instead:
+// queries resident in LDS, every wave streams 8 database rows at a time with 16-byte loads (8 KiB
+// in flight per wave), v_dot2 accumulation in fp32, wave reduction, the same gmax / tmax outputs.
+// One workgroup (4 waves) per half tile of 128 rows; wave w takes its groups 4w .. 4w+3.
+// ---------------------------------------------------------------------------
+template <typename Tag> struct Dot2;
+template <> struct Dot2<dlc_bf16_tag> {
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2_t;
+    static __device__ __forceinline__ float run(unsigned a, unsigned b, float c) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2_t, a), __builtin_bit_cast(v2_t, b), c, false);
+    }
+};
+template <> struct Dot2<dlc_f16_tag> {
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2_t;
+    static __device__ __forceinline__ float run(unsigned a, unsigned b, float c) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2_t, a), __builtin_bit_cast(v2_t, b), c, false);
+    }
+};
+
+constexpr int GEMV_MAX_Q = 4;
+constexpr int GEMV_MAX_LDS = 64 * 1024;
+
+template <typename Tag, int QB>
+__global__ __launch_bounds__(256) void score_gemv_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [QB][d] stored queries
+    __shared__ float wmax[4][QB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long long half = blockIdx.x;
+    const int d_bytes = p.nk * 128;
+    for (int off = tid * 16; off < QB * d_bytes; off += 256 * 16) {
+        const int qi = off / d_bytes, within = off - qi * d_bytes;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (qi < p.q) v = *(const uint4*)(p.Q + (long long)qi * p.ldq_b + within);
+        *(uint4*)(smem + off) = v;
+    }
+    __syncthreads();
+    float hmax[QB];
+#pragma unroll
+    for (int qq = 0; qq < QB; ++qq) hmax[qq] = -INFINITY;
+    for (int gi = 0; gi < 4; ++gi) {
+        const long long g = half * GROUPS_PER_HALF + w * 4 + gi;
+        const char* rows[GROUP];
+#pragma unroll
+        for (int r = 0; r < GROUP; ++r) {
+            long long rr = g * GROUP + r;
+            if (rr > p.n - 1) rr = p.n - 1;                          // duplicates of the last row, as the GEMM's clamp
+            rows[r] = p.DB + rr * p.lddb_b;
+        }
+        float acc[QB][GROUP];
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r) acc[qq][r] = 0.f;
+        for (int c = lane * 16; c < d_bytes; c += 1024) {
+            uint4 rv[GROUP];
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r) rv[r] = *(const uint4*)(rows[r] + c);
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) {
+                const uint4 qv = *(const uint4*)(smem + qq * d_bytes + c);
+#pragma unroll
+                for (int r = 0; r < GROUP; ++r) {
+                    float a = acc[qq][r];
+                    a = Dot2<Tag>::run(rv[r].x, qv.x, a);
+                    a = Dot2<Tag>::run(rv[r].y, qv.y, a);
+                    a = Dot2<Tag>::run(rv[r].z, qv.z, a);
+                    a = Dot2<Tag>::run(rv[r].w, qv.w, a);
+                    acc[qq][r] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r) {
+                float v = acc[qq][r];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                m = fmaxf(m, v);
+            }
+            hmax[qq] = fmaxf(hmax[qq], m);
+            if (lane == 0 && qq < p.q && g < p.ng) p.gmax[(long long)qq * p.ldg + g] = m;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) wmax[w][qq] = hmax[qq];
+    }
+    __syncthreads();
+    if (tid < QB && tid < p.q && half < p.nh)
+        p.tmax[(long long)tid * p.ldt + half] = fmaxf(fmaxf(wmax[0][tid], wmax[1][tid]), fmaxf(wmax[2][tid], wmax[3][tid]));
 }
 
 // ---------------------------------------------------------------------------
@@ -880,9 +981,19 @@ int check_operands(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ld
     return DLC_OK;
 }
 
+template <typename Tag, int MODE, bool MASKQ>
+int launch_gemm_masked(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st);
+
 template <typename Tag, int MODE>
 int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
-    auto kern = score_gemm_kernel<Tag, MODE>;
+    const int tail = a.q % BNQ;                            // queries in the last query block (0 = full)
+    return (tail > 0 && tail <= 192) ? launch_gemm_masked<Tag, MODE, true>(ctx, a, st)
+                                     : launch_gemm_masked<Tag, MODE, false>(ctx, a, st);
+}
+
+template <typename Tag, int MODE, bool MASKQ>
+int launch_gemm_masked(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
+    auto kern = score_gemm_kernel<Tag, MODE, MASKQ>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -902,10 +1013,38 @@ int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
     return DLC_OK;
 }
 
+// Few queries: the bandwidth kernel (needs the stored queries in LDS: q <= 4 and q * d * 2 bytes <= 64 KiB).
+inline bool use_gemv(const GemmArgs& a) {
+    const int qb = a.q <= 1 ? 1 : (a.q <= 2 ? 2 : 4);
+    return a.q <= GEMV_MAX_Q && (long long)qb * a.nk * 128 <= GEMV_MAX_LDS;
+}
+
+template <typename Tag, int QB>
+int launch_gemv_qb(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
+    auto kern = score_gemv_kernel<Tag, QB>;
+    const int lds = QB * a.nk * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMV_MAX_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.nh), dim3(256), lds, st, a);
+    DLC_LAUNCH_CHECK(ctx, "score_gemv_kernel");
+    return DLC_OK;
+}
+
+template <typename Tag>
+int launch_gemv(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
+    if (a.q <= 1) return launch_gemv_qb<Tag, 1>(ctx, a, st);
+    if (a.q <= 2) return launch_gemv_qb<Tag, 2>(ctx, a, st);
+    return launch_gemv_qb<Tag, 4>(ctx, a, st);
+}
+
 // The score pass of a match: one kernel, or split-K partials + the reducing second pass.
 // dense: write S instead of the group maxima.
 template <typename Tag>
 int launch_scores(dlc_ctx* ctx, const GemmArgs& a, bool dense, hipStream_t st) {
+    if (!dense && use_gemv(a)) return launch_gemv<Tag>(ctx, a, st);
     if (a.nsplit <= 1) return dense ? launch_gemm<Tag, GEMM_DENSE>(ctx, a, st) : launch_gemm<Tag, GEMM_GROUPS>(ctx, a, st);
     int rc = launch_gemm<Tag, GEMM_PARTIAL>(ctx, a, st);
     if (rc != DLC_OK) return rc;

@@ -102,6 +102,26 @@ def test_cosine_scores_split_k_vs_oracle(eng):
     assert torch.equal(s, s2)                                  # chunk-ordered reduction: bit-reproducible
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("nq,n,d,k", [(1, 1, 64, 1), (1, 100, 4096, 5), (2, 5000, 4096, 20), (3, 70001, 1024, 20),
+                                      (4, 3000, 8192, 7), (1, 130, 8192, 128), (4, 999, 192, 20)])
+def test_cosine_topk_few_queries_bandwidth_kernel(eng, dtype, nq, n, d, k):
+    """q <= 4 (a single frame's query) is scored by the streaming dot-product kernel instead of the
+    256-query MFMA tile; same selection + exact re-score after it, same results."""
+    rng = np.random.RandomState(n + nq)
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    if n > 40:
+        q[0] = db[n // 2] + 0.3 * q[0]
+        db[n - 3] = db[n // 2]                                 # duplicate rows: the tie goes to the lower index
+    db_st, q_st = stored(eng, db, dtype), stored(eng, q, dtype)
+    s, i = eng.match_topk(q_st, db_st, k, row_offset=11)
+    torch.cuda.synchronize()
+    if n > 40:
+        assert i[0, 0].item() == n // 2 + 11 and (k < 2 or i[0, 1].item() == n - 3 + 11)
+    assert_topk_matches(s, i, q_st, db_st, k, row_offset=11)
+
+
 def test_cosine_topk_planted_neighbours_exact(eng):
     """Planted-margin data: indices must be IDENTICAL to the oracle's."""
     rng = np.random.RandomState(7)
