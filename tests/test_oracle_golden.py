@@ -100,3 +100,34 @@ def test_cosine_topk_tie_break_and_merge():
     ms, mi = ocos.merge_topk(np.concatenate([p[0] for p in parts], 1), np.concatenate([p[1] for p in parts], 1), 10)
     np.testing.assert_array_equal(mi, gi)
     np.testing.assert_allclose(ms, gs, rtol=0, atol=1e-14)
+
+
+def test_config1_plumbing_on_cpu():
+    """BASELINE configs[0] without a GPU: the reference's own frames -> grey -> key-points ->
+    30 patches -> SDAV forward -> cosine matrix on the flattened descriptors + the reference-semantics
+    similarity matrix, all through the oracle (hidden width reduced so it runs in seconds)."""
+    import glob
+    import os
+    from conftest import GOLDEN
+    from oracle import cosine as ocos, keypoints as okp, patches as opatch, sdav as osdav, similarity as osim
+    frames = sorted(glob.glob(os.path.join(GOLDEN, "frames", "*.ppm")))
+    assert len(frames) == 3
+    x = []
+    for f in frames:
+        gray = opatch.bgr2gray_opencv(opatch.read_ppm(f))
+        pts, resp, count = okp.key_points(gray, 30)
+        assert count == 30 and np.all(np.diff(resp) <= 0)
+        x.append(opatch.parse(gray, [tuple(p) for p in pts], 41))
+    x = np.stack(x)
+    assert x.shape == (3, 30, 1681) and 0.0 <= x.min() and x.max() <= 1.0
+    ws, bs = osdav.init_weights(7, hidden_units=[48, 40, 32, 24, 16], scale="fan_in")
+    h = osdav.transform(x, ws, bs)
+    assert h.shape == (90, 16) and np.all((h > 0) & (h < 1))
+    desc = h.reshape(3, 30, 16)
+    place = ocos.l2_normalize(desc.reshape(3, -1), center=True)
+    s = ocos.scores(place, place)
+    assert np.allclose(np.diag(s), 1.0) and np.allclose(s, s.T) and np.all(s <= 1 + 1e-12)
+    top_s, top_i = ocos.cosine_topk(place, place, 2)
+    assert top_i[:, 0].tolist() == [0, 1, 2]                                # every frame's best match is itself
+    m = osim.similarity_matrix(desc)
+    assert m.dtype == np.int64 and m.shape == (3, 3) and np.all(np.diag(m) == -1) and np.array_equal(m, m.T)
