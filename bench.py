@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the N>1 path with several ranks on ONE GPU")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
@@ -75,6 +76,46 @@ def pmc_traffic(n, d, nq, dtype, world):
         if (w.get("db_rows"), w.get("dim"), w.get("queries"), w.get("dtype"), w.get("n_gpus")) == (n, d, nq, dtype, world):
             best = (g.get("hbm_traffic_bytes_per_launch"), os.path.basename(f))
     return best
+
+
+def power_probe(step, seconds=2.5):
+    """Keep submitting steps for `seconds` while a thread samples `rocm-smi --showpower --showclocks`
+    (a child process); returns the median package power (W) and shader clock (MHz), or None."""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True,
+                                     timeout=10).stdout
+                pw = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+                sc = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", txt)
+                if pw and sc:
+                    samples.append((float(pw.group(1)), int(sc.group(1))))
+            except Exception:
+                return
+            stop.wait(0.3)
+
+    try:
+        th = threading.Thread(target=sample, daemon=True)
+        th.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+        stop.set()
+        th.join(timeout=15)
+    except Exception:
+        return None
+    if len(samples) < 2:
+        return None
+    good = samples[1:]                                   # the first sample may predate the load
+    return {"package_power_w": float(np.median([g[0] for g in good])), "sclk_mhz": float(np.median([g[1] for g in good])),
+            "samples": len(good), "source": "rocm-smi while the timed loop's step keeps running (untimed)"}
 
 
 def synth_shard(eng, n_total, dim, lo, hi, dtype, planted_rows, chunk=32768):
@@ -210,6 +251,11 @@ def main():
                          "mfma_achieved_tflops": achieved_tf, "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
                          "mfma_frac": achieved_tf / MFMA_PEAK_TFLOPS},
         }
+
+    # ---- package power / clock while the same loop runs on (untimed; rank 0, N=1 only): the score GEMM
+    # sits on the board's power cap, which is what bounds it -------------------------
+    if rank == 0 and world == 1 and not args.no_power_probe:
+        out["roofline"]["power_probe"] = power_probe(step, seconds=2.5)
 
     # ---- CPU baseline + index agreement on a bounded sample (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # one bench line per BASELINE config that fits one GPU (GPU box only)
 for args in "--dtype f16" "--rows 100000" "--rows 100000 --dtype f16" "--rows 12500" "--rows 125000"; do
-  timeout -k 10 300 python bench.py $args --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null > /tmp/b.json || exit 1
+  timeout -k 10 300 python bench.py $args --steps 50 --warmup 5 --no-cpu-baseline --no-power-probe 2>/dev/null > /tmp/b.json || exit 1
   python - "$args" <<'PY'
 import sys, json
 d = json.loads(open("/tmp/b.json").read().strip().splitlines()[-1])

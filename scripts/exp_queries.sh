@@ -1,7 +1,7 @@
 #!/bin/bash
 # query-frames/s against the 1M-row database for several batch sizes (GPU box only)
 for q in 4 8 64 128 192 256 300; do
-  timeout -k 10 300 python bench.py --queries $q --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null > /tmp/b.json || exit 1
+  timeout -k 10 300 python bench.py --queries $q --steps 40 --warmup 5 --no-cpu-baseline --no-power-probe 2>/dev/null > /tmp/b.json || exit 1
   python - "$q" <<'PY'
 import sys, json
 d = json.loads(open("/tmp/b.json").read().strip().splitlines()[-1])
