@@ -266,9 +266,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
             dma4(voff[H], a_base + (long long)kk_ * 128, lds_stage + (POS) + (H) * HALF_BYTES);      \
         }                                                                                            \
     } while (0)
+    // wave 4 + j stages exactly the queries of column block j: nobody reads them when that block is idle
+    const bool b_on = !MASKQ || (qblk * BNQ + ridx * 64 < p.q);
 #define DLC_ISSUE_B(POS, H, t2)                                                                      \
     do {                                                                                             \
-        if (!is_a) {                                                                                 \
+        if (!is_a && b_on) {                                                                         \
             int kk_ = (t2) < nk ? (t2) : nk - 1;                                                     \
             dma4(voff[H], b_base + (long long)kk_ * 128, lds_stage + B_RING + (POS) + (H) * HALF_BYTES); \
         }                                                                                            \
