@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu rehearses the N>1 path with several ranks on ONE GPU")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="two-stream MatchPipeline also on one GPU (default there: one-shot calls, measured 3 %% faster "
+                         "-- at the power cap the overlapped selection costs the GEMM more than it hides)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one stream, no overlap of a batch's selection / all-gather with the next batch's GEMM")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
@@ -180,7 +183,8 @@ def main():
     queries = eng.normalize(planted + sigma * noise, dt, center=True)
     db = dlc.KeyframeDatabase(rows, dtype=dt, row_offset=lo, stored=True)
     sharded = dlc.ShardedKeyframeDatabase.from_database(db)
-    pipe = None if args.no_pipeline else dlc.MatchPipeline(db, k, depth=2 if world == 1 else 3)
+    use_pipe = not args.no_pipeline and (world > 1 or args.pipeline)
+    pipe = dlc.MatchPipeline(db, k, depth=2 if world == 1 else 3) if use_pipe else None
     torch.cuda.synchronize()
     last = [None]
 
