@@ -141,7 +141,9 @@ class KeyframeDatabase:
 
 
 class MatchPipeline:
-    """Two-stream pipelined top-k match against one resident shard.
+    """Two-stream pipelined top-k match against one resident shard.  Meant for the sharded case: on a
+    single GPU the score GEMM runs at the board's power cap and an overlapped selection slows it by
+    more than it hides (measured -3 %), so plain KeyframeDatabase.match_topk calls are the faster form there.
 
     The score GEMM of batch i+1 runs on the submitting stream while the selection /
     re-score / final top-k of batch i (and, when sharded, the RCCL all-gather of the
