@@ -167,6 +167,12 @@ def test_cosine_topk_row_stride_and_padding(eng):
     big[:, :128] = db_st
     s, i = eng.match_topk(q_st, big[:, :128], 10)
     assert_topk_matches(s, i, q_st, db_st, 10)
+    s, i = eng.match_topk(q_st[:2], big[:, :128], 10)           # q <= 4: the streaming kernel, same strided rows
+    assert_topk_matches(s, i, q_st[:2], db_st, 10)
+    qbig = torch.zeros((9, 192), dtype=torch.bfloat16, device=eng.device)
+    qbig[:, :128] = q_st
+    s, i = eng.match_topk(qbig[:3, :128], big[:, :128], 10)     # strided queries as well
+    assert_topk_matches(s, i, q_st[:3], db_st, 10)
 
 
 def test_cosine_scores_dense_vs_oracle(eng):
