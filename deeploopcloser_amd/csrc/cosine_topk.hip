@@ -576,8 +576,12 @@ struct FinishExtra {
                               // groups e with e % gparts == y and writes its top-k at [y][q][k]
 };
 
+// The 256-thread forms are meant to sit beside a resident score-GEMM workgroup (2 x 200 VGPRs per
+// SIMD): 5 waves per SIMD caps them at 96 VGPRs.  (Left to itself the compiler chose 116-118 for two
+// of them -- more loads in flight, but no room beside the GEMM.)
 template <typename Tag, int THREADS, int RS_UNROLL, int MODE>
-__global__ __launch_bounds__(THREADS) void finish_topk_kernel(
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 5 : 1)))
+void finish_topk_kernel(
     float* __restrict__ tmax, long long ldt, int nh, int tv_in_lds, const float* __restrict__ gmax, long long ldg,
     long long ng, int kg, const char* __restrict__ Q, long long ldq_b, const char* __restrict__ DB, long long lddb_b,
     long long n, int d, int k, long long row_offset, float* __restrict__ out_s, long long* __restrict__ out_i,
@@ -608,6 +612,40 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(
         const int chunk = (nh + FIN_WAVES - 1) / FIN_WAVES;
         const int lo_e = w * chunk, hi_e = min(nh, lo_e + chunk);
         unsigned bh = 0, bl = 0;               // this lane's best key (hi, lo); 0,0 = none
+        constexpr int LV = 16;                 // a lane's values live in registers when its slice has <= LV of them
+        // (not in the small-footprint fused form, which has to stay under ~110 VGPRs to sit beside a GEMM workgroup)
+        if ((THREADS == 512 || MODE == FIN_GROUPS) && chunk <= 64 * LV) {
+            // (up to 8 waves x 1024 half tiles = 1 M rows per shard: the benchmark; an owner's rescan is then
+            // 16 register compares instead of 16 dependent LDS reads, 24 times per wave)
+            unsigned vk[LV];                   // score keys; 0 = none / retired
+#pragma unroll
+            for (int j = 0; j < LV; ++j) {
+                const int e = lo_e + lane + 64 * j;
+                const float v = e < hi_e ? tv[e] : -INFINITY;
+                vk[j] = v == -INFINITY ? 0u : f32_key(v);
+            }
+            auto rescan_regs = [&]() {
+                bh = 0; bl = 0;
+#pragma unroll
+                for (int j = 0; j < LV; ++j) {             // ascending e: the first maximum has the lowest index
+                    const unsigned l = ~(unsigned)(lo_e + lane + 64 * j);
+                    if (vk[j] > bh) { bh = vk[j]; bl = l; }
+                }
+            };
+            rescan_regs();
+            for (int it = 0; it < kt; ++it) {
+                const unsigned mh = wave_max_u32(bh);
+                const unsigned ml = wave_max_u32(bh == mh ? bl : 0u);
+                if (lane == 0) ckey[w * kt + it] = mh == 0u ? 0ull : (((unsigned long long)mh << 32) | ml);
+                if (mh != 0u && bh == mh && bl == ml) {  // the owner retires it and finds its next best
+                    const int jr = (int)((~ml) - (unsigned)(lo_e + lane)) >> 6;
+#pragma unroll
+                    for (int j = 0; j < LV; ++j)
+                        if (j == jr) vk[j] = 0u;
+                    rescan_regs();
+                }
+            }
+        } else {
         auto rescan = [&]() {
             bh = 0; bl = 0;
             for (int e = lo_e + lane; e < hi_e; e += 64) {
@@ -626,6 +664,7 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(
                 tv[~ml] = -INFINITY;
                 rescan();
             }
+        }
         }
     }
     __syncthreads();
