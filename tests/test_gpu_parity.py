@@ -122,6 +122,33 @@ def test_cosine_topk_few_queries_bandwidth_kernel(eng, dtype, nq, n, d, k):
     assert_topk_matches(s, i, q_st, db_st, k, row_offset=11)
 
 
+def test_cosine_topk_plan_boundaries_fuzz(eng):
+    """Shapes on and around every plan boundary of dlc_cosine_topk (streaming kernel q <= 4 / LDS limit,
+    masked query blocks, split-K, multi-workgroup re-score, tile edges), seeded, against the oracle."""
+    rng = np.random.RandomState(2026)
+    shapes = [(4, 256, 8192, 3), (5, 256, 8192, 3), (4, 257, 8256, 5), (2, 511, 16384, 9), (3, 512, 16448, 1),
+              (32, 300, 8192, 20), (33, 300, 8192, 20), (192, 1500, 256, 4), (193, 1500, 256, 4), (256, 255, 64, 128),
+              (257, 256, 64, 2), (449, 2049, 128, 6), (1, 32769, 64, 20), (7, 40000, 64, 20), (64, 33000, 1024, 20),
+              (512, 4000, 512, 10)]
+    for _ in range(10):
+        shapes.append((int(rng.choice([1, 3, 4, 5, 31, 64, 200, 260])), int(rng.randint(1, 6000)),
+                       64 * int(rng.randint(1, 40)), int(rng.choice([1, 2, 20, 77, 128]))))
+    for nq, n, d, k in shapes:
+        db = rng.standard_normal((n, d)).astype(np.float32)
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        if n > 3:
+            q[0] = db[n // 2]
+            db[n - 1] = db[n // 2]                              # an exact duplicate at the very end
+        dtype = "bf16" if (n + nq) % 2 else "f16"
+        db_st, q_st = stored(eng, db, dtype), stored(eng, q, dtype)
+        s, i = eng.match_topk(q_st, db_st, k, row_offset=3)
+        torch.cuda.synchronize()
+        if n > 3:
+            assert i[0, 0].item() == n // 2 + 3, (nq, n, d, k)
+            assert k < 2 or i[0, 1].item() == n - 1 + 3, (nq, n, d, k)
+        assert_topk_matches(s, i, q_st, db_st, k, row_offset=3)
+
+
 def test_cosine_topk_planted_neighbours_exact(eng):
     """Planted-margin data: indices must be IDENTICAL to the oracle's."""
     rng = np.random.RandomState(7)
