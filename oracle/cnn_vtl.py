@@ -56,8 +56,8 @@ def conv2d_nhwc(x, w, b, stride, padding, relu):
     oh, ph = _out_size(h, kh, stride, padding)
     ow, pw = _out_size(wd, kw, stride, padding)
     if padding == "SAME":
-        hp = (oh - 1) * stride + kh
-        wp = (ow - 1) * stride + kw
+        hp = max((oh - 1) * stride + kh, ph + h)     # stride > 1 can leave trailing pixels unused (no pad needed)
+        wp = max((ow - 1) * stride + kw, pw + wd)
         xp = np.zeros((n, hp, wp, c), dtype=np.float64)
         xp[:, ph:ph + h, pw:pw + wd, :] = x
     else:

@@ -312,6 +312,38 @@ def test_gemm_split_k_latency_mode(eng, m, n, k, blayout):
     assert (split - one_pass).abs().max().item() < 1e-12
 
 
+def test_conv_and_gemm_fuzz_in_both_modes(eng):
+    """Seeded random conv geometries (C % 8 == 0) and GEMM shapes, one-pass and split-K (scratch on):
+    both within 1e-10 of the oracle; the split start (ky, kx, c) of every K chunk is exercised."""
+    from oracle import cnn_vtl as ocnn
+    rng = np.random.RandomState(77)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    cases = []
+    for _ in range(8):
+        kh = int(rng.choice([1, 3, 5]))
+        cases.append((int(rng.randint(kh, 14)), int(rng.randint(kh, 14)), 8 * int(rng.randint(1, 40)), kh,
+                      int(rng.randint(1, 200)), int(rng.choice([1, 2])), str(rng.choice(["SAME", "VALID"])), bool(rng.randint(2))))
+    for mode in (False, True):
+        eng.set_scratch(1 << 26 if mode else 0)
+        try:
+            for (h, w, c, kh, cout, stride, pad, relu) in cases:
+                x = rng.standard_normal((2, h, w, c))
+                wk = rng.standard_normal((kh, kh, c, cout)) / np.sqrt(kh * kh * c)
+                b = rng.standard_normal(cout)
+                oh, ph = ocnn._out_size(h, kh, stride, pad)
+                ow, pw = ocnn._out_size(w, kh, stride, pad)
+                got = eng.conv2d(dev(x), dev(wk.reshape(-1, cout)), dev(b), kh, kh, stride, ph, pw, oh, ow, 2 if relu else 0)
+                ref = ocnn.conv2d_nhwc(x, wk, b, stride, pad, relu)
+                assert np.abs(got.cpu().numpy() - ref).max() < 1e-10, (mode, h, w, c, kh, cout, stride, pad)
+            for _ in range(6):
+                m, n, k = int(rng.randint(1, 300)), int(rng.randint(1, 300)), int(rng.randint(1, 5000))
+                a, bm, bias = rng.standard_normal((m, k)) / np.sqrt(k), rng.standard_normal((k, n)), rng.standard_normal(n)
+                got = eng.gemm_bias_act(dev(a), dev(bm), dev(bias), act=1)
+                assert np.abs(got.cpu().numpy() - 1.0 / (1.0 + np.exp(-(a @ bm + bias)))).max() < 1e-10, (mode, m, n, k)
+        finally:
+            eng.set_scratch(0)
+
+
 def test_latency_mode_encoders_vs_oracle(dlc, eng):
     """Single-frame SDAV and CnnVtl encodes with the split-K scratch on: same oracle tolerances."""
     from oracle import sdav as osdav, cnn_vtl as ocnn

@@ -23,6 +23,7 @@ def tf_same_pads(n, k, s):
     (22, 28, 5, 5, 6, 10, 1, "SAME", True),          # conv2 (5x5 SAME)
     (10, 13, 3, 3, 16, 12, 1, "SAME", False),        # conv5 (3x3 SAME, no activation)
     (12, 9, 3, 3, 4, 5, 2, "SAME", True),            # stride-2 SAME: asymmetric pads (not in the model, pins the rule)
+    (8, 6, 1, 1, 4, 3, 2, "SAME", True),             # 1x1 stride 2: no padding and a trailing row / column left unused
 ])
 def test_conv2d_oracle_equals_torch_and_scipy(h, w, kh, kw, cin, cout, stride, padding, relu):
     from scipy.signal import correlate
