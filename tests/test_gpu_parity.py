@@ -521,6 +521,30 @@ def test_distance_matrix_vs_oracle_larger(dlc):
     assert got[50, 3] == 0 and np.array_equal(got, got.T)
 
 
+def test_match_reference_semantics_fuzz(dlc):
+    """Seeded random sizes for the two reference-semantics matrices: ragged N / D / P / H, 1-frame and
+    1-byte cases, duplicates (distance 0, similarity +inf), int8 extremes."""
+    from oracle import distance as odist, similarity as osim
+    rng = np.random.RandomState(99)
+    for n, d in [(1, 1), (2, 3), (65, 64), (64, 65), (129, 17), (33, 4099), (7, 1), (200, 255)]:
+        desc = rng.randint(-128, 128, size=(n, d)).astype(np.int8)
+        if n > 2:
+            desc[n - 1] = desc[0]
+            desc[1] = -128
+        got = dlc.DistanceCalculator.distance_matrix(desc)
+        assert got.dtype == np.int64 and np.array_equal(got, odist.distance_matrix(desc)), (n, d)
+    for n, p, h in [(2, 1, 1), (3, 30, 7), (9, 64, 33), (17, 5, 129), (4, 30, 2500), (31, 2, 64)]:
+        ds = rng.uniform(0, 1, size=(n, p, h))
+        if n > 2:
+            ds[n - 1] = ds[1]
+        got = dlc.SimilarityCalculator(ds).similarity_matrix(as_int64=False)
+        ref = osim.similarity_matrix_f64(ds)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isposinf(got), np.isposinf(ref)) and np.array_equal(np.isnan(got), np.isnan(ref)), (n, p, h)
+        assert np.abs(got[fin] - ref[fin]).max() <= 1e-9 * max(1.0, np.abs(ref[fin]).max()), (n, p, h)
+        assert np.array_equal(dlc.SimilarityCalculator(ds).similarity_matrix(), osim.similarity_matrix(ds)), (n, p, h)
+
+
 # --------------------------------------------------------------------------- CnnVtl
 def test_cnn_vtl_pieces_vs_oracle(eng):
     from oracle import cnn_vtl as ocnn
