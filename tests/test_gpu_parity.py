@@ -521,6 +521,32 @@ def test_distance_matrix_vs_oracle_larger(dlc):
     assert got[50, 3] == 0 and np.array_equal(got, got.T)
 
 
+def test_encoders_fuzz(dlc, eng):
+    """Seeded odd sizes: dlc_sdav_encode with 1-5 layers of arbitrary widths, CnnVtl at non-reference
+    frame sizes (down to the smallest that survives both pools)."""
+    from oracle import sdav as osdav, cnn_vtl as ocnn
+    rng = np.random.RandomState(5)
+    for _ in range(8):
+        layers = int(rng.randint(1, 6))
+        dims = [int(rng.randint(1, 260)) for _ in range(layers + 1)]
+        rows = int(rng.randint(1, 400))
+        ws = [rng.standard_normal((dims[l], dims[l + 1])) for l in range(layers)]
+        bs = [rng.standard_normal(dims[l + 1]) for l in range(layers)]
+        x = rng.uniform(0, 1, (rows, 1, dims[0]))
+        got = eng.sdav_encode(torch.from_numpy(x.reshape(rows, dims[0])).to(eng.device),
+                              [torch.from_numpy(w).to(eng.device) for w in ws], [torch.from_numpy(b).to(eng.device) for b in bs])
+        assert np.abs(got.cpu().numpy() - osdav.transform(x, ws, bs)).max() < 1e-10, dims
+    for h, w, n in [(35, 39, 2), (67, 83, 3), (50, 131, 1)]:
+        frames = rng.randint(0, 256, size=(n, h, w, 3)).astype(np.float64)
+        net = dlc.CnnVtl(input_shape=[n, h, w, 3], seed=11, mask_seed=12, compress_factor=90.0)
+        cols = ocnn.column_indices(ocnn.layer_sizes((h, w)), 90.0, seed=12)
+        assert np.array_equal(net.columns, cols)
+        cw, cb = ocnn.init_weights(11)
+        got, ref = net.transform(frames), ocnn.transform(frames, cw, cb, cols)
+        diff = (got.astype(np.int16) - ref.astype(np.int16)) % 256
+        assert got.shape == ref.shape and np.count_nonzero(diff) <= 2 and np.all((diff == 0) | (diff == 1) | (diff == 255)), (h, w)
+
+
 def test_match_reference_semantics_fuzz(dlc):
     """Seeded random sizes for the two reference-semantics matrices: ragged N / D / P / H, 1-frame and
     1-byte cases, duplicates (distance 0, similarity +inf), int8 extremes."""
