@@ -142,6 +142,25 @@ def test_harris_keypoints_bit_exact_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_frontend_fuzz_odd_image_sizes():
+    """Detector and patch gather on odd frame sizes (down to the 7x7 / 41x41 minima), seeded."""
+    import deeploopcloser_amd as dlc
+    from oracle import keypoints as okp
+    eng = dlc.default_engine()
+    rng = np.random.RandomState(31)
+    for h, w, n in [(7, 7, 3), (8, 300, 5), (41, 41, 30), (100, 57, 30), (193, 241, 64)]:
+        imgs = rng.randint(0, 256, (3, h, w)).astype(np.uint8)
+        pts, resp, cnt = eng.harris_keypoints(torch.from_numpy(imgs).to(eng.device), n)
+        for f in range(3):
+            ep, er, ec = okp.key_points(imgs[f], n)
+            assert int(cnt[f]) == ec and np.array_equal(pts[f].cpu().numpy(), ep) and np.array_equal(resp[f].cpu().numpy(), er), (h, w)
+        if h >= 41 and w >= 41:
+            parser = dlc.CvInputParser(n, 41)
+            kps = dlc.harris_key_points(imgs[0], n)
+            assert np.array_equal(parser.parse(imgs[0], kps), opatch.parse(imgs[0], [k.pt for k in kps], 41)), (h, w)
+
+
+@pytest.mark.gpu
 def test_parser_default_detector_and_batch():
     """parse(image) without key-points = Harris key-points through the reference's patch rule;
     parse_batch does the same for a stack of frames on the GPU, topping up with grid points."""
