@@ -44,7 +44,7 @@ constexpr int A_STAGES = DLC_A_STAGES;
 constexpr int B_RING = A_STAGES * A_TILE;  // A ring first, then the B ring of 2 K tiles (64 KiB)
 constexpr int LDS_BYTES = A_STAGES * A_TILE + 2 * B_TILE;
 #ifndef DLC_STAGGER_SLEEP
-#define DLC_STAGGER_SLEEP 31     // s_sleep units of 64 cycles per stagger step (~1 us); x stagger_mult
+#define DLC_STAGGER_SLEEP 15     // s_sleep units of 64 cycles per stagger step (~0.5 us); x stagger_mult
 #endif
 #ifndef DLC_STAGGER_PHASES
 #define DLC_STAGGER_PHASES 16
@@ -1047,8 +1047,8 @@ int launch_gemm_masked(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
     const long long nwg = dlc::cdiv(b.ntiles, 8) * 8 * b.nqb * b.nsplit;
     if (nwg > 0x7fffffffll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: %lld workgroups exceed the grid limit", nwg);
     dim3 grid((unsigned)nwg);
-    // measured: 0-60 us of stagger pays from ~4 dispatch rounds on, 0-15 us below (scripts/exp_rows.py)
-    b.stagger_mult = (nwg >= 3 * 256) ? 4 : 1;
+    // measured: 0-30 us of stagger pays from ~3 dispatch rounds on, 0-15 us below (scripts/exp_rows.py, exp_gemm.py)
+    b.stagger_mult = (nwg >= 3 * 256) ? 4 : 2;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), LDS_BYTES, st, b);
     DLC_LAUNCH_CHECK(ctx, "score_gemm_kernel");
     return DLC_OK;
