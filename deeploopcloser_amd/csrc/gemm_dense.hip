@@ -47,8 +47,8 @@ __device__ __forceinline__ T apply_act(T z, int act) {
 
 // Implicit im2col (tf.layers.conv2d on NHWC, src/cnn_vtl/network/cnn_vtl.py:33-93): row m of the
 // A operand is output pixel (img, oy, ox), column k is (ky, kx, c) with c fastest; A then points
-// at the NHWC input and lda is unused.  Needs C % 8 == 0 (a thread's 8 consecutive k stay inside
-// one input pixel).
+// at the NHWC input and lda is unused.  With C % 8 == 0 a thread's 8 consecutive k are 8 channels of
+// one input pixel (one 64-byte load); other C (conv1: 3) are loaded element by element.
 struct ConvGeom {
     int H, W, C, KW, stride, pad_t, pad_l, OH, OW;
 };
@@ -66,7 +66,9 @@ struct Args {
     T* P;               // split-K partial results [chunks][M][N] (null when one pass)
 };
 
-template <typename T, int BLAYOUT, bool CONV = false>
+// CONV: 0 plain GEMM; 1 implicit im2col, 8 consecutive channels of one pixel per thread (C % 8 == 0);
+//       2 implicit im2col element by element (any C: conv1's 3 input channels)
+template <typename T, int BLAYOUT, int CONV = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     constexpr int LDB_S = BLAYOUT == DLC_B_KN ? LDB_KN : LDB_NK;
     constexpr int B_ELEMS = BLAYOUT == DLC_B_KN ? TK * LDB_KN : TN * LDB_NK;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     // implicit im2col: this thread's output pixel (fixed for the whole K loop)
     long long cv_img_base = 0;
     int cv_iy0 = 0, cv_ix0 = 0;
-    if constexpr (CONV) {
+    if constexpr (CONV != 0) {
         const long long gm = m0 + a_row;
         const long long gmc = gm < p.M ? gm : p.M - 1;
         const long long img = gmc / ((long long)p.cv.OH * p.cv.OW);
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     // (ky, kx, c) of this thread's 8 channels in the NEXT tile to load: load_tile is called with
     // k0 = 0, TK, 2 TK, ... and steps them instead of dividing by C and KW in every K step
     int cv_c = 0, cv_kx = 0, cv_ky = 0;
-    if constexpr (CONV) {
+    if constexpr (CONV != 0) {
         const long long t = (kb + a_k) / p.cv.C;
         cv_c = (int)(kb + a_k - t * p.cv.C);
         cv_ky = (int)(t / p.cv.KW);
@@ -111,7 +113,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     auto load_tile = [&](long long k0) {
         const bool k_full = (k0 + TK <= p.K);
         const long long gm = m0 + a_row;
-        if constexpr (CONV) {
+        if constexpr (CONV == 2) {
+            // element e of this thread's 8 is (ky, kx, c) stepped e times from the first one
+            int c = cv_c, kx = cv_kx, ky = cv_ky;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int iy = cv_iy0 + ky, ix = cv_ix0 + kx;
+                const bool ok = gm < p.M && k0 + a_k + e < p.K && iy >= 0 && iy < p.cv.H && ix >= 0 && ix < p.cv.W;
+                ra[e] = ok ? p.A[cv_img_base + ((long long)iy * p.cv.W + ix) * p.cv.C + c] : (T)0;
+                if (++c == p.cv.C) { c = 0; if (++kx == p.cv.KW) { kx = 0; ++ky; } }
+            }
+            cv_c += TK;                                          // first element of the next tile
+            while (cv_c >= p.cv.C) {
+                cv_c -= p.cv.C;
+                if (++cv_kx == p.cv.KW) { cv_kx = 0; ++cv_ky; }
+            }
+        } else if constexpr (CONV == 1) {
             const long long gk = k0 + a_k;                       // multiple of 8; 8 channels of one input pixel
             const int iy = cv_iy0 + cv_ky, ix = cv_ix0 + cv_kx;
             const bool ok = gm < p.M && gk < p.K && iy >= 0 && iy < p.cv.H && ix >= 0 && ix < p.cv.W;
@@ -295,7 +312,8 @@ int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, 
     const int chunks = plan_split<T>(ctx, M, N, K, &a.kchunk);
     a.P = chunks > 1 ? (T*)ctx->scratch : nullptr;
     dim3 grid((unsigned)dlc::cdiv(M, TM), (unsigned)dlc::cdiv(N, TN), (unsigned)chunks);
-    if (cv) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, true>), grid, dim3(256), 0, st, a);
+    if (cv && cv->C % 8 == 0) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, 1>), grid, dim3(256), 0, st, a);
+    else if (cv) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, 2>), grid, dim3(256), 0, st, a);
     else if (blayout == DLC_B_KN) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_NK>), grid, dim3(256), 0, st, a);
     DLC_LAUNCH_CHECK(ctx, "gemm_bias_act_kernel");
@@ -337,9 +355,6 @@ extern "C" int dlc_conv2d_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int
         pad_top < 0 || pad_left < 0 || oh < 1 || ow < 1)
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "conv2d: bad argument");
     if (act < DLC_ACT_NONE || act > DLC_ACT_RELU) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "conv2d: act %d", act);
-    if (c % 8 != 0)
-        return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "conv2d: the implicit-GEMM loader needs C %% 8 == 0 (C=%d): use "
-                                                   "dlc_im2col_nhwc_f64 + dlc_gemm_bias_act", c);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     dlc_gemm::ConvGeom cv{h, w, c, kw, stride, pad_top, pad_left, oh, ow};

@@ -241,14 +241,11 @@ class Engine:
         return cols
 
     def conv2d(self, x, kernel2d, bias, kh, kw, stride, pad_top, pad_left, oh, ow, act):
-        """NHWC fp64 convolution + bias + activation; implicit GEMM when C % 8 == 0, else
-        im2col + GEMM.  kernel2d is the HWIO kernel reshaped [kh*kw*c, cout]."""
+        """NHWC fp64 convolution + bias + activation as an implicit GEMM (no im2col matrix).
+        kernel2d is the HWIO kernel reshaped [kh*kw*c, cout]."""
         x = x.contiguous()
         n, h, w, c = x.shape
         cout = kernel2d.shape[1]
-        if c % 8 != 0:
-            cols = self.im2col(x, kh, kw, stride, pad_top, pad_left, oh, ow)
-            return self.gemm_bias_act(cols, kernel2d, bias, act=act).reshape(n, oh, ow, cout)
         out = torch.empty((n, oh, ow, cout), dtype=torch.float64, device=self.device)
         self._check(self.lib.dlc_conv2d_nhwc_f64(self.ctx, _ptr(x), n, h, w, c, _ptr(kernel2d), _ptr(bias), kh, kw, cout,
                                                   stride, pad_top, pad_left, oh, ow, act, _ptr(out), self._stream()))

@@ -178,8 +178,10 @@ int dlc_im2col_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, 
 /*
  * tf.layers.conv2d (NHWC fp64, HWIO kernel reshaped [kh*kw*c, cout]) + bias + activation as an
  * IMPLICIT GEMM: the A-tile loader of the fp64 MFMA GEMM gathers input pixels directly, the
- * im2col matrix is never written.  Needs c %% 8 == 0 (conv2..conv5 of cnn_vtl.py:49-93); conv1
- * (c = 3) goes through dlc_im2col_nhwc_f64 + dlc_gemm_bias_act.  out is [n, oh, ow, cout].
+ * im2col matrix is never written.  With c %% 8 == 0 (conv2..conv5 of cnn_vtl.py:49-93) a thread
+ * fetches 8 channels of one pixel per 64-byte load; other channel counts (conv1: c = 3) are
+ * gathered element by element.  out is [n, oh, ow, cout].  (dlc_im2col_nhwc_f64 +
+ * dlc_gemm_bias_act give bit-identical sums.)
  */
 int dlc_conv2d_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c,
                         const double* kernel, const double* bias, int kh, int kw, int cout,

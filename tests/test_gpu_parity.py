@@ -609,8 +609,19 @@ def test_conv2d_implicit_gemm_vs_oracle(eng):
         cols = eng.im2col(dev(x), kh, kh, stride, ph, pw, oh, ow)                  # explicit path: bit-identical sums
         alt = eng.gemm_bias_act(cols, dev(wk.reshape(-1, cout)), dev(b), act=2 if relu else 0).reshape(got.shape)
         assert torch.equal(alt, got)
-    with pytest.raises(ValueError):
-        eng.lib and eng._check(eng.lib.dlc_conv2d_nhwc_f64(eng.ctx, 1, 1, 4, 4, 3, 1, 1, 3, 3, 2, 1, 0, 0, 2, 2, 0, 1, None))
+    # channel counts that are not multiples of 8 (conv1: 3 input channels) take the element-wise loader
+    for (h, w, c, kh, cout, stride, pad, relu) in ((27, 31, 3, 11, 96, 4, "VALID", True), (9, 11, 5, 3, 7, 1, "SAME", False),
+                                                   (8, 8, 1, 1, 3, 2, "SAME", True), (12, 10, 12, 5, 130, 2, "SAME", True)):
+        x = rng.standard_normal((2, h, w, c))
+        wk = rng.standard_normal((kh, kh, c, cout)) / np.sqrt(kh * kh * c)
+        b = rng.standard_normal(cout)
+        oh, ph = ocnn._out_size(h, kh, stride, pad)
+        ow, pw = ocnn._out_size(w, kh, stride, pad)
+        got = eng.conv2d(dev(x), dev(wk.reshape(-1, cout)), dev(b), kh, kh, stride, ph, pw, oh, ow, 2 if relu else 0)
+        assert np.abs(got.cpu().numpy() - ocnn.conv2d_nhwc(x, wk, b, stride, pad, relu)).max() < 1e-10, (h, w, c, kh)
+        cols = eng.im2col(dev(x), kh, kh, stride, ph, pw, oh, ow)
+        alt = eng.gemm_bias_act(cols, dev(wk.reshape(-1, cout)), dev(b), act=2 if relu else 0).reshape(got.shape)
+        assert torch.equal(alt, got)
 
 
 def test_cnn_vtl_transform_vs_oracle(dlc):
