@@ -1,10 +1,11 @@
 """CnnVtl encoder with the reference's call surface, running on MI355X.
 
 Mirrors src/cnn_vtl/network/cnn_vtl.py: ctor (:13-17), model (:28-128),
-transform (:130-133).  Each convolution is one fp64 MFMA GEMM with the bias / ReLU fused:
-conv2..conv5 as an implicit GEMM (dlc_conv2d_nhwc_f64: the A-tile loader gathers input
-pixels, no im2col matrix), conv1 (3 input channels) as im2col + dlc_gemm_bias_act; pooling, per-row min/max, the 0..255
-scaling, the int8 cast and the column gather are HIP kernels too.
+transform (:130-133).  Each convolution is one fp64 MFMA GEMM with the bias / ReLU fused, run as
+an implicit GEMM (dlc_conv2d_nhwc_f64: the A-tile loader gathers input pixels straight from the
+NHWC tensor, no im2col matrix -- 8 channels per load for conv2..conv5, element by element for
+conv1's 3 input channels); pooling, per-row min/max, the 0..255 scaling, the int8 cast and the
+column gather are HIP kernels too.
 
 The reference's weights (bvlc_alexnet.npy, cnn_vtl.py:137-149) are a git-LFS
 pointer upstream, so weights here are seeded synthetic AlexNet-shaped tensors
@@ -27,6 +28,45 @@ _LAYERS = (
     ("conv4", 3, 3, 384, 384, 1, "SAME", True, False),
     ("conv5", 3, 3, 384, 256, 1, "SAME", False, False),
 )
+
+
+def tf1_constant_fill(value, shape):
+    """What ``tf.constant_initializer(value)`` (TF 1.x) yields for a variable of `shape`
+    (cnn_vtl.py:137-149 hands it the arrays of bvlc_alexnet.npy as they are): the values in C
+    order, and when there are FEWER than the shape holds the last one repeated to the end
+    (tensor_util.make_tensor_proto + the Const kernel's fill); more values than the shape holds is
+    TensorFlow's "Too many elements provided" ValueError.  The published blob stores AlexNet's
+    grouped kernels -- conv2 (5,5,48,256), conv4 (3,3,192,384), conv5 (3,3,192,256) -- while the
+    reference builds ungrouped 96->256 / 384->384 / 384->256 convolutions (:47-93), so half of each of
+    those kernels is the blob in C order and the other half one repeated number."""
+    v = np.asarray(value, dtype=np.float64).reshape(-1)
+    need = int(np.prod(shape))
+    if v.size > need:
+        raise ValueError("Too many elements provided. Needed at most %d, but received %d" % (need, v.size))
+    if v.size == 0:
+        raise ValueError("constant_initializer needs at least one value")
+    out = np.empty(need, dtype=np.float64)
+    out[:v.size] = v
+    out[v.size:] = v[-1]
+    return out.reshape(shape)
+
+
+def alexnet_params_from_dict(layer_params):
+    """conv1..conv5 (HWIO kernels, biases) from the {layer: [W, b]} dict of bvlc_alexnet.npy the
+    way the reference's graph ends up holding them (cnn_vtl.py:137-149: fc6-8 skipped, every array
+    through tf.constant_initializer into the ungrouped variable shapes of :33-93).  Keys may be
+    str or bytes (np.load(..., encoding='bytes'))."""
+    def get(name):
+        for key in (name, name.encode()):
+            if key in layer_params:
+                return layer_params[key]
+        raise KeyError("layer %r missing from the weight dict" % name)
+    ws, bs = [], []
+    for name, kh, kw, cin, cout, *_ in _LAYERS:
+        w, b = get(name)[0], get(name)[1]
+        ws.append(tf1_constant_fill(w, (kh, kw, cin, cout)))
+        bs.append(tf1_constant_fill(b, (cout,)))
+    return ws, bs
 
 
 def _out_size(n, k, s, padding):
@@ -98,10 +138,10 @@ class CnnVtl:
         self._w, self._b = ws, bs
 
     def load_alexnet_npy(self, path):
-        """The {layer: [W, b]} dict layout of bvlc_alexnet.npy (cnn_vtl.py:137-149), fc6-8 skipped."""
+        """The {layer: [W, b]} dict layout of bvlc_alexnet.npy (cnn_vtl.py:137-149), fc6-8 skipped;
+        grouped kernels are filled the way TF-1's constant_initializer fills them (tf1_constant_fill)."""
         d = np.load(path, encoding="bytes", allow_pickle=True).item()
-        names = [l[0] for l in _LAYERS]
-        self.set_weights([d[n][0] for n in names], [d[n][1] for n in names])
+        self.set_weights(*alexnet_params_from_dict(d))
 
     def _features(self, x):
         """conv1..conv5 outputs of a frame chunk: list of [n, oh, ow, cout] fp64 tensors."""

@@ -574,6 +574,8 @@ struct FinishExtra {
     long long nq;
     int gparts;               // FIN_RESCORE: > 1 = grid.y workgroups per query, workgroup y re-scores the listed
                               // groups e with e % gparts == y and writes its top-k at [y][q][k]
+    const float* dense_S;     // small-database plan: the score matrix itself [q, ld_s] is in the workspace, so the
+    long long ld_s;           // selected groups' scores are READ from it instead of re-computed from gathered rows
 };
 
 // The 256-thread forms are meant to sit beside a resident score-GEMM workgroup (2 x 200 VGPRs per
@@ -723,6 +725,11 @@ void finish_topk_kernel(
             continue;
         }
         const long long row0 = (long long)g * GROUP;
+        if (x.dense_S) {                                  // the group's 8 scores are already there
+            if (lane < GROUP)
+                cval[s * GROUP + lane] = (row0 + lane < n) ? x.dense_S[(long long)qi * x.ld_s + row0 + lane] : -INFINITY;
+            continue;
+        }
         const char* rows[GROUP];
 #pragma unroll
         for (int r = 0; r < GROUP; ++r) {
@@ -887,22 +894,108 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const Src* __restrict
     }
 }
 
+// One-pass form for rows that fit in registers: TPR threads per row (64 = one wave per row, no
+// barrier; 256 = one workgroup per row), NVEC 16-byte vectors per thread, so a row is read from HBM
+// once and written once (the multi-pass kernel above reads it up to three times: mean, norm,
+// scale).  Same per-element arithmetic: fp64 statistics, (x - mean) * (1 / norm) in fp64, rounded
+// to fp32 and then to the stored type.  HBM-bound: n * (d * sizeof(Src) + ldd * 2) bytes.
+template <typename Src, typename Tag, int TPR, int NVEC>
+__global__ __launch_bounds__(256) void l2_normalize_regs_kernel(const Src* __restrict__ src, long long lds, long long n,
+                                                                int d, int center, unsigned short* __restrict__ dst,
+                                                                long long ldd) {
+    constexpr int VW = 16 / (int)sizeof(Src);            // elements per 16-byte vector: 4 floats / 2 doubles
+    typedef Src vec_t __attribute__((ext_vector_type(VW)));
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int t = TPR == 64 ? lane : tid;                // index inside the row's thread group
+    const long long row = TPR == 64 ? (long long)blockIdx.x * 4 + (tid >> 6) : (long long)blockIdx.x;
+    if (row >= n) return;                                // wave-uniform (TPR == 64) or block-uniform
+    const Src* x = src + row * lds;
+    vec_t v[NVEC];
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) {
+        const int e0 = (j * TPR + t) * VW;
+        if (e0 + VW <= d) {
+            v[j] = *(const vec_t*)(x + e0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VW; ++i) v[j][i] = e0 + i < d ? x[e0 + i] : (Src)0;
+        }
+    }
+    auto row_sum = [&](double s, int slot) -> double {
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if constexpr (TPR == 64) return s;
+        if (lane == 0) red[slot][tid >> 6] = s;
+        __syncthreads();
+        return red[slot][0] + red[slot][1] + red[slot][2] + red[slot][3];
+    };
+    double mean = 0.0;
+    if (center) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NVEC; ++j)
+#pragma unroll
+            for (int i = 0; i < VW; ++i) s += (double)v[j][i];          // elements past d are zero
+        mean = row_sum(s, 0) / (double)d;
+    }
+    double ss = 0.0;
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j)
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            const double c = (double)v[j][i] - mean;
+            ss += ((j * TPR + t) * VW + i < d) ? c * c : 0.0;
+        }
+    const double nrm = sqrt(row_sum(ss, 1));
+    const double inv = nrm > 0.0 ? 1.0 / nrm : 1.0;
+    unsigned short* o = dst + row * ldd;
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) {
+        const int e0 = (j * TPR + t) * VW;
+        if (e0 >= ldd) continue;                         // ldd is a multiple of 64: vectors never straddle it
+        unsigned short bits[VW];
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            bits[i] = 0;
+            if (e0 + i < d) {
+                const float f = (float)(((double)v[j][i] - mean) * inv);
+                if constexpr (__is_same(Tag, dlc_bf16_tag)) bits[i] = __builtin_bit_cast(unsigned short, (__bf16)f);
+                else bits[i] = __builtin_bit_cast(unsigned short, (_Float16)f);
+            }
+        }
+        if constexpr (VW == 4) {
+            *(uint2*)(o + e0) = make_uint2((unsigned)bits[0] | ((unsigned)bits[1] << 16),
+                                           (unsigned)bits[2] | ((unsigned)bits[3] << 16));
+        } else {
+            *(unsigned*)(o + e0) = (unsigned)bits[0] | ((unsigned)bits[1] << 16);
+        }
+    }
+}
+
 // Split-K second pass.  Sums the chunk partials in chunk order (deterministic) and applies the
 // epilogue of the one-pass kernel: GROUPS -> gmax / tmax, DENSE -> the score matrix.
 // grid (q, ceil(groups / 256)), 256 threads: one thread per group of 8 rows.
-__global__ __launch_bounds__(256) void splitk_groups_kernel(const float* __restrict__ P, long long ldp, int q, int nsplit,
+// keep_sum: also store the summed scores over chunk 0's slot (thread-private elements, so in place):
+// the small-database plan selects its top-k from them.
+__global__ __launch_bounds__(256) void splitk_groups_kernel(float* __restrict__ P, long long ldp, int q, int nsplit,
                                                             float* __restrict__ gmax, long long ldg, long long ng,
-                                                            float* __restrict__ tmax, long long ldt, long long nh) {
+                                                            float* __restrict__ tmax, long long ldt, long long nh,
+                                                            int keep_sum) {
     const int qi = blockIdx.x;
     const long long g = (long long)blockIdx.y * 256 + threadIdx.x;
     float m = -INFINITY;
     if (g < ng) {
         f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-        const float* src = P + (long long)qi * ldp + g * GROUP;
+        float* dst0 = P + (long long)qi * ldp + g * GROUP;
+        const float* src = dst0;
         for (int c = 0; c < nsplit; ++c) {
             a += *(const f32x4_t*)(src);
             b += *(const f32x4_t*)(src + 4);
             src += (long long)q * ldp;
+        }
+        if (keep_sum && nsplit > 1) {
+            *(f32x4_t*)dst0 = a;
+            *(f32x4_t*)(dst0 + 4) = b;
         }
         m = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
         gmax[(long long)qi * ldg + g] = m;
@@ -972,7 +1065,29 @@ struct WsLayout {
     int kg;
     SplitPlan sp;
     int rparts;     // > 1: dlc_cosine_topk re-scores with this many workgroups per query (few queries, long rows)
+    bool dense;     // small database: the score matrix itself is kept (chunk 0 of `part`) and the top-k is read off it
 };
+
+// Few queries take the bandwidth kernel (stored queries in LDS: q <= 4 and q * d * 2 bytes <= 64 KiB).
+inline bool gemv_shape(int64_t q, int64_t nk) {
+    const int qb = q <= 1 ? 1 : (q <= 2 ? 2 : 4);
+    return q <= GEMV_MAX_Q && (long long)qb * nk * 128 <= GEMV_MAX_LDS;
+}
+
+// Small-database plan.  The standard plan never writes the score matrix: it keeps group maxima and
+// re-scores the kg * 8 rows of the selected groups exactly -- a gather of kg * 8 * d * 2 bytes per
+// query whatever the database size.  Against a small database (the reference's own scale: 1063
+// key-frames x 75 000-d, where that gather is 192 of the 1063 rows, 29 MB per query, 30 GB per
+// call) the whole score matrix is cheaper than the gather: q * n * 4 bytes.  The score pass then
+// writes its tile(s) to the workspace, the reducing pass keeps the sum, and the selection reads the
+// scores of its groups from it.  Scores are the MFMA-order fp32 sums (chunk-ordered when split).
+constexpr int64_t DENSE_MAX_ROWS = 16384;
+inline bool dense_plan(int64_t q, int64_t n, int64_t d) {
+#ifdef DLC_EXPERIMENT_NO_DENSE   // perf experiment build only (scripts/)
+    return false;
+#endif
+    return n <= DENSE_MAX_ROWS && !gemv_shape(q, d / BK);
+}
 
 // One workgroup per query gathers kg * 8 rows: with a handful of queries and long rows (1 query x
 // 75 000-d: 29 MB through one CU, 300 us) the re-score is spread over one workgroup per selected group.
@@ -991,10 +1106,11 @@ WsLayout ws_layout(int64_t q, int64_t n, int64_t d, int k) {
     w.gmax = o; o += dlc::align_up((size_t)q * w.ldg * 4, 256);
     w.tmax = o; o += dlc::align_up((size_t)q * w.ldt * 4, 256);
     w.sp = split_plan(q, n, d);
+    w.dense = dense_plan(q, n, d);
     w.ldp = ntiles * BM;
     w.part = o;
-    if (w.sp.nsplit > 1) o += dlc::align_up((size_t)w.sp.nsplit * q * w.ldp * 4, 256);
-    w.rparts = rescore_parts(q, d, w.kg, k);
+    if (w.sp.nsplit > 1 || w.dense) o += dlc::align_up((size_t)w.sp.nsplit * q * w.ldp * 4, 256);
+    w.rparts = w.dense ? 1 : rescore_parts(q, d, w.kg, k);
     w.rs_ids = w.rs_max = w.rs_scores = w.rs_idx = o;
     if (w.rparts > 1) {
         w.rs_ids = o; o += dlc::align_up((size_t)q * w.kg * 4, 256);
@@ -1017,6 +1133,11 @@ int check_operands(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ld
         return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: row strides must be >= d and multiples of 8 elements");
     if (((uintptr_t)Q & 15) || ((uintptr_t)DB & 15))
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine match: operands must be 16-byte aligned");
+    // the score GEMM addresses a lane's 16 bytes as a 32-bit offset from its tile's first row:
+    // 255 rows * stride + 128 bytes must stay below 2^32
+    if (ldq * 2 * 255 + 128 > 0xffffffffll || lddb * 2 * 255 + 128 > 0xffffffffll)
+        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: row stride %lld elements too large (255 rows must span < 4 GiB)",
+                         (long long)(ldq > lddb ? ldq : lddb));
     if (q > 0x7fffff00ll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: q too large");
     if (n > 0x7ffffff0ll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "cosine match: more than 2^31 rows in one shard");
     return DLC_OK;
@@ -1032,14 +1153,26 @@ int launch_gemm(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
                                      : launch_gemm_masked<Tag, MODE, false>(ctx, a, st);
 }
 
+template <typename Tag> constexpr int tag_id() { return __is_same(Tag, dlc_bf16_tag) ? 0 : 1; }
+
+// hipFuncSetAttribute acts on the CURRENT device (the context's, under its DeviceGuard), so the "already
+// raised" flag lives in the context -- one context per device; a process-wide static would leave the
+// second GPU of a process without the 128 KiB limit.
+template <typename K>
+int raise_lds_limit(dlc_ctx* ctx, K kern, int bit, int bytes) {
+    const unsigned long long m = 1ull << bit;
+    if (!(ctx->func_attr_set & m)) {
+        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        ctx->func_attr_set |= m;
+    }
+    return DLC_OK;
+}
+
 template <typename Tag, int MODE, bool MASKQ>
 int launch_gemm_masked(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
     auto kern = score_gemm_kernel<Tag, MODE, MASKQ>;
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    int rc_attr = raise_lds_limit(ctx, kern, DLC_ATTR_GEMM_BASE + tag_id<Tag>() * 8 + MODE * 2 + (MASKQ ? 1 : 0), LDS_BYTES);
+    if (rc_attr != DLC_OK) return rc_attr;
     GemmArgs b = a;
     b.ntiles = dlc::cdiv(a.n, BM);
     b.nqb = (int)dlc::cdiv(a.q, BNQ);
@@ -1054,21 +1187,14 @@ int launch_gemm_masked(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
     return DLC_OK;
 }
 
-// Few queries: the bandwidth kernel (needs the stored queries in LDS: q <= 4 and q * d * 2 bytes <= 64 KiB).
-inline bool use_gemv(const GemmArgs& a) {
-    const int qb = a.q <= 1 ? 1 : (a.q <= 2 ? 2 : 4);
-    return a.q <= GEMV_MAX_Q && (long long)qb * a.nk * 128 <= GEMV_MAX_LDS;
-}
+inline bool use_gemv(const GemmArgs& a) { return gemv_shape(a.q, a.nk); }
 
 template <typename Tag, int QB>
 int launch_gemv_qb(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
     auto kern = score_gemv_kernel<Tag, QB>;
     const int lds = QB * a.nk * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMV_MAX_LDS));
-        attr_set = true;
-    }
+    int rc_attr = raise_lds_limit(ctx, kern, DLC_ATTR_GEMV_BASE + tag_id<Tag>() * 3 + (QB == 1 ? 0 : (QB == 2 ? 1 : 2)), GEMV_MAX_LDS);
+    if (rc_attr != DLC_OK) return rc_attr;
     hipLaunchKernelGGL(kern, dim3((unsigned)a.nh), dim3(256), lds, st, a);
     DLC_LAUNCH_CHECK(ctx, "score_gemv_kernel");
     return DLC_OK;
@@ -1083,10 +1209,13 @@ int launch_gemv(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
 
 // The score pass of a match: one kernel, or split-K partials + the reducing second pass.
 // dense: write S instead of the group maxima.
+// keep: the top-k call's small-database plan -- score tile(s) to the workspace even when K is not split,
+// group maxima from the reducing pass, the summed scores kept in chunk 0.
 template <typename Tag>
-int launch_scores(dlc_ctx* ctx, const GemmArgs& a, bool dense, hipStream_t st) {
-    if (!dense && use_gemv(a)) return launch_gemv<Tag>(ctx, a, st);
-    if (a.nsplit <= 1) return dense ? launch_gemm<Tag, GEMM_DENSE>(ctx, a, st) : launch_gemm<Tag, GEMM_GROUPS>(ctx, a, st);
+int launch_scores(dlc_ctx* ctx, const GemmArgs& a, bool dense, hipStream_t st, bool keep = false) {
+    if (!dense && !keep && use_gemv(a)) return launch_gemv<Tag>(ctx, a, st);
+    if (a.nsplit <= 1 && !keep)
+        return dense ? launch_gemm<Tag, GEMM_DENSE>(ctx, a, st) : launch_gemm<Tag, GEMM_GROUPS>(ctx, a, st);
     int rc = launch_gemm<Tag, GEMM_PARTIAL>(ctx, a, st);
     if (rc != DLC_OK) return rc;
     if (dense) {
@@ -1097,7 +1226,7 @@ int launch_scores(dlc_ctx* ctx, const GemmArgs& a, bool dense, hipStream_t st) {
         const long long groups = dlc::cdiv(a.n, BM) * (BM / GROUP);    // whole tiles: every lane of a half-tile reduction is live
         dim3 grid((unsigned)a.q, (unsigned)dlc::cdiv(groups, (long long)256));
         hipLaunchKernelGGL(splitk_groups_kernel, grid, dim3(256), 0, st, a.P, a.ldp, a.q, a.nsplit, a.gmax, a.ldg, a.ng,
-                           a.tmax, a.ldt, a.nh);
+                           a.tmax, a.ldt, a.nh, keep ? 1 : 0);
         DLC_LAUNCH_CHECK(ctx, "splitk_groups_kernel");
     }
     return DLC_OK;
@@ -1146,7 +1275,8 @@ int run_score(dlc_ctx* ctx, int dtype, MatchCall& mc, hipStream_t st) {
 #endif
     const int slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[slot], st));
-    int rc = (dtype == DLC_BF16) ? launch_scores<dlc_bf16_tag>(ctx, mc.a, false, st) : launch_scores<dlc_f16_tag>(ctx, mc.a, false, st);
+    int rc = (dtype == DLC_BF16) ? launch_scores<dlc_bf16_tag>(ctx, mc.a, false, st, mc.w.dense)
+                                 : launch_scores<dlc_f16_tag>(ctx, mc.a, false, st, mc.w.dense);
     if (rc != DLC_OK) return rc;
     if (ctx->profiling) {
         DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[slot], st));
@@ -1171,6 +1301,13 @@ int launch_finish(dlc_ctx* ctx, const MatchCall& mc, int k, int64_t n, int64_t d
                        out_scores, (long long*)out_idx, x);
     DLC_LAUNCH_CHECK(ctx, "finish_topk_kernel");
     return DLC_OK;
+}
+
+// FinishExtra of a fused selection: under the small-database plan the scores are read from the workspace
+inline FinishExtra fused_extra(const MatchCall& mc) {
+    FinishExtra x{};
+    if (mc.w.dense) { x.dense_S = mc.a.P; x.ld_s = mc.a.ldp; }
+    return x;
 }
 
 template <int MODE>
@@ -1199,7 +1336,7 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
     rc = run_score(ctx, dtype, mc, (hipStream_t)stream);
     if (rc != DLC_OK) return rc;
     if (mc.w.rparts <= 1)
-        return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, 0, FinishExtra{}, (hipStream_t)stream);
+        return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, 0, fused_extra(mc), (hipStream_t)stream);
     // few queries, long rows: group selection, re-score with one workgroup per selected group, merge
     char* ws = (char*)workspace;
     FinishExtra x{};
@@ -1237,7 +1374,7 @@ extern "C" int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, in
     if (rc != DLC_OK) return rc;
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, flags, FinishExtra{}, (hipStream_t)stream);
+    return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, flags, fused_extra(mc), (hipStream_t)stream);
 }
 
 extern "C" int dlc_cosine_groups_per_query(int k) { return (k < 1 || k > DLC_MAX_K) ? 0 : k + SLACK; }
@@ -1347,15 +1484,33 @@ extern "C" int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* sr
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)n), block(256);
+    if (src_dtype != DLC_F32 && src_dtype != DLC_F64)
+        return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "l2_normalize_rows: dtype pair %d -> %d", src_dtype, dst_dtype);
+    if (dst_dtype != DLC_BF16 && dst_dtype != DLC_F16)
+        return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "l2_normalize_rows: dtype pair %d -> %d", src_dtype, dst_dtype);
     unsigned short* o = (unsigned short*)dst;
+    // one-pass register form: rows of <= 64 (a wave per row) or <= 256 threads x 16 vectors of 16 bytes
+    // whose vectors can be loaded / stored aligned; anything else takes the multi-pass kernel
+    const int vw = src_dtype == DLC_F32 ? 4 : 2;
+    const bool aligned = ((uintptr_t)src & 15) == 0 && (lds % vw) == 0 && ((uintptr_t)dst & 7) == 0;
+    const int64_t cap_wave = 64 * 16 * vw, cap_block = 256 * 16 * vw;
+#define DLC_NORM_REGS(SRC, TAG, TPR)                                                                              \
+    hipLaunchKernelGGL((l2_normalize_regs_kernel<SRC, TAG, TPR, 16>), dim3((unsigned)(TPR == 64 ? dlc::cdiv(n, 4) : n)), \
+                       dim3(256), 0, st, (const SRC*)src, (long long)lds, (long long)n, (int)d, center, o, (long long)ldd)
 #define DLC_NORM(SRC, TAG) \
-    hipLaunchKernelGGL((l2_normalize_kernel<SRC, TAG>), grid, block, 0, st, (const SRC*)src, (long long)lds, (int)d, center, o, (long long)ldd)
-    if (src_dtype == DLC_F32 && dst_dtype == DLC_BF16) DLC_NORM(float, dlc_bf16_tag);
-    else if (src_dtype == DLC_F32 && dst_dtype == DLC_F16) DLC_NORM(float, dlc_f16_tag);
-    else if (src_dtype == DLC_F64 && dst_dtype == DLC_BF16) DLC_NORM(double, dlc_bf16_tag);
-    else if (src_dtype == DLC_F64 && dst_dtype == DLC_F16) DLC_NORM(double, dlc_f16_tag);
-    else return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "l2_normalize_rows: dtype pair %d -> %d", src_dtype, dst_dtype);
+    hipLaunchKernelGGL((l2_normalize_kernel<SRC, TAG>), dim3((unsigned)n), dim3(256), 0, st, (const SRC*)src, (long long)lds, (int)d, center, o, (long long)ldd)
+#define DLC_NORM_PICK(SRC, TAG)                                                   \
+    do {                                                                          \
+        if (aligned && ldd <= cap_wave) DLC_NORM_REGS(SRC, TAG, 64);              \
+        else if (aligned && ldd <= cap_block) DLC_NORM_REGS(SRC, TAG, 256);       \
+        else DLC_NORM(SRC, TAG);                                                  \
+    } while (0)
+    if (src_dtype == DLC_F32 && dst_dtype == DLC_BF16) DLC_NORM_PICK(float, dlc_bf16_tag);
+    else if (src_dtype == DLC_F32 && dst_dtype == DLC_F16) DLC_NORM_PICK(float, dlc_f16_tag);
+    else if (src_dtype == DLC_F64 && dst_dtype == DLC_BF16) DLC_NORM_PICK(double, dlc_bf16_tag);
+    else DLC_NORM_PICK(double, dlc_f16_tag);
+#undef DLC_NORM_PICK
+#undef DLC_NORM_REGS
 #undef DLC_NORM
     DLC_LAUNCH_CHECK(ctx, "l2_normalize_kernel");
     return DLC_OK;

@@ -17,6 +17,15 @@ struct dlc_ctx {
     hipEvent_t ev_stop[DLC_PROFILE_RING];
     void* scratch;                              // caller-owned split-K scratch (dlc_set_scratch), may be null
     size_t scratch_bytes;
+    // hipFuncSetAttribute is per DEVICE and a context is bound to one device: which kernels already
+    // have their dynamic-LDS limit raised on this context's device (bit = DLC_ATTR_* id)
+    unsigned long long func_attr_set;
+};
+
+// ids of the kernels that need hipFuncAttributeMaxDynamicSharedMemorySize (bits of dlc_ctx::func_attr_set)
+enum {
+    DLC_ATTR_GEMM_BASE = 0,      // + tag (0 bf16, 1 f16) * 8 + mode (0..3) * 2 + maskq   -> bits 0..15
+    DLC_ATTR_GEMV_BASE = 16,     // + tag * 3 + {QB 1,2,4 -> 0,1,2}                        -> bits 16..21
 };
 
 namespace dlc {

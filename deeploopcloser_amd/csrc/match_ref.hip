@@ -87,15 +87,55 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __re
 // Column mean of desc viewed as [rows, H], summed row by row in order (what
 // np.average(axis=0) does on a C-contiguous array, SimilarityCalculator.py:20-23),
 // then the distinctive score exp(-(avg-mu)^2 / (2 sigma^2)) (:25-27).
+//
+// The row-ordered fp64 add chain of a column IS the specification (bit parity with NumPy), the
+// serial LOAD chain is not: a workgroup owns DS_COLS = 16 columns (one 128-byte segment of every
+// row) and all of its 256 threads fetch -- 16 lane groups x DS_U rows each = 256 rows = 32 KiB in
+// flight per workgroup, 157 workgroups at H = 2500 -- while the first 16 lanes add the previous
+// batch out of LDS in row order.  One barrier per batch (double-buffered LDS).  HBM-bound
+// (rows*H*8 bytes read once) down to the latency of the add chain itself (rows x one v_add_f64).
+constexpr int DS_COLS = 16;               // columns per workgroup
+constexpr int DS_U = 16;                  // rows per thread and batch
+constexpr int DS_ROWS = 16 * DS_U;        // rows per batch
 __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __restrict__ desc, long long rows, int H,
                                                                 double mu, double sigma, double* __restrict__ score) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= H) return;
+    __shared__ double buf[2][DS_ROWS][DS_COLS];
+    const int tid = threadIdx.x, c = tid & 15, g = tid >> 4;
+    const int col = blockIdx.x * DS_COLS + c;
+    const bool col_ok = col < H;
+    const double* src = desc + (col_ok ? col : 0);
+    double v[DS_U];
+    auto fetch = [&](long long r0) {
+#pragma unroll
+        for (int u = 0; u < DS_U; ++u) {
+            const long long r = r0 + u * 16 + g;
+            v[u] = (col_ok && r < rows) ? src[r * H] : 0.0;
+        }
+    };
     double s = 0.0;
-    for (long long r = 0; r < rows; ++r) s += desc[r * H + c];
-    const double avg = s / (double)rows;
-    const double e = -((avg - mu) * (avg - mu)) / (2.0 * sigma * sigma);
-    score[c] = exp(e);
+    fetch(0);
+    int b = 0;
+    for (long long r0 = 0; r0 < rows; r0 += DS_ROWS, b ^= 1) {
+#pragma unroll
+        for (int u = 0; u < DS_U; ++u) buf[b][u * 16 + g][c] = v[u];
+        __syncthreads();
+        if (r0 + DS_ROWS < rows) fetch(r0 + DS_ROWS);          // in flight while the batch is added
+        if (tid < DS_COLS) {
+            const long long left = rows - r0;
+            const int m = left < DS_ROWS ? (int)left : DS_ROWS;
+            if (m == DS_ROWS) {
+#pragma unroll 32
+                for (int r = 0; r < DS_ROWS; ++r) s += buf[b][r][c];
+            } else {
+                for (int r = 0; r < m; ++r) s += buf[b][r][c];
+            }
+        }
+    }
+    if (tid < DS_COLS && col_ok) {
+        const double avg = s / (double)rows;
+        const double e = -((avg - mu) * (avg - mu)) / (2.0 * sigma * sigma);
+        score[col] = exp(e);
+    }
 }
 
 // Per patch row: squared norm and p = dot(score, row).  One wave per row.
@@ -227,7 +267,7 @@ extern "C" int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, i
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "distinctive_score: bad argument");
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    hipLaunchKernelGGL(distinctive_score_kernel, dim3((unsigned)dlc::cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(distinctive_score_kernel, dim3((unsigned)dlc::cdiv(H, DS_COLS)), dim3(256), 0, (hipStream_t)stream,
                        dataset, (long long)rows, (int)H, mu, sigma, score);
     DLC_LAUNCH_CHECK(ctx, "distinctive_score_kernel");
     return DLC_OK;

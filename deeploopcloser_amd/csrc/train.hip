@@ -68,9 +68,11 @@ __global__ __launch_bounds__(256) void xent_grad_kernel(const double* __restrict
     if (threadIdx.x == 0) atomicAdd(&acc[0], cd * inv_rows);
 }
 
-// n_t = || H_t - H_{t+1} ||_F over a frame's P x N block (SDAV.py:176-183); also cs (:174)
+// n_t = || H_t - H_{t+1} ||_F over a frame's P x N block (SDAV.py:176-183); also cs (:174):
+// sum |h - s| / cs_den, where cs_den is the number of entries reduce_mean sees after the axis-1
+// norm -- batch*N at layer 0 (h is 3-D [B,P,N] there: axis 1 = patches), batch*P afterwards.
 __global__ __launch_bounds__(256) void frame_norm_kernel(const double* __restrict__ h, int batch, long long frame_elems,
-                                                         double sparse_level, long long rows, double* __restrict__ nrm,
+                                                         double sparse_level, double cs_den, double* __restrict__ nrm,
                                                          double* __restrict__ acc) {
     __shared__ double red[4];
     const int t = blockIdx.x;                                   // 0 .. batch-1
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void frame_norm_kernel(const double* __restric
     s2 = block_sum(s2, red);
     l1 = block_sum(l1, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&acc[1], l1 / (double)rows);
+        atomicAdd(&acc[1], l1 / cs_den);
         if (t + 1 < batch) {
             const double n = sqrt(s2);
             nrm[t] = n;
@@ -93,14 +95,14 @@ __global__ __launch_bounds__(256) void frame_norm_kernel(const double* __restric
     }
 }
 
-// dh += sparse_penalty*sign(h - s)/rows + consecutive term;  dz1 = dh * h(1-h)
+// dh += sparse_penalty*sign(h - s)/cs_den + consecutive term;  dz1 = dh * h(1-h)
 __global__ __launch_bounds__(256) void hidden_grad_kernel(const double* __restrict__ h, const double* __restrict__ dh_in,
                                                           const double* __restrict__ nrm, int batch,
-                                                          long long frame_elems, long long rows, double sparse_level,
+                                                          long long frame_elems, double cs_den, double sparse_level,
                                                           double sparse_penalty, double consecutive_penalty,
                                                           double* __restrict__ dz1) {
     const long long total = (long long)batch * frame_elems;
-    const double ccs = consecutive_penalty / (double)(batch - 1), sps = sparse_penalty / (double)rows;
+    const double ccs = consecutive_penalty / (double)(batch - 1), sps = sparse_penalty / cs_den;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long f = e / frame_elems;
         const double hv = h[e];
@@ -260,11 +262,13 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
     DLC_HIP_CHECK(ctx, hipMemsetAsync(P(w.acc), 0, 32, st));
     hipLaunchKernelGGL(xent_grad_kernel, dim3((unsigned)rows), dim3(256), 0, st, P(w.y), labels, rows, (int)K, P(w.dz2),
                        layer > 0 ? P(w.dlab) : (double*)nullptr, P(w.acc));
+    // tf.norm(h - s, axis=1, ord=1) + reduce_mean (SDAV.py:174): h is [B,P,N] at layer 0, [B*P,N] afterwards
+    const double cs_den = layer == 0 ? (double)batch * (double)N : (double)rows;
     hipLaunchKernelGGL(frame_norm_kernel, dim3((unsigned)batch), dim3(256), 0, st, h, (int)batch, (long long)patches * N,
-                       sparse_level, rows, P(w.nrm), P(w.acc));
+                       sparse_level, cs_den, P(w.nrm), P(w.acc));
     GEMM(DLC_B_KN, DLC_ACT_NONE, rows, N, K, P(w.dz2), K, W[layer], N, nullptr, P(w.dh), N);      // dh = dz2 W
     hipLaunchKernelGGL(hidden_grad_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, h, P(w.dh), P(w.nrm), (int)batch,
-                       (long long)patches * N, rows, sparse_level, sparse_penalty, consecutive_penalty, P(w.dz1a));
+                       (long long)patches * N, cs_den, sparse_level, sparse_penalty, consecutive_penalty, P(w.dz1a));
     // decoder use of the tied weight: gw2 = dz2^T h ; b_dec gradient
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0, st,
                        P(w.dz2), rows, K, P(w.tr));

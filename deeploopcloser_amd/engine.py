@@ -95,11 +95,22 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def workspace(self, key, nbytes):
+        """Named scratch tensor of at least nbytes, one per (name, current stream): calls on different
+        streams must not share a workspace (a match keeps its group maxima there between its kernels)."""
         nbytes = max(int(nbytes), 256)
+        key = (key, torch.cuda.current_stream(self.device).cuda_stream)
         t = self._ws.get(key)
         if t is None or t.numel() < nbytes:
             t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws[key] = t
+        return t
+
+    def _check_out(self, name, t, shape, dtype):
+        """Caller-supplied buffers reach the kernels as raw pointers: refuse anything that is not exactly
+        the contiguous tensor the kernel will write."""
+        if not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != dtype or \
+                not t.is_contiguous() or t.device != self.device:
+            raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (name, dtype, tuple(shape), self.device))
         return t
 
     def to_device(self, x, dtype=None):
@@ -135,6 +146,10 @@ class Engine:
                 raise ValueError("gemm_bias_act: bias must be [N] of the operand dtype")
         if out is None:
             out = torch.empty((m, n), dtype=a.dtype, device=self.device)
+        elif not isinstance(out, torch.Tensor) or tuple(out.shape) != (m, n) or out.dtype != a.dtype or \
+                out.stride(1) != 1 or out.stride(0) < n or out.device != self.device:
+            raise ValueError("gemm_bias_act: out must be a [%d, %d] %s tensor with unit column stride on %s"
+                             % (m, n, a.dtype, self.device))
         self._check(self.lib.dlc_gemm_bias_act(self.ctx, _TORCH_TO_DLC[a.dtype], blayout, act, m, n, k, _ptr(a),
                                                 a.stride(0), _ptr(b), b.stride(0), _ptr(bias), _ptr(out),
                                                 out.stride(0), self._stream()))
@@ -345,7 +360,8 @@ class Engine:
             scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
             idx = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         else:
-            scores, idx = out
+            scores = self._check_out("out[0] (scores)", out[0], (nq, k), torch.float32)
+            idx = self._check_out("out[1] (idx)", out[1], (nq, k), torch.int64)
         self._check(self.lib.dlc_cosine_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
                                               db.stride(0), d, k, row_offset, _ptr(scores), _ptr(idx), _ptr(ws),
                                               ws.numel(), self._stream()))
@@ -360,6 +376,7 @@ class Engine:
     def score_groups(self, q, db, k, ws, stream=None):
         """Stage 1 of match_topk (the MFMA score GEMM) into the caller's workspace tensor."""
         self._check_stored(q, db)
+        self._check_ws(ws)
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         self._check(self.lib.dlc_cosine_score_groups(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
                                                       _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, _ptr(ws),
@@ -367,11 +384,19 @@ class Engine:
 
     def select_topk(self, q, db, k, ws, scores, idx, row_offset=0, coop=False, stream=None):
         """Stage 2 of match_topk (selection, exact re-score, final top-k) from the workspace."""
+        self._check_stored(q, db)
+        self._check_ws(ws)
+        self._check_out("scores", scores, (q.shape[0], k), torch.float32)
+        self._check_out("idx", idx, (q.shape[0], k), torch.int64)
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         self._check(self.lib.dlc_cosine_select_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
                                                      _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, row_offset,
                                                      _ptr(scores), _ptr(idx), _ptr(ws), ws.numel(),
                                                      L.DLC_SELECT_COOP if coop else 0, st))
+
+    def _check_ws(self, ws):
+        if not isinstance(ws, torch.Tensor) or ws.dtype != torch.uint8 or not ws.is_contiguous() or ws.device != self.device:
+            raise ValueError("workspace must be a contiguous uint8 tensor on %s" % (self.device,))
 
     def groups_per_query(self, k):
         kg = self.lib.dlc_cosine_groups_per_query(k)
@@ -381,6 +406,11 @@ class Engine:
 
     def select_groups(self, q, db, k, ws, grp_ids, grp_max, coop=False, stream=None):
         """Stage 2a: the kg best groups of every query (shard-local ids + their maxima)."""
+        self._check_stored(q, db)
+        self._check_ws(ws)
+        kg = self.groups_per_query(k)
+        self._check_out("grp_ids", grp_ids, (q.shape[0], kg), torch.int32)
+        self._check_out("grp_max", grp_max, (q.shape[0], kg), torch.float32)
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         self._check(self.lib.dlc_cosine_select_groups(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
                                                        _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, _ptr(ws),
@@ -390,6 +420,14 @@ class Engine:
     def rescore_topk(self, q, db, k, grp_ids, grp_max, scores, idx, all_max=None, row_offset=0, coop=False, stream=None):
         """Stage 2b: exact re-score of the listed groups (filtered against all shards' maxima
         when all_max [parts, Q, kg] is given) and the shard's top-k."""
+        self._check_stored(q, db)
+        kg = self.groups_per_query(k)
+        self._check_out("grp_ids", grp_ids, (q.shape[0], kg), torch.int32)
+        self._check_out("grp_max", grp_max, (q.shape[0], kg), torch.float32)
+        self._check_out("scores", scores, (q.shape[0], k), torch.float32)
+        self._check_out("idx", idx, (q.shape[0], k), torch.int64)
+        if all_max is not None:
+            self._check_out("all_max", all_max, (all_max.shape[0], q.shape[0], kg), torch.float32)
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         parts = 0 if all_max is None else all_max.shape[0]
         self._check(self.lib.dlc_cosine_rescore_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
@@ -403,8 +441,10 @@ class Engine:
         parts = gathered.shape[0]
         if (nq * k) % 2:
             raise ValueError("packed merge needs an even nq*k")
+        self._check_out("gathered", gathered, (parts, nq * k * 12), torch.uint8)
         base = gathered.data_ptr()
-        o_s, o_i = out
+        o_s = self._check_out("out[0] (scores)", out[0], (nq, k), torch.float32)
+        o_i = self._check_out("out[1] (idx)", out[1], (nq, k), torch.int64)
         self._check(self.lib.dlc_topk_merge_strided(self.ctx, C.c_void_p(base + nq * k * 8), nq * k * 3,
                                                      C.c_void_p(base), nq * k * 3 // 2, parts, nq, k, _ptr(o_s),
                                                      _ptr(o_i), self._stream()))
@@ -413,12 +453,15 @@ class Engine:
     def topk_merge(self, scores, idx, out=None):
         """Merge [parts, Q, k] per-shard results into the global [Q, k]."""
         scores, idx = scores.contiguous(), idx.contiguous()
+        if scores.dim() != 3 or idx.shape != scores.shape or scores.dtype != torch.float32 or idx.dtype != torch.int64:
+            raise ValueError("topk_merge: scores float32 / idx int64 of one shape [parts, Q, k]")
         parts, nq, k = scores.shape
         if out is None:
             o_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
             o_i = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         else:
-            o_s, o_i = out
+            o_s = self._check_out("out[0] (scores)", out[0], (nq, k), torch.float32)
+            o_i = self._check_out("out[1] (idx)", out[1], (nq, k), torch.int64)
         self._check(self.lib.dlc_topk_merge(self.ctx, _ptr(scores), _ptr(idx), parts, nq, k, _ptr(o_s), _ptr(o_i),
                                              self._stream()))
         return o_s, o_i

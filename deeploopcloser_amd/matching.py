@@ -182,7 +182,7 @@ class MatchPipeline:
             s = {"nq": nq, "n": len(self.db), "ws": torch.empty(need, dtype=torch.uint8, device=dev),
                  "scores": torch.empty((nq, self.k), dtype=torch.float32, device=dev),
                  "idx": torch.empty((nq, self.k), dtype=torch.int64, device=dev),
-                 "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "q": None}
+                 "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "q": None, "rows": None}
             if self.world > 1:
                 kg = self.engine.groups_per_query(self.k)
                 nb = nq * self.k * 12                      # packed result: int64 idx [nq,k] | float32 scores [nq,k]
@@ -208,20 +208,23 @@ class MatchPipeline:
         if s["busy"]:
             main.wait_event(s["done"])          # the workspace / outputs of this slot are free again
         s["q"] = q                              # keep the stored queries alive until the batch is done
-        eng.score_groups(q, self.db.rows, self.k, s["ws"], stream=main)
+        # ... and the database rows: append() may replace the store (reserve) while this batch's
+        # selection / re-score still gathers rows from the old one on the second stream
+        rows = s["rows"] = self.db.rows
+        eng.score_groups(q, rows, self.k, s["ws"], stream=main)
         s["scored"].record(main)
         self.s_select.wait_event(s["scored"])
         with torch.cuda.stream(self.s_select):
             if self.world == 1:
-                eng.select_topk(q, self.db.rows, self.k, s["ws"], s["scores"], s["idx"],
+                eng.select_topk(q, rows, self.k, s["ws"], s["scores"], s["idx"],
                                 row_offset=self.db.row_offset, coop=True, stream=self.s_select)
             else:
                 # exchange the selected groups' maxima first, so that every shard re-scores only the
                 # groups that can be among the best of the WHOLE database (~kg/world per query)
-                eng.select_groups(q, self.db.rows, self.k, s["ws"], s["grp_ids"], s["grp_max"], coop=True,
+                eng.select_groups(q, rows, self.k, s["ws"], s["grp_ids"], s["grp_max"], coop=True,
                                   stream=self.s_select)
                 dist.all_gather_into_tensor(s["g_max"].view(-1, s["g_max"].shape[-1]), s["grp_max"], group=self.group)
-                eng.rescore_topk(q, self.db.rows, self.k, s["grp_ids"], s["grp_max"], s["scores"], s["idx"],
+                eng.rescore_topk(q, rows, self.k, s["grp_ids"], s["grp_max"], s["scores"], s["idx"],
                                  all_max=s["g_max"], row_offset=self.db.row_offset, coop=True, stream=self.s_select)
                 dist.all_gather_into_tensor(s["g_pack"].view(-1), s["pack"], group=self.group)
                 eng.topk_merge_packed(s["g_pack"], q.shape[0], self.k, out=(s["m_scores"], s["m_idx"]))

@@ -39,6 +39,28 @@ def init_weights(seed, scale="fan_in"):
     return ws, bs
 
 
+def constant_initializer_fill(value, shape):
+    """tf.constant_initializer(value) into a variable of `shape` (cnn_vtl.py:137-149, TF 1.x):
+    C-order values, the last one repeated when there are fewer than the shape holds; more is an
+    error.  This is how bvlc_alexnet.npy's grouped kernels (conv2 [5,5,48,256], conv4 [3,3,192,384],
+    conv5 [3,3,192,256]) land in the reference's ungrouped conv variables (:47-93)."""
+    flat = np.asarray(value, dtype=np.float64).ravel()
+    total = int(np.prod(shape))
+    if flat.size > total:
+        raise ValueError("Too many elements provided")
+    return np.concatenate([flat, np.full(total - flat.size, flat[-1])]).reshape(shape)
+
+
+def weights_from_alexnet_dict(layer_params):
+    """(weights, biases) of conv1..conv5 from the {layer: [W, b]} dict (fc6-8 skipped, :141-148)."""
+    ws, bs = [], []
+    for name, kh, kw, cin, cout, _, _, _ in LAYERS:
+        entry = layer_params[name] if name in layer_params else layer_params[name.encode()]
+        ws.append(constant_initializer_fill(entry[0], (kh, kw, cin, cout)))
+        bs.append(constant_initializer_fill(entry[1], (cout,)))
+    return ws, bs
+
+
 def _out_size(n, k, s, padding):
     if padding == "VALID":
         return (n - k) // s + 1, 0

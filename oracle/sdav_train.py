@@ -15,7 +15,13 @@ Quirks of the reference that ARE the spec and are reproduced:
     (x_l is defined after .corrupt(), :135,142,149,156);
   * the mask is [P, K], shared by all frames of the batch;
   * cc slices hidden_units[0] columns of `frames` and hidden_units[l] of `frames_next` (:178-181;
-    equal widths in the shipped configuration, required equal here).
+    equal widths in the shipped configuration, required equal here);
+  * the sparsity term cs = reduce_mean(tf.norm(h - s, axis=1, ord=1)) (:174) sees a 3-D h
+    [B, P, N] at layer 0 (the 3-D x 2-D matmul of TensorflowWrapper.py:57-67 re-batches its result,
+    SDAV.py:129-131) and a 2-D h [B*P, N] at layers >= 1 (flat_batch, :135-157): axis 1 is the
+    PATCH axis at layer 0 (sum over P, mean over B*N entries) and the UNIT axis afterwards (sum
+    over N, mean over B*P rows).  Same numerator, denominators B*N vs B*P: layer 0's cs and its
+    gradient are P/N (30/2500) of what the 2-D form would give.
 A batch of one frame makes cc the mean of an empty tensor (NaN in TensorFlow); this
 restatement, like the MI355X build, requires batch >= 2.
 """
@@ -33,13 +39,23 @@ def forward_layer(x_in, mask, w, b_enc, b_dec):
     return xt, h, y
 
 
-def layer_loss(labels, h, y, batch, patches, sparse_level=0.05, sparse_penalty=1.0, consecutive_penalty=0.2):
-    """_define_loss_for_layer (SDAV.py:171-186): (loss, cd, cs, cc)."""
+def sparsity_denominator(layer, batch, patches, units):
+    """Number of entries reduce_mean averages over in cs (SDAV.py:174): h is [B,P,N] at layer 0
+    (norm over axis 1 = patches -> [B,N]) and [B*P,N] afterwards (norm over axis 1 = units -> [B*P])."""
+    return batch * units if layer == 0 else batch * patches
+
+
+def layer_loss(labels, h, y, batch, patches, sparse_level=0.05, sparse_penalty=1.0, consecutive_penalty=0.2, layer=1):
+    """_define_loss_for_layer (SDAV.py:171-186): (loss, cd, cs, cc).  `layer` selects the shape h has
+    in the reference's graph (3-D at layer 0, 2-D afterwards), which changes the cs normalisation."""
     ymax = y.max(axis=1, keepdims=True)
     logsm = y - ymax - np.log(np.exp(y - ymax).sum(axis=1, keepdims=True))
     cd = np.mean(-(labels * logsm).sum(axis=1))
-    cs = np.mean(np.abs(h - sparse_level).sum(axis=1))
     hb = h.reshape(batch, patches, -1)
+    if layer == 0:
+        cs = np.mean(np.abs(hb - sparse_level).sum(axis=1))       # [B,N]: summed over the patch axis
+    else:
+        cs = np.mean(np.abs(h - sparse_level).sum(axis=1))        # [B*P]: summed over the unit axis
     diff = hb[:-1] - hb[1:]
     cc = np.mean(np.sqrt((diff ** 2).sum(axis=(1, 2))))
     return cd + sparse_penalty * cs + consecutive_penalty * cc, cd, cs, cc
@@ -65,7 +81,8 @@ def loss_and_grads(layer, x, masks, ws, b_encs, b_dec, sparse_level=0.05, sparse
     w, xt, h = ws[layer], xts[layer], hs[layer]
     y = sigmoid(h @ w.T + b_dec)
     labels = x.reshape(rows, -1) if layer == 0 else xt            # :131 vs :138-159
-    loss, cd, cs, cc = layer_loss(labels, h, y, batch, patches, sparse_level, sparse_penalty, consecutive_penalty)
+    loss, cd, cs, cc = layer_loss(labels, h, y, batch, patches, sparse_level, sparse_penalty, consecutive_penalty,
+                                  layer=layer)
 
     # ---- backward
     ymax = y.max(axis=1, keepdims=True)
@@ -78,7 +95,7 @@ def loss_and_grads(layer, x, masks, ws, b_encs, b_dec, sparse_level=0.05, sparse
     g_w = d_z2.T @ h                                              # decoder use of the tied weight
     g_bdec = d_z2.sum(axis=0)
     d_h = d_z2 @ w
-    d_h += sparse_penalty * np.sign(h - sparse_level) / rows
+    d_h += sparse_penalty * np.sign(h - sparse_level) / sparsity_denominator(layer, batch, patches, h.shape[1])
     hb = h.reshape(batch, patches, -1)
     diff = hb[:-1] - hb[1:]
     nrm = np.sqrt((diff ** 2).sum(axis=(1, 2)))

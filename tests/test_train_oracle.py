@@ -48,12 +48,17 @@ def test_analytic_gradients_match_finite_differences(layer):
 def test_loss_pieces_and_sgd_step():
     x, masks, ws, b_encs, b_dec = setup(0)
     xt, h, y = ot.forward_layer(x, masks[0], ws[0], b_encs[0], b_dec)
-    loss, cd, cs, cc = ot.layer_loss(x.reshape(12, 6), h, y, 3, 4)
+    loss, cd, cs, cc = ot.layer_loss(x.reshape(12, 6), h, y, 3, 4, layer=0)
     # softmax cross entropy with sigmoid outputs as logits and x as (unnormalised) labels (:172)
     lsm = y - np.log(np.exp(y).sum(1, keepdims=True))
     assert abs(cd - np.mean(-(x.reshape(12, 6) * lsm).sum(1))) < 1e-12
-    assert abs(cs - np.mean(np.abs(h - 0.05).sum(1))) < 1e-12
+    # layer 0: h is [B,P,N] in the reference's graph, tf.norm(axis=1) sums over the P patches (:174)
     hb = h.reshape(3, 4, -1)
+    assert abs(cs - np.mean(np.abs(hb - 0.05).sum(1))) < 1e-12
+    assert abs(cs - np.abs(h - 0.05).sum() / (3 * h.shape[1])) < 1e-12
+    # layers >= 1: h is [B*P,N], axis 1 is the unit axis
+    cs1 = ot.layer_loss(x.reshape(12, 6), h, y, 3, 4, layer=1)[2]
+    assert abs(cs1 - np.mean(np.abs(h - 0.05).sum(1))) < 1e-12 and abs(cs1 / cs - h.shape[1] / 4) < 1e-9
     assert abs(cc - np.mean([np.linalg.norm(hb[0] - hb[1]), np.linalg.norm(hb[1] - hb[2])])) < 1e-12
     b_decs = [b_dec] + [np.zeros(5), np.zeros(7)]
     l0, w1, be1, bd1 = ot.sgd_step(0, x, masks, ws, b_encs, b_decs, lr=0.1)
@@ -90,8 +95,9 @@ def test_analytic_gradients_match_torch_autograd(layer):
     y = torch.sigmoid(h @ tw[layer].T + tbd)                                 # tied decoder weights
     labels = torch.tensor(x).reshape(batch * patches, -1) if layer == 0 else xt
     cd = (-(labels * torch.log_softmax(y, dim=1)).sum(1)).mean()
-    cs = (h - 0.05).abs().sum(1).mean()
     hb = h.reshape(batch, patches, -1)
+    # tf.norm(h - s, axis=1, ord=1): h is 3-D [B,P,N] at layer 0 (axis 1 = patches), 2-D afterwards
+    cs = (hb - 0.05).abs().sum(1).mean() if layer == 0 else (h - 0.05).abs().sum(1).mean()
     cc = ((hb[:-1] - hb[1:]) ** 2).sum((1, 2)).sqrt().mean()
     tl = cd + 1.0 * cs + 0.2 * cc
     tl.backward()
