@@ -18,7 +18,13 @@ Rank 0 prints ONE JSON line (the driver's contract) carrying also
                   per launch / mean launch duration from HIP events recorded on
                   the launch stream inside the timed region;
   cpu_baseline -- the CPU oracle (oracle/cosine.py, a port: fp64 NumPy) timed
-                  on this host's cores on a bounded sample at N=1.
+                  on this host's cores on a bounded sample at N=1;
+  paths        -- (N=1 only, outside the timed region) the other rows of the hot path at
+                  BASELINE configs[1] / configs[2] size (1063 frames): SDAV.transform, the SDAV
+                  similarity matrix, the cosine matrix / top-20 over the flattened SDAV
+                  descriptors, CnnVtl.transform, the cnn_vtl distance matrix -- each with its own
+                  roofline (dominant-kernel time from HIP events on the launch stream) and
+                  cpu_baseline (the oracle on a bounded sample of the same input).
 """
 import argparse
 import json
@@ -37,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA peak
+MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 MFMA peak (v_mfma_f64_16x16x4_f64)
 
 
 def parse():
@@ -60,7 +67,21 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one stream, no overlap of a batch's selection / all-gather with the next batch's GEMM")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--no-paths", action="store_true", help="skip the `paths` entries (configs[1] / configs[2] rows)")
+    ap.add_argument("--path-frames", type=int, default=1063, help="frames of the `paths` entries (outdoor_kennedylong: 1063)")
     return ap.parse_args()
+
+
+def blas_threads():
+    """Threads of the BLAS pool NumPy's matmul runs on (what the fp64 oracles are timed with)."""
+    try:
+        from threadpoolctl import threadpool_info
+        n = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
+        if n:
+            return int(max(n))
+    except Exception:
+        pass
+    return int(os.cpu_count() or 1)
 
 
 def pmc_traffic(n, d, nq, dtype, world):
@@ -146,6 +167,208 @@ def synth_shard(eng, n_total, dim, lo, hi, dtype, planted_rows, chunk=32768):
     return rows, planted
 
 
+def _timed_path(eng, fn, reps=3):
+    """fn() on the current stream: (wall ms of the whole call from stream events, summed ms of its dense-GEMM
+    launches from the HIP events the library records around each of them, number of launches, result) of
+    the fastest of `reps` calls after one warm-up."""
+    fn()
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        eng.set_profiling(True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        k = eng.profile_gemm_ms(256)
+        eng.set_profiling(False)
+        cur = (e0.elapsed_time(e1), float(np.sum(k)) if k else None, len(k), r)
+        if best is None or cur[0] < best[0]:
+            best = cur
+    return best
+
+
+def _mfma_f64_roofline(flops, kernel_ms, launches, call_ms, kernel):
+    tf = flops / (kernel_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms,
+            "kernel_launches_timed": launches, "call_ms": call_ms, "algorithmic_flops_per_call": flops}
+
+
+def bench_paths(eng, n_frames):
+    """The rows of the hot path other than the headline match, at BASELINE configs[1] / configs[2] size, each
+    with the roofline of its dominant kernel and the CPU oracle timed on a bounded sample of the same input
+    (the reference's Python cannot travel to this box; oracle/ restates it, `kind: port`)."""
+    import deeploopcloser_amd as dlc
+    from oracle import sdav as osdav, similarity as osim, distance as odist, cnn_vtl as ocnn, cosine as ocos
+    N, P, K0, H = n_frames, 30, 1681, 2500
+    cores = blas_threads()
+    out = []
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(0)
+
+    # ---- E1/E2: SDAV.transform (SDAV.py:293-302), fp64 like the reference ----------------------------------
+    x = torch.rand((N, P, K0), generator=g, device=eng.device, dtype=torch.float64)
+    net = dlc.SDAV(seed=1)
+    call_ms, k_ms, k_n, h = _timed_path(eng, lambda: net.transform_tensor(x))
+    flops = 2.0 * P * N * (K0 * H + 4 * H * H)
+    ws, bs = net.get_weights()
+    nb = min(N, 64)
+    xs = x[:nb].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = osdav.transform(xs, ws, bs)
+    t_cpu = time.perf_counter() - t0
+    err = float(np.abs(h[:nb * P].cpu().numpy() - ref).max())
+    out.append({"path": "SDAV.transform", "reference": "src/sdav/network/SDAV.py:293-302", "frames": N, "dtype": "f64",
+                "value": N / (call_ms * 1e-3), "unit": "frames/s", "ms": call_ms,
+                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_bias_act_kernel<double> (5 layers, fused bias + sigmoid)"),
+                "cpu_baseline": {"value": nb / t_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
+                                 "sample": "oracle/sdav.py (fp64 NumPy) on the first %d of the %d frames, same weights: "
+                                           "%.1f s of CPU work" % (nb, N, t_cpu)},
+                "max_abs_err_vs_oracle": err})
+    del ws, bs, xs, ref
+
+    # ---- M1/M2: SDAV similarity matrix (SimilarityCalculator.py:12-49 + create_similarity_matrix.py:29-38) ----
+    desc = h.reshape(N, P, H)
+
+    def sim():
+        score = eng.distinctive_score(desc, 0.5, 0.2)
+        return eng.sdav_similarity_matrix(desc, score, 10.0, -10.0)
+    call_ms, k_ms, k_n, (mf, mi) = _timed_path(eng, sim, reps=2)
+    # Gram GEMMs as dlc_sdav_similarity_matrix launches them (match_ref.hip sim_ws): row chunks of <= 1 GiB,
+    # frames [i_lo, i_hi) against every later frame
+    cf = max(1, min(N, (1 << 30) // (N * P * 8 * P)))
+    flops, i_lo = 0.0, 0
+    while i_lo + 1 < N:
+        i_hi = min(i_lo + cf, N - 1)
+        flops += 2.0 * (i_hi - i_lo) * P * (N * P - (i_lo + 1) * P) * H
+        i_lo += cf
+    pairs = N * (N - 1) // 2
+    ns = min(N, 20)                                           # the reference-literal per-pair loop at datasets/test size
+    dsn = desc[:ns].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = osim.similarity_matrix_f64(dsn)
+    t_cpu = time.perf_counter() - t0
+    # literal form: the reference recomputes the dataset mean and the distinctive score for EVERY pair (:13-14)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        osim.similarity_score(dsn, dsn[0], dsn[1])
+    t_lit = (time.perf_counter() - t0) / 8
+    sub = eng.sdav_similarity_matrix(desc[:ns].contiguous(), eng.distinctive_score(desc[:ns].contiguous(), 0.5, 0.2), 10.0, -10.0)[0]
+    fin = np.isfinite(ref)
+    err = float(np.abs(sub.cpu().numpy()[fin] - ref[fin]).max() / max(1.0, np.abs(ref[fin]).max()))
+    out.append({"path": "SDAV similarity matrix", "reference": "src/sdav/similarity/SimilarityCalculator.py:12-49, "
+                "src/sdav/create_similarity_matrix.py:29-38", "frames": N, "dtype": "f64",
+                "value": pairs / (call_ms * 1e-3), "unit": "frame-pairs/s", "ms": call_ms,
+                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_bias_act_kernel<double> (Gram blocks desc . desc^T)"),
+                "cpu_baseline": {"value": (ns * (ns - 1) // 2) / t_cpu, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                                 "sample": "oracle/similarity.py all-vs-all loop on the first %d frames (%d pairs, mean / "
+                                           "distinctive score hoisted): %.2f s; the literal similarity_score (mean recomputed "
+                                           "per pair, SimilarityCalculator.py:13-14) takes %.1f ms per pair at N=%d"
+                                           % (ns, ns * (ns - 1) // 2, t_cpu, t_lit * 1e3, ns),
+                                 "literal_ms_per_pair": t_lit * 1e3},
+                "max_rel_err_vs_oracle": err})
+    del mf, mi, sub, ref, dsn
+
+    # ---- M5 at configs[1]: cosine matrix and top-20 over the flattened 75 000-d SDAV place descriptors --------
+    db = dlc.KeyframeDatabase(h.reshape(N, P * H), dtype="bf16", center=True)
+    rows = db.rows
+    d_st = rows.shape[1]
+    call_ms, _, _, sm = _timed_path(eng, lambda: eng.cosine_scores(rows, rows))
+    cflops = 2.0 * N * N * d_st
+    ns = min(N, 256)
+    rh = rows.float().cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    ref = ocos.scores(rh[:ns], rh)
+    t_cpu = time.perf_counter() - t0
+    err = float(np.abs(sm[:ns].cpu().numpy() - ref).max())
+    tf = cflops / (call_ms * 1e-3) / 1e12
+    out.append({"path": "cosine similarity matrix (flattened SDAV descriptors)", "reference": "BASELINE.json configs[1] "
+                "(no reference implementation: SURVEY 8a-M5)", "frames": N, "dim": d_st, "dtype": "bf16",
+                "value": N * N / (call_ms * 1e-3), "unit": "frame-pairs/s", "ms": call_ms,
+                "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "score_gemm_kernel (split-K partial "
+                             "tiles) + splitk_dense_kernel", "kernel_ms": call_ms, "call_ms": call_ms,
+                             "algorithmic_flops_per_call": cflops},
+                "cpu_baseline": {"value": ns * N / t_cpu, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                                 "sample": "oracle/cosine.py scores (fp64 NumPy matmul) of the first %d frames against all %d: "
+                                           "%.2f s" % (ns, N, t_cpu)},
+                "max_abs_err_vs_oracle": err})
+    call_ms, _, _, (ts, ti) = _timed_path(eng, lambda: eng.match_topk(rows, rows, 20))
+    t0 = time.perf_counter()
+    es, ei = ocos.topk_from_scores(ref, 20)
+    t_cpu += time.perf_counter() - t0
+    tf = cflops / (call_ms * 1e-3) / 1e12
+    out.append({"path": "cosine top-20 (flattened SDAV descriptors)", "reference": "BASELINE.json configs[1] / north_star "
+                "(no reference implementation)", "frames": N, "dim": d_st, "dtype": "bf16", "k": 20,
+                "value": N / (call_ms * 1e-3), "unit": "query-frames/s", "ms": call_ms,
+                "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "score_gemm_kernel (split-K) + "
+                             "splitk_groups_kernel + finish_topk_kernel (small-database plan)", "kernel_ms": call_ms,
+                             "call_ms": call_ms, "algorithmic_flops_per_call": cflops},
+                "cpu_baseline": {"value": ns / t_cpu, "unit": "query-frames/s", "cores": cores, "kind": "port",
+                                 "sample": "oracle/cosine.py scores + exact top-20 for the first %d frames: %.2f s" % (ns, t_cpu)},
+                "topk_index_agreement_vs_oracle": float((ti[:ns].cpu().numpy() == ei).mean())})
+    del db, rows, sm, rh, ref, ts, ti, h, desc, x
+
+    # ---- E8-E11: CnnVtl.transform (cnn_vtl.py:28-133) on 192x240 frames (configs[2]) -----------------------
+    frames = torch.randint(0, 256, (N, 192, 240, 3), generator=g, device=eng.device).to(torch.float64)
+    cnn = dlc.CnnVtl(input_shape=[N, 192, 240, 3], seed=3, mask_seed=4)
+    call_ms, k_ms, k_n, d8 = _timed_path(eng, lambda: cnn.transform_tensor(frames), reps=2)
+    flops, hh, ww = 0.0, 192, 240
+    for (kh, kw, cin, cout, s_, ph, pw, oh, ow, relu, pool) in cnn._geom:
+        flops += 2.0 * N * oh * ow * kh * kw * cin * cout
+    nb = min(N, 6)
+    cw, cb = ocnn.init_weights(3)
+    fh = frames[:nb].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = ocnn.transform(fh, cw, cb, ocnn.column_indices(cnn.layer_sizes, 99.59, seed=4))
+    t_cpu = time.perf_counter() - t0
+    diff = int((d8[:nb].cpu().numpy() != ref).sum())
+    out.append({"path": "CnnVtl.transform", "reference": "src/cnn_vtl/network/cnn_vtl.py:28-133", "frames": N, "dtype": "f64",
+                "descriptor_bytes": int(d8.shape[1]), "value": N / (call_ms * 1e-3), "unit": "frames/s", "ms": call_ms,
+                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_bias_act_kernel<double> (implicit-GEMM conv1..conv5, fused bias + ReLU)"),
+                "cpu_baseline": {"value": nb / t_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
+                                 "sample": "oracle/cnn_vtl.py (fp64 NumPy im2col + matmul) on the first %d frames, same weights and "
+                                           "columns: %.1f s" % (nb, t_cpu)},
+                "int8_bytes_differing_from_oracle": diff, "int8_bytes_compared": int(ref.size)})
+    del frames, fh, ref, cw, cb
+
+    # ---- M3/M4: cnn_vtl distance matrix (DistanceCalculator.py:4-12 + create_distance_matrix.py:30-36) -------
+    desc8 = d8.contiguous()
+    dp = int(desc8.shape[1])
+    call_ms, _, _, dm = _timed_path(eng, lambda: eng.cnnvtl_distance_matrix(desc8))
+    bytes_alg = N * dp + N * N * 8                                  # descriptors read once + the int64 matrix written
+    ns = min(N, 160)
+    dh = desc8[:ns].cpu().numpy()
+    t0 = time.perf_counter()
+    ref = odist.distance_matrix(dh)
+    t_cpu = time.perf_counter() - t0
+    npair = min(ns * ns, 1500)                                      # the literal form: one Python-level call per pair
+    t0 = time.perf_counter()
+    for e in range(npair):
+        odist.calculate_distance(dh[e // ns], dh[e % ns])
+    t_lit = (time.perf_counter() - t0) / npair
+    exact = bool(np.array_equal(dm[:ns, :ns].cpu().numpy(), ref))
+    gbs = bytes_alg / (call_ms * 1e-3) / 1e9
+    out.append({"path": "cnn_vtl distance matrix", "reference": "src/cnn_vtl/similarity/DistanceCalculator.py:4-12, "
+                "src/cnn_vtl/create_distance_matrix.py:30-36", "frames": N, "descriptor_bytes": dp, "dtype": "i8",
+                "value": N * N / (call_ms * 1e-3), "unit": "frame-pairs/s", "ms": call_ms,
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "traffic": None, "kernel": "distance_matrix_kernel", "kernel_ms": call_ms, "call_ms": call_ms,
+                             "algorithmic_bytes_per_call": bytes_alg,
+                             "byte_pairs_per_s": N * N * dp / (call_ms * 1e-3),
+                             "note": "N*D' bytes in, N*N*8 out: the kernel is VALU work (xor, |x|, popcount on N*N*D' byte "
+                                     "pairs), not HBM traffic; byte_pairs_per_s is its own rate"},
+                "cpu_baseline": {"value": ns * ns / t_cpu, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                                 "sample": "oracle/distance.py (NumPy table lookup per row) on %d x %d frames: %.2f s; one "
+                                           "calculate_distance call per pair, the reference's loop shape: %.3f ms per pair"
+                                           % (ns, ns, t_cpu, t_lit * 1e3), "literal_ms_per_pair": t_lit * 1e3},
+                "bit_exact_vs_oracle": exact})
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -225,6 +448,9 @@ def main():
 
     # ---- quality: recall@1 on the planted neighbours -------------------------------------
     recall1 = float((idx[:, 0].cpu().numpy() == planted_rows).mean())
+    import hashlib
+    idx_sha = hashlib.sha256(np.ascontiguousarray(idx.cpu().numpy()).tobytes()).hexdigest()
+    scores_sha = hashlib.sha256(np.ascontiguousarray(scores.cpu().numpy()).tobytes()).hexdigest()
 
     out = None
     if rank == 0:
@@ -247,9 +473,13 @@ def main():
                        "db_rows": n, "dim": d, "queries_per_step": nq, "k": k, "rows_per_gpu": shard_rows,
                        "pipelined": pipe is not None},
             "recall_at_1": recall1,
+            # traffic: HBM bytes per launch from the rocprofv3 PMC passes of this same command, as committed under
+            # profiles/ (bench.py cannot run the profiler on itself): a REPLAYED figure, not measured in this run
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
-                         "traffic_source": traffic[1] if traffic else None,
+                         "traffic_profiled": traffic[0] if traffic else None,
+                         "traffic_source": ("profiles/%s (separate rocprofv3 --pmc passes of this command, replayed here -- "
+                                            "not measured in this run)" % traffic[1]) if traffic else None,
                          "kernel": "score_gemm_kernel", "kernel_ms": gemm_avg_ms, "kernel_launches_timed": len(gemm_ms),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "mfma_achieved_tflops": achieved_tf, "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
@@ -283,15 +513,32 @@ def main():
             s_gpu, i_gpu = eng.match_topk(queries, db.rows[:ns], k)
         torch.cuda.synchronize()
         agree = float((i_gpu.cpu().numpy() == best_i).mean())
+        # the same oracle in fp32 (BASELINE.md section 4(1)'s plan) on the first blocks only, scaled linearly in rows
+        ns32 = min(ns, 4 * blk)
+        q32 = qh.astype(np.float32)
+        t32 = 0.0
+        for b0 in range(0, ns32, blk):
+            dbh = db.rows[b0:min(b0 + blk, ns32)].float().cpu().numpy()
+            t0 = time.perf_counter()
+            ocos.cosine_topk(q32, dbh, k, row_offset=b0, dtype=np.float32)
+            t32 += time.perf_counter() - t0
+            del dbh
         out["cpu_baseline"] = {
-            "value": nq / (t_cpu * (n / ns)), "unit": "query-frames/s", "cores": int(torch.get_num_threads()),
-            "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": "oracle/cosine.py (fp64 NumPy matmul + exact top-k, blocks of %d rows) on %d queries x %d of %d "
-                      "DB rows: %.1f s of CPU work%s" % (blk, nq, ns, n, t_cpu,
-                                                         "" if ns == n else "; scaled linearly in DB rows")}
+            "value": nq / (t_cpu * (n / ns)), "unit": "query-frames/s", "cores": blas_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port", "arithmetic": "f64",
+            "value_f32": nq / (t32 * (n / ns32)),
+            "sample": "oracle/cosine.py (NumPy matmul on the BLAS pool of `cores` threads + exact top-k, blocks of %d rows) "
+                      "on %d queries x %d of %d DB rows in fp64: %.1f s of CPU work%s; value_f32: the same in fp32 on the "
+                      "first %d rows (%.1f s), scaled linearly in DB rows"
+                      % (blk, nq, ns, n, t_cpu, "" if ns == n else "; scaled linearly in DB rows", ns32, t32)}
         out["topk_index_agreement_vs_oracle"] = agree
         out["topk_index_agreement_rows"] = ns
         out["topk_score_max_abs_err_vs_oracle"] = float(np.abs(s_gpu.cpu().numpy() - best_s).max())
+
+    # ---- the other rows of the hot path at configs[1] / configs[2] size (rank 0, N=1 only; untimed above) ----
+    if rank == 0 and world == 1 and not args.no_paths:
+        del rows, planted, noise
+        out["paths"] = bench_paths(eng, args.path_frames)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -312,11 +312,18 @@ int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, 
     const int chunks = plan_split<T>(ctx, M, N, K, &a.kchunk);
     a.P = chunks > 1 ? (T*)ctx->scratch : nullptr;
     dim3 grid((unsigned)dlc::cdiv(M, TM), (unsigned)dlc::cdiv(N, TN), (unsigned)chunks);
+    // bench.py's kernel-only timing (dlc_set_profiling): an event pair around the GEMM kernel on its stream
+    const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
+    if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
     if (cv && cv->C % 8 == 0) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, 1>), grid, dim3(256), 0, st, a);
     else if (cv) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, 2>), grid, dim3(256), 0, st, a);
     else if (blayout == DLC_B_KN) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_NK>), grid, dim3(256), 0, st, a);
     DLC_LAUNCH_CHECK(ctx, "gemm_bias_act_kernel");
+    if (ctx->profiling) {
+        DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[prof_slot], st));
+        ctx->prof_calls++;
+    }
     if (chunks > 1) {
         long long blocks = dlc::cdiv(M * N, (int64_t)256);
         if (blocks > 256 * 32) blocks = 256 * 32;

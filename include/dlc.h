@@ -362,8 +362,10 @@ int dlc_set_scratch(dlc_ctx* ctx, void* scratch, size_t bytes);
 
 /* ---- introspection used by bench.py (kernel-only timing with HIP events) -- */
 /*
- * With profiling enabled every dlc_cosine_topk call records a hipEvent pair on
- * the call's stream around its dominant kernel (the MFMA score GEMM), into a
+ * With profiling enabled every dlc_cosine_topk / dlc_cosine_score_groups call records a
+ * hipEvent pair on the call's stream around its dominant kernel (the MFMA score GEMM), and so
+ * does every launch of the dense fp64 / fp32 GEMM kernel (dlc_gemm_bias_act, dlc_conv2d_nhwc_f64,
+ * the layers of dlc_sdav_encode, the Gram GEMMs of dlc_sdav_similarity_matrix), into one
  * ring of DLC_PROFILE_RING slots.  dlc_profile_gemm_ms() waits for the recorded
  * events and writes the durations (milliseconds, oldest first) of the last
  * min(calls, capacity, DLC_PROFILE_RING) calls to the HOST array out_ms; it

@@ -54,14 +54,15 @@ def topk_from_scores(s, k, row_offset=0):
     return out_s, out_i
 
 
-def cosine_topk(q, db, k, row_offset=0, block=65536):
-    """Blocked exact top-k so that a 100k-row oracle run stays in memory."""
-    q = np.asarray(q, dtype=np.float64)
+def cosine_topk(q, db, k, row_offset=0, block=65536, dtype=np.float64):
+    """Blocked exact top-k so that a 100k-row oracle run stays in memory.  dtype: the matmul's
+    arithmetic (float64 = the oracle; float32 only for bench.py's fp32 CPU timing)."""
+    q = np.asarray(q, dtype=dtype)
     n = db.shape[0]
     best_s = np.empty((q.shape[0], 0))
     best_i = np.empty((q.shape[0], 0), dtype=np.int64)
     for lo in range(0, n, block):
-        s = q @ np.asarray(db[lo:lo + block], dtype=np.float64).T
+        s = q @ np.asarray(db[lo:lo + block], dtype=dtype).T
         bs, bi = topk_from_scores(s, k, row_offset + lo)
         best_s, best_i = merge_topk(np.concatenate([best_s, bs], 1), np.concatenate([best_i, bi], 1), k)
     return best_s, best_i

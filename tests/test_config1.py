@@ -1,0 +1,83 @@
+"""BASELINE configs[0] at its stated size: the 20 frames of the reference's datasets/test, frames -> grey ->
+key-points -> patches -> SDAV descriptors -> 20 x 20 cosine matrix + 20 x 20 SDAV-similarity matrix.
+
+CPU (no GPU): the oracle end to end; its similarity matrix == what the REFERENCE's own
+SimilarityCalculator returned for the same descriptors (tests/golden/config1.npz, captured by
+tests/golden/make_config1_golden.py by importing the reference in the build container).
+GPU: the same pipeline through the HIP path against the oracle and against that golden matrix."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+import config1_common as c1
+from oracle import cosine as ocos
+from oracle import similarity as osim
+
+N = 20
+
+
+@pytest.fixture(scope="module")
+def patches():
+    paths = c1.frame_paths()
+    assert len(paths) == N and [p[-10:-4] for p in paths] == ["%06d" % i for i in range(N)]
+    x = c1.oracle_patches(paths)
+    assert x.shape == (N, 30, 1681) and x.min() >= 0.0 and x.max() <= 1.0
+    return paths, x
+
+
+@pytest.mark.parametrize("scale", ["reference", "fan_in"])
+def test_config1_oracle_end_to_end_vs_reference_similarity(patches, scale):
+    g = load_golden("config1.npz")
+    _, x = patches
+    h = c1.oracle_descriptors(x, scale)
+    assert h.shape == (N * 30, 2500) and abs(h.sum() - float(g["descriptor_sum_" + scale])) < 1e-6 * h.sum()
+    ds = h.reshape(N, 30, 2500)
+    m = osim.similarity_matrix_f64(ds)
+    want = g["similarity_f64_" + scale]                                   # the reference module's own outputs
+    assert m.shape == (N, N) and np.array_equal(np.isfinite(m), np.isfinite(want))
+    assert np.abs(m - want).max() <= 1e-9 * np.abs(want).max()
+    mi = osim.similarity_matrix(ds)
+    assert mi.dtype == np.int64 and np.all(np.diag(mi) == -1) and np.array_equal(mi, mi.T)
+    assert np.array_equal(mi, osim.truncate_to_int64(want))               # create_similarity_matrix.py:31,36-37
+    c = c1.oracle_cosine(h, N)
+    assert c.shape == (N, N) and np.allclose(np.diag(c), 1.0) and np.allclose(c, c.T)
+    _, idx = ocos.topk_from_scores(c, 3)
+    assert np.array_equal(idx[:, 0], np.arange(N))                        # each frame's best match is itself
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", ["reference", "fan_in"])
+def test_config1_gpu_end_to_end_vs_oracle(patches, scale):
+    import torch
+    import deeploopcloser_amd as dlc
+    g = load_golden("config1.npz")
+    paths, x = patches
+    parser = dlc.CvInputParser(30, 41)
+    rgb = np.stack([dlc.read_ppm(p) for p in paths])
+    xg = parser.parse_batch(rgb).cpu().numpy()                            # grey, Harris, patch gather: all on the GPU
+    assert np.array_equal(xg, x)                                          # byte work: bit-exact
+    assert np.array_equal(np.stack([parser.parse_from_path(p) for p in paths]), x)
+    net = dlc.SDAV(seed=c1.SEED, weight_scale=scale)
+    h = dlc.encode(xg, net)
+    ho = c1.oracle_descriptors(x, scale)
+    assert h.shape == (N * 30, 2500) and np.abs(h - ho).max() < 1e-10
+    # SDAV similarity 20 x 20: the reference's int64 matrix
+    calc = dlc.SimilarityCalculator(h.reshape(N, 30, 2500))
+    mf = calc.similarity_matrix(as_int64=False)
+    want = g["similarity_f64_" + scale]
+    assert np.abs(mf - want).max() <= 1e-9 * np.abs(want).max()
+    assert np.array_equal(calc.similarity_matrix(), osim.truncate_to_int64(want))
+    assert np.array_equal(calc.similarity_matrix(), osim.similarity_matrix(ho.reshape(N, 30, 2500)))
+    assert calc.similarity_score(h[:30], h[30:60]) == mf[0, 1]            # the per-pair entry point
+    # cosine 20 x 20 over the flattened place descriptors + top-k
+    place = dlc.flatten_frame_descriptors(h)
+    db = dlc.KeyframeDatabase(place, dtype="bf16", center=True)
+    s = db.match(db.rows).cpu().numpy()
+    stored = db.rows.float().cpu().numpy().astype(np.float64)
+    assert s.shape == (N, N) and np.abs(s - ocos.scores(stored, stored)).max() < 2e-5
+    assert np.abs(s - c1.oracle_cosine(ho, N)).max() < 6e-3              # + bf16 rounding of the stored rows
+    ts, ti = db.match_topk(db.rows, 5)
+    es, ei = ocos.cosine_topk(stored, stored, 5)
+    assert np.array_equal(ti.cpu().numpy(), ei) and np.abs(ts.cpu().numpy() - es).max() < 2e-5
+    assert ti[:, 0].cpu().tolist() == list(range(N))
+    torch.cuda.synchronize()

@@ -1,4 +1,6 @@
-"""bench.py's one-line JSON contract (the driver parses it), on a small database so it runs in seconds."""
+"""bench.py's one-line JSON contract (the driver parses it), on a small database so it runs in seconds;
+and the N>1 path of bench.py itself -- MatchPipeline's two-all-gather protocol under torch.distributed --
+rehearsed with two gloo ranks sharing the one GPU of the box, against the one-rank run."""
 import json
 import os
 import subprocess
@@ -11,25 +13,68 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_json_contract():
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
-           "--rows", "30000", "--cpu-sample-rows", "30000", "--no-power-probe"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert res.returncode == 0, res.stderr[-2000:]
+def run_bench(extra, launcher=None, timeout=900):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]                       # exactly ONE JSON line
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract():
+    d = run_bench(["--gpus", "1", "--steps", "4", "--warmup", "1", "--rows", "30000", "--cpu-sample-rows", "30000",
+                   "--no-power-probe", "--path-frames", "24"])
     for key, typ in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
-                     ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)]:
+                     ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict), ("paths", list)]:
         assert isinstance(d[key], typ), key
     assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1
     assert d["scaling"] == "strong" and d["higher_is_better"] is True and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0 and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
+    assert "traffic" in r and "traffic_profiled" in r and "traffic_source" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == d["unit"] and c["sample"]
+    assert c["value_f32"] > 0 and c["arithmetic"] == "f64"
     assert d["recall_at_1"] == 1.0 and d["topk_index_agreement_vs_oracle"] == 1.0
     assert abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4 / 1e3)) / d["value"] < 1e-6
+    # the other rows of the hot path, each with its own roofline and CPU baseline, each checked against the oracle
+    paths = {p["path"]: p for p in d["paths"]}
+    assert set(paths) == {"SDAV.transform", "SDAV similarity matrix", "cosine similarity matrix (flattened SDAV descriptors)",
+                          "cosine top-20 (flattened SDAV descriptors)", "CnnVtl.transform", "cnn_vtl distance matrix"}
+    for p in d["paths"]:
+        pr, pc = p["roofline"], p["cpu_baseline"]
+        assert p["frames"] == 24 and p["value"] > 0 and p["ms"] > 0 and p["reference"]
+        assert pr["bound"] in ("hbm", "mfma") and pr["achieved"] > 0 and abs(pr["frac"] - pr["achieved"] / pr["peak"]) < 1e-9
+        assert pr["kernel_ms"] > 0 and pr["kernel_ms"] <= pr["call_ms"] * 1.001 and "traffic" in pr
+        assert pc["kind"] == "port" and pc["value"] > 0 and pc["cores"] >= 1 and pc["unit"] == p["unit"] and pc["sample"]
+    assert paths["SDAV.transform"]["max_abs_err_vs_oracle"] < 1e-9
+    assert paths["SDAV similarity matrix"]["max_rel_err_vs_oracle"] < 1e-9
+    assert paths["cosine similarity matrix (flattened SDAV descriptors)"]["max_abs_err_vs_oracle"] < 2e-5
+    assert paths["cosine top-20 (flattened SDAV descriptors)"]["topk_index_agreement_vs_oracle"] == 1.0
+    assert paths["CnnVtl.transform"]["int8_bytes_differing_from_oracle"] == 0
+    assert paths["cnn_vtl distance matrix"]["bit_exact_vs_oracle"] is True
+    assert paths["SDAV.transform"]["roofline"]["kernel_launches_timed"] == 5
+
+
+def test_bench_two_ranks_equal_one_rank():
+    """`bench.py --gpus 2` as the driver launches it (python -m torch.distributed.run, one process per rank),
+    with --backend gloo --share-gpu so that both ranks can use this box's single GPU: MatchPipeline's sharded
+    protocol (group selection -> all-gather of the group maxima -> filtered re-score -> all-gather of the
+    packed per-shard top-k -> merge) must give recall 1.0 and exactly the one-rank result."""
+    common = ["--steps", "6", "--warmup", "2", "--rows", "40000", "--no-cpu-baseline", "--no-power-probe", "--no-paths"]
+    one = run_bench(["--gpus", "1"] + common)
+    port = 29600 + os.getpid() % 300
+    two = run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                    launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port)])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["pipelined"] is True
+    assert two["config"]["rows_per_gpu"] == 20000 and one["config"]["rows_per_gpu"] == 40000
+    assert one["recall_at_1"] == 1.0 and two["recall_at_1"] == 1.0
+    assert two["topk_idx_sha256"] == one["topk_idx_sha256"]
+    assert two["topk_scores_sha256"] == one["topk_scores_sha256"]
+    assert two["steps"] == 6 and two["value"] > 0 and two["scaling"] == "strong"

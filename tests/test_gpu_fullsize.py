@@ -95,13 +95,20 @@ def test_cosine_config4_shape_properties(dlc):
     assert torch.all(s[:, :-1] >= s[:, 1:])                             # sorted
     s_self, i_self = eng.match_topk(db[pi], db, 1)
     assert torch.equal(i_self[:, 0], pi) and float((s_self - 1).abs().max()) < 5e-3
-    ps, pidx = [], []
-    for r in range(8):
-        lo, hi = dlc.shard_bounds(n, 8, r)
-        a, b = eng.match_topk(q, db[lo:hi], k, row_offset=lo)
-        ps.append(a.clone()), pidx.append(b.clone())
-    ms, mi = eng.topk_merge(torch.stack(ps), torch.stack(pidx))
-    assert torch.equal(mi, i) and torch.equal(ms, s)
+    for parts in (4, 8):
+        ps, pidx = [], []
+        for r in range(parts):
+            lo, hi = dlc.shard_bounds(n, parts, r)
+            a, b = eng.match_topk(q, db[lo:hi], k, row_offset=lo)
+            ps.append(a.clone()), pidx.append(b.clone())
+        ms, mi = eng.topk_merge(torch.stack(ps), torch.stack(pidx))
+        assert torch.equal(mi, i)
+        if parts == 4:
+            assert torch.equal(ms, s)           # 25 000-row shards: same plan as the whole database, same bits
+        else:
+            # 12 500-row shards take the small-database plan (<= 16384 rows): its scores are the MFMA-order
+            # fp32 sums, the whole database's the sequential-order re-score -- equal to fp32 rounding
+            assert float((ms - s).abs().max()) < 1e-6
     # exact scores of the returned rows, recomputed in fp64 on the host
     rows = db[i[:8].reshape(-1)].double().reshape(8, k, d)
     ref = torch.einsum("qkd,qd->qk", rows, q[:8].double())
@@ -146,3 +153,108 @@ def test_score_gemm_every_element_repeated(dlc):
         assert err < 2e-3 * 64 ** 0.5, err              # |x| ~ N(0,1): fp32 accumulation of 4096 products
         rel = ((s.double() - ref).abs() / (ref.abs() + 64.0)).max().item()
         assert rel < 1e-5, rel
+
+
+def test_cosine_config5_fp16_one_million_rows(dlc):
+    """configs[4]: 1 M x 4096 fp16 key-frames, 256 queries, top-20, on one GPU.  Planted-neighbour recall,
+    8 row shards + merge == unsharded (bit for bit: 125 000-row shards and the whole take the same plan),
+    the MatchPipeline result == the one-shot call, and for a sample of queries the exact top-20 of an fp64
+    product over ALL 1 M rows (computed on the GPU in row chunks -- the checker, not the product)."""
+    eng = dlc.default_engine()
+    n, d, nq, k, chunk = 1_000_000, 4096, 256, 20, 50_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2025)
+    pi = torch.randperm(n, generator=g, device="cuda")[:nq]
+    db = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    planted = torch.empty((nq, d), dtype=torch.float32, device="cuda")
+    for c0 in range(0, n, chunk):
+        x = torch.rand((chunk, d), generator=g, device="cuda", dtype=torch.float32)
+        sel = torch.nonzero((pi >= c0) & (pi < c0 + chunk)).flatten()
+        planted[sel] = x[pi[sel] - c0]
+        eng.normalize(x, "f16", center=True, out=db[c0:c0 + chunk])
+        del x
+    q = eng.normalize(planted + 0.17 * torch.randn((nq, d), generator=g, device="cuda"), "f16", center=True)
+    s, i = eng.match_topk(q, db, k)
+    assert torch.equal(i[:, 0], pi)                                     # recall@1 = 1.0
+    assert torch.all(s[:, :-1] >= s[:, 1:]) and int(i.min()) >= 0 and int(i.max()) < n
+    # 8 shards (one rank's 125 000 rows each) + merge == unsharded
+    ps, pidx = [], []
+    for r in range(8):
+        lo, hi = dlc.shard_bounds(n, 8, r)
+        a, b = eng.match_topk(q, db[lo:hi], k, row_offset=lo)
+        ps.append(a.clone()), pidx.append(b.clone())
+    ms, mi = eng.topk_merge(torch.stack(ps), torch.stack(pidx))
+    assert torch.equal(mi, i) and torch.equal(ms, s)
+    # two-stream pipeline (what bench.py --pipeline runs) == one-shot
+    pipe = dlc.MatchPipeline(dlc.KeyframeDatabase(db, dtype="f16", stored=True), k)
+    s2, i2 = pipe.result(pipe.submit(q))
+    assert torch.equal(i2, i) and torch.equal(s2, s)
+    # sampled queries against the fp64 scores of the whole database
+    sample = torch.tensor([0, 1, 17, 100, 128, 200, 254, 255], device="cuda")
+    qs = q[sample].double()
+    ref = torch.empty((sample.numel(), n), dtype=torch.float64, device="cuda")
+    for c0 in range(0, n, chunk):
+        ref[:, c0:c0 + chunk] = qs @ db[c0:c0 + chunk].double().T
+    rs, ri = torch.sort(ref, dim=1, descending=True, stable=True)
+    assert torch.equal(i[sample], ri[:, :k])
+    assert float((s[sample].double() - rs[:, :k]).abs().max()) < 2e-5
+
+
+def test_cnn_vtl_transform_kennedylong_multi_chunk(dlc):
+    """configs[2]: CnnVtl.transform on 1063 frames of 192x240 (chunks of 504 + 504 + 55 inside the call) ==
+    the same frames encoded chunk by chunk and frame by frame, bit for bit; == the oracle on sampled frames."""
+    from oracle import cnn_vtl as ocnn
+    eng = dlc.default_engine()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    frames = torch.randint(0, 256, (N_FRAMES, 192, 240, 3), generator=g, device="cuda").to(torch.float64)
+    net = dlc.CnnVtl(input_shape=[N_FRAMES, 192, 240, 3], seed=5, mask_seed=9)
+    assert net.frame_chunk == 504
+    d = net.transform_tensor(frames)
+    assert d.shape == (N_FRAMES, net.columns.size) and d.dtype == torch.int8 and net.columns.size <= 2243
+    for lo, hi in ((0, 504), (504, 1008), (1008, 1063), (503, 505), (1062, 1063), (700, 701)):
+        assert torch.equal(net.transform_tensor(frames[lo:hi]), d[lo:hi]), (lo, hi)
+    small = dlc.CnnVtl(input_shape=[N_FRAMES, 192, 240, 3], seed=5, mask_seed=9, frame_chunk=100)
+    assert torch.equal(small.transform_tensor(frames[400:650]), d[400:650])
+    ws, bs = ocnn.init_weights(5)
+    cols = ocnn.column_indices(net.layer_sizes, 99.59, seed=9)
+    pick = [0, 503, 504, 1007, 1008, 1062]
+    ref = ocnn.transform(frames[pick].cpu().numpy(), ws, bs, cols)
+    assert np.array_equal(d[pick].cpu().numpy(), ref)
+    # the distance matrix over these descriptors: symmetric, zero diagonal, sampled entries == the oracle
+    from oracle import distance as odist
+    m = dlc.DistanceCalculator.distance_matrix(d)
+    dn = d.cpu().numpy()
+    assert np.array_equal(m, m.T) and np.all(np.diag(m) == 0)
+    rng = np.random.RandomState(3)
+    for _ in range(40):
+        a, b = rng.randint(0, N_FRAMES, 2)
+        assert m[a, b] == odist.calculate_distance(dn[a], dn[b])
+
+
+def test_cosine_matrix_config2_dense_full(dlc, descriptors):
+    """configs[1]: the FULL 1063 x 1063 cosine matrix over the flattened 75 000-d SDAV place descriptors
+    (stored width 75 008, split-K) against the fp64 oracle on sampled rows, its symmetry and unit diagonal,
+    and the top-20 read off it (small-database plan) against the oracle's exact top-20 for every frame."""
+    from oracle import cosine as ocos
+    eng = dlc.default_engine()
+    _, _, h = descriptors
+    place = h.reshape(N_FRAMES, 30 * 2500)
+    db = dlc.KeyframeDatabase(place, dtype="bf16", center=True)
+    rows = db.rows
+    assert rows.shape == (N_FRAMES, 75008)
+    s = eng.cosine_scores(rows, rows)
+    assert s.shape == (N_FRAMES, N_FRAMES)
+    assert torch.equal(s, eng.cosine_scores(rows, rows))                 # chunk-ordered reduction: reproducible
+    assert float((s - s.T).abs().max()) == 0.0                          # same products, same order, both ways
+    assert float((torch.diagonal(s) - 1).abs().max()) < 5e-3
+    rh = rows.float().cpu().numpy().astype(np.float64)
+    pick = np.array([0, 1, 255, 256, 511, 777, 1024, 1062])
+    ref = ocos.scores(rh[pick], rh)
+    assert np.abs(s[pick].cpu().numpy() - ref).max() < 2e-5
+    ts, ti = eng.match_topk(rows, rows, 20)
+    full = ocos.scores(rh, rh)
+    es, ei = ocos.topk_from_scores(full, 20)
+    assert np.array_equal(ti.cpu().numpy(), ei)
+    assert np.abs(ts.cpu().numpy() - es).max() < 2e-5
+    assert np.array_equal(ti[:, 0].cpu().numpy(), np.arange(N_FRAMES))  # every frame's best match is itself

@@ -35,9 +35,13 @@ def stored(eng, x, dtype):
     return eng.normalize(torch.from_numpy(np.ascontiguousarray(x)).to(eng.device), dtype)
 
 
-def assert_topk_matches(s, i, q_st, db_st, k, row_offset=0, exact=False):
-    """Compare a GPU top-k with the fp64 oracle on the stored values.  Positions may
-    differ only where the oracle's own scores are closer than fp32 can resolve."""
+FLIPS = {"slots": 0, "flipped": 0}          # over the fuzz loops of this module (printed at the end of the session)
+
+
+def assert_topk_matches(s, i, q_st, db_st, k, row_offset=0, exact=True):
+    """Compare a GPU top-k with the fp64 oracle on the stored values: IDENTICAL indices (north_star).
+    exact=False (fuzz loops over random shapes only): positions may differ where the oracle's own
+    scores are closer than fp32 can resolve (2e-6), at most 0.1 % of the slots; the count is recorded."""
     from oracle import cosine as ocos
     qn, dbn = q_st.float().cpu().numpy().astype(np.float64), db_st.float().cpu().numpy().astype(np.float64)
     es, ei = ocos.cosine_topk(qn, dbn, k, row_offset=row_offset)
@@ -50,6 +54,8 @@ def assert_topk_matches(s, i, q_st, db_st, k, row_offset=0, exact=False):
         assert np.array_equal(i, ei)
         return
     diff = i != ei
+    FLIPS["slots"] += diff.size
+    FLIPS["flipped"] += int(diff.sum())
     if diff.any():
         full = qn @ dbn.T
         rows, cols = np.nonzero(diff)
@@ -129,7 +135,10 @@ def test_cosine_topk_plan_boundaries_fuzz(eng):
     shapes = [(4, 256, 8192, 3), (5, 256, 8192, 3), (4, 257, 8256, 5), (2, 511, 16384, 9), (3, 512, 16448, 1),
               (32, 300, 8192, 20), (33, 300, 8192, 20), (192, 1500, 256, 4), (193, 1500, 256, 4), (256, 255, 64, 128),
               (257, 256, 64, 2), (449, 2049, 128, 6), (1, 32769, 64, 20), (7, 40000, 64, 20), (64, 33000, 1024, 20),
-              (512, 4000, 512, 10)]
+              (512, 4000, 512, 10),
+              # small-database plan (<= 16384 rows, > 4 queries): on / around its row and query boundaries
+              (5, 16384, 128, 20), (5, 16385, 128, 20), (4, 16384, 128, 20), (64, 16383, 256, 128), (300, 16384, 64, 3),
+              (9, 8191, 2048, 20), (1063, 1063, 1024, 20)]
     for _ in range(10):
         shapes.append((int(rng.choice([1, 3, 4, 5, 31, 64, 200, 260])), int(rng.randint(1, 6000)),
                        64 * int(rng.randint(1, 40)), int(rng.choice([1, 2, 20, 77, 128]))))
@@ -146,7 +155,9 @@ def test_cosine_topk_plan_boundaries_fuzz(eng):
         if n > 3:
             assert i[0, 0].item() == n // 2 + 3, (nq, n, d, k)
             assert k < 2 or i[0, 1].item() == n - 1 + 3, (nq, n, d, k)
-        assert_topk_matches(s, i, q_st, db_st, k, row_offset=3)
+        assert_topk_matches(s, i, q_st, db_st, k, row_offset=3, exact=False)
+    print("plan-boundary fuzz: %d of %d top-k slots differ from the oracle (near-ties below fp32 resolution)"
+          % (FLIPS["flipped"], FLIPS["slots"]))
 
 
 def test_cosine_topk_planted_neighbours_exact(eng):
@@ -228,10 +239,14 @@ def test_topk_merge_vs_oracle(eng):
     assert np.array_equal(mi.cpu().numpy(), ei) and np.array_equal(ms.cpu().numpy(), es.astype(np.float32))
 
 
-def test_sharded_equals_unsharded(eng, dlc):
-    """Size-independent property: 4 row shards + merge == one shard."""
+@pytest.mark.parametrize("n", [80000, 40000, 12000])
+def test_sharded_equals_unsharded(eng, dlc, n):
+    """Size-independent property: 4 row shards + merge == one shard.  Bit for bit when the shards and the
+    whole database take the same plan (80 000: all re-scored; 12 000: all read off the score matrix);
+    at 40 000 the 10 000-row shards take the small-database plan and the whole the re-scoring one:
+    same indices, scores equal to fp32 rounding."""
     rng = np.random.RandomState(9)
-    n, d, nq, k = 40000, 256, 128, 20
+    d, nq, k = 256, 128, 20
     db_st = stored(eng, rng.standard_normal((n, d)).astype(np.float32), "bf16")
     q_st = stored(eng, rng.standard_normal((nq, d)).astype(np.float32), "bf16")
     s0, i0 = eng.match_topk(q_st, db_st, k)
@@ -241,7 +256,11 @@ def test_sharded_equals_unsharded(eng, dlc):
         s, i = eng.match_topk(q_st, db_st[lo:hi], k, row_offset=lo)
         ps.append(s.clone()), pi.append(i.clone())
     ms, mi = eng.topk_merge(torch.stack(ps), torch.stack(pi))
-    assert torch.equal(mi, i0) and torch.equal(ms, s0)
+    assert torch.equal(mi, i0)
+    if n == 40000:
+        assert float((ms - s0).abs().max()) < 1e-6
+    else:
+        assert torch.equal(ms, s0)
 
 
 def test_match_errors(eng):
@@ -362,8 +381,8 @@ def test_latency_mode_encoders_vs_oracle(dlc, eng):
     assert np.abs(h - osdav.transform(x, ws, bs)).max() < 1e-10
     cw, cb = ocnn.init_weights(3)
     ref = ocnn.transform(frame, cw, cb, ocnn.column_indices(cnn.layer_sizes, 99.59, seed=4))
-    diff = (d.astype(np.int16) - ref.astype(np.int16)) % 256      # a value on a truncation boundary may flip by one
-    assert d.dtype == np.int8 and np.count_nonzero(diff) <= 2 and np.all((diff == 0) | (diff == 1) | (diff == 255))
+    assert d.dtype == np.int8 and np.array_equal(d, ref)          # every byte (a value within ~1e-11 of an integer
+    # could truncate differently under another summation order: none does for this seed)
 
 
 def test_gemm_bias_act_f32(eng):
@@ -637,12 +656,38 @@ def test_cnn_vtl_transform_vs_oracle(dlc):
     got = net.transform(x)
     ref = ocnn.transform(x, ws, bs, cols)
     assert got.dtype == np.int8 and got.shape == ref.shape == (3, cols.size)
-    diff = (got.astype(np.int16) - ref.astype(np.int16)) % 256
-    bad = np.count_nonzero(diff)
-    # fp64 on both sides, different summation order: a value within ~1e-11 of an integer may
-    # truncate differently.  Expect none; allow 2 off-by-one elements out of ~6700.
-    assert bad <= 2 and np.all((diff == 0) | (diff == 1) | (diff == 255))
+    # fp64 on both sides, different summation order: a value within ~1e-11 of an integer could
+    # truncate differently.  None does for this seed: every one of the ~6700 bytes is identical.
+    assert np.array_equal(got, ref)
     assert (ref < 0).any() and (ref > 0).any()                       # the wrap (>127 -> negative) is exercised
+
+
+def test_cnn_vtl_load_alexnet_npy_grouped_layout(dlc, tmp_path):
+    """load_alexnet_npy on a synthetic blob in bvlc_alexnet.npy's REAL layout (cnn_vtl.py:137-149): a pickled
+    {layer: [W, b]} dict with fc6-8 present and AlexNet's grouped kernels for conv2 / conv4 / conv5, which the
+    reference pushes through tf.constant_initializer into ungrouped variables (values in C order, the last one
+    repeated).  The loaded network == the oracle on the oracle's own fill of the same dict, byte for byte."""
+    from oracle import cnn_vtl as ocnn
+    from test_host_logic_cpu import _grouped_alexnet_dict
+    rng = np.random.RandomState(17)
+    d = _grouped_alexnet_dict(rng)
+    path = str(tmp_path / "bvlc_alexnet.npy")
+    np.save(path, d, allow_pickle=True)
+    net = dlc.CnnVtl(input_shape=[2, 192, 240, 3], seed=1, mask_seed=6)
+    before = net.transform(np.ones((1, 192, 240, 3)))
+    net.load_alexnet_npy(path)
+    x = rng.randint(0, 256, size=(2, 192, 240, 3)).astype(np.float64)
+    ws, bs = ocnn.weights_from_alexnet_dict(d)
+    assert ws[1].shape == (5, 5, 96, 256) and ws[3].shape == (3, 3, 384, 384) and ws[4].shape == (3, 3, 384, 256)
+    got = net.transform(x)
+    ref = ocnn.transform(x, ws, bs, ocnn.column_indices(net.layer_sizes, 99.59, seed=6))
+    assert np.array_equal(got, ref)
+    assert not np.array_equal(net.transform(np.ones((1, 192, 240, 3))), before)      # the weights really changed
+    with pytest.raises(ValueError):                                                    # more values than the variable holds
+        bad = dict(d)
+        bad["conv1"] = [np.zeros((11, 11, 4, 96), dtype=np.float32), d["conv1"][1]]
+        np.save(path, bad, allow_pickle=True)
+        net.load_alexnet_npy(path)
 
 
 def test_cnn_vtl_surface(dlc):
@@ -683,11 +728,13 @@ def test_pipeline_and_coop_select_equal_one_shot(eng, dlc):
     assert torch.equal(i, want[0][1]) and torch.equal(s, want[0][0])
 
 
-def test_group_exchange_protocol_equals_unsharded(eng, dlc):
+@pytest.mark.parametrize("n", [50000, 80000])
+def test_group_exchange_protocol_equals_unsharded(eng, dlc, n):
     """The sharded protocol of MatchPipeline, emulated with 4 shards on one GPU: select groups per
-    shard, 'all-gather' their maxima, filtered re-score per shard, packed merge == one shard."""
+    shard, 'all-gather' their maxima, filtered re-score per shard, packed merge == one shard.
+    (50 000: 12 500-row shards, whose one-shot call takes the small-database plan; 80 000: 20 000-row shards.)"""
     rng = np.random.RandomState(33)
-    n, d, nq, k, parts = 50000, 256, 96, 20, 4
+    d, nq, k, parts = 256, 96, 20, 4
     x = rng.standard_normal((n, d)).astype(np.float32)
     x[[100, 20000, 20001, 40000]] = x[7]                       # exact ties across shards
     db = stored(eng, x, "bf16")
@@ -725,7 +772,11 @@ def test_group_exchange_protocol_equals_unsharded(eng, dlc):
         i2 = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
         eng.rescore_topk(q, db[lo:hi], k, ids[r], mx[r], s2, i2, all_max=None, row_offset=lo)
         s1, i1 = eng.match_topk(q, db[lo:hi], k, row_offset=lo)
-        assert torch.equal(i1, i2) and torch.equal(s1, s2)
+        assert torch.equal(i1, i2)
+        if hi - lo > 16384:
+            assert torch.equal(s1, s2)
+        else:       # one-shot call under the small-database plan: MFMA-order scores, equal to fp32 rounding
+            assert float((s1 - s2).abs().max()) < 1e-6
     o_s = torch.empty((nq, k), dtype=torch.float32, device=eng.device)
     o_i = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
     eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i))
