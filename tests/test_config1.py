@@ -8,7 +8,7 @@ GPU: the same pipeline through the HIP path against the oracle and against that 
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, topk_flips_are_ties
 import config1_common as c1
 from oracle import cosine as ocos
 from oracle import similarity as osim
@@ -77,7 +77,11 @@ def test_config1_gpu_end_to_end_vs_oracle(patches, scale):
     assert s.shape == (N, N) and np.abs(s - ocos.scores(stored, stored)).max() < 2e-5
     assert np.abs(s - c1.oracle_cosine(ho, N)).max() < 6e-3              # + bf16 rounding of the stored rows
     ts, ti = db.match_topk(db.rows, 5)
-    es, ei = ocos.cosine_topk(stored, stored, 5)
-    assert np.array_equal(ti.cpu().numpy(), ei) and np.abs(ts.cpu().numpy() - es).max() < 2e-5
-    assert ti[:, 0].cpu().tolist() == list(range(N))
+    full = ocos.scores(stored, stored)
+    es, ei = ocos.topk_from_scores(full, 5)
+    # 75 008-d rows of real frames under an untrained encoder: every frame looks alike, scores crowd together;
+    # slots may only differ where the exact scores are closer than the fp32 sum of 75 008 products resolves
+    flips, ties = topk_flips_are_ties(ti.cpu().numpy(), ei, full, es, tol=1e-5)
+    assert ties and flips <= 4, flips
+    assert np.abs(ts.cpu().numpy() - es).max() < 2e-5
     torch.cuda.synchronize()

@@ -55,7 +55,8 @@ def test_bench_json_contract():
     assert paths["SDAV.transform"]["max_abs_err_vs_oracle"] < 1e-9
     assert paths["SDAV similarity matrix"]["max_rel_err_vs_oracle"] < 1e-9
     assert paths["cosine similarity matrix (flattened SDAV descriptors)"]["max_abs_err_vs_oracle"] < 2e-5
-    assert paths["cosine top-20 (flattened SDAV descriptors)"]["topk_index_agreement_vs_oracle"] == 1.0
+    top = paths["cosine top-20 (flattened SDAV descriptors)"]
+    assert top["topk_index_agreement_vs_oracle"] > 0.99 and top["topk_differing_slots_are_near_ties"] is True
     assert paths["CnnVtl.transform"]["int8_bytes_differing_from_oracle"] == 0
     assert paths["cnn_vtl distance matrix"]["bit_exact_vs_oracle"] is True
     assert paths["SDAV.transform"]["roofline"]["kernel_launches_timed"] == 5

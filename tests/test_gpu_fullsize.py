@@ -255,6 +255,11 @@ def test_cosine_matrix_config2_dense_full(dlc, descriptors):
     ts, ti = eng.match_topk(rows, rows, 20)
     full = ocos.scores(rh, rh)
     es, ei = ocos.topk_from_scores(full, 20)
-    assert np.array_equal(ti.cpu().numpy(), ei)
+    # 21 260 slots over crowded scores (untrained encoder on random frames: every frame looks alike): slots may
+    # differ only where two exact scores are closer than an fp32 sum of 75 008 products resolves (~5e-6)
+    from conftest import topk_flips_are_ties
+    flips, ties = topk_flips_are_ties(ti.cpu().numpy(), ei, full, es, tol=1e-5)
+    print("config-2 top-20: %d of %d slots differ from the fp64 oracle, all near-ties: %s" % (flips, ei.size, ties))
+    assert ties and flips < 0.005 * ei.size
     assert np.abs(ts.cpu().numpy() - es).max() < 2e-5
     assert np.array_equal(ti[:, 0].cpu().numpy(), np.arange(N_FRAMES))  # every frame's best match is itself
