@@ -9,8 +9,18 @@
 // Workgroup tile 128 x 128, K step 16, 4 waves (2 x 2), each wave 64 x 64 =
 // 4 x 4 MFMA tiles.  Operands are staged global -> registers -> LDS (padded
 // rows, so arbitrary M/N/K and odd leading dimensions such as 1681 work with
-// plain predicated loads); the next K tile's global loads are issued before
-// the current tile's MFMAs.
+// plain predicated loads).  The LDS image is double-buffered: the next K tile's
+// global loads are issued before the current tile's MFMAs and stored into the
+// other buffer after them -- one barrier per K tile.
+//
+// Tile order (one-pass launches): a 1-D grid whose workgroup ids -- dealt round-robin to
+// the 8 XCDs, each with its own 4 MiB L2 -- are mapped so that the ~64 workgroups an
+// XCD runs at a time (32 CUs x 2) form a compact block of br x bc tiles (8 x 8 when the
+// matrix allows).  A row-major (x fastest) 3-D grid makes those 64 workgroups 64 different
+// row tiles of ONE column tile: the B panel is shared, every A row tile is private, and A
+// is re-streamed from HBM once per column tile (measured r02: 13.4 GB of fabric reads per
+// SDAV layer for 0.69 GB of operands, L2 hit rate 60 %).  In a block every A and B K-slice
+// is fetched once per 8 users.
 #include "dlc_internal.h"
 
 #include <algorithm>
@@ -62,8 +72,18 @@ struct Args {
     long long M, N, K;
     int act;
     ConvGeom cv;
-    long long kchunk;   // split-K: elements of K per chunk (a multiple of TK; >= K when one pass), chunk = blockIdx.z
+    long long kchunk;   // split-K: elements of K per chunk (a multiple of TK; >= K when one pass)
     T* P;               // split-K partial results [chunks][M][N] (null when one pass)
+    // tile order: tiles_m x tiles_n tiles (x chunks K chunks when split); one-pass launches walk blocks of
+    // br x bc tiles (br * bc = 64), nbr x nbc of them, block gb = 8 * (local block of the XCD) + XCD
+    long long tiles_m, tiles_n;
+    int chunks, br, bc;
+    long long nbr, nblocks;
+    // triangular skip (the Gram blocks of the SDAV similarity, match_ref.hip): rows / columns are patches of
+    // frames of tri_p patches, row r is global patch tri_row0 + r, column c global patch tri_col0 + c; only
+    // (row frame < column frame) entries are ever read, so a tile that holds none is not computed.  0 = off.
+    int tri_p;
+    long long tri_row0, tri_col0;
 };
 
 // CONV: 0 plain GEMM; 1 implicit im2col, 8 consecutive channels of one pixel per thread (C % 8 == 0);
@@ -72,12 +92,40 @@ template <typename T, int BLAYOUT, int CONV = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     constexpr int LDB_S = BLAYOUT == DLC_B_KN ? LDB_KN : LDB_NK;
     constexpr int B_ELEMS = BLAYOUT == DLC_B_KN ? TK * LDB_KN : TN * LDB_NK;
-    __shared__ T As[TM * LDA_S];
-    __shared__ T Bs[B_ELEMS];
+    constexpr int A_ELEMS = TM * LDA_S;
+    extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
+    T* const As = (T*)gemm_smem;                 // [2][A_ELEMS]
+    T* const Bs = As + 2 * A_ELEMS;              // [2][B_ELEMS]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
-    const long long m0 = (long long)blockIdx.x * TM, n0 = (long long)blockIdx.y * TN;
-    const long long kb = (long long)blockIdx.z * p.kchunk;          // this workgroup's K range [kb, kend)
+    // ---- workgroup id -> (row tile, column tile, K chunk)
+    long long tile_m, tile_n;
+    int chunk = 0;
+    {
+        const long long w = blockIdx.x;
+        if (p.chunks > 1) {                      // split-K (latency mode, a handful of tiles): plain order
+            tile_m = w % p.tiles_m;
+            tile_n = (w / p.tiles_m) % p.tiles_n;
+            chunk = (int)(w / (p.tiles_m * p.tiles_n));
+        } else {
+            const long long l = w >> 3;                      // position in the XCD's own queue
+            const long long gb = (l >> 6) * 8 + (w & 7);     // block: 8 consecutive ones run side by side, one per XCD
+            if (gb >= p.nblocks) return;
+            const int i = (int)(l & 63);
+            tile_m = (gb % p.nbr) * p.br + (i % p.br);
+            tile_n = (gb / p.nbr) * p.bc + (i / p.br);
+            if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;      // block padding (before any barrier)
+        }
+    }
+#ifdef DLC_EXP_GEMM_PRIO      // experiment: static priority for every other workgroup of an XCD's queue (bit DLC_EXP_GEMM_PRIO of its position)
+    if ((blockIdx.x >> (3 + DLC_EXP_GEMM_PRIO)) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef DLC_EXP_GEMM_STAGGER   // experiment: delay every other workgroup by about half a K tile
+    if ((blockIdx.x >> (3 + DLC_EXP_GEMM_STAGGER)) & 1) for (int s_ = 0; s_ < 4; ++s_) __builtin_amdgcn_s_sleep(8);
+#endif
+    const long long m0 = tile_m * TM, n0 = tile_n * TN;
+    if (p.tri_p > 0 && (p.tri_col0 + n0 + TN - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;   // no (row frame < column frame) pair
+    const long long kb = (long long)chunk * p.kchunk;               // this workgroup's K range [kb, kend)
     const long long kend = kb + p.kchunk < p.K ? kb + p.kchunk : p.K;
 
     // staging coordinates
@@ -185,15 +233,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
             }
         }
     };
-    auto store_tile = [&]() {
+    // Branch-free loader for interior tiles and whole K tiles (the main loop's form): no per-element predicates,
+    // the one per-thread condition there is (a convolution's padding / image border) selects a safe address and
+    // zeroes the result instead of branching, so that the iteration stays ONE basic block and its loads, LDS
+    // stores and address arithmetic can be scheduled into the gaps of the 64 MFMAs.
+    auto load_tile_fast = [&](long long k0) {
+        const long long gm = m0 + a_row;
+        if constexpr (CONV == 1) {
+            const int iy = cv_iy0 + cv_ky, ix = cv_ix0 + cv_kx;
+            const bool ok = iy >= 0 && iy < p.cv.H && ix >= 0 && ix < p.cv.W;
+            const T* src = p.A + (ok ? cv_img_base + ((long long)iy * p.cv.W + ix) * p.cv.C + cv_c : 0);
+            cv_c += TK;
+            while (cv_c >= p.cv.C) {
+                cv_c -= p.cv.C;
+                if (++cv_kx == p.cv.KW) { cv_kx = 0; ++cv_ky; }
+            }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) As[a_row * LDA_S + a_k + e] = ra[e];
+            for (int e = 0; e < 8; ++e) {
+                const T v = src[e];
+                ra[e] = ok ? v : (T)0;
+            }
+        } else {
+            const T* src = p.A + gm * p.lda + k0 + a_k;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ra[e] = src[e];
+        }
+        if constexpr (BLAYOUT == DLC_B_KN) {
+            const T* src = p.B + (k0 + bkn_k) * p.ldb + n0 + bkn_n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rb[e] = src[e];
+        } else {
+            const T* src = p.B + (n0 + a_row) * p.ldb + k0 + a_k;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rb[e] = src[e];
+        }
+    };
+    auto store_tile = [&](int buf) {
+        T* as = As + buf * A_ELEMS;
+        T* bs = Bs + buf * B_ELEMS;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) as[a_row * LDA_S + a_k + e] = ra[e];
         if constexpr (BLAYOUT == DLC_B_KN) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) Bs[bkn_k * LDB_S + bkn_n + e] = rb[e];
+            for (int e = 0; e < 8; ++e) bs[bkn_k * LDB_S + bkn_n + e] = rb[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) Bs[a_row * LDB_S + a_k + e] = rb[e];
+            for (int e = 0; e < 8; ++e) bs[a_row * LDB_S + a_k + e] = rb[e];
         }
     };
 
@@ -205,31 +290,84 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
 
     const int fr = lane & 15, fk = lane >> 4;
     const long long nkt = (kend - kb + TK - 1) / TK;
+    // Software pipeline (one barrier per K tile; the two LDS buffers alternate):
+    //   iteration kt:  MFMAs of k-slices 0,1 of tile kt | registers (tile kt+1, loaded during iteration kt-1) -> the
+    //                  other LDS buffer | global loads of tile kt+2 -> registers | MFMAs of k-slices 2,3 | barrier
+    // so the LDS stores and the address arithmetic / issue of the global loads sit between two halves of a tile's 64
+    // MFMAs (4096 matrix-pipe cycles in fp64) instead of between two tiles with the pipe idle, and a global load has a
+    // whole iteration to land.  Reads of buffer b in iteration kt and writes to it in iteration kt+1 are separated by
+    // the barrier at the end of iteration kt.
+    auto compute = [&](const T* as, const T* bs, int kk) {
+        T a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = as[(wr * 64 + i * 16 + fr) * LDA_S + kk * 4 + fk];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (BLAYOUT == DLC_B_KN) b[j] = bs[(kk * 4 + fk) * LDB_S + wc * 64 + j * 16 + fr];
+            else b[j] = bs[(wc * 64 + j * 16 + fr) * LDB_S + kk * 4 + fk];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+    };
     load_tile(kb);
-    for (long long kt = 0; kt < nkt; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kb + (kt + 1) * TK);
+    store_tile(0);
+    if (nkt > 1) load_tile(kb + TK);
+    __syncthreads();
+    long long kt = 0;
+#ifndef DLC_EXP_GEMM_NO_FAST
+    if (CONV != 2 && rows_full && cols_full) {
+        // iterations whose load (K tile kt+2) is a whole tile inside this workgroup's K range: one basic block each
+        const long long n_fast = (kend - kb) / TK - 2;
+        for (; kt < n_fast; ++kt) {
+            const int cur = (int)(kt & 1);
+            const T* as = As + cur * A_ELEMS;
+            const T* bs = Bs + cur * B_ELEMS;
+            compute(as, bs, 0);
+            compute(as, bs, 1);
+            store_tile(cur ^ 1);
+            load_tile_fast(kb + (kt + 2) * TK);
+            compute(as, bs, 2);
+            compute(as, bs, 3);
+            // the schedule asked of the compiler: the LDS stores of the next tile in the gaps of the first 32 MFMAs,
+            // the global loads of the one after it (and their address arithmetic) in the gaps of the last 32
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // DS read: the fragments of k-slices 0, 1
 #pragma unroll
-        for (int kk = 0; kk < TK / 4; ++kk) {
-            T a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[(wr * 64 + i * 16 + fr) * LDA_S + kk * 4 + fk];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (BLAYOUT == DLC_B_KN) b[j] = Bs[(kk * 4 + fk) * LDB_S + wc * 64 + j * 16 + fr];
-                else b[j] = Bs[(wc * 64 + j * 16 + fr) * LDB_S + kk * 4 + fk];
+            for (int g_ = 0; g_ < 8; ++g_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);   // DS write
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read: the fragments of k-slices 2, 3, ahead of use
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::run(a[i], b[j], acc[i][j]);
+            for (int g_ = 0; g_ < 8; ++g_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU
+            }
+            __syncthreads();
         }
+    }
+#endif
+    for (; kt < nkt; ++kt) {
+        const int cur = (int)(kt & 1);
+        const T* as = As + cur * A_ELEMS;
+        const T* bs = Bs + cur * B_ELEMS;
+        compute(as, bs, 0);
+        compute(as, bs, 1);
+#ifndef DLC_EXP_GEMM_NO_STAGING     // timing experiments only (wrong results): what the loop costs without its operand traffic
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        if (kt + 2 < nkt) load_tile(kb + (kt + 2) * TK);
+#endif
+        compute(as, bs, 2);
+        compute(as, bs, 3);
+#ifndef DLC_EXP_GEMM_NO_BARRIER
         __syncthreads();
+#endif
     }
 
     if (p.P) {                                  // split-K: this chunk's raw partial tile
-        T* part = p.P + (long long)blockIdx.z * p.M * p.N;
+        T* part = p.P + (long long)chunk * p.M * p.N;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long long gn = n0 + wc * 64 + j * 16 + fr;
@@ -299,26 +437,66 @@ int plan_split(const dlc_ctx* ctx, int64_t M, int64_t N, int64_t K, long long* k
     return (int)dlc::cdiv(ksteps, best_steps);
 }
 
+// Triangular skip of a launch (see Args): patches per frame and the global patch index of row / column 0.
+struct TriSkip {
+    int p;
+    long long row0, col0;
+};
+
+template <typename T, int BLAYOUT, int CONV>
+int launch_kernel(dlc_ctx* ctx, const Args<T>& a, long long nwg, hipStream_t st) {
+    constexpr int B_ELEMS = BLAYOUT == DLC_B_KN ? TK * LDB_KN : TN * LDB_NK;
+    constexpr int LDS = 2 * (TM * LDA_S + B_ELEMS) * (int)sizeof(T);      // 70 KiB in fp64: two workgroups per CU
+    auto kern = gemm_bias_act_kernel<T, BLAYOUT, CONV>;
+    constexpr int bit = DLC_ATTR_DGEMM_BASE + (sizeof(T) == 8 ? 0 : 4) + (CONV != 0 ? 1 + CONV : (BLAYOUT == DLC_B_KN ? 0 : 1));
+    const unsigned long long m = 1ull << bit;
+    if (LDS > 48 * 1024 && !(ctx->func_attr_set & m)) {                   // per device: the context's own flag
+        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        ctx->func_attr_set |= m;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), LDS, st, a);
+    return DLC_OK;
+}
+
 template <typename T>
 int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
            const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st,
-           const ConvGeom* cv = nullptr) {
+           const ConvGeom* cv = nullptr, const TriSkip* tri = nullptr) {
     Args<T> a;
     a.A = (const T*)A; a.lda = lda; a.B = (const T*)B; a.ldb = ldb; a.bias = (const T*)bias;
     a.C = (T*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
     a.cv = cv ? *cv : ConvGeom{};
-    if (dlc::cdiv(N, TN) > 65535 || dlc::cdiv(M, TM) > 0x7fffffffll)
-        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "gemm: M or N too large for one launch");
+    a.tri_p = tri ? tri->p : 0;
+    a.tri_row0 = tri ? tri->row0 : 0;
+    a.tri_col0 = tri ? tri->col0 : 0;
+    a.tiles_m = dlc::cdiv(M, TM);
+    a.tiles_n = dlc::cdiv(N, TN);
     const int chunks = plan_split<T>(ctx, M, N, K, &a.kchunk);
+    a.chunks = chunks;
     a.P = chunks > 1 ? (T*)ctx->scratch : nullptr;
-    dim3 grid((unsigned)dlc::cdiv(M, TM), (unsigned)dlc::cdiv(N, TN), (unsigned)chunks);
+    // block of 64 tiles: 8 x 8, narrower along a dimension with fewer than 8 tiles (powers of two)
+    int bc = 8;
+    while (bc > 1 && bc / 2 >= a.tiles_n) bc /= 2;
+    int br = 64 / bc;
+    if (a.tiles_m < br) {                                    // few row tiles: widen along N instead
+        br = 1;
+        while (br < a.tiles_m) br *= 2;
+        bc = 64 / br;
+    }
+    a.br = br; a.bc = bc;
+    a.nbr = dlc::cdiv(a.tiles_m, (int64_t)br);
+    a.nblocks = a.nbr * dlc::cdiv(a.tiles_n, (int64_t)bc);
+    const long long nwg = chunks > 1 ? a.tiles_m * a.tiles_n * chunks : dlc::cdiv(a.nblocks, (int64_t)8) * 8 * 64;
+    if (nwg > 0x7fffffffll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "gemm: M x N too large for one launch");
     // bench.py's kernel-only timing (dlc_set_profiling): an event pair around the GEMM kernel on its stream
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
-    if (cv && cv->C % 8 == 0) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, 1>), grid, dim3(256), 0, st, a);
-    else if (cv) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN, 2>), grid, dim3(256), 0, st, a);
-    else if (blayout == DLC_B_KN) hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_KN>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_bias_act_kernel<T, DLC_B_NK>), grid, dim3(256), 0, st, a);
+    int rc;
+    if (cv && cv->C % 8 == 0) rc = launch_kernel<T, DLC_B_KN, 1>(ctx, a, nwg, st);
+    else if (cv) rc = launch_kernel<T, DLC_B_KN, 2>(ctx, a, nwg, st);
+    else if (blayout == DLC_B_KN) rc = launch_kernel<T, DLC_B_KN, 0>(ctx, a, nwg, st);
+    else rc = launch_kernel<T, DLC_B_NK, 0>(ctx, a, nwg, st);
+    if (rc != DLC_OK) return rc;
     DLC_LAUNCH_CHECK(ctx, "gemm_bias_act_kernel");
     if (ctx->profiling) {
         DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[prof_slot], st));
@@ -345,6 +523,14 @@ int gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int6
     if (dtype == DLC_F64) return launch<double>(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st);
     if (dtype == DLC_F32) return launch<float>(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st);
     return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "gemm: dtype %d (need DLC_F64 or DLC_F32)", dtype);
+}
+
+// Gram block of the SDAV similarity (match_ref.hip): C = A . B^T in fp64 with B stored [N,K], tiles that hold no
+// (row frame < column frame) entry skipped (their part of C stays unwritten and is never read).
+int gram_upper_f64(dlc_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
+                   int64_t ldb, double* C, int64_t ldc, int patches, int64_t row0, int64_t col0, hipStream_t st) {
+    TriSkip tri{patches, row0, col0};
+    return launch<double>(ctx, DLC_B_NK, DLC_ACT_NONE, M, N, K, A, lda, B, ldb, nullptr, C, ldc, st, nullptr, &tri);
 }
 
 int conv2d_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, const double* x, const double* w,

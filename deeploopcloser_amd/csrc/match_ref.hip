@@ -10,8 +10,8 @@
 #include "dlc_internal.h"
 
 namespace dlc_gemm {
-int gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A,
-                  int64_t lda, const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st);
+int gram_upper_f64(dlc_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
+                   int64_t ldb, double* C, int64_t ldc, int patches, int64_t row0, int64_t col0, hipStream_t st);
 }
 
 namespace {
@@ -31,29 +31,52 @@ __device__ __forceinline__ int popabs4(unsigned w) {
 constexpr int DT = 64;      // output tile (frames x frames)
 constexpr int DCH = 64;     // descriptor bytes per step (16 words)
 
+// popcount(|a ^ b|) is symmetric, so only tiles on or above the diagonal are computed and every off-diagonal
+// tile is stored twice (the reference's loop evaluates both orders, create_distance_matrix.py:33-36: same
+// integers).  The descriptor width is cut into gridDim.z chunks -- 153 tile pairs alone would leave a third of
+// the chip idle with one wave per SIMD -- whose partial sums are added with 64-bit integer atomics onto a
+// zeroed matrix: integer addition, so the result does not depend on the order.  WORDS: rows are 4-byte
+// aligned (base and ldd), loaded a word at a time; otherwise byte by byte.
+template <bool WORDS>
 __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __restrict__ desc, long long n, long long d,
-                                                              long long ldd, long long* __restrict__ out) {
+                                                              long long ldd, long long kchunk,
+                                                              unsigned long long* __restrict__ out) {
+    if (blockIdx.x < blockIdx.y) return;                  // below the diagonal: the mirror of another tile
     __shared__ unsigned As[DT][DCH / 4 + 1];
     __shared__ unsigned Bs[DT][DCH / 4 + 1];
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const long long i0 = (long long)blockIdx.y * DT, j0 = (long long)blockIdx.x * DT;
+    const long long k_lo = (long long)blockIdx.z * kchunk;
+    const long long k_hi = k_lo + kchunk < d ? k_lo + kchunk : d;
     int acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0;
     const int lrow = tid >> 2, lw0 = (tid & 3) * 4;   // 4 threads per row, 4 words each
-    for (long long k0 = 0; k0 < d; k0 += DCH) {
+    const bool a_ok = i0 + lrow < n, b_ok = j0 + lrow < n;
+    const int8_t* arow = desc + (a_ok ? i0 + lrow : 0) * ldd;
+    const int8_t* brow = desc + (b_ok ? j0 + lrow : 0) * ldd;
+    for (long long k0 = k_lo; k0 < k_hi; k0 += DCH) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             unsigned va = 0, vb = 0;
+            const long long k = k0 + (lw0 + w) * 4;
+            if constexpr (WORDS) {
+                if (k < k_hi) {
+                    const long long left = k_hi - k;
+                    const unsigned mask = left >= 4 ? 0xffffffffu : ((1u << (8 * (int)left)) - 1u);
+                    if (a_ok) va = *(const unsigned*)(arow + k) & mask;
+                    if (b_ok) vb = *(const unsigned*)(brow + k) & mask;
+                }
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const long long k = k0 + (lw0 + w) * 4 + e;
-                if (k < d) {
-                    if (i0 + lrow < n) va |= ((unsigned)(unsigned char)desc[(i0 + lrow) * ldd + k]) << (8 * e);
-                    if (j0 + lrow < n) vb |= ((unsigned)(unsigned char)desc[(j0 + lrow) * ldd + k]) << (8 * e);
+                for (int e = 0; e < 4; ++e) {
+                    if (k + e < k_hi) {
+                        if (a_ok) va |= ((unsigned)(unsigned char)arow[k + e]) << (8 * e);
+                        if (b_ok) vb |= ((unsigned)(unsigned char)brow[k + e]) << (8 * e);
+                    }
                 }
             }
             As[lrow][lw0 + w] = va;
@@ -72,12 +95,16 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __re
         }
         __syncthreads();
     }
+    const bool diag = blockIdx.x == blockIdx.y;           // a diagonal tile holds both orders itself
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const long long i = i0 + ty * 4 + r, j = j0 + tx * 4 + c;
-            if (i < n && j < n) out[i * n + j] = (long long)acc[r][c];
+            if (i < n && j < n) {
+                atomicAdd(&out[i * n + j], (unsigned long long)acc[r][c]);
+                if (!diag) atomicAdd(&out[j * n + i], (unsigned long long)acc[r][c]);
+            }
         }
 }
 
@@ -249,8 +276,23 @@ extern "C" int dlc_cnnvtl_distance_matrix(dlc_ctx* ctx, const int8_t* desc, int6
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     const unsigned t = (unsigned)dlc::cdiv(N, DT);
     if (t > 65535) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "distance_matrix: N too large");
-    hipLaunchKernelGGL(distance_matrix_kernel, dim3(t, t), dim3(256), 0, (hipStream_t)stream, desc, (long long)N,
-                       (long long)D, (long long)ldd, (long long*)out);
+    // descriptor chunks: enough workgroups for ~3 per CU, each at least 4 steps of 64 bytes
+    const long long pairs = (long long)t * (t + 1) / 2;
+    long long z = dlc::cdiv((int64_t)768, pairs);
+    const long long steps = dlc::cdiv(D, DCH);
+    if (z > steps / 4) z = steps / 4;
+    if (z < 1) z = 1;
+    if (z > 64) z = 64;
+    const long long kchunk = dlc::cdiv(steps, z) * DCH;
+    z = dlc::cdiv(D, kchunk);
+    DLC_HIP_CHECK(ctx, hipMemsetAsync(out, 0, (size_t)N * (size_t)N * 8, (hipStream_t)stream));
+    const bool words = (((uintptr_t)desc) & 3) == 0 && (ldd & 3) == 0;
+    if (words)
+        hipLaunchKernelGGL(distance_matrix_kernel<true>, dim3(t, t, (unsigned)z), dim3(256), 0, (hipStream_t)stream, desc,
+                           (long long)N, (long long)D, (long long)ldd, kchunk, (unsigned long long*)out);
+    else
+        hipLaunchKernelGGL(distance_matrix_kernel<false>, dim3(t, t, (unsigned)z), dim3(256), 0, (hipStream_t)stream, desc,
+                           (long long)N, (long long)D, (long long)ldd, kchunk, (unsigned long long*)out);
     DLC_LAUNCH_CHECK(ctx, "distance_matrix_kernel");
     return DLC_OK;
 }
@@ -308,8 +350,9 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         const long long col0 = (i_lo + 1) * P;
         const long long ncols = rows - col0;
         const long long mrows = (i_hi - i_lo) * P;
-        int rc = dlc_gemm::gemm_bias_act(ctx, DLC_F64, DLC_B_NK, DLC_ACT_NONE, mrows, ncols, H, desc + i_lo * P * H, H,
-                                         desc + col0 * H, H, nullptr, gram, ncols, st);
+        // only entries with (row frame < column frame) are read below: tiles under the diagonal are skipped
+        int rc = dlc_gemm::gram_upper_f64(ctx, mrows, ncols, H, desc + i_lo * P * H, H, desc + col0 * H, H, gram, ncols,
+                                          (int)P, i_lo * P, col0, st);
         if (rc != DLC_OK) return rc;
         dim3 grid((unsigned)dlc::cdiv(N, 4), (unsigned)(i_hi - i_lo));
         hipLaunchKernelGGL(pair_score_kernel, grid, dim3(256), 0, st, desc, gram, ncols, col0, nrm2, proj, score,

@@ -305,6 +305,10 @@ class Engine:
     def cnnvtl_distance_matrix(self, desc):
         desc = desc.contiguous()
         n, d = desc.shape
+        if d % 4:       # rows on 4-byte boundaries let the kernel load words (the bytes past d are masked there)
+            padded = torch.zeros((n, (d + 15) // 16 * 16), dtype=torch.int8, device=self.device)
+            padded[:, :d] = desc
+            desc = padded
         out = torch.empty((n, n), dtype=torch.int64, device=self.device)
         self._check(self.lib.dlc_cnnvtl_distance_matrix(self.ctx, _ptr(desc), n, d, desc.stride(0), _ptr(out),
                                                          self._stream()))

@@ -34,6 +34,8 @@ def run(libpath, label, n=1_000_000, d=4096, nq=256, k=20, iters=10):
 
 base = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deeploopcloser_amd", "libdlc_hip.so")
 libs = [("shipped", base)] + [(os.path.basename(p), p) for p in os.environ.get("DLC_EXP_LIBS", "").split(":") if p]
+if os.environ.get("DLC_EXP_SKIP_SHIPPED"):
+    libs = libs[1:]
 for rnd in range(int(os.environ.get("DLC_EXP_ROUNDS", "2"))):
     for label, path in libs:
         run(path, label)
