@@ -246,7 +246,12 @@ def bench_paths(eng, n_frames):
     call_ms, k_ms, k_n, (mf, mi) = _timed_path(eng, sim, reps=2)
     # Gram GEMMs as dlc_sdav_similarity_matrix launches them (match_ref.hip sim_ws): row chunks of <= 1 GiB,
     # frames [i_lo, i_hi) against every later frame
-    cf = max(1, min(N, (1 << 30) // (N * P * 8 * P)))
+    cf = max(1, (1 << 30) // (N * P * 8 * P))
+    for q_ in (256, 128, 64, 32, 16, 8):
+        if cf >= q_ and (q_ * P) % 256 == 0:
+            cf = cf // q_ * q_
+            break
+    cf = min(cf, N)
     flops, i_lo = 0.0, 0
     while i_lo + 1 < N:
         i_hi = min(i_lo + cf, N - 1)

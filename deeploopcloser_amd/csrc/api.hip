@@ -38,6 +38,10 @@ extern "C" int dlc_create(int device, dlc_ctx** out) {
             return DLC_ERR_HIP;
         }
     }
+    if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+        delete c;
+        return DLC_ERR_HIP;
+    }
     *out = c;
     return DLC_OK;
 }
@@ -50,6 +54,7 @@ extern "C" int dlc_destroy(dlc_ctx* ctx) {
             (void)hipEventDestroy(ctx->ev_start[i]);
             (void)hipEventDestroy(ctx->ev_stop[i]);
         }
+        if (ctx->zero_page) (void)hipFree(ctx->zero_page);
     }
     delete ctx;
     return DLC_OK;

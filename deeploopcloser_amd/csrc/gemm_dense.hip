@@ -21,7 +21,7 @@
 // is re-streamed from HBM once per column tile (measured r02: 13.4 GB of fabric reads per
 // SDAV layer for 0.69 GB of operands, L2 hit rate 60 %).  In a block every A and B K-slice
 // is fetched once per 8 users.
-#include "dlc_internal.h"
+#include "gemm_internal.h"
 
 #include <algorithm>
 
@@ -55,13 +55,8 @@ __device__ __forceinline__ T apply_act(T z, int act) {
     return z;
 }
 
-// Implicit im2col (tf.layers.conv2d on NHWC, src/cnn_vtl/network/cnn_vtl.py:33-93): row m of the
-// A operand is output pixel (img, oy, ox), column k is (ky, kx, c) with c fastest; A then points
-// at the NHWC input and lda is unused.  With C % 8 == 0 a thread's 8 consecutive k are 8 channels of
+// Implicit im2col (ConvGeom, gemm_internal.h): with C % 8 == 0 a thread's 8 consecutive k are 8 channels of
 // one input pixel (one 64-byte load); other C (conv1: 3) are loaded element by element.
-struct ConvGeom {
-    int H, W, C, KW, stride, pad_t, pad_l, OH, OW;
-};
 
 template <typename T>
 struct Args {
@@ -437,12 +432,6 @@ int plan_split(const dlc_ctx* ctx, int64_t M, int64_t N, int64_t K, long long* k
     return (int)dlc::cdiv(ksteps, best_steps);
 }
 
-// Triangular skip of a launch (see Args): patches per frame and the global patch index of row / column 0.
-struct TriSkip {
-    int p;
-    long long row0, col0;
-};
-
 template <typename T, int BLAYOUT, int CONV>
 int launch_kernel(dlc_ctx* ctx, const Args<T>& a, long long nwg, hipStream_t st) {
     constexpr int B_ELEMS = BLAYOUT == DLC_B_KN ? TK * LDB_KN : TN * LDB_NK;
@@ -472,6 +461,14 @@ int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, 
     a.tiles_m = dlc::cdiv(M, TM);
     a.tiles_n = dlc::cdiv(N, TN);
     const int chunks = plan_split<T>(ctx, M, N, K, &a.kchunk);
+    if constexpr (sizeof(T) == 8) {
+        // large aligned fp64 launches: the LDS-DMA kernel (gemm_dma_f64.hip); anything else stays here
+        if (chunks == 1 && (!cv || cv->C % 8 == 0)) {
+            const int rc_dma = launch_dma_f64(ctx, blayout, act, M, N, K, (const double*)A, lda, (const double*)B, ldb,
+                                              (const double*)bias, (double*)C, ldc, st, cv, tri);
+            if (rc_dma <= 0) return rc_dma;
+        }
+    }
     a.chunks = chunks;
     a.P = chunks > 1 ? (T*)ctx->scratch : nullptr;
     // block of 64 tiles: 8 x 8, narrower along a dimension with fewer than 8 tiles (powers of two)

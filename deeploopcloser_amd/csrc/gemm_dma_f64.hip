@@ -1,0 +1,411 @@
+// fp64 GEMM with fused bias + activation whose operands reach LDS by DMA (global_load_lds_dwordx4) through a
+// 3-deep ring, for the large launches of the SDAV layers (SDAV.py:129-157), the CnnVtl convolutions as implicit
+// GEMMs (cnn_vtl.py:47-93) and the Gram blocks of the SDAV similarity (SimilarityCalculator.py:30-37).
+//
+// Why a second kernel.  The register-staged kernel of gemm_dense.hip keeps the fp64 matrix pipe 72-80 % busy
+// (profiles/r02_gemm_f64_pmc.json); timing builds without its operand staging run the same MFMAs + LDS reads
+// 13 % faster, without its barrier another 6 %.  What costs is not LDS or HBM bandwidth but (a)
+// 16 global loads, 16 LDS stores and their address arithmetic per thread and K tile in the waves' instruction
+// streams, and (b) one K tile of prefetch distance, so that every workgroup's barrier waits for the slowest of its
+// 2048 loads.  Here a K tile of both operands is 6 DMA instructions per wave: no registers, no LDS stores.
+//
+// Tile 256 x 128 x 16, 512 threads = 8 waves (4 x 2), each wave 64 x 64 = 4 x 4 v_mfma_f64_16x16x4_f64 tiles.
+// One workgroup per CU (two waves per SIMD), LDS ring of 3 stages x 48 KiB:
+//   A stage  256 rows x 128 B (16 doubles of K per row), 16-byte piece q of row r at slot q ^ ((r >> 1) & 7)
+//   B stage  [N,K] operand: 128 rows x 128 B, same swizzle;  [K,N] operand: 16 k-rows x 1 KiB, piece q of k-row k
+//            at slot q ^ ((k & 1) << 3)
+// so that each half-wave of a ds_read_b64 fragment read (16 rows x one 16-byte slot: even rows sit in banks 0-31,
+// odd rows in 32-63, and 8 rows of one parity take 8 different slots) touches every bank once.  (Keyed on r & 7
+// instead, rows r and r + 8 shared their banks: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE.)  The swizzle is applied to the DMA's per-lane SOURCE address; the LDS destination stays lane-linear.
+// Rows past M / columns past N are clamped to the last valid one (their results are never stored); K tails and
+// convolution padding read a page of zeros instead.
+//
+// One barrier per K tile t: before it every wave waits for its own DMA pieces of tile t, behind it tile t is
+// readable and tile t+1's DMA is issued into the stage of tile t-2.  Waves 0-3 then run k-slices 0-3 of tile t;
+// their SIMD partners 4-7 run half a tile behind (k-slices 2-3 of tile t-1, then 0-1 of tile t) -- see the main loop.
+#include "gemm_internal.h"
+
+namespace dlc_gemm {
+namespace {
+
+constexpr int TM3 = 256, TN3 = 128, TK3 = 16, NT3 = 512;
+constexpr int A_STAGE = TM3 * TK3 * 8;          // 32 KiB
+constexpr int B_STAGE = TN3 * TK3 * 8;          // 16 KiB
+constexpr int STAGE = A_STAGE + B_STAGE;        // 48 KiB
+constexpr int NSTAGE = 3;
+constexpr int LDS3 = NSTAGE * STAGE;            // 144 KiB
+
+struct DmaArgs {
+    const char* A; long long lda_b;             // plain: row stride in BYTES; conv: unused
+    const char* B; long long ldb_b;
+    const double* bias;
+    double* C; long long ldc;
+    long long M, N, K;
+    int act;
+    ConvGeom cv;
+    const char* zero;                           // >= 128 bytes of zeros
+    long long tiles_m, tiles_n, nbr, nblocks;
+    int br, bc;
+    int tri_p;
+    long long tri_row0, tri_col0;
+};
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA wave-instructions of one K tile: four 1 KiB pieces of the A stage (dma_a4), two of the B stage (dma_b2).
+// Inline asm so that hipcc does not count them in vmcnt (it would wait for vmcnt(0) in front of every LDS read); M0
+// carries the wave-uniform LDS destination and is saved / restored because the compiler owns it.  s_nop 4 covers
+// SGPR operands freshly written by v_readfirstlane.
+__device__ __forceinline__ void dma_a4(const char* a0, const char* a1, const char* a2, const char* a3, unsigned lds_a) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_add_u32 m0, %5, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_add_u32 m0, %5, 0x800\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, off\n\t"
+        "s_add_u32 m0, %5, 0xc00\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(lds_a)
+        : "memory", "scc");
+}
+__device__ __forceinline__ void dma_b2(const char* b0, const char* b1, unsigned lds_b) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_add_u32 m0, %3, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(b0), "v"(b1), "s"(lds_b)
+        : "memory", "scc");
+}
+
+__device__ __forceinline__ double act_f64(double z, int act) {
+    if (act == DLC_ACT_SIGMOID) return 1.0 / (1.0 + exp(-z));
+    if (act == DLC_ACT_RELU) return z > 0.0 ? z : 0.0;
+    return z;
+}
+
+// BLAYOUT: DLC_B_KN / DLC_B_NK.  CONV: A is the NHWC input of a convolution with C % 16 == 0 (a K tile is 16
+// consecutive channels of one kernel tap), B its HWIO kernel as [K,N].
+template <int BLAYOUT, bool CONV>
+__global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    // ---- workgroup id -> tile: blocks of br x bc = 32 tiles, one block per XCD at a time (gemm_dense.hip, tile order)
+    long long tile_m, tile_n;
+    {
+        const long long wg = blockIdx.x;
+        const long long l = wg >> 3;
+        const long long gb = (l >> 5) * 8 + (wg & 7);
+        if (gb >= p.nblocks) return;
+        const int i = (int)(l & 31);
+        tile_m = (gb % p.nbr) * p.br + (i % p.br);
+        tile_n = (gb / p.nbr) * p.bc + (i / p.br);
+        if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+    }
+    const long long m0 = tile_m * TM3, n0 = tile_n * TN3;
+    if (p.tri_p > 0 && (p.tri_col0 + n0 + TN3 - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;
+    const int nkt = (int)((p.K + TK3 - 1) / TK3);
+    const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem3;
+
+    // ---- DMA sources.  A (and an [N,K] B): instruction j of this wave covers rows 8 * (4w + j) .. + 7 of the stage,
+    // lane -> (row = lane >> 3, slot = lane & 7), source piece = slot ^ ((row >> 1) & 7).
+    const int slot = lane & 7;
+    const char* a_src[4];
+    int a_piece[4];                               // source piece (k offset 2 * piece doubles inside the K tile)
+    long long cv_base[4];                         // CONV: element offset of the row's image; iy0 / ix0 of its output pixel
+    int cv_iy0[4], cv_ix0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (w * 4 + j) * 8 + (lane >> 3);
+        a_piece[j] = slot ^ ((r >> 1) & 7);
+        long long gm = m0 + r;
+        if (gm > p.M - 1) gm = p.M - 1;
+        if constexpr (CONV) {
+            const long long img = gm / ((long long)p.cv.OH * p.cv.OW);
+            const int rem = (int)(gm - img * p.cv.OH * p.cv.OW);
+            const int oy = rem / p.cv.OW, ox = rem - oy * p.cv.OW;
+            cv_iy0[j] = oy * p.cv.stride - p.cv.pad_t;
+            cv_ix0[j] = ox * p.cv.stride - p.cv.pad_l;
+            cv_base[j] = img * (long long)p.cv.H * p.cv.W * p.cv.C;
+            a_src[j] = p.A;
+        } else {
+            a_src[j] = p.A + gm * p.lda_b + a_piece[j] * 16;
+        }
+    }
+    const char* b_src[2];
+    int b_piece[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if constexpr (BLAYOUT == DLC_B_NK) {
+            const int r = (w * 2 + j) * 8 + (lane >> 3);
+            b_piece[j] = slot ^ ((r >> 1) & 7);
+            long long gn = n0 + r;
+            if (gn > p.N - 1) gn = p.N - 1;
+            b_src[j] = p.B + gn * p.ldb_b + b_piece[j] * 16;
+        } else {
+            // [K,N]: instruction j covers k-row kr = 2w + j of the stage, lane -> 16-byte slot, source piece = slot ^ ((kr & 1) << 3)
+            const int kr = w * 2 + j;
+            int piece = lane ^ ((kr & 1) << 3);
+            const long long cols = p.N - n0 < TN3 ? p.N - n0 : TN3;      // valid columns of this tile (even: N is)
+            const int last = (int)(cols / 2) - 1;
+            if (piece > last) piece = last;                              // columns past N: never stored
+            b_piece[j] = kr;
+            b_src[j] = p.B + (long long)kr * p.ldb_b + n0 * 8 + piece * 16;
+        }
+    }
+    const char* zsrc = p.zero + slot * 16;
+    // wave-uniform kernel tap of the NEXT tile to issue (CONV): k0 = (ky * KW + kx) * C + c0
+    int cv_c0 = 0, cv_kx = 0, cv_ky = 0;
+
+    // The A part (4 instructions) and the B part (2) of K tile t's DMA, issued separately (see the main loop).
+    auto issue_a = [&](int t, int stage) {
+        const int tt = t < nkt ? t : nkt - 1;                            // past the end: the last tile again, into a dead stage
+        const long long k0 = (long long)tt * TK3;
+        const int klim = (int)(p.K - k0 < TK3 ? p.K - k0 : TK3);         // valid k of this tile (16 except in a K tail); selects, no branches
+        const char* sa[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (CONV) {
+                const int iy = cv_iy0[j] + cv_ky, ix = cv_ix0[j] + cv_kx;
+                const bool ok = iy >= 0 && iy < p.cv.H && ix >= 0 && ix < p.cv.W;
+                const long long e = cv_base[j] + ((long long)iy * p.cv.W + ix) * p.cv.C + cv_c0 + a_piece[j] * 2;
+                sa[j] = ok ? p.A + e * 8 : zsrc;
+            } else {
+                sa[j] = a_piece[j] * 2 >= klim ? zsrc : a_src[j] + k0 * 8;
+            }
+        }
+        if constexpr (CONV) {
+            if (t < nkt - 1) {                                           // step the tap; frozen once the last tile is reached
+                cv_c0 += TK3;
+                if (cv_c0 >= p.cv.C) {
+                    cv_c0 = 0;
+                    if (++cv_kx == p.cv.KW) { cv_kx = 0; ++cv_ky; }
+                }
+            }
+        }
+        dma_a4(sa[0], sa[1], sa[2], sa[3], lds_base + stage * STAGE + w * 4096);
+    };
+    auto issue_b = [&](int t, int stage) {
+        const int tt = t < nkt ? t : nkt - 1;
+        const long long k0 = (long long)tt * TK3;
+        const int klim = (int)(p.K - k0 < TK3 ? p.K - k0 : TK3);
+        const char* sb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (BLAYOUT == DLC_B_NK) sb[j] = b_piece[j] * 2 >= klim ? zsrc : b_src[j] + k0 * 8;
+            else sb[j] = b_piece[j] >= klim ? zsrc : b_src[j] + k0 * p.ldb_b;
+        }
+        dma_b2(sb[0], sb[1], lds_base + stage * STAGE + A_STAGE + w * 2048);
+    };
+
+    // ---- fragment read offsets (bytes inside a stage)
+    const int fr = lane & 15, fk = lane >> 4;
+    const int x7 = (fr >> 1) & 7;           // the rows' swizzle key: stage row = 16 * something + fr
+    int pk[4];                                    // slot offset of this lane's piece in k-slice kk (A and [N,K] B rows)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) pk[kk] = (((kk * 2 + (fk >> 1)) ^ x7) << 4) + (fk & 1) * 8;
+    int ra_off[4], rb_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra_off[i] = (wr * 64 + i * 16 + fr) * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (BLAYOUT == DLC_B_NK) rb_off[j] = A_STAGE + (wc * 64 + j * 16 + fr) * 128;
+        else rb_off[j] = A_STAGE + fk * 1024 + ((((wc * 32 + j * 8 + (fr >> 1)) ^ ((fk & 1) << 3))) << 4) + (fr & 1) * 8;
+    }
+
+    f64x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4_t){0, 0, 0, 0};
+
+    // fragments of one k-slice, double-buffered in registers: rd() reads slice kk of a stage into buffer b, mm() runs
+    // the 16 MFMAs of a buffer.  A slice's reads are always issued before the MFMAs of the slice in front of it.
+    double fa[2][4], fb[2][4];
+    auto rd = [&](const char* st, int kk, int b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[b][i] = *(const double*)(st + ra_off[i] + pk[kk]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const double*)(st + rb_off[j] + pk[kk]);
+            else fb[b][j] = *(const double*)(st + rb_off[j] + kk * 4096);
+        }
+    };
+    auto mm = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[b][i], fb[b][j], acc[i][j], 0, 0, 0);
+    };
+    // wait for this wave's DMA pieces (all that are in flight belong to the tile about to become readable), then the
+    // workgroup barrier: behind it that tile is visible to every wave and the stage of the tile two back is free
+    auto arrive = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef DLC_EXP_DMA_NO_BARRIER      // timing experiments only (wrong results)
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+    };
+    auto issue = [&](int t, int stage) {
+#ifdef DLC_EXP_DMA_NO_ISSUE        // timing experiments only (wrong results): only the first tile is ever loaded
+        if (t > 0) return;
+#endif
+        issue_a(t, stage);
+        issue_b(t, stage);
+    };
+    auto next_stage = [](int s_) { return s_ + 1 == NSTAGE ? 0 : s_ + 1; };
+
+    // The two waves of a SIMD (w and w + 4) run HALF A K TILE APART.  Run in phase, all eight waves leave a barrier
+    // together, issue their fragment reads together and wait for LDS together, with the matrix pipes empty; and they
+    // do so again wherever the compiler batches reads.  Out of phase, the late wave of each SIMD crosses barrier t
+    // with the fragments of k-slice 2 of tile t-1 already in registers and issues MFMAs at once, while the early
+    // wave reads k-slice 0 of tile t; half a tile later the roles are swapped.  Tile t+1's DMA is issued behind
+    // barrier t into the stage of tile t-2, whose last readers (the late waves, k-slices 2-3, during iteration t-1)
+    // are through; it has a whole iteration to land.  Both groups execute nkt + 1 barriers.
+    issue(0, 0);
+    int cur = 0;
+    if (w < 4) {
+        for (int t = 0; t < nkt; ++t) {
+            arrive();                                                    // barrier t
+            const char* st = smem3 + cur * STAGE;
+            const int nxt = next_stage(cur);
+            rd(st, 0, 0);
+            if (t + 1 < nkt) issue(t + 1, nxt);
+            rd(st, 1, 1); mm(0);
+            rd(st, 2, 0); mm(1);
+            rd(st, 3, 1); mm(0);
+            mm(1);
+            cur = nxt;
+        }
+        arrive();                                                        // barrier nkt (the late waves' last half tile)
+    } else {
+        {                                                                // t = 0: the first half of tile 0
+            arrive();
+            const char* st = smem3;
+            rd(st, 0, 0);
+            if (1 < nkt) issue(1, 1);
+            rd(st, 1, 1); mm(0);
+            rd(st, 2, 0); mm(1);                                         // buffer 0 now holds k-slice 2 of tile 0
+        }
+        for (int t = 1; t < nkt; ++t) {
+            arrive();                                                    // barrier t
+            const char* sp = smem3 + cur * STAGE;                        // tile t-1
+            const int nxt = next_stage(cur);
+            const char* st = smem3 + nxt * STAGE;                        // tile t
+            rd(sp, 3, 1); mm(0);
+            if (t + 1 < nkt) issue(t + 1, next_stage(nxt));
+            rd(st, 0, 0); mm(1);
+            rd(st, 1, 1); mm(0);
+            rd(st, 2, 0); mm(1);
+            cur = nxt;
+        }
+        arrive();                                                        // barrier nkt
+        const char* sp = smem3 + cur * STAGE;
+        rd(sp, 3, 1); mm(0);
+        mm(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup's LDS
+
+    // ---- epilogue: bias + activation, C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long gn = n0 + wc * 64 + j * 16 + fr;
+        if (gn >= p.N) continue;
+        const double bv = p.bias ? p.bias[gn] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long gm = m0 + wr * 64 + i * 16 + fk + 4 * r;
+                if (gm < p.M) p.C[gm * p.ldc + gn] = act_f64(acc[i][j][r] + bv, p.act);
+            }
+    }
+}
+
+template <int BLAYOUT, bool CONV>
+int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
+    auto kern = gemm_dma_f64_kernel<BLAYOUT, CONV>;
+    const unsigned long long m = 1ull << (DLC_ATTR_DMA64_BASE + (CONV ? 2 : (BLAYOUT == DLC_B_KN ? 0 : 1)));
+    if (!(ctx->func_attr_set & m)) {
+        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3));
+        ctx->func_attr_set |= m;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(NT3), LDS3, st, a);
+    return DLC_OK;
+}
+
+}  // namespace
+
+int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
+                   const ConvGeom* cv, const TriSkip* tri) {
+#ifdef DLC_EXP_NO_DMA_GEMM      // experiment build: always the register-staged kernel
+    return 1;
+#endif
+    // 16-byte pieces: operand rows must start on 16-byte boundaries and K, N be even (a piece = 2 doubles)
+    if (!ctx->zero_page || (K & 1) || (N & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 1)) return 1;
+    if (cv) {
+        if (blayout != DLC_B_KN || cv->C % TK3 != 0) return 1;
+    } else if (lda & 1) {
+        return 1;
+    }
+    // worth a 256 x 128 tile per CU only when the launch fills the chip a few times over
+    const int64_t tiles_m = dlc::cdiv(M, TM3), tiles_n = dlc::cdiv(N, TN3);
+    if (tiles_m * tiles_n < 512 || K < 4 * TK3) return 1;
+    DmaArgs a;
+    a.A = (const char*)A; a.lda_b = lda * 8; a.B = (const char*)B; a.ldb_b = ldb * 8;
+    a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
+    a.cv = cv ? *cv : ConvGeom{};
+    a.zero = (const char*)ctx->zero_page;
+    a.tiles_m = tiles_m; a.tiles_n = tiles_n;
+    a.tri_p = tri ? tri->p : 0; a.tri_row0 = tri ? tri->row0 : 0; a.tri_col0 = tri ? tri->col0 : 0;
+    // block of 32 tiles (one XCD's 32 CUs): 4 row tiles x 8 column tiles = 1024 x 1024 outputs, narrower where the
+    // matrix has fewer tiles along a dimension (powers of two)
+    int bc = 8;
+    while (bc > 1 && bc / 2 >= tiles_n) bc /= 2;
+    int br = 32 / bc;
+    if (tiles_m < br) {
+        br = 1;
+        while (br < tiles_m) br *= 2;
+        bc = 32 / br;
+    }
+    a.br = br; a.bc = bc;
+    a.nbr = dlc::cdiv(tiles_m, (int64_t)br);
+    a.nblocks = a.nbr * dlc::cdiv(tiles_n, (int64_t)bc);
+    const long long nwg = dlc::cdiv(a.nblocks, (int64_t)8) * 8 * 32;
+    if (nwg > 0x7fffffffll) return 1;
+    const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
+    if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
+    int rc;
+    if (cv) rc = launch_one<DLC_B_KN, true>(ctx, a, nwg, st);
+    else if (blayout == DLC_B_KN) rc = launch_one<DLC_B_KN, false>(ctx, a, nwg, st);
+    else rc = launch_one<DLC_B_NK, false>(ctx, a, nwg, st);
+    if (rc != DLC_OK) return rc;
+    DLC_LAUNCH_CHECK(ctx, "gemm_dma_f64_kernel");
+    if (ctx->profiling) {
+        DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[prof_slot], st));
+        ctx->prof_calls++;
+    }
+    return DLC_OK;
+}
+
+}  // namespace dlc_gemm

@@ -258,6 +258,9 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H) {
     const size_t row_bytes = (size_t)N * P * 8;
     long long cf = (long long)((1ull << 30) / (row_bytes * (size_t)P));
     if (cf < 1) cf = 1;
+    // whole 256-row tiles of the Gram GEMM (gemm_dma_f64.hip) where the chunk allows: cf * P a multiple of 256
+    for (long long q = 256; q >= 8; q /= 2)
+        if (cf >= q && (q * P) % 256 == 0) { cf = cf / q * q; break; }
     if (cf > N) cf = N;
     w.chunk_frames = cf;
     w.gram = o; o += dlc::align_up((size_t)cf * P * row_bytes, 256);

@@ -19,7 +19,7 @@ summary = {"tag": tag, "command": "rocprofv3 --kernel-trace [--stats | --pmc ...
                     "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (gfx950: double FETCH_SIZE for wide streams)",
            "kernels": {}}
 for row in csv.DictReader(open(stats)):
-    if "gemm_bias_act_kernel" in row["Name"] or "pair_score" in row["Name"] or "distinctive" in row["Name"]:
+    if "gemm_bias_act_kernel" in row["Name"] or "gemm_dma_f64_kernel" in row["Name"] or "pair_score" in row["Name"] or "distinctive" in row["Name"]:
         summary["kernels"].setdefault(row["Name"], {}).update(avg_ns=float(row["AverageNs"]), calls=int(row["Calls"]),
                                                                total_ns=float(row["TotalDurationNs"]))
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):

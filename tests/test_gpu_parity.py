@@ -827,3 +827,90 @@ def test_error_paths_raise_value_error(eng, dlc):
 
 from deeploopcloser_amd._lib import DlcError as _DlcError   # noqa: E402
 L_ERRORS = (_DlcError, ValueError)
+
+
+def test_row_stride_bound_and_buffer_validation(eng, dlc):
+    """The score GEMM addresses a lane's bytes as a 32-bit offset inside its 256-row tile: row strides for which
+    255 rows would not fit below 4 GiB are refused (DLC_ERR_BAD_SHAPE), not wrapped.  Caller-supplied output
+    buffers of the wrong shape / dtype / layout are refused before any pointer reaches a kernel."""
+    import ctypes as C
+    L = dlc._lib
+    q = torch.zeros((4, 64), dtype=torch.bfloat16, device=eng.device)
+    s = torch.empty((4, 2), dtype=torch.float32, device=eng.device)
+    i = torch.empty((4, 2), dtype=torch.int64, device=eng.device)
+    need = eng.lib.dlc_cosine_topk_workspace_bytes(4, 4, 64, 2)
+    ws = torch.empty(need, dtype=torch.uint8, device=eng.device)
+    big = (1 << 32) // (2 * 255) // 8 * 8 + 8                       # elements: 255 rows x 2 bytes >= 4 GiB
+    for ldq, lddb in ((64, big), (big, 64)):
+        rc = eng.lib.dlc_cosine_topk(eng.ctx, L.DLC_BF16, C.c_void_p(q.data_ptr()), 4, ldq, C.c_void_p(q.data_ptr()), 1, lddb,
+                                     64, 2, 0, C.c_void_p(s.data_ptr()), C.c_void_p(i.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                     ws.numel(), None)
+        assert rc == L.DLC_ERR_BAD_SHAPE and b"stride" in eng.lib.dlc_last_error(eng.ctx)
+    ok = (1 << 32) // (2 * 255) // 8 * 8 - 64                       # just below the bound: accepted (one row: the stride is unused)
+    rc = eng.lib.dlc_cosine_topk(eng.ctx, L.DLC_BF16, C.c_void_p(q.data_ptr()), 1, ok, C.c_void_p(q.data_ptr()), 1, ok, 64, 1, 0,
+                                 C.c_void_p(s.data_ptr()), C.c_void_p(i.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), None)
+    torch.cuda.synchronize()
+    assert rc == L.DLC_OK
+    for bad in ((s[:, :1], i), (s, i.to(torch.int32)), (s.t().contiguous().t(), i), (s.cpu(), i)):
+        with pytest.raises(ValueError):
+            eng.match_topk(q, q, 2, out=bad)
+    with pytest.raises(ValueError):
+        eng.select_topk(q, q, 2, ws, s[:2], i)
+    with pytest.raises(ValueError):
+        eng.topk_merge(torch.zeros((2, 4, 2), device=eng.device), torch.zeros((2, 4, 2), dtype=torch.int64, device=eng.device),
+                       out=(s[:3], i))
+    with pytest.raises(ValueError):
+        eng.gemm_bias_act(torch.zeros((4, 5), dtype=torch.float64, device=eng.device),
+                          torch.zeros((5, 7), dtype=torch.float64, device=eng.device),
+                          out=torch.zeros((4, 6), dtype=torch.float64, device=eng.device))
+
+
+def test_two_contexts_two_devices(dlc):
+    """One context per GPU: the kernels' dynamic-LDS limits are set per DEVICE (the flags live in the context), so a
+    second context on another GPU of the same process runs the 128 KiB score GEMM too.  Needs two visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the per-device attribute path needs two")
+    rng = np.random.RandomState(1)
+    x = rng.standard_normal((3000, 256)).astype(np.float32)
+    res = []
+    for dev in (0, 1):
+        e = dlc.default_engine(dev)
+        with torch.cuda.device(dev):
+            st = e.normalize(torch.from_numpy(x).to(e.device), "bf16")
+            s_, i_ = e.match_topk(st[:300], st, 5)
+            h = e.gemm_bias_act(torch.ones((200, 300), dtype=torch.float64, device=e.device),
+                                torch.ones((300, 130), dtype=torch.float64, device=e.device))
+            torch.cuda.synchronize(dev)
+            assert float(h.min()) == 300.0 == float(h.max())
+            res.append((s_.cpu(), i_.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_normalize_one_pass_forms_vs_reference_rounding(eng):
+    """dlc_l2_normalize_rows: the wave-per-row and workgroup-per-row register forms and the multi-pass fall-back
+    (wide rows, unaligned rows) against the same fp64 formula, for fp32 / fp64 sources and both stored types."""
+    rng = np.random.RandomState(5)
+    for d in (64, 100, 1000, 4096, 4097, 5000, 16384, 16400, 75000):
+        for src in (np.float32, np.float64):
+            x = rng.standard_normal((7, d)).astype(src)
+            for center in (False, True):
+                for dt, tdt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+                    got = eng.normalize(torch.from_numpy(x).to(eng.device), dt, center)
+                    assert got.shape == (7, (d + 63) // 64 * 64) and got.dtype == tdt
+                    y = x.astype(np.float64) - (x.astype(np.float64).mean(1, keepdims=True) if center else 0.0)
+                    ref = torch.from_numpy((y / np.linalg.norm(y, axis=1, keepdims=True)).astype(np.float32)).to(tdt).float().numpy()
+                    g = got.float().cpu().numpy()
+                    assert np.all(g[:, d:] == 0)
+                    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+                    assert np.abs(g[:, :d] - ref).max() <= ulp * np.abs(ref).max() and (g[:, :d] == ref).mean() > 0.998, (d, src, center, dt)
+    # a strided (unaligned) source view takes the multi-pass kernel: same values as the aligned copy
+    x = torch.from_numpy(rng.standard_normal((5, 1001)).astype(np.float32)).to(eng.device)
+    a = eng.normalize(x[:, 1:].contiguous(), "bf16")
+    wide = torch.zeros((5, 1003), dtype=torch.float32, device=eng.device)
+    wide[:, 3:] = x[:, 1:]
+    rc_view = wide[:, 3:]
+    out = torch.empty_like(a)
+    eng._check(eng.lib.dlc_l2_normalize_rows(eng.ctx, dlc._lib.DLC_F32, rc_view.data_ptr(), 5, 1000, rc_view.stride(0), 0,
+                                              dlc._lib.DLC_BF16, out.data_ptr(), out.stride(0), None))
+    torch.cuda.synchronize()
+    assert (a.float() - out.float()).abs().max().item() <= 2.0 ** -8
