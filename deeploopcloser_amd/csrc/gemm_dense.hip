@@ -522,12 +522,13 @@ int gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int6
     return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "gemm: dtype %d (need DLC_F64 or DLC_F32)", dtype);
 }
 
-// Gram block of the SDAV similarity (match_ref.hip): C = A . B^T in fp64 with B stored [N,K], tiles that hold no
-// (row frame < column frame) entry skipped (their part of C stays unwritten and is never read).
-int gram_upper_f64(dlc_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
-                   int64_t ldb, double* C, int64_t ldc, int patches, int64_t row0, int64_t col0, hipStream_t st) {
+// Gram block of the SDAV similarity (match_ref.hip): C = A . B^T in fp64 (B stored [N,K], or its transpose stored
+// [K,N]), tiles that hold no (row frame < column frame) entry skipped (their part of C stays unwritten, never read).
+int gram_upper_f64(dlc_ctx* ctx, int blayout, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double* C, int64_t ldc, int patches, int64_t row0, int64_t col0,
+                   hipStream_t st) {
     TriSkip tri{patches, row0, col0};
-    return launch<double>(ctx, DLC_B_NK, DLC_ACT_NONE, M, N, K, A, lda, B, ldb, nullptr, C, ldc, st, nullptr, &tri);
+    return launch<double>(ctx, blayout, DLC_ACT_NONE, M, N, K, A, lda, B, ldb, nullptr, C, ldc, st, nullptr, &tri);
 }
 
 int conv2d_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, const double* x, const double* w,

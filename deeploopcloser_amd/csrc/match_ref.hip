@@ -10,8 +10,9 @@
 #include "dlc_internal.h"
 
 namespace dlc_gemm {
-int gram_upper_f64(dlc_ctx* ctx, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B,
-                   int64_t ldb, double* C, int64_t ldc, int patches, int64_t row0, int64_t col0, hipStream_t st);
+int gram_upper_f64(dlc_ctx* ctx, int blayout, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double* C, int64_t ldc, int patches, int64_t row0, int64_t col0,
+                   hipStream_t st);
 }
 
 namespace {
@@ -236,6 +237,70 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
     }
 }
 
+// The same for P <= 32 patches per frame (the reference: 30) with the Gram rows read COALESCED: a lane is a patch b
+// of frame j, the two halves of the wave take two patches a of frame i at a time, so one load instruction fetches
+// two 8*P-byte row segments (the form above has lane = a: every lane walks its own row, 30 scattered 8-byte reads
+// per instruction, 0.6 TB/s from L2).  Same arithmetic per (a, b), first minimum = lowest b among the lanes that
+// hold the half's minimum, the per-patch terms end up in lanes 0..P-1 and are summed by the same xor tree.
+__global__ __launch_bounds__(256) void pair_score_rows_kernel(const double* __restrict__ desc, const double* __restrict__ G,
+                                                              long long ldg, long long col0, const double* __restrict__ nrm2,
+                                                              const double* __restrict__ proj,
+                                                              const double* __restrict__ score, long long N, int P, int H,
+                                                              long long i_lo, long long i_hi, double ca, double cb,
+                                                              double* __restrict__ out_f64, long long* __restrict__ out_i64) {
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long i = i_lo + blockIdx.y;
+    if (i >= i_hi || j >= N || j <= i) return;                  // wave-uniform
+    const int half = lane >> 5, b = lane & 31;
+    const bool bok = b < P;
+    const double nbv = bok ? nrm2[j * P + b] : 0.0;
+    const double* gcol = G + (j * P - col0) + (bok ? b : 0);
+    double myterm = 0.0;
+    for (int a0 = 0; a0 < P; a0 += 2) {
+        const int a = a0 + half;
+        const bool aok = a < P;
+        const long long ra = i * P + (aok ? a : 0);
+        double dist = INFINITY;
+        if (aok && bok) {
+            double d2 = nrm2[ra] + nbv - 2.0 * gcol[(ra - i_lo * P) * ldg];
+            d2 = d2 > 0.0 ? d2 : 0.0;
+            dist = sqrt(d2);                                    // np.linalg.norm, :34
+        }
+        double m = dist;
+        for (int o = 16; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));      // minimum of this half (32 lanes)
+        const unsigned long long hit = __ballot(dist == m);
+        const unsigned mine = half ? (unsigned)(hit >> 32) : (unsigned)hit;
+        const int bi = mine ? __ffs(mine) - 1 : 0;              // np.argmin: first minimum
+        double term = 0.0;
+        if (aok) {
+            const long long rb = j * P + bi;
+            double wd = fabs(proj[ra] - proj[rb]);              // |dot(score, m_i - m_j*)|, :42-43
+            if (wd < 1e-6 * (fabs(proj[ra]) + fabs(proj[rb]))) {    // cancellation: evaluate the difference directly
+                const double* xa = desc + ra * H;
+                const double* xb = desc + rb * H;
+                double s = 0.0;
+                for (int k = 0; k < H; ++k) s = fma(score[k], xa[k] - xb[k], s);
+                wd = fabs(s);
+            }
+            term = ca + cb * log(wd);                           // :48
+        }
+        const double t1 = __shfl(term, 32);                     // patch a0 + 1 was worked out by the upper half
+        if (lane == a0) myterm = term;
+        if (lane == a0 + 1 && a0 + 1 < P) myterm = t1;
+    }
+    for (int o = 32; o > 0; o >>= 1) myterm += __shfl_xor(myterm, o);
+    if (lane == 0) {
+        out_f64[i * N + j] = myterm;
+        out_f64[j * N + i] = myterm;
+        if (out_i64) {
+            const long long t = f64_to_i64_trunc(myterm);
+            out_i64[i * N + j] = t;
+            out_i64[j * N + i] = t;
+        }
+    }
+}
+
 __global__ void fill_diag_kernel(long long N, double* out_f64, long long* out_i64) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -243,8 +308,21 @@ __global__ void fill_diag_kernel(long long N, double* out_f64, long long* out_i6
     if (out_i64) out_i64[i * N + i] = -1;
 }
 
+// out[c, r] = in[r, c] through a padded LDS tile (32 x 32)
+__global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __restrict__ in, long long rows, long long cols,
+                                                            double* __restrict__ out) {
+    __shared__ double tile[32][33];
+    const long long r0 = (long long)blockIdx.x * 32, c0 = (long long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
 struct SimWs {
-    size_t nrm2, proj, gram, total;
+    size_t nrm2, proj, gram, desc_t, total;
     long long chunk_frames;
 };
 
@@ -264,6 +342,11 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H) {
     if (cf > N) cf = N;
     w.chunk_frames = cf;
     w.gram = o; o += dlc::align_up((size_t)cf * P * row_bytes, 256);
+    // the descriptors transposed [H, N*P] (one extra pass over them): the Gram blocks then read their B operand as
+    // [K,N] -- 1 KiB contiguous per k-row and tile instead of 128 scattered 128-byte row segments (an even N*P keeps
+    // the rows 16-byte aligned for the LDS-DMA kernel; an odd one falls back to the [N,K] form)
+    w.desc_t = o;
+    if (((N * P) & 1) == 0) o += dlc::align_up((size_t)N * P * H * 8, 256);
     w.total = o;
     return w;
 }
@@ -337,6 +420,13 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
     double* proj = (double*)(ws + w.proj);
     double* gram = (double*)(ws + w.gram);
     const long long rows = N * P;
+    const bool use_t = (rows & 1) == 0;
+    double* desc_t = (double*)(ws + w.desc_t);
+    if (use_t) {
+        hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)dlc::cdiv(rows, 32), (unsigned)dlc::cdiv(H, 32)), dim3(256), 0, st,
+                           desc, rows, (long long)H, desc_t);
+        DLC_LAUNCH_CHECK(ctx, "transpose_f64_kernel");
+    }
 
     hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)dlc::cdiv(rows, 4)), dim3(256), 0, st, desc, rows, (int)H, score,
                        nrm2, proj);
@@ -354,12 +444,18 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         const long long ncols = rows - col0;
         const long long mrows = (i_hi - i_lo) * P;
         // only entries with (row frame < column frame) are read below: tiles under the diagonal are skipped
-        int rc = dlc_gemm::gram_upper_f64(ctx, mrows, ncols, H, desc + i_lo * P * H, H, desc + col0 * H, H, gram, ncols,
-                                          (int)P, i_lo * P, col0, st);
+        int rc = use_t ? dlc_gemm::gram_upper_f64(ctx, DLC_B_KN, mrows, ncols, H, desc + i_lo * P * H, H, desc_t + col0, rows, gram,
+                                                  ncols, (int)P, i_lo * P, col0, st)
+                       : dlc_gemm::gram_upper_f64(ctx, DLC_B_NK, mrows, ncols, H, desc + i_lo * P * H, H, desc + col0 * H, H, gram,
+                                                  ncols, (int)P, i_lo * P, col0, st);
         if (rc != DLC_OK) return rc;
         dim3 grid((unsigned)dlc::cdiv(N, 4), (unsigned)(i_hi - i_lo));
-        hipLaunchKernelGGL(pair_score_kernel, grid, dim3(256), 0, st, desc, gram, ncols, col0, nrm2, proj, score,
-                           (long long)N, (int)P, (int)H, i_lo, i_hi, a, b, out_f64, (long long*)out_i64);
+        if (P <= 32)
+            hipLaunchKernelGGL(pair_score_rows_kernel, grid, dim3(256), 0, st, desc, gram, ncols, col0, nrm2, proj, score,
+                               (long long)N, (int)P, (int)H, i_lo, i_hi, a, b, out_f64, (long long*)out_i64);
+        else
+            hipLaunchKernelGGL(pair_score_kernel, grid, dim3(256), 0, st, desc, gram, ncols, col0, nrm2, proj, score,
+                               (long long)N, (int)P, (int)H, i_lo, i_hi, a, b, out_f64, (long long*)out_i64);
         DLC_LAUNCH_CHECK(ctx, "pair_score_kernel");
     }
     return DLC_OK;

@@ -886,7 +886,7 @@ def test_two_contexts_two_devices(dlc):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
-def test_normalize_one_pass_forms_vs_reference_rounding(eng):
+def test_normalize_one_pass_forms_vs_reference_rounding(eng, dlc):
     """dlc_l2_normalize_rows: the wave-per-row and workgroup-per-row register forms and the multi-pass fall-back
     (wide rows, unaligned rows) against the same fp64 formula, for fp32 / fp64 sources and both stored types."""
     rng = np.random.RandomState(5)
