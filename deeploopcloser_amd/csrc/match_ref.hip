@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
 // of frame j, the two halves of the wave take two patches a of frame i at a time, so one load instruction fetches
 // two 8*P-byte row segments (the form above has lane = a: every lane walks its own row, 30 scattered 8-byte reads
 // per instruction, 0.6 TB/s from L2).  Same arithmetic per (a, b), first minimum = lowest b among the lanes that
-// hold the half's minimum, the per-patch terms end up in lanes 0..P-1 and are summed by the same xor tree.
+// hold the half's minimum; lane a then holds the index of its nearest patch and the rest (weighted distance, log,
+// the xor-tree sum over lanes 0..P-1) is the general kernel's.
 __global__ __launch_bounds__(256) void pair_score_rows_kernel(const double* __restrict__ desc, const double* __restrict__ G,
                                                               long long ldg, long long col0, const double* __restrict__ nrm2,
                                                               const double* __restrict__ proj,
@@ -256,38 +257,45 @@ __global__ __launch_bounds__(256) void pair_score_rows_kernel(const double* __re
     const bool bok = b < P;
     const double nbv = bok ? nrm2[j * P + b] : 0.0;
     const double* gcol = G + (j * P - col0) + (bok ? b : 0);
-    double myterm = 0.0;
-    for (int a0 = 0; a0 < P; a0 += 2) {
-        const int a = a0 + half;
-        const bool aok = a < P;
-        const long long ra = i * P + (aok ? a : 0);
+    // pass 1: the nearest patch of frame j for every patch a of frame i (two a per step); every Gram load is
+    // independent of the others, so all 16 steps' loads are in flight together.  Lane a ends up with bi(a).
+    double g[16];
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+        const int a = 2 * s_ + half;
+        g[s_] = (a < P && bok) ? gcol[(i * P + a - i_lo * P) * ldg] : 0.0;
+    }
+    int mybi = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+        const int a = 2 * s_ + half;
         double dist = INFINITY;
-        if (aok && bok) {
-            double d2 = nrm2[ra] + nbv - 2.0 * gcol[(ra - i_lo * P) * ldg];
+        if (a < P && bok) {
+            double d2 = nrm2[i * P + a] + nbv - 2.0 * g[s_];
             d2 = d2 > 0.0 ? d2 : 0.0;
             dist = sqrt(d2);                                    // np.linalg.norm, :34
         }
         double m = dist;
         for (int o = 16; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));      // minimum of this half (32 lanes)
         const unsigned long long hit = __ballot(dist == m);
-        const unsigned mine = half ? (unsigned)(hit >> 32) : (unsigned)hit;
-        const int bi = mine ? __ffs(mine) - 1 : 0;              // np.argmin: first minimum
-        double term = 0.0;
-        if (aok) {
-            const long long rb = j * P + bi;
-            double wd = fabs(proj[ra] - proj[rb]);              // |dot(score, m_i - m_j*)|, :42-43
-            if (wd < 1e-6 * (fabs(proj[ra]) + fabs(proj[rb]))) {    // cancellation: evaluate the difference directly
-                const double* xa = desc + ra * H;
-                const double* xb = desc + rb * H;
-                double s = 0.0;
-                for (int k = 0; k < H; ++k) s = fma(score[k], xa[k] - xb[k], s);
-                wd = fabs(s);
-            }
-            term = ca + cb * log(wd);                           // :48
+        const unsigned lo = (unsigned)hit, hi = (unsigned)(hit >> 32);
+        const int bi0 = lo ? __ffs(lo) - 1 : 0, bi1 = hi ? __ffs(hi) - 1 : 0;   // np.argmin: first minimum
+        if (lane == 2 * s_) mybi = bi0;
+        if (lane == 2 * s_ + 1) mybi = bi1;
+    }
+    // pass 2: one patch of frame i per lane, as the general kernel
+    double myterm = 0.0;
+    if (lane < P) {
+        const long long ra = i * P + lane, rb = j * P + mybi;
+        double wd = fabs(proj[ra] - proj[rb]);                  // |dot(score, m_i - m_j*)|, :42-43
+        if (wd < 1e-6 * (fabs(proj[ra]) + fabs(proj[rb]))) {    // cancellation: evaluate the difference directly
+            const double* xa = desc + ra * H;
+            const double* xb = desc + rb * H;
+            double s = 0.0;
+            for (int k = 0; k < H; ++k) s = fma(score[k], xa[k] - xb[k], s);
+            wd = fabs(s);
         }
-        const double t1 = __shfl(term, 32);                     // patch a0 + 1 was worked out by the upper half
-        if (lane == a0) myterm = term;
-        if (lane == a0 + 1 && a0 + 1 < P) myterm = t1;
+        myterm = ca + cb * log(wd);                             // :48
     }
     for (int o = 32; o > 0; o >>= 1) myterm += __shfl_xor(myterm, o);
     if (lane == 0) {
