@@ -244,18 +244,25 @@ def bench_paths(eng, n_frames):
         score = eng.distinctive_score(desc, 0.5, 0.2)
         return eng.sdav_similarity_matrix(desc, score, 10.0, -10.0)
     call_ms, k_ms, k_n, (mf, mi) = _timed_path(eng, sim, reps=2)
-    # Gram GEMMs as dlc_sdav_similarity_matrix launches them (match_ref.hip sim_ws): row chunks of <= 1 GiB,
-    # frames [i_lo, i_hi) against every later frame
-    cf = max(1, (1 << 30) // (N * P * 8 * P))
-    for q_ in (256, 128, 64, 32, 16, 8):
-        if cf >= q_ and (q_ * P) % 256 == 0:
-            cf = cf // q_ * q_
-            break
+    # Gram GEMMs as dlc_sdav_similarity_matrix launches them (match_ref.hip sim_ws): row chunks of <= 8 GiB,
+    # frames [i_lo, i_hi) against every later frame; tiles under the diagonal are skipped, so the flops counted
+    # are the upper triangle's (what the similarity needs), not the launched rectangle's
+    cf = max(1, (8 << 30) // (N * P * 8 * P))
+    if cf >= N - 1:
+        cf = max(N - 1, 1)
+    else:
+        for q_ in (256, 128, 64, 32, 16, 8):
+            if cf >= q_ and (q_ * P) % 256 == 0:
+                cf = cf // q_ * q_
+                break
     cf = min(cf, N)
     flops, i_lo = 0.0, 0
     while i_lo + 1 < N:
         i_hi = min(i_lo + cf, N - 1)
-        flops += 2.0 * (i_hi - i_lo) * P * (N * P - (i_lo + 1) * P) * H
+        # rows of frames [i_lo, i_hi) x columns of frames > i_lo, minus the (skipped) lower triangle inside the chunk
+        rect = (i_hi - i_lo) * P * (N * P - (i_lo + 1) * P)
+        lower = (i_hi - i_lo - 1) * (i_hi - i_lo) / 2.0 * P * P
+        flops += 2.0 * (rect - lower) * H
         i_lo += cf
     pairs = N * (N - 1) // 2
     ns = min(N, 20)                                           # the reference-literal per-pair loop at datasets/test size

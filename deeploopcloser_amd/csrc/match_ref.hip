@@ -340,13 +340,19 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H) {
     (void)H;
     w.nrm2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
     w.proj = o; o += dlc::align_up((size_t)N * P * 8, 256);
-    // Gram row chunk: at most ~1 GiB, at least one frame
+    // Gram row chunk: at most ~8 GiB of the 288 GB (the work is triangular, so every chunk's launch is smaller than
+    // the one before and each pays its own last partial round of the chip: 1063 frames in 9 chunks of <= 1 GiB lost
+    // ~5 % to that; 8 GiB holds all of them in one), at least one frame
     const size_t row_bytes = (size_t)N * P * 8;
-    long long cf = (long long)((1ull << 30) / (row_bytes * (size_t)P));
+    long long cf = (long long)((8ull << 30) / (row_bytes * (size_t)P));
     if (cf < 1) cf = 1;
-    // whole 256-row tiles of the Gram GEMM (gemm_dma_f64.hip) where the chunk allows: cf * P a multiple of 256
-    for (long long q = 256; q >= 8; q /= 2)
-        if (cf >= q && (q * P) % 256 == 0) { cf = cf / q * q; break; }
+    if (cf >= N - 1) {
+        cf = N > 1 ? N - 1 : 1;                  // everything at once (the last frame has no later frame to pair with)
+    } else {
+        // whole 256-row tiles of the Gram GEMM (gemm_dma_f64.hip) where the chunk allows: cf * P a multiple of 256
+        for (long long q = 256; q >= 8; q /= 2)
+            if (cf >= q && (q * P) % 256 == 0) { cf = cf / q * q; break; }
+    }
     if (cf > N) cf = N;
     w.chunk_frames = cf;
     w.gram = o; o += dlc::align_up((size_t)cf * P * row_bytes, 256);
