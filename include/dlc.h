@@ -222,6 +222,9 @@ int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows
  * score [H] comes from dlc_sdav_distinctive_score.  out_f64 [N,N] receives the
  * float scores (+inf where a matched pair is identical); out_i64 (may be NULL)
  * the reference's int64 matrix (truncation toward zero, non-finite -> INT64_MIN).
+ * The workspace holds the descriptors' transpose and the patch-to-patch Gram blocks, in row chunks
+ * of at most 8 GiB: sized for 288 GB of HBM, it is 8.7 GB at the reference's 1063 frames (one chunk)
+ * and stays below 9.5 GB + N*P*H*8 bytes for any N.
  */
 size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int64_t H);
 int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H,
