@@ -914,3 +914,31 @@ def test_normalize_one_pass_forms_vs_reference_rounding(eng, dlc):
                                               dlc._lib.DLC_BF16, out.data_ptr(), out.stride(0), None))
     torch.cuda.synchronize()
     assert (a.float() - out.float()).abs().max().item() <= 2.0 ** -8
+
+
+@pytest.mark.parametrize("m,n,k,blayout", [(33000, 770, 338, "kn"), (65537, 256, 64, "kn"), (40000, 514, 1002, "nk"),
+                                           (70000, 128, 2500, "nk"), (257 * 128, 1026, 70, "kn")])
+def test_gemm_dma_kernel_edges(eng, m, n, k, blayout):
+    """Launches large enough for the LDS-DMA fp64 kernel (>= 512 tiles of 256 x 128, even K / N / strides), with every
+    edge it clamps or masks: M, N not multiples of the tile, a K tail that ends inside a 16-byte piece's pair and one
+    that ends inside a K tile, both B layouts -- against a torch fp64 product (the checker), and bit-identical to the
+    register-staged kernel, reached by giving A an odd row stride (8-byte-aligned rows cannot be DMA'd)."""
+    from deeploopcloser_amd import _lib as L
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(m + n + k)
+    a = torch.randn((m, k), generator=g, device=eng.device, dtype=torch.float64) / k ** 0.5
+    b = torch.randn((k, n) if blayout == "kn" else (n, k), generator=g, device=eng.device, dtype=torch.float64)
+    bias = torch.randn((n,), generator=g, device=eng.device, dtype=torch.float64)
+    lay = L.DLC_B_KN if blayout == "kn" else L.DLC_B_NK
+    got = eng.gemm_bias_act(a, b, bias, act=L.DLC_ACT_SIGMOID, blayout=lay)
+    ref = torch.sigmoid(a @ (b if blayout == "kn" else b.T) + bias)
+    assert float((got - ref).abs().max()) < 1e-12
+    # the same operands with an odd leading dimension of A: the register-staged kernel, same k order -> same bits
+    import ctypes as C
+    wide = torch.zeros((m, k + 1), dtype=torch.float64, device=eng.device)
+    wide[:, :k] = a
+    out = torch.empty((m, n), dtype=torch.float64, device=eng.device)
+    eng._check(eng.lib.dlc_gemm_bias_act(eng.ctx, L.DLC_F64, lay, L.DLC_ACT_SIGMOID, m, n, k, wide.data_ptr(), k + 1,
+                                          b.data_ptr(), b.stride(0), bias.data_ptr(), out.data_ptr(), n, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, got)
