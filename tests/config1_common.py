@@ -57,3 +57,17 @@ def oracle_cosine(h, n):
     """The N x N cosine matrix of the flattened [30*2500] place descriptors (mean-centred), fp64."""
     place = ocos.l2_normalize(h.reshape(n, -1), center=True)
     return ocos.scores(place, place)
+
+
+def bgr_frames(paths):
+    """The frames as create_distance_matrix.py:23 feeds them: cv2.imread order (BGR), uint8 values as float64."""
+    return np.stack([opatch.read_ppm(p)[:, :, ::-1] for p in paths]).astype(np.float64)
+
+
+def oracle_cnn_descriptors(paths, seed=3, mask_seed=4):
+    """CnnVtl.transform (cnn_vtl.py:28-133) of the frames with seeded AlexNet-shaped weights and column mask."""
+    from oracle import cnn_vtl as ocnn
+    x = bgr_frames(paths)
+    ws, bs = ocnn.init_weights(seed)
+    cols = ocnn.column_indices(ocnn.layer_sizes(x.shape[1:3]), 99.59, seed=mask_seed)
+    return ocnn.transform(x, ws, bs, cols)

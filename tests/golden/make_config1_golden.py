@@ -4,7 +4,8 @@
 BASELINE configs[0] at size: the 20 frames of the reference's datasets/test -> oracle patches -> oracle
 SDAV descriptors (TensorFlow is not installable, so the ENCODER stays parity-unpinned) -> the
 REFERENCE's own SimilarityCalculator (importable here: NumPy only) driven with the loop shape of
-src/sdav/create_similarity_matrix.py:29-38.  The matrices it returns for these descriptors are the
+src/sdav/create_similarity_matrix.py:29-38; and oracle CnnVtl descriptors -> the REFERENCE's DistanceCalculator
+in the loop of src/cnn_vtl/create_distance_matrix.py:30-36.  The matrices it returns for these descriptors are the
 golden data; tests/test_config1.py regenerates the descriptors with the oracle and checks the
 oracle's and the GPU's matrices against them.
 
@@ -24,6 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from src.sdav.similarity.SimilarityCalculator import SimilarityCalculator  # noqa: E402
+from src.cnn_vtl.similarity.DistanceCalculator import DistanceCalculator   # noqa: E402
 import config1_common as c1                                                 # noqa: E402
 
 
@@ -44,6 +46,17 @@ def main():
         out["similarity_f64_" + scale] = m
         out["descriptor_sum_" + scale] = np.array(h.sum())
         print(scale, "finite pairs:", int(np.isfinite(m).sum() - 20) // 2, "of 190; descriptor sum", h.sum())
+    # configs[2] at the same size: oracle CnnVtl descriptors of the 20 frames -> the REFERENCE's DistanceCalculator in
+    # the full N x N loop of src/cnn_vtl/create_distance_matrix.py:30-36 (diagonal and both triangles evaluated)
+    d8 = c1.oracle_cnn_descriptors(paths)
+    dm = np.zeros([20, 20], dtype=np.int64)
+    for i in range(20):
+        for j in range(20):
+            dm[i, j] = DistanceCalculator.calculate_distance(d8[i], d8[j])
+    out["distance_i64"] = dm
+    out["cnn_descriptor_sum"] = np.array(int(d8.astype(np.int64).sum()))
+    out["cnn_descriptor_width"] = np.array(d8.shape[1])
+    print("cnn_vtl descriptors", d8.shape, "distance matrix max", dm.max())
     np.savez_compressed(os.path.join(HERE, "config1.npz"), **out)
 
 

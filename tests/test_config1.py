@@ -85,3 +85,35 @@ def test_config1_gpu_end_to_end_vs_oracle(patches, scale):
     assert ties and flips <= 4, flips
     assert np.abs(ts.cpu().numpy() - es).max() < 2e-5
     torch.cuda.synchronize()
+
+
+@pytest.fixture(scope="module")
+def cnn_descriptors(patches):
+    paths, _ = patches
+    return c1.oracle_cnn_descriptors(paths)
+
+
+def test_config3_oracle_distance_matrix_vs_reference(cnn_descriptors):
+    """configs[2] on the same 20 frames: oracle CnnVtl descriptors -> oracle distance matrix == what the REFERENCE's
+    DistanceCalculator returned for them in the loop of create_distance_matrix.py:30-36 (tests/golden/config1.npz)."""
+    from oracle import distance as odist
+    g = load_golden("config1.npz")
+    d8 = cnn_descriptors
+    assert d8.dtype == np.int8 and d8.shape == (N, int(g["cnn_descriptor_width"])) and d8.shape[1] <= 2243
+    assert int(d8.astype(np.int64).sum()) == int(g["cnn_descriptor_sum"])
+    m = odist.distance_matrix(d8)
+    assert m.dtype == np.int64 and np.array_equal(m, g["distance_i64"])
+    assert np.array_equal(m, m.T) and np.all(np.diag(m) == 0) and m.max() > 0
+
+
+@pytest.mark.gpu
+def test_config3_gpu_end_to_end_vs_oracle(patches, cnn_descriptors):
+    import deeploopcloser_amd as dlc
+    g = load_golden("config1.npz")
+    paths, _ = patches
+    net = dlc.CnnVtl(input_shape=[N, 192, 240, 3], seed=3, mask_seed=4)
+    d = net.transform(c1.bgr_frames(paths))
+    assert np.array_equal(d, cnn_descriptors)                             # every int8 byte
+    m = dlc.DistanceCalculator.distance_matrix(d)
+    assert np.array_equal(m, g["distance_i64"])                           # the reference's own integers
+    assert dlc.DistanceCalculator.calculate_distance(d[3], d[17]) == g["distance_i64"][3, 17]
