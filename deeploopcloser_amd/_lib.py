@@ -43,6 +43,7 @@ SIGNATURES = {
     "dlc_im2col_nhwc_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     "dlc_conv2d_nhwc_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _int, _int, _int, _int, _int, _int, _int,
                                   _int, _int, _vp, _vp]),
+    "dlc_space_to_depth_nhwc_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp]),
     "dlc_maxpool3x3s2_nhwc_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
     "dlc_minmax_quant_gather_i8": (_int, [_vp, C.POINTER(_vp), C.POINTER(_i64), _int, _i64, _vp, _i64, _vp, _vp, _vp]),
     "dlc_sdav_distinctive_score": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),

@@ -69,6 +69,18 @@ def alexnet_params_from_dict(layer_params):
     return ws, bs
 
 
+def space_to_depth_kernel(w, s):
+    """HWIO kernel [k, k, c, o] of a stride-s VALID convolution -> the [ceil(k/s), ceil(k/s), s*s*c, o] kernel of the
+    equivalent stride-1 VALID convolution over the space-to-depth(s) input (include/dlc.h, dlc_space_to_depth_nhwc_f64):
+    W'[ky', kx', (dy*s + dx)*c + ch] = W[ky'*s + dy, kx'*s + dx, ch], zero where an index reaches k."""
+    kh, kw, c, o = w.shape
+    k2h, k2w = -(-kh // s), -(-kw // s)
+    wp = np.zeros((k2h * s, k2w * s, c, o), dtype=np.float64)
+    wp[:kh, :kw] = w
+    # [ky', dy, kx', dx, c, o] -> [ky', kx', dy, dx, c, o]
+    return wp.reshape(k2h, s, k2w, s, c, o).transpose(0, 2, 1, 3, 4, 5).reshape(k2h, k2w, s * s * c, o)
+
+
 def _out_size(n, k, s, padding):
     if padding == "VALID":
         return (n - k) // s + 1, 0
@@ -136,6 +148,17 @@ class CnnVtl:
             ws.append(self.engine.to_device(w.reshape(kh * kw * cin, cout), torch.float64))
             bs.append(self.engine.to_device(np.asarray(b, dtype=np.float64).reshape(cout), torch.float64))
         self._w, self._b = ws, bs
+        # Strided VALID layers whose input is a whole number of stride blocks (conv1: 11x11 / 4 on 192x240 or 224x224)
+        # run as a stride-1 convolution over the space-to-depth input: 3 input channels become 48, which the implicit
+        # GEMM's loaders fetch 8 / 16 at a time (the element-wise gather of a 3-channel input ran at 30 TF, the
+        # channel-tiled form at 50-60).  Same products; the zero taps of the padded 12x12 kernel add nothing.
+        self._s2d = {}
+        for l, ((name, kh, kw, cin, cout, s, pad, *_), w) in enumerate(zip(_LAYERS, weights)):
+            if l == 0 and s > 1 and pad == "VALID" and self.input_shape[1] % s == 0 and self.input_shape[2] % s == 0 \
+                    and (s * s * cin) % 8 == 0:
+                wp = space_to_depth_kernel(np.asarray(w, dtype=np.float64), s)
+                self._s2d[l] = (s, wp.shape[0], wp.shape[1],
+                                self.engine.to_device(wp.reshape(-1, cout), torch.float64))
 
     def load_alexnet_npy(self, path):
         """The {layer: [W, b]} dict layout of bvlc_alexnet.npy (cnn_vtl.py:137-149), fc6-8 skipped;
@@ -149,8 +172,13 @@ class CnnVtl:
         outs = []
         h = x
         n = x.shape[0]
-        for (kh, kw, cin, cout, s, ph, pw, oh, ow, relu, pool), w, b in zip(self._geom, self._w, self._b):
-            y = e.conv2d(h, w, b, kh, kw, s, ph, pw, oh, ow, L.DLC_ACT_RELU if relu else L.DLC_ACT_NONE)
+        for l, ((kh, kw, cin, cout, s, ph, pw, oh, ow, relu, pool), w, b) in enumerate(zip(self._geom, self._w, self._b)):
+            act = L.DLC_ACT_RELU if relu else L.DLC_ACT_NONE
+            if l in self._s2d:
+                bs_, k2h, k2w, wp = self._s2d[l]
+                y = e.conv2d(e.space_to_depth(h, bs_), wp, b, k2h, k2w, 1, 0, 0, oh, ow, act)
+            else:
+                y = e.conv2d(h, w, b, kh, kw, s, ph, pw, oh, ow, act)
             outs.append(y)
             h = e.maxpool3x3s2(y) if pool else y
         return outs

@@ -50,6 +50,24 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const double* __restrict__
     }
 }
 
+// y[n, h/s, w/s, (dy*s + dx)*c + ch] = x[n, (h/s index)*s + dy, (w/s index)*s + dx, ch]: one element per thread along
+// the output's contiguous axis; for a fixed dy the s*c values (dx, ch) are contiguous in the input as well.
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const double* __restrict__ x, long long n, int h, int w, int c,
+                                                             int s, double* __restrict__ y) {
+    const int oh = h / s, ow = w / s, oc = s * s * c, sc = s * c;
+    const long long total = n * oh * ow * oc;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int k = (int)(e % oc);
+        long long t = e / oc;
+        const int ox = (int)(t % ow);
+        t /= ow;
+        const int oy = (int)(t % oh);
+        const long long img = t / oh;
+        const int dy = k / sc, rem = k - dy * sc;            // rem = dx * c + ch
+        y[e] = x[((img * h + (long long)oy * s + dy) * w + (long long)ox * s) * c + rem];
+    }
+}
+
 constexpr int MAX_SEGS = 8;
 struct Segs {
     const double* ptr[MAX_SEGS];
@@ -156,6 +174,21 @@ extern "C" int dlc_maxpool3x3s2_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t 
     hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, h, w, c,
                        oh, ow, y);
     DLC_LAUNCH_CHECK(ctx, "maxpool_kernel");
+    return DLC_OK;
+}
+
+extern "C" int dlc_space_to_depth_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c, int s, double* y,
+                                          void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!x || !y || n < 1 || h < 1 || w < 1 || c < 1 || s < 1) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "space_to_depth: bad argument");
+    if (h % s || w % s) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "space_to_depth: %d x %d is not a multiple of the block %d", h, w, s);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    long long blocks = dlc::cdiv((long long)n * h * w * c, 256);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(space_to_depth_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, h, w,
+                       c, s, y);
+    DLC_LAUNCH_CHECK(ctx, "space_to_depth_kernel");
     return DLC_OK;
 }
 

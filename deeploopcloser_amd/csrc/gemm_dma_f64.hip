@@ -103,8 +103,11 @@ __device__ __forceinline__ double act_f64(double z, int act) {
 
 // BLAYOUT: DLC_B_KN / DLC_B_NK.  CONV: A is the NHWC input of a convolution with C % 16 == 0 (a K tile is 16
 // consecutive channels of one kernel tap), B its HWIO kernel as [K,N].
-template <int BLAYOUT, bool CONV>
+// NJ: MFMA column tiles per wave (4: the 128-column tile; 3: a 96-column tile for N <= 96 such as conv1's 96 filters,
+// which would waste a quarter of a 128-column tile's MFMAs).  The B stage keeps its 128-column geometry.
+template <int BLAYOUT, bool CONV, int NJ>
 __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
+    constexpr int TNJ = 2 * NJ * 16;              // columns per tile: two wave columns of NJ MFMA tiles
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,8 +124,8 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         tile_n = (gb / p.nbr) * p.bc + (i / p.br);
         if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
     }
-    const long long m0 = tile_m * TM3, n0 = tile_n * TN3;
-    if (p.tri_p > 0 && (p.tri_col0 + n0 + TN3 - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;
+    const long long m0 = tile_m * TM3, n0 = tile_n * TNJ;
+    if (p.tri_p > 0 && (p.tri_col0 + n0 + TNJ - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;
     const int nkt = (int)((p.K + TK3 - 1) / TK3);
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem3;
 
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             // [K,N]: instruction j covers k-row kr = 2w + j of the stage, lane -> 16-byte slot, source piece = slot ^ ((kr & 1) << 3)
             const int kr = w * 2 + j;
             int piece = lane ^ ((kr & 1) << 3);
-            const long long cols = p.N - n0 < TN3 ? p.N - n0 : TN3;      // valid columns of this tile (even: N is)
+            const long long cols = p.N - n0 < TNJ ? p.N - n0 : TNJ;      // valid columns of this tile (even: N is)
             const int last = (int)(cols / 2) - 1;
             if (piece > last) piece = last;                              // columns past N: never stored
             b_piece[j] = kr;
@@ -223,29 +226,29 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     int pk[4];                                    // slot offset of this lane's piece in k-slice kk (A and [N,K] B rows)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) pk[kk] = (((kk * 2 + (fk >> 1)) ^ x7) << 4) + (fk & 1) * 8;
-    int ra_off[4], rb_off[4];
+    int ra_off[4], rb_off[NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra_off[i] = (wr * 64 + i * 16 + fr) * 128;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if constexpr (BLAYOUT == DLC_B_NK) rb_off[j] = A_STAGE + (wc * 64 + j * 16 + fr) * 128;
-        else rb_off[j] = A_STAGE + fk * 1024 + ((((wc * 32 + j * 8 + (fr >> 1)) ^ ((fk & 1) << 3))) << 4) + (fr & 1) * 8;
+    for (int j = 0; j < NJ; ++j) {
+        if constexpr (BLAYOUT == DLC_B_NK) rb_off[j] = A_STAGE + ((wc * NJ + j) * 16 + fr) * 128;
+        else rb_off[j] = A_STAGE + fk * 1024 + (((((wc * NJ + j) * 8 + (fr >> 1)) ^ ((fk & 1) << 3))) << 4) + (fr & 1) * 8;
     }
 
-    f64x4_t acc[4][4];
+    f64x4_t acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4_t){0, 0, 0, 0};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f64x4_t){0, 0, 0, 0};
 
     // fragments of one k-slice, double-buffered in registers: rd() reads slice kk of a stage into buffer b, mm() runs
     // the 16 MFMAs of a buffer.  A slice's reads are always issued before the MFMAs of the slice in front of it.
-    double fa[2][4], fb[2][4];
+    double fa[2][4], fb[2][NJ];
     auto rd = [&](const char* st, int kk, int b) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[b][i] = *(const double*)(st + ra_off[i] + pk[kk]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const double*)(st + rb_off[j] + pk[kk]);
             else fb[b][j] = *(const double*)(st + rb_off[j] + kk * 4096);
         }
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[b][i], fb[b][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[b][i], fb[b][j], acc[i][j], 0, 0, 0);
     };
     // wait for this wave's DMA pieces (all that are in flight belong to the tile about to become readable), then the
     // workgroup barrier: behind it that tile is visible to every wave and the stage of the tile two back is free
@@ -327,8 +330,8 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 
     // ---- epilogue: bias + activation, C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long long gn = n0 + wc * 64 + j * 16 + fr;
+    for (int j = 0; j < NJ; ++j) {
+        const long long gn = n0 + (wc * NJ + j) * 16 + fr;
         if (gn >= p.N) continue;
         const double bv = p.bias ? p.bias[gn] : 0.0;
 #pragma unroll
@@ -341,10 +344,10 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     }
 }
 
-template <int BLAYOUT, bool CONV>
+template <int BLAYOUT, bool CONV, int NJ>
 int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
-    auto kern = gemm_dma_f64_kernel<BLAYOUT, CONV>;
-    const unsigned long long m = 1ull << (DLC_ATTR_DMA64_BASE + (CONV ? 2 : (BLAYOUT == DLC_B_KN ? 0 : 1)));
+    auto kern = gemm_dma_f64_kernel<BLAYOUT, CONV, NJ>;
+    const unsigned long long m = 1ull << (DLC_ATTR_DMA64_BASE + (CONV ? 2 : (BLAYOUT == DLC_B_KN ? 0 : 1)) + (NJ == 3 ? 3 : 0));
     if (!(ctx->func_attr_set & m)) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3));
         ctx->func_attr_set |= m;
@@ -369,7 +372,10 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
         return 1;
     }
     // worth a 256 x 128 tile per CU only when the launch fills the chip a few times over
-    const int64_t tiles_m = dlc::cdiv(M, TM3), tiles_n = dlc::cdiv(N, TN3);
+    // N <= 96 (conv1's 96 filters): 96-column tiles, so that no quarter of the MFMAs works on padding
+    const bool narrow = N <= 96;
+    const int tn = narrow ? 96 : TN3;
+    const int64_t tiles_m = dlc::cdiv(M, TM3), tiles_n = dlc::cdiv(N, (int64_t)tn);
     if (tiles_m * tiles_n < 512 || K < 4 * TK3) return 1;
     DmaArgs a;
     a.A = (const char*)A; a.lda_b = lda * 8; a.B = (const char*)B; a.ldb_b = ldb * 8;
@@ -396,9 +402,9 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
     int rc;
-    if (cv) rc = launch_one<DLC_B_KN, true>(ctx, a, nwg, st);
-    else if (blayout == DLC_B_KN) rc = launch_one<DLC_B_KN, false>(ctx, a, nwg, st);
-    else rc = launch_one<DLC_B_NK, false>(ctx, a, nwg, st);
+    if (cv) rc = narrow ? launch_one<DLC_B_KN, true, 3>(ctx, a, nwg, st) : launch_one<DLC_B_KN, true, 4>(ctx, a, nwg, st);
+    else if (blayout == DLC_B_KN) rc = narrow ? launch_one<DLC_B_KN, false, 3>(ctx, a, nwg, st) : launch_one<DLC_B_KN, false, 4>(ctx, a, nwg, st);
+    else rc = narrow ? launch_one<DLC_B_NK, false, 3>(ctx, a, nwg, st) : launch_one<DLC_B_NK, false, 4>(ctx, a, nwg, st);
     if (rc != DLC_OK) return rc;
     DLC_LAUNCH_CHECK(ctx, "gemm_dma_f64_kernel");
     if (ctx->profiling) {

@@ -266,6 +266,14 @@ class Engine:
                                                   stride, pad_top, pad_left, oh, ow, act, _ptr(out), self._stream()))
         return out
 
+    def space_to_depth(self, x, s):
+        """NHWC fp64 [n,h,w,c] -> [n, h/s, w/s, s*s*c] (block s; dlc_space_to_depth_nhwc_f64)."""
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        y = torch.empty((n, h // s, w // s, s * s * c), dtype=torch.float64, device=self.device)
+        self._check(self.lib.dlc_space_to_depth_nhwc_f64(self.ctx, _ptr(x), n, h, w, c, s, _ptr(y), self._stream()))
+        return y
+
     def maxpool3x3s2(self, x):
         n, h, w, c = x.shape
         y = torch.empty((n, (h - 3) // 2 + 1, (w - 3) // 2 + 1, c), dtype=torch.float64, device=self.device)

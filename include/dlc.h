@@ -187,6 +187,16 @@ int dlc_conv2d_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, 
                         const double* kernel, const double* bias, int kh, int kw, int cout,
                         int stride, int pad_top, int pad_left, int oh, int ow, int act,
                         double* out, void* stream);
+/*
+ * Space-to-depth with block s on NHWC fp64: y[n, h/s, w/s, (dy*s + dx)*c + ch] = x[n, y*s + dy, x*s + dx, ch]
+ * (h, w multiples of s).  A stride-s VALID convolution with a k x k kernel over x is the stride-1 VALID convolution
+ * with the ceil(k/s) x ceil(k/s) kernel W'[ky', kx', (dy*s + dx)*c + ch, :] = W[ky'*s + dy, kx'*s + dx, ch, :] (zero
+ * where the index reaches k) over y: same products, and the channel count becomes s*s*c.  cnn_vtl's conv1
+ * (11x11, stride 4, 3 channels; cnn_vtl.py:33-40) turns into a 3x3 convolution over 48 channels, which the implicit
+ * GEMM gathers 8 / 16 channels at a time instead of element by element.
+ */
+int dlc_space_to_depth_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c, int s,
+                                double* y, void* stream);
 /* tf.layers.max_pooling2d(3x3, stride 2, VALID) on NHWC fp64 (cnn_vtl.py:42-45,58-61). */
 int dlc_maxpool3x3s2_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c,
                               double* y, void* stream);

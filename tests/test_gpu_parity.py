@@ -942,3 +942,27 @@ def test_gemm_dma_kernel_edges(eng, m, n, k, blayout):
                                           b.data_ptr(), b.stride(0), bias.data_ptr(), out.data_ptr(), n, None))
     torch.cuda.synchronize()
     assert torch.equal(out, got)
+
+
+def test_space_to_depth_and_conv1_equivalence(eng, dlc):
+    """dlc_space_to_depth_nhwc_f64 against the NumPy reshape / transpose, and CnnVtl's conv1 through it (a 3x3
+    convolution over 48 channels) against the oracle's 11x11 / 4 convolution and against the direct call."""
+    from oracle import cnn_vtl as ocnn
+    from deeploopcloser_amd import _lib as L
+    rng = np.random.RandomState(2)
+    for (n, h, w, c, s) in [(3, 8, 12, 3, 4), (2, 6, 6, 5, 2), (1, 192, 240, 3, 4)]:
+        x = rng.standard_normal((n, h, w, c))
+        got = eng.space_to_depth(torch.from_numpy(x).to(eng.device), s).cpu().numpy()
+        ref = x.reshape(n, h // s, s, w // s, s, c).transpose(0, 1, 3, 2, 4, 5).reshape(n, h // s, w // s, s * s * c)
+        assert np.array_equal(got, ref)
+    with pytest.raises(ValueError):
+        eng.space_to_depth(torch.zeros((1, 7, 8, 3), dtype=torch.float64, device=eng.device), 4)
+    net = dlc.CnnVtl(input_shape=[2, 192, 240, 3], seed=5, mask_seed=9)
+    assert 0 in net._s2d and net._s2d[0][:3] == (4, 3, 3)
+    x = rng.randint(0, 256, size=(2, 192, 240, 3)).astype(np.float64)
+    outs = net._features(torch.from_numpy(x).to(eng.device))
+    ws, bs = ocnn.init_weights(5)
+    ref1 = ocnn.conv2d_nhwc(x, ws[0], bs[0], 4, "VALID", True)
+    assert outs[0].shape == (2, 46, 58, 96) and np.abs(outs[0].cpu().numpy() - ref1).max() < 1e-9 * np.abs(ref1).max()
+    direct = eng.conv2d(torch.from_numpy(x).to(eng.device), net._w[0], net._b[0], 11, 11, 4, 0, 0, 46, 58, L.DLC_ACT_RELU)
+    assert float((direct - outs[0]).abs().max()) < 1e-9 * np.abs(ref1).max()

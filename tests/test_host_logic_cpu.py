@@ -136,3 +136,21 @@ def test_tf1_constant_fill_and_grouped_alexnet_dict():
         assert np.array_equal(ws[0], np.asarray(d[key("conv1")][0], dtype=np.float64))   # ungrouped layers unchanged
     with pytest.raises(KeyError):
         alexnet_params_from_dict({"conv1": d[key("conv1")]})
+
+
+def test_space_to_depth_kernel_rearrangement():
+    """CnnVtl runs conv1 (11x11, stride 4, VALID) as a stride-1 3x3 convolution over the space-to-depth(4) input: the
+    rearranged kernel over the rearranged input gives the oracle's strided convolution (same products, zero taps)."""
+    from deeploopcloser_amd.cnn_vtl import space_to_depth_kernel
+    from oracle import cnn_vtl as ocnn
+    rng = np.random.RandomState(0)
+    for (h, w, c, k, s, o) in [(24, 32, 3, 11, 4, 5), (12, 12, 2, 3, 2, 4), (20, 28, 3, 7, 4, 3)]:
+        x = rng.standard_normal((2, h, w, c))
+        wk = rng.standard_normal((k, k, c, o))
+        b = rng.standard_normal(o)
+        ref = ocnn.conv2d_nhwc(x, wk, b, s, "VALID", True)
+        xs = x.reshape(2, h // s, s, w // s, s, c).transpose(0, 1, 3, 2, 4, 5).reshape(2, h // s, w // s, s * s * c)
+        wp = space_to_depth_kernel(wk, s)
+        assert wp.shape == (-(-k // s), -(-k // s), s * s * c, o)
+        got = ocnn.conv2d_nhwc(xs, wp, b, 1, "VALID", True)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-12
