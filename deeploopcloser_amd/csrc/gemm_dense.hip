@@ -531,6 +531,13 @@ int gram_upper_f64(dlc_ctx* ctx, int blayout, int64_t M, int64_t N, int64_t K, c
     return launch<double>(ctx, blayout, DLC_ACT_NONE, M, N, K, A, lda, B, ldb, nullptr, C, ldc, st, nullptr, &tri);
 }
 
+int gemm_bias_act_padded_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, int64_t Kpad, const double* A,
+                             const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st) {
+    const int rc = launch_dma_f64(ctx, DLC_B_KN, act, M, N, Kpad, A, Kpad, B, ldb, bias, C, ldc, st, nullptr, nullptr, K);
+    if (rc <= 0) return rc;
+    return launch<double>(ctx, DLC_B_KN, act, M, N, K, A, Kpad, B, ldb, bias, C, ldc, st);
+}
+
 int conv2d_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, const double* x, const double* w,
                const double* bias, double* out, const ConvGeom& cv, hipStream_t st) {
     return launch<double>(ctx, DLC_B_KN, act, M, N, K, x, 0, w, N, bias, out, N, st, &cv);
@@ -601,12 +608,35 @@ extern "C" int dlc_bias_act(dlc_ctx* ctx, int dtype, int act, int64_t M, int64_t
 
 static size_t elem_size(int dtype) { return dtype == DLC_F64 ? 8 : (dtype == DLC_F32 ? 4 : 0); }
 
+// Input rows of an ODD width (SDAV: 1681 = 41 x 41 pixels) are 8-byte aligned only, which keeps layer 0 off the
+// LDS-DMA kernel; for batches large enough for that kernel the input is first copied into zero-padded rows of a
+// multiple of 16 columns (one extra pass over x, ~1 % of the layer's time).
+static int64_t sdav_pad_width(int64_t rows, const int64_t* dims, int dtype) {
+#ifdef DLC_EXP_NO_SDAV_PAD      // experiment build
+    return 0;
+#endif
+    if (dtype != DLC_F64 || (dims[0] & 1) == 0 || (dims[1] & 1) || rows * dims[1] < (int64_t)512 * 256 * 128) return 0;
+    return (dims[0] + 15) / 16 * 16;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void pad_rows_kernel(const double* __restrict__ x, long long rows, long long cols,
+                                                       long long ldp, double* __restrict__ out) {
+    const long long total = rows * ldp;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / ldp, c = e - r * ldp;
+        out[e] = c < cols ? x[r * cols + c] : 0.0;
+    }
+}
+}  // namespace
+
 extern "C" size_t dlc_sdav_encode_workspace_bytes(int64_t rows, const int64_t* dims, int n_layers, int dtype) {
     if (rows < 1 || !dims || n_layers < 1 || elem_size(dtype) == 0) return 0;
     int64_t wmax = 0;
     for (int l = 1; l < n_layers; ++l) wmax = dims[l] > wmax ? dims[l] : wmax;   // widths of the hidden hand-offs
-    if (n_layers == 1) return 256;
-    return 2 * dlc::align_up((size_t)rows * (size_t)wmax * elem_size(dtype), 256);
+    const size_t pad = dlc::align_up((size_t)rows * (size_t)sdav_pad_width(rows, dims, dtype) * 8, 256);
+    if (n_layers == 1) return 256 + pad;
+    return 2 * dlc::align_up((size_t)rows * (size_t)wmax * elem_size(dtype), 256) + pad;
 }
 
 extern "C" int dlc_sdav_encode(dlc_ctx* ctx, int dtype, int64_t rows, int n_layers, const int64_t* dims, const void* x,
@@ -619,17 +649,33 @@ extern "C" int dlc_sdav_encode(dlc_ctx* ctx, int dtype, int64_t rows, int n_laye
     for (int l = 0; l <= n_layers; ++l)
         if (dims[l] < 1) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_encode: dims[%d] = %lld", l, (long long)dims[l]);
     const size_t need = dlc_sdav_encode_workspace_bytes(rows, dims, n_layers, dtype);
-    if (n_layers > 1 && (!workspace || workspace_bytes < need))
+    if ((n_layers > 1 || sdav_pad_width(rows, dims, dtype) > 0) && (!workspace || workspace_bytes < need))
         return dlc::fail(ctx, DLC_ERR_WORKSPACE, "sdav_encode: workspace %zu < %zu bytes", workspace_bytes, need);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    char* ping[2] = {(char*)workspace, (char*)workspace + need / 2};
+    const int64_t kpad = sdav_pad_width(rows, dims, dtype);
+    const size_t pad_bytes = dlc::align_up((size_t)rows * (size_t)kpad * 8, 256);
+    const size_t half = (need - pad_bytes) / 2;
+    char* ping[2] = {(char*)workspace, (char*)workspace + half};
+    double* xpad = (double*)((char*)workspace + 2 * half);
     const void* in = x;
     for (int l = 0; l < n_layers; ++l) {
         if (!W[l]) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_encode: W[%d] is null", l);
         void* o = (l == n_layers - 1) ? out : (void*)ping[l & 1];
-        int rc = dlc_gemm::gemm_bias_act(ctx, dtype, DLC_B_KN, DLC_ACT_SIGMOID, rows, dims[l + 1], dims[l], in, dims[l],
+        int rc;
+        if (l == 0 && kpad > 0) {
+            long long blocks = dlc::cdiv(rows * kpad, (int64_t)256);
+            if (blocks > 256 * 64) blocks = 256 * 64;
+            hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const double*)x,
+                               (long long)rows, (long long)dims[0], (long long)kpad, xpad);
+            DLC_LAUNCH_CHECK(ctx, "pad_rows_kernel");
+            rc = dlc_gemm::gemm_bias_act_padded_f64(ctx, DLC_ACT_SIGMOID, rows, dims[1], dims[0], kpad, xpad, (const double*)W[0],
+                                                    dims[1], b ? (const double*)b[0] : nullptr, (double*)o, dims[1],
+                                                    (hipStream_t)stream);
+        } else {
+            rc = dlc_gemm::gemm_bias_act(ctx, dtype, DLC_B_KN, DLC_ACT_SIGMOID, rows, dims[l + 1], dims[l], in, dims[l],
                                          W[l], dims[l + 1], b ? b[l] : nullptr, o, dims[l + 1], (hipStream_t)stream);
+        }
         if (rc != DLC_OK) return rc;
         in = o;
     }

@@ -40,7 +40,8 @@ struct DmaArgs {
     const char* B; long long ldb_b;
     const double* bias;
     double* C; long long ldc;
-    long long M, N, K;
+    long long M, N, K;                          // K: the reduction length as the A operand has it (even)
+    long long Kb;                               // ... and as B has it (<= K): B's k-rows Kb .. K-1 do not exist and read as zeros
     int act;
     ConvGeom cv;
     const char* zero;                           // >= 128 bytes of zeros
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     auto issue_b = [&](int t, int stage) {
         const int tt = t < nkt ? t : nkt - 1;
         const long long k0 = (long long)tt * TK3;
-        const int klim = (int)(p.K - k0 < TK3 ? p.K - k0 : TK3);
+        const int klim = (int)(p.Kb - k0 < TK3 ? (p.Kb - k0 > 0 ? p.Kb - k0 : 0) : TK3);      // B's own reduction length
         const char* sb[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -360,12 +361,14 @@ int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
 
 int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                    const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
-                   const ConvGeom* cv, const TriSkip* tri) {
+                   const ConvGeom* cv, const TriSkip* tri, int64_t Kb) {
+    if (Kb <= 0 || Kb > K) Kb = K;
 #ifdef DLC_EXP_NO_DMA_GEMM      // experiment build: always the register-staged kernel
     return 1;
 #endif
     // 16-byte pieces: operand rows must start on 16-byte boundaries and K, N be even (a piece = 2 doubles)
     if (!ctx->zero_page || (K & 1) || (N & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 1)) return 1;
+    if (Kb != K && blayout != DLC_B_KN) return 1;          // a shorter B is a [K,N] operand with fewer rows
     if (cv) {
         if (blayout != DLC_B_KN || cv->C % TK3 != 0) return 1;
     } else if (lda & 1) {
@@ -379,7 +382,7 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     if (tiles_m * tiles_n < 512 || K < 4 * TK3) return 1;
     DmaArgs a;
     a.A = (const char*)A; a.lda_b = lda * 8; a.B = (const char*)B; a.ldb_b = ldb * 8;
-    a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.act = act;
+    a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.Kb = Kb; a.act = act;
     a.cv = cv ? *cv : ConvGeom{};
     a.zero = (const char*)ctx->zero_page;
     a.tiles_m = tiles_m; a.tiles_n = tiles_n;

@@ -21,8 +21,15 @@ struct TriSkip {
 
 // The LDS-DMA form of the fp64 GEMM (gemm_dma_f64.hip).  Returns DLC_OK after launching, or 1 when the shape /
 // alignment is not one it handles (the caller then takes the register-staged kernel of gemm_dense.hip).
+// Kb (0 = K): the reduction length of the B operand when A has been zero-padded past it (an odd K such as SDAV's
+// 1681 input columns, copied into rows of 1696): B's missing k-rows read as zeros.
 int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                    const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
-                   const ConvGeom* cv, const TriSkip* tri);
+                   const ConvGeom* cv, const TriSkip* tri, int64_t Kb = 0);
+
+// A zero-padded by the caller to lda = Kpad columns (columns K .. Kpad-1 are zeros): act(A[:, :K] . B + bias) with the
+// LDS-DMA kernel when it applies (it then walks Kpad), else the register-staged kernel on the first K columns.
+int gemm_bias_act_padded_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, int64_t Kpad, const double* A,
+                             const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st);
 
 }  // namespace dlc_gemm
