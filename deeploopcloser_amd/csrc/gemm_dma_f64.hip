@@ -246,6 +246,9 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     // the 16 MFMAs of a buffer.  A slice's reads are always issued before the MFMAs of the slice in front of it.
     double fa[2][4], fb[2][NJ];
     auto rd = [&](const char* st, int kk, int b) {
+#ifdef DLC_EXP_DMA_NO_LDS_READ     // timing experiments only (wrong results): MFMAs on whatever the registers hold
+        if (kk >= 0) { asm volatile("" : "+v"(fa[b][0]), "+v"(fb[b][0])); return; }
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[b][i] = *(const double*)(st + ra_off[i] + pk[kk]);
 #pragma unroll
