@@ -182,7 +182,11 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 
     // The A part (4 instructions) and the B part (2) of K tile t's DMA, issued separately (see the main loop).
     auto issue_a = [&](int t, int stage) {
+#ifdef DLC_EXP_DMA_SAME_TILE       // timing experiments only (wrong results): every DMA re-reads K tile 0 (L2-resident)
+        const int tt = 0;
+#else
         const int tt = t < nkt ? t : nkt - 1;                            // past the end: the last tile again, into a dead stage
+#endif
         const long long k0 = (long long)tt * TK3;
         const int klim = (int)(p.K - k0 < TK3 ? p.K - k0 : TK3);         // valid k of this tile (16 except in a K tail); selects, no branches
         const char* sa[4];
@@ -209,7 +213,11 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         dma_a4(sa[0], sa[1], sa[2], sa[3], lds_base + stage * STAGE + w * 4096);
     };
     auto issue_b = [&](int t, int stage) {
+#ifdef DLC_EXP_DMA_SAME_TILE
+        const int tt = 0;
+#else
         const int tt = t < nkt ? t : nkt - 1;
+#endif
         const long long k0 = (long long)tt * TK3;
         const int klim = (int)(p.Kb - k0 < TK3 ? (p.Kb - k0 > 0 ? p.Kb - k0 : 0) : TK3);      // B's own reduction length
         const char* sb[2];
@@ -288,6 +296,10 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     // wave reads k-slice 0 of tile t; half a tile later the roles are swapped.  Tile t+1's DMA is issued behind
     // barrier t into the stage of tile t-2, whose last readers (the late waves, k-slices 2-3, during iteration t-1)
     // are through; it has a whole iteration to land.  Both groups execute nkt + 1 barriers.
+    // (A second barrier in the middle of the iteration, behind which tile t+2 can go into tile t-1's stage -- a tile
+    // and a half of prefetch distance -- measured the same for the SDAV layers and 3 % slower for the convolutions.
+    // Timing builds that re-read ONE resident K tile with the same DMA instructions run as fast as builds without
+    // any DMA: what the operand traffic costs, 8 %, is neither instruction issue nor prefetch distance.)
     issue(0, 0);
     int cur = 0;
     if (w < 4) {
