@@ -1059,11 +1059,16 @@ SplitPlan split_plan(int64_t q, int64_t n, int64_t d) {
     if (base >= 256 || nk < 8) return best;
     const double t_k = 1.6, t_fix = 8.0, t_launch = 5.0, bytes_per_us = 3.0e6;
     const double part_bytes = (double)q * (double)ntiles * BM * 4.0;             // one chunk's partial scores
-    double best_t = (double)dlc::cdiv(base, (int64_t)256) * ((double)nk * t_k + t_fix);
-    for (int64_t ns = 2; ns <= nk / 4; ns = ns < 8 ? ns + 1 : ns + ns / 4) {
+    // rounds of the chip are counted on the workgroups that DO work: the grid pads the tile count to a multiple of 8
+    // (XCD mapping), the padding exits at once.  (Counting the padded grid made 1063 x 1063 x 75 008 pick 21 chunks =
+    // 525 working workgroups = two rounds and 13 stragglers; 10 chunks = 250 is one round.)
+    const int64_t work = ntiles * dlc::cdiv(q, BNQ);
+    double best_t = (double)dlc::cdiv(work, (int64_t)256) * ((double)nk * t_k + t_fix);
+    for (int64_t ns = 2; ns <= nk / 4 && ns <= 256; ++ns) {
         const int64_t kc = dlc::cdiv(nk, ns), ns_eff = dlc::cdiv(nk, kc);
+        if (ns_eff != ns) continue;                                               // the same chunking as a smaller ns
         if ((double)ns_eff * part_bytes > (double)(1ll << 30)) break;
-        const double t = (double)dlc::cdiv(base * ns_eff, (int64_t)256) * ((double)kc * t_k + t_fix) +
+        const double t = (double)dlc::cdiv(work * ns_eff, (int64_t)256) * ((double)kc * t_k + t_fix) +
                          2.0 * (double)ns_eff * part_bytes / bytes_per_us + t_launch;
         if (t < best_t * 0.9) {                                                   // split only for a clear gain
             best_t = t;
