@@ -47,8 +47,9 @@ constexpr int LDS_BYTES = A_STAGES * A_TILE + 2 * B_TILE;
 #define DLC_STAGGER_SLEEP 15     // s_sleep units of 64 cycles per stagger step (~0.5 us); x stagger_mult
 #endif
 #ifndef DLC_STAGGER_PHASES
-#define DLC_STAGGER_PHASES 16
-#endif
+#define DLC_STAGGER_PHASES 32    // r02, with the non-temporal database stream: 32 phases 1-2 % faster than 16, 64 the same as 32;
+#endif                           // no stagger at all now costs 1 % (it was 8 % before `nt`): scripts/exp_gemm.py, three rounds
+
 constexpr int GROUP = 8;         // database rows per group
 constexpr int HALF = 128;        // database rows per half tile
 constexpr int GROUPS_PER_HALF = HALF / GROUP;
