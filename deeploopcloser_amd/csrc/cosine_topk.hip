@@ -47,8 +47,9 @@ constexpr int LDS_BYTES = A_STAGES * A_TILE + 2 * B_TILE;
 #define DLC_STAGGER_SLEEP 15     // s_sleep units of 64 cycles per stagger step (~0.5 us); x stagger_mult
 #endif
 #ifndef DLC_STAGGER_PHASES
-#define DLC_STAGGER_PHASES 32    // r02, with the non-temporal database stream: 32 phases 1-2 % faster than 16, 64 the same as 32;
-#endif                           // no stagger at all now costs 1 % (it was 8 % before `nt`): scripts/exp_gemm.py, three rounds
+#define DLC_STAGGER_PHASES 32    // launches of >= 3 dispatch rounds (r02, with the non-temporal database stream: 32 phases 1-2 %
+#endif                           // faster than 16, 64 the same as 32; no stagger at all now costs 1 %, it was 8 % before `nt`:
+                                 // scripts/exp_gemm.py, three rounds); smaller launches keep 16 phases of half the length
 
 constexpr int GROUP = 8;         // database rows per group
 constexpr int HALF = 128;        // database rows per half tile
@@ -103,6 +104,7 @@ struct GemmArgs {
     float* S;           // dense mode: [q, lds]
     long long lds;
     int stagger_mult;   // first-round start stagger: phase * mult * DLC_STAGGER_SLEEP * 64 cycles
+    int stagger_phases;
     int nqb;            // query blocks of 256 (grid mapping below)
     long long ntiles;   // database tiles of 256 rows
     int nsplit;         // split-K: chunks of kchunk K tiles, one workgroup each (1 = whole K in one)
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void score_gemm_kernel(GemmArgs p) {
     // 128-byte column of their rows at the same time; a small start stagger of the FIRST round
     // (later rounds inherit it) spreads them over K without changing any result.
     if (MODE != GEMM_PARTIAL && wg < 256) {
-        const int steps = (int)((tile >> 3) % DLC_STAGGER_PHASES) * p.stagger_mult;
+        const int steps = (int)((tile >> 3) % p.stagger_phases) * p.stagger_mult;
         for (int s_ = 0; s_ < steps; ++s_) __builtin_amdgcn_s_sleep(DLC_STAGGER_SLEEP);
     }
     // ---- prologue: A tiles 0..A_STAGES-1 and B tiles 0,1 issued (per-tile order A1,A0 / B0,B1, as the
@@ -1202,6 +1204,7 @@ int launch_gemm_masked(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
     dim3 grid((unsigned)nwg);
     // measured: 0-30 us of stagger pays from ~3 dispatch rounds on, 0-15 us below (scripts/exp_rows.py, exp_gemm.py)
     b.stagger_mult = (nwg >= 3 * 256) ? 4 : 2;
+    b.stagger_phases = (nwg >= 3 * 256) ? DLC_STAGGER_PHASES : 16;
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), LDS_BYTES, st, b);
     DLC_LAUNCH_CHECK(ctx, "score_gemm_kernel");
     return DLC_OK;
