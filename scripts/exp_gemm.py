@@ -6,7 +6,7 @@ import torch
 import deeploopcloser_amd as dlc
 from deeploopcloser_amd import _lib as L
 
-def run(libpath, label, n=1_000_000, d=4096, nq=256, k=20, iters=10):
+def run(libpath, label, n=int(os.environ.get('DLC_EXP_ROWS', '1000000')), d=4096, nq=256, k=20, iters=int(os.environ.get('DLC_EXP_ITERS', '10'))):
     L._lib = None
     L.LIB_PATH = libpath
     if os.environ.get("DLC_EXP_OLD_ABI") and label != "shipped":       # libraries built before ABI 2
