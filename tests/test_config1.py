@@ -82,7 +82,8 @@ def test_config1_gpu_end_to_end_vs_oracle(patches, scale):
     # 75 008-d rows of real frames under an untrained encoder: every frame looks alike, scores crowd together;
     # slots may only differ where the exact scores are closer than the fp32 sum of 75 008 products resolves
     flips, ties = topk_flips_are_ties(ti.cpu().numpy(), ei, full, es, tol=1e-5)
-    assert ties and flips <= 4, flips
+    assert ties and flips <= 0.15 * ei.size, flips       # every differing slot is such a near-tie; how many there are depends
+    # on the summation order (the split-K plan): 2-8 of the 100 slots have been seen
     assert np.abs(ts.cpu().numpy() - es).max() < 2e-5
     torch.cuda.synchronize()
 
