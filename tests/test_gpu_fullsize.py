@@ -263,3 +263,36 @@ def test_cosine_matrix_config2_dense_full(dlc, descriptors):
     assert ties and flips < 0.005 * ei.size
     assert np.abs(ts.cpu().numpy() - es).max() < 2e-5
     assert np.array_equal(ti[:, 0].cpu().numpy(), np.arange(N_FRAMES))  # every frame's best match is itself
+
+
+def test_gemm_dma_every_element_repeated(dlc):
+    """Race screen for the LDS-DMA ring of the fp64 GEMM (a mis-ordered wait or a stage refilled too early shows up
+    as rare wrong tiles): every output element of several launches on fresh random data against torch's fp64 product,
+    at the SDAV layer shape (K = 2500: 157 K tiles, a tail of 4), a convolution shape through the conv entry point
+    (SAME padding: zero-page pieces) and a Gram-like [N,K] product."""
+    from deeploopcloser_amd import _lib as L
+    eng = dlc.default_engine()
+    g = torch.Generator(device="cuda")
+    for rep in range(3):
+        g.manual_seed(500 + rep)
+        m = 31890 + 17 * rep
+        a = torch.rand((m, 2500), generator=g, device="cuda", dtype=torch.float64)
+        w = torch.randn((2500, 2500), generator=g, device="cuda", dtype=torch.float64) / 50.0
+        b = torch.randn((2500,), generator=g, device="cuda", dtype=torch.float64)
+        got = eng.gemm_bias_act(a, w, b, act=L.DLC_ACT_SIGMOID)
+        ref = torch.sigmoid(a @ w + b)
+        assert float((got - ref).abs().max()) < 1e-12, rep
+        del a, w, got, ref
+        # conv3-like: 384 frames of 10 x 13 x 256 -> 384 filters, 3 x 3 SAME (M = 49 920 rows, K = 2304)
+        x = torch.randn((384 + rep, 10, 13, 256), generator=g, device="cuda", dtype=torch.float64)
+        k = torch.randn((3 * 3 * 256, 384), generator=g, device="cuda", dtype=torch.float64) / 48.0
+        bias = torch.randn((384,), generator=g, device="cuda", dtype=torch.float64)
+        y = eng.conv2d(x, k, bias, 3, 3, 1, 1, 1, 10, 13, L.DLC_ACT_RELU)
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), k.reshape(3, 3, 256, 384).permute(3, 2, 0, 1), bias, padding=1)
+        ref = torch.relu(ref).permute(0, 2, 3, 1)
+        assert float((y - ref).abs().max()) < 1e-11, rep
+        del x, y, ref
+        p = torch.randn((20000 + 30 * rep, 1000), generator=g, device="cuda", dtype=torch.float64)
+        got = eng.gemm_bias_act(p[:12800], p, None, act=L.DLC_ACT_NONE, blayout=L.DLC_B_NK)
+        assert float((got - p[:12800] @ p.T).abs().max()) < 1e-10, rep
+        del p, got
