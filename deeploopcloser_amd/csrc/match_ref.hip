@@ -383,6 +383,9 @@ extern "C" int dlc_cnnvtl_distance_matrix(dlc_ctx* ctx, const int8_t* desc, int6
     if (z > steps / 4) z = steps / 4;
     if (z < 1) z = 1;
     if (z > 64) z = 64;
+#ifdef DLC_EXP_DIST_Z       // experiment build: fixed number of descriptor chunks
+    z = DLC_EXP_DIST_Z;
+#endif
     const long long kchunk = dlc::cdiv(steps, z) * DCH;
     z = dlc::cdiv(D, kchunk);
     DLC_HIP_CHECK(ctx, hipMemsetAsync(out, 0, (size_t)N * (size_t)N * 8, (hipStream_t)stream));
