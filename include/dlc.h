@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DLC_ABI_VERSION 2
+#define DLC_ABI_VERSION 3
 
 typedef struct dlc_ctx dlc_ctx;
 
