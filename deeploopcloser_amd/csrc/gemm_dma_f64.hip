@@ -53,6 +53,10 @@ struct DmaArgs {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+#ifdef DLC_EXP_DMA_STAMPS       // diagnostic build only: where a wave's cycles go, summed over its K tiles (s_memtime ticks)
+__device__ unsigned long long dlc_exp_stamps[256][8][4];   // [workgroup < 256][wave][wait for DMA, barrier, tile body, tiles]
+#endif
+
 // LDS-DMA wave-instructions of one K tile: four 1 KiB pieces of the A stage (dma_a4), two of the B stage (dma_b2).
 // Inline asm so that hipcc does not count them in vmcnt (it would wait for vmcnt(0) in front of every LDS read); M0
 // carries the wave-uniform LDS destination and is saved / restored because the compiler owns it.  s_nop 4 covers
@@ -273,12 +277,28 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     };
     // wait for this wave's DMA pieces (all that are in flight belong to the tile about to become readable), then the
     // workgroup barrier: behind it that tile is visible to every wave and the stage of the tile two back is free
+#ifdef DLC_EXP_DMA_STAMPS
+    unsigned long long st_wait = 0, st_bar = 0, st_body = 0, st_n = 0, st_last = __builtin_amdgcn_s_memtime();
+#endif
     auto arrive = [&]() {
+#ifdef DLC_EXP_DMA_STAMPS
+        const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+        st_body += s0 - st_last;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DLC_EXP_DMA_STAMPS
+        const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+        st_wait += s1 - s0;
+#endif
 #ifndef DLC_EXP_DMA_NO_BARRIER      // timing experiments only (wrong results)
         __builtin_amdgcn_s_barrier();
 #endif
         asm volatile("" ::: "memory");
+#ifdef DLC_EXP_DMA_STAMPS
+        st_last = __builtin_amdgcn_s_memtime();
+        st_bar += st_last - s1;
+        ++st_n;
+#endif
     };
     auto issue = [&](int t, int stage) {
 #ifdef DLC_EXP_DMA_NO_ISSUE        // timing experiments only (wrong results): only the first tile is ever loaded
@@ -343,6 +363,12 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         mm(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup's LDS
+#ifdef DLC_EXP_DMA_STAMPS
+    if (blockIdx.x < 256 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {   // the workgroups of XCD 0 among the first ids
+        unsigned long long* o = dlc_exp_stamps[blockIdx.x >> 3][w];
+        o[0] = st_wait; o[1] = st_bar; o[2] = st_body; o[3] = st_n;
+    }
+#endif
 
     // ---- epilogue: bias + activation, C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
 #pragma unroll
@@ -431,5 +457,11 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     }
     return DLC_OK;
 }
+
+#ifdef DLC_EXP_DMA_STAMPS
+extern "C" int dlc_exp_read_stamps(unsigned long long* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dlc_gemm::dlc_exp_stamps), bytes < sizeof(dlc_gemm::dlc_exp_stamps) ? bytes : sizeof(dlc_gemm::dlc_exp_stamps));
+}
+#endif
 
 }  // namespace dlc_gemm
