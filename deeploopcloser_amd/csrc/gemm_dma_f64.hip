@@ -386,207 +386,17 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The same tile with ONE wave per SIMD: 4 waves (2 x 2), each 128 x 64 (8 x NJ MFMA tiles, 256 accumulator
-// registers of the 512 a lone wave may use).  Why: cycle stamps of the 8-wave kernel above (scripts/exp_dma_stamps.py)
-// show no wait for DMA data at all (22 cycles per K tile) but the two waves of a SIMD taking turns badly -- the older
-// wave runs its 64 MFMAs in 5971 cycles and then sits 3755 at the barrier while its partner, which got the leftovers,
-// needs 9329: 9748 cycles per K tile for 8192 of matrix work.  A lone wave issues its MFMAs back to back (the bare
-// loop of scripts/micro/mfma_f64_peak.hip: 77.6 TF with one wave per SIMD); everything else -- 24 fragment reads,
-// 12 DMA instructions per K tile -- goes into the MFMAs' shadows.  The barrier sits in the MIDDLE of a tile:
-//   k-slices 0,1 of tile t | wait for this wave's DMA pieces of tile t+1, barrier | DMA of tile t+2 into the stage
-//   of tile t-1 | k-slices 2,3 of tile t, with k-slice 0 of tile t+1 (readable since the barrier) prefetched
-// so that no wave ever leaves a barrier without fragments in registers.  Same k order, same bits.
-constexpr int NT4 = 256;
-
-template <int BLAYOUT, bool CONV, int NJ>
-__global__ __launch_bounds__(NT4, 1) void gemm_dma_f64_w4_kernel(DmaArgs p) {
-    constexpr int TNJ = 2 * NJ * 16;
-    extern __shared__ __attribute__((aligned(16))) char smem3[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1;
-    long long tile_m, tile_n;
-    {
-        const long long wg = blockIdx.x;
-        const long long l = wg >> 3;
-        const long long gb = (l >> 5) * 8 + (wg & 7);
-        if (gb >= p.nblocks) return;
-        const int i = (int)(l & 31);
-        tile_m = (gb % p.nbr) * p.br + (i % p.br);
-        tile_n = (gb / p.nbr) * p.bc + (i / p.br);
-        if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
-    }
-    const long long m0 = tile_m * TM3, n0 = tile_n * TNJ;
-    if (p.tri_p > 0 && (p.tri_col0 + n0 + TNJ - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;
-    const int nkt = (int)((p.K + TK3 - 1) / TK3);
-    const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem3;
-
-    // ---- DMA sources: instruction j (0..7) of this wave covers stage rows 8 * (8w + j) .. + 7 of A; instruction j
-    // (0..3) rows 8 * (4w + j) .. of an [N,K] B or k-row 4w + j of a [K,N] B.  Swizzles as in the 8-wave kernel.
-    // 256 of the 512 registers are accumulators, so per-lane DMA state is kept compact and the pointers are rebuilt
-    // for every K tile (in the shadow of the MFMAs): a convolution keeps (image, oy, ox) of its 8 rows packed.
-    const int slot = lane & 7;
-    const int ra0 = w * 64 + (lane >> 3);                       // stage row of instruction 0; instruction j: + 8j
-    const int rb0 = w * 32 + (lane >> 3);
-    int cv_img[8], cv_pix[8];                                   // CONV: image of the row; (oy << 16) | ox
-    if constexpr (CONV) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            long long gm = m0 + ra0 + 8 * j;
-            if (gm > p.M - 1) gm = p.M - 1;
-            const long long img = gm / ((long long)p.cv.OH * p.cv.OW);
-            const int rem = (int)(gm - img * p.cv.OH * p.cv.OW);
-            const int oy = rem / p.cv.OW, ox = rem - oy * p.cv.OW;
-            cv_img[j] = (int)img;
-            cv_pix[j] = (oy << 16) | ox;
-        }
-    }
-    const char* zsrc = p.zero + slot * 16;
-    int cv_c0 = 0, cv_kx = 0, cv_ky = 0;
-
-    auto issue = [&](int t, int stage) {                       // K tile t (< nkt) -> ring stage
-        const long long k0 = (long long)t * TK3;
-        const int klim = (int)(p.K - k0 < TK3 ? p.K - k0 : TK3);
-        const int klim_b = (int)(p.Kb - k0 < TK3 ? (p.Kb - k0 > 0 ? p.Kb - k0 : 0) : TK3);
-        const char* sa[8];
-        const char* sb[4];
-        int ra = ra0, rb = rb0;
-        asm volatile("" : "+v"(ra), "+v"(rb));                 // keep the per-row address arithmetic INSIDE the loop (hoisted,
-                                                                // it costs 24 registers the accumulators need)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = ra + 8 * j;
-            const int piece = slot ^ ((r >> 1) & 7);
-            if constexpr (CONV) {
-                const int iy = (cv_pix[j] >> 16) * p.cv.stride - p.cv.pad_t + cv_ky;
-                const int ix = (cv_pix[j] & 0xffff) * p.cv.stride - p.cv.pad_l + cv_kx;
-                const bool ok = iy >= 0 && iy < p.cv.H && ix >= 0 && ix < p.cv.W;
-                const long long e = ((long long)cv_img[j] * p.cv.H * p.cv.W + (long long)iy * p.cv.W + ix) * p.cv.C + cv_c0 + piece * 2;
-                sa[j] = ok ? p.A + e * 8 : zsrc;
-            } else {
-                long long gm = m0 + r;
-                if (gm > p.M - 1) gm = p.M - 1;
-                sa[j] = piece * 2 >= klim ? zsrc : p.A + gm * p.lda_b + k0 * 8 + piece * 16;
-            }
-        }
-        if constexpr (CONV) {
-            cv_c0 += TK3;
-            if (cv_c0 >= p.cv.C) {
-                cv_c0 = 0;
-                if (++cv_kx == p.cv.KW) { cv_kx = 0; ++cv_ky; }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (BLAYOUT == DLC_B_NK) {
-                const int r = rb + 8 * j;
-                const int piece = slot ^ ((r >> 1) & 7);
-                long long gn = n0 + r;
-                if (gn > p.N - 1) gn = p.N - 1;
-                sb[j] = piece * 2 >= klim_b ? zsrc : p.B + gn * p.ldb_b + k0 * 8 + piece * 16;
-            } else {
-                const int kr = w * 4 + j;
-                int piece = (rb & 0) + (lane ^ ((kr & 1) << 3));
-                const long long cols = p.N - n0 < TNJ ? p.N - n0 : TNJ;
-                const int last = (int)(cols / 2) - 1;
-                if (piece > last) piece = last;
-                sb[j] = kr >= klim_b ? zsrc : p.B + (k0 + kr) * p.ldb_b + n0 * 8 + piece * 16;
-            }
-        }
-        const unsigned la = lds_base + stage * STAGE + w * 8192;
-        dma_a4(sa[0], sa[1], sa[2], sa[3], la);
-        dma_a4(sa[4], sa[5], sa[6], sa[7], la + 4096);
-        dma_a4(sb[0], sb[1], sb[2], sb[3], lds_base + stage * STAGE + A_STAGE + w * 4096);
-    };
-
-    const int fr = lane & 15, fk = lane >> 4;
-    const int x7 = (fr >> 1) & 7;
-    int pk[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) pk[kk] = (((kk * 2 + (fk >> 1)) ^ x7) << 4) + (fk & 1) * 8;
-    const int ra_base = (wr * 128 + fr) * 128;                  // A fragment i: + i * 2048 (an immediate of the LDS read)
-    int rb_off[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if constexpr (BLAYOUT == DLC_B_NK) rb_off[j] = A_STAGE + ((wc * NJ + j) * 16 + fr) * 128;
-        else rb_off[j] = A_STAGE + fk * 1024 + (((((wc * NJ + j) * 8 + (fr >> 1)) ^ ((fk & 1) << 3))) << 4) + (fr & 1) * 8;
-    }
-    f64x4_t acc[8][NJ];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (f64x4_t){0, 0, 0, 0};
-    double fa[2][8], fb[2][NJ];
-    auto rd = [&](const char* st, int kk, int b) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fa[b][i] = *(const double*)(st + ra_base + pk[kk] + i * 2048);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const double*)(st + rb_off[j] + pk[kk]);
-            else fb[b][j] = *(const double*)(st + rb_off[j] + kk * 4096);
-        }
-    };
-    auto mm = [&](int b) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[b][i], fb[b][j], acc[i][j], 0, 0, 0);
-    };
-    auto sync_all = [&]() {                                     // every DMA this wave has in flight landed; workgroup barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-
-    issue(0, 0);
-    sync_all();                                                 // tile 0 readable
-    if (nkt > 1) issue(1, 1);
-    rd(smem3, 0, 0);
-    int cur = 0;                                                // stage of tile t
-    for (int t = 0; t < nkt; ++t) {
-        const char* st = smem3 + cur * STAGE;
-        const int nxt = cur + 1 == NSTAGE ? 0 : cur + 1;        // stage of tile t+1
-        const int prv = cur == 0 ? NSTAGE - 1 : cur - 1;        // stage of tile t-1 == stage of tile t+2
-        rd(st, 1, 1); mm(0);                                    // k-slice 0
-        rd(st, 2, 0); mm(1);                                    // k-slice 1
-        sync_all();                                             // tile t+1 readable; nobody reads tile t-1 any more
-        if (t + 2 < nkt) issue(t + 2, prv);
-        rd(st, 3, 1); mm(0);                                    // k-slice 2
-        if (t + 1 < nkt) rd(smem3 + nxt * STAGE, 0, 0);         // k-slice 0 of the next tile
-        mm(1);                                                  // k-slice 3
-        cur = nxt;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const long long gn = n0 + (wc * NJ + j) * 16 + fr;
-        if (gn >= p.N) continue;
-        const double bv = p.bias ? p.bias[gn] : 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long gm = m0 + wr * 128 + i * 16 + fk + 4 * r;
-                if (gm < p.M) p.C[gm * p.ldc + gn] = act_f64(acc[i][j][r] + bv, p.act);
-            }
-    }
-}
-
-#ifndef DLC_DMA_WAVES
-#define DLC_DMA_WAVES 4          // 4: one wave per SIMD (above); 8: two waves per SIMD half a K tile apart
-#endif
+// (A one-wave-per-SIMD form of this kernel -- 4 waves of 128 x 64, the barrier in the middle of a K tile, every wave
+// leaving it with fragments in registers -- is in commit 0d57e84: bit-identical, and 49.5 vs 30.5 ms on SDAV.transform,
+// 88.7 vs 36.0 ms on CnnVtl.transform.  The cycle stamps that motivated it (scripts/exp_dma_stamps.py: the older wave of
+// a SIMD runs its 64 MFMAs in 5971 cycles and then sits 3755 at the barrier while its partner needs 9329; no wait for
+// DMA data at all) are real, but a lone compiler-scheduled wave with 256 accumulator registers spills inside the loop
+// and does not keep the matrix pipe fed; two waves covering each other do better.)
 
 template <int BLAYOUT, bool CONV, int NJ>
 int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
-#if DLC_DMA_WAVES == 4
-    auto kern = gemm_dma_f64_w4_kernel<BLAYOUT, CONV, NJ>;
-    constexpr int threads = NT4;
-#else
     auto kern = gemm_dma_f64_kernel<BLAYOUT, CONV, NJ>;
     constexpr int threads = NT3;
-#endif
     const unsigned long long m = 1ull << (DLC_ATTR_DMA64_BASE + (CONV ? 2 : (BLAYOUT == DLC_B_KN ? 0 : 1)) + (NJ == 3 ? 3 : 0));
     if (!(ctx->func_attr_set & m)) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3));
