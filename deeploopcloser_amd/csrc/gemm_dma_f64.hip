@@ -49,9 +49,53 @@ struct DmaArgs {
     int br, bc;
     int tri_p;
     long long tri_row0, tri_col0;
+    // triangular launches enumerate only the blocks that hold wanted entries, column by column (see block_of)
+    long long tri_nbc;                          // block columns
+    int tri_blk_cols, tri_rem0, tri_step, tri_lg_rows;
+};
+
+// Triangular launches (the Gram blocks of the similarity: only entries whose row frame < column frame are read).
+// Workgroup ids go round-robin to the 8 XCDs, so XCD x runs blocks x, x + 8, ... of whatever order the blocks are
+// numbered in.  Numbered row-major over the full rectangle, with a row count that is a multiple of 8 (32 at 1063
+// frames), XCD x owns block ROWS x, x + 8, ..: XCD 0 got 80 blocks' worth of the triangle and XCD 7 got 52 -- the
+// launch took 49.4 ms where half of the full product's 80.5 ms is 40.7 (scripts/exp_gram_shapes.py).  So: number only
+// the blocks that hold at least one wanted entry, column by column; every XCD then gets the same count +- 1.
+// In block column c the wanted block rows are 0 .. cnt(c) - 1:  block (r, c) is wanted iff its last column's frame
+// is past its first row's frame, (col0 + (c + 1) * BC - 1) / p > (row0 + r * BR) / p, i.e. r * BR < F * p - row0 with
+// F * p = the column's last index rounded down to a multiple of p.  BR is a power of two; the remainder is stepped.
+struct TriWalk {
+    long long t;                                // last column index (col0 based) of the current block column
+    int rem;                                    // t % p
+    __host__ __device__ long long count(const DmaArgs& a) const {
+        const long long thr = t - rem - a.tri_row0;
+        if (thr <= 0) return 0;
+        const long long c = (thr + (1ll << a.tri_lg_rows) - 1) >> a.tri_lg_rows;
+        return c < a.nbr ? c : a.nbr;
+    }
+    __host__ __device__ void step(const DmaArgs& a) {
+        t += a.tri_blk_cols;
+        rem += a.tri_step;
+        if (rem >= a.tri_p) rem -= a.tri_p;
+    }
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+#ifdef DLC_EXP_DMA_VOLATILE     // experiment: fragment reads the compiler may not pair into ds_read2st64_b64
+#define DLC_FRAG_Q volatile
+#else
+#define DLC_FRAG_Q
+#endif
+// experiment: wave priority by progress through the K tile (the wave that is behind gets the matrix pipe)
+#if defined(DLC_EXP_DMA_PRIO) && DLC_EXP_DMA_PRIO == 1
+#define DLC_PRIO(slice) do { __builtin_amdgcn_s_setprio(3 - (slice)); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(DLC_EXP_DMA_PRIO) && DLC_EXP_DMA_PRIO == 3
+#define DLC_PRIO(slice) do { __builtin_amdgcn_s_setprio((slice) < 2 ? 1 : 0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(DLC_EXP_DMA_PRIO) && DLC_EXP_DMA_PRIO == 4
+#define DLC_PRIO(slice) do { __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DLC_PRIO(slice) do { } while (0)
+#endif
 
 #ifdef DLC_EXP_DMA_STAMPS       // diagnostic build only: where a wave's cycles go, summed over its K tiles (s_memtime ticks)
 __device__ unsigned long long dlc_exp_stamps[256][8][4];   // [workgroup < 256][wave][wait for DMA, barrier, tile body, tiles]
@@ -122,11 +166,27 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     {
         const long long wg = blockIdx.x;
         const long long l = wg >> 3;
-        const long long gb = (l >> 5) * 8 + (wg & 7);
+        long long gb = (l >> 5) * 8 + (wg & 7);
         if (gb >= p.nblocks) return;
         const int i = (int)(l & 31);
-        tile_m = (gb % p.nbr) * p.br + (i % p.br);
-        tile_n = (gb / p.nbr) * p.bc + (i / p.br);
+        long long brow, bcol;
+        if (p.tri_p > 0) {                                               // the gb-th wanted block, columns first
+            TriWalk tw{p.tri_col0 + p.tri_blk_cols - 1, p.tri_rem0};
+            bcol = 0;
+            for (;;) {
+                const long long cnt = tw.count(p);
+                if (gb < cnt) break;
+                gb -= cnt;
+                tw.step(p);
+                if (++bcol >= p.tri_nbc) return;                          // cannot happen: nblocks is the sum of the counts
+            }
+            brow = gb;
+        } else {
+            brow = gb % p.nbr;
+            bcol = gb / p.nbr;
+        }
+        tile_m = brow * p.br + (i % p.br);
+        tile_n = bcol * p.bc + (i / p.br);
         if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
     }
     const long long m0 = tile_m * TM3, n0 = tile_n * TNJ;
@@ -262,11 +322,11 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         if (kk >= 0) { asm volatile("" : "+v"(fa[b][0]), "+v"(fb[b][0])); return; }
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[b][i] = *(const double*)(st + ra_off[i] + pk[kk]);
+        for (int i = 0; i < 4; ++i) fa[b][i] = *(const DLC_FRAG_Q double*)(st + ra_off[i] + pk[kk]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const double*)(st + rb_off[j] + pk[kk]);
-            else fb[b][j] = *(const double*)(st + rb_off[j] + kk * 4096);
+            if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const DLC_FRAG_Q double*)(st + rb_off[j] + pk[kk]);
+            else fb[b][j] = *(const DLC_FRAG_Q double*)(st + rb_off[j] + kk * 4096);
         }
     };
     auto mm = [&](int b) {
@@ -322,6 +382,9 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     // any DMA: what the operand traffic costs, 8 %, is neither instruction issue nor prefetch distance.)
     issue(0, 0);
     int cur = 0;
+#if defined(DLC_EXP_DMA_PRIO) && DLC_EXP_DMA_PRIO == 2
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     if (w < 4) {
         for (int t = 0; t < nkt; ++t) {
             arrive();                                                    // barrier t
@@ -329,10 +392,10 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             const int nxt = next_stage(cur);
             rd(st, 0, 0);
             if (t + 1 < nkt) issue(t + 1, nxt);
-            rd(st, 1, 1); mm(0);
-            rd(st, 2, 0); mm(1);
-            rd(st, 3, 1); mm(0);
-            mm(1);
+            rd(st, 1, 1); DLC_PRIO(0); mm(0);
+            rd(st, 2, 0); DLC_PRIO(1); mm(1);
+            rd(st, 3, 1); DLC_PRIO(2); mm(0);
+            DLC_PRIO(3); mm(1);
             cur = nxt;
         }
         arrive();                                                        // barrier nkt (the late waves' last half tile)
@@ -350,11 +413,11 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             const char* sp = smem3 + cur * STAGE;                        // tile t-1
             const int nxt = next_stage(cur);
             const char* st = smem3 + nxt * STAGE;                        // tile t
-            rd(sp, 3, 1); mm(0);
+            rd(sp, 3, 1); DLC_PRIO(0); mm(0);
             if (t + 1 < nkt) issue(t + 1, next_stage(nxt));
-            rd(st, 0, 0); mm(1);
-            rd(st, 1, 1); mm(0);
-            rd(st, 2, 0); mm(1);
+            rd(st, 0, 0); DLC_PRIO(1); mm(1);
+            rd(st, 1, 1); DLC_PRIO(2); mm(0);
+            rd(st, 2, 0); DLC_PRIO(3); mm(1);
             cur = nxt;
         }
         arrive();                                                        // barrier nkt
@@ -448,7 +511,18 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     }
     a.br = br; a.bc = bc;
     a.nbr = dlc::cdiv(tiles_m, (int64_t)br);
-    a.nblocks = a.nbr * dlc::cdiv(tiles_n, (int64_t)bc);
+    a.tri_nbc = dlc::cdiv(tiles_n, (int64_t)bc);
+    a.nblocks = a.nbr * a.tri_nbc;
+    a.tri_blk_cols = bc * tn; a.tri_rem0 = 0; a.tri_step = 0; a.tri_lg_rows = 0;
+    if (a.tri_p > 0) {
+        while ((1 << a.tri_lg_rows) < br * TM3) ++a.tri_lg_rows;         // br is a power of two, and so is the tile height
+        a.tri_step = a.tri_blk_cols % a.tri_p;
+        TriWalk tw{a.tri_col0 + a.tri_blk_cols - 1, (int)((a.tri_col0 + a.tri_blk_cols - 1) % a.tri_p)};
+        a.tri_rem0 = tw.rem;
+        a.nblocks = 0;
+        for (long long c = 0; c < a.tri_nbc; ++c, tw.step(a)) a.nblocks += tw.count(a);
+        if (a.nblocks == 0) return DLC_OK;                               // nothing wanted (the caller never reads this block)
+    }
     const long long nwg = dlc::cdiv(a.nblocks, (int64_t)8) * 8 * 32;
     if (nwg > 0x7fffffffll) return 1;
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);

@@ -64,6 +64,36 @@ def test_similarity_matrix_kennedylong_properties(dlc, descriptors):
             want = np.sum(10 - 10 * np.log(d))
         assert (np.isinf(want) and mf[i, j] == want) or abs(mf[i, j] - want) <= 1e-9 * abs(want)
         assert calc.similarity_score(dsn[i], dsn[j]) == mf[i, j]          # per-pair entry == matrix entry
+    # every entry, against launches that walk other Gram blocks in another order: a frame range scored on its own
+    # (same distinctive score) is that range of the full matrix, bit for bit
+    eng = calc.engine
+    for lo, hi in ((0, 500), (300, 1000), (563, N_FRAMES)):
+        sub, _ = eng.sdav_similarity_matrix(ds[lo:hi], calc._score, 10.0, -10.0, want_int64=False)
+        assert np.array_equal(sub.cpu().numpy(), mf[lo:hi, lo:hi]), (lo, hi)
+
+
+def test_similarity_matrix_two_gram_chunks(dlc):
+    """More frames than one 8 GiB Gram block holds (1500 x 30 patches: row chunks of 768 + 731 frames, the second
+    launch's triangle starting at row0 > 0): == frame ranges scored alone, bit for bit, and the oracle on sampled pairs."""
+    from oracle import similarity as osim
+    eng = dlc.default_engine()
+    n, p, h = 1500, 30, 64
+    g = torch.Generator(device=eng.device); g.manual_seed(21)
+    ds = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
+    score = eng.distinctive_score(ds, 0.5, 0.2)
+    mf, _ = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, want_int64=False)
+    mf = mf.cpu().numpy()
+    assert np.array_equal(mf, mf.T) and np.all(np.diag(mf) == -1)
+    for lo, hi in ((0, 760), (700, n), (760, 1300)):
+        sub, _ = eng.sdav_similarity_matrix(ds[lo:hi], score, 10.0, -10.0, want_int64=False)
+        assert np.array_equal(sub.cpu().numpy(), mf[lo:hi, lo:hi]), (lo, hi)
+    dsn, sc = ds.cpu().numpy(), score.cpu().numpy()
+    rng = np.random.RandomState(1)
+    for _ in range(8):
+        i, j = sorted(rng.choice(n, 2, replace=False))
+        d = osim.weighted_distances(dsn[i], dsn[j], osim.match_features(dsn[i], dsn[j]), sc)
+        want = np.sum(10 - 10 * np.log(d))
+        assert abs(mf[i, j] - want) <= 1e-9 * abs(want)
 
 
 def test_distance_matrix_kennedylong_properties(dlc):
