@@ -7,7 +7,7 @@ eng = dlc.default_engine()
 g = torch.Generator(device=eng.device); g.manual_seed(0)
 nf = 1063
 frames = torch.randint(0, 256, (nf, 192, 240, 3), generator=g, device=eng.device).to(torch.float64)
-for chunk in (64, 128, 252, 256, 504, 1063):
+for chunk in (213, 266, 355, 532, 1063):
     cnn = dlc.CnnVtl(input_shape=[nf, 192, 240, 3], frame_chunk=chunk)
     cnn.transform_tensor(frames); torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -231,16 +231,20 @@ def test_cosine_config5_fp16_one_million_rows(dlc):
 
 
 def test_cnn_vtl_transform_kennedylong_multi_chunk(dlc):
-    """configs[2]: CnnVtl.transform on 1063 frames of 192x240 (chunks of 504 + 504 + 55 inside the call) ==
-    the same frames encoded chunk by chunk and frame by frame, bit for bit; == the oracle on sampled frames."""
+    """configs[2]: CnnVtl.transform on 1063 frames of 192x240, in one chunk (the default) and in three of 355 / 354 /
+    354 frames inside the call == the same frames encoded range by range and frame by frame, bit for bit; == the
+    oracle on sampled frames."""
     from oracle import cnn_vtl as ocnn
     eng = dlc.default_engine()
     g = torch.Generator(device="cuda")
     g.manual_seed(11)
     frames = torch.randint(0, 256, (N_FRAMES, 192, 240, 3), generator=g, device="cuda").to(torch.float64)
-    net = dlc.CnnVtl(input_shape=[N_FRAMES, 192, 240, 3], seed=5, mask_seed=9)
-    assert net.frame_chunk == 504
+    net = dlc.CnnVtl(input_shape=[N_FRAMES, 192, 240, 3], seed=5, mask_seed=9, frame_chunk=504)
     d = net.transform_tensor(frames)
+    whole = dlc.CnnVtl(input_shape=[N_FRAMES, 192, 240, 3], seed=5, mask_seed=9)
+    assert whole.frame_chunk >= N_FRAMES
+    assert torch.equal(whole.transform_tensor(frames), d)
+    del whole
     assert d.shape == (N_FRAMES, net.columns.size) and d.dtype == torch.int8 and net.columns.size <= 2243
     for lo, hi in ((0, 504), (504, 1008), (1008, 1063), (503, 505), (1062, 1063), (700, 701)):
         assert torch.equal(net.transform_tensor(frames[lo:hi]), d[lo:hi]), (lo, hi)
