@@ -230,7 +230,7 @@ def bench_paths(eng, n_frames):
     err = float(np.abs(h[:nb * P].cpu().numpy() - ref).max())
     out.append({"path": "SDAV.transform", "reference": "src/sdav/network/SDAV.py:293-302", "frames": N, "dtype": "f64",
                 "value": N / (call_ms * 1e-3), "unit": "frames/s", "ms": call_ms,
-                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_bias_act_kernel<double> (5 layers, fused bias + sigmoid)"),
+                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_dma_f64_kernel (5 layers, LDS-DMA fp64 GEMM, fused bias + sigmoid)"),
                 "cpu_baseline": {"value": nb / t_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/sdav.py (fp64 NumPy) on the first %d of the %d frames, same weights: "
                                            "%.1f s of CPU work" % (nb, N, t_cpu)},
@@ -281,7 +281,7 @@ def bench_paths(eng, n_frames):
     out.append({"path": "SDAV similarity matrix", "reference": "src/sdav/similarity/SimilarityCalculator.py:12-49, "
                 "src/sdav/create_similarity_matrix.py:29-38", "frames": N, "dtype": "f64",
                 "value": pairs / (call_ms * 1e-3), "unit": "frame-pairs/s", "ms": call_ms,
-                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_bias_act_kernel<double> (Gram blocks desc . desc^T)"),
+                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_dma_f64_kernel (Gram blocks desc . desc^T, wanted blocks only)"),
                 "cpu_baseline": {"value": (ns * (ns - 1) // 2) / t_cpu, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/similarity.py all-vs-all loop on the first %d frames (%d pairs, mean / "
                                            "distinctive score hoisted): %.2f s; the literal similarity_score (mean recomputed "
@@ -351,7 +351,7 @@ def bench_paths(eng, n_frames):
     diff = int((d8[:nb].cpu().numpy() != ref).sum())
     out.append({"path": "CnnVtl.transform", "reference": "src/cnn_vtl/network/cnn_vtl.py:28-133", "frames": N, "dtype": "f64",
                 "descriptor_bytes": int(d8.shape[1]), "value": N / (call_ms * 1e-3), "unit": "frames/s", "ms": call_ms,
-                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_bias_act_kernel<double> (implicit-GEMM conv1..conv5, fused bias + ReLU)"),
+                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_dma_f64_kernel (implicit-GEMM conv1..conv5, fused bias + ReLU)"),
                 "cpu_baseline": {"value": nb / t_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/cnn_vtl.py (fp64 NumPy im2col + matmul) on the first %d frames, same weights and "
                                            "columns: %.1f s" % (nb, t_cpu)},

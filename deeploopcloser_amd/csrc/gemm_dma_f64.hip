@@ -81,25 +81,16 @@ struct TriWalk {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-#ifdef DLC_EXP_DMA_VOLATILE     // experiment: fragment reads the compiler may not pair into ds_read2st64_b64
-#define DLC_FRAG_Q volatile
-#else
-#define DLC_FRAG_Q
-#endif
-// experiment: wave priority by progress through the K tile (the wave that is behind gets the matrix pipe)
-#if defined(DLC_EXP_DMA_PRIO) && DLC_EXP_DMA_PRIO == 1
-#define DLC_PRIO(slice) do { __builtin_amdgcn_s_setprio(3 - (slice)); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif defined(DLC_EXP_DMA_PRIO) && DLC_EXP_DMA_PRIO == 3
-#define DLC_PRIO(slice) do { __builtin_amdgcn_s_setprio((slice) < 2 ? 1 : 0); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif defined(DLC_EXP_DMA_PRIO) && DLC_EXP_DMA_PRIO == 4
-#define DLC_PRIO(slice) do { __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define DLC_PRIO(slice) do { } while (0)
-#endif
-
-#ifdef DLC_EXP_DMA_STAMPS       // diagnostic build only: where a wave's cycles go, summed over its K tiles (s_memtime ticks)
-__device__ unsigned long long dlc_exp_stamps[256][8][4];   // [workgroup < 256][wave][wait for DMA, barrier, tile body, tiles]
-#endif
+// Between the k-slices of a K tile: for the plain operands, a scheduling fence -- the source's order (reads of slice
+// k+1, then the 16 MFMAs of slice k) is the schedule; left alone hipcc pairs B reads of neighbouring slices and moves
+// them up, which measured 1.8 % (SDAV layers) and 2.7 % (Gram) slower.  The convolution form, whose DMA addresses are
+// VALU work the compiler spreads between the MFMAs, is 1 % faster without the fence.
+// Measured and not kept (scripts/exp_dgemm.py, one device): s_setprio by progress through the tile (the wave that is
+// behind gets the matrix pipe), by half tile, or static for the late waves: each 2 % SLOWER than no priorities -- the
+// 1.6 : 1 split of a K tile's cycles between the two waves of a SIMD (cycle stamps) is not what costs
+// the time; volatile fragment reads (to keep hipcc from pairing A reads into ds_read2st64_b64, which has half the
+// rate of ds_read_b64 and sees 32 banks): 37 % slower, every read followed by a full wait.
+#define DLC_SLICE_FENCE() do { if constexpr (!CONV) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // LDS-DMA wave-instructions of one K tile: four 1 KiB pieces of the A stage (dma_a4), two of the B stage (dma_b2).
 // Inline asm so that hipcc does not count them in vmcnt (it would wait for vmcnt(0) in front of every LDS read); M0
@@ -322,11 +313,11 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         if (kk >= 0) { asm volatile("" : "+v"(fa[b][0]), "+v"(fb[b][0])); return; }
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[b][i] = *(const DLC_FRAG_Q double*)(st + ra_off[i] + pk[kk]);
+        for (int i = 0; i < 4; ++i) fa[b][i] = *(const double*)(st + ra_off[i] + pk[kk]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const DLC_FRAG_Q double*)(st + rb_off[j] + pk[kk]);
-            else fb[b][j] = *(const DLC_FRAG_Q double*)(st + rb_off[j] + kk * 4096);
+            if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const double*)(st + rb_off[j] + pk[kk]);
+            else fb[b][j] = *(const double*)(st + rb_off[j] + kk * 4096);
         }
     };
     auto mm = [&](int b) {
@@ -382,9 +373,6 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     // any DMA: what the operand traffic costs, 8 %, is neither instruction issue nor prefetch distance.)
     issue(0, 0);
     int cur = 0;
-#if defined(DLC_EXP_DMA_PRIO) && DLC_EXP_DMA_PRIO == 2
-    if (w >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     if (w < 4) {
         for (int t = 0; t < nkt; ++t) {
             arrive();                                                    // barrier t
@@ -392,10 +380,10 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             const int nxt = next_stage(cur);
             rd(st, 0, 0);
             if (t + 1 < nkt) issue(t + 1, nxt);
-            rd(st, 1, 1); DLC_PRIO(0); mm(0);
-            rd(st, 2, 0); DLC_PRIO(1); mm(1);
-            rd(st, 3, 1); DLC_PRIO(2); mm(0);
-            DLC_PRIO(3); mm(1);
+            rd(st, 1, 1); DLC_SLICE_FENCE(); mm(0);
+            rd(st, 2, 0); DLC_SLICE_FENCE(); mm(1);
+            rd(st, 3, 1); DLC_SLICE_FENCE(); mm(0);
+            DLC_SLICE_FENCE(); mm(1);
             cur = nxt;
         }
         arrive();                                                        // barrier nkt (the late waves' last half tile)
@@ -413,11 +401,11 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             const char* sp = smem3 + cur * STAGE;                        // tile t-1
             const int nxt = next_stage(cur);
             const char* st = smem3 + nxt * STAGE;                        // tile t
-            rd(sp, 3, 1); DLC_PRIO(0); mm(0);
+            rd(sp, 3, 1); DLC_SLICE_FENCE(); mm(0);
             if (t + 1 < nkt) issue(t + 1, next_stage(nxt));
-            rd(st, 0, 0); DLC_PRIO(1); mm(1);
-            rd(st, 1, 1); DLC_PRIO(2); mm(0);
-            rd(st, 2, 0); DLC_PRIO(3); mm(1);
+            rd(st, 0, 0); DLC_SLICE_FENCE(); mm(1);
+            rd(st, 1, 1); DLC_SLICE_FENCE(); mm(0);
+            rd(st, 2, 0); DLC_SLICE_FENCE(); mm(1);
             cur = nxt;
         }
         arrive();                                                        // barrier nkt
