@@ -44,6 +44,7 @@ struct DmaArgs {
     long long Kb;                               // ... and as B has it (<= K): B's k-rows Kb .. K-1 do not exist and read as zeros
     int act;
     ConvGeom cv;
+    int cv_all_valid;                           // no tap of any output pixel falls outside the input (VALID, no padding)
     const char* zero;                           // >= 128 bytes of zeros
     long long tiles_m, tiles_n, nbr, nblocks;
     int br, bc;
@@ -80,6 +81,7 @@ struct TriWalk {
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) const char* lcptr_t;
 
 // Between the k-slices of a K tile: for the plain operands, a scheduling fence -- the source's order (reads of slice
 // k+1, then the 16 MFMAs of slice k) is the schedule; left alone hipcc pairs B reads of neighbouring slices and moves
@@ -132,6 +134,86 @@ __device__ __forceinline__ void dma_b2(const char* b0, const char* b1, unsigned 
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(b0), "v"(b1), "s"(lds_b)
+        : "memory", "scc");
+}
+
+// The same with a wave-uniform 64-bit base in SGPRs and 32-bit per-lane offsets that never change: a K tile's
+// addresses then cost scalar adds only (each vector instruction beside the fp64 MFMAs costs the SIMD ~7 cycles:
+// 20 more of them per K tile measured 1.4 % -- DLC_EXP_DMA_SPLIT_A_READS).
+__device__ __forceinline__ void dma_a4s(unsigned o0, unsigned o1, unsigned o2, unsigned o3, const char* base, unsigned lds_a) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, %6, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_add_u32 m0, %6, 0x800\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %5\n\t"
+        "s_add_u32 m0, %6, 0xc00\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "s"(lds_a)
+        : "memory", "scc");
+}
+// The convolution's A operand: buffer addressing -- a wave-uniform descriptor (base stepping with the kernel tap and
+// channel block) + per-lane 32-bit offsets; a lane whose tap falls into the padding carries an offset past
+// num_records and the hardware writes ZEROS to its LDS slot (scripts/micro/buffer_lds_oob.hip: out-of-range dwords of
+// a `buffer_load ... lds` land as 0; an soffset counts in the range check, so the base is stepped instead).
+typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+constexpr unsigned DMA_OOB = 0xfffffff0u;       // >= num_records of every descriptor built here
+constexpr unsigned DMA_NUM_RECORDS = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const char* base) {
+    const unsigned long long a = (unsigned long long)base;
+    rsrc_t r;
+    r[0] = (unsigned)a;
+    r[1] = (unsigned)(a >> 32) & 0xffffu;       // stride 0: raw buffer
+    r[2] = DMA_NUM_RECORDS;
+    r[3] = 0x00020000u;                         // gfx9 raw-buffer word (32-bit data format)
+    return r;
+}
+__device__ __forceinline__ void dma_a4b(unsigned o0, unsigned o1, unsigned o2, unsigned o3, rsrc_t rsrc, unsigned lds_a) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %5, 0 offen lds\n\t"
+        "s_add_u32 m0, %6, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %5, 0 offen lds\n\t"
+        "s_add_u32 m0, %6, 0x800\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %3, %5, 0 offen lds\n\t"
+        "s_add_u32 m0, %6, 0xc00\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %4, %5, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rsrc), "s"(lds_a)
+        : "memory", "scc");
+}
+__device__ __forceinline__ void dma_b2s(unsigned o0, unsigned o1, const char* base, unsigned lds_b) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, %4, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(o0), "v"(o1), "s"(base), "s"(lds_b)
         : "memory", "scc");
 }
 
@@ -188,10 +270,17 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     // ---- DMA sources.  A (and an [N,K] B): instruction j of this wave covers rows 8 * (4w + j) .. + 7 of the stage,
     // lane -> (row = lane >> 3, slot = lane & 7), source piece = slot ^ ((row >> 1) & 7).
     const int slot = lane & 7;
-    const char* a_src[4];
+    // Plain operands: a wave-uniform 64-bit base that steps from K tile to K tile (scalar adds) + per-lane 32-bit byte
+    // offsets that never change; 64-bit per-lane addresses are formed for a K-tail tile only (at most the last one).
+    unsigned a_off[4];
     int a_piece[4];                               // source piece (k offset 2 * piece doubles inside the K tile)
-    long long cv_base[4];                         // CONV: element offset of the row's image; iy0 / ix0 of its output pixel
+    // CONV: a row is an output pixel.  a_off = byte offset of its tap (0, 0), channel 2 * piece, from the image of the
+    // tile's first row shifted up-left by the padding (so that it is never negative); the tap and the channel block
+    // move the descriptor's base, the same for every row.  iy0 / ix0: the pixel's input position at tap (0, 0).
     int cv_iy0[4], cv_ix0[4];
+    unsigned a_eff[4];                            // a_off, or DMA_OOB while the current tap is padding for this row
+    long long cv_img0 = 0;
+    if constexpr (CONV) cv_img0 = m0 / ((long long)p.cv.OH * p.cv.OW);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = (w * 4 + j) * 8 + (lane >> 3);
@@ -204,14 +293,19 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             const int oy = rem / p.cv.OW, ox = rem - oy * p.cv.OW;
             cv_iy0[j] = oy * p.cv.stride - p.cv.pad_t;
             cv_ix0[j] = ox * p.cv.stride - p.cv.pad_l;
-            cv_base[j] = img * (long long)p.cv.H * p.cv.W * p.cv.C;
-            a_src[j] = p.A;
+            a_off[j] = (unsigned)((((img - cv_img0) * p.cv.H + oy * p.cv.stride) * p.cv.W + ox * p.cv.stride) * p.cv.C + a_piece[j] * 2) * 8u;
+            a_eff[j] = a_off[j];
         } else {
-            a_src[j] = p.A + gm * p.lda_b + a_piece[j] * 16;
+            a_off[j] = (unsigned)((gm - m0) * p.lda_b) + a_piece[j] * 16;     // < 2^32: checked by the launcher
         }
     }
-    const char* b_src[2];
+    // CONV: element offset of tap (0, 0), channel 0 of the tile's first image, shifted by the padding
+    const long long cv_e0 = CONV ? (cv_img0 * p.cv.H - p.cv.pad_t) * (long long)p.cv.W * p.cv.C - (long long)p.cv.pad_l * p.cv.C : 0;
+    const char* a_base = p.A + m0 * p.lda_b;      // (CONV: unused)
+    unsigned b_off[2];
     int b_piece[2];
+    const char* b_base;
+    long long b_step;                             // bytes from one K tile to the next
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if constexpr (BLAYOUT == DLC_B_NK) {
@@ -219,7 +313,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             b_piece[j] = slot ^ ((r >> 1) & 7);
             long long gn = n0 + r;
             if (gn > p.N - 1) gn = p.N - 1;
-            b_src[j] = p.B + gn * p.ldb_b + b_piece[j] * 16;
+            b_off[j] = (unsigned)((gn - n0) * p.ldb_b) + b_piece[j] * 16;
         } else {
             // [K,N]: instruction j covers k-row kr = 2w + j of the stage, lane -> 16-byte slot, source piece = slot ^ ((kr & 1) << 3)
             const int kr = w * 2 + j;
@@ -228,35 +322,35 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             const int last = (int)(cols / 2) - 1;
             if (piece > last) piece = last;                              // columns past N: never stored
             b_piece[j] = kr;
-            b_src[j] = p.B + (long long)kr * p.ldb_b + n0 * 8 + piece * 16;
+            b_off[j] = (unsigned)(kr * p.ldb_b) + piece * 16;
         }
     }
+    if constexpr (BLAYOUT == DLC_B_NK) { b_base = p.B + n0 * p.ldb_b; b_step = TK3 * 8; }
+    else { b_base = p.B + n0 * 8; b_step = TK3 * p.ldb_b; }
     const char* zsrc = p.zero + slot * 16;
+    const bool a_tail = (p.K & (TK3 - 1)) != 0;                          // the last tile's k past K reads zeros
+    const bool b_tail = a_tail || p.Kb != p.K;                           // ... and B's k past Kb (Kb >= the last tile's first k)
     // wave-uniform kernel tap of the NEXT tile to issue (CONV): k0 = (ky * KW + kx) * C + c0
     int cv_c0 = 0, cv_kx = 0, cv_ky = 0;
 
-    // The A part (4 instructions) and the B part (2) of K tile t's DMA, issued separately (see the main loop).
+    // The A part (4 instructions) and the B part (2) of K tile t's DMA.
     auto issue_a = [&](int t, int stage) {
 #ifdef DLC_EXP_DMA_SAME_TILE       // timing experiments only (wrong results): every DMA re-reads K tile 0 (L2-resident)
         const int tt = 0;
 #else
-        const int tt = t < nkt ? t : nkt - 1;                            // past the end: the last tile again, into a dead stage
+        const int tt = t;
 #endif
-        const long long k0 = (long long)tt * TK3;
-        const int klim = (int)(p.K - k0 < TK3 ? p.K - k0 : TK3);         // valid k of this tile (16 except in a K tail); selects, no branches
-        const char* sa[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (CONV) {
-                const int iy = cv_iy0[j] + cv_ky, ix = cv_ix0[j] + cv_kx;
-                const bool ok = iy >= 0 && iy < p.cv.H && ix >= 0 && ix < p.cv.W;
-                const long long e = cv_base[j] + ((long long)iy * p.cv.W + ix) * p.cv.C + cv_c0 + a_piece[j] * 2;
-                sa[j] = ok ? p.A + e * 8 : zsrc;
-            } else {
-                sa[j] = a_piece[j] * 2 >= klim ? zsrc : a_src[j] + k0 * 8;
-            }
-        }
+        const unsigned lds_a = lds_base + stage * STAGE + w * 4096;
         if constexpr (CONV) {
+            if (cv_c0 == 0 && !p.cv_all_valid) {                         // a new tap: which rows does it send into the padding?
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = (unsigned)(cv_iy0[j] + cv_ky) < (unsigned)p.cv.H && (unsigned)(cv_ix0[j] + cv_kx) < (unsigned)p.cv.W;
+                    a_eff[j] = ok ? a_off[j] : DMA_OOB;
+                }
+            }
+            const long long e = cv_e0 + ((long long)cv_ky * p.cv.W + cv_kx) * p.cv.C + cv_c0;
+            const rsrc_t rs = make_rsrc(p.A + e * 8);
             if (t < nkt - 1) {                                           // step the tap; frozen once the last tile is reached
                 cv_c0 += TK3;
                 if (cv_c0 >= p.cv.C) {
@@ -264,40 +358,67 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
                     if (++cv_kx == p.cv.KW) { cv_kx = 0; ++cv_ky; }
                 }
             }
+            dma_a4b(a_eff[0], a_eff[1], a_eff[2], a_eff[3], rs, lds_a);
+        } else {
+            const char* base = a_base + (long long)tt * (TK3 * 8);
+            if (a_tail && tt == nkt - 1) {
+                const int klim = (int)(p.K - (long long)tt * TK3);       // valid k of this tile
+                const char* sa[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sa[j] = a_piece[j] * 2 >= klim ? zsrc : base + a_off[j];
+                dma_a4(sa[0], sa[1], sa[2], sa[3], lds_a);
+            } else {
+                dma_a4s(a_off[0], a_off[1], a_off[2], a_off[3], base, lds_a);
+            }
         }
-        dma_a4(sa[0], sa[1], sa[2], sa[3], lds_base + stage * STAGE + w * 4096);
     };
     auto issue_b = [&](int t, int stage) {
 #ifdef DLC_EXP_DMA_SAME_TILE
         const int tt = 0;
 #else
-        const int tt = t < nkt ? t : nkt - 1;
+        const int tt = t;
 #endif
-        const long long k0 = (long long)tt * TK3;
-        const int klim = (int)(p.Kb - k0 < TK3 ? (p.Kb - k0 > 0 ? p.Kb - k0 : 0) : TK3);      // B's own reduction length
-        const char* sb[2];
+        const unsigned lds_b = lds_base + stage * STAGE + A_STAGE + w * 2048;
+        const char* base = b_base + (long long)tt * b_step;
+        if (b_tail && tt == nkt - 1) {
+            const long long left = p.Kb - (long long)tt * TK3;           // B's own reduction length
+            const int klim = (int)(left < TK3 ? (left > 0 ? left : 0) : TK3);
+            const char* sb[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if constexpr (BLAYOUT == DLC_B_NK) sb[j] = b_piece[j] * 2 >= klim ? zsrc : b_src[j] + k0 * 8;
-            else sb[j] = b_piece[j] >= klim ? zsrc : b_src[j] + k0 * p.ldb_b;
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (BLAYOUT == DLC_B_NK) sb[j] = b_piece[j] * 2 >= klim ? zsrc : base + b_off[j];
+                else sb[j] = b_piece[j] >= klim ? zsrc : base + b_off[j];
+            }
+            dma_b2(sb[0], sb[1], lds_b);
+        } else {
+            dma_b2s(b_off[0], b_off[1], base, lds_b);
         }
-        dma_b2(sb[0], sb[1], lds_base + stage * STAGE + A_STAGE + w * 2048);
     };
 
-    // ---- fragment read offsets (bytes inside a stage)
+    // ---- fragment read addresses: byte offsets into the ring, for the stage being read; they step with the ring once
+    // per K tile (8 vector adds) instead of being rebuilt from stage + lane offsets in front of every k-slice's reads.
     const int fr = lane & 15, fk = lane >> 4;
     const int x7 = (fr >> 1) & 7;           // the rows' swizzle key: stage row = 16 * something + fr
-    int pk[4];                                    // slot offset of this lane's piece in k-slice kk (A and [N,K] B rows)
+    lcptr_t fa_addr[4];                     // A, k-slice kk: row wr * 64 + fr; MFMA row tile i adds i * 2048 (an immediate)
+    lcptr_t fb_addr[4];                     // [N,K] B, k-slice kk: row wc * NJ * 16 + fr (column tile j adds j * 2048);
+                                            // [K,N] B, column tile j: k-row fk (k-slice kk adds kk * 4096)
+    const lcptr_t ring = (lcptr_t)smem3;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) pk[kk] = (((kk * 2 + (fk >> 1)) ^ x7) << 4) + (fk & 1) * 8;
-    int ra_off[4], rb_off[NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ra_off[i] = (wr * 64 + i * 16 + fr) * 128;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if constexpr (BLAYOUT == DLC_B_NK) rb_off[j] = A_STAGE + ((wc * NJ + j) * 16 + fr) * 128;
-        else rb_off[j] = A_STAGE + fk * 1024 + (((((wc * NJ + j) * 8 + (fr >> 1)) ^ ((fk & 1) << 3))) << 4) + (fr & 1) * 8;
+    for (int kk = 0; kk < 4; ++kk) {
+        const int pk = (((kk * 2 + (fk >> 1)) ^ x7) << 4) + (fk & 1) * 8;
+        fa_addr[kk] = ring + (wr * 64 + fr) * 128 + pk;
+        if constexpr (BLAYOUT == DLC_B_NK) fb_addr[kk] = ring + A_STAGE + (wc * NJ * 16 + fr) * 128 + pk;
+        else fb_addr[kk] = ring + A_STAGE + fk * 1024 + (((((wc * NJ + (kk < NJ ? kk : 0)) * 8 + (fr >> 1)) ^ ((fk & 1) << 3))) << 4) + (fr & 1) * 8;
     }
+    auto advance = [&](int stage_now) {                                  // the addresses move on to the next stage of the ring
+        const int d = stage_now == NSTAGE - 1 ? -(NSTAGE - 1) * STAGE : STAGE;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            fa_addr[x] += d;
+            fb_addr[x] += d;
+            asm volatile("" : "+v"(fa_addr[x]), "+v"(fb_addr[x]));
+        }
+    };
 
     f64x4_t acc[4][NJ];
 #pragma unroll
@@ -308,16 +429,16 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     // fragments of one k-slice, double-buffered in registers: rd() reads slice kk of a stage into buffer b, mm() runs
     // the 16 MFMAs of a buffer.  A slice's reads are always issued before the MFMAs of the slice in front of it.
     double fa[2][4], fb[2][NJ];
-    auto rd = [&](const char* st, int kk, int b) {
+    auto rd = [&](int kk, int b) {
 #ifdef DLC_EXP_DMA_NO_LDS_READ     // timing experiments only (wrong results): MFMAs on whatever the registers hold
         if (kk >= 0) { asm volatile("" : "+v"(fa[b][0]), "+v"(fb[b][0])); return; }
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[b][i] = *(const double*)(st + ra_off[i] + pk[kk]);
+        for (int i = 0; i < 4; ++i) fa[b][i] = *(const __attribute__((address_space(3))) double*)(fa_addr[kk] + i * 2048);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const double*)(st + rb_off[j] + pk[kk]);
-            else fb[b][j] = *(const double*)(st + rb_off[j] + kk * 4096);
+            if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const __attribute__((address_space(3))) double*)(fb_addr[kk] + j * 2048);
+            else fb[b][j] = *(const __attribute__((address_space(3))) double*)(fb_addr[j] + kk * 4096);
         }
     };
     auto mm = [&](int b) {
@@ -372,17 +493,17 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     // Timing builds that re-read ONE resident K tile with the same DMA instructions run as fast as builds without
     // any DMA: what the operand traffic costs, 8 %, is neither instruction issue nor prefetch distance.)
     issue(0, 0);
-    int cur = 0;
+    int cur = 0;                                                         // the stage the read addresses point at
     if (w < 4) {
         for (int t = 0; t < nkt; ++t) {
             arrive();                                                    // barrier t
-            const char* st = smem3 + cur * STAGE;
             const int nxt = next_stage(cur);
-            rd(st, 0, 0);
+            rd(0, 0);
             if (t + 1 < nkt) issue(t + 1, nxt);
-            rd(st, 1, 1); DLC_SLICE_FENCE(); mm(0);
-            rd(st, 2, 0); DLC_SLICE_FENCE(); mm(1);
-            rd(st, 3, 1); DLC_SLICE_FENCE(); mm(0);
+            rd(1, 1); DLC_SLICE_FENCE(); mm(0);
+            rd(2, 0); DLC_SLICE_FENCE(); mm(1);
+            rd(3, 1); DLC_SLICE_FENCE(); mm(0);
+            advance(cur);
             DLC_SLICE_FENCE(); mm(1);
             cur = nxt;
         }
@@ -390,27 +511,24 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     } else {
         {                                                                // t = 0: the first half of tile 0
             arrive();
-            const char* st = smem3;
-            rd(st, 0, 0);
+            rd(0, 0);
             if (1 < nkt) issue(1, 1);
-            rd(st, 1, 1); mm(0);
-            rd(st, 2, 0); mm(1);                                         // buffer 0 now holds k-slice 2 of tile 0
+            rd(1, 1); mm(0);
+            rd(2, 0); mm(1);                                             // buffer 0 now holds k-slice 2 of tile 0
         }
         for (int t = 1; t < nkt; ++t) {
             arrive();                                                    // barrier t
-            const char* sp = smem3 + cur * STAGE;                        // tile t-1
-            const int nxt = next_stage(cur);
-            const char* st = smem3 + nxt * STAGE;                        // tile t
-            rd(sp, 3, 1); DLC_SLICE_FENCE(); mm(0);
+            const int nxt = next_stage(cur);                             // tile t's stage; the addresses still point at tile t-1's
+            rd(3, 1); DLC_SLICE_FENCE(); mm(0);
             if (t + 1 < nkt) issue(t + 1, next_stage(nxt));
-            rd(st, 0, 0); DLC_SLICE_FENCE(); mm(1);
-            rd(st, 1, 1); DLC_SLICE_FENCE(); mm(0);
-            rd(st, 2, 0); DLC_SLICE_FENCE(); mm(1);
+            advance(cur);
+            rd(0, 0); DLC_SLICE_FENCE(); mm(1);
+            rd(1, 1); DLC_SLICE_FENCE(); mm(0);
+            rd(2, 0); DLC_SLICE_FENCE(); mm(1);
             cur = nxt;
         }
         arrive();                                                        // barrier nkt
-        const char* sp = smem3 + cur * STAGE;
-        rd(sp, 3, 1); mm(0);
+        rd(3, 1); mm(0);
         mm(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup's LDS
@@ -469,6 +587,10 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     // 16-byte pieces: operand rows must start on 16-byte boundaries and K, N be even (a piece = 2 doubles)
     if (!ctx->zero_page || (K & 1) || (N & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 1)) return 1;
     if (Kb != K && blayout != DLC_B_KN) return 1;          // a shorter B is a [K,N] operand with fewer rows
+    if (Kb < (dlc::cdiv(K, (int64_t)TK3) - 1) * TK3) return 1;   // ... whose missing rows all lie in the last K tile
+    // per-lane source offsets inside a tile are 32-bit: 256 rows of A, 128 rows ([N,K]) or 16 k-rows ([K,N]) of B
+    if (!cv && lda * 8 * TM3 > 0xffffffffll) return 1;
+    if (ldb * 8 * (blayout == DLC_B_NK ? TN3 : TK3) + 4096 > 0xffffffffll) return 1;
     if (cv) {
         if (blayout != DLC_B_KN || cv->C % TK3 != 0) return 1;
     } else if (lda & 1) {
@@ -484,6 +606,16 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     a.A = (const char*)A; a.lda_b = lda * 8; a.B = (const char*)B; a.ldb_b = ldb * 8;
     a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.Kb = Kb; a.act = act;
     a.cv = cv ? *cv : ConvGeom{};
+    a.cv_all_valid = 0;
+    if (cv) {
+        // per-lane offsets of the A operand are 32-bit and must stay below the descriptor's num_records: a tile's
+        // 256 output pixels span at most cdiv(256, OH * OW) + 1 images
+        const int64_t img_bytes = (int64_t)cv->H * cv->W * cv->C * 8;
+        if ((dlc::cdiv((int64_t)TM3, (int64_t)cv->OH * cv->OW) + 1) * img_bytes >= 0x7ff00000ll) return 1;
+        const int64_t KH = K / ((int64_t)cv->KW * cv->C);
+        a.cv_all_valid = cv->pad_t == 0 && cv->pad_l == 0 && (int64_t)(cv->OH - 1) * cv->stride + KH <= cv->H &&
+                         (int64_t)(cv->OW - 1) * cv->stride + cv->KW <= cv->W;
+    }
     a.zero = (const char*)ctx->zero_page;
     a.tiles_m = tiles_m; a.tiles_n = tiles_n;
     a.tri_p = tri ? tri->p : 0; a.tri_row0 = tri ? tri->row0 : 0; a.tri_col0 = tri ? tri->col0 : 0;
