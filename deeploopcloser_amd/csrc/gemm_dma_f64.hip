@@ -12,8 +12,8 @@
 // Tile 256 x 128 x 16, 512 threads = 8 waves (4 x 2), each wave 64 x 64 = 4 x 4 v_mfma_f64_16x16x4_f64 tiles.
 // One workgroup per CU (two waves per SIMD), LDS ring of 3 stages x 48 KiB:
 //   A stage  256 rows x 128 B (16 doubles of K per row), 16-byte piece q of row r at slot q ^ ((r >> 1) & 7)
-//   B stage  [N,K] operand: 128 rows x 128 B, same swizzle;  [K,N] operand: 16 k-rows x 1 KiB, piece q of k-row k
-//            at slot q ^ ((k & 1) << 3)
+//   B stage  [N,K] operand: 128 rows x 128 B, same swizzle;  [K,N] operand: 16 k-rows x 1 KiB, the tile's eight
+//            16-column groups in kn_unit() order, neighbouring 128-byte units swapped in odd k-rows
 // so that each half-wave of a ds_read_b64 fragment read (16 rows x one 16-byte slot: even rows sit in banks 0-31,
 // odd rows in 32-63, and 8 rows of one parity take 8 different slots) touches every bank once.  (Keyed on r & 7
 // instead, rows r and r + 8 shared their banks: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE.)  The swizzle is applied to the DMA's per-lane SOURCE address; the LDS destination stays lane-linear.
@@ -223,6 +223,17 @@ __device__ __forceinline__ double act_f64(double z, int act) {
     return z;
 }
 
+// [K,N] B stage: where the tile's 16-column groups sit in a 1 KiB k-row.  Group (wc, j) -- wave column wc, MFMA
+// column tile j -- is unit ((j >> 1) << 2) | (wc << 1) | (j & 1), so that a wave's groups j and j + 2 are 512 bytes
+// apart: one ds_read2st64_b64 fetches both (the fragment reads of a k-slice are then 2 + 2 instructions, not 2 + 4).
+__device__ __forceinline__ int kn_unit(int wc, int j) { return ((j >> 1) << 2) | (wc << 1) | (j & 1); }
+template <int NJ>
+__device__ __forceinline__ int kn_group(int unit) {       // inverse: the column group (0 .. 2 * NJ - 1) a unit holds
+    const int j = ((unit >> 2) << 1) | (unit & 1), wc = (unit >> 1) & 1;
+    const int g = wc * NJ + j;
+    return g < 2 * NJ ? (j < NJ ? g : 2 * NJ - 1) : 2 * NJ - 1;  // NJ = 3: units of j = 3 are never read
+}
+
 // BLAYOUT: DLC_B_KN / DLC_B_NK.  CONV: A is the NHWC input of a convolution with C % 16 == 0 (a K tile is 16
 // consecutive channels of one kernel tap), B its HWIO kernel as [K,N].
 // NJ: MFMA column tiles per wave (4: the 128-column tile; 3: a 96-column tile for N <= 96 such as conv1's 96 filters,
@@ -315,9 +326,11 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             if (gn > p.N - 1) gn = p.N - 1;
             b_off[j] = (unsigned)((gn - n0) * p.ldb_b) + b_piece[j] * 16;
         } else {
-            // [K,N]: instruction j covers k-row kr = 2w + j of the stage, lane -> 16-byte slot, source piece = slot ^ ((kr & 1) << 3)
+            // [K,N]: instruction j covers k-row kr = 2w + j of the stage; lane -> 16-byte slot of the 1 KiB row.  The
+            // row holds the tile's eight 16-column groups (128 B each) in the order kn_unit() gives, odd k-rows with
+            // neighbouring units swapped (the bank swizzle): unit u of the row comes from column group kn_group(u).
             const int kr = w * 2 + j;
-            int piece = lane ^ ((kr & 1) << 3);
+            int piece = kn_group<NJ>((lane >> 3) ^ (kr & 1)) * 8 + (lane & 7);
             const long long cols = p.N - n0 < TNJ ? p.N - n0 : TNJ;      // valid columns of this tile (even: N is)
             const int last = (int)(cols / 2) - 1;
             if (piece > last) piece = last;                              // columns past N: never stored
@@ -408,15 +421,18 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         const int pk = (((kk * 2 + (fk >> 1)) ^ x7) << 4) + (fk & 1) * 8;
         fa_addr[kk] = ring + (wr * 64 + fr) * 128 + pk;
         if constexpr (BLAYOUT == DLC_B_NK) fb_addr[kk] = ring + A_STAGE + (wc * NJ * 16 + fr) * 128 + pk;
-        else fb_addr[kk] = ring + A_STAGE + fk * 1024 + (((((wc * NJ + (kk < NJ ? kk : 0)) * 8 + (fr >> 1)) ^ ((fk & 1) << 3))) << 4) + (fr & 1) * 8;
+        else fb_addr[kk] = ring + A_STAGE + fk * 1024 + ((kn_unit(wc, kk & 1) ^ (fk & 1)) << 7) + fr * 8;       // kk = j: 0, 1
     }
     auto advance = [&](int stage_now) {                                  // the addresses move on to the next stage of the ring
         const int d = stage_now == NSTAGE - 1 ? -(NSTAGE - 1) * STAGE : STAGE;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             fa_addr[x] += d;
-            fb_addr[x] += d;
-            asm volatile("" : "+v"(fa_addr[x]), "+v"(fb_addr[x]));
+            asm volatile("" : "+v"(fa_addr[x]));
+            if (BLAYOUT == DLC_B_NK || x < 2) {
+                fb_addr[x] += d;
+                asm volatile("" : "+v"(fb_addr[x]));
+            }
         }
     };
 
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const __attribute__((address_space(3))) double*)(fb_addr[kk] + j * 2048);
-            else fb[b][j] = *(const __attribute__((address_space(3))) double*)(fb_addr[j] + kk * 4096);
+            else fb[b][j] = *(const __attribute__((address_space(3))) double*)(fb_addr[j & 1] + (j >> 1) * 512 + kk * 4096);
         }
     };
     auto mm = [&](int b) {
