@@ -86,7 +86,8 @@ typedef __attribute__((address_space(3))) const char* lcptr_t;
 // Between the k-slices of a K tile: for the plain operands, a scheduling fence -- the source's order (reads of slice
 // k+1, then the 16 MFMAs of slice k) is the schedule; left alone hipcc pairs B reads of neighbouring slices and moves
 // them up, which measured 1.8 % (SDAV layers) and 2.7 % (Gram) slower.  The convolution form, whose DMA addresses are
-// VALU work the compiler spreads between the MFMAs, is 1 % faster without the fence.
+// VALU work the compiler spreads between the MFMAs, is 1 % faster without the fence (re-measured after that VALU work
+// had moved to the scalar unit: still 1.2 %).
 // Measured and not kept (scripts/exp_dgemm.py, one device): s_setprio by progress through the tile (the wave that is
 // behind gets the matrix pipe), by half tile, or static for the late waves: each 2 % SLOWER than no priorities -- the
 // 1.6 : 1 split of a K tile's cycles between the two waves of a SIMD (cycle stamps) is not what costs
@@ -355,6 +356,8 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 #endif
         const unsigned lds_a = lds_base + stage * STAGE + w * 4096;
         if constexpr (CONV) {
+            // (Keeping the rows' validity as four SGPR lane masks and selecting the offsets with one v_cndmask per row and
+            // tile removes the 8-12 register copies per tile this conditional update costs -- and measured 4 % slower.)
             if (cv_c0 == 0 && !p.cv_all_valid) {                         // a new tap: which rows does it send into the padding?
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
