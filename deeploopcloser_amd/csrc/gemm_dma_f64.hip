@@ -23,6 +23,7 @@
 // One barrier per K tile t: before it every wave waits for its own DMA pieces of tile t, behind it tile t is
 // readable and tile t+1's DMA is issued into the stage of tile t-2.  Waves 0-3 then run k-slices 0-3 of tile t;
 // their SIMD partners 4-7 run half a tile behind (k-slices 2-3 of tile t-1, then 0-1 of tile t) -- see the main loop.
+#include <algorithm>
 #include "gemm_internal.h"
 
 namespace dlc_gemm {
@@ -47,7 +48,7 @@ struct DmaArgs {
     int cv_all_valid;                           // no tap of any output pixel falls outside the input (VALID, no padding)
     const char* zero;                           // >= 128 bytes of zeros
     long long tiles_m, tiles_n, nbr, nblocks;
-    int br, bc;
+    int br, bc, lg_blk;                         // blocks of br x bc = 1 << lg_blk tiles
     int tri_p;
     long long tri_row0, tri_col0;
     // triangular launches enumerate only the blocks that hold wanted entries, column by column (see block_of)
@@ -94,6 +95,13 @@ typedef __attribute__((address_space(3))) const char* lcptr_t;
 // the time; volatile fragment reads (to keep hipcc from pairing A reads into ds_read2st64_b64, which has half the
 // rate of ds_read_b64 and sees 32 banks): 37 % slower, every read followed by a full wait.
 #define DLC_SLICE_FENCE() do { if constexpr (!CONV) __builtin_amdgcn_sched_barrier(0); } while (0)
+
+#ifdef DLC_EXP_DMA_STAMPS       // diagnostic build only: where a wave's cycles go, summed over its K tiles (s_memtime ticks)
+__device__ unsigned long long dlc_exp_stamps[256][8][4];   // [workgroup < 256][wave][wait for DMA, barrier, tile body, tiles]
+#endif
+#ifdef DLC_EXP_DMA_PLACEMENT    // diagnostic build only: where and when each workgroup of the LAST launch ran
+__device__ unsigned long long dlc_exp_place[8192][4];      // [workgroup id][HW_ID | XCC_ID << 32, start, end (s_memrealtime), did work]
+#endif
 
 // LDS-DMA wave-instructions of one K tile: four 1 KiB pieces of the A stage (dma_a4), two of the B stage (dma_b2).
 // Inline asm so that hipcc does not count them in vmcnt (it would wait for vmcnt(0) in front of every LDS read); M0
@@ -167,14 +175,22 @@ __device__ __forceinline__ void dma_a4s(unsigned o0, unsigned o1, unsigned o2, u
 // channel block) + per-lane 32-bit offsets; a lane whose tap falls into the padding carries an offset past
 // num_records and the hardware writes ZEROS to its LDS slot (scripts/micro/buffer_lds_oob.hip: out-of-range dwords of
 // a `buffer_load ... lds` land as 0; an soffset counts in the range check, so the base is stepped instead).
+// "s" operands must BE in SGPRs: hipcc does not move a value it keeps in VGPRs there by itself (a diagnostic build
+// failed to assemble that way), so the wave-uniform bases go through readfirstlane -- a no-op on a value that is
+// already scalar.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
 typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
 constexpr unsigned DMA_OOB = 0xfffffff0u;       // >= num_records of every descriptor built here
 constexpr unsigned DMA_NUM_RECORDS = 0x80000000u;
 __device__ __forceinline__ rsrc_t make_rsrc(const char* base) {
     const unsigned long long a = (unsigned long long)base;
     rsrc_t r;
-    r[0] = (unsigned)a;
-    r[1] = (unsigned)(a >> 32) & 0xffffu;       // stride 0: raw buffer
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);       // stride 0: raw buffer
     r[2] = DMA_NUM_RECORDS;
     r[3] = 0x00020000u;                         // gfx9 raw-buffer word (32-bit data format)
     return r;
@@ -246,14 +262,25 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1;
+#ifdef DLC_EXP_DMA_PLACEMENT
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dlc_exp_place[blockIdx.x][0] = hw | ((unsigned long long)xcc << 32);
+        dlc_exp_place[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        dlc_exp_place[blockIdx.x][2] = 0;
+        dlc_exp_place[blockIdx.x][3] = 0;
+    }
+#endif
     // ---- workgroup id -> tile: blocks of br x bc = 32 tiles, one block per XCD at a time (gemm_dense.hip, tile order)
     long long tile_m, tile_n;
     {
         const long long wg = blockIdx.x;
         const long long l = wg >> 3;
-        long long gb = (l >> 5) * 8 + (wg & 7);
+        long long gb = (l >> p.lg_blk) * 8 + (wg & 7);
         if (gb >= p.nblocks) return;
-        const int i = (int)(l & 31);
+        const int i = (int)(l & ((1 << p.lg_blk) - 1));
         long long brow, bcol;
         if (p.tri_p > 0) {                                               // the gb-th wanted block, columns first
             TriWalk tw{p.tri_col0 + p.tri_blk_cols - 1, p.tri_rem0};
@@ -270,8 +297,18 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             brow = gb % p.nbr;
             bcol = gb / p.nbr;
         }
-        tile_m = brow * p.br + (i % p.br);
-        tile_n = bcol * p.bc + (i / p.br);
+        // Inside an XCD the dispatcher deals workgroups round-robin to 4 shader engines of 8 CUs, and a workgroup waits
+        // for ITS engine even while others have free CUs (scripts/exp_placement.py).  The tiles of a block that exist
+        // must therefore be spread over i % 4: columns first in general (a right-edge block keeps i < br * cols), rows
+        // first in the last block row when it is cut short (it keeps i < bc * rows) -- numbered columns first, the three
+        // tiles of a 1-row block sat at i = 0, 8, 16, all on one engine: conv3 of 128 frames ran two rounds for 195 tiles.
+        if (brow == p.nbr - 1 && (p.tiles_m & (p.br - 1)) != 0) {
+            tile_m = brow * p.br + (i / p.bc);
+            tile_n = bcol * p.bc + (i % p.bc);
+        } else {
+            tile_m = brow * p.br + (i % p.br);
+            tile_n = bcol * p.bc + (i / p.br);
+        }
         if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
     }
     const long long m0 = tile_m * TM3, n0 = tile_n * TNJ;
@@ -376,7 +413,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
             }
             dma_a4b(a_eff[0], a_eff[1], a_eff[2], a_eff[3], rs, lds_a);
         } else {
-            const char* base = a_base + (long long)tt * (TK3 * 8);
+            const char* base = uniform_ptr(a_base + (long long)tt * (TK3 * 8));
             if (a_tail && tt == nkt - 1) {
                 const int klim = (int)(p.K - (long long)tt * TK3);       // valid k of this tile
                 const char* sa[4];
@@ -395,7 +432,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         const int tt = t;
 #endif
         const unsigned lds_b = lds_base + stage * STAGE + A_STAGE + w * 2048;
-        const char* base = b_base + (long long)tt * b_step;
+        const char* base = uniform_ptr(b_base + (long long)tt * b_step);
         if (b_tail && tt == nkt - 1) {
             const long long left = p.Kb - (long long)tt * TK3;           // B's own reduction length
             const int klim = (int)(left < TK3 ? (left > 0 ? left : 0) : TK3);
@@ -558,6 +595,12 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     }
 #endif
 
+#ifdef DLC_EXP_DMA_PLACEMENT
+    if (tid == 0 && blockIdx.x < 8192) {
+        dlc_exp_place[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
+        dlc_exp_place[blockIdx.x][3] = 1;
+    }
+#endif
     // ---- epilogue: bias + activation, C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -620,7 +663,13 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     const bool narrow = N <= 96;
     const int tn = narrow ? 96 : TN3;
     const int64_t tiles_m = dlc::cdiv(M, TM3), tiles_n = dlc::cdiv(N, (int64_t)tn);
-    if (tiles_m * tiles_n < 512 || K < 4 * TK3) return 1;
+    // From 16 tiles on, and with more than 3/4 of a tile's rows real (scripts/exp_dma_threshold.py: below that the
+    // register-staged 128 x 128 kernel's twice as many workgroups win; above it this kernel wins at every size once the
+    // tiles of edge blocks are dealt evenly to the shader engines -- it used to be taken from 512 tiles on only)
+#ifndef DLC_DMA_MIN_TILES
+#define DLC_DMA_MIN_TILES 16
+#endif
+    if (tiles_m * tiles_n < DLC_DMA_MIN_TILES || M < TM3 * 3 / 4 || K < 4 * TK3) return 1;
     DmaArgs a;
     a.A = (const char*)A; a.lda_b = lda * 8; a.B = (const char*)B; a.ldb_b = ldb * 8;
     a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.Kb = Kb; a.act = act;
@@ -639,7 +688,11 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     a.tiles_m = tiles_m; a.tiles_n = tiles_n;
     a.tri_p = tri ? tri->p : 0; a.tri_row0 = tri ? tri->row0 : 0; a.tri_col0 = tri ? tri->col0 : 0;
     // block of 32 tiles (one XCD's 32 CUs): 4 row tiles x 8 column tiles = 1024 x 1024 outputs, narrower where the
-    // matrix has fewer tiles along a dimension (powers of two)
+    // matrix has fewer tiles along a dimension (powers of two).  Blocks go round-robin to the XCDs, so a launch of a
+    // few blocks can leave some XCDs with twice the tiles of others (conv3 of 128 frames: 195 tiles in 9 blocks -- XCD 0
+    // ran two rounds of its 32 CUs while XCDs 1-7 ran one, 19 % on the whole CnnVtl.transform call).  For such launches
+    // the block shrinks (rows first) until the busiest XCD needs no more rounds than the tiles / 256 CUs do; L2
+    // sharing inside a block matters little when the whole launch is a round or two.
     int bc = 8;
     while (bc > 1 && bc / 2 >= tiles_n) bc /= 2;
     int br = 32 / bc;
@@ -648,6 +701,33 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
         while (br < tiles_m) br *= 2;
         bc = 32 / br;
     }
+    if (!tri) {
+        auto busiest_rounds = [&](int r, int c) {           // rounds the fullest shader engine (8 CUs) of any XCD runs
+            const int64_t nr = dlc::cdiv(tiles_m, (int64_t)r), nc = dlc::cdiv(tiles_n, (int64_t)c);
+            int64_t load[8][4] = {};
+            for (int64_t g = 0; g < nr * nc; ++g) {
+                const int64_t rows = std::min<int64_t>(r, tiles_m - (g % nr) * r), cols = std::min<int64_t>(c, tiles_n - (g / nr) * c);
+                const bool rows_first = (g % nr) == nr - 1 && (tiles_m & (r - 1)) != 0;
+                for (int i = 0; i < r * c; ++i) {
+                    const bool exists = rows_first ? (i / c < rows && i % c < cols) : (i % r < rows && i / r < cols);
+                    if (exists) load[g & 7][((g >> 3) * (r * c) + i) & 3]++;     // this XCD's ((g >> 3) * block + i)-th workgroup
+                }
+            }
+            int64_t m = 0;
+            for (int x = 0; x < 8; ++x)
+                for (int e = 0; e < 4; ++e) m = std::max(m, load[x][e]);
+            return dlc::cdiv(m, (int64_t)8);
+        };
+        if (tiles_m * tiles_n <= 32 * 1024) {               // larger launches: dozens of rounds, the block stays
+            const int64_t want = dlc::cdiv(tiles_m * tiles_n, (int64_t)256);
+            while (br * bc > 1 && busiest_rounds(br, bc) > want) {
+                if (br > 1) br /= 2; else bc /= 2;
+            }
+        }
+    }
+    int lg_blk = 0;
+    while ((1 << lg_blk) < br * bc) ++lg_blk;
+    a.lg_blk = lg_blk;
     a.br = br; a.bc = bc;
     a.nbr = dlc::cdiv(tiles_m, (int64_t)br);
     a.tri_nbc = dlc::cdiv(tiles_n, (int64_t)bc);
@@ -662,7 +742,7 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
         for (long long c = 0; c < a.tri_nbc; ++c, tw.step(a)) a.nblocks += tw.count(a);
         if (a.nblocks == 0) return DLC_OK;                               // nothing wanted (the caller never reads this block)
     }
-    const long long nwg = dlc::cdiv(a.nblocks, (int64_t)8) * 8 * 32;
+    const long long nwg = (dlc::cdiv(a.nblocks, (int64_t)8) * 8) << a.lg_blk;
     if (nwg > 0x7fffffffll) return 1;
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
@@ -679,6 +759,11 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     return DLC_OK;
 }
 
+#ifdef DLC_EXP_DMA_PLACEMENT
+extern "C" int dlc_exp_read_placement(unsigned long long* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dlc_gemm::dlc_exp_place), bytes < sizeof(dlc_gemm::dlc_exp_place) ? bytes : sizeof(dlc_gemm::dlc_exp_place));
+}
+#endif
 #ifdef DLC_EXP_DMA_STAMPS
 extern "C" int dlc_exp_read_stamps(unsigned long long* host, size_t bytes) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dlc_gemm::dlc_exp_stamps), bytes < sizeof(dlc_gemm::dlc_exp_stamps) ? bytes : sizeof(dlc_gemm::dlc_exp_stamps));

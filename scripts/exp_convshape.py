@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import deeploopcloser_amd as dlc
 from deeploopcloser_amd import _lib as L
+if len(sys.argv) > 1:                      # another build of the library
+    L._lib = None
+    L.LIB_PATH = os.path.abspath(sys.argv[1])
 eng = dlc.default_engine()
 g = torch.Generator(device=eng.device); g.manual_seed(0)
 def t(fn, reps=5):
@@ -14,7 +17,7 @@ def t(fn, reps=5):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
-F = 128
+F = int(os.environ.get('DLC_FRAMES', '128'))
 layers = [("conv2", 22, 28, 96, 5, 256, 2), ("conv3", 10, 13, 256, 3, 384, 1), ("conv4", 10, 13, 384, 3, 384, 1), ("conv5", 10, 13, 384, 3, 256, 1)]
 for name, h, w, c, ks, cout, pad in layers:
     M, K, N = F * h * w, ks * ks * c, cout
