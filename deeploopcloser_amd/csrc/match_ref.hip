@@ -237,75 +237,118 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
     }
 }
 
-// The same for P <= 32 patches per frame (the reference: 30) with the Gram rows read COALESCED: a lane is a patch b
-// of frame j, the two halves of the wave take two patches a of frame i at a time, so one load instruction fetches
-// two 8*P-byte row segments (the form above has lane = a: every lane walks its own row, 30 scattered 8-byte reads
-// per instruction, 0.6 TB/s from L2).  Same arithmetic per (a, b), first minimum = lowest b among the lanes that
-// hold the half's minimum; lane a then holds the index of its nearest patch and the rest (weighted distance, log,
-// the xor-tree sum over lanes 0..P-1) is the general kernel's.
-__global__ __launch_bounds__(256) void pair_score_rows_kernel(const double* __restrict__ desc, const double* __restrict__ G,
+// The same for P <= 32 patches per frame (the reference: 30) with the Gram rows read as long contiguous runs: a workgroup takes frame i against PS_JT consecutive
+// frames j, stages the P x (PS_JT * P) block of G through LDS (every row a run of PS_JT * P doubles -- 1920 bytes at
+// P = 30 -- instead of 240-byte segments of two rows per load instruction, which read HBM at 1.8 TB/s), then thread
+// (jj, a) walks the P distances of its patch a to frame j0 + jj in b order -- the general kernel's loop, so the first
+// minimum and every rounding are the same -- and the 32-lane xor tree sums the P terms of a pair.
+constexpr int PS_JT = 8;
+constexpr int PS_GX = 8;        // workgroups per frame i: each walks every PS_GX-th run of PS_JT frames
+__global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __restrict__ desc, const double* __restrict__ G,
                                                               long long ldg, long long col0, const double* __restrict__ nrm2,
                                                               const double* __restrict__ proj,
                                                               const double* __restrict__ score, long long N, int P, int H,
                                                               long long i_lo, long long i_hi, double ca, double cb,
                                                               double* __restrict__ out_f64, long long* __restrict__ out_i64) {
-    const int lane = threadIdx.x & 63;
-    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ double ps_lds[];
     const long long i = i_lo + blockIdx.y;
-    if (i >= i_hi || j >= N || j <= i) return;                  // wave-uniform
-    const int half = lane >> 5, b = lane & 31;
-    const bool bok = b < P;
-    const double nbv = bok ? nrm2[j * P + b] : 0.0;
-    const double* gcol = G + (j * P - col0) + (bok ? b : 0);
-    // pass 1: the nearest patch of frame j for every patch a of frame i (two a per step); every Gram load is
-    // independent of the others, so all 16 steps' loads are in flight together.  Lane a ends up with bi(a).
-    double g[16];
+    if (i >= i_hi) return;
+    const int tid = threadIdx.x;
+    const int width = PS_JT * P, row = width | 1;                // odd row pitch: 32 patches a read 32 different banks
+    double* g = ps_lds;                                          // [P][row]
+    double* nb = ps_lds + (size_t)P * row;                       // [PS_JT * P] squared norms of the frames' patches
+    const int w = tid >> 6, lane = tid & 63;
+    const int jj = tid >> 5, a = tid & 31;
+    const long long ra = i * P + (a < P ? a : 0);
+    const double na = nrm2[ra], pa = proj[ra];
+    const double* grow0 = G + (i * P - i_lo * P) * ldg - col0;   // column 0 of the matrix in row a = 0 (left of the block: only frames > i are read)
+    // wave w stages rows w, w + 4, ..; a lane columns lane, lane + 64, ..: the (up to 32) loads of a run are issued
+    // together, and the NEXT run's are in flight while this one is scored
+    double v[8][4];
+    auto fetch = [&](long long j0) {
+        const long long jlo = j0 > i + 1 ? j0 : i + 1;           // first frame of the run that is wanted
+        const long long jhi = j0 + PS_JT < N ? j0 + PS_JT : N;   // one past the last
+        const int c_lo = (int)((jlo - j0) * P), c_hi = (int)((jhi - j0) * P);
+        const double* gb = grow0 + j0 * P;
 #pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_) {
-        const int a = 2 * s_ + half;
-        g[s_] = (a < P && bok) ? gcol[(i * P + a - i_lo * P) * ldg] : 0.0;
-    }
-    int mybi = 0;
+        for (int r = 0; r < 8; ++r)
 #pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_) {
-        const int a = 2 * s_ + half;
-        double dist = INFINITY;
-        if (a < P && bok) {
-            double d2 = nrm2[i * P + a] + nbv - 2.0 * g[s_];
-            d2 = d2 > 0.0 ? d2 : 0.0;
-            dist = sqrt(d2);                                    // np.linalg.norm, :34
+            for (int cc = 0; cc < 4; ++cc) {
+                const int ar = w + 4 * r, c = lane + 64 * cc;
+                v[r][cc] = (ar < P && c >= c_lo && c < c_hi) ? gb[(long long)ar * ldg + c] : 0.0;
+            }
+    };
+    long long j0 = ((i + 1) / PS_JT + blockIdx.x) * PS_JT;       // the first run with a frame > i, then every PS_GX-th
+    if (j0 < N) fetch(j0);
+    for (; j0 < N; j0 += (long long)PS_GX * PS_JT) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int ar = w + 4 * r, c = lane + 64 * cc;
+                if (ar < P && c < width) g[ar * row + c] = v[r][cc];
+            }
+        for (int c = tid; c < width; c += 256) nb[c] = (j0 * P + c < N * P) ? nrm2[j0 * P + c] : 0.0;
+        __syncthreads();
+        const long long jn = j0 + (long long)PS_GX * PS_JT;
+        if (jn < N) fetch(jn);
+        const long long j = j0 + jj;
+        double term = 0.0;
+        const bool pair_ok = j > i && j < N;
+        if (pair_ok && a < P) {
+            const double* grow = g + a * row + jj * P;
+            const double* nbj = nb + jj * P;
+            // np.argmin(np.linalg.norm(..)) (:34-35) without 30 square roots: sqrt is monotone, so the first minimum of
+            // the distances is the first minimum of the SQUARED distances unless another patch's square lies so close
+            // above the smallest that the two roots round to one double.  One pass keeps the two smallest squares; only
+            // when the second is within 2^-50 (relative) of the first are the roots taken and compared as the reference does.
+            double best = 0.0, second = INFINITY;
+            int bi = 0;
+            auto scan = [&](int b) {
+                double d2 = na + nbj[b] - 2.0 * grow[b];
+                d2 = d2 > 0.0 ? d2 : 0.0;
+                if (b == 0) { best = d2; bi = 0; }
+                else if (d2 < best) { second = best; best = d2; bi = b; }
+                else if (d2 < second) second = d2;
+            };
+            if (P == 30) {                                      // the reference's patch count: fully unrolled, all LDS reads up front
+#pragma unroll
+                for (int b = 0; b < 30; ++b) scan(b);
+            } else {
+#pragma unroll 4
+                for (int b = 0; b < P; ++b) scan(b);
+            }
+            if (second <= best * (1.0 + 0x1p-50)) {             // (best = 0: second = 0 too -- equal roots, first index wins)
+                for (int b = 0; b < P; ++b) {
+                    double d2 = na + nbj[b] - 2.0 * grow[b];
+                    d2 = d2 > 0.0 ? d2 : 0.0;
+                    const double dist = sqrt(d2);               // np.linalg.norm, :34
+                    if (b == 0 || dist < best) { best = dist; bi = b; }     // np.argmin: first minimum
+                }
+            }
+            const long long rb = j * P + bi;
+            const double pb = proj[rb];
+            double wd = fabs(pa - pb);                          // |dot(score, m_i - m_j*)|, :42-43
+            if (wd < 1e-6 * (fabs(pa) + fabs(pb))) {            // cancellation: evaluate the difference directly
+                const double* xa = desc + ra * H;
+                const double* xb = desc + rb * H;
+                double s_ = 0.0;
+                for (int k = 0; k < H; ++k) s_ = fma(score[k], xa[k] - xb[k], s_);
+                wd = fabs(s_);
+            }
+            term = ca + cb * log(wd);                           // :48
         }
-        double m = dist;
-        for (int o = 16; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o));      // minimum of this half (32 lanes)
-        const unsigned long long hit = __ballot(dist == m);
-        const unsigned lo = (unsigned)hit, hi = (unsigned)(hit >> 32);
-        const int bi0 = lo ? __ffs(lo) - 1 : 0, bi1 = hi ? __ffs(hi) - 1 : 0;   // np.argmin: first minimum
-        if (lane == 2 * s_) mybi = bi0;
-        if (lane == 2 * s_ + 1) mybi = bi1;
-    }
-    // pass 2: one patch of frame i per lane, as the general kernel
-    double myterm = 0.0;
-    if (lane < P) {
-        const long long ra = i * P + lane, rb = j * P + mybi;
-        double wd = fabs(proj[ra] - proj[rb]);                  // |dot(score, m_i - m_j*)|, :42-43
-        if (wd < 1e-6 * (fabs(proj[ra]) + fabs(proj[rb]))) {    // cancellation: evaluate the difference directly
-            const double* xa = desc + ra * H;
-            const double* xb = desc + rb * H;
-            double s = 0.0;
-            for (int k = 0; k < H; ++k) s = fma(score[k], xa[k] - xb[k], s);
-            wd = fabs(s);
+        for (int o = 16; o > 0; o >>= 1) term += __shfl_xor(term, o);      // the 32 lanes of this pair (lanes >= P hold 0)
+        if (pair_ok && a == 0) {
+            out_f64[i * N + j] = term;
+            out_f64[j * N + i] = term;
+            if (out_i64) {
+                const long long t = f64_to_i64_trunc(term);
+                out_i64[i * N + j] = t;
+                out_i64[j * N + i] = t;
+            }
         }
-        myterm = ca + cb * log(wd);                             // :48
-    }
-    for (int o = 32; o > 0; o >>= 1) myterm += __shfl_xor(myterm, o);
-    if (lane == 0) {
-        out_f64[i * N + j] = myterm;
-        out_f64[j * N + i] = myterm;
-        if (out_i64) {
-            const long long t = f64_to_i64_trunc(myterm);
-            out_i64[i * N + j] = t;
-            out_i64[j * N + i] = t;
-        }
+        __syncthreads();                                         // g / nb are rewritten for the next run
     }
 }
 
@@ -467,10 +510,17 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
                                                   ncols, (int)P, i_lo * P, col0, st);
         if (rc != DLC_OK) return rc;
         dim3 grid((unsigned)dlc::cdiv(N, 4), (unsigned)(i_hi - i_lo));
-        if (P <= 32)
-            hipLaunchKernelGGL(pair_score_rows_kernel, grid, dim3(256), 0, st, desc, gram, ncols, col0, nrm2, proj, score,
-                               (long long)N, (int)P, (int)H, i_lo, i_hi, a, b, out_f64, (long long*)out_i64);
-        else
+        const size_t tile_lds = ((size_t)P * ((PS_JT * P) | 1) + (size_t)PS_JT * P) * sizeof(double);
+        const bool tiled = P <= 32;
+        if (tiled) {
+            if (tile_lds > 48 * 1024 && !(ctx->func_attr_set & (1ull << DLC_ATTR_PAIR_TILE))) {
+                DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)pair_score_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+                ctx->func_attr_set |= 1ull << DLC_ATTR_PAIR_TILE;
+            }
+            hipLaunchKernelGGL(pair_score_tile_kernel, dim3(PS_GX, (unsigned)(i_hi - i_lo)), dim3(256), tile_lds,
+                               st, desc, gram, ncols, col0, nrm2, proj, score, (long long)N, (int)P, (int)H, i_lo, i_hi, a, b,
+                               out_f64, (long long*)out_i64);
+        } else
             hipLaunchKernelGGL(pair_score_kernel, grid, dim3(256), 0, st, desc, gram, ncols, col0, nrm2, proj, score,
                                (long long)N, (int)P, (int)H, i_lo, i_hi, a, b, out_f64, (long long*)out_i64);
         DLC_LAUNCH_CHECK(ctx, "pair_score_kernel");

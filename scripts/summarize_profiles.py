@@ -9,7 +9,7 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 OURS = ("score_gemm_kernel", "finish_topk_kernel", "merge_topk_kernel", "l2_normalize_kernel", "l2_normalize_regs_kernel",
         "gemm_dma_f64_kernel", "gemm_bias_act_kernel", "distance_matrix_kernel", "distinctive_score_kernel",
-        "pair_score_kernel", "pair_score_rows_kernel", "transpose_f64_kernel", "splitk_groups_kernel", "splitk_dense_kernel", "maxpool_kernel", "row_minmax_kernel",
+        "pair_score_kernel", "pair_score_tile_kernel", "transpose_f64_kernel", "splitk_groups_kernel", "splitk_dense_kernel", "maxpool_kernel", "row_minmax_kernel",
         "quant_gather_kernel", "row_stats_kernel")
 
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
