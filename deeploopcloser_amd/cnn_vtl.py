@@ -166,8 +166,9 @@ class CnnVtl:
         d = np.load(path, encoding="bytes", allow_pickle=True).item()
         self.set_weights(*alexnet_params_from_dict(d))
 
-    def _features(self, x):
-        """conv1..conv5 outputs of a frame chunk: list of [n, oh, ow, cout] fp64 tensors."""
+    def _features(self, x, frame_keys=None):
+        """conv1..conv5 outputs of a frame chunk: list of [n, oh, ow, cout] fp64 tensors.  frame_keys: every layer
+        folds the per-frame minimum / maximum of its outputs into it (the descriptor's range, cnn_vtl.py:110-112)."""
         e = self.engine
         outs = []
         h = x
@@ -176,9 +177,9 @@ class CnnVtl:
             act = L.DLC_ACT_RELU if relu else L.DLC_ACT_NONE
             if l in self._s2d:
                 bs_, k2h, k2w, wp = self._s2d[l]
-                y = e.conv2d(e.space_to_depth(h, bs_), wp, b, k2h, k2w, 1, 0, 0, oh, ow, act)
+                y = e.conv2d(e.space_to_depth(h, bs_), wp, b, k2h, k2w, 1, 0, 0, oh, ow, act, frame_keys=frame_keys)
             else:
-                y = e.conv2d(h, w, b, kh, kw, s, ph, pw, oh, ow, act)
+                y = e.conv2d(h, w, b, kh, kw, s, ph, pw, oh, ow, act, frame_keys=frame_keys)
             outs.append(y)
             h = e.maxpool3x3s2(y) if pool else y
         return outs
@@ -196,8 +197,12 @@ class CnnVtl:
         n_chunks = max(1, -(-n // max(1, self.frame_chunk)))
         step = -(-n // n_chunks) if n else 1
         for lo in range(0, n, step):
-            outs = self._features(x[lo:lo + step].contiguous())
-            parts.append(self.engine.minmax_quant_gather(outs, self._columns_dev))
+            chunk = x[lo:lo + step].contiguous()
+            if chunk.shape[0] <= 65535:
+                keys = self.engine.frame_minmax_keys(chunk.shape[0])
+                parts.append(self.engine.quant_gather(self._features(chunk, keys), self._columns_dev, keys))
+            else:
+                parts.append(self.engine.minmax_quant_gather(self._features(chunk), self._columns_dev))
         if not parts:
             return torch.empty((0, self.columns.size), dtype=torch.int8, device=self.engine.device)
         return torch.cat(parts, dim=0)

@@ -3,7 +3,7 @@
 // per-row min/max -> scale to 0..255 -> int8 cast -> column gather.
 // All three are HBM-bound streaming kernels: one element per thread along the
 // contiguous (channel / column) axis so that loads and stores coalesce.
-#include "dlc_internal.h"
+#include "gemm_internal.h"
 
 namespace {
 
@@ -76,16 +76,6 @@ struct Segs {
     int n;
 };
 
-// Order-preserving 64-bit key of a double (for atomicMin / atomicMax on unsigned long long).
-__device__ __forceinline__ unsigned long long f64_key(double v) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double f64_unkey(unsigned long long k) {
-    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)u);
-}
-
 __global__ void minmax_init_kernel(unsigned long long* __restrict__ keys, long long n) {
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
     if (r < n) { keys[r * 2] = ~0ull; keys[r * 2 + 1] = 0ull; }
@@ -113,15 +103,15 @@ __global__ __launch_bounds__(256) void row_minmax_kernel(Segs s, unsigned long l
         mn = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
         mx = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
         if (mn <= mx) {                                         // this slice saw at least one element
-            atomicMin(&keys[r * 2], f64_key(mn));
-            atomicMax(&keys[r * 2 + 1], f64_key(mx));
+            atomicMin(&keys[r * 2], dlc_f64_key(mn));
+            atomicMax(&keys[r * 2 + 1], dlc_f64_key(mx));
         }
     }
 }
 
 __global__ void minmax_decode_kernel(const unsigned long long* __restrict__ keys, long long n, double* __restrict__ minmax) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e < 2 * n) minmax[e] = f64_unkey(keys[e]);
+    if (e < 2 * n) minmax[e] = dlc_f64_unkey(keys[e]);
 }
 
 // out[r, j] = int8( trunc( (d[r, cols[j]] - min_r) * (255 / (max_r - min_r)) ) ), wrap mod 256
@@ -192,6 +182,78 @@ extern "C" int dlc_space_to_depth_nhwc_f64(dlc_ctx* ctx, const double* x, int64_
     return DLC_OK;
 }
 
+namespace {
+int build_segs(dlc_ctx* ctx, const double* const* segs, const int64_t* seg_sizes, int n_segs, Segs* s) {
+    s->n = n_segs;
+    s->start[0] = 0;
+    for (int g = 0; g < MAX_SEGS; ++g) {
+        s->ptr[g] = g < n_segs ? segs[g] : nullptr;
+        s->size[g] = g < n_segs ? seg_sizes[g] : 0;
+        if (g < n_segs && (!segs[g] || seg_sizes[g] < 1))
+            return dlc::fail(ctx, DLC_ERR_BAD_ARG, "minmax_quant_gather: segment %d is null/empty", g);
+        s->start[g + 1] = s->start[g] + s->size[g];
+    }
+    return DLC_OK;
+}
+
+// rows of `s` folded into keys (no initialisation): slices of a row over many workgroups
+int fold_rows(dlc_ctx* ctx, const Segs& s, int64_t n, unsigned long long* keys, hipStream_t st) {
+    const long long width = s.start[s.n];
+    long long slices = dlc::cdiv(width, (long long)256 * 16);   // >= 16 elements per thread
+    const long long want = dlc::cdiv((long long)256 * 8, (long long)n);      // ~8 workgroups per CU over all rows
+    if (slices > want) slices = want;
+    if (slices < 1) slices = 1;
+    for (int64_t r0 = 0; r0 < n; r0 += 65535) {                 // grid.y
+        const int64_t nr = n - r0 < 65535 ? n - r0 : 65535;
+        Segs t = s;
+        for (int g = 0; g < s.n; ++g) t.ptr[g] = s.ptr[g] + r0 * s.size[g];
+        hipLaunchKernelGGL(row_minmax_kernel, dim3((unsigned)slices, (unsigned)nr), dim3(256), 0, st, t, keys + 2 * r0);
+    }
+    DLC_LAUNCH_CHECK(ctx, "row_minmax_kernel");
+    return DLC_OK;
+}
+}  // namespace
+
+namespace dlc_cnn {
+int fold_minmax_f64(dlc_ctx* ctx, const double* x, int64_t n_img, int64_t per_img, unsigned long long* keys, hipStream_t st) {
+    Segs s{};
+    s.n = 1; s.ptr[0] = x; s.size[0] = per_img; s.start[0] = 0; s.start[1] = per_img;
+    return fold_rows(ctx, s, n_img, keys, st);
+}
+}  // namespace dlc_cnn
+
+extern "C" int dlc_cnnvtl_frame_minmax_init(dlc_ctx* ctx, uint64_t* keys, int64_t n, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!keys || n < 1) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "frame_minmax_init: bad argument");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((unsigned)dlc::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long*)keys, (long long)n);
+    DLC_LAUNCH_CHECK(ctx, "minmax_init_kernel");
+    return DLC_OK;
+}
+
+extern "C" int dlc_quant_gather_i8(dlc_ctx* ctx, const double* const* segs, const int64_t* seg_sizes, int n_segs, int64_t n,
+                                   const int64_t* cols, int64_t n_cols, const uint64_t* keys, double* minmax, int8_t* out,
+                                   void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!segs || !seg_sizes || n_segs < 1 || n_segs > MAX_SEGS || n < 1 || !cols || n_cols < 1 || !keys || !minmax || !out)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "quant_gather: bad argument (1..%d segments)", MAX_SEGS);
+    if (n > 65535) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "quant_gather: more than 65535 rows per call");
+    Segs s;
+    const int rc = build_segs(ctx, segs, seg_sizes, n_segs, &s);
+    if (rc != DLC_OK) return rc;
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(minmax_decode_kernel, dim3((unsigned)dlc::cdiv(2 * n, 256)), dim3(256), 0, st,
+                       (const unsigned long long*)keys, (long long)n, minmax);
+    hipLaunchKernelGGL(quant_gather_kernel, dim3((unsigned)dlc::cdiv(n_cols, 256), (unsigned)n), dim3(256), 0, st, s,
+                       (const long long*)cols, (long long)n_cols, (const double*)minmax, out);
+    DLC_LAUNCH_CHECK(ctx, "quant_gather_kernel");
+    return DLC_OK;
+}
+
 extern "C" int dlc_minmax_quant_gather_i8(dlc_ctx* ctx, const double* const* segs, const int64_t* seg_sizes, int n_segs,
                                           int64_t n, const int64_t* cols, int64_t n_cols, double* minmax, int8_t* out,
                                           void* stream) {
@@ -200,31 +262,18 @@ extern "C" int dlc_minmax_quant_gather_i8(dlc_ctx* ctx, const double* const* seg
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "minmax_quant_gather: bad argument (1..%d segments)", MAX_SEGS);
     if (n > 65535) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "minmax_quant_gather: more than 65535 rows per call");
     Segs s;
-    s.n = n_segs;
-    s.start[0] = 0;
-    for (int g = 0; g < MAX_SEGS; ++g) {
-        s.ptr[g] = g < n_segs ? segs[g] : nullptr;
-        s.size[g] = g < n_segs ? seg_sizes[g] : 0;
-        if (g < n_segs && (!segs[g] || seg_sizes[g] < 1))
-            return dlc::fail(ctx, DLC_ERR_BAD_ARG, "minmax_quant_gather: segment %d is null/empty", g);
-        s.start[g + 1] = s.start[g] + s.size[g];
-    }
+    int rc = build_segs(ctx, segs, seg_sizes, n_segs, &s);
+    if (rc != DLC_OK) return rc;
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     hipStream_t st = (hipStream_t)stream;
     // minmax doubles as the key scratch: [n,2] u64 keys first, decoded in place afterwards
     unsigned long long* keys = (unsigned long long*)minmax;
     hipLaunchKernelGGL(minmax_init_kernel, dim3((unsigned)dlc::cdiv(n, 256)), dim3(256), 0, st, keys, (long long)n);
-    long long width = 0;
-    for (int g = 0; g < n_segs; ++g) width += seg_sizes[g];
-    long long slices = dlc::cdiv(width, 256 * 16);              // >= 16 elements per thread
-    const long long want = dlc::cdiv(256 * 8, n);               // ~8 workgroups per CU over all rows
-    if (slices > want) slices = want;
-    if (slices < 1) slices = 1;
-    hipLaunchKernelGGL(row_minmax_kernel, dim3((unsigned)slices, (unsigned)n), dim3(256), 0, st, s, keys);
+    rc = fold_rows(ctx, s, n, keys, st);
+    if (rc != DLC_OK) return rc;
     hipLaunchKernelGGL(minmax_decode_kernel, dim3((unsigned)dlc::cdiv(2 * n, 256)), dim3(256), 0, st, keys, (long long)n,
                        minmax);
-    DLC_LAUNCH_CHECK(ctx, "row_minmax_kernel");
     hipLaunchKernelGGL(quant_gather_kernel, dim3((unsigned)dlc::cdiv(n_cols, 256), (unsigned)n), dim3(256), 0, st, s,
                        (const long long*)cols, (long long)n_cols, (const double*)minmax, out);
     DLC_LAUNCH_CHECK(ctx, "quant_gather_kernel");

@@ -94,3 +94,15 @@ __device__ __forceinline__ float dlc_f16_bits_to_f32(unsigned short h) {
     _Float16 v = __builtin_bit_cast(_Float16, h);
     return (float)v;
 }
+
+// Order-preserving 64-bit key of a double (atomicMin / atomicMax on unsigned long long): per-frame minima / maxima of
+// the CnnVtl descriptor are folded this way by several kernels (cnnvtl.hip, the convolution epilogue of gemm_dma_f64.hip).
+// keys[2 f] = key of the minimum of frame f (initially ~0), keys[2 f + 1] = key of its maximum (initially 0).
+__device__ __forceinline__ unsigned long long dlc_f64_key(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dlc_f64_unkey(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}

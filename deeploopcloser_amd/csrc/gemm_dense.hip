@@ -469,6 +469,8 @@ int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, 
             if (rc_dma <= 0) return rc_dma;
         }
     }
+    // the kernel below does not fold per-image minima / maxima in its epilogue: a pass over its output does (end of this function)
+    unsigned long long* const fold_keys = cv ? cv->mm_keys : nullptr;
     a.chunks = chunks;
     a.P = chunks > 1 ? (T*)ctx->scratch : nullptr;
     // block of 64 tiles: 8 x 8, narrower along a dimension with fewer than 8 tiles (powers of two)
@@ -505,6 +507,13 @@ int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, 
         hipLaunchKernelGGL(splitk_bias_act_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)a.P, chunks,
                            (const T*)bias, (T*)C, (long long)ldc, (long long)M, (long long)N, act);
         DLC_LAUNCH_CHECK(ctx, "splitk_bias_act_kernel");
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (fold_keys) {
+            if (ldc != N) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "conv2d: per-image statistics need a contiguous output");
+            const int64_t per_img = (int64_t)cv->OH * cv->OW;
+            return dlc_cnn::fold_minmax_f64(ctx, (const double*)C, M / per_img, per_img * N, fold_keys, st);
+        }
     }
     return DLC_OK;
 }
@@ -545,6 +554,21 @@ int conv2d_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, const dou
 
 }  // namespace dlc_gemm
 
+extern "C" int dlc_conv2d_nhwc_f64_stats(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c, const double* kernel,
+                                         const double* bias, int kh, int kw, int cout, int stride, int pad_top, int pad_left,
+                                         int oh, int ow, int act, double* out, uint64_t* frame_keys, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!x || !kernel || !out || n < 1 || h < 1 || w < 1 || c < 1 || kh < 1 || kw < 1 || cout < 1 || stride < 1 ||
+        pad_top < 0 || pad_left < 0 || oh < 1 || ow < 1)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "conv2d: bad argument");
+    if (act < DLC_ACT_NONE || act > DLC_ACT_RELU) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "conv2d: act %d", act);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    dlc_gemm::ConvGeom cv{h, w, c, kw, stride, pad_top, pad_left, oh, ow, (unsigned long long*)frame_keys};
+    return dlc_gemm::conv2d_f64(ctx, act, n * oh * ow, cout, (int64_t)kh * kw * c, x, kernel, bias, out, cv,
+                                (hipStream_t)stream);
+}
+
 extern "C" int dlc_conv2d_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c, const double* kernel,
                                    const double* bias, int kh, int kw, int cout, int stride, int pad_top, int pad_left,
                                    int oh, int ow, int act, double* out, void* stream) {
@@ -555,7 +579,7 @@ extern "C" int dlc_conv2d_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int
     if (act < DLC_ACT_NONE || act > DLC_ACT_RELU) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "conv2d: act %d", act);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    dlc_gemm::ConvGeom cv{h, w, c, kw, stride, pad_top, pad_left, oh, ow};
+    dlc_gemm::ConvGeom cv{h, w, c, kw, stride, pad_top, pad_left, oh, ow, nullptr};
     return dlc_gemm::conv2d_f64(ctx, act, n * oh * ow, cout, (int64_t)kh * kw * c, x, kernel, bias, out, cv,
                                 (hipStream_t)stream);
 }

@@ -602,6 +602,17 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     }
 #endif
     // ---- epilogue: bias + activation, C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
+    // CONV with mm_keys: the minimum / maximum of every image's outputs is folded into ordered keys on the way out
+    // (the CnnVtl descriptor's per-frame range, cnn_vtl.py:110-112: a separate pass over the five layers' outputs read
+    // 4.9 GB again).  A wave's 64 rows (output pixels) touch at most two images -- the launcher checks OH * OW >= 64.
+    double mn0 = INFINITY, mx0 = -INFINITY, mn1 = INFINITY, mx1 = -INFINITY;
+    long long mm_img0 = 0, mm_bnd = 0;
+    const bool fold = CONV && p.cv.mm_keys != nullptr;
+    if (fold) {
+        const long long per_img = (long long)p.cv.OH * p.cv.OW;
+        mm_img0 = (m0 + wr * 64) / per_img;
+        mm_bnd = (mm_img0 + 1) * per_img;                                // first row of the next image
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const long long gn = n0 + (wc * NJ + j) * 16 + fr;
@@ -612,8 +623,32 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long gm = m0 + wr * 64 + i * 16 + fk + 4 * r;
-                if (gm < p.M) p.C[gm * p.ldc + gn] = act_f64(acc[i][j][r] + bv, p.act);
+                if (gm < p.M) {
+                    const double v = act_f64(acc[i][j][r] + bv, p.act);
+                    p.C[gm * p.ldc + gn] = v;
+                    if (fold) {
+                        if (gm < mm_bnd) { mn0 = fmin(mn0, v); mx0 = fmax(mx0, v); }
+                        else { mn1 = fmin(mn1, v); mx1 = fmax(mx1, v); }
+                    }
+                }
             }
+    }
+    if (fold) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn0 = fmin(mn0, __shfl_xor(mn0, o)); mx0 = fmax(mx0, __shfl_xor(mx0, o));
+            mn1 = fmin(mn1, __shfl_xor(mn1, o)); mx1 = fmax(mx1, __shfl_xor(mx1, o));
+        }
+        if (lane == 0) {
+            if (mn0 <= mx0) {                                            // saw at least one element of that image
+                atomicMin(&p.cv.mm_keys[2 * mm_img0], dlc_f64_key(mn0));
+                atomicMax(&p.cv.mm_keys[2 * mm_img0 + 1], dlc_f64_key(mx0));
+            }
+            if (mn1 <= mx1) {
+                atomicMin(&p.cv.mm_keys[2 * mm_img0 + 2], dlc_f64_key(mn1));
+                atomicMax(&p.cv.mm_keys[2 * mm_img0 + 3], dlc_f64_key(mx1));
+            }
+        }
     }
 }
 
@@ -675,6 +710,7 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.Kb = Kb; a.act = act;
     a.cv = cv ? *cv : ConvGeom{};
     a.cv_all_valid = 0;
+    if (cv && cv->mm_keys && (int64_t)cv->OH * cv->OW < 64) return 1;     // the epilogue folds at most two images per wave
     if (cv) {
         // per-lane offsets of the A operand are 32-bit and must stay below the descriptor's num_records: a tile's
         // 256 output pixels span at most cdiv(256, OH * OW) + 1 images

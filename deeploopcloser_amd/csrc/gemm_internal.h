@@ -9,6 +9,9 @@ namespace dlc_gemm {
 // at the NHWC input and lda is unused.
 struct ConvGeom {
     int H, W, C, KW, stride, pad_t, pad_l, OH, OW;
+    // optional: [images, 2] ordered keys (dlc_f64_key) into which the minimum / maximum of every image's outputs is
+    // folded (cnn_vtl.py:110-112 takes them over the whole descriptor of a frame; dlc_cnnvtl_frame_minmax_init)
+    unsigned long long* mm_keys;
 };
 
 // Triangular skip of a launch (the Gram blocks of the SDAV similarity, match_ref.hip): rows / columns are
@@ -33,3 +36,8 @@ int gemm_bias_act_padded_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_
                              const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st);
 
 }  // namespace dlc_gemm
+
+namespace dlc_cnn {
+// Folds min / max of x[img, per_img] (fp64, contiguous) into keys[img, 2] (cnnvtl.hip).
+int fold_minmax_f64(dlc_ctx* ctx, const double* x, int64_t n_img, int64_t per_img, unsigned long long* keys, hipStream_t st);
+}

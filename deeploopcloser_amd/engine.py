@@ -255,15 +255,46 @@ class Engine:
                                                   ow, _ptr(cols), self._stream()))
         return cols
 
-    def conv2d(self, x, kernel2d, bias, kh, kw, stride, pad_top, pad_left, oh, ow, act):
+    def conv2d(self, x, kernel2d, bias, kh, kw, stride, pad_top, pad_left, oh, ow, act, frame_keys=None):
         """NHWC fp64 convolution + bias + activation as an implicit GEMM (no im2col matrix).
-        kernel2d is the HWIO kernel reshaped [kh*kw*c, cout]."""
+        kernel2d is the HWIO kernel reshaped [kh*kw*c, cout].  frame_keys ([n, 2] int64 from
+        frame_minmax_keys()): the minimum / maximum of every frame's outputs is folded into it on the way."""
         x = x.contiguous()
         n, h, w, c = x.shape
         cout = kernel2d.shape[1]
         out = torch.empty((n, oh, ow, cout), dtype=torch.float64, device=self.device)
-        self._check(self.lib.dlc_conv2d_nhwc_f64(self.ctx, _ptr(x), n, h, w, c, _ptr(kernel2d), _ptr(bias), kh, kw, cout,
-                                                  stride, pad_top, pad_left, oh, ow, act, _ptr(out), self._stream()))
+        if frame_keys is None:
+            self._check(self.lib.dlc_conv2d_nhwc_f64(self.ctx, _ptr(x), n, h, w, c, _ptr(kernel2d), _ptr(bias), kh, kw, cout,
+                                                      stride, pad_top, pad_left, oh, ow, act, _ptr(out), self._stream()))
+        else:
+            self._check_keys(frame_keys, n)
+            self._check(self.lib.dlc_conv2d_nhwc_f64_stats(self.ctx, _ptr(x), n, h, w, c, _ptr(kernel2d), _ptr(bias), kh, kw,
+                                                            cout, stride, pad_top, pad_left, oh, ow, act, _ptr(out),
+                                                            _ptr(frame_keys), self._stream()))
+        return out
+
+    def _check_keys(self, keys, n):
+        if not isinstance(keys, torch.Tensor) or keys.dtype != torch.int64 or tuple(keys.shape) != (n, 2) or \
+                not keys.is_contiguous() or keys.device != self.device:
+            raise ValueError("frame keys must be a contiguous [%d, 2] int64 tensor on %s" % (n, self.device))
+
+    def frame_minmax_keys(self, n):
+        """[n, 2] ordered keys, initialised to 'nothing seen', for conv2d(frame_keys=) / quant_gather()."""
+        keys = torch.empty((n, 2), dtype=torch.int64, device=self.device)
+        self._check(self.lib.dlc_cnnvtl_frame_minmax_init(self.ctx, _ptr(keys), n, self._stream()))
+        return keys
+
+    def quant_gather(self, segments, columns, frame_keys):
+        """minmax_quant_gather with the per-frame range taken from frame_keys (folded by the convolutions)."""
+        n = segments[0].shape[0]
+        self._check_keys(frame_keys, n)
+        segs = [s.reshape(n, -1).contiguous() for s in segments]
+        ptrs = (C.c_void_p * len(segs))(*[s.data_ptr() for s in segs])
+        sizes = (C.c_int64 * len(segs))(*[s.shape[1] for s in segs])
+        minmax = torch.empty((n, 2), dtype=torch.float64, device=self.device)
+        out = torch.empty((n, columns.numel()), dtype=torch.int8, device=self.device)
+        self._check(self.lib.dlc_quant_gather_i8(self.ctx, ptrs, sizes, len(segs), n, _ptr(columns), columns.numel(),
+                                                  _ptr(frame_keys), _ptr(minmax), _ptr(out), self._stream()))
         return out
 
     def space_to_depth(self, x, s):

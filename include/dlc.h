@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DLC_ABI_VERSION 3
+#define DLC_ABI_VERSION 4
 
 typedef struct dlc_ctx dlc_ctx;
 
@@ -213,6 +213,26 @@ int dlc_maxpool3x3s2_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, i
 int dlc_minmax_quant_gather_i8(dlc_ctx* ctx, const double* const* segs, const int64_t* seg_sizes, int n_segs,
                                int64_t n, const int64_t* cols, int64_t n_cols, double* minmax,
                                int8_t* out, void* stream);
+/*
+ * The same with the per-frame minimum / maximum gathered WHILE the layers are computed instead of in a pass over
+ * their outputs (4.9 GB at 1063 frames of 192x240):
+ *   dlc_cnnvtl_frame_minmax_init   keys[n, 2] (DEVICE, 64-bit ordered keys) <- "no element seen yet";
+ *   dlc_conv2d_nhwc_f64_stats      dlc_conv2d_nhwc_f64 that also folds min / max of out[f, :, :, :] into keys[f]
+ *                                  (frame_keys may be NULL: plain convolution).  Large launches fold in the GEMM's
+ *                                  epilogue (wave reduction + atomicMin / atomicMax on the keys), small ones in a pass
+ *                                  over their own output;
+ *   dlc_quant_gather_i8            decodes the keys into minmax[n, 2] (fp64 DEVICE scratch, as above) and quantises /
+ *                                  gathers exactly as dlc_minmax_quant_gather_i8 does.
+ * min / max are order-independent, so the descriptors are bit-identical to the one-call form.
+ */
+int dlc_cnnvtl_frame_minmax_init(dlc_ctx* ctx, uint64_t* keys, int64_t n, void* stream);
+int dlc_conv2d_nhwc_f64_stats(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c,
+                              const double* kernel, const double* bias, int kh, int kw, int cout,
+                              int stride, int pad_top, int pad_left, int oh, int ow, int act,
+                              double* out, uint64_t* frame_keys, void* stream);
+int dlc_quant_gather_i8(dlc_ctx* ctx, const double* const* segs, const int64_t* seg_sizes, int n_segs,
+                        int64_t n, const int64_t* cols, int64_t n_cols, const uint64_t* keys, double* minmax,
+                        int8_t* out, void* stream);
 
 /* ---- match: reference semantics --------------------------------------- */
 /*

@@ -643,6 +643,40 @@ def test_conv2d_implicit_gemm_vs_oracle(eng):
         assert torch.equal(alt, got)
 
 
+def test_conv2d_frame_minmax_keys(eng):
+    """dlc_conv2d_nhwc_f64_stats: the per-frame minimum / maximum folded while the convolution runs == min / max of its
+    output, exactly, on every route: the LDS-DMA kernel's epilogue (large launches, signed values, a tile spanning two
+    frames), the pass over the output (small launches, fewer than 64 output pixels per frame), several layers into one
+    set of keys; and quant_gather from those keys == the one-call minmax_quant_gather, byte for byte."""
+    g = torch.Generator(device=eng.device); g.manual_seed(12)
+    rnd = lambda *shape: torch.randn(shape, generator=g, device=eng.device, dtype=torch.float64)
+    for (n, h, w, c, k, cout, pad, act) in ((40, 22, 28, 96, 5, 256, 2, 0),      # 40 * 616 rows: LDS-DMA kernel, no ReLU
+                                            (300, 10, 13, 256, 3, 384, 1, 2),     # 130 pixels per frame: two frames per wave tile
+                                            (3, 10, 13, 32, 3, 24, 1, 0),         # small launch: register-staged kernel + pass
+                                            (700, 6, 7, 32, 3, 128, 1, 0)):       # 42 pixels per frame: more than two per wave
+        x, wk, b = rnd(n, h, w, c), rnd(k * k * c, cout) / (k * np.sqrt(c)), rnd(cout)
+        keys = eng.frame_minmax_keys(n)
+        y = eng.conv2d(x, wk, b, k, k, 1, pad, pad, h, w, act, frame_keys=keys)
+        assert torch.equal(y, eng.conv2d(x, wk, b, k, k, 1, pad, pad, h, w, act))
+        cols = torch.arange(0, y[0].numel(), 7, device=eng.device)
+        got = eng.quant_gather([y], cols, keys)
+        assert torch.equal(got, eng.minmax_quant_gather([y], cols)), (n, h, w, c)
+        flat = y.reshape(n, -1).cpu().numpy()                   # NumPy: torch's scalar / tensor is reciprocal * scalar
+        mn, mx = flat.min(axis=1, keepdims=True), flat.max(axis=1, keepdims=True)
+        scaled = (flat[:, cols.cpu().numpy()] - mn) * (255.0 / (mx - mn))
+        assert np.array_equal(got.cpu().numpy(), np.trunc(scaled).astype(np.int64).astype(np.int8))
+    # two layers into one set of keys
+    x, w1, b1 = rnd(64, 12, 16, 16), rnd(9 * 16, 64) / 12, rnd(64)
+    w2, b2 = rnd(9 * 64, 32) / 24, rnd(32)
+    keys = eng.frame_minmax_keys(64)
+    y1 = eng.conv2d(x, w1, b1, 3, 3, 1, 1, 1, 12, 16, 2, frame_keys=keys)
+    y2 = eng.conv2d(y1, w2, b2, 3, 3, 1, 1, 1, 12, 16, 0, frame_keys=keys)
+    cols = torch.arange(0, y1[0].numel() + y2[0].numel(), 11, device=eng.device)
+    assert torch.equal(eng.quant_gather([y1, y2], cols, keys), eng.minmax_quant_gather([y1, y2], cols))
+    with pytest.raises(ValueError):
+        eng.conv2d(x, w1, b1, 3, 3, 1, 1, 1, 12, 16, 2, frame_keys=keys[:10])
+
+
 def test_cnn_vtl_transform_vs_oracle(dlc):
     """CnnVtl.transform at the reference's 192x240 frame size, seeded weights + mask."""
     from oracle import cnn_vtl as ocnn
