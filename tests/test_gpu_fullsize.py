@@ -96,6 +96,30 @@ def test_similarity_matrix_two_gram_chunks(dlc):
         assert abs(mf[i, j] - want) <= 1e-9 * abs(want)
 
 
+@pytest.mark.parametrize("n,p,h", [(300, 13, 64), (420, 7, 96), (257, 30, 66), (129, 32, 80)])
+def test_similarity_matrix_odd_patch_counts(dlc, n, p, h):
+    """Patch counts that do not divide the Gram tiles (the wanted-block walk steps a remainder per block column), sizes
+    that put the Gram on the LDS-DMA kernel: == the oracle on sampled pairs, == frame ranges scored alone."""
+    from oracle import similarity as osim
+    eng = dlc.default_engine()
+    g = torch.Generator(device=eng.device); g.manual_seed(n + p)
+    ds = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
+    score = eng.distinctive_score(ds, 0.5, 0.2)
+    mf, _ = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, want_int64=False)
+    mf = mf.cpu().numpy()
+    assert np.array_equal(mf, mf.T) and np.all(np.diag(mf) == -1)
+    for lo, hi in ((0, n // 2), (n // 3, n), (n // 2 - 5, n // 2 + 40)):
+        sub, _ = eng.sdav_similarity_matrix(ds[lo:hi], score, 10.0, -10.0, want_int64=False)
+        assert np.array_equal(sub.cpu().numpy(), mf[lo:hi, lo:hi]), (lo, hi)
+    dsn, sc = ds.cpu().numpy(), score.cpu().numpy()
+    rng = np.random.RandomState(2)
+    for _ in range(10):
+        i, j = sorted(rng.choice(n, 2, replace=False))
+        d = osim.weighted_distances(dsn[i], dsn[j], osim.match_features(dsn[i], dsn[j]), sc)
+        want = np.sum(10 - 10 * np.log(d))
+        assert abs(mf[i, j] - want) <= 1e-9 * abs(want)
+
+
 def test_distance_matrix_kennedylong_properties(dlc):
     from oracle import distance as odist
     rng = np.random.RandomState(1)
