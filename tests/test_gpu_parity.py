@@ -978,6 +978,35 @@ def test_gemm_dma_kernel_edges(eng, m, n, k, blayout):
     assert torch.equal(out, got)
 
 
+def test_gemm_dma_small_launch_fuzz(eng):
+    """The LDS-DMA kernel is taken from 16 tiles on: random small / medium shapes (edge blocks numbered rows-first,
+    blocks shrunk for the shader engines, N <= 96 on the 96-column tile, K tails, both B layouts, all activations)
+    against torch fp64 and, bit for bit, against the register-staged kernel (odd row stride of A)."""
+    from deeploopcloser_amd import _lib as L
+    rng = np.random.RandomState(77)
+    g = torch.Generator(device=eng.device); g.manual_seed(77)
+    for _ in range(36):
+        m = int(rng.randint(192, 6000))
+        n = int(rng.choice([2, 34, 66, 96, 98, 128, 130, 256, 300, 384, 640, 1024])) if rng.rand() < 0.7 else 2 * int(rng.randint(1, 400))
+        k = 2 * int(rng.randint(32, 400))
+        lay = L.DLC_B_KN if rng.rand() < 0.5 else L.DLC_B_NK
+        act = int(rng.randint(0, 3))
+        a = torch.randn((m, k), generator=g, device=eng.device, dtype=torch.float64) / k ** 0.5
+        b = torch.randn((k, n) if lay == L.DLC_B_KN else (n, k), generator=g, device=eng.device, dtype=torch.float64)
+        bias = torch.randn((n,), generator=g, device=eng.device, dtype=torch.float64)
+        got = eng.gemm_bias_act(a, b, bias, act=act, blayout=lay)
+        z = a @ (b if lay == L.DLC_B_KN else b.T) + bias
+        ref = torch.sigmoid(z) if act == L.DLC_ACT_SIGMOID else (torch.relu(z) if act == L.DLC_ACT_RELU else z)
+        assert float((got - ref).abs().max()) < 1e-11, (m, n, k, lay, act)
+        wide = torch.zeros((m, k + 1), dtype=torch.float64, device=eng.device)
+        wide[:, :k] = a
+        out = torch.empty((m, n), dtype=torch.float64, device=eng.device)
+        eng._check(eng.lib.dlc_gemm_bias_act(eng.ctx, L.DLC_F64, lay, act, m, n, k, wide.data_ptr(), k + 1,
+                                              b.data_ptr(), b.stride(0), bias.data_ptr(), out.data_ptr(), n, None))
+        torch.cuda.synchronize()
+        assert torch.equal(out, got), (m, n, k, lay, act)
+
+
 def test_space_to_depth_and_conv1_equivalence(eng, dlc):
     """dlc_space_to_depth_nhwc_f64 against the NumPy reshape / transpose, and CnnVtl's conv1 through it (a 3x3
     convolution over 48 channels) against the oracle's 11x11 / 4 convolution and against the direct call."""
