@@ -643,6 +643,30 @@ def test_conv2d_implicit_gemm_vs_oracle(eng):
         assert torch.equal(alt, got)
 
 
+def test_conv2d_dma_kernel_padding_and_stride_fuzz(eng):
+    """Convolutions large enough for the LDS-DMA kernel (C % 16 == 0, >= 16 tiles) whose padding is served by
+    out-of-range buffer offsets: SAME / VALID, strides 1-3, kernels 1-7, odd image sizes, tiles that span several
+    images -- against the oracle and, bit for bit, the explicit im2col + GEMM path."""
+    from oracle import cnn_vtl as ocnn
+    rng = np.random.RandomState(9)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    for (n, h, w, c, kh, cout, stride, pad) in ((40, 17, 19, 16, 3, 40, 2, "VALID"), (70, 12, 10, 32, 5, 130, 2, "SAME"),
+                                                (90, 9, 9, 16, 5, 96, 1, "SAME"), (25, 21, 23, 48, 7, 64, 3, "SAME"),
+                                                (33, 14, 15, 64, 1, 256, 1, "VALID"), (300, 5, 6, 16, 3, 34, 1, "SAME"),
+                                                (16, 31, 29, 16, 3, 8, 1, "SAME")):
+        x = rng.standard_normal((n, h, w, c))
+        wk = rng.standard_normal((kh, kh, c, cout)) / np.sqrt(kh * kh * c)
+        b = rng.standard_normal(cout)
+        oh, ph = ocnn._out_size(h, kh, stride, pad)
+        ow, pw = ocnn._out_size(w, kh, stride, pad)
+        got = eng.conv2d(dev(x), dev(wk.reshape(-1, cout)), dev(b), kh, kh, stride, ph, pw, oh, ow, 2)
+        ref = ocnn.conv2d_nhwc(x[:4], wk, b, stride, pad, True)
+        assert np.abs(got[:4].cpu().numpy() - ref).max() < 1e-10, (n, h, w, c, kh)
+        cols = eng.im2col(dev(x), kh, kh, stride, ph, pw, oh, ow)
+        alt = eng.gemm_bias_act(cols, dev(wk.reshape(-1, cout)), dev(b), act=2).reshape(got.shape)
+        assert torch.equal(alt, got), (n, h, w, c, kh)
+
+
 def test_conv2d_frame_minmax_keys(eng):
     """dlc_conv2d_nhwc_f64_stats: the per-frame minimum / maximum folded while the convolution runs == min / max of its
     output, exactly, on every route: the LDS-DMA kernel's epilogue (large launches, signed values, a tile spanning two
