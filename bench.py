@@ -237,6 +237,44 @@ def bench_paths(eng, n_frames):
                 "max_abs_err_vs_oracle": err})
     del ws, bs, xs, ref
 
+    # ---- f-2: one SDAV training step (sess.run(train_steps[0]), SDAV.py:262) on the reference's default batch -------
+    from oracle import sdav_train as otrain
+    B = min(10, N)                                                       # SDAV.default_batch_size
+    if B >= 2:
+        tnet = dlc.SDAV(seed=3)
+        xb = x[:B].contiguous()
+        masks = [tnet._mask(0)]
+        w0, be0 = [w.cpu().numpy() for w in tnet._weights], [b.cpu().numpy() for b in tnet._biases]
+        bd0 = tnet._biases_dec[0].cpu().numpy()
+        t0 = time.perf_counter()
+        want = otrain.loss_and_grads(0, xb.cpu().numpy(), [masks[0].cpu().numpy()], w0, be0, bd0, tnet.sparse_level,
+                                     tnet.sparse_penalty, tnet.consecutive_penalty)[0]
+        t_cpu = time.perf_counter() - t0
+        with eng.latency_mode():                                          # as SDAV.fit / fit_dataset run their steps: split-K scratch on
+            got = float(tnet.train_step(0, xb, masks)[0].item())          # the loss of the first step: same parameters as the oracle's
+            for _ in range(3):
+                tnet.train_step(0, xb, masks)
+            torch.cuda.synchronize()
+            steps_t = 20
+            t0 = time.perf_counter()
+            for _ in range(steps_t):
+                tnet.train_step(0, xb, masks)
+            torch.cuda.synchronize()
+            step_ms = (time.perf_counter() - t0) / steps_t * 1e3
+        tflops = 5 * 2.0 * (B * P) * K0 * H                               # encoder, decoder, dh, and the two weight gradients
+        tf = tflops / (step_ms * 1e-3) / 1e12
+        out.append({"path": "SDAV.train_step (layer 0, %d frames)" % B, "reference": "src/sdav/network/SDAV.py:129-226, 262",
+                    "frames": B, "dtype": "f64", "value": 1e3 / step_ms, "unit": "steps/s", "ms": step_ms,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
+                                 "kernel": "five fp64 GEMMs of 300 x 1681 x 2500 (split-K, as SDAV.fit runs them) + 14 small kernels per step: launch- and latency-bound at this batch",
+                                 "kernel_ms": step_ms, "call_ms": step_ms, "algorithmic_flops_per_call": tflops},
+                    "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "steps/s", "cores": cores, "kind": "port",
+                                     "sample": "oracle/sdav_train.py loss_and_grads (fp64 NumPy) on the same batch, masks and "
+                                               "parameters: %.2f s" % t_cpu},
+                    "loss_rel_err_vs_oracle": abs(got - want) / abs(want)})
+        del tnet, xb, masks
+
     # ---- M1/M2: SDAV similarity matrix (SimilarityCalculator.py:12-49 + create_similarity_matrix.py:29-38) ----
     desc = h.reshape(N, P, H)
 

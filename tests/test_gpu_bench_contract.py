@@ -44,11 +44,13 @@ def test_bench_json_contract():
     assert abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4 / 1e3)) / d["value"] < 1e-6
     # the other rows of the hot path, each with its own roofline and CPU baseline, each checked against the oracle
     paths = {p["path"]: p for p in d["paths"]}
-    assert set(paths) == {"SDAV.transform", "SDAV similarity matrix", "cosine similarity matrix (flattened SDAV descriptors)",
+    assert set(paths) == {"SDAV.transform", "SDAV.train_step (layer 0, 10 frames)", "SDAV similarity matrix",
+                          "cosine similarity matrix (flattened SDAV descriptors)",
                           "cosine top-20 (flattened SDAV descriptors)", "CnnVtl.transform", "cnn_vtl distance matrix"}
+    assert paths["SDAV.train_step (layer 0, 10 frames)"]["loss_rel_err_vs_oracle"] < 1e-9
     for p in d["paths"]:
         pr, pc = p["roofline"], p["cpu_baseline"]
-        assert p["frames"] == 24 and p["value"] > 0 and p["ms"] > 0 and p["reference"]
+        assert p["frames"] == (10 if "train_step" in p["path"] else 24) and p["value"] > 0 and p["ms"] > 0 and p["reference"]
         assert pr["bound"] in ("hbm", "mfma") and pr["achieved"] > 0 and abs(pr["frac"] - pr["achieved"] / pr["peak"]) < 1e-9
         assert pr["kernel_ms"] > 0 and pr["kernel_ms"] <= pr["call_ms"] * 1.001 and "traffic" in pr
         assert pc["kind"] == "port" and pc["value"] > 0 and pc["cores"] >= 1 and pc["unit"] == p["unit"] and pc["sample"]
