@@ -275,6 +275,66 @@ def bench_paths(eng, n_frames):
                     "loss_rel_err_vs_oracle": abs(got - want) / abs(want)})
         del tnet, xb, masks
 
+    # ---- f-1: the patch front-end on resident uint8 frames (CvInputParser.py:19-49 with the build's detector) -------
+    from oracle import patches as opatch, keypoints as okp
+    from deeploopcloser_amd.input import CvInputParser
+    fh, fw = 192, 240
+    rgb = torch.randint(0, 256, (N, fh, fw, 3), generator=g, device=eng.device, dtype=torch.uint8)
+    parser = CvInputParser(P, 41)
+    fe_ms, _, _, pat = _timed_path(eng, lambda: parser.parse_batch(rgb))
+    fe_bytes = float(N) * (fh * fw * 3 + fh * fw + P * K0 * 8)           # RGB in, grey out and in again, fp64 patches out
+    nf = min(N, 3)
+    pat_h = pat[:nf].cpu().numpy()
+    t0 = time.perf_counter()
+    fe_exact = True
+    for f in range(nf):
+        gray = opatch.bgr2gray_opencv(rgb[f].cpu().numpy())
+        pts, _, cnt = okp.key_points(gray, P)
+        if cnt == P:                                                     # (a frame with fewer corners is topped up with grid points)
+            fe_exact = fe_exact and bool(np.array_equal(pat_h[f], opatch.parse(gray, [tuple(q) for q in pts], 41)))
+    t_cpu = time.perf_counter() - t0
+    out.append({"path": "patch front-end (grey + Harris + %d patches of 41x41)" % P,
+                "reference": "src/sdav/input/CvInputParser.py:19-49 (SURF replaced by the build's integer Harris detector)",
+                "frames": N, "dtype": "u8", "value": N / (fe_ms * 1e-3), "unit": "frames/s", "ms": fe_ms,
+                "roofline": {"bound": "hbm", "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": "rgb_to_gray + harris (response, non-maximum suppression, n arg-max rounds) + patch gather",
+                             "kernel_ms": fe_ms, "call_ms": fe_ms, "algorithmic_bytes_per_call": fe_bytes},
+                "cpu_baseline": {"value": nf / t_cpu, "unit": "frames/s", "cores": 1, "kind": "port",
+                                 "sample": "oracle/patches.py grey conversion + oracle/keypoints.py Harris on the first %d frames "
+                                           "(NumPy): %.2f s" % (nf, t_cpu)},
+                "bit_exact_vs_oracle": fe_exact})
+    del rgb, pat
+
+    # ---- f-4: the streaming loop-closure query over a growing key-frame database ---------------------------------
+    from oracle import loop_closure as oloop
+    Dl, kl, excl, bl = 4096, 5, 30, 32
+    xs_l = torch.randn((N, Dl), generator=g, device=eng.device, dtype=torch.float32)
+
+    def stream():
+        det = dlc.LoopClosureDetector(Dl, k=kl, threshold=0.5, exclusion=excl, capacity=max(64, N))
+        outs = [det.query_and_insert(xs_l[lo:lo + bl]) for lo in range(0, N, bl)]
+        return det, torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+    lc_ms, _, _, (det, ls, li) = _timed_path(eng, stream)
+    nl = min(N, 200)
+    rows_l = det.db.rows[:nl].float().cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    es, ei = oloop.stream_topk(rows_l, kl, excl)
+    t_cpu = time.perf_counter() - t0
+    lc_agree = float((li[:nl].cpu().numpy() == ei).mean())
+    lc_bytes = float(N) * N / 2 * Dl * 2                                 # every frame reads the older key-frames' bf16 rows once
+    out.append({"path": "LoopClosureDetector.query_and_insert (batches of %d frames)" % bl,
+                "reference": "SURVEY 8f-4 (no reference implementation); oracle/loop_closure.py", "frames": N, "dim": Dl,
+                "dtype": "bf16", "k": kl, "value": N / (lc_ms * 1e-3), "unit": "frames/s", "ms": lc_ms,
+                "roofline": {"bound": "hbm", "achieved": lc_bytes / (lc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": lc_bytes / (lc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": "l2_normalize into the store + top-(k+B-1) match per batch (%d launches of a few microseconds of work: launch-bound at this database size)" % (-(-N // bl)),
+                             "kernel_ms": lc_ms, "call_ms": lc_ms, "algorithmic_bytes_per_call": lc_bytes},
+                "cpu_baseline": {"value": nl / t_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
+                                 "sample": "oracle/loop_closure.py per-frame fp64 loop over the first %d stored rows: %.2f s" % (nl, t_cpu)},
+                "index_agreement_vs_oracle": lc_agree})
+    del xs_l, det, ls, li
+
     # ---- M1/M2: SDAV similarity matrix (SimilarityCalculator.py:12-49 + create_similarity_matrix.py:29-38) ----
     desc = h.reshape(N, P, H)
 

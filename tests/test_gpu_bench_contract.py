@@ -45,9 +45,13 @@ def test_bench_json_contract():
     # the other rows of the hot path, each with its own roofline and CPU baseline, each checked against the oracle
     paths = {p["path"]: p for p in d["paths"]}
     assert set(paths) == {"SDAV.transform", "SDAV.train_step (layer 0, 10 frames)", "SDAV similarity matrix",
+                          "patch front-end (grey + Harris + 30 patches of 41x41)",
+                          "LoopClosureDetector.query_and_insert (batches of 32 frames)",
                           "cosine similarity matrix (flattened SDAV descriptors)",
                           "cosine top-20 (flattened SDAV descriptors)", "CnnVtl.transform", "cnn_vtl distance matrix"}
     assert paths["SDAV.train_step (layer 0, 10 frames)"]["loss_rel_err_vs_oracle"] < 1e-9
+    assert paths["patch front-end (grey + Harris + 30 patches of 41x41)"]["bit_exact_vs_oracle"] is True
+    assert paths["LoopClosureDetector.query_and_insert (batches of 32 frames)"]["index_agreement_vs_oracle"] > 0.999
     for p in d["paths"]:
         pr, pc = p["roofline"], p["cpu_baseline"]
         assert p["frames"] == (10 if "train_step" in p["path"] else 24) and p["value"] > 0 and p["ms"] > 0 and p["reference"]
