@@ -67,6 +67,7 @@ SIGNATURES = {
                                       _vp, _vp, _int, _vp]),
     "dlc_topk_merge_strided": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp]),
     "dlc_topk_merge": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp]),
+    "dlc_topk_keep_older": (_int, [_vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp]),
     "dlc_cosine_scores_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dlc_cosine_scores": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _sz, _vp]),
     "dlc_set_scratch": (_int, [_vp, _vp, _sz]),

@@ -1443,6 +1443,48 @@ extern "C" int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, i
     return run_select<FIN_RESCORE>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, flags, x, (hipStream_t)stream);
 }
 
+namespace {
+// Row b of a best-first candidate list [rows, kk] keeps its first k entries whose id lies in [0, limit0 + b); the rest
+// of its k slots hold (-inf, -1).  One wave per row; kk <= DLC_MAX_K.
+__global__ __launch_bounds__(256) void keep_older_kernel(const float* __restrict__ scores, const long long* __restrict__ idx,
+                                                         long long rows, int kk, long long limit0, int k,
+                                                         float* __restrict__ out_s, long long* __restrict__ out_i) {
+    const int lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= rows) return;
+    int kept = 0;
+    for (int c0 = 0; c0 < kk && kept < k; c0 += 64) {
+        const int c = c0 + lane;
+        const long long id = c < kk ? idx[b * kk + c] : -1;
+        const bool ok = id >= 0 && id < limit0 + b;
+        const unsigned long long m = __ballot(ok);
+        const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && pos < k) {
+            out_s[b * k + pos] = scores[b * kk + c];
+            out_i[b * k + pos] = id;
+        }
+        kept += __popcll(m);
+    }
+    for (int e = (kept < k ? kept : k) + lane; e < k; e += 64) {
+        out_s[b * k + e] = -INFINITY;
+        out_i[b * k + e] = -1;
+    }
+}
+}  // namespace
+
+extern "C" int dlc_topk_keep_older(dlc_ctx* ctx, const float* scores, const int64_t* idx, int64_t rows, int kk,
+                                   int64_t limit0, int k, float* out_scores, int64_t* out_idx, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!scores || !idx || !out_scores || !out_idx || rows < 1 || kk < 1 || kk > DLC_MAX_K || k < 1 || k > DLC_MAX_K)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "topk_keep_older: bad argument (1 <= kk, k <= %d)", DLC_MAX_K);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipLaunchKernelGGL(keep_older_kernel, dim3((unsigned)dlc::cdiv(rows, (int64_t)4)), dim3(256), 0, (hipStream_t)stream, scores,
+                       (const long long*)idx, (long long)rows, kk, (long long)limit0, k, out_scores, (long long*)out_idx);
+    DLC_LAUNCH_CHECK(ctx, "keep_older_kernel");
+    return DLC_OK;
+}
+
 extern "C" int dlc_topk_merge_strided(dlc_ctx* ctx, const float* scores, int64_t score_part_stride, const int64_t* idx,
                                       int64_t idx_part_stride, int parts, int64_t q, int k, float* out_scores,
                                       int64_t* out_idx, void* stream) {

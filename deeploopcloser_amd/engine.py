@@ -493,6 +493,18 @@ class Engine:
                                                      _ptr(o_i), self._stream()))
         return o_s, o_i
 
+    def topk_keep_older(self, scores, idx, limit0, k):
+        """Row b of best-first (scores, idx) [B, kk] -> its first k entries with 0 <= id < limit0 + b, (-inf, -1) after."""
+        scores, idx = scores.contiguous(), idx.contiguous()
+        if scores.dim() != 2 or idx.shape != scores.shape or scores.dtype != torch.float32 or idx.dtype != torch.int64:
+            raise ValueError("topk_keep_older: scores float32 / idx int64 of one shape [B, kk]")
+        b, kk = scores.shape
+        o_s = torch.empty((b, k), dtype=torch.float32, device=self.device)
+        o_i = torch.empty((b, k), dtype=torch.int64, device=self.device)
+        self._check(self.lib.dlc_topk_keep_older(self.ctx, _ptr(scores), _ptr(idx), b, kk, int(limit0), int(k), _ptr(o_s),
+                                                  _ptr(o_i), self._stream()))
+        return o_s, o_i
+
     def topk_merge(self, scores, idx, out=None):
         """Merge [parts, Q, k] per-shard results into the global [Q, k]."""
         scores, idx = scores.contiguous(), idx.contiguous()

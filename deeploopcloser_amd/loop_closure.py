@@ -89,8 +89,7 @@ class LoopClosureDetector:
             return (torch.full((b, k), float("-inf"), dtype=torch.float32, device=dev),
                     torch.full((b, k), -1, dtype=torch.int64, device=dev))
         s, i = db.engine.match_topk(q, db.rows[:n_search], min(k + b - 1, L.DLC_MAX_K))
-        limit = torch.arange(g0 - self.exclusion, g0 - self.exclusion + b, device=dev)
-        return first_k_eligible(s, i, limit, k)
+        return db.engine.topk_keep_older(s, i, g0 - self.exclusion, k)      # one kernel; first_k_eligible is its torch form
 
     def loops(self, scores, ids, first_id):
         """[(frame id, matched key-frame id, score)] of the candidates at or above the threshold."""

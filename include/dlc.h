@@ -355,6 +355,14 @@ int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, i
                             const float* all_group_max, int parts,
                             float* out_scores, int64_t* out_idx, int flags, void* stream);
 /*
+ * Streaming loop-closure queries: a batch of B new frames is matched in one dlc_cosine_topk call with
+ * kk = k + B - 1 candidates per frame; frame b may only see key-frames older than limit0 + b.  Row b of the best-first
+ * lists scores / idx [rows, kk] keeps its first k entries with 0 <= id < limit0 + b (order kept); the rest of its k
+ * slots are (-inf, -1).  kk, k <= DLC_MAX_K.
+ */
+int dlc_topk_keep_older(dlc_ctx* ctx, const float* scores, const int64_t* idx, int64_t rows, int kk,
+                        int64_t limit0, int k, float* out_scores, int64_t* out_idx, void* stream);
+/*
  * Merge `parts` per-shard results ([parts, q, k], as an all-gather leaves
  * them) into the global top-k with the same ordering rule.
  */

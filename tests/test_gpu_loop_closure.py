@@ -117,3 +117,19 @@ def test_cli_streams_the_reference_frames(dlc, capsys):
                             "--threshold", "-1", "--batch", "3"])
     out = capsys.readouterr().out.strip().splitlines()
     assert rc == 0 and len(out) == 2
+
+
+def test_keep_older_kernel_equals_torch_form(dlc):
+    """dlc_topk_keep_older == first_k_eligible (its torch form, tested on the CPU) on random candidate lists: empty
+    slots, every candidate too recent, fewer candidates than k, more than 64 candidates per row."""
+    from deeploopcloser_amd.loop_closure import first_k_eligible
+    eng = dlc.default_engine()
+    g = torch.Generator(device=eng.device); g.manual_seed(5)
+    for (b, kk, k, limit0) in ((1, 1, 1, 0), (7, 11, 5, 3), (32, 36, 5, 100), (200, 128, 20, -50), (64, 100, 128, 40), (3, 5, 8, 2)):
+        idx = torch.randint(-1, 160, (b, kk), generator=g, device=eng.device, dtype=torch.int64)
+        sc = torch.rand((b, kk), generator=g, device=eng.device, dtype=torch.float32).sort(dim=1, descending=True).values
+        limit = torch.arange(limit0, limit0 + b, device=eng.device)
+        ws, wi = first_k_eligible(sc, idx, limit, k)
+        gs, gi = eng.topk_keep_older(sc, idx, limit0, k)
+        assert torch.equal(gi, wi) and torch.equal(gs, ws), (b, kk, k, limit0)
+
