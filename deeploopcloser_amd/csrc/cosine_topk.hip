@@ -873,14 +873,39 @@ template <typename Src, typename Tag>
 __global__ __launch_bounds__(256) void l2_normalize_kernel(const Src* __restrict__ src, long long lds, int d,
                                                            int center, unsigned short* __restrict__ dst,
                                                            long long ldd) {
+    // Rows too long for registers (the 75 008-d flattened SDAV descriptors): one workgroup per row, three walks over it
+    // (mean, centred sum of squares, output), the second and third out of L2.  16-byte loads, four of them in flight per
+    // lane, packed 16-bit stores -- element-wise 8-byte loads and 2-byte stores ran 1063 x 75 008 doubles at 1.4 TB/s.
     __shared__ double red[8];
+    constexpr int VW = 16 / (int)sizeof(Src);            // elements per 16-byte vector: 4 floats / 2 doubles
+    typedef Src vec_t __attribute__((ext_vector_type(VW)));
     const long long row = blockIdx.x;
     const Src* x = src + row * lds;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool vec_ok = (((uintptr_t)x) & 15) == 0;       // rows on 16-byte boundaries (else: the scalar walk)
+    const int dv = vec_ok ? d / VW * VW : 0;              // elements covered by whole vectors
+    auto walk = [&](auto&& f) {                           // f(value, element index) over the row, a fixed order per thread
+        int e = tid * VW;
+        for (; e + 3 * 256 * VW < dv; e += 4 * 256 * VW) {
+            vec_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const vec_t*)(x + e + u * 256 * VW);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < VW; ++i) f((double)v[u][i], e + u * 256 * VW + i);
+        }
+        for (; e < dv; e += 256 * VW) {
+            const vec_t v = *(const vec_t*)(x + e);
+#pragma unroll
+            for (int i = 0; i < VW; ++i) f((double)v[i], e + i);
+        }
+        for (int t = dv + tid; t < d; t += 256) f((double)x[t], t);
+    };
     double mean = 0.0;
     if (center) {
         double s = 0.0;
-        for (int e = tid; e < d; e += 256) s += (double)x[e];
+        walk([&](double v, int) { s += v; });
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) red[w] = s;
         __syncthreads();
@@ -888,26 +913,23 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const Src* __restrict
         __syncthreads();
     }
     double ss = 0.0;
-    for (int e = tid; e < d; e += 256) {
-        const double v = (double)x[e] - mean;
-        ss += v * v;
-    }
+    walk([&](double v, int) { const double c = v - mean; ss += c * c; });
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     if (lane == 0) red[4 + w] = ss;
     __syncthreads();
     const double nrm = sqrt(red[4] + red[5] + red[6] + red[7]);
     const double inv = nrm > 0.0 ? 1.0 / nrm : 1.0;
-    for (int e = tid; e < (int)ldd; e += 256) {
-        unsigned short bits = 0;
-        if (e < d) {
-            const float v = (float)(((double)x[e] - mean) * inv);
-            if constexpr (__is_same(Tag, dlc_bf16_tag)) {
-                bits = __builtin_bit_cast(unsigned short, (__bf16)v);
-            } else {
-                bits = __builtin_bit_cast(unsigned short, (_Float16)v);
-            }
-        }
-        dst[row * ldd + e] = bits;
+    auto to16 = [&](double v) -> unsigned {
+        const float f = (float)((v - mean) * inv);
+        if constexpr (__is_same(Tag, dlc_bf16_tag)) return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f);
+        else return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)f);
+    };
+    unsigned short* o = dst + row * ldd;                  // ldd is a multiple of 64: rows of dst are 128-byte aligned
+    // pairs of outputs as one 32-bit store (ldd is even); elements past d are zero padding
+    for (int e = tid * 2; e < (int)ldd; e += 512) {
+        const unsigned lo = e < d ? to16((double)x[e]) : 0u;
+        const unsigned hi = e + 1 < d ? to16((double)x[e + 1]) : 0u;
+        *(unsigned*)(o + e) = lo | (hi << 16);
     }
 }
 
