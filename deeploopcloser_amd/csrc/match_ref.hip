@@ -304,12 +304,12 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
             // when the second is within 2^-50 (relative) of the first are the roots taken and compared as the reference does.
             double best = 0.0, second = INFINITY;
             int bi = 0;
-            auto scan = [&](int b) {
-                double d2 = na + nbj[b] - 2.0 * grow[b];
-                d2 = d2 > 0.0 ? d2 : 0.0;
-                if (b == 0) { best = d2; bi = 0; }
-                else if (d2 < best) { second = best; best = d2; bi = b; }
-                else if (d2 < second) second = d2;
+            auto scan = [&](int b) {                            // min / max instructions instead of compare-select chains
+                const double d2 = fmax(na + nbj[b] - 2.0 * grow[b], 0.0);
+                if (b == 0) { best = d2; bi = 0; return; }
+                second = fmin(second, fmax(best, d2));          // the smaller of the two that are not the new minimum
+                bi = d2 < best ? b : bi;                        // strict: the first minimum keeps its index
+                best = fmin(best, d2);
             };
             if (P == 30) {                                      // the reference's patch count: fully unrolled, all LDS reads up front
 #pragma unroll
