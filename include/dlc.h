@@ -178,10 +178,12 @@ int dlc_im2col_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, 
 /*
  * tf.layers.conv2d (NHWC fp64, HWIO kernel reshaped [kh*kw*c, cout]) + bias + activation as an
  * IMPLICIT GEMM: the A-tile loader of the fp64 MFMA GEMM gathers input pixels directly, the
- * im2col matrix is never written.  With c %% 8 == 0 (conv2..conv5 of cnn_vtl.py:49-93) a thread
- * fetches 8 channels of one pixel per 64-byte load; other channel counts (conv1: c = 3) are
- * gathered element by element.  out is [n, oh, ow, cout].  (dlc_im2col_nhwc_f64 +
- * dlc_gemm_bias_act give bit-identical sums.)
+ * im2col matrix is never written.  With c %% 16 == 0 (conv2..conv5 of cnn_vtl.py:49-93, conv1 over its
+ * space-to-depth input) and at least 16 output tiles of 256 x 128 the operands reach LDS by DMA -- 16 channels
+ * of one kernel tap per K tile, padding served as zeros by out-of-range buffer offsets; smaller launches and
+ * c %% 8 == 0 fetch 8 channels per 64-byte load into registers; other channel counts (c = 3) are gathered element
+ * by element.  Every form sums in the same k order: out is [n, oh, ow, cout], bit-identical between them and to
+ * dlc_im2col_nhwc_f64 + dlc_gemm_bias_act, whatever the batch a frame is part of.
  */
 int dlc_conv2d_nhwc_f64(dlc_ctx* ctx, const double* x, int64_t n, int h, int w, int c,
                         const double* kernel, const double* bias, int kh, int kw, int cout,
