@@ -480,8 +480,12 @@ def bench_paths(eng, n_frames):
                              "traffic": None, "kernel": "distance_matrix_kernel", "kernel_ms": call_ms, "call_ms": call_ms,
                              "algorithmic_bytes_per_call": bytes_alg,
                              "byte_pairs_per_s": N * N * dp / (call_ms * 1e-3),
+                             "valu_frac": (N * (N + 1) / 2.0) * ((dp + 3) // 4) * 8 / (call_ms * 1e-3) / 39.3e12,
                              "note": "N*D' bytes in, N*N*8 out: the kernel is VALU work (xor, |x|, popcount on N*N*D' byte "
-                                     "pairs), not HBM traffic; byte_pairs_per_s is its own rate"},
+                                     "pairs), not HBM traffic; byte_pairs_per_s is its own rate; valu_frac = 8 integer "
+                                     "instructions per 4-byte word pair of the upper triangle against 39.3 T lane-operations/s "
+                                     "(256 CUs x 64 lanes x 2.4 GHz): 0.3 at 1063 frames (153 tiles of 64 x 64 frames: a small "
+                                     "launch), 0.66 at 4000 frames (scripts/exp_distance.py)"},
                 "cpu_baseline": {"value": ns * ns / t_cpu, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
                                  "sample": "oracle/distance.py (NumPy table lookup per row) on %d x %d frames: %.2f s; one "
                                            "calculate_distance call per pair, the reference's loop shape: %.3f ms per pair"
