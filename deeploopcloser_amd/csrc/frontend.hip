@@ -66,51 +66,54 @@ __global__ __launch_bounds__(256) void harris_grad_kernel(const uint8_t* __restr
     }
     grad[frame * H * W + p] = out;
 }
-__global__ __launch_bounds__(256) void harris_response_kernel(const int* __restrict__ grad, int H, int W,
-                                                              long long* __restrict__ resp) {
-    const long long frame = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= H * W) return;
-    const int r = p / W, c = p - r * W;
-    long long out = 0;
-    if (r >= 3 && r < H - 3 && c >= 3 && c < W - 3) {
-        const int* g = grad + frame * H * W;
-        long long sxx = 0, syy = 0, sxy = 0;
+__device__ __forceinline__ long long harris_response_at(const int* __restrict__ g, int H, int W, int r, int c) {
+    if (r < 3 || r >= H - 3 || c < 3 || c >= W - 3) return 0;
+    int sxx32 = 0, syy32 = 0, sxy32 = 0;                  // 25 products of at most 1020^2: well inside 32 bits
 #pragma unroll
-        for (int dr = -2; dr <= 2; ++dr)
+    for (int dr = -2; dr <= 2; ++dr)
 #pragma unroll
-            for (int dc = -2; dc <= 2; ++dc) {
-                const int v = g[(long long)(r + dr) * W + c + dc];
-                const int ix = (int)(short)(v & 0xffff), iy = v >> 16;
-                sxx += ix * ix; syy += iy * iy; sxy += ix * iy;
-            }
-        out = 16 * (sxx * syy - sxy * sxy) - (sxx + syy) * (sxx + syy);
-    }
-    resp[frame * H * W + p] = out;
+        for (int dc = -2; dc <= 2; ++dc) {
+            const int v = g[(long long)(r + dr) * W + c + dc];
+            const int ix = (int)(short)(v & 0xffff), iy = v >> 16;
+            sxx32 += ix * ix; syy32 += iy * iy; sxy32 += ix * iy;
+        }
+    const long long sxx = sxx32, syy = syy32, sxy = sxy32;
+    return 16 * (sxx * syy - sxy * sxy) - (sxx + syy) * (sxx + syy);
 }
-__global__ __launch_bounds__(256) void harris_nms_kernel(const long long* __restrict__ resp, int H, int W,
-                                                         long long* __restrict__ cand) {
-    const long long frame = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= H * W) return;
-    const long long* R = resp + frame * H * W;
-    const long long v = R[p];
+// Response + 3 x 3 non-maximum suppression in one pass: a workgroup computes the responses of its 16 x 16 pixels and
+// their one-pixel halo into LDS and suppresses from there (as two kernels the responses made a round trip through
+// 392 MB of int64 per 1063 frames).  cand[p] = the response where it is a strict local maximum (ties: the lower
+// row-major index wins), else 0.
+__global__ __launch_bounds__(256) void harris_response_nms_kernel(const int* __restrict__ grad, int H, int W,
+                                                                  long long* __restrict__ cand) {
+    __shared__ long long tile[18][19];
+    const long long frame = blockIdx.z;
+    const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+    const int* g = grad + frame * H * W;
+    for (int e = threadIdx.x; e < 18 * 18; e += 256) {
+        const int tr = e / 18, tc = e - tr * 18;
+        const int r = r0 + tr - 1, c = c0 + tc - 1;
+        tile[tr][tc] = (r >= 0 && r < H && c >= 0 && c < W) ? harris_response_at(g, H, W, r, c) : 0;
+    }
+    __syncthreads();
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+    const int r = r0 + tr, c = c0 + tc;
+    if (r >= H || c >= W) return;
+    const long long v = tile[tr + 1][tc + 1];
     bool keep = v > 0;
     if (keep) {
-        const int r = p / W, c = p - r * W;       // v > 0 only inside the margin: all 8 neighbours exist
-        for (int dr = -1; dr <= 1 && keep; ++dr)
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
             for (int dc = -1; dc <= 1; ++dc) {
                 if (dr == 0 && dc == 0) continue;
-                const int q = (r + dr) * W + (c + dc);
-                const long long u = R[q];
-                if (u > v || (u == v && q < p)) { keep = false; break; }
+                const long long u = tile[tr + 1 + dr][tc + 1 + dc];
+                const bool before = dr < 0 || (dr == 0 && dc < 0);          // the neighbour's row-major index is lower
+                if (u > v || (u == v && before)) keep = false;
             }
     }
-    cand[frame * H * W + p] = keep ? v : 0;
+    cand[frame * H * W + (long long)r * W + c] = keep ? v : 0;
 }
-
-// The n strongest candidates of a frame, response descending, ties toward the lower linear
-// index: n rounds of a block-wide arg-max, the winner is cleared.  One workgroup per frame.
 __global__ __launch_bounds__(1024) void harris_select_kernel(long long* __restrict__ cand, int H, int W, int n,
                                                              int* __restrict__ pts, long long* __restrict__ resp_out,
                                                              int* __restrict__ count) {
@@ -217,11 +220,14 @@ extern "C" int dlc_harris_keypoints_u8(dlc_ctx* ctx, const uint8_t* gray, int64_
     long long* resp = (long long*)workspace;
     long long* cand = (long long*)((char*)workspace + need / 2);
     dim3 grid((unsigned)dlc::cdiv((int64_t)H * W, (int64_t)256), (unsigned)frames);
-    hipLaunchKernelGGL(harris_grad_kernel, grid, dim3(256), 0, st, gray, H, W, (int*)cand);      // cand is free until the NMS pass
-    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(256), 0, st, (const int*)cand, H, W, resp);
-    DLC_LAUNCH_CHECK(ctx, "harris_response_kernel");
-    hipLaunchKernelGGL(harris_nms_kernel, grid, dim3(256), 0, st, (const long long*)resp, H, W, cand);
-    DLC_LAUNCH_CHECK(ctx, "harris_nms_kernel");
+    {
+        // gradients into the first half of the workspace, candidates into the second
+        int* grad = (int*)resp;
+        hipLaunchKernelGGL(harris_grad_kernel, grid, dim3(256), 0, st, gray, H, W, grad);
+        dim3 tiles((unsigned)dlc::cdiv((int64_t)W, (int64_t)16), (unsigned)dlc::cdiv((int64_t)H, (int64_t)16), (unsigned)frames);
+        hipLaunchKernelGGL(harris_response_nms_kernel, tiles, dim3(256), 0, st, (const int*)grad, H, W, cand);
+        DLC_LAUNCH_CHECK(ctx, "harris_response_nms_kernel");
+    }
     hipLaunchKernelGGL(harris_select_kernel, dim3((unsigned)frames), dim3(1024), 0, st, cand, H, W, n, (int*)points,
                        (long long*)responses, (int*)counts);
     DLC_LAUNCH_CHECK(ctx, "harris_select_kernel");
