@@ -28,8 +28,8 @@ enum {
     DLC_ATTR_GEMM_BASE = 0,      // + tag (0 bf16, 1 f16) * 8 + mode (0..3) * 2 + maskq   -> bits 0..15
     DLC_ATTR_GEMV_BASE = 16,     // + tag * 3 + {QB 1,2,4 -> 0,1,2}                        -> bits 16..21
     DLC_ATTR_DGEMM_BASE = 24,    // + (fp32 ? 4 : 0) + {KN, NK, conv C%8, conv any -> 0..3}  -> bits 24..31
-    DLC_ATTR_DMA64_BASE = 32,    // gemm_dma_f64_kernel: + {KN, NK, conv} + (96-column form ? 3 : 0) -> bits 32..37
-    DLC_ATTR_PAIR_TILE = 40,     // pair_score_tile_kernel
+    DLC_ATTR_DMA64_BASE = 32,    // gemm_dma_f64_kernel: + {KN, NK, conv} + (96-column form ? 3 : 0) + (128-row tile ? 6 : 0) -> bits 32..43
+    DLC_ATTR_PAIR_TILE = 48,     // pair_score_tile_kernel
 };
 
 namespace dlc {

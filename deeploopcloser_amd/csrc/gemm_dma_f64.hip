@@ -10,7 +10,8 @@
 // 2048 loads.  Here a K tile of both operands is 6 DMA instructions per wave: no registers, no LDS stores.
 //
 // Tile 256 x 128 x 16, 512 threads = 8 waves (4 x 2), each wave 64 x 64 = 4 x 4 v_mfma_f64_16x16x4_f64 tiles.
-// One workgroup per CU (two waves per SIMD), LDS ring of 3 stages x 48 KiB:
+// (A 128 x 128 form of the same kernel -- MI = 2: each wave 32 x 64, stages of 32 KiB -- takes launches of at most half a
+// round of 256-row tiles.)  One workgroup per CU (two waves per SIMD), LDS ring of 3 stages x 48 KiB:
 //   A stage  256 rows x 128 B (16 doubles of K per row), 16-byte piece q of row r at slot q ^ ((r >> 1) & 7)
 //   B stage  [N,K] operand: 128 rows x 128 B, same swizzle;  [K,N] operand: 16 k-rows x 1 KiB, the tile's eight
 //            16-column groups in kn_unit() order, neighbouring 128-byte units swapped in odd k-rows
@@ -30,11 +31,8 @@ namespace dlc_gemm {
 namespace {
 
 constexpr int TM3 = 256, TN3 = 128, TK3 = 16, NT3 = 512;
-constexpr int A_STAGE = TM3 * TK3 * 8;          // 32 KiB
 constexpr int B_STAGE = TN3 * TK3 * 8;          // 16 KiB
-constexpr int STAGE = A_STAGE + B_STAGE;        // 48 KiB
 constexpr int NSTAGE = 3;
-constexpr int LDS3 = NSTAGE * STAGE;            // 144 KiB
 
 struct DmaArgs {
     const char* A; long long lda_b;             // plain: row stride in BYTES; conv: unused
@@ -217,6 +215,22 @@ __device__ __forceinline__ void dma_a4b(unsigned o0, unsigned o1, unsigned o2, u
         : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rsrc), "s"(lds_a)
         : "memory", "scc");
 }
+__device__ __forceinline__ void dma_a2b(unsigned o0, unsigned o1, rsrc_t rsrc, unsigned lds_a) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+        "s_add_u32 m0, %4, 0x400\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(o0), "v"(o1), "s"(rsrc), "s"(lds_a)
+        : "memory", "scc");
+}
 __device__ __forceinline__ void dma_b2s(unsigned o0, unsigned o1, const char* base, unsigned lds_b) {
     unsigned keep;
     asm volatile(
@@ -255,8 +269,13 @@ __device__ __forceinline__ int kn_group(int unit) {       // inverse: the column
 // consecutive channels of one kernel tap), B its HWIO kernel as [K,N].
 // NJ: MFMA column tiles per wave (4: the 128-column tile; 3: a 96-column tile for N <= 96 such as conv1's 96 filters,
 // which would waste a quarter of a 128-column tile's MFMAs).  The B stage keeps its 128-column geometry.
-template <int BLAYOUT, bool CONV, int NJ>
+// MI: MFMA row tiles per wave -- 4: the 256-row tile; 2: a 128-row tile (8 waves of 32 x 64) for launches of at most
+// half a round of 256-row tiles, which then spread over twice the CUs at half the work each.  Same k order, same bits.
+template <int BLAYOUT, bool CONV, int NJ, int MI>
 __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
+    constexpr int TM = 64 * MI;                   // rows per tile: four wave rows of MI MFMA tiles
+    constexpr int A_STAGE = TM * TK3 * 8;         // 32 / 16 KiB (shadows the namespace constants of the 256-row tile)
+    constexpr int STAGE = A_STAGE + B_STAGE;
     constexpr int TNJ = 2 * NJ * 16;              // columns per tile: two wave columns of NJ MFMA tiles
     extern __shared__ __attribute__((aligned(16))) char smem3[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         }
         if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
     }
-    const long long m0 = tile_m * TM3, n0 = tile_n * TNJ;
+    const long long m0 = tile_m * TM, n0 = tile_n * TNJ;
     if (p.tri_p > 0 && (p.tri_col0 + n0 + TNJ - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;
     const int nkt = (int)((p.K + TK3 - 1) / TK3);
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem3;
@@ -321,18 +340,18 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     const int slot = lane & 7;
     // Plain operands: a wave-uniform 64-bit base that steps from K tile to K tile (scalar adds) + per-lane 32-bit byte
     // offsets that never change; 64-bit per-lane addresses are formed for a K-tail tile only (at most the last one).
-    unsigned a_off[4];
-    int a_piece[4];                               // source piece (k offset 2 * piece doubles inside the K tile)
+    unsigned a_off[MI];
+    int a_piece[MI];                               // source piece (k offset 2 * piece doubles inside the K tile)
     // CONV: a row is an output pixel.  a_off = byte offset of its tap (0, 0), channel 2 * piece, from the image of the
     // tile's first row shifted up-left by the padding (so that it is never negative); the tap and the channel block
     // move the descriptor's base, the same for every row.  iy0 / ix0: the pixel's input position at tap (0, 0).
-    int cv_iy0[4], cv_ix0[4];
-    unsigned a_eff[4];                            // a_off, or DMA_OOB while the current tap is padding for this row
+    int cv_iy0[MI], cv_ix0[MI];
+    unsigned a_eff[MI];                            // a_off, or DMA_OOB while the current tap is padding for this row
     long long cv_img0 = 0;
     if constexpr (CONV) cv_img0 = m0 / ((long long)p.cv.OH * p.cv.OW);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (w * 4 + j) * 8 + (lane >> 3);
+    for (int j = 0; j < MI; ++j) {
+        const int r = (w * MI + j) * 8 + (lane >> 3);
         a_piece[j] = slot ^ ((r >> 1) & 7);
         long long gm = m0 + r;
         if (gm > p.M - 1) gm = p.M - 1;
@@ -391,13 +410,13 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 #else
         const int tt = t;
 #endif
-        const unsigned lds_a = lds_base + stage * STAGE + w * 4096;
+        const unsigned lds_a = lds_base + stage * STAGE + w * (MI * 1024);
         if constexpr (CONV) {
             // (Keeping the rows' validity as four SGPR lane masks and selecting the offsets with one v_cndmask per row and
             // tile removes the 8-12 register copies per tile this conditional update costs -- and measured 4 % slower.)
             if (cv_c0 == 0 && !p.cv_all_valid) {                         // a new tap: which rows does it send into the padding?
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < MI; ++j) {
                     const bool ok = (unsigned)(cv_iy0[j] + cv_ky) < (unsigned)p.cv.H && (unsigned)(cv_ix0[j] + cv_kx) < (unsigned)p.cv.W;
                     a_eff[j] = ok ? a_off[j] : DMA_OOB;
                 }
@@ -411,17 +430,20 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
                     if (++cv_kx == p.cv.KW) { cv_kx = 0; ++cv_ky; }
                 }
             }
-            dma_a4b(a_eff[0], a_eff[1], a_eff[2], a_eff[3], rs, lds_a);
+            if constexpr (MI == 4) dma_a4b(a_eff[0], a_eff[1], a_eff[2], a_eff[3], rs, lds_a);
+            else dma_a2b(a_eff[0], a_eff[1], rs, lds_a);
         } else {
             const char* base = uniform_ptr(a_base + (long long)tt * (TK3 * 8));
             if (a_tail && tt == nkt - 1) {
                 const int klim = (int)(p.K - (long long)tt * TK3);       // valid k of this tile
-                const char* sa[4];
+                const char* sa[MI];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sa[j] = a_piece[j] * 2 >= klim ? zsrc : base + a_off[j];
-                dma_a4(sa[0], sa[1], sa[2], sa[3], lds_a);
+                for (int j = 0; j < MI; ++j) sa[j] = a_piece[j] * 2 >= klim ? zsrc : base + a_off[j];
+                if constexpr (MI == 4) dma_a4(sa[0], sa[1], sa[2], sa[3], lds_a);
+                else dma_b2(sa[0], sa[1], lds_a);
             } else {
-                dma_a4s(a_off[0], a_off[1], a_off[2], a_off[3], base, lds_a);
+                if constexpr (MI == 4) dma_a4s(a_off[0], a_off[1], a_off[2], a_off[3], base, lds_a);
+                else dma_b2s(a_off[0], a_off[1], base, lds_a);
             }
         }
     };
@@ -461,7 +483,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const int pk = (((kk * 2 + (fk >> 1)) ^ x7) << 4) + (fk & 1) * 8;
-        fa_addr[kk] = ring + (wr * 64 + fr) * 128 + pk;
+        fa_addr[kk] = ring + (wr * (16 * MI) + fr) * 128 + pk;
         if constexpr (BLAYOUT == DLC_B_NK) fb_addr[kk] = ring + A_STAGE + (wc * NJ * 16 + fr) * 128 + pk;
         else fb_addr[kk] = ring + A_STAGE + fk * 1024 + ((kn_unit(wc, kk & 1) ^ (fk & 1)) << 7) + fr * 8;       // kk = j: 0, 1
     }
@@ -478,21 +500,21 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         }
     };
 
-    f64x4_t acc[4][NJ];
+    f64x4_t acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f64x4_t){0, 0, 0, 0};
 
     // fragments of one k-slice, double-buffered in registers: rd() reads slice kk of a stage into buffer b, mm() runs
     // the 16 MFMAs of a buffer.  A slice's reads are always issued before the MFMAs of the slice in front of it.
-    double fa[2][4], fb[2][NJ];
+    double fa[2][MI], fb[2][NJ];
     auto rd = [&](int kk, int b) {
 #ifdef DLC_EXP_DMA_NO_LDS_READ     // timing experiments only (wrong results): MFMAs on whatever the registers hold
         if (kk >= 0) { asm volatile("" : "+v"(fa[b][0]), "+v"(fb[b][0])); return; }
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[b][i] = *(const __attribute__((address_space(3))) double*)(fa_addr[kk] + i * 2048);
+        for (int i = 0; i < MI; ++i) fa[b][i] = *(const __attribute__((address_space(3))) double*)(fa_addr[kk] + i * 2048);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if constexpr (BLAYOUT == DLC_B_NK) fb[b][j] = *(const __attribute__((address_space(3))) double*)(fb_addr[kk] + j * 2048);
@@ -501,7 +523,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     };
     auto mm = [&](int b) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[b][i], fb[b][j], acc[i][j], 0, 0, 0);
     };
@@ -612,7 +634,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     const bool fold = CONV && p.cv.mm_keys != nullptr;
     if (fold) {
         const long long per_img = (long long)p.cv.OH * p.cv.OW;
-        mm_img0 = (m0 + wr * 64) / per_img;
+        mm_img0 = (m0 + wr * (16 * MI)) / per_img;
         mm_bnd = (mm_img0 + 1) * per_img;                                // first row of the next image
     }
 #pragma unroll
@@ -621,10 +643,10 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         if (gn >= p.N) continue;
         const double bv = p.bias ? p.bias[gn] : 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long gm = m0 + wr * 64 + i * 16 + fk + 4 * r;
+                const long long gm = m0 + wr * (16 * MI) + i * 16 + fk + 4 * r;
                 if (gm < p.M) {
                     const double v = act_f64(acc[i][j][r] + bv, p.act);
                     p.C[gm * p.ldc + gn] = v;
@@ -661,16 +683,18 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 // DMA data at all) are real, but a lone compiler-scheduled wave with 256 accumulator registers spills inside the loop
 // and does not keep the matrix pipe fed; two waves covering each other do better.)
 
-template <int BLAYOUT, bool CONV, int NJ>
+template <int BLAYOUT, bool CONV, int NJ, int MI>
 int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
-    auto kern = gemm_dma_f64_kernel<BLAYOUT, CONV, NJ>;
+    auto kern = gemm_dma_f64_kernel<BLAYOUT, CONV, NJ, MI>;
     constexpr int threads = NT3;
-    const unsigned long long m = 1ull << (DLC_ATTR_DMA64_BASE + (CONV ? 2 : (BLAYOUT == DLC_B_KN ? 0 : 1)) + (NJ == 3 ? 3 : 0));
+    constexpr int lds = NSTAGE * (64 * MI * TK3 * 8 + B_STAGE);          // 144 / 96 KiB
+    const unsigned long long m = 1ull << (DLC_ATTR_DMA64_BASE + (CONV ? 2 : (BLAYOUT == DLC_B_KN ? 0 : 1)) + (NJ == 3 ? 3 : 0) +
+                                          (MI == 2 ? 6 : 0));
     if (!(ctx->func_attr_set & m)) {
-        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3));
+        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ctx->func_attr_set |= m;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), LDS3, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(threads), lds, st, a);
     return DLC_OK;
 }
 
@@ -699,14 +723,21 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     // N <= 96 (conv1's 96 filters): 96-column tiles, so that no quarter of the MFMAs works on padding
     const bool narrow = N <= 96;
     const int tn = narrow ? 96 : TN3;
-    const int64_t tiles_m = dlc::cdiv(M, TM3), tiles_n = dlc::cdiv(N, (int64_t)tn);
+    // 256-row tiles, unless they would fill at most half a round of the chip (a batch of a few frames): 128-row tiles
+    // then put twice the workgroups on twice the CUs at half the work each -- SDAV.transform of 8-32 frames 2.9 -> 1.6 ms;
+    // the k order and so every bit are the same.  (Triangular launches and the 96-column form keep the large tile.)
+    int tm = TM3;
+#ifndef DLC_EXP_NO_HALF_TILE
+    if (!tri && !narrow && dlc::cdiv(M, (int64_t)TM3) * dlc::cdiv(N, (int64_t)tn) <= 128) tm = TM3 / 2;
+#endif
+    const int64_t tiles_m = dlc::cdiv(M, (int64_t)tm), tiles_n = dlc::cdiv(N, (int64_t)tn);
     // From 16 tiles on, and with more than 3/4 of a tile's rows real (scripts/exp_dma_threshold.py: below that the
     // register-staged 128 x 128 kernel's twice as many workgroups win; above it this kernel wins at every size once the
     // tiles of edge blocks are dealt evenly to the shader engines -- it used to be taken from 512 tiles on only)
 #ifndef DLC_DMA_MIN_TILES
 #define DLC_DMA_MIN_TILES 16
 #endif
-    if (tiles_m * tiles_n < DLC_DMA_MIN_TILES || M < TM3 * 3 / 4 || K < 4 * TK3) return 1;
+    if (dlc::cdiv(M, (int64_t)TM3) * tiles_n < DLC_DMA_MIN_TILES || M < tm * 3 / 4 || K < 4 * TK3) return 1;
     DmaArgs a;
     a.A = (const char*)A; a.lda_b = lda * 8; a.B = (const char*)B; a.ldb_b = ldb * 8;
     a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.Kb = Kb; a.act = act;
@@ -772,7 +803,7 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     a.nblocks = a.nbr * a.tri_nbc;
     a.tri_blk_cols = bc * tn; a.tri_rem0 = 0; a.tri_step = 0; a.tri_lg_rows = 0;
     if (a.tri_p > 0) {
-        while ((1 << a.tri_lg_rows) < br * TM3) ++a.tri_lg_rows;         // br is a power of two, and so is the tile height
+        while ((1 << a.tri_lg_rows) < br * tm) ++a.tri_lg_rows;         // br is a power of two, and so is the tile height
         a.tri_step = a.tri_blk_cols % a.tri_p;
         TriWalk tw{a.tri_col0 + a.tri_blk_cols - 1, (int)((a.tri_col0 + a.tri_blk_cols - 1) % a.tri_p)};
         a.tri_rem0 = tw.rem;
@@ -785,9 +816,15 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
     int rc;
-    if (cv) rc = narrow ? launch_one<DLC_B_KN, true, 3>(ctx, a, nwg, st) : launch_one<DLC_B_KN, true, 4>(ctx, a, nwg, st);
-    else if (blayout == DLC_B_KN) rc = narrow ? launch_one<DLC_B_KN, false, 3>(ctx, a, nwg, st) : launch_one<DLC_B_KN, false, 4>(ctx, a, nwg, st);
-    else rc = narrow ? launch_one<DLC_B_NK, false, 3>(ctx, a, nwg, st) : launch_one<DLC_B_NK, false, 4>(ctx, a, nwg, st);
+    if (tm == TM3) {
+        if (cv) rc = narrow ? launch_one<DLC_B_KN, true, 3, 4>(ctx, a, nwg, st) : launch_one<DLC_B_KN, true, 4, 4>(ctx, a, nwg, st);
+        else if (blayout == DLC_B_KN) rc = narrow ? launch_one<DLC_B_KN, false, 3, 4>(ctx, a, nwg, st) : launch_one<DLC_B_KN, false, 4, 4>(ctx, a, nwg, st);
+        else rc = narrow ? launch_one<DLC_B_NK, false, 3, 4>(ctx, a, nwg, st) : launch_one<DLC_B_NK, false, 4, 4>(ctx, a, nwg, st);
+    } else {
+        if (cv) rc = launch_one<DLC_B_KN, true, 4, 2>(ctx, a, nwg, st);
+        else if (blayout == DLC_B_KN) rc = launch_one<DLC_B_KN, false, 4, 2>(ctx, a, nwg, st);
+        else rc = launch_one<DLC_B_NK, false, 4, 2>(ctx, a, nwg, st);
+    }
     if (rc != DLC_OK) return rc;
     DLC_LAUNCH_CHECK(ctx, "gemm_dma_f64_kernel");
     if (ctx->profiling) {
