@@ -43,6 +43,7 @@ struct DmaArgs {
     long long Kb;                               // ... and as B has it (<= K): B's k-rows Kb .. K-1 do not exist and read as zeros
     int act;
     ConvGeom cv;
+    long long m_base;                           // CONV: output pixel index of row 0 (a launch over the tail rows of a convolution)
     int cv_all_valid;                           // no tap of any output pixel falls outside the input (VALID, no padding)
     const char* zero;                           // >= 128 bytes of zeros
     long long tiles_m, tiles_n, nbr, nblocks;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     int cv_iy0[MI], cv_ix0[MI];
     unsigned a_eff[MI];                            // a_off, or DMA_OOB while the current tap is padding for this row
     long long cv_img0 = 0;
-    if constexpr (CONV) cv_img0 = m0 / ((long long)p.cv.OH * p.cv.OW);
+    if constexpr (CONV) cv_img0 = (p.m_base + m0) / ((long long)p.cv.OH * p.cv.OW);
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
         const int r = (w * MI + j) * 8 + (lane >> 3);
@@ -356,8 +357,9 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         long long gm = m0 + r;
         if (gm > p.M - 1) gm = p.M - 1;
         if constexpr (CONV) {
-            const long long img = gm / ((long long)p.cv.OH * p.cv.OW);
-            const int rem = (int)(gm - img * p.cv.OH * p.cv.OW);
+            const long long px = p.m_base + gm;                          // output pixel index over all images
+            const long long img = px / ((long long)p.cv.OH * p.cv.OW);
+            const int rem = (int)(px - img * p.cv.OH * p.cv.OW);
             const int oy = rem / p.cv.OW, ox = rem - oy * p.cv.OW;
             cv_iy0[j] = oy * p.cv.stride - p.cv.pad_t;
             cv_ix0[j] = ox * p.cv.stride - p.cv.pad_l;
@@ -634,8 +636,8 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     const bool fold = CONV && p.cv.mm_keys != nullptr;
     if (fold) {
         const long long per_img = (long long)p.cv.OH * p.cv.OW;
-        mm_img0 = (m0 + wr * (16 * MI)) / per_img;
-        mm_bnd = (mm_img0 + 1) * per_img;                                // first row of the next image
+        mm_img0 = (p.m_base + m0 + wr * (16 * MI)) / per_img;
+        mm_bnd = (mm_img0 + 1) * per_img - p.m_base;                     // first row of the next image
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -700,9 +702,11 @@ int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
 
 }  // namespace
 
-int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
-                   const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
-                   const ConvGeom* cv, const TriSkip* tri, int64_t Kb) {
+// One launch.  m_base: CONV, the output pixel index of row 0 (A stays the whole input, C points at row 0's outputs);
+// force_tm: 0 = choose the tile height, else 128 / 256; dry: only say whether the launch would be taken (DLC_OK / 1).
+static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                           const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
+                           const ConvGeom* cv, const TriSkip* tri, int64_t Kb, int64_t m_base, int force_tm, bool dry) {
     if (Kb <= 0 || Kb > K) Kb = K;
 #ifdef DLC_EXP_NO_DMA_GEMM      // experiment build: always the register-staged kernel
     return 1;
@@ -730,6 +734,7 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
 #ifndef DLC_EXP_NO_HALF_TILE
     if (!tri && !narrow && dlc::cdiv(M, (int64_t)TM3) * dlc::cdiv(N, (int64_t)tn) <= 128) tm = TM3 / 2;
 #endif
+    if (force_tm && !(force_tm == TM3 / 2 && (tri || narrow))) tm = force_tm;
     const int64_t tiles_m = dlc::cdiv(M, (int64_t)tm), tiles_n = dlc::cdiv(N, (int64_t)tn);
     // From 16 tiles on, and with more than 3/4 of a tile's rows real (scripts/exp_dma_threshold.py: below that the
     // register-staged 128 x 128 kernel's twice as many workgroups win; above it this kernel wins at every size once the
@@ -738,10 +743,12 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
 #define DLC_DMA_MIN_TILES 16
 #endif
     if (dlc::cdiv(M, (int64_t)TM3) * tiles_n < DLC_DMA_MIN_TILES || M < tm * 3 / 4 || K < 4 * TK3) return 1;
+    if (dry) return DLC_OK;
     DmaArgs a;
     a.A = (const char*)A; a.lda_b = lda * 8; a.B = (const char*)B; a.ldb_b = ldb * 8;
     a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.Kb = Kb; a.act = act;
     a.cv = cv ? *cv : ConvGeom{};
+    a.m_base = m_base;
     a.cv_all_valid = 0;
     if (cv && cv->mm_keys && (int64_t)cv->OH * cv->OW < 64) return 1;     // the epilogue folds at most two images per wave
     if (cv) {
@@ -832,6 +839,37 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
         ctx->prof_calls++;
     }
     return DLC_OK;
+}
+
+// The public entry: one launch, or two when the rows past the last FULL round of 256-row tiles fill at most half a
+// round -- those rows then go in a second launch of 128-row tiles (half a tile time instead of a whole one on a
+// third of the chip: conv3-5 of 1063 frames run 6.3 / 6.3 / 4.2 rounds).  Rows are independent: same bits.
+int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
+                   const ConvGeom* cv, const TriSkip* tri, int64_t Kb) {
+#ifndef DLC_EXP_NO_TAIL_SPLIT
+    if (!tri && N > 96) {
+        const int64_t tn_ = dlc::cdiv(N, (int64_t)TN3), tm_ = dlc::cdiv(M, (int64_t)TM3), total = tm_ * tn_;
+        if (total > 256 && total % 256 != 0) {
+            const int64_t rm = (total / 256) * 256 / tn_;                 // row tiles of the main launch
+            const int64_t m1 = rm * TM3, m2 = M - m1;
+            if (rm > 0 && m2 > 0) {
+                const int64_t t2 = dlc::cdiv(m2, (int64_t)(TM3 / 2)) * tn_;
+                const double whole = (double)dlc::cdiv(total, (int64_t)256);
+                const double split = (double)dlc::cdiv(rm * tn_, (int64_t)256) + 0.52 * (double)dlc::cdiv(t2, (int64_t)256) + 0.05;
+                const double* a2 = cv ? A : A + m1 * lda;
+                if (split < whole - 0.15 &&
+                    launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, true) == DLC_OK &&
+                    launch_dma_part(ctx, blayout, act, m2, N, K, a2, lda, B, ldb, bias, C + m1 * ldc, ldc, st, cv, tri, Kb, cv ? m1 : 0, TM3 / 2, true) == DLC_OK) {
+                    const int rc = launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, false);
+                    if (rc != DLC_OK) return rc;
+                    return launch_dma_part(ctx, blayout, act, m2, N, K, a2, lda, B, ldb, bias, C + m1 * ldc, ldc, st, cv, tri, Kb, cv ? m1 : 0, TM3 / 2, false);
+                }
+            }
+        }
+    }
+#endif
+    return launch_dma_part(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, 0, false);
 }
 
 #ifdef DLC_EXP_DMA_PLACEMENT
