@@ -53,7 +53,8 @@ def conv_case():
     else:
         oh, ow = (h - kh) // stride + 1, (w - kh) // stride + 1
         pt = pl = 0
-    n = int(rng.randint(1, max(2, 200000 // (oh * ow * 16))))
+    cap = 3000000 if rng.rand() < 0.15 else 200000                 # now and then large enough for several rounds of tiles (row-split launches)
+    n = min(60000, int(rng.randint(1, max(2, cap // (oh * ow * 16)))))
     x, wk, b = rnd(n, h, w, c), rnd(kh * kh * c, cout) / (kh * c ** 0.5), rnd(cout)
     act = int(rng.choice([0, 2]))
     keys = eng.frame_minmax_keys(n)
