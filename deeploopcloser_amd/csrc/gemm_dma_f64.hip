@@ -703,7 +703,7 @@ int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
 }  // namespace
 
 // One launch.  m_base: CONV, the output pixel index of row 0 (A stays the whole input, C points at row 0's outputs);
-// force_tm: 0 = choose the tile height, else 128 / 256; dry: only say whether the launch would be taken (DLC_OK / 1).
+// force_tm: 128 / 256 rows per tile; dry: only say whether the launch would be taken (DLC_OK / 1).
 static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                            const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
                            const ConvGeom* cv, const TriSkip* tri, int64_t Kb, int64_t m_base, int force_tm, bool dry) {
@@ -727,14 +727,11 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
     // N <= 96 (conv1's 96 filters): 96-column tiles, so that no quarter of the MFMAs works on padding
     const bool narrow = N <= 96;
     const int tn = narrow ? 96 : TN3;
-    // 256-row tiles, unless they would fill at most half a round of the chip (a batch of a few frames): 128-row tiles
-    // then put twice the workgroups on twice the CUs at half the work each -- SDAV.transform of 8-32 frames 2.9 -> 1.6 ms;
-    // the k order and so every bit are the same.  (Triangular launches and the 96-column form keep the large tile.)
-    int tm = TM3;
-#ifndef DLC_EXP_NO_HALF_TILE
-    if (!tri && !narrow && dlc::cdiv(M, (int64_t)TM3) * dlc::cdiv(N, (int64_t)tn) <= 128) tm = TM3 / 2;
+    // tile height: the caller's choice (launch_dma_f64); triangular launches and the 96-column form keep the large tile
+    int tm = (force_tm == TM3 / 2 && !tri && !narrow) ? TM3 / 2 : TM3;
+#ifdef DLC_EXP_FORCE_HALF_TILE   // timing experiment: what a 128-row tile costs when it fills the chip
+    if (!tri && !narrow) tm = TM3 / 2;
 #endif
-    if (force_tm && !(force_tm == TM3 / 2 && (tri || narrow))) tm = force_tm;
     const int64_t tiles_m = dlc::cdiv(M, (int64_t)tm), tiles_n = dlc::cdiv(N, (int64_t)tn);
     // From 16 tiles on, and with more than 3/4 of a tile's rows real (scripts/exp_dma_threshold.py: below that the
     // register-staged 128 x 128 kernel's twice as many workgroups win; above it this kernel wins at every size once the
@@ -841,24 +838,32 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
     return DLC_OK;
 }
 
-// The public entry: one launch, or two when the rows past the last FULL round of 256-row tiles fill at most half a
-// round -- those rows then go in a second launch of 128-row tiles (half a tile time instead of a whole one on a
-// third of the chip: conv3-5 of 1063 frames run 6.3 / 6.3 / 4.2 rounds).  Rows are independent: same bits.
+// The public entry chooses between three forms by the rounds of the chip's 256 CUs each would take (a 128-row tile
+// costs 0.51 of a 256-row tile at full occupancy -- SDAV.transform on 128-row tiles only: 28.3 against 27.8 ms):
+//   one launch of 256-row tiles;  one launch of 128-row tiles (few tiles: twice the CUs busy; or a tile count that
+//   rounds up badly: 300 tiles are 2 rounds, 600 half tiles 3 half rounds);  or 256-row tiles for the whole rounds and
+//   a second launch of 128-row tiles for the rows behind them (conv3-5 of 1063 frames: 6.3 / 6.3 / 4.2 rounds).
+// Rows are independent and every form sums k in the same order: the same bits whichever is taken.
 int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                    const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
                    const ConvGeom* cv, const TriSkip* tri, int64_t Kb) {
-#ifndef DLC_EXP_NO_TAIL_SPLIT
+    int tm = TM3;
+#if !defined(DLC_EXP_NO_HALF_TILE)
     if (!tri && N > 96) {
-        const int64_t tn_ = dlc::cdiv(N, (int64_t)TN3), tm_ = dlc::cdiv(M, (int64_t)TM3), total = tm_ * tn_;
-        if (total > 256 && total % 256 != 0) {
-            const int64_t rm = (total / 256) * 256 / tn_;                 // row tiles of the main launch
+        constexpr double HALF = 0.51;
+        const int64_t tn_ = dlc::cdiv(N, (int64_t)TN3), t4 = dlc::cdiv(M, (int64_t)TM3) * tn_;
+        const int64_t t2 = dlc::cdiv(M, (int64_t)(TM3 / 2)) * tn_;
+        const double whole4 = (double)dlc::cdiv(t4, (int64_t)256);
+        const double whole2 = HALF * (double)dlc::cdiv(t2, (int64_t)256) + 0.01;
+#if !defined(DLC_EXP_NO_TAIL_SPLIT)
+        if (t4 > 256 && t4 % 256 != 0) {
+            const int64_t rm = (t4 / 256) * 256 / tn_;                    // row tiles of the main launch
             const int64_t m1 = rm * TM3, m2 = M - m1;
             if (rm > 0 && m2 > 0) {
-                const int64_t t2 = dlc::cdiv(m2, (int64_t)(TM3 / 2)) * tn_;
-                const double whole = (double)dlc::cdiv(total, (int64_t)256);
-                const double split = (double)dlc::cdiv(rm * tn_, (int64_t)256) + 0.52 * (double)dlc::cdiv(t2, (int64_t)256) + 0.05;
+                const int64_t tt = dlc::cdiv(m2, (int64_t)(TM3 / 2)) * tn_;
+                const double split = (double)dlc::cdiv(rm * tn_, (int64_t)256) + HALF * (double)dlc::cdiv(tt, (int64_t)256) + 0.05;
                 const double* a2 = cv ? A : A + m1 * lda;
-                if (split < whole - 0.15 &&
+                if (split < whole4 - 0.15 && split < whole2 - 0.03 &&
                     launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, true) == DLC_OK &&
                     launch_dma_part(ctx, blayout, act, m2, N, K, a2, lda, B, ldb, bias, C + m1 * ldc, ldc, st, cv, tri, Kb, cv ? m1 : 0, TM3 / 2, true) == DLC_OK) {
                     const int rc = launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, false);
@@ -867,9 +872,11 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
                 }
             }
         }
+#endif
+        if (whole2 < whole4 - 0.1) tm = TM3 / 2;
     }
 #endif
-    return launch_dma_part(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, 0, false);
+    return launch_dma_part(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, tm, false);
 }
 
 #ifdef DLC_EXP_DMA_PLACEMENT
