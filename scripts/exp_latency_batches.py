@@ -4,6 +4,10 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import deeploopcloser_amd as dlc
+if len(sys.argv) > 1:                      # another build of the library
+    from deeploopcloser_amd import _lib as L
+    L._lib = None
+    L.LIB_PATH = os.path.abspath(sys.argv[1])
 eng = dlc.default_engine()
 g = torch.Generator(device=eng.device); g.manual_seed(0)
 
