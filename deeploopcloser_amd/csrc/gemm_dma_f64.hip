@@ -3,7 +3,7 @@
 // GEMMs (cnn_vtl.py:47-93) and the Gram blocks of the SDAV similarity (SimilarityCalculator.py:30-37).
 //
 // Why a second kernel.  The register-staged kernel of gemm_dense.hip keeps the fp64 matrix pipe 72-80 % busy
-// (profiles/r02_gemm_f64_pmc.json); timing builds without its operand staging run the same MFMAs + LDS reads
+// (profiles/r02a_gemm_f64_pmc.json); timing builds without its operand staging run the same MFMAs + LDS reads
 // 13 % faster, without its barrier another 6 %.  What costs is not LDS or HBM bandwidth but (a)
 // 16 global loads, 16 LDS stores and their address arithmetic per thread and K tile in the waves' instruction
 // streams, and (b) one K tile of prefetch distance, so that every workgroup's barrier waits for the slowest of its
@@ -18,8 +18,10 @@
 // so that each half-wave of a ds_read_b64 fragment read (16 rows x one 16-byte slot: even rows sit in banks 0-31,
 // odd rows in 32-63, and 8 rows of one parity take 8 different slots) touches every bank once.  (Keyed on r & 7
 // instead, rows r and r + 8 shared their banks: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE.)  The swizzle is applied to the DMA's per-lane SOURCE address; the LDS destination stays lane-linear.
-// Rows past M / columns past N are clamped to the last valid one (their results are never stored); K tails and
-// convolution padding read a page of zeros instead.
+// Rows past M / columns past N are clamped to the last valid one (their results are never stored); a K tail reads a
+// page of zeros instead, convolution padding is served as zeros by out-of-range buffer offsets (dma_a4b).
+// Addresses cost the vector unit nothing per K tile: DMA sources are a scalar base + fixed 32-bit lane offsets, LDS
+// read pointers step once per tile -- every vector / LDS instruction beside an fp64 MFMA costs the SIMD ~7 cycles.
 //
 // One barrier per K tile t: before it every wave waits for its own DMA pieces of tile t, behind it tile t is
 // readable and tile t+1's DMA is issued into the stage of tile t-2.  Waves 0-3 then run k-slices 0-3 of tile t;
