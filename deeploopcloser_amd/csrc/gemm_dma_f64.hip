@@ -743,7 +743,9 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
 #endif
     // (a single frame's 30 rows on the 128-row tile: SDAV.transform 2.0 -> 1.5 ms -- the register-staged kernel's
     // K loop is the slower one even at a quarter of the tile's rows; the 256-row tile wants 3/4 of its rows real)
-    if (dlc::cdiv(M, (int64_t)TM3) * tiles_n < DLC_DMA_MIN_TILES || (tm == TM3 && M < TM3 * 3 / 4) || K < 4 * TK3) return 1;
+    // (the 128-row form has as many workgroups as the register-staged kernel and the faster K loop: it is taken at any
+    // tile count -- CnnVtl.transform of 1 / 8 frames 2.0 / 2.6 -> 1.5 ms)
+    if ((tm == TM3 && (tiles_m * tiles_n < DLC_DMA_MIN_TILES || M < TM3 * 3 / 4)) || K < 4 * TK3) return 1;
     if (dry) return DLC_OK;
     DmaArgs a;
     a.A = (const char*)A; a.lda_b = lda * 8; a.B = (const char*)B; a.ldb_b = ldb * 8;
