@@ -218,6 +218,22 @@ __device__ __forceinline__ void dma_a4b(unsigned o0, unsigned o1, unsigned o2, u
         : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rsrc), "s"(lds_a)
         : "memory", "scc");
 }
+// ... and of one (the 64-row tile's A part: 8 rows per wave)
+__device__ __forceinline__ void dma_1(const char* a0, unsigned lds_a) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(a0), "s"(lds_a) : "memory", "scc");
+}
+__device__ __forceinline__ void dma_1s(unsigned o0, const char* base, unsigned lds_a) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o0), "s"(base), "s"(lds_a) : "memory", "scc");
+}
+__device__ __forceinline__ void dma_1b(unsigned o0, rsrc_t rsrc, unsigned lds_a) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(o0), "s"(rsrc), "s"(lds_a) : "memory", "scc");
+}
 __device__ __forceinline__ void dma_a2b(unsigned o0, unsigned o1, rsrc_t rsrc, unsigned lds_a) {
     unsigned keep;
     asm volatile(
@@ -435,7 +451,8 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
                 }
             }
             if constexpr (MI == 4) dma_a4b(a_eff[0], a_eff[1], a_eff[2], a_eff[3], rs, lds_a);
-            else dma_a2b(a_eff[0], a_eff[1], rs, lds_a);
+            else if constexpr (MI == 2) dma_a2b(a_eff[0], a_eff[1], rs, lds_a);
+            else dma_1b(a_eff[0], rs, lds_a);
         } else {
             const char* base = uniform_ptr(a_base + (long long)tt * (TK3 * 8));
             if (a_tail && tt == nkt - 1) {
@@ -444,10 +461,12 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 #pragma unroll
                 for (int j = 0; j < MI; ++j) sa[j] = a_piece[j] * 2 >= klim ? zsrc : base + a_off[j];
                 if constexpr (MI == 4) dma_a4(sa[0], sa[1], sa[2], sa[3], lds_a);
-                else dma_b2(sa[0], sa[1], lds_a);
+                else if constexpr (MI == 2) dma_b2(sa[0], sa[1], lds_a);
+                else dma_1(sa[0], lds_a);
             } else {
                 if constexpr (MI == 4) dma_a4s(a_off[0], a_off[1], a_off[2], a_off[3], base, lds_a);
-                else dma_b2s(a_off[0], a_off[1], base, lds_a);
+                else if constexpr (MI == 2) dma_b2s(a_off[0], a_off[1], base, lds_a);
+                else dma_1s(a_off[0], base, lds_a);
             }
         }
     };
@@ -693,7 +712,7 @@ int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
     constexpr int threads = NT3;
     constexpr int lds = NSTAGE * (64 * MI * TK3 * 8 + B_STAGE);          // 144 / 96 KiB
     const unsigned long long m = 1ull << (DLC_ATTR_DMA64_BASE + (CONV ? 2 : (BLAYOUT == DLC_B_KN ? 0 : 1)) + (NJ == 3 ? 3 : 0) +
-                                          (MI == 2 ? 6 : 0));
+                                          (MI == 2 ? 6 : (MI == 1 ? 12 : 0)));
     if (!(ctx->func_attr_set & m)) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ctx->func_attr_set |= m;
@@ -730,9 +749,9 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
     const bool narrow = N <= 96;
     const int tn = narrow ? 96 : TN3;
     // tile height: the caller's choice (launch_dma_f64); triangular launches and the 96-column form keep the large tile
-    int tm = (force_tm == TM3 / 2 && !tri && !narrow) ? TM3 / 2 : TM3;
-#ifdef DLC_EXP_FORCE_HALF_TILE   // timing experiment: what a 128-row tile costs when it fills the chip
-    if (!tri && !narrow) tm = TM3 / 2;
+    int tm = (((force_tm == TM3 / 2 && !tri) || force_tm == TM3 / 4) && !narrow) ? force_tm : TM3;
+#ifdef DLC_EXP_FORCE_HALF_TILE   // timing experiment: what a 128-row (or, = 4, a 64-row) tile costs when it fills the chip
+    if ((!tri || DLC_EXP_FORCE_HALF_TILE == 4) && !narrow) tm = TM3 / DLC_EXP_FORCE_HALF_TILE;
 #endif
     const int64_t tiles_m = dlc::cdiv(M, (int64_t)tm), tiles_n = dlc::cdiv(N, (int64_t)tn);
     // From 16 tiles on, and with more than 3/4 of a tile's rows real (scripts/exp_dma_threshold.py: below that the
@@ -830,10 +849,14 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
         if (cv) rc = narrow ? launch_one<DLC_B_KN, true, 3, 4>(ctx, a, nwg, st) : launch_one<DLC_B_KN, true, 4, 4>(ctx, a, nwg, st);
         else if (blayout == DLC_B_KN) rc = narrow ? launch_one<DLC_B_KN, false, 3, 4>(ctx, a, nwg, st) : launch_one<DLC_B_KN, false, 4, 4>(ctx, a, nwg, st);
         else rc = narrow ? launch_one<DLC_B_NK, false, 3, 4>(ctx, a, nwg, st) : launch_one<DLC_B_NK, false, 4, 4>(ctx, a, nwg, st);
-    } else {
+    } else if (tm == TM3 / 2) {
         if (cv) rc = launch_one<DLC_B_KN, true, 4, 2>(ctx, a, nwg, st);
         else if (blayout == DLC_B_KN) rc = launch_one<DLC_B_KN, false, 4, 2>(ctx, a, nwg, st);
         else rc = launch_one<DLC_B_NK, false, 4, 2>(ctx, a, nwg, st);
+    } else {
+        if (cv) rc = launch_one<DLC_B_KN, true, 4, 1>(ctx, a, nwg, st);
+        else if (blayout == DLC_B_KN) rc = launch_one<DLC_B_KN, false, 4, 1>(ctx, a, nwg, st);
+        else rc = launch_one<DLC_B_NK, false, 4, 1>(ctx, a, nwg, st);
     }
     if (rc != DLC_OK) return rc;
     DLC_LAUNCH_CHECK(ctx, "gemm_dma_f64_kernel");
@@ -861,6 +884,11 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
         const int64_t t2 = dlc::cdiv(M, (int64_t)(TM3 / 2)) * tn_;
         const double whole4 = (double)dlc::cdiv(t4, (int64_t)256);
         const double whole2 = HALF * (double)dlc::cdiv(t2, (int64_t)256) + 0.01;
+#ifndef DLC_EXP_NO_QUARTER_TILE
+        const double quarter = (cv ? 0.27 : 0.248) * (double)dlc::cdiv(dlc::cdiv(M, (int64_t)(TM3 / 4)) * tn_, (int64_t)256) + 0.02;
+#else
+        const double quarter = 1e30;
+#endif
 #if !defined(DLC_EXP_NO_TAIL_SPLIT)
         if (t4 > 256 && t4 % 256 != 0) {
             const int64_t rm = (t4 / 256) * 256 / tn_;                    // row tiles of the main launch
@@ -869,7 +897,7 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
                 const int64_t tt = dlc::cdiv(m2, (int64_t)(TM3 / 2)) * tn_;
                 const double split = (double)dlc::cdiv(rm * tn_, (int64_t)256) + HALF * (double)dlc::cdiv(tt, (int64_t)256) + 0.05;
                 const double* a2 = cv ? A : A + m1 * lda;
-                if (split < whole4 - 0.15 && split < whole2 - 0.03 &&
+                if (split < whole4 - 0.15 && split < whole2 - 0.03 && split < quarter - 0.03 &&
                     launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, true) == DLC_OK &&
                     launch_dma_part(ctx, blayout, act, m2, N, K, a2, lda, B, ldb, bias, C + m1 * ldc, ldc, st, cv, tri, Kb, cv ? m1 : 0, TM3 / 2, true) == DLC_OK) {
                     const int rc = launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, false);
@@ -880,7 +908,22 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
         }
 #endif
         if (whole2 < whole4 - 0.1) tm = TM3 / 2;
+#ifndef DLC_EXP_NO_QUARTER_TILE
+        // 64-row tiles (two workgroups fit a CU) while they leave the chip under one round: the K loop of a workgroup is
+        // what a small launch waits for, and a quarter of the MFMAs per K tile shortens it
+        // ... and, for plain operands, whenever their round count comes out lower: two 64-row workgroups share a CU
+        // and cover each other's prologues, epilogues and barriers -- SDAV.transform of 1063 frames on 64-row tiles
+        // only: 26.8 against 27.8 ms, i.e. 0.248 of a 256-row tile each; the convolution form pays its per-tile
+        // tap bookkeeping four times over (CnnVtl.transform 29.2 against 28.8 ms): 0.27
+        const int64_t t1 = dlc::cdiv(M, (int64_t)(TM3 / 4)) * tn_;
+        const double whole1 = (cv ? 0.27 : 0.248) * (double)dlc::cdiv(t1, (int64_t)256) + 0.02;
+        if (whole1 < whole4 - 0.1 && whole1 < whole2 - 0.05) tm = TM3 / 4;
+#endif
     }
+#endif
+#ifndef DLC_EXP_NO_QUARTER_TILE
+    // the Gram blocks of the similarity: 64-row tiles for the same reason (similarity of 1063 frames 39.8 -> 39.0 ms)
+    if (tri && N > 96 && dlc::cdiv(M, (int64_t)TM3) * dlc::cdiv(N, (int64_t)TN3) > 512) tm = TM3 / 4;
 #endif
     return launch_dma_part(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, tm, false);
 }
