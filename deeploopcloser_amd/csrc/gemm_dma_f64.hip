@@ -750,6 +750,7 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
     const int tn = narrow ? 96 : TN3;
     // tile height: the caller's choice (launch_dma_f64); triangular launches and the 96-column form keep the large tile
     int tm = (((force_tm == TM3 / 2 && !tri) || force_tm == TM3 / 4) && !narrow) ? force_tm : TM3;
+    // (conv1's 96-column form on 64-row tiles, two workgroups per CU: CnnVtl.transform 29.1 against 28.75 ms -- not kept)
 #ifdef DLC_EXP_FORCE_HALF_TILE   // timing experiment: what a 128-row (or, = 4, a 64-row) tile costs when it fills the chip
     if ((!tri || DLC_EXP_FORCE_HALF_TILE == 4) && !narrow) tm = TM3 / DLC_EXP_FORCE_HALF_TILE;
 #endif
