@@ -868,11 +868,12 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
     return DLC_OK;
 }
 
-// The public entry chooses between three forms by the rounds of the chip's 256 CUs each would take (a 128-row tile
-// costs 0.51 of a 256-row tile at full occupancy -- SDAV.transform on 128-row tiles only: 28.3 against 27.8 ms):
-//   one launch of 256-row tiles;  one launch of 128-row tiles (few tiles: twice the CUs busy; or a tile count that
-//   rounds up badly: 300 tiles are 2 rounds, 600 half tiles 3 half rounds);  or 256-row tiles for the whole rounds and
-//   a second launch of 128-row tiles for the rows behind them (conv3-5 of 1063 frames: 6.3 / 6.3 / 4.2 rounds).
+// The public entry chooses between four forms by the rounds of the chip's 256 CUs each would take (a 128-row tile
+// costs 0.51 of a 256-row tile at full occupancy -- SDAV.transform on 128-row tiles only: 28.3 against 27.8 ms; a
+// 64-row tile 0.248, two of its workgroups sharing a CU -- 26.8 ms; 0.27 in the convolution form):
+//   one launch of 256-row tiles;  one of 128-row tiles;  one of 64-row tiles (small launches: a workgroup's K loop is
+//   what they wait for; and plain operands at any size);  or 256-row tiles for the whole rounds and a second launch of
+//   128-row tiles for the rows behind them (conv3-5 of 1063 frames: 6.3 / 6.3 / 4.2 rounds).
 // Rows are independent and every form sums k in the same order: the same bits whichever is taken.
 int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                    const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
