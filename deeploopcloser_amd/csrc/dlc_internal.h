@@ -30,6 +30,8 @@ enum {
     DLC_ATTR_DGEMM_BASE = 24,    // + (fp32 ? 4 : 0) + {KN, NK, conv C%8, conv any -> 0..3}  -> bits 24..31
     DLC_ATTR_DMA64_BASE = 32,    // gemm_dma_f64_kernel: + {KN, NK, conv} + (96-column form ? 3 : 0) + (128-row tile ? 6 : 0) -> bits 32..43
     DLC_ATTR_PAIR_TILE = 48,     // pair_score_tile_kernel
+    DLC_ATTR_GRAM_I8 = 49,       // gram_i8_kernel
+    DLC_ATTR_PAIR_FILTER = 50,   // pair_score_filter_kernel
 };
 
 namespace dlc {

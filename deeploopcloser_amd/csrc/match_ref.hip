@@ -6,8 +6,12 @@
 //   * SDAV similarity matrix (src/sdav/similarity/SimilarityCalculator.py:12-49,
 //     loop of src/sdav/create_similarity_matrix.py:29-38): patch-to-patch
 //     distances from one fp64 MFMA Gram GEMM (||a||^2+||b||^2-2a.b), then one
-//     wave per frame pair for argmin / weighted distance / log-sum.
-#include "dlc_internal.h"
+//     wave per frame pair for argmin / weighted distance / log-sum; or, for up to 32 patches per frame, the arg-min
+//     from exact integer products of 21-bit fixed-point descriptors with a direct fp64 evaluation wherever their
+//     error bound cannot separate the candidates (gram_i8.hip).
+#include <cstdlib>
+#include <cstring>
+#include "gemm_internal.h"
 
 namespace dlc_gemm {
 int gram_upper_f64(dlc_ctx* ctx, int blayout, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
@@ -244,6 +248,8 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
 // minimum and every rounding are the same -- and the 32-lane xor tree sums the P terms of a pair.
 constexpr int PS_JT = 8;
 constexpr int PS_GX = 8;        // workgroups per frame i: each walks every PS_GX-th run of PS_JT frames
+constexpr int PF_STACK_DEPTH = 16;                           // value stack of the pairwise-summation program (H <= 32768: 9 levels)
+constexpr int PF_STACK_BYTES = 4 * 8 * PF_STACK_DEPTH * 8;  // one per 8-lane group of each wave
 __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __restrict__ desc, const double* __restrict__ G,
                                                               long long ldg, long long col0, const double* __restrict__ nrm2,
                                                               const double* __restrict__ proj,
@@ -352,6 +358,213 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
     }
 }
 
+// The filter form (gram_i8.hip): G holds the exact integer products of the descriptors' 21-bit fixed-point values,
+// acc 2^-14 <= u_a . u_b <= acc 2^-14 + E.  Thread (jj, a) takes the arg-min of |u_b|^2 - 2 acc 2^-14 over the P
+// patches b; when the runner-up lies within 2 E of it, the bound cannot tell them apart and the wave evaluates the
+// candidates inside that window directly: |x_b - x_a| in fp64 from the descriptors, square roots compared as the
+// reference compares them (np.argmin of np.linalg.norm, first minimum).
+__global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __restrict__ desc, const int* __restrict__ G,
+                                                                long long ldg, long long col0, const double* __restrict__ nu2,
+                                                                const double* __restrict__ proj, const double* __restrict__ score,
+                                                                const unsigned long long* __restrict__ keys, long long N, int P,
+                                                                int H, long long i_lo, long long i_hi, double ca, double cb,
+                                                                double* __restrict__ out_f64, long long* __restrict__ out_i64,
+                                                                const int2* __restrict__ prog) {
+    extern __shared__ double ps_lds_all[];
+    double* ps_lds = ps_lds_all + PF_STACK_BYTES / 8;            // in front: the value stacks of the summation program
+    unsigned long long* n_fallback = const_cast<unsigned long long*>(keys) + 4;
+    const int prog_len = (int)keys[5];
+    const long long i = i_lo + blockIdx.y;
+    if (i >= i_hi) return;
+    const int tid = threadIdx.x;
+    const int width = PS_JT * P, row = width | 1;
+    double* nb = ps_lds;                                         // [PS_JT * P] |u_b|^2 of the frames' patches
+    int* g = (int*)(ps_lds + width);                             // [P][row]
+    const int w = tid >> 6, lane = tid & 63;
+    const int jj = tid >> 5, a = tid & 31;
+    const long long ra = i * P + (a < P ? a : 0);
+    const double pa = proj[ra];
+    const bool flat = !(dlc_f64_unkey(keys[1]) > dlc_f64_unkey(keys[0]));      // every descriptor value the same: all distances 0
+    const double E = 0x1p-20 * dlc_f64_unkey(keys[3]) + (double)H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
+    const double window = 2.0 * E + 1e-8;
+    const int* grow0 = G + (i * P - i_lo * P) * ldg - col0;
+    int v[8][4];
+    auto fetch = [&](long long j0) {
+        const long long jlo = j0 > i + 1 ? j0 : i + 1;
+        const long long jhi = j0 + PS_JT < N ? j0 + PS_JT : N;
+        const int c_lo = (int)((jlo - j0) * P), c_hi = (int)((jhi - j0) * P);
+        const int* gb = grow0 + j0 * P;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int ar = w + 4 * r, c = lane + 64 * cc;
+                v[r][cc] = (ar < P && c >= c_lo && c < c_hi) ? gb[(long long)ar * ldg + c] : 0;
+            }
+    };
+    long long j0 = ((i + 1) / PS_JT + blockIdx.x) * PS_JT;
+    if (j0 < N) fetch(j0);
+    unsigned long long fallbacks = 0;
+    for (; j0 < N; j0 += (long long)PS_GX * PS_JT) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int ar = w + 4 * r, c = lane + 64 * cc;
+                if (ar < P && c < width) g[ar * row + c] = v[r][cc];
+            }
+        for (int c = tid; c < width; c += 256) nb[c] = (j0 * P + c < N * P) ? nu2[j0 * P + c] : 0.0;
+        __syncthreads();
+        const long long jn = j0 + (long long)PS_GX * PS_JT;
+        if (jn < N) fetch(jn);
+        const long long j = j0 + jj;
+        const bool pair_ok = j > i && j < N;
+        const bool live = pair_ok && a < P;
+        int bi = 0;
+        unsigned cand = 0;
+        if (live && !flat) {
+            const int* grow = g + a * row + jj * P;
+            const double* nbj = nb + jj * P;
+            double best = 0.0, second = INFINITY;
+            auto scan = [&](int b) {
+                const double d2 = nbj[b] - 0x1p-13 * (double)grow[b];
+                if (b == 0) { best = d2; bi = 0; return; }
+                second = fmin(second, fmax(best, d2));
+                bi = d2 < best ? b : bi;
+                best = fmin(best, d2);
+            };
+            if (P == 30) {
+#pragma unroll
+                for (int b = 0; b < 30; ++b) scan(b);
+            } else {
+#pragma unroll 4
+                for (int b = 0; b < P; ++b) scan(b);
+            }
+            if (second <= best + window)
+                for (int b = 0; b < P; ++b)
+                    if (nbj[b] - 0x1p-13 * (double)grow[b] <= best + window) cand |= 1u << b;
+        }
+        // the undecided arg-mins of this wave, one after the other
+        unsigned long long todo = __ballot(cand != 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned cm = (unsigned)__shfl((int)cand, src);
+            const int a_s = src & 31;
+            const long long j_s = j0 + (w * 2 + (src >> 5));
+            const double* xa = desc + (i * P + a_s) * H;
+            const double* xj = desc + j_s * P * H;
+            // (1) all 64 lanes on each candidate's 2 H doubles: squared distances to ~5e-15 (relative); lane b keeps
+            // candidate b's
+            double mine = INFINITY, emin = INFINITY;
+            for (int b = 0; b < P; ++b) {
+                if (!((cm >> b) & 1)) continue;
+                const double* xb = xj + (long long)b * H;
+                double s_ = 0.0;
+                for (int k = lane; k < H; k += 64) { const double d = xb[k] - xa[k]; s_ = fma(d, d, s_); }
+                for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
+                if (lane == b) mine = s_;
+                emin = fmin(emin, s_);
+            }
+            unsigned long long close = __ballot(mine <= emin * (1.0 + 1e-11));
+            int ebi = __ffsll((long long)close) - 1;
+            if (close & (close - 1)) {
+                // (2) still closer than either summation resolves: the candidates' norms exactly as NumPy forms them
+                // (np.linalg.norm: sqrt(np.add.reduce((x - m) ** 2)) with pairwise summation), eight candidates at a
+                // time -- 8 lanes per candidate, one per strided accumulator of a leaf
+                const int grp = lane >> 3, q = lane & 7;
+                double* stack = ps_lds_all + (w * 8 + grp) * PF_STACK_DEPTH;
+                double nbest = 0.0;
+                bool first = true;
+                while (close) {
+                    int b_mine = -1, b_first = __ffsll((long long)close) - 1, nb_ = 0;
+                    for (int c = 0; c < 8 && close; ++c) {
+                        const int b = __ffsll((long long)close) - 1;
+                        close &= close - 1;
+                        if (grp == c) b_mine = b;
+                        ++nb_;
+                    }
+                    const double* xb = xj + (long long)(b_mine >= 0 ? b_mine : b_first) * H;
+                    // (HIP's __dmul_rn / __dadd_rn are plain * and + that hipcc contracts into fma: the pragma is what
+                    // keeps every product and every sum rounded on its own, as NumPy's are)
+                    auto sq = [&](int k) {
+#pragma clang fp contract(off)
+                        const double d = xb[k] - xa[k];
+                        const double d2 = d * d;
+                        return d2;
+                    };
+                    int sp = 0;
+                    for (int e = 0; e < prog_len; ++e) {
+#pragma clang fp contract(off)
+                        const int2 op = prog[e];
+                        if (op.x < 0) {
+                            const double rhs = stack[sp - 1], lhs = stack[sp - 2];
+                            sp -= 2;
+                            const double r = __dadd_rn(lhs, rhs);
+                            if (q == 0) stack[sp] = r;
+                            ++sp;
+                            continue;
+                        }
+                        double r;
+                        if (op.y < 8) {
+                            r = 0.0;
+                            for (int t = 0; t < op.y; ++t) r = __dadd_rn(r, sq(op.x + t));
+                        } else {
+                            const int m = op.y - (op.y & 7);
+                            r = sq(op.x + q);
+#pragma unroll 4
+                            for (int t = 8; t < m; t += 8) r = __dadd_rn(r, sq(op.x + t + q));
+                            r = __dadd_rn(r, __shfl_xor(r, 1));
+                            r = __dadd_rn(r, __shfl_xor(r, 2));
+                            r = __dadd_rn(r, __shfl_xor(r, 4));
+                            for (int t = m; t < op.y; ++t) r = __dadd_rn(r, sq(op.x + t));
+                        }
+                        if (q == 0) stack[sp] = r;
+                        ++sp;
+                    }
+                    const double dist = sqrt(0.0 + stack[0]);
+                    for (int c = 0; c < nb_; ++c) {
+                        const double dc = __shfl(dist, c * 8);
+                        const int bc = __shfl(b_mine, c * 8);
+#ifdef DLC_EXP_PF_PRINT
+                        if (lane == 0 && N == 6) printf("i=%lld j=%lld a=%d cm=%x cand b=%d dist=%.17g sum=%.17g proglen=%d\n", i, j_s, a_s, cm, bc, dc, __shfl(stack[0], c * 8) , prog_len);
+#endif
+                        if (first || dc < nbest) { nbest = dc; ebi = bc; first = false; }    // np.argmin: first minimum
+                    }
+                }
+            }
+            if (lane == src) bi = ebi;
+            if (lane == 0) ++fallbacks;
+        }
+        double term = 0.0;
+        if (live) {
+            const long long rb = j * P + bi;
+            const double pb = proj[rb];
+            double wd = fabs(pa - pb);                          // |dot(score, m_i - m_j*)|, :42-43
+            if (wd < 1e-6 * (fabs(pa) + fabs(pb))) {            // cancellation: evaluate the difference directly
+                const double* xa = desc + ra * H;
+                const double* xb = desc + rb * H;
+                double s_ = 0.0;
+                for (int k = 0; k < H; ++k) s_ = fma(score[k], xa[k] - xb[k], s_);
+                wd = fabs(s_);
+            }
+            term = ca + cb * log(wd);                           // :48
+        }
+        for (int o = 16; o > 0; o >>= 1) term += __shfl_xor(term, o);
+        if (pair_ok && a == 0) {
+            out_f64[i * N + j] = term;
+            out_f64[j * N + i] = term;
+            if (out_i64) {
+                const long long t = f64_to_i64_trunc(term);
+                out_i64[i * N + j] = t;
+                out_i64[j * N + i] = t;
+            }
+        }
+        __syncthreads();
+    }
+    if (n_fallback && lane == 0 && fallbacks) atomicAdd(n_fallback, fallbacks);
+}
+
 __global__ void fill_diag_kernel(long long N, double* out_f64, long long* out_i64) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -373,37 +586,65 @@ __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __rest
 }
 
 struct SimWs {
-    size_t nrm2, proj, gram, desc_t, total;
-    long long chunk_frames;
+    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, qx, qy, total;
+    long long chunk_frames, chunk_frames_i8;
 };
 
-SimWs sim_ws(int64_t N, int64_t P, int64_t H) {
-    SimWs w;
-    size_t o = 0;
-    (void)H;
-    w.nrm2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
-    w.proj = o; o += dlc::align_up((size_t)N * P * 8, 256);
+// The arg-min filter (gram_i8.hip) takes the call when the tiled pair kernel does (P <= 32) and the integer
+// accumulators cannot overflow; DLC_SIM_GRAM=f64 / i8 in the environment forces one form (experiments, tests).
+bool sim_use_filter(int64_t P, int64_t H) {
+    const char* e = getenv("DLC_SIM_GRAM");
+    if (e && !strcmp(e, "f64")) return false;
+    return P <= 32 && H <= 32768;
+}
+
+long long sim_chunk(int64_t N, int64_t P, size_t row_bytes) {
     // Gram row chunk: at most ~8 GiB of the 288 GB (the work is triangular, so every chunk's launch is smaller than
     // the one before and each pays its own last partial round of the chip: 1063 frames in 9 chunks of <= 1 GiB lost
     // ~5 % to that; 8 GiB holds all of them in one), at least one frame
-    const size_t row_bytes = (size_t)N * P * 8;
     long long cf = (long long)((8ull << 30) / (row_bytes * (size_t)P));
     if (cf < 1) cf = 1;
     if (cf >= N - 1) {
         cf = N > 1 ? N - 1 : 1;                  // everything at once (the last frame has no later frame to pair with)
     } else {
-        // whole 256-row tiles of the Gram GEMM (gemm_dma_f64.hip) where the chunk allows: cf * P a multiple of 256
+        // whole 256-row tiles of the Gram GEMM where the chunk allows: cf * P a multiple of 256
         for (long long q = 256; q >= 8; q /= 2)
             if (cf >= q && (q * P) % 256 == 0) { cf = cf / q * q; break; }
     }
     if (cf > N) cf = N;
-    w.chunk_frames = cf;
-    w.gram = o; o += dlc::align_up((size_t)cf * P * row_bytes, 256);
-    // the descriptors transposed [H, N*P] (one extra pass over them): the Gram blocks then read their B operand as
+    return cf;
+}
+
+SimWs sim_ws(int64_t N, int64_t P, int64_t H) {
+    SimWs w;
+    size_t o = 0;
+    w.nrm2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
+    w.proj = o; o += dlc::align_up((size_t)N * P * 8, 256);
+    const bool filter = sim_use_filter(P, H);
+    const size_t row_bytes = (size_t)N * P * 8;
+    const size_t row_bytes_i8 = ((size_t)N * P + 4) * 4;        // int32 accumulators, the leading dimension a multiple of 4
+    w.chunk_frames = sim_chunk(N, P, row_bytes);
+    w.chunk_frames_i8 = sim_chunk(N, P, row_bytes_i8);
+    const size_t gram_f64 = (size_t)w.chunk_frames * P * row_bytes, gram_i8 = (size_t)w.chunk_frames_i8 * P * row_bytes_i8;
+    // (the filter's region holds at least one frame's fp64 rows: a dataset with a NaN / infinity in it takes the fp64
+    // route after all, in as many chunks as that needs and without the transposed copy)
+    w.gram_bytes = filter ? (gram_i8 > (size_t)P * row_bytes ? gram_i8 : (size_t)P * row_bytes) : gram_f64;
+    w.gram = o; o += dlc::align_up(w.gram_bytes, 256);
+    // the descriptors transposed [H, N*P] (one extra pass over them): the fp64 Gram blocks then read their B operand as
     // [K,N] -- 1 KiB contiguous per k-row and tile instead of 128 scattered 128-byte row segments (an even N*P keeps
     // the rows 16-byte aligned for the LDS-DMA kernel; an odd one falls back to the [N,K] form)
     w.desc_t = o;
-    if (((N * P) & 1) == 0) o += dlc::align_up((size_t)N * P * H * 8, 256);
+    w.keys = w.prog = w.nu2 = w.qx = w.qy = 0;
+    if (filter) {
+        const size_t panel = dlc_gemm::sim_filter_panel_bytes(N * P, H);
+        w.keys = o; o += 256;
+        w.prog = o; o += 8192;
+        w.nu2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
+        w.qx = o; o += dlc::align_up(panel, 256);
+        w.qy = o; o += dlc::align_up(panel, 256);
+    } else if (((N * P) & 1) == 0) {
+        o += dlc::align_up((size_t)N * P * H * 8, 256);
+    }
     w.total = o;
     return w;
 }
@@ -480,13 +721,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
     double* proj = (double*)(ws + w.proj);
     double* gram = (double*)(ws + w.gram);
     const long long rows = N * P;
-    const bool use_t = (rows & 1) == 0;
-    double* desc_t = (double*)(ws + w.desc_t);
-    if (use_t) {
-        hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)dlc::cdiv(rows, 32), (unsigned)dlc::cdiv(H, 32)), dim3(256), 0, st,
-                           desc, rows, (long long)H, desc_t);
-        DLC_LAUNCH_CHECK(ctx, "transpose_f64_kernel");
-    }
+    bool filter = sim_use_filter(P, H);
 
     hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)dlc::cdiv(rows, 4)), dim3(256), 0, st, desc, rows, (int)H, score,
                        nrm2, proj);
@@ -495,8 +730,63 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
                        (long long*)out_i64);
     DLC_LAUNCH_CHECK(ctx, "fill_diag_kernel");
 
-    for (long long i_lo = 0; i_lo + 1 < N; i_lo += w.chunk_frames) {
-        long long i_hi = i_lo + w.chunk_frames;
+    if (filter) {
+        unsigned long long* keys = (unsigned long long*)(ws + w.keys);
+        double* nu2 = (double*)(ws + w.nu2);
+        char* qx = ws + w.qx;
+        char* qy = ws + w.qy;
+        int2* prog = (int2*)(ws + w.prog);
+        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, rows, H, keys, qx, qy, nu2, prog, st);
+        if (rc != DLC_OK) return rc;
+        // the one host read of this call: did the range pass meet a NaN or an infinity?  (Their distances are NaN in the
+        // reference too, np.argmin then takes the first of them: the fp64 kernels reproduce that, a fixed-point
+        // fraction cannot.)
+        unsigned long long bad = 0;
+        DLC_HIP_CHECK(ctx, hipMemcpyAsync(&bad, keys + 2, sizeof(bad), hipMemcpyDeviceToHost, st));
+        DLC_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (bad) filter = false;
+        else {
+            const size_t tile_lds = PF_STACK_BYTES + (size_t)PS_JT * P * sizeof(double) + (size_t)P * ((PS_JT * P) | 1) * sizeof(int);
+            for (long long i_lo = 0; i_lo + 1 < N; i_lo += w.chunk_frames_i8) {
+                long long i_hi = i_lo + w.chunk_frames_i8;
+                if (i_hi > N - 1) i_hi = N - 1;
+                if (i_hi <= i_lo) break;
+                const long long col0 = (i_lo + 1) * P;
+                const long long ncols = rows - col0;
+                const long long ldo = (ncols + 3) / 4 * 4;
+                const long long mrows = (i_hi - i_lo) * P;
+                rc = dlc_gemm::gram_upper_i8(ctx, mrows, ncols, H, qx, qy, (int*)gram, ldo, (int)P, i_lo * P, col0, st);
+                if (rc != DLC_OK) return rc;
+                hipLaunchKernelGGL(pair_score_filter_kernel, dim3(PS_GX, (unsigned)(i_hi - i_lo)), dim3(256), tile_lds, st, desc,
+                                   (const int*)gram, ldo, col0, nu2, proj, score, keys, (long long)N, (int)P, (int)H, i_lo, i_hi, a,
+                                   b, out_f64, (long long*)out_i64, prog);
+                DLC_LAUNCH_CHECK(ctx, "pair_score_filter_kernel");
+            }
+            if (getenv("DLC_SIM_DEBUG")) {       // experiments: how many arg-mins went to the direct evaluation
+                unsigned long long k[5] = {0, 0, 0, 0, 0};
+                DLC_HIP_CHECK(ctx, hipMemcpyAsync(k, keys, sizeof(k), hipMemcpyDeviceToHost, st));
+                DLC_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                fprintf(stderr, "similarity filter: %llu of %lld arg-mins evaluated directly\n", k[4], (long long)N * (N - 1) / 2 * P);
+            }
+            return DLC_OK;
+        }
+    }
+
+    // the fp64 Gram route
+    long long chunk_frames = w.chunk_frames;
+    bool use_t = (rows & 1) == 0;
+    if (sim_use_filter(P, H)) {                  // the filter's workspace: no transposed copy, the chunk that fits its Gram region
+        use_t = false;
+        chunk_frames = (long long)(w.gram_bytes / ((size_t)P * rows * 8));
+    }
+    double* desc_t = (double*)(ws + w.desc_t);
+    if (use_t) {
+        hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)dlc::cdiv(rows, 32), (unsigned)dlc::cdiv(H, 32)), dim3(256), 0, st,
+                           desc, rows, (long long)H, desc_t);
+        DLC_LAUNCH_CHECK(ctx, "transpose_f64_kernel");
+    }
+    for (long long i_lo = 0; i_lo + 1 < N; i_lo += chunk_frames) {
+        long long i_hi = i_lo + chunk_frames;
         if (i_hi > N - 1) i_hi = N - 1;          // the last frame has no j > i
         if (i_hi <= i_lo) break;
         // columns: frames j > i_lo, i.e. from frame i_lo+1 on

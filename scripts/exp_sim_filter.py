@@ -1,0 +1,78 @@
+"""The SDAV similarity's arg-min filter (csrc/gram_i8.hip) against the fp64 Gram route (GPU box only): the two must agree
+bit for bit on every shape, and the timing at the reference's size says what the filter buys.
+Usage: python scripts/exp_sim_filter.py [full]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import deeploopcloser_amd as dlc
+
+eng = dlc.default_engine()
+g = torch.Generator(device=eng.device); g.manual_seed(3)
+rng = np.random.RandomState(3)
+
+
+def both(ds, a=10.0, b=-10.0):
+    score = eng.distinctive_score(ds, 0.5, 0.2)
+    out = {}
+    for mode in ("f64", "i8"):
+        os.environ["DLC_SIM_GRAM"] = mode
+        mf, mi = eng.sdav_similarity_matrix(ds, score, a, b)
+        torch.cuda.synchronize()
+        out[mode] = (mf.clone(), mi.clone())
+    return out
+
+
+def check(name, ds):
+    o = both(ds)
+    same_f = torch.equal(o["f64"][0], o["i8"][0]) or bool(((o["f64"][0] == o["i8"][0]) | (o["f64"][0].isnan() & o["i8"][0].isnan())).all())
+    same_i = torch.equal(o["f64"][1], o["i8"][1])
+    nbad = int((o["f64"][0] != o["i8"][0]).sum())
+    print("%-44s %s (%d of %d entries differ)" % (name, "ok" if same_f and same_i else "DIFFERENT", nbad, o["i8"][0].numel()), flush=True)
+    return same_f and same_i
+
+
+ok = True
+for n, p, h in ((2, 1, 8), (3, 7, 64), (6, 30, 8), (6, 30, 64), (20, 30, 250), (40, 32, 2500), (33, 30, 2500), (70, 13, 129),
+                (300, 30, 256), (150, 5, 1000)):
+    ok &= check("uniform  n=%d p=%d h=%d" % (n, p, h), torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+    ok &= check("normal   n=%d p=%d h=%d" % (n, p, h), 3.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64) - 1.0)
+    x = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+    ok &= check("saturated n=%d p=%d h=%d" % (n, p, h), x)
+    if n * p > 4:                                                 # duplicated patches: exact ties, first index wins
+        y = x.clone().reshape(n * p, h)
+        idx = torch.from_numpy(rng.randint(0, n * p, size=max(2, n * p // 3))).to(eng.device)
+        y[idx] = y[torch.from_numpy(rng.randint(0, n * p, size=len(idx))).to(eng.device)].clone()
+        ok &= check("duplicates n=%d p=%d h=%d" % (n, p, h), y.reshape(n, p, h))
+        # near-ties far inside the filter's window: patches that differ in one entry by 1e-7
+        z = x.clone().reshape(n * p, h)
+        z[1::2] = z[0::2][: z[1::2].shape[0]].clone()
+        z[1::2, 0] += 1e-7
+        ok &= check("near-ties n=%d p=%d h=%d" % (n, p, h), z.reshape(n, p, h))
+ok &= check("constant", torch.full((5, 30, 64), 0.25, device=eng.device, dtype=torch.float64))
+w = torch.rand((6, 30, 64), generator=g, device=eng.device, dtype=torch.float64); w[2, 3, 5] = float("nan")
+ok &= check("a NaN (fp64 route taken for both)", w)
+print("small shapes:", "all equal" if ok else "MISMATCH", flush=True)
+
+if len(sys.argv) > 1 and sys.argv[1] == "full":
+    n, p, h = 1063, 30, 2500
+    for kind in ("saturated", "uniform"):
+        x = torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
+        ds = torch.sigmoid(35.0 * x) if kind == "saturated" else torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
+        del x
+        score = eng.distinctive_score(ds, 0.5, 0.2)
+        res = {}
+        for mode in ("f64", "i8"):
+            os.environ["DLC_SIM_GRAM"] = mode
+            for rep in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+                torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
+            res[mode] = (mf.clone(), mi.clone(), dt)
+        os.environ["DLC_SIM_DEBUG"] = "1"
+        eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+        del os.environ["DLC_SIM_DEBUG"]
+        print("%s 1063 x 30 x 2500: fp64 Gram %.2f ms, filter %.2f ms, equal: %s / %s" % (
+            kind, res["f64"][2], res["i8"][2], torch.equal(res["f64"][0], res["i8"][0]), torch.equal(res["f64"][1], res["i8"][1])), flush=True)
+        del ds, res
+        torch.cuda.empty_cache()

@@ -519,6 +519,64 @@ def test_similarity_matrix_vs_oracle_larger(dlc):
     assert np.abs(got[fin] - ref[fin]).max() < 1e-9 * np.abs(ref[fin]).max()
 
 
+def test_similarity_near_ties_follow_the_reference(dlc, monkeypatch):
+    """Patches of a frame that differ from each other by 1e-7 in one of their entries: the nearest one is decided far
+    below what a Gram-matrix distance |a|^2 + |b|^2 - 2 a.b resolves.  The arg-min filter (csrc/gram_i8.hip) sends
+    such candidates to a direct evaluation of |b - a|, which orders them as the reference's np.linalg.norm does."""
+    from oracle import similarity as osim
+    monkeypatch.delenv("DLC_SIM_GRAM", raising=False)
+    rng = np.random.RandomState(17)
+    for n, p, h in [(6, 30, 64), (9, 30, 250), (5, 32, 2500), (12, 7, 129)]:
+        x = 1.0 / (1.0 + np.exp(-35.0 * rng.standard_normal((n * p, h))))
+        x[1::2] = x[0::2][: x[1::2].shape[0]]
+        x[1::2, 0] += 1e-7
+        ds = x.reshape(n, p, h)
+        got = dlc.SimilarityCalculator(ds).similarity_matrix(as_int64=False)
+        ref = osim.similarity_matrix_f64(ds)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isposinf(got), np.isposinf(ref)), (n, p, h)
+        assert np.abs(got[fin] - ref[fin]).max() <= 1e-9 * max(1.0, np.abs(ref[fin]).max()), (n, p, h)
+
+
+def test_similarity_filter_equals_fp64_gram_route(eng, monkeypatch):
+    """The two routes of dlc_sdav_similarity_matrix -- exact integer products of 21-bit fixed-point descriptors that
+    decide the arg-min (with a direct fp64 evaluation where their error bound cannot), and the fp64 Gram matrix --
+    give the same matrix bit for bit: uniform, normal (negative values, range far from [0, 1]), saturated sigmoid
+    outputs, duplicated patches (exact ties: first index), constant data, ragged sizes."""
+    g = torch.Generator(device=eng.device); g.manual_seed(5)
+    rng = np.random.RandomState(5)
+
+    def both(ds):
+        score = eng.distinctive_score(ds, 0.5, 0.2)
+        out = []
+        for mode in ("f64", "i8"):
+            monkeypatch.setenv("DLC_SIM_GRAM", mode)
+            mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+            out.append((mf.clone(), mi.clone()))
+        monkeypatch.delenv("DLC_SIM_GRAM")
+        return out
+
+    for n, p, h in [(2, 1, 8), (3, 7, 64), (6, 30, 8), (20, 30, 250), (40, 32, 2500), (70, 13, 129), (300, 30, 256), (150, 5, 1000)]:
+        sat = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+        dup = sat.clone().reshape(n * p, h)
+        if n * p > 4:
+            src = torch.from_numpy(rng.randint(0, n * p, size=n * p // 3 + 1)).to(eng.device)
+            dst = torch.from_numpy(rng.randint(0, n * p, size=n * p // 3 + 1)).to(eng.device)
+            dup[dst] = dup[src].clone()
+        for name, ds in (("uniform", torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)),
+                         ("normal", 3.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64) - 1.0),
+                         ("saturated", sat), ("duplicates", dup.reshape(n, p, h))):
+            (f_ref, i_ref), (f_got, i_got) = both(ds)
+            assert torch.equal(f_got, f_ref) and torch.equal(i_got, i_ref), (name, n, p, h)
+    (f_ref, i_ref), (f_got, i_got) = both(torch.full((5, 30, 64), 0.25, device=eng.device, dtype=torch.float64))
+    assert torch.equal(f_got, f_ref) and torch.equal(i_got, i_ref)
+    bad = torch.rand((6, 30, 64), generator=g, device=eng.device, dtype=torch.float64)
+    bad[2, 3, 5] = float("nan")                       # a NaN in the data: the filter hands the call to the fp64 route
+    (f_ref, i_ref), (f_got, i_got) = both(bad)
+    assert torch.equal(i_got, i_ref) and torch.equal(f_got.isnan(), f_ref.isnan())
+    assert torch.equal(torch.nan_to_num(f_got), torch.nan_to_num(f_ref))
+
+
 def test_distance_vs_reference_fixture(dlc, golden):
     g = golden("distance.npz")
     dc = dlc.DistanceCalculator
