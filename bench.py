@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA peak
 MFMA_F64_PEAK_TFLOPS = 78.6  # dense fp64 MFMA peak (v_mfma_f64_16x16x4_f64)
+MFMA_I8_PEAK_TOPS = 5000.0   # dense int8 MFMA peak (v_mfma_i32_16x16x64_i8: twice the bf16 form's work per clock)
 
 
 def parse():
@@ -342,10 +343,11 @@ def bench_paths(eng, n_frames):
         score = eng.distinctive_score(desc, 0.5, 0.2)
         return eng.sdav_similarity_matrix(desc, score, 10.0, -10.0)
     call_ms, k_ms, k_n, (mf, mi) = _timed_path(eng, sim, reps=2)
-    # Gram GEMMs as dlc_sdav_similarity_matrix launches them (match_ref.hip sim_ws): row chunks of <= 8 GiB,
-    # frames [i_lo, i_hi) against every later frame; tiles under the diagonal are skipped, so the flops counted
-    # are the upper triangle's (what the similarity needs), not the launched rectangle's
-    cf = max(1, (8 << 30) // (N * P * 8 * P))
+    # The patch products as dlc_sdav_similarity_matrix launches them (match_ref.hip sim_ws): row chunks of <= 8 GiB of
+    # int32 accumulators, frames [i_lo, i_hi) against every later frame; tiles under the diagonal are skipped, so the
+    # operations counted are the upper triangle's (what the similarity needs), not the launched rectangle's -- six int8
+    # products of length H per patch pair (csrc/gram_i8.hip: the 21-bit fixed-point slices' classes 2, 3 and 4)
+    cf = max(1, (8 << 30) // ((N * P + 4) * 4 * P))
     if cf >= N - 1:
         cf = max(N - 1, 1)
     else:
@@ -354,14 +356,15 @@ def bench_paths(eng, n_frames):
                 cf = cf // q_ * q_
                 break
     cf = min(cf, N)
-    flops, i_lo = 0.0, 0
+    patch_pairs, i_lo = 0.0, 0
     while i_lo + 1 < N:
         i_hi = min(i_lo + cf, N - 1)
         # rows of frames [i_lo, i_hi) x columns of frames > i_lo, minus the (skipped) lower triangle inside the chunk
         rect = (i_hi - i_lo) * P * (N * P - (i_lo + 1) * P)
         lower = (i_hi - i_lo - 1) * (i_hi - i_lo) / 2.0 * P * P
-        flops += 2.0 * (rect - lower) * H
+        patch_pairs += rect - lower
         i_lo += cf
+    i8_ops = 6 * 2.0 * patch_pairs * H
     pairs = N * (N - 1) // 2
     ns = min(N, 20)                                           # the reference-literal per-pair loop at datasets/test size
     dsn = desc[:ns].cpu().numpy()
@@ -379,7 +382,13 @@ def bench_paths(eng, n_frames):
     out.append({"path": "SDAV similarity matrix", "reference": "src/sdav/similarity/SimilarityCalculator.py:12-49, "
                 "src/sdav/create_similarity_matrix.py:29-38", "frames": N, "dtype": "f64",
                 "value": pairs / (call_ms * 1e-3), "unit": "frame-pairs/s", "ms": call_ms,
-                "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_dma_f64_kernel (Gram blocks desc . desc^T, wanted blocks only)"),
+                "roofline": {"bound": "mfma", "achieved": i8_ops / (k_ms * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                             "frac": i8_ops / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": None,
+                             "kernel": "gram_i8_kernel (exact int8 products of the descriptors' 21-bit fixed-point slices, "
+                                       "wanted blocks only; they decide the patch arg-min, the rest is evaluated directly in fp64)",
+                             "kernel_ms": k_ms, "kernel_launches_timed": k_n, "call_ms": call_ms,
+                             "algorithmic_ops_per_call": i8_ops,
+                             "fp64_equivalent_tflops": 2.0 * patch_pairs * H / (k_ms * 1e-3) / 1e12},
                 "cpu_baseline": {"value": (ns * (ns - 1) // 2) / t_cpu, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/similarity.py all-vs-all loop on the first %d frames (%d pairs, mean / "
                                            "distinctive score hoisted): %.2f s; the literal similarity_score (mean recomputed "

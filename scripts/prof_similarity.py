@@ -1,0 +1,21 @@
+"""The SDAV similarity matrix at the reference's size (1063 frames x 30 patches x 2500) a few times, for rocprofv3:
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sim -- python3 scripts/prof_similarity.py [saturated|uniform]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import deeploopcloser_amd as dlc
+
+eng = dlc.default_engine()
+g = torch.Generator(device=eng.device); g.manual_seed(3)
+n, p, h = 1063, 30, 2500
+kind = sys.argv[1] if len(sys.argv) > 1 else "saturated"
+if kind == "saturated":
+    ds = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+else:
+    ds = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
+score = eng.distinctive_score(ds, 0.5, 0.2)
+for rep in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+    torch.cuda.synchronize()
+    print("%s: %.2f ms" % (kind, (time.perf_counter() - t0) * 1e3), flush=True)
