@@ -347,7 +347,7 @@ def bench_paths(eng, n_frames):
     # int32 accumulators, frames [i_lo, i_hi) against every later frame; tiles under the diagonal are skipped, so the
     # operations counted are the upper triangle's (what the similarity needs), not the launched rectangle's -- six int8
     # products of length H per patch pair (csrc/gram_i8.hip: the 21-bit fixed-point slices' classes 2, 3 and 4)
-    cf = max(1, (8 << 30) // ((N * P + 4) * 4 * P))
+    cf = max(1, (8 << 30) // ((N * P + 20) * 4 * P))
     if cf >= N - 1:
         cf = max(N - 1, 1)
     else:

@@ -15,10 +15,12 @@
 // inside that window directly in fp64 from the descriptors.  Six int8 products of K = H replace one fp64 product:
 // 1/5 of the matrix-pipe time at the int8 rate, and the result is the arg-min of the true distances either way.
 //
-// Layout: X [rows_pad, 3 Kp] = (q1 | q2 | q3), Y [rows_pad, 3 Kp] = (q3 | q2 | q1), Kp = H rounded up to 128, zero
-// padded; then class 4 is X[:, 0:3Kp] . Y[:, 0:3Kp]^T, class 3 is X[:, 0:2Kp] . Y[:, Kp:3Kp]^T, class 2 is
-// X[:, 0:Kp] . Y[:, 2Kp:3Kp]^T: one NT int8 GEMM over three K segments with the accumulators shifted right by 7 between
-// them.
+// Layout: X = (q1 | q2 | q3), Y = (q3 | q2 | q1) along K (Kp = H rounded up to 256, zero padded); then class 4 is
+// X[:, 0:3Kp] . Y[:, 0:3Kp]^T, class 3 is X[:, 0:2Kp] . Y[:, Kp:3Kp]^T, class 2 is X[:, 0:Kp] . Y[:, 2Kp:3Kp]^T: one NT
+// int8 GEMM over three K segments with the accumulators shifted right by 7 between them.  In memory both are tiled the
+// way the MFMA reads them: [16-row group][k-step of 64 bytes][lane l: row l % 16, bytes (l / 16) * 16 .. + 15] -- every
+// LDS-DMA piece is then 1 KiB of consecutive bytes, eight whole cache lines.  (Row-major slices made each piece 16
+// half lines; every line crossed the L2 -> L1 path twice, once per k-step, and the kernel sat at 12 B / clock / CU.)
 #include <type_traits>
 #include "gemm_internal.h"
 
@@ -36,39 +38,34 @@ constexpr int GI_STAGE = 2 * GI_HALF;
 constexpr int GI_NSTAGE = 4;              // 128 KiB: three stages in flight behind the one being read
 
 struct GramI8Args {
-    const char* X;                        // row panel: X + row0 * pitch
-    const char* Y;                        // column panel: Y + col0 * pitch
+    const char* X;                        // row panel: the group of row patch row0 (a multiple of 16)
+    const char* Y;                        // column panel: the group of column patch col0 (a multiple of 16)
     int* out;                             // [mrows, ldo] accumulators (units of 2^-14 in u . u)
     long long ldo, mrows, ncols;
-    int pitch, kp;
+    long long gpitch;                     // bytes of one 16-row group: 3 Kp / 64 k-steps of 1 KiB
+    int kp;
     int tiles_m, tiles_n, nsm, nsn, nsup;
     int tri_p;
     long long tri_row0, tri_col0;
 };
 
-// four 1 KiB LDS-DMA pieces (four 16-row groups: per-lane offsets o0..o3 from a wave-uniform base).  Inline asm so that
-// hipcc does not count them in vmcnt; M0 carries the wave-uniform LDS destination and is saved / restored because the
-// compiler owns it.  (An immediate offset on global_load_lds moves the LDS destination as well as the address.)
-__device__ __forceinline__ void dma4(unsigned o0, unsigned o1, unsigned o2, unsigned o3, const char* base, unsigned lds) {
+// two 1 KiB LDS-DMA pieces (two 16-row groups: wave-uniform bases b0, b1; lane l fetches bytes l * 16 .. + 15).  Inline
+// asm so that hipcc does not count them in vmcnt; M0 carries the wave-uniform LDS destination and is saved / restored
+// because the compiler owns it.
+__device__ __forceinline__ void dma2(unsigned voff, const char* b0, const char* b1, unsigned lds) {
     unsigned keep;
     asm volatile(
         "s_nop 4\n\t"
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %6\n\t"
+        "s_mov_b32 m0, %4\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %5\n\t"
-        "s_add_u32 m0, %6, 0x400\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_add_u32 m0, %4, 0x400\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %5\n\t"
-        "s_add_u32 m0, %6, 0x800\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %5\n\t"
-        "s_add_u32 m0, %6, 0xc00\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, %5\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(base), "s"(lds)
+        : "v"(voff), "s"(b0), "s"(b1), "s"(lds)
         : "memory", "scc");
 }
 
@@ -86,7 +83,7 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 // while it reads those of stage t+1 -- one wave per SIMD (256 accumulators per lane), so nothing else hides the LDS
 // latency.  Barrier t therefore says "stage t+1 has landed everywhere and everybody is through reading stage t", and
 // behind it stage t+4 goes into stage t's slot: three k-steps for a piece to arrive.
-__global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
+__global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem_i8[];
     // workgroup -> tile: ids go round-robin to the 8 XCDs; an XCD's 32 resident workgroups take one 4 x 8 block of
     // tiles (12 panels feed 32 tiles out of that XCD's L2).  Only blocks with a wanted tile are numbered, row by row, and
@@ -115,44 +112,43 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     if ((p.tri_col0 + n0 + GI_T - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;   // no (row frame < column frame) entry
 
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w >> 2, wc = w & 3;              // 128 row patches x 64 column patches per wave
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem_i8;
-    unsigned off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) off[j] = (unsigned)(((w * 4 + j) * 16 + (lane & 15)) * p.pitch + (lane >> 4) * 16);
-    const char* xb = p.X + m0 * p.pitch;
-    const char* yb = p.Y + n0 * p.pitch;
+    const unsigned voff = lane * 16;
+    // this wave's two groups of each panel (groups 2 w, 2 w + 1 of the tile's 16)
+    const char* xb = uniform_ptr(p.X + (m0 / 16 + w * 2) * p.gpitch);
+    const char* yb = uniform_ptr(p.Y + (n0 / 16 + w * 2) * p.gpitch);
     const int n64 = p.kp / GI_KS;
     const int nst = 6 * n64;
 
     auto issue = [&](int t) {
         const int seg = (t >= 3 * n64) + (t >= 5 * n64);                  // selects, not branches
-        const int xo = (t - (seg == 0 ? 0 : seg == 1 ? 3 * n64 : 5 * n64)) * GI_KS;
-        const int yo = xo + seg * p.kp;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (t & (GI_NSTAGE - 1)) * GI_STAGE + w * 4096);
-        dma4(off[0], off[1], off[2], off[3], uniform_ptr(xb + xo), dst);
-        dma4(off[0], off[1], off[2], off[3], uniform_ptr(yb + yo), dst + GI_HALF);
+        const int xo = (t - (seg == 0 ? 0 : seg == 1 ? 3 * n64 : 5 * n64)) * 1024;      // k-step blocks of 1 KiB
+        const int yo = xo + seg * n64 * 1024;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (t & (GI_NSTAGE - 1)) * GI_STAGE + w * 2048);
+        dma2(voff, xb + xo, xb + xo + p.gpitch, dst);
+        dma2(voff, yb + yo, yb + yo + p.gpitch, dst + GI_HALF);
     };
 
-    v4i acc[8][8];                          // [column group j of this wave][row group i]
+    v4i acc[4][8];                          // [column group j of this wave][row group i]
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[j][i] = v4i{0, 0, 0, 0};
-    v4i fx[2][8], fy[2][8];
+    v4i fx[2][8], fy[2][4];
 
     const char* sx = smem_i8 + (wr * 8) * 1024 + lane * 16;
-    const char* sy = smem_i8 + GI_HALF + (wc * 8) * 1024 + lane * 16;
+    const char* sy = smem_i8 + GI_HALF + (wc * 4) * 1024 + lane * 16;
     // s_waitcnt immediates (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
     // builtin, not inline asm, so that hipcc's own wait insertion knows the LDS reads are done
-    constexpr int GI_WAIT_VM16 = 0x4070, GI_WAIT_VM8 = 0x0078, GI_WAIT_VM0 = 0x0070;
+    constexpr int GI_WAIT_VM8 = 0x0078, GI_WAIT_VM4 = 0x0074, GI_WAIT_VM0 = 0x0070;
     // (a macro: through a generic lambda hipcc kept the fragment and accumulator arrays in scratch memory; and the steady
     // state has no branch in it -- with the tail's conditions inside, hipcc moved accumulators between register files
     // in every iteration)
 #define GI_BODY(T, CUR, NXT, WAIT, ISSUE)                                                                                  \
     {                                                                                                                      \
         const int t_ = (T);                                                                                                \
-        /* this wave's pieces of stage t+1 (8 instructions per stage; stages up to t+3 are in flight) and its LDS reads */ \
+        /* this wave's pieces of stage t+1 (4 instructions per stage; stages up to t+3 are in flight) and its LDS reads */ \
         /* of stage t, whose slot is about to be overwritten */                                                            \
         __builtin_amdgcn_s_waitcnt(WAIT);                                                                                  \
         asm volatile("" ::: "memory");                                                                                     \
@@ -162,12 +158,10 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
         const int so = ((t_ + 1) & (GI_NSTAGE - 1)) * GI_STAGE;                                                            \
         /* the reads of stage t+1 go out first and land under the 64 MFMAs (left alone hipcc puts them behind the MFMAs */ \
         /* and the next iteration waits for them); the last iteration reads a slot nobody writes any more: unused */      \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                    \
-            fx[NXT][j] = *(const v4i*)(sx + so + j * 1024);                                                                \
-            fy[NXT][j] = *(const v4i*)(sy + so + j * 1024);                                                                \
-        }                                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) fx[NXT][j] = *(const v4i*)(sx + so + j * 1024);                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) fy[NXT][j] = *(const v4i*)(sy + so + j * 1024);                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                  \
                 acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fy[CUR][j], fx[CUR][i], acc[j][i], 0, 0, 0);           \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
@@ -175,25 +169,24 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     // the K stages of one segment, two per trip (the fragment buffers alternate)
 #define GI_RUN(T_LO, T_HI)                                                                                                 \
     for (int t = (T_LO); t < (T_HI); t += 2) {                                                                             \
-        GI_BODY(t, 0, 1, GI_WAIT_VM16, true)                                                          \
-        GI_BODY(t + 1, 1, 0, GI_WAIT_VM16, true)                                                       \
+        GI_BODY(t, 0, 1, GI_WAIT_VM8, true)                                                          \
+        GI_BODY(t + 1, 1, 0, GI_WAIT_VM8, true)                                                       \
     }
     auto shift = [&]() {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[j][i] = acc[j][i] >> 7;
     };
 #pragma unroll
     for (int t = 0; t < GI_NSTAGE; ++t) issue(t);                        // nst >= 24
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                    // stage 0
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                    // stage 0
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        fx[0][j] = *(const v4i*)(sx + j * 1024);
-        fy[0][j] = *(const v4i*)(sy + j * 1024);
-    }
+    for (int j = 0; j < 8; ++j) fx[0][j] = *(const v4i*)(sx + j * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fy[0][j] = *(const v4i*)(sy + j * 1024);
     // (iteration 0's barrier finds stage 0's readers done only because every wave reads it before that barrier)
     // (one copy of the steady-state loop for the three segments: as three loops in a row, hipcc gave the first one a
     // register assignment that moved 200 accumulators between the register files in every trip)
@@ -204,23 +197,23 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
         GI_RUN(t_lo, t_hi)
         if (seg < 2) shift();
     }
-    GI_BODY(nst - 4, 0, 1, GI_WAIT_VM16, false)      // stages nst-3 .. nst-1 in flight
-    GI_BODY(nst - 3, 1, 0, GI_WAIT_VM8, false)
+    GI_BODY(nst - 4, 0, 1, GI_WAIT_VM8, false)       // stages nst-3 .. nst-1 in flight
+    GI_BODY(nst - 3, 1, 0, GI_WAIT_VM4, false)
     GI_BODY(nst - 2, 0, 1, GI_WAIT_VM0, false)
     GI_BODY(nst - 1, 1, 0, GI_WAIT_VM0, false)
 #undef GI_RUN
 #undef GI_BODY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // D[m][n] of MFMA (j, i): m = column patch (wc * 8 + j) * 16 + (lane / 16) * 4 + v, n = row patch (wr * 8 + i) * 16 + lane % 16
+    // D[m][n] of MFMA (j, i): m = column patch (wc * 4 + j) * 16 + (lane / 16) * 4 + v, n = row patch (wr * 8 + i) * 16 + lane % 16
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const long long r = m0 + (wr * 8 + i) * 16 + (lane & 15);
         if (r >= p.mrows) continue;
         int* orow = p.out + r * p.ldo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const long long c = n0 + (wc * 8 + j) * 16 + (lane >> 4) * 4;
+        for (int j = 0; j < 4; ++j) {
+            const long long c = n0 + (wc * 4 + j) * 16 + (lane >> 4) * 4;
             if (c + 3 < p.ldo) *(v4i*)(orow + c) = acc[j][i];          // ldo is a multiple of 4 >= ncols
         }
     }
@@ -235,11 +228,20 @@ __global__ void sim_keys_init_kernel(unsigned long long* keys) {
 __global__ __launch_bounds__(256) void sim_range_kernel(const double* __restrict__ x, long long n, unsigned long long* keys) {
     double lo = INFINITY, hi = -INFINITY;
     bool bad = false;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const double v = x[i];
-        bad |= !(fabs(v) < INFINITY);
-        lo = fmin(lo, v); hi = fmax(hi, v);
+    auto take = [&](double v) { bad |= !(fabs(v) < INFINITY); lo = fmin(lo, v); hi = fmax(hi, v); };
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
+    long long head = ((16 - ((unsigned long long)x & 15)) & 15) / 8;      // doubles in front of the first 16-byte boundary
+    if (head > n) head = n;
+    const double2* x2 = (const double2*)(x + head);
+    const long long n2 = (n - head) / 2;
+    long long i = tid;
+    for (; i + 3 * nth < n2; i += 4 * nth) {
+        const double2 a = x2[i], b = x2[i + nth], c = x2[i + 2 * nth], d = x2[i + 3 * nth];
+        take(a.x); take(a.y); take(b.x); take(b.y); take(c.x); take(c.y); take(d.x); take(d.y);
     }
+    for (; i < n2; i += nth) { const double2 a = x2[i]; take(a.x); take(a.y); }
+    if (tid < head) take(x[tid]);
+    if (tid == 0 && head + 2 * n2 < n) take(x[n - 1]);
     for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
     const bool any_bad = __ballot(bad) != 0;
     if ((threadIdx.x & 63) == 0) {
@@ -249,45 +251,89 @@ __global__ __launch_bounds__(256) void sim_range_kernel(const double* __restrict
     }
 }
 
-// One wave per patch row: the three slices into X and Y (a lane packs 4 consecutive k into a word), sum u and |u|^2.
-// keys[3]: the largest row sum (ordered key).
-__global__ __launch_bounds__(256) void sim_quant_kernel(const double* __restrict__ desc, long long rows, int H, int kp,
-                                                        unsigned long long* keys, char* __restrict__ X, char* __restrict__ Y,
-                                                        double* __restrict__ nu2) {
+// u = clamp((x - lo) / (hi - lo)) and its 21-bit fixed-point value (a NaN lands on 0; such datasets take the fp64 route)
+__device__ __forceinline__ double sim_unit(double x, double lo, double inv) {
+    const double u = (x - lo) * inv;
+    return u > 0.0 ? (u < 1.0 ? u : 1.0) : 0.0;
+}
+__device__ __forceinline__ int sim_fixed(double u) {
+    const int q = (int)(u * 2097152.0);                                 // floor (u >= 0)
+    return q > 2097151 ? 2097151 : q;
+}
+
+// One wave per patch row: sum u (its largest value into keys[3], an ordered key), |u|^2, and p = dot(score, row) -- the
+// same fma chain per lane and the same tree as match_ref.hip's row_stats_kernel, whose pass over the rows this saves.
+__global__ __launch_bounds__(256) void sim_rowsum_kernel(const double* __restrict__ desc, long long rows, int H,
+                                                         const double* __restrict__ score, unsigned long long* keys,
+                                                         double* __restrict__ nu2, double* __restrict__ proj) {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
     const double lo = dlc_f64_unkey(keys[0]), hi = dlc_f64_unkey(keys[1]);
-    const double range = hi - lo;
-    const double inv = range > 0.0 ? 1.0 / range : 0.0;
+    const double inv = hi - lo > 0.0 ? 1.0 / (hi - lo) : 0.0;
     const double* x = desc + r * H;
-    unsigned* xr = (unsigned*)(X + r * 3ll * kp);
-    unsigned* yr = (unsigned*)(Y + r * 3ll * kp);
-    const int wpk = kp / 4;                 // words per slice
-    double su = 0.0, s2 = 0.0;
-    for (int wd = lane; wd < wpk; wd += 64) {
-        unsigned w1 = 0, w2 = 0, w3 = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = wd * 4 + e;
-            if (k < H) {
-                double u = (x[k] - lo) * inv;
-                u = u > 0.0 ? (u < 1.0 ? u : 1.0) : 0.0;            // (a NaN lands on 0; such datasets take the fp64 route)
-                su += u; s2 = fma(u, u, s2);
-                int q = (int)(u * 2097152.0);                       // floor (u >= 0)
-                q = q > 2097151 ? 2097151 : q;
-                w1 |= (unsigned)(q >> 14) << (8 * e);
-                w2 |= (unsigned)((q >> 7) & 127) << (8 * e);
-                w3 |= (unsigned)(q & 127) << (8 * e);
-            }
-        }
-        xr[wd] = w1; xr[wpk + wd] = w2; xr[2 * wpk + wd] = w3;
-        yr[wd] = w3; yr[wpk + wd] = w2; yr[2 * wpk + wd] = w1;
+    double su = 0.0, s2 = 0.0, pr = 0.0;
+#pragma unroll 8
+    for (int k = lane; k < H; k += 64) {
+        const double v = x[k];
+        const double u = sim_unit(v, lo, inv);
+        su += u; s2 = fma(u, u, s2);
+        pr = fma(score[k], v, pr);
     }
-    for (int o = 32; o > 0; o >>= 1) { su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o); }
+    for (int o = 32; o > 0; o >>= 1) { su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o); pr += __shfl_xor(pr, o); }
     if (lane == 0) {
         nu2[r] = s2;
+        proj[r] = pr;
         atomicMax(&keys[3], dlc_f64_key(su));
+    }
+}
+
+// One workgroup per 16-row group, a wave per k-step of 64: lane l quantises row l % 16, k = ks * 64 + (l / 16) * 16 .. + 15
+// and stores 16 bytes of each slice at lane * 16 of that (group, slice, k-step) block -- 1 KiB per store instruction.
+// Rows past the last one and k >= H are zeros.
+__global__ __launch_bounds__(256) void sim_quant_kernel(const double* __restrict__ desc, long long rows, int H, int kp,
+                                                        const unsigned long long* __restrict__ keys, char* __restrict__ X,
+                                                        char* __restrict__ Y) {
+    const long long g = blockIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double lo = dlc_f64_unkey(keys[0]), hi = dlc_f64_unkey(keys[1]);
+    const double inv = hi - lo > 0.0 ? 1.0 / (hi - lo) : 0.0;
+    const long long r = g * 16 + (lane & 15);
+    const int nks = kp / 64;
+    const double* x = desc + r * H;
+    const bool vec = (H & 1) == 0 && ((unsigned long long)desc & 15) == 0;
+    char* xg = X + g * (3ll * nks * 1024) + lane * 16;
+    char* yg = Y + g * (3ll * nks * 1024) + lane * 16;
+    for (int ks = w; ks < nks; ks += 4) {
+        const int k0 = ks * 64 + (lane >> 4) * 16;
+        unsigned w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0}, w3[4] = {0, 0, 0, 0};
+        auto put = [&](int e, double v) {
+            const int q = sim_fixed(sim_unit(v, lo, inv));
+            w1[e >> 2] |= (unsigned)(q >> 14) << (8 * (e & 3));
+            w2[e >> 2] |= (unsigned)((q >> 7) & 127) << (8 * (e & 3));
+            w3[e >> 2] |= (unsigned)(q & 127) << (8 * (e & 3));
+        };
+        if (r < rows) {
+            if (vec && k0 + 16 <= H) {                                  // 128 contiguous, 16-byte aligned bytes per lane
+                double2 v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = *(const double2*)(x + k0 + 2 * e);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { put(2 * e, v[e].x); put(2 * e + 1, v[e].y); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (k0 + e < H) put(e, x[k0 + e]);
+            }
+        }
+        const uint4 v1 = make_uint4(w1[0], w1[1], w1[2], w1[3]), v2 = make_uint4(w2[0], w2[1], w2[2], w2[3]),
+                    v3 = make_uint4(w3[0], w3[1], w3[2], w3[3]);
+        *(uint4*)(xg + (0ll * nks + ks) * 1024) = v1;
+        *(uint4*)(xg + (1ll * nks + ks) * 1024) = v2;
+        *(uint4*)(xg + (2ll * nks + ks) * 1024) = v3;
+        *(uint4*)(yg + (0ll * nks + ks) * 1024) = v3;
+        *(uint4*)(yg + (1ll * nks + ks) * 1024) = v2;
+        *(uint4*)(yg + (2ll * nks + ks) * 1024) = v1;
     }
 }
 
@@ -297,8 +343,8 @@ __global__ __launch_bounds__(256) void sim_quant_kernel(const double* __restrict
 // one by one from 0 -- and (-1, 0) adds the two results before it.  A range of more than 128 splits at n / 2 rounded down
 // to a multiple of 8.  The pair kernel runs this program where candidates are too close for anything else.
 __global__ void sim_pairwise_program_kernel(int H, int2* prog, unsigned long long* len) {
+    __shared__ int st_start[32], st_n[32], st_phase[32];    // (in scratch memory this one thread took 0.2 ms)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int st_start[32], st_n[32], st_phase[32];
     int sp = 0, L = 0;
     st_start[0] = 0; st_n[0] = H; st_phase[0] = 0; sp = 1;
     while (sp > 0) {
@@ -315,43 +361,42 @@ __global__ void sim_pairwise_program_kernel(int H, int2* prog, unsigned long lon
 
 }  // namespace
 
+// rows of a panel: whole tiles, 256 rows of slack behind the last one (a tile of the column panel starts at any group)
+static int64_t sim_panel_rows(int64_t rows) { return (int64_t)dlc::align_up((size_t)rows, (size_t)GI_T) + GI_T + 16; }
+
 size_t sim_filter_panel_bytes(int64_t rows, int64_t H) {
     const size_t kp = dlc::align_up((size_t)H, (size_t)GI_KPAD);
-    // a tile of the column panel starts at any patch: 256 rows of slack behind the last whole tile
-    return (dlc::align_up((size_t)rows, (size_t)GI_T) + GI_T) * 3 * kp;
+    return (size_t)sim_panel_rows(rows) * 3 * kp;
 }
 
 // keys[6]: min key, max key, non-finite flag, max row sum key, direct evaluations (a count), length of prog (up to
-// 1023 int2 entries for H <= 32768).  X / Y: sim_filter_panel_bytes each (zeroed here).
-int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, unsigned long long* keys, char* X, char* Y,
-                       double* nu2, void* prog, hipStream_t st) {
-    const size_t pb = sim_filter_panel_bytes(rows, H);
+// 1023 int2 entries for H <= 32768).  X / Y: sim_filter_panel_bytes each.
+int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, unsigned long long* keys,
+                       char* X, char* Y, double* nu2, double* proj, void* prog, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     hipLaunchKernelGGL(sim_keys_init_kernel, dim3(1), dim3(64), 0, st, keys);
-    // only the padding rows need zeros (the kernel writes every word of a real row, padding columns included)
-    const size_t real = (size_t)rows * 3 * kp;
-    if (pb > real) {
-        DLC_HIP_CHECK(ctx, hipMemsetAsync(X + real, 0, pb - real, st));
-        DLC_HIP_CHECK(ctx, hipMemsetAsync(Y + real, 0, pb - real, st));
-    }
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
     hipLaunchKernelGGL(sim_range_kernel, dim3(2048), dim3(256), 0, st, desc, (long long)(rows * H), keys);
     DLC_LAUNCH_CHECK(ctx, "sim_range_kernel");
-    hipLaunchKernelGGL(sim_quant_kernel, dim3((unsigned)dlc::cdiv(rows, 4)), dim3(256), 0, st, desc, (long long)rows, (int)H, kp,
-                       keys, X, Y, nu2);
+    hipLaunchKernelGGL(sim_rowsum_kernel, dim3((unsigned)dlc::cdiv(rows, 4)), dim3(256), 0, st, desc, (long long)rows, (int)H, score,
+                       keys, nu2, proj);
+    DLC_LAUNCH_CHECK(ctx, "sim_rowsum_kernel");
+    hipLaunchKernelGGL(sim_quant_kernel, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(256), 0, st, desc, (long long)rows,
+                       (int)H, kp, keys, X, Y);
     DLC_LAUNCH_CHECK(ctx, "sim_quant_kernel");
     return DLC_OK;
 }
 
-// out[r, c] = acc of (row patch row0 + r, column patch col0 + c), r < mrows, c < ncols (ldo: a multiple of 4 >= ncols);
-// tiles without a (row frame < column frame) entry are skipped
+// out[r, c] = acc of (row patch row0 + r, column patch col0 + c), r < mrows, c < ncols; row0 and col0 multiples of 16
+// (the panels' groups), ldo a multiple of 4 >= ncols; tiles without a (row frame < column frame) entry are skipped
 int gram_upper_i8(dlc_ctx* ctx, int64_t mrows, int64_t ncols, int64_t H, const char* X, const char* Y, int* out, int64_t ldo,
                   int patches, int64_t row0, int64_t col0, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
+    if ((row0 & 15) || (col0 & 15)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "gram_upper_i8: panel origins must be multiples of 16");
     GramI8Args a;
-    a.pitch = 3 * kp; a.kp = kp;
-    a.X = X + row0 * (long long)a.pitch;
-    a.Y = Y + col0 * (long long)a.pitch;
+    a.gpitch = 3ll * kp * 16; a.kp = kp;
+    a.X = X + (row0 / 16) * a.gpitch;
+    a.Y = Y + (col0 / 16) * a.gpitch;
     a.out = out; a.ldo = ldo; a.mrows = mrows; a.ncols = ncols;
     a.tiles_m = (int)dlc::cdiv(mrows, (int64_t)GI_T); a.tiles_n = (int)dlc::cdiv(ncols, (int64_t)GI_T);
     a.nsm = (a.tiles_m + 3) / 4;
@@ -375,7 +420,7 @@ int gram_upper_i8(dlc_ctx* ctx, int64_t mrows, int64_t ncols, int64_t H, const c
     // bench.py's kernel-only timing (dlc_set_profiling): an event pair around the kernel on its stream
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
-    hipLaunchKernelGGL(gram_i8_kernel, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(gram_i8_kernel, dim3(grid), dim3(512), lds, st, a);
     DLC_LAUNCH_CHECK(ctx, "gram_i8_kernel");
     if (ctx->profiling) {
         DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[prof_slot], st));

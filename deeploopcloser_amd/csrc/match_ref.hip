@@ -367,9 +367,9 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                                                                 long long ldg, long long col0, const double* __restrict__ nu2,
                                                                 const double* __restrict__ proj, const double* __restrict__ score,
                                                                 const unsigned long long* __restrict__ keys, long long N, int P,
-                                                                int H, long long i_lo, long long i_hi, double ca, double cb,
-                                                                double* __restrict__ out_f64, long long* __restrict__ out_i64,
-                                                                const int2* __restrict__ prog) {
+                                                                int H, long long i_lo, long long i_hi, long long row_base,
+                                                                double ca, double cb, double* __restrict__ out_f64,
+                                                                long long* __restrict__ out_i64, const int2* __restrict__ prog) {
     extern __shared__ double ps_lds_all[];
     double* ps_lds = ps_lds_all + PF_STACK_BYTES / 8;            // in front: the value stacks of the summation program
     unsigned long long* n_fallback = const_cast<unsigned long long*>(keys) + 4;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
     const bool flat = !(dlc_f64_unkey(keys[1]) > dlc_f64_unkey(keys[0]));      // every descriptor value the same: all distances 0
     const double E = 0x1p-20 * dlc_f64_unkey(keys[3]) + (double)H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
     const double window = 2.0 * E + 1e-8;
-    const int* grow0 = G + (i * P - i_lo * P) * ldg - col0;
+    const int* grow0 = G + (i * P - row_base) * ldg - col0;      // G[0][0]: patches (row_base, col0), the panels' 16-row groups
     int v[8][4];
     auto fetch = [&](long long j0) {
         const long long jlo = j0 > i + 1 ? j0 : i + 1;
@@ -622,10 +622,10 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H) {
     w.proj = o; o += dlc::align_up((size_t)N * P * 8, 256);
     const bool filter = sim_use_filter(P, H);
     const size_t row_bytes = (size_t)N * P * 8;
-    const size_t row_bytes_i8 = ((size_t)N * P + 4) * 4;        // int32 accumulators, the leading dimension a multiple of 4
+    const size_t row_bytes_i8 = ((size_t)N * P + 20) * 4;       // int32 accumulators; the block starts at a 16-patch group, its leading dimension is a multiple of 4
     w.chunk_frames = sim_chunk(N, P, row_bytes);
     w.chunk_frames_i8 = sim_chunk(N, P, row_bytes_i8);
-    const size_t gram_f64 = (size_t)w.chunk_frames * P * row_bytes, gram_i8 = (size_t)w.chunk_frames_i8 * P * row_bytes_i8;
+    const size_t gram_f64 = (size_t)w.chunk_frames * P * row_bytes, gram_i8 = ((size_t)w.chunk_frames_i8 * P + 16) * row_bytes_i8;
     // (the filter's region holds at least one frame's fp64 rows: a dataset with a NaN / infinity in it takes the fp64
     // route after all, in as many chunks as that needs and without the transposed copy)
     w.gram_bytes = filter ? (gram_i8 > (size_t)P * row_bytes ? gram_i8 : (size_t)P * row_bytes) : gram_f64;
@@ -723,9 +723,6 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
     const long long rows = N * P;
     bool filter = sim_use_filter(P, H);
 
-    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)dlc::cdiv(rows, 4)), dim3(256), 0, st, desc, rows, (int)H, score,
-                       nrm2, proj);
-    DLC_LAUNCH_CHECK(ctx, "row_stats_kernel");
     hipLaunchKernelGGL(fill_diag_kernel, dim3((unsigned)dlc::cdiv(N, 256)), dim3(256), 0, st, (long long)N, out_f64,
                        (long long*)out_i64);
     DLC_LAUNCH_CHECK(ctx, "fill_diag_kernel");
@@ -736,7 +733,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         char* qx = ws + w.qx;
         char* qy = ws + w.qy;
         int2* prog = (int2*)(ws + w.prog);
-        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, rows, H, keys, qx, qy, nu2, prog, st);
+        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, rows, H, score, keys, qx, qy, nu2, proj, prog, st);
         if (rc != DLC_OK) return rc;
         // the one host read of this call: did the range pass meet a NaN or an infinity?  (Their distances are NaN in the
         // reference too, np.argmin then takes the first of them: the fp64 kernels reproduce that, a fixed-point
@@ -751,15 +748,16 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
                 long long i_hi = i_lo + w.chunk_frames_i8;
                 if (i_hi > N - 1) i_hi = N - 1;
                 if (i_hi <= i_lo) break;
-                const long long col0 = (i_lo + 1) * P;
-                const long long ncols = rows - col0;
+                // the panels are stored in groups of 16 patches: the block starts at the groups of its first row / column
+                const long long row_base = (i_lo * P) & ~15ll, col_base = ((i_lo + 1) * P) & ~15ll;
+                const long long ncols = rows - col_base;
                 const long long ldo = (ncols + 3) / 4 * 4;
-                const long long mrows = (i_hi - i_lo) * P;
-                rc = dlc_gemm::gram_upper_i8(ctx, mrows, ncols, H, qx, qy, (int*)gram, ldo, (int)P, i_lo * P, col0, st);
+                const long long mrows = i_hi * P - row_base;
+                rc = dlc_gemm::gram_upper_i8(ctx, mrows, ncols, H, qx, qy, (int*)gram, ldo, (int)P, row_base, col_base, st);
                 if (rc != DLC_OK) return rc;
                 hipLaunchKernelGGL(pair_score_filter_kernel, dim3(PS_GX, (unsigned)(i_hi - i_lo)), dim3(256), tile_lds, st, desc,
-                                   (const int*)gram, ldo, col0, nu2, proj, score, keys, (long long)N, (int)P, (int)H, i_lo, i_hi, a,
-                                   b, out_f64, (long long*)out_i64, prog);
+                                   (const int*)gram, ldo, col_base, nu2, proj, score, keys, (long long)N, (int)P, (int)H, i_lo, i_hi,
+                                   row_base, a, b, out_f64, (long long*)out_i64, prog);
                 DLC_LAUNCH_CHECK(ctx, "pair_score_filter_kernel");
             }
             if (getenv("DLC_SIM_DEBUG")) {       // experiments: how many arg-mins went to the direct evaluation
@@ -773,6 +771,9 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
     }
 
     // the fp64 Gram route
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)dlc::cdiv(rows, 4)), dim3(256), 0, st, desc, rows, (int)H, score,
+                       nrm2, proj);
+    DLC_LAUNCH_CHECK(ctx, "row_stats_kernel");
     long long chunk_frames = w.chunk_frames;
     bool use_t = (rows & 1) == 0;
     if (sim_use_filter(P, H)) {                  // the filter's workspace: no transposed copy, the chunk that fits its Gram region
