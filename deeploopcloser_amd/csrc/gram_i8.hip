@@ -126,7 +126,13 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
         const int xo = (t - (seg == 0 ? 0 : seg == 1 ? 3 * n64 : 5 * n64)) * 1024;      // k-step blocks of 1 KiB
         const int yo = xo + seg * n64 * 1024;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (t & (GI_NSTAGE - 1)) * GI_STAGE + w * 2048);
+#ifdef GI_EXP_NO_DMA            // timing experiments only (wrong results): what the loop costs without its operand traffic
+        if (t >= GI_NSTAGE) return;
+#endif
         dma2(voff, xb + xo, xb + xo + p.gpitch, dst);
+#ifdef GI_EXP_HALF_DMA          // ... and with half of it
+        if (t >= GI_NSTAGE) return;
+#endif
         dma2(voff, yb + yo, yb + yo + p.gpitch, dst + GI_HALF);
     };
 
@@ -139,6 +145,7 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
 
     const char* sx = smem_i8 + (wr * 8) * 1024 + lane * 16;
     const char* sy = smem_i8 + GI_HALF + (wc * 4) * 1024 + lane * 16;
+    // (Measured and not kept: the two waves of a SIMD issuing their DMA at opposite ends of the iteration -- 6.35 -> 6.58 ms.)
     // s_waitcnt immediates (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
     // builtin, not inline asm, so that hipcc's own wait insertion knows the LDS reads are done
     constexpr int GI_WAIT_VM8 = 0x0078, GI_WAIT_VM4 = 0x0074, GI_WAIT_VM0 = 0x0070;
@@ -154,17 +161,23 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
         asm volatile("" ::: "memory");                                                                                     \
         __builtin_amdgcn_s_barrier();                                                                                      \
         asm volatile("" ::: "memory");                                                                                     \
-        if (ISSUE) issue(t_ + GI_NSTAGE);                                                                                  \
         const int so = ((t_ + 1) & (GI_NSTAGE - 1)) * GI_STAGE;                                                            \
-        /* the reads of stage t+1 go out first and land under the 64 MFMAs (left alone hipcc puts them behind the MFMAs */ \
-        /* and the next iteration waits for them); the last iteration reads a slot nobody writes any more: unused */      \
+        /* MFMAs first (their fragments are in registers), the 12 reads of stage t+1 one per pair of MFMAs, the DMA of  */ \
+        /* stage t+4 behind them: all eight waves leave the barrier together, and whatever stands between the barrier    */ \
+        /* and a wave's first MFMA is time both matrix-pipe users of a SIMD spend idle (reads + DMA first: 6.8 ms)       */ \
+        /* (the last iteration reads a slot nobody writes any more: unused) */                                            \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) fx[NXT][j] = *(const v4i*)(sx + so + j * 1024);                      \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) fy[NXT][j] = *(const v4i*)(sy + so + j * 1024);                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                  \
                 acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fy[CUR][j], fx[CUR][i], acc[j][i], 0, 0, 0);           \
+        _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                             \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if (ISSUE) issue(t_ + GI_NSTAGE);                                                                                  \
     }
     // the K stages of one segment, two per trip (the fragment buffers alternate)
 #define GI_RUN(T_LO, T_HI)                                                                                                 \

@@ -1,8 +1,11 @@
 """The SDAV similarity matrix at the reference's size (1063 frames x 30 patches x 2500) a few times, for rocprofv3:
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sim -- python3 scripts/prof_similarity.py [saturated|uniform]"""
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sim -- python3 scripts/prof_similarity.py [saturated|uniform] [library]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if len(sys.argv) > 2:                      # another build of the library
+    import deeploopcloser_amd._lib as L
+    L.LIB_PATH = os.path.abspath(sys.argv[2])
 import deeploopcloser_amd as dlc
 
 eng = dlc.default_engine()
