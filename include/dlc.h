@@ -254,9 +254,18 @@ int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows
  * score [H] comes from dlc_sdav_distinctive_score.  out_f64 [N,N] receives the
  * float scores (+inf where a matched pair is identical); out_i64 (may be NULL)
  * the reference's int64 matrix (truncation toward zero, non-finite -> INT64_MIN).
- * The workspace holds the descriptors' transpose and the patch-to-patch Gram blocks, in row chunks
- * of at most 8 GiB: sized for 288 GB of HBM, it is 8.7 GB at the reference's 1063 frames (one chunk)
- * and stays below 9.5 GB + N*P*H*8 bytes for any N.
+ * What the reference takes from the patch-to-patch distances is the arg-min only (np.argmin of
+ * np.linalg.norm, :30-37).  For P <= 32 and H <= 32768 it is decided by exact integer products of
+ * the descriptors' 21-bit fixed-point values (int8 MFMA, csrc/gram_i8.hip), whose error bound says
+ * which candidates it cannot separate; those are evaluated directly in fp64, and where that is
+ * still a tie to 1e-11, as np.linalg.norm forms them (NumPy's pairwise summation order).  Other
+ * shapes, a dataset with a NaN or an infinity in it, or DLC_SIM_GRAM=f64 in the environment take
+ * the fp64 Gram matrix (|a|^2 + |b|^2 - 2 a.b).  The call is stream-ordered except for ONE blocking
+ * 8-byte device-to-host read in the filter form (the NaN / infinity flag of the range pass).
+ * The workspace holds the quantised descriptors (or their fp64 transpose) and the patch-to-patch
+ * product blocks, in row chunks of at most 8 GiB: sized for 288 GB of HBM, it is 4.6 GB at the
+ * reference's 1063 frames (one chunk; 8.7 GB in the fp64 form) and stays below 9.5 GB + N*P*H*8
+ * bytes for any N.
  */
 size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int64_t H);
 int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H,
@@ -408,7 +417,7 @@ int dlc_set_scratch(dlc_ctx* ctx, void* scratch, size_t bytes);
  * With profiling enabled every dlc_cosine_topk / dlc_cosine_score_groups call records a
  * hipEvent pair on the call's stream around its dominant kernel (the MFMA score GEMM), and so
  * does every launch of the dense fp64 / fp32 GEMM kernel (dlc_gemm_bias_act, dlc_conv2d_nhwc_f64,
- * the layers of dlc_sdav_encode, the Gram GEMMs of dlc_sdav_similarity_matrix), into one
+ * the layers of dlc_sdav_encode, the int8 / fp64 Gram kernels of dlc_sdav_similarity_matrix), into one
  * ring of DLC_PROFILE_RING slots.  dlc_profile_gemm_ms() waits for the recorded
  * events and writes the durations (milliseconds, oldest first) of the last
  * min(calls, capacity, DLC_PROFILE_RING) calls to the HOST array out_ms; it
