@@ -2,8 +2,8 @@
 many random shapes, every result checked bit for bit against an independent route through the library --
   GEMM         LDS-DMA kernel  vs  register-staged kernel (odd row stride of A);
   convolution  implicit GEMM (+ per-frame min / max keys)  vs  im2col + GEMM (+ row min / max pass);
-  similarity   whole matrix  vs  frame ranges scored alone.
-Usage: python scripts/stress_fp64.py [seconds per family, default 60] [seed]"""
+  similarity   whole matrix  vs  frame ranges scored alone;  arg-min filter (int8 products)  vs  fp64 Gram form.
+Usage: python scripts/stress_fp64.py [seconds per family, default 60] [seed] [gemm | conv | similarity]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -68,10 +68,36 @@ def conv_case():
 
 
 def sim_case():
-    p = int(rng.randint(1, 33)); hdim = 2 * int(rng.randint(8, 80)); n = int(rng.randint(2, max(3, 9000 // p)))
-    ds = torch.rand((n, p, hdim), generator=g, device=eng.device, dtype=torch.float64)
+    """whole matrix vs frame ranges scored alone, and the arg-min filter (csrc/gram_i8.hip) vs the fp64 Gram form"""
+    p = int(rng.randint(1, 33)); hdim = 2 * int(rng.randint(8, 80)) if rng.rand() < 0.7 else int(rng.randint(1, 700))
+    n = int(rng.randint(2, max(3, 9000 // p)))
+    kind = int(rng.randint(0, 4))
+    if kind == 0:
+        ds = torch.rand((n, p, hdim), generator=g, device=eng.device, dtype=torch.float64)
+    elif kind == 1:
+        ds = torch.sigmoid(35.0 * torch.randn((n, p, hdim), generator=g, device=eng.device, dtype=torch.float64))
+    elif kind == 2:
+        ds = 5.0 * torch.randn((n, p, hdim), generator=g, device=eng.device, dtype=torch.float64) + 2.0
+    else:                                                             # a video: every frame the one before plus a little noise
+        base = torch.rand((1, p, hdim), generator=g, device=eng.device, dtype=torch.float64)
+        ds = base + 1e-3 * torch.cumsum(torch.randn((n, p, hdim), generator=g, device=eng.device, dtype=torch.float64), 0)
+    if n * p > 8 and rng.rand() < 0.3:                                # duplicated patches: exact ties, first index wins
+        flat = ds.reshape(n * p, hdim)
+        src = torch.from_numpy(rng.randint(0, n * p, size=n * p // 5 + 1)).to(eng.device)
+        dst = torch.from_numpy(rng.randint(0, n * p, size=n * p // 5 + 1)).to(eng.device)
+        flat[dst] = flat[src].clone()
     score = eng.distinctive_score(ds, 0.5, 0.2)
+    os.environ["DLC_SIM_GRAM"] = "i8"
     mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+    if hdim >= 32 and kind in (0, 2):
+        # (narrow or saturated descriptors have patch distances that agree to the last bits -- sums of zeros and ones:
+        # there the two forms may take different arg-mins, 4 entries of 71 000 at 267 x 25 x 78 saturated; the filter
+        # takes NumPy's -- tests/test_gpu_parity.py::test_similarity_tiny_descriptors_follow_the_reference)
+        mf, mi = mf.clone(), mi.clone()
+        os.environ["DLC_SIM_GRAM"] = "f64"
+        rf, ri = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+        os.environ["DLC_SIM_GRAM"] = "i8"
+        assert torch.equal(mf, rf) and torch.equal(mi, ri), ("filter vs fp64 Gram", n, p, hdim, kind, int((mf != rf).sum()))
     assert torch.equal(mf, mf.T) and torch.equal(mi, mi.T)
     lo = int(rng.randint(0, n - 1)); hi = int(rng.randint(lo + 2, n + 1)) if lo + 2 <= n else n
     sub, _ = eng.sdav_similarity_matrix(ds[lo:hi].contiguous(), score, 10.0, -10.0, want_int64=False)
@@ -79,7 +105,10 @@ def sim_case():
     return (n, p, hdim)
 
 
+only = sys.argv[3] if len(sys.argv) > 3 else None
 for name, fn in (("gemm", gemm_case), ("conv", conv_case), ("similarity", sim_case)):
+    if only and name != only:
+        continue
     t0, cnt, last = time.time(), 0, None
     while time.time() - t0 < budget:
         r = fn()

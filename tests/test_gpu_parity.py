@@ -538,6 +538,31 @@ def test_similarity_near_ties_follow_the_reference(dlc, monkeypatch):
         assert np.abs(got[fin] - ref[fin]).max() <= 1e-9 * max(1.0, np.abs(ref[fin]).max()), (n, p, h)
 
 
+def test_similarity_tiny_descriptors_follow_the_reference(dlc, monkeypatch):
+    """Two- and three-dimensional saturated descriptors: most patch distances of a frame pair agree to the last bits
+    (values 0, 1 and 1 - 1e-12 in every combination), so nearly every arg-min is one the integer products cannot decide
+    and many are ties only NumPy's own summation order resolves.  The matrix must still be the reference's."""
+    from oracle import similarity as osim
+    monkeypatch.delenv("DLC_SIM_GRAM", raising=False)
+    rng = np.random.RandomState(23)
+    for n, p, h in [(12, 6, 3), (9, 30, 2), (14, 5, 1), (7, 32, 9), (10, 17, 8)]:
+        ds = 1.0 / (1.0 + np.exp(-35.0 * rng.standard_normal((n, p, h))))
+        got = dlc.SimilarityCalculator(ds).similarity_matrix(as_int64=False)
+        ref = osim.similarity_matrix_f64(ds)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isposinf(got), np.isposinf(ref)) and np.array_equal(np.isnan(got), np.isnan(ref)), (n, p, h)
+        assert np.abs(got[fin] - ref[fin]).max() <= 1e-9 * max(1.0, np.abs(ref[fin]).max()), (n, p, h)
+    # zeros and ones with 1e-13 of noise: every squared distance an integer up to the last bits, ties among the
+    # candidates of nearly every arg-min, at widths of one, several and many leaves of the pairwise summation
+    for n, p, h in [(10, 25, 78), (6, 20, 300), (4, 30, 2500), (5, 11, 129), (5, 8, 1031)]:
+        ds = (rng.uniform(size=(n, p, h)) < 0.5).astype(np.float64) + 1e-13 * rng.uniform(size=(n, p, h))
+        got = dlc.SimilarityCalculator(ds).similarity_matrix(as_int64=False)
+        ref = osim.similarity_matrix_f64(ds)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isposinf(got), np.isposinf(ref)), (n, p, h)
+        assert np.abs(got[fin] - ref[fin]).max() <= 1e-9 * max(1.0, np.abs(ref[fin]).max()), (n, p, h)
+
+
 def test_similarity_filter_equals_fp64_gram_route(eng, monkeypatch):
     """The two routes of dlc_sdav_similarity_matrix -- exact integer products of 21-bit fixed-point descriptors that
     decide the arg-min (with a direct fp64 evaluation where their error bound cannot), and the fp64 Gram matrix --
