@@ -193,6 +193,19 @@ __device__ __forceinline__ long long f64_to_i64_trunc(double v) {
     return (long long)v;   // truncation toward zero
 }
 
+// |dot(score, x_a - x_b)| evaluated directly (SimilarityCalculator.py:42-43) where the difference of the two projections
+// has cancelled: all 64 lanes of the wave on the two rows, lane-strided fma chains and the xor tree -- every lane
+// returns the same sum.  (One lane walking the H elements alone, two dependent loads per step, held its whole
+// workgroup for milliseconds: a handful of such patches set the duration of the pair kernels.)
+__device__ __forceinline__ double weighted_diff_wave(const double* __restrict__ xa, const double* __restrict__ xb,
+                                                     const double* __restrict__ score, int H, int lane) {
+    double s_ = 0.0;
+#pragma unroll 8
+    for (int k = lane; k < H; k += 64) s_ = fma(score[k], xa[k] - xb[k], s_);
+    for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
+    return s_;
+}
+
 // One wave per frame pair (i, j), i in [i_lo, i_hi), j in (i, N).  G is the Gram
 // block  desc[i_lo*P .. i_hi*P) . desc[col0 ..)^T  with leading dimension ldg.
 __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restrict__ desc, const double* __restrict__ G,
@@ -205,7 +218,9 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
     const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long i = i_lo + blockIdx.y;
     if (i >= i_hi || j >= N || j <= i) return;
-    double term = 0.0;
+    double term = 0.0, wd = 1.0;
+    long long rb = 0;
+    bool redo = false;
     if (lane < P) {
         const long long ra = i * P + lane;
         const double* grow = G + (ra - i_lo * P) * ldg + (j * P - col0);
@@ -218,17 +233,17 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
             const double dist = sqrt(d2);                       // np.linalg.norm, :34
             if (b == 0 || dist < best) { best = dist; bi = b; } // np.argmin: first minimum
         }
-        const long long rb = j * P + bi;
-        double wd = fabs(proj[ra] - proj[rb]);                  // |dot(score, m_i - m_j*)|, :42-43
-        if (wd < 1e-6 * (fabs(proj[ra]) + fabs(proj[rb]))) {    // cancellation: evaluate the difference directly
-            const double* xa = desc + ra * H;
-            const double* xb = desc + rb * H;
-            double s = 0.0;
-            for (int k = 0; k < H; ++k) s = fma(score[k], xa[k] - xb[k], s);
-            wd = fabs(s);
-        }
-        term = ca + cb * log(wd);                               // :48
+        rb = j * P + bi;
+        wd = fabs(proj[ra] - proj[rb]);                         // |dot(score, m_i - m_j*)|, :42-43
+        redo = wd < 1e-6 * (fabs(proj[ra]) + fabs(proj[rb]));   // cancellation: evaluate the difference directly
     }
+    for (unsigned long long m = __ballot(redo); m; m &= m - 1) {
+        const int src = __ffsll((long long)m) - 1;
+        const long long rb_s = __shfl(rb, src);
+        const double s_ = weighted_diff_wave(desc + (i * P + src) * H, desc + rb_s * H, score, H, lane);
+        if (lane == src) wd = fabs(s_);
+    }
+    if (lane < P) term = ca + cb * log(wd);                     // :48
     for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o);
     if (lane == 0) {
         out_f64[i * N + j] = term;
@@ -299,7 +314,9 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
         const long long jn = j0 + (long long)PS_GX * PS_JT;
         if (jn < N) fetch(jn);
         const long long j = j0 + jj;
-        double term = 0.0;
+        double term = 0.0, wd = 1.0;
+        long long rb = 0;
+        bool redo = false;
         const bool pair_ok = j > i && j < N;
         if (pair_ok && a < P) {
             const double* grow = g + a * row + jj * P;
@@ -332,18 +349,18 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
                     if (b == 0 || dist < best) { best = dist; bi = b; }     // np.argmin: first minimum
                 }
             }
-            const long long rb = j * P + bi;
+            rb = j * P + bi;
             const double pb = proj[rb];
-            double wd = fabs(pa - pb);                          // |dot(score, m_i - m_j*)|, :42-43
-            if (wd < 1e-6 * (fabs(pa) + fabs(pb))) {            // cancellation: evaluate the difference directly
-                const double* xa = desc + ra * H;
-                const double* xb = desc + rb * H;
-                double s_ = 0.0;
-                for (int k = 0; k < H; ++k) s_ = fma(score[k], xa[k] - xb[k], s_);
-                wd = fabs(s_);
-            }
-            term = ca + cb * log(wd);                           // :48
+            wd = fabs(pa - pb);                                 // |dot(score, m_i - m_j*)|, :42-43
+            redo = wd < 1e-6 * (fabs(pa) + fabs(pb));           // cancellation: evaluate the difference directly
         }
+        for (unsigned long long m = __ballot(redo); m; m &= m - 1) {
+            const int src = __ffsll((long long)m) - 1;
+            const long long rb_s = __shfl(rb, src);
+            const double s_ = weighted_diff_wave(desc + (i * P + (src & 31)) * H, desc + rb_s * H, score, H, lane);
+            if (lane == src) wd = fabs(s_);
+        }
+        if (pair_ok && a < P) term = ca + cb * log(wd);         // :48
         for (int o = 16; o > 0; o >>= 1) term += __shfl_xor(term, o);      // the 32 lanes of this pair (lanes >= P hold 0)
         if (pair_ok && a == 0) {
             out_f64[i * N + j] = term;
@@ -461,6 +478,7 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                 if (!((cm >> b) & 1)) continue;
                 const double* xb = xj + (long long)b * H;
                 double s_ = 0.0;
+#pragma unroll 8
                 for (int k = lane; k < H; k += 64) { const double d = xb[k] - xa[k]; s_ = fma(d, d, s_); }
                 for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
                 if (lane == b) mine = s_;
@@ -536,20 +554,22 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
             if (lane == src) bi = ebi;
             if (lane == 0) ++fallbacks;
         }
-        double term = 0.0;
+        double term = 0.0, wd = 1.0;
+        long long rb = 0;
+        bool redo = false;
         if (live) {
-            const long long rb = j * P + bi;
+            rb = j * P + bi;
             const double pb = proj[rb];
-            double wd = fabs(pa - pb);                          // |dot(score, m_i - m_j*)|, :42-43
-            if (wd < 1e-6 * (fabs(pa) + fabs(pb))) {            // cancellation: evaluate the difference directly
-                const double* xa = desc + ra * H;
-                const double* xb = desc + rb * H;
-                double s_ = 0.0;
-                for (int k = 0; k < H; ++k) s_ = fma(score[k], xa[k] - xb[k], s_);
-                wd = fabs(s_);
-            }
-            term = ca + cb * log(wd);                           // :48
+            wd = fabs(pa - pb);                                 // |dot(score, m_i - m_j*)|, :42-43
+            redo = wd < 1e-6 * (fabs(pa) + fabs(pb));           // cancellation: evaluate the difference directly
         }
+        for (unsigned long long m = __ballot(redo); m; m &= m - 1) {
+            const int src = __ffsll((long long)m) - 1;
+            const long long rb_s = __shfl(rb, src);
+            const double s_ = weighted_diff_wave(desc + (i * P + (src & 31)) * H, desc + rb_s * H, score, H, lane);
+            if (lane == src) wd = fabs(s_);
+        }
+        if (live) term = ca + cb * log(wd);                     // :48
         for (int o = 16; o > 0; o >>= 1) term += __shfl_xor(term, o);
         if (pair_ok && a == 0) {
             out_f64[i * N + j] = term;
