@@ -406,7 +406,9 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
     const double window = 2.0 * E + 1e-8;
     const int* grow0 = G + (i * P - row_base) * ldg - col0;      // G[0][0]: patches (row_base, col0), the panels' 16-row groups
     int v[8][4];
+    double nbv = 0.0;                                            // this thread's |u_b|^2 of the run in flight (width <= 256)
     auto fetch = [&](long long j0) {
+        nbv = (tid < width && j0 * P + tid < N * P) ? nu2[j0 * P + tid] : 0.0;
         const long long jlo = j0 > i + 1 ? j0 : i + 1;
         const long long jhi = j0 + PS_JT < N ? j0 + PS_JT : N;
         const int c_lo = (int)((jlo - j0) * P), c_hi = (int)((jhi - j0) * P);
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                 const int ar = w + 4 * r, c = lane + 64 * cc;
                 if (ar < P && c < width) g[ar * row + c] = v[r][cc];
             }
-        for (int c = tid; c < width; c += 256) nb[c] = (j0 * P + c < N * P) ? nu2[j0 * P + c] : 0.0;
+        if (tid < width) nb[tid] = nbv;                          // (loaded here it was a global-memory latency per run on the critical path)
         __syncthreads();
         const long long jn = j0 + (long long)PS_GX * PS_JT;
         if (jn < N) fetch(jn);
@@ -622,7 +624,12 @@ long long sim_chunk(int64_t N, int64_t P, size_t row_bytes) {
     // Gram row chunk: at most ~8 GiB of the 288 GB (the work is triangular, so every chunk's launch is smaller than
     // the one before and each pays its own last partial round of the chip: 1063 frames in 9 chunks of <= 1 GiB lost
     // ~5 % to that; 8 GiB holds all of them in one), at least one frame
-    long long cf = (long long)((8ull << 30) / (row_bytes * (size_t)P));
+    size_t cap = 8ull << 30;
+    if (const char* e = getenv("DLC_SIM_CHUNK_BYTES")) {      // tests: several chunks at small sizes
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= (1ull << 16)) cap = (size_t)v;
+    }
+    long long cf = (long long)(cap / (row_bytes * (size_t)P));
     if (cf < 1) cf = 1;
     if (cf >= N - 1) {
         cf = N > 1 ? N - 1 : 1;                  // everything at once (the last frame has no later frame to pair with)

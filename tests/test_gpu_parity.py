@@ -602,6 +602,22 @@ def test_similarity_filter_equals_fp64_gram_route(eng, monkeypatch):
     assert torch.equal(torch.nan_to_num(f_got), torch.nan_to_num(f_ref))
 
 
+def test_similarity_filter_in_row_chunks(eng, monkeypatch):
+    """The product block in several row chunks (DLC_SIM_CHUNK_BYTES shrinks the 8 GiB cap): chunk origins that are not
+    multiples of the panels' 16-patch groups, for patch counts that are and are not; the same matrix as in one chunk."""
+    g = torch.Generator(device=eng.device); g.manual_seed(11)
+    for n, p, h in [(150, 30, 64), (90, 7, 130), (64, 32, 256), (200, 13, 40)]:
+        ds = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
+        score = eng.distinctive_score(ds, 0.5, 0.2)
+        monkeypatch.delenv("DLC_SIM_CHUNK_BYTES", raising=False)
+        f_one, i_one = (t.clone() for t in eng.sdav_similarity_matrix(ds, score, 10.0, -10.0))
+        for frames_per_chunk in (1, 3, 17):
+            monkeypatch.setenv("DLC_SIM_CHUNK_BYTES", str(max(1 << 16, frames_per_chunk * p * (n * p + 20) * 4 + 64)))
+            f_c, i_c = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+            assert torch.equal(f_c, f_one) and torch.equal(i_c, i_one), (n, p, h, frames_per_chunk)
+        monkeypatch.delenv("DLC_SIM_CHUNK_BYTES")
+
+
 def test_distance_vs_reference_fixture(dlc, golden):
     g = golden("distance.npz")
     dc = dlc.DistanceCalculator
