@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void sim_range_kernel(const double* __restrict
     const double2* x2 = (const double2*)(x + head);
     const long long n2 = (n - head) / 2;
     long long i = tid;
-    for (; i + 3 * nth < n2; i += 4 * nth) {
+    for (; i + 3 * nth < n2; i += 4 * nth) {                               // (eight loads per thread on 4096 workgroups: 0.24 -> 0.41 ms)
         const double2 a = x2[i], b = x2[i + nth], c = x2[i + 2 * nth], d = x2[i + 3 * nth];
         take(a.x); take(a.y); take(b.x); take(b.y); take(c.x); take(c.y); take(d.x); take(d.y);
     }
@@ -274,79 +274,92 @@ __device__ __forceinline__ int sim_fixed(double u) {
     return q > 2097151 ? 2097151 : q;
 }
 
-// One wave per patch row: sum u (its largest value into keys[3], an ordered key), |u|^2, and p = dot(score, row) -- the
-// same fma chain per lane and the same tree as match_ref.hip's row_stats_kernel, whose pass over the rows this saves.
-__global__ __launch_bounds__(256) void sim_rowsum_kernel(const double* __restrict__ desc, long long rows, int H,
-                                                         const double* __restrict__ score, unsigned long long* keys,
-                                                         double* __restrict__ nu2, double* __restrict__ proj) {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= rows) return;
-    const double lo = dlc_f64_unkey(keys[0]), hi = dlc_f64_unkey(keys[1]);
-    const double inv = hi - lo > 0.0 ? 1.0 / (hi - lo) : 0.0;
-    const double* x = desc + r * H;
-    double su = 0.0, s2 = 0.0, pr = 0.0;
-#pragma unroll 8
-    for (int k = lane; k < H; k += 64) {
-        const double v = x[k];
-        const double u = sim_unit(v, lo, inv);
-        su += u; s2 = fma(u, u, s2);
-        pr = fma(score[k], v, pr);
-    }
-    for (int o = 32; o > 0; o >>= 1) { su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o); pr += __shfl_xor(pr, o); }
-    if (lane == 0) {
-        nu2[r] = s2;
-        proj[r] = pr;
-        atomicMax(&keys[3], dlc_f64_key(su));
-    }
-}
-
-// One workgroup per 16-row group, a wave per k-step of 64: lane l quantises row l % 16, k = ks * 64 + (l / 16) * 16 .. + 15
-// and stores 16 bytes of each slice at lane * 16 of that (group, slice, k-step) block -- 1 KiB per store instruction.
-// Rows past the last one and k >= H are zeros.
-__global__ __launch_bounds__(256) void sim_quant_kernel(const double* __restrict__ desc, long long rows, int H, int kp,
-                                                        const unsigned long long* __restrict__ keys, char* __restrict__ X,
-                                                        char* __restrict__ Y) {
+// The pass over the descriptors that both forms of the similarity share, a workgroup per group of 16 patch rows, a wave
+// per k-step of 64 elements (w, w + 4, ..), lane l on row l % 16, elements ks * 64 + (l / 16) * 16 .. + 15 -- 128
+// contiguous bytes per lane:
+//   |x|^2 (the fp64 Gram form's norms) and p = dot(score, row) for every row -- per lane in k order, then the row's four
+//   lanes (xor 16, 32), then its four waves in order: one fixed summation order for both forms, whose projections must
+//   agree bit for bit;
+//   QUANT (the filter): sum u (its largest value into keys[3], an ordered key), |u|^2, and the three 7-bit slices of
+//   the 21-bit fixed-point value, 16 bytes of each per lane at lane * 16 of that (group, slice, k-step) block -- 1 KiB per
+//   store instruction.  Rows past the last one and k >= H are zeros there and take no part in the sums.
+template <bool QUANT>
+__global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict__ desc, long long rows, int H, int kp,
+                                                       const double* __restrict__ score, unsigned long long* keys,
+                                                       char* __restrict__ X, char* __restrict__ Y, double* __restrict__ nrm2,
+                                                       double* __restrict__ nu2, double* __restrict__ proj) {
+    __shared__ double red[4][16][4];
     const long long g = blockIdx.x;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const double lo = dlc_f64_unkey(keys[0]), hi = dlc_f64_unkey(keys[1]);
-    const double inv = hi - lo > 0.0 ? 1.0 / (hi - lo) : 0.0;
-    const long long r = g * 16 + (lane & 15);
-    const int nks = kp / 64;
-    const double* x = desc + r * H;
-    const bool vec = (H & 1) == 0 && ((unsigned long long)desc & 15) == 0;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, rr = lane & 15, chunk = lane >> 4;
+    double lo = 0.0, inv = 0.0;
+    if constexpr (QUANT) {
+        const double hi = dlc_f64_unkey(keys[1]);
+        lo = dlc_f64_unkey(keys[0]);
+        inv = hi - lo > 0.0 ? 1.0 / (hi - lo) : 0.0;
+    }
+    const long long r = g * 16 + rr;
+    const bool row_ok = r < rows;
+    const int nks = QUANT ? kp / 64 : (H + 63) / 64;
+    const double* x = desc + (row_ok ? r : 0) * H;
+    const bool vec = (H & 1) == 0 && ((unsigned long long)desc & 15) == 0 && ((unsigned long long)score & 15) == 0;
     char* xg = X + g * (3ll * nks * 1024) + lane * 16;
     char* yg = Y + g * (3ll * nks * 1024) + lane * 16;
+    double n2 = 0.0, pr = 0.0, su = 0.0, s2 = 0.0;
     for (int ks = w; ks < nks; ks += 4) {
-        const int k0 = ks * 64 + (lane >> 4) * 16;
+        const int k0 = ks * 64 + chunk * 16;
         unsigned w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0}, w3[4] = {0, 0, 0, 0};
-        auto put = [&](int e, double v) {
-            const int q = sim_fixed(sim_unit(v, lo, inv));
-            w1[e >> 2] |= (unsigned)(q >> 14) << (8 * (e & 3));
-            w2[e >> 2] |= (unsigned)((q >> 7) & 127) << (8 * (e & 3));
-            w3[e >> 2] |= (unsigned)(q & 127) << (8 * (e & 3));
+        auto put = [&](int e, double v, double sc) {
+            n2 = fma(v, v, n2);
+            pr = fma(sc, v, pr);
+            if constexpr (QUANT) {
+                const double u = sim_unit(v, lo, inv);
+                su += u; s2 = fma(u, u, s2);
+                const int q = sim_fixed(u);
+                w1[e >> 2] |= (unsigned)(q >> 14) << (8 * (e & 3));
+                w2[e >> 2] |= (unsigned)((q >> 7) & 127) << (8 * (e & 3));
+                w3[e >> 2] |= (unsigned)(q & 127) << (8 * (e & 3));
+            }
         };
-        if (r < rows) {
+        if (row_ok) {
             if (vec && k0 + 16 <= H) {                                  // 128 contiguous, 16-byte aligned bytes per lane
-                double2 v[8];
+                double2 v[8], c[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = *(const double2*)(x + k0 + 2 * e);
+                for (int e = 0; e < 8; ++e) { v[e] = *(const double2*)(x + k0 + 2 * e); c[e] = *(const double2*)(score + k0 + 2 * e); }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { put(2 * e, v[e].x); put(2 * e + 1, v[e].y); }
+                for (int e = 0; e < 8; ++e) { put(2 * e, v[e].x, c[e].x); put(2 * e + 1, v[e].y, c[e].y); }
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (k0 + e < H) put(e, x[k0 + e]);
+                    if (k0 + e < H) put(e, x[k0 + e], score[k0 + e]);
             }
         }
-        const uint4 v1 = make_uint4(w1[0], w1[1], w1[2], w1[3]), v2 = make_uint4(w2[0], w2[1], w2[2], w2[3]),
-                    v3 = make_uint4(w3[0], w3[1], w3[2], w3[3]);
-        *(uint4*)(xg + (0ll * nks + ks) * 1024) = v1;
-        *(uint4*)(xg + (1ll * nks + ks) * 1024) = v2;
-        *(uint4*)(xg + (2ll * nks + ks) * 1024) = v3;
-        *(uint4*)(yg + (0ll * nks + ks) * 1024) = v3;
-        *(uint4*)(yg + (1ll * nks + ks) * 1024) = v2;
-        *(uint4*)(yg + (2ll * nks + ks) * 1024) = v1;
+        if constexpr (QUANT) {
+            const uint4 v1 = make_uint4(w1[0], w1[1], w1[2], w1[3]), v2 = make_uint4(w2[0], w2[1], w2[2], w2[3]),
+                        v3 = make_uint4(w3[0], w3[1], w3[2], w3[3]);
+            *(uint4*)(xg + (0ll * nks + ks) * 1024) = v1;
+            *(uint4*)(xg + (1ll * nks + ks) * 1024) = v2;
+            *(uint4*)(xg + (2ll * nks + ks) * 1024) = v3;
+            *(uint4*)(yg + (0ll * nks + ks) * 1024) = v3;
+            *(uint4*)(yg + (1ll * nks + ks) * 1024) = v2;
+            *(uint4*)(yg + (2ll * nks + ks) * 1024) = v1;
+        }
+    }
+    for (int o = 16; o <= 32; o <<= 1) {
+        n2 += __shfl_xor(n2, o); pr += __shfl_xor(pr, o);
+        if constexpr (QUANT) { su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o); }
+    }
+    if (chunk == 0) { red[w][rr][0] = n2; red[w][rr][1] = pr; red[w][rr][2] = su; red[w][rr][3] = s2; }
+    __syncthreads();
+    if (w == 0 && chunk == 0 && row_ok) {
+        double t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = ((red[0][rr][c] + red[1][rr][c]) + red[2][rr][c]) + red[3][rr][c];
+        if (nrm2) nrm2[r] = t[0];
+        proj[r] = t[1];
+        if constexpr (QUANT) {
+            nu2[r] = t[3];
+            atomicMax(&keys[3], dlc_f64_key(t[2]));
+        }
     }
 }
 
@@ -391,12 +404,18 @@ int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
     hipLaunchKernelGGL(sim_range_kernel, dim3(2048), dim3(256), 0, st, desc, (long long)(rows * H), keys);
     DLC_LAUNCH_CHECK(ctx, "sim_range_kernel");
-    hipLaunchKernelGGL(sim_rowsum_kernel, dim3((unsigned)dlc::cdiv(rows, 4)), dim3(256), 0, st, desc, (long long)rows, (int)H, score,
-                       keys, nu2, proj);
-    DLC_LAUNCH_CHECK(ctx, "sim_rowsum_kernel");
-    hipLaunchKernelGGL(sim_quant_kernel, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(256), 0, st, desc, (long long)rows,
-                       (int)H, kp, keys, X, Y);
-    DLC_LAUNCH_CHECK(ctx, "sim_quant_kernel");
+    hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(256), 0, st, desc, (long long)rows,
+                       (int)H, kp, score, keys, X, Y, (double*)nullptr, nu2, proj);
+    DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
+    return DLC_OK;
+}
+
+// |x|^2 and dot(score, x) of every patch row (the fp64 Gram form; the filter's prepare computes the same projections)
+int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
+                 hipStream_t st) {
+    hipLaunchKernelGGL(sim_rows_kernel<false>, dim3((unsigned)dlc::cdiv(rows, (int64_t)16)), dim3(256), 0, st, desc, (long long)rows,
+                       (int)H, 0, score, (unsigned long long*)nullptr, (char*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj);
+    DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
 

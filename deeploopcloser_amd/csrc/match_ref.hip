@@ -170,24 +170,6 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
     }
 }
 
-// Per patch row: squared norm and p = dot(score, row).  One wave per row.
-__global__ __launch_bounds__(256) void row_stats_kernel(const double* __restrict__ desc, long long rows, int H,
-                                                        const double* __restrict__ score, double* __restrict__ nrm2,
-                                                        double* __restrict__ proj) {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= rows) return;
-    const double* x = desc + r * H;
-    double n2 = 0.0, p = 0.0;
-    for (int k = lane; k < H; k += 64) {
-        const double v = x[k];
-        n2 = fma(v, v, n2);
-        p = fma(score[k], v, p);
-    }
-    for (int o = 32; o > 0; o >>= 1) { n2 += __shfl_xor(n2, o); p += __shfl_xor(p, o); }
-    if (lane == 0) { nrm2[r] = n2; proj[r] = p; }
-}
-
 __device__ __forceinline__ long long f64_to_i64_trunc(double v) {
     if (!(fabs(v) < 9.2233720368547758e18)) return (long long)0x8000000000000000ull;   // inf / nan / overflow
     return (long long)v;   // truncation toward zero
@@ -798,9 +780,10 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
     }
 
     // the fp64 Gram route
-    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)dlc::cdiv(rows, 4)), dim3(256), 0, st, desc, rows, (int)H, score,
-                       nrm2, proj);
-    DLC_LAUNCH_CHECK(ctx, "row_stats_kernel");
+    {
+        const int rc = dlc_gemm::sim_row_sums(ctx, desc, rows, H, score, nrm2, proj, st);
+        if (rc != DLC_OK) return rc;
+    }
     long long chunk_frames = w.chunk_frames;
     bool use_t = (rows & 1) == 0;
     if (sim_use_filter(P, H)) {                  // the filter's workspace: no transposed copy, the chunk that fits its Gram region

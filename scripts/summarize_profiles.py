@@ -10,8 +10,8 @@ os.makedirs(dst, exist_ok=True)
 OURS = ("score_gemm_kernel", "finish_topk_kernel", "merge_topk_kernel", "l2_normalize_kernel", "l2_normalize_regs_kernel",
         "gemm_dma_f64_kernel", "gemm_bias_act_kernel", "distance_matrix_kernel", "distinctive_score_kernel",
         "pair_score_kernel", "pair_score_tile_kernel", "transpose_f64_kernel", "splitk_groups_kernel", "splitk_dense_kernel", "maxpool_kernel", "row_minmax_kernel",
-        "quant_gather_kernel", "row_stats_kernel", "gram_i8_kernel", "pair_score_filter_kernel", "sim_quant_kernel",
-        "sim_rowsum_kernel", "sim_range_kernel", "sim_pairwise_program_kernel")
+        "quant_gather_kernel", "row_stats_kernel", "gram_i8_kernel", "pair_score_filter_kernel", "sim_rows_kernel",
+        "sim_range_kernel", "sim_pairwise_program_kernel")
 
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 stats = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))

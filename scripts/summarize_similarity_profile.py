@@ -7,7 +7,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02i"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_sim_" + tag)
 dst = os.path.join(root, "profiles")
-KERNELS = ("gram_i8_kernel", "pair_score_filter_kernel", "sim_quant_kernel", "sim_rowsum_kernel", "sim_range_kernel",
+KERNELS = ("gram_i8_kernel", "pair_score_filter_kernel", "sim_rows_kernel", "sim_range_kernel",
            "sim_pairwise_program_kernel", "distinctive_score_kernel", "fill_diag_kernel")
 with open(os.path.join(src, "stats", "sim_kernel_stats.csv")) as f, open(os.path.join(dst, tag + "_similarity_kernel_stats.csv"), "w") as g:
     for i, line in enumerate(f):
@@ -17,7 +17,7 @@ out = {"tag": tag, "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (se
        "kernels": {}}
 for row in csv.DictReader(open(os.path.join(src, "stats", "sim_kernel_stats.csv"))):
     for k in KERNELS:
-        if k + "(" in row["Name"]:
+        if k + "(" in row["Name"] or k + "<" in row["Name"]:
             out["kernels"][k] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"])}
 pmc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
