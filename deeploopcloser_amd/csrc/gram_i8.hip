@@ -121,19 +121,28 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
     const int n64 = p.kp / GI_KS;
     const int nst = 6 * n64;
 
-    auto issue = [&](int t) {
-        const int seg = (t >= 3 * n64) + (t >= 5 * n64);                  // selects, not branches
-        const int xo = (t - (seg == 0 ? 0 : seg == 1 ? 3 * n64 : 5 * n64)) * 1024;      // k-step blocks of 1 KiB
-        const int yo = xo + seg * n64 * 1024;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (t & (GI_NSTAGE - 1)) * GI_STAGE + w * 2048);
+    // The next stage to fetch and where it lies, kept as running scalars: worked out from the stage number (two
+    // compares, selects, a multiply, a readfirstlane) the address arithmetic of an issue was ~30 scalar and 2 vector
+    // instructions in front of its four DMA instructions, in the gap of every iteration.
+    const char* xb1 = xb + p.gpitch;
+    const char* yb1 = yb + p.gpitch;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_base + w * 2048);
+    int is_t = 0, is_x = 0, is_y = 0, is_wrap = 3 * n64, is_ybase = n64 * 1024;
+    auto issue = [&]() {
+        const unsigned dst = lds_w + (is_t & (GI_NSTAGE - 1)) * GI_STAGE;
 #ifdef GI_EXP_NO_DMA            // timing experiments only (wrong results): what the loop costs without its operand traffic
-        if (t >= GI_NSTAGE) return;
+        if (is_t >= GI_NSTAGE) return;
 #endif
-        dma2(voff, xb + xo, xb + xo + p.gpitch, dst);
+        dma2(voff, xb + is_x, xb1 + is_x, dst);
 #ifdef GI_EXP_HALF_DMA          // ... and with half of it
-        if (t >= GI_NSTAGE) return;
+        if (is_t >= GI_NSTAGE) return;
 #endif
-        dma2(voff, yb + yo, yb + yo + p.gpitch, dst + GI_HALF);
+        dma2(voff, yb + is_y, yb1 + is_y, dst + GI_HALF);
+        ++is_t; is_x += 1024; is_y += 1024;                                 // k-step blocks of 1 KiB
+        if (is_t == is_wrap) {                                              // the next segment: X from its start, Y one slice on
+            is_x = 0; is_y = is_ybase;
+            is_ybase += n64 * 1024; is_wrap += 2 * n64;                     // 3 n64, then 5 n64
+        }
     };
 
     v4i acc[4][8];                          // [column group j of this wave][row group i]
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
         }                                                                                                                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        if (ISSUE) issue(t_ + GI_NSTAGE);                                                                                  \
+        if (ISSUE) issue();                                                                                                \
     }
     // the K stages of one segment, two per trip (the fragment buffers alternate)
 #define GI_RUN(T_LO, T_HI)                                                                                                 \
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
             for (int i = 0; i < 8; ++i) acc[j][i] = acc[j][i] >> 7;
     };
 #pragma unroll
-    for (int t = 0; t < GI_NSTAGE; ++t) issue(t);                        // nst >= 24
+    for (int t = 0; t < GI_NSTAGE; ++t) issue();                         // nst >= 24
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                    // stage 0
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
