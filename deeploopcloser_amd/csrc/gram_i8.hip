@@ -154,7 +154,8 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
 
     const char* sx = smem_i8 + (wr * 8) * 1024 + lane * 16;
     const char* sy = smem_i8 + GI_HALF + (wc * 4) * 1024 + lane * 16;
-    // (Measured and not kept: the two waves of a SIMD issuing their DMA at opposite ends of the iteration -- 6.35 -> 6.58 ms.)
+    // (Measured and not kept: the two waves of a SIMD issuing their DMA at opposite ends of the iteration -- 6.35 -> 6.58 ms;
+    // a fifth LDS stage, all 160 KiB, four k-steps for a piece to arrive -- 6.15 vs 6.17 ms: its latency is covered.)
     // s_waitcnt immediates (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
     // builtin, not inline asm, so that hipcc's own wait insertion knows the LDS reads are done
     constexpr int GI_WAIT_VM8 = 0x0078, GI_WAIT_VM4 = 0x0074, GI_WAIT_VM0 = 0x0070;

