@@ -69,6 +69,13 @@ __device__ __forceinline__ void dma2(unsigned voff, const char* b0, const char* 
         : "memory", "scc");
 }
 
+// ... and one piece
+__device__ __forceinline__ void dma1(unsigned voff, const char* b0, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(b0), "s"(lds) : "memory", "scc");
+}
+
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const unsigned long long a = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
@@ -145,6 +152,20 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
         }
     };
 
+    // the same, a piece at a time (piece 0..3: X group 0, X group 1, Y group 0, Y group 1): between the MFMAs of an iteration
+    auto issue_piece = [&](int piece) {
+        const unsigned dst = lds_w + (is_t & (GI_NSTAGE - 1)) * GI_STAGE + (piece >> 1) * GI_HALF + (piece & 1) * 1024;
+        const char* src = (piece >> 1) ? ((piece & 1) ? yb1 : yb) + is_y : ((piece & 1) ? xb1 : xb) + is_x;
+        dma1(voff, src, dst);
+        if (piece == 3) {
+            ++is_t; is_x += 1024; is_y += 1024;
+            if (is_t == is_wrap) {
+                is_x = 0; is_y = is_ybase;
+                is_ybase += n64 * 1024; is_wrap += 2 * n64;
+            }
+        }
+    };
+
     v4i acc[4][8];                          // [column group j of this wave][row group i]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -159,6 +180,18 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
     // s_waitcnt immediates (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
     // builtin, not inline asm, so that hipcc's own wait insertion knows the LDS reads are done
     constexpr int GI_WAIT_VM8 = 0x0078, GI_WAIT_VM4 = 0x0074, GI_WAIT_VM0 = 0x0070;
+#ifdef GI_EXP_STAMPS             // diagnostic build only: where a wave's cycles go (s_memtime ticks), printed for a few workgroups
+    unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_body = 0, st_wait = 0, st_bar = 0, st_mark = 0;
+#define GI_STAMP(K)                                                                                                        \
+    {                                                                                                                      \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                      \
+        if ((K) == 0) { st_body += now_ - st_last; st_mark = now_; }                                                      \
+        if ((K) == 1) { st_wait += now_ - st_mark; st_mark = now_; }                                                      \
+        if ((K) == 2) { st_bar += now_ - st_mark; st_last = now_; }                                                       \
+    }
+#else
+#define GI_STAMP(K)
+#endif
     // (a macro: through a generic lambda hipcc kept the fragment and accumulator arrays in scratch memory; and the steady
     // state has no branch in it -- with the tail's conditions inside, hipcc moved accumulators between register files
     // in every iteration)
@@ -167,27 +200,37 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
         const int t_ = (T);                                                                                                \
         /* this wave's pieces of stage t+1 (4 instructions per stage; stages up to t+3 are in flight) and its LDS reads */ \
         /* of stage t, whose slot is about to be overwritten */                                                            \
+        GI_STAMP(0)                                                                                                        \
         __builtin_amdgcn_s_waitcnt(WAIT);                                                                                  \
         asm volatile("" ::: "memory");                                                                                     \
+        GI_STAMP(1)                                                                                                        \
         __builtin_amdgcn_s_barrier();                                                                                      \
         asm volatile("" ::: "memory");                                                                                     \
+        GI_STAMP(2)                                                                                                        \
         const int so = ((t_ + 1) & (GI_NSTAGE - 1)) * GI_STAGE;                                                            \
         /* MFMAs first (their fragments are in registers), the 12 reads of stage t+1 one per pair of MFMAs, the DMA of  */ \
         /* stage t+4 behind them: all eight waves leave the barrier together, and whatever stands between the barrier    */ \
         /* and a wave's first MFMA is time both matrix-pipe users of a SIMD spend idle (reads + DMA first: 6.8 ms)       */ \
         /* (the last iteration reads a slot nobody writes any more: unused) */                                            \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) fx[NXT][j] = *(const v4i*)(sx + so + j * 1024);                      \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) fy[NXT][j] = *(const v4i*)(sy + so + j * 1024);                      \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+            fx[NXT][2 * j] = *(const v4i*)(sx + so + (2 * j) * 1024);                                                      \
+            fx[NXT][2 * j + 1] = *(const v4i*)(sx + so + (2 * j + 1) * 1024);                                              \
+            fy[NXT][j] = *(const v4i*)(sy + so + j * 1024);                                                                \
             _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                  \
                 acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fy[CUR][j], fx[CUR][i], acc[j][i], 0, 0, 0);           \
-        _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                                                \
+            _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) {                                                             \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                         \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                         \
+            }                                                                                                              \
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
+            /* one DMA piece of stage t+4 behind each quarter of the MFMAs (all four behind the last MFMA measured the   */  \
+            /* same: cycle stamps -- GI_EXP_STAMPS -- put a stage at 1490 cycles for 1024 of MFMA per SIMD, none of it    */  \
+            /* waiting for DMA data; the first wave of a SIMD is through its body after 920 and stands 530 at the barrier, */  \
+            /* the second takes 1285: about 60 cycles per DMA piece that neither wave of the SIMD issues MFMAs in)        */  \
+            if (ISSUE) issue_piece(j);                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                             \
         }                                                                                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        if (ISSUE) issue();                                                                                                \
     }
     // the K stages of one segment, two per trip (the fragment buffers alternate)
 #define GI_RUN(T_LO, T_HI)                                                                                                 \
@@ -224,9 +267,15 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
     GI_BODY(nst - 3, 1, 0, GI_WAIT_VM4, false)
     GI_BODY(nst - 2, 0, 1, GI_WAIT_VM0, false)
     GI_BODY(nst - 1, 1, 0, GI_WAIT_VM0, false)
+#undef GI_STAMP
 #undef GI_RUN
 #undef GI_BODY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GI_EXP_STAMPS
+    if (lane == 0 && (blockIdx.x % 1501) == 7)
+        printf("wg %d wave %d: body %llu  wait-dma %llu  barrier %llu  per stage of %d\n", (int)blockIdx.x, w, st_body / nst, st_wait / nst,
+               st_bar / nst, nst);
+#endif
 
     // D[m][n] of MFMA (j, i): m = column patch (wc * 4 + j) * 16 + (lane / 16) * 4 + v, n = row patch (wr * 8 + i) * 16 + lane % 16
 #pragma unroll
