@@ -365,13 +365,13 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
 __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __restrict__ desc, const int* __restrict__ G,
                                                                 long long ldg, long long col0, const double* __restrict__ nu2,
                                                                 const double* __restrict__ proj, const double* __restrict__ score,
-                                                                const unsigned long long* __restrict__ keys, long long N, int P,
+                                                                unsigned long long* __restrict__ keys, long long N, int P,
                                                                 int H, long long i_lo, long long i_hi, long long row_base,
                                                                 double ca, double cb, double* __restrict__ out_f64,
                                                                 long long* __restrict__ out_i64, const int2* __restrict__ prog) {
     extern __shared__ double ps_lds_all[];
     double* ps_lds = ps_lds_all + PF_STACK_BYTES / 8;            // in front: the value stacks of the summation program
-    unsigned long long* n_fallback = const_cast<unsigned long long*>(keys) + 4;
+    unsigned long long* n_fallback = keys + 4;              // a count of the direct evaluations (DLC_SIM_DEBUG)
     const int prog_len = (int)keys[5];
     const long long i = i_lo + blockIdx.y;
     if (i >= i_hi) return;
