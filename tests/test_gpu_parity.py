@@ -618,6 +618,35 @@ def test_similarity_filter_in_row_chunks(eng, monkeypatch):
         monkeypatch.delenv("DLC_SIM_CHUNK_BYTES")
 
 
+def test_similarity_filter_accumulator_extremes(eng, monkeypatch):
+    """The widest descriptors the filter takes (H = 32768) with rows of ones against rows of ones: every slice of every
+    element 127, the class-4 accumulators at 3 * 32768 * 127^2 = 1.59e9 of the int32 range; one frame, two frames, a
+    single patch per frame; results equal to the fp64 Gram form."""
+    g = torch.Generator(device=eng.device); g.manual_seed(2)
+
+    def both(ds):
+        score = eng.distinctive_score(ds, 0.5, 0.2)
+        out = []
+        for mode in ("f64", "i8"):
+            monkeypatch.setenv("DLC_SIM_GRAM", mode)
+            mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+            out.append((mf.clone(), mi.clone()))
+        monkeypatch.delenv("DLC_SIM_GRAM")
+        return out
+
+    h = 32768
+    ds = (torch.rand((5, 3, h), generator=g, device=eng.device, dtype=torch.float64) < 0.5).double()
+    ds[0, 0] = 1.0; ds[1, 1] = 1.0; ds[2, 0] = 1.0; ds[3, 2] = 0.0; ds[4, 1] = 1.0
+    ds += 1e-3 * torch.rand((5, 3, h), generator=g, device=eng.device, dtype=torch.float64)
+    ds.clamp_(0.0, 1.0)
+    (f_ref, i_ref), (f_got, i_got) = both(ds)
+    assert torch.equal(f_got, f_ref) and torch.equal(i_got, i_ref)
+    for n, p, hh in [(1, 30, 64), (2, 30, 64), (2, 1, 1), (3, 32, 33), (40, 1, 700)]:
+        ds = torch.rand((n, p, hh), generator=g, device=eng.device, dtype=torch.float64)
+        (f_ref, i_ref), (f_got, i_got) = both(ds)
+        assert torch.equal(f_got, f_ref) and torch.equal(i_got, i_ref), (n, p, hh)
+
+
 def test_distance_vs_reference_fixture(dlc, golden):
     g = golden("distance.npz")
     dc = dlc.DistanceCalculator
