@@ -334,6 +334,17 @@ __device__ __forceinline__ int sim_fixed(double u) {
     return q > 2097151 ? 2097151 : q;
 }
 
+// A 128-bit content hash of a row: two sums over the elements of a strong 64-bit mix of (bit pattern, position) -- order
+// independent, so lanes and waves add their parts in any grouping.  Rows with equal hashes are taken to be the same patch
+// (a key-point found twice, a blank patch repeated): their distances to anything are equal however they are summed and
+// np.argmin keeps the first of them, so the pair kernel drops the later ones from its undecided candidates without
+// reading a row.  (Different rows collide with probability 2^-128 per comparison.)
+__device__ __forceinline__ unsigned long long sim_mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
 // The pass over the descriptors that both forms of the similarity share, a workgroup per group of 16 patch rows, a wave
 // per k-step of 64 elements (w, w + 4, ..), lane l on row l % 16, elements ks * 64 + (l / 16) * 16 .. + 15 -- 128
 // contiguous bytes per lane:
@@ -347,8 +358,11 @@ template <bool QUANT>
 __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict__ desc, long long rows, int H, int kp,
                                                        const double* __restrict__ score, unsigned long long* keys,
                                                        char* __restrict__ X, char* __restrict__ Y, double* __restrict__ nrm2,
-                                                       double* __restrict__ nu2, double* __restrict__ proj) {
+                                                       double* __restrict__ nu2, double* __restrict__ proj,
+                                                       unsigned long long* __restrict__ rowhash) {
     __shared__ double red[4][16][4];
+    __shared__ unsigned long long redh[4][16][2];
+    unsigned long long h1 = 0, h2 = 0;
     const long long g = blockIdx.x;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, rr = lane & 15, chunk = lane >> 4;
     double lo = 0.0, inv = 0.0;
@@ -372,6 +386,9 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
             n2 = fma(v, v, n2);
             pr = fma(sc, v, pr);
             if constexpr (QUANT) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v), pos = (unsigned long long)(k0 + e);
+                h1 += sim_mix64(bits + pos * 0x9e3779b97f4a7c15ull);
+                h2 += sim_mix64((bits ^ 0xd6e8feb86659fd93ull) + pos * 0xc2b2ae3d27d4eb4full);
                 const double u = sim_unit(v, lo, inv);
                 su += u; s2 = fma(u, u, s2);
                 const int q = sim_fixed(u);
@@ -406,9 +423,15 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
     }
     for (int o = 16; o <= 32; o <<= 1) {
         n2 += __shfl_xor(n2, o); pr += __shfl_xor(pr, o);
-        if constexpr (QUANT) { su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o); }
+        if constexpr (QUANT) {
+            su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o);
+            h1 += __shfl_xor(h1, o); h2 += __shfl_xor(h2, o);
+        }
     }
-    if (chunk == 0) { red[w][rr][0] = n2; red[w][rr][1] = pr; red[w][rr][2] = su; red[w][rr][3] = s2; }
+    if (chunk == 0) {
+        red[w][rr][0] = n2; red[w][rr][1] = pr; red[w][rr][2] = su; red[w][rr][3] = s2;
+        redh[w][rr][0] = h1; redh[w][rr][1] = h2;
+    }
     __syncthreads();
     if (w == 0 && chunk == 0 && row_ok) {
         double t[4];
@@ -419,6 +442,8 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
         if constexpr (QUANT) {
             nu2[r] = t[3];
             atomicMax(&keys[3], dlc_f64_key(t[2]));
+            rowhash[2 * r] = redh[0][rr][0] + redh[1][rr][0] + redh[2][rr][0] + redh[3][rr][0];
+            rowhash[2 * r + 1] = redh[0][rr][1] + redh[1][rr][1] + redh[2][rr][1] + redh[3][rr][1];
         }
     }
 }
@@ -458,14 +483,14 @@ size_t sim_filter_panel_bytes(int64_t rows, int64_t H) {
 // keys[6]: min key, max key, non-finite flag, max row sum key, direct evaluations (a count), length of prog (up to
 // 1023 int2 entries for H <= 32768).  X / Y: sim_filter_panel_bytes each.
 int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, unsigned long long* keys,
-                       char* X, char* Y, double* nu2, double* proj, void* prog, hipStream_t st) {
+                       char* X, char* Y, double* nu2, double* proj, unsigned long long* rowhash, void* prog, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     hipLaunchKernelGGL(sim_keys_init_kernel, dim3(1), dim3(64), 0, st, keys);
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
     hipLaunchKernelGGL(sim_range_kernel, dim3(2048), dim3(256), 0, st, desc, (long long)(rows * H), keys);
     DLC_LAUNCH_CHECK(ctx, "sim_range_kernel");
     hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(256), 0, st, desc, (long long)rows,
-                       (int)H, kp, score, keys, X, Y, (double*)nullptr, nu2, proj);
+                       (int)H, kp, score, keys, X, Y, (double*)nullptr, nu2, proj, rowhash);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
@@ -474,7 +499,8 @@ int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H
 int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
                  hipStream_t st) {
     hipLaunchKernelGGL(sim_rows_kernel<false>, dim3((unsigned)dlc::cdiv(rows, (int64_t)16)), dim3(256), 0, st, desc, (long long)rows,
-                       (int)H, 0, score, (unsigned long long*)nullptr, (char*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj);
+                       (int)H, 0, score, (unsigned long long*)nullptr, (char*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj,
+                       (unsigned long long*)nullptr);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                                                                 unsigned long long* __restrict__ keys, long long N, int P,
                                                                 int H, long long i_lo, long long i_hi, long long row_base,
                                                                 double ca, double cb, double* __restrict__ out_f64,
-                                                                long long* __restrict__ out_i64, const int2* __restrict__ prog) {
+                                                                long long* __restrict__ out_i64, const int2* __restrict__ prog,
+                                                                const unsigned long long* __restrict__ rowhash) {
     extern __shared__ double ps_lds_all[];
     double* ps_lds = ps_lds_all + PF_STACK_BYTES / 8;            // in front: the value stacks of the summation program
     unsigned long long* n_fallback = keys + 4;              // a count of the direct evaluations (DLC_SIM_DEBUG)
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
     const int tid = threadIdx.x;
     const int width = PS_JT * P, row = width | 1;
     double* nb = ps_lds;                                         // [PS_JT * P] |u_b|^2 of the frames' patches
-    int* g = (int*)(ps_lds + width);                             // [P][row]
+    unsigned long long* hb = (unsigned long long*)(ps_lds + width);      // [PS_JT * P][2] their content hashes
+    int* g = (int*)(ps_lds + 3 * width);                         // [P][row]
     const int w = tid >> 6, lane = tid & 63;
     const int jj = tid >> 5, a = tid & 31;
     const long long ra = i * P + (a < P ? a : 0);
@@ -389,8 +391,12 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
     const int* grow0 = G + (i * P - row_base) * ldg - col0;      // G[0][0]: patches (row_base, col0), the panels' 16-row groups
     int v[8][4];
     double nbv = 0.0;                                            // this thread's |u_b|^2 of the run in flight (width <= 256)
+    unsigned long long hv0 = 0, hv1 = 0;                         // ... and its hash
     auto fetch = [&](long long j0) {
-        nbv = (tid < width && j0 * P + tid < N * P) ? nu2[j0 * P + tid] : 0.0;
+        const bool in_ = tid < width && j0 * P + tid < N * P;
+        nbv = in_ ? nu2[j0 * P + tid] : 0.0;
+        hv0 = in_ ? rowhash[2 * (j0 * P + tid)] : 0;
+        hv1 = in_ ? rowhash[2 * (j0 * P + tid) + 1] : 0;
         const long long jlo = j0 > i + 1 ? j0 : i + 1;
         const long long jhi = j0 + PS_JT < N ? j0 + PS_JT : N;
         const int c_lo = (int)((jlo - j0) * P), c_hi = (int)((jhi - j0) * P);
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                 const int ar = w + 4 * r, c = lane + 64 * cc;
                 if (ar < P && c < width) g[ar * row + c] = v[r][cc];
             }
-        if (tid < width) nb[tid] = nbv;                          // (loaded here it was a global-memory latency per run on the critical path)
+        if (tid < width) { nb[tid] = nbv; hb[2 * tid] = hv0; hb[2 * tid + 1] = hv1; }
         __syncthreads();
         const long long jn = j0 + (long long)PS_GX * PS_JT;
         if (jn < N) fetch(jn);
@@ -441,9 +447,21 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
 #pragma unroll 4
                 for (int b = 0; b < P; ++b) scan(b);
             }
-            if (second <= best + window)
-                for (int b = 0; b < P; ++b)
-                    if (nbj[b] - 0x1p-13 * (double)grow[b] <= best + window) cand |= 1u << b;
+            if (second <= best + window) {
+                const unsigned long long* hbj = hb + 2 * jj * P;
+                for (int b = 0; b < P; ++b) {
+                    if (!(nbj[b] - 0x1p-13 * (double)grow[b] <= best + window)) continue;
+                    // a copy of an earlier candidate (equal content hashes: sim_mix64) has that candidate's distance
+                    // and a later index: np.argmin never takes it
+                    bool copy = false;
+                    for (unsigned m = cand; m; m &= m - 1) {
+                        const int e = __ffs((int)m) - 1;
+                        copy |= hbj[2 * e] == hbj[2 * b] && hbj[2 * e + 1] == hbj[2 * b + 1];
+                    }
+                    if (!copy) cand |= 1u << b;
+                }
+                if (!(cand & (cand - 1))) { bi = __ffs((int)cand) - 1; cand = 0; }       // one patch left: decided
+            }
         }
         // the undecided arg-mins of this wave, one after the other
         unsigned long long todo = __ballot(cand != 0);
@@ -470,7 +488,22 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
             }
             unsigned long long close = __ballot(mine <= emin * (1.0 + 1e-11));
             int ebi = __ffsll((long long)close) - 1;
+            bool same_rows = false;
             if (close & (close - 1)) {
+                // (1b) the commonest tie: the close candidates are the SAME patch (a key-point found twice, a blank patch
+                // repeated) -- bit-identical rows have identical norms however they are summed, the first one wins
+                const double* x0 = xj + (long long)ebi * H;
+                bool differ = false;
+                for (unsigned long long m = close & (close - 1); m && !differ; m &= m - 1) {
+                    const double* xb = xj + (long long)(__ffsll((long long)m) - 1) * H;
+                    bool d_ = false;
+#pragma unroll 8
+                    for (int k = lane; k < H; k += 64) d_ |= __double_as_longlong(xb[k]) != __double_as_longlong(x0[k]);
+                    differ = __ballot(d_) != 0;
+                }
+                same_rows = !differ;
+            }
+            if ((close & (close - 1)) && !same_rows) {
                 // (2) still closer than either summation resolves: the candidates' norms exactly as NumPy forms them
                 // (np.linalg.norm: sqrt(np.add.reduce((x - m) ** 2)) with pairwise summation), eight candidates at a
                 // time -- 8 lanes per candidate, one per strided accumulator of a leaf
@@ -590,7 +623,7 @@ __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __rest
 }
 
 struct SimWs {
-    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, qx, qy, total;
+    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, qy, total;
     long long chunk_frames, chunk_frames_i8;
 };
 
@@ -643,12 +676,13 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H) {
     // [K,N] -- 1 KiB contiguous per k-row and tile instead of 128 scattered 128-byte row segments (an even N*P keeps
     // the rows 16-byte aligned for the LDS-DMA kernel; an odd one falls back to the [N,K] form)
     w.desc_t = o;
-    w.keys = w.prog = w.nu2 = w.qx = w.qy = 0;
+    w.keys = w.prog = w.nu2 = w.rowhash = w.qx = w.qy = 0;
     if (filter) {
         const size_t panel = dlc_gemm::sim_filter_panel_bytes(N * P, H);
         w.keys = o; o += 256;
         w.prog = o; o += 8192;
         w.nu2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
+        w.rowhash = o; o += dlc::align_up((size_t)N * P * 16, 256);
         w.qx = o; o += dlc::align_up(panel, 256);
         w.qy = o; o += dlc::align_up(panel, 256);
     } else if (((N * P) & 1) == 0) {
@@ -742,7 +776,8 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         char* qx = ws + w.qx;
         char* qy = ws + w.qy;
         int2* prog = (int2*)(ws + w.prog);
-        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, rows, H, score, keys, qx, qy, nu2, proj, prog, st);
+        unsigned long long* rowhash = (unsigned long long*)(ws + w.rowhash);
+        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, rows, H, score, keys, qx, qy, nu2, proj, rowhash, prog, st);
         if (rc != DLC_OK) return rc;
         // the one host read of this call: did the range pass meet a NaN or an infinity?  (Their distances are NaN in the
         // reference too, np.argmin then takes the first of them: the fp64 kernels reproduce that, a fixed-point
@@ -752,7 +787,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         DLC_HIP_CHECK(ctx, hipStreamSynchronize(st));
         if (bad) filter = false;
         else {
-            const size_t tile_lds = PF_STACK_BYTES + (size_t)PS_JT * P * sizeof(double) + (size_t)P * ((PS_JT * P) | 1) * sizeof(int);
+            const size_t tile_lds = PF_STACK_BYTES + (size_t)PS_JT * P * (sizeof(double) + 16) + (size_t)P * ((PS_JT * P) | 1) * sizeof(int);
             for (long long i_lo = 0; i_lo + 1 < N; i_lo += w.chunk_frames_i8) {
                 long long i_hi = i_lo + w.chunk_frames_i8;
                 if (i_hi > N - 1) i_hi = N - 1;
@@ -766,7 +801,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
                 if (rc != DLC_OK) return rc;
                 hipLaunchKernelGGL(pair_score_filter_kernel, dim3(PS_GX, (unsigned)(i_hi - i_lo)), dim3(256), tile_lds, st, desc,
                                    (const int*)gram, ldo, col_base, nu2, proj, score, keys, (long long)N, (int)P, (int)H, i_lo, i_hi,
-                                   row_base, a, b, out_f64, (long long*)out_i64, prog);
+                                   row_base, a, b, out_f64, (long long*)out_i64, prog, rowhash);
                 DLC_LAUNCH_CHECK(ctx, "pair_score_filter_kernel");
             }
             if (getenv("DLC_SIM_DEBUG")) {       // experiments: how many arg-mins went to the direct evaluation

@@ -1,5 +1,5 @@
 """The SDAV similarity matrix at the reference's size (1063 frames x 30 patches x 2500) a few times, for rocprofv3:
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sim -- python3 scripts/prof_similarity.py [saturated|uniform] [library]"""
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sim -- python3 scripts/prof_similarity.py [saturated|uniform|duplicates|twins] [library]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,6 +14,15 @@ n, p, h = 1063, 30, 2500
 kind = sys.argv[1] if len(sys.argv) > 1 else "saturated"
 if kind == "saturated":
     ds = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+elif kind == "duplicates":                 # every fifth patch a copy of another one: exact ties wherever a copy is nearest
+    ds = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+    flat = ds.reshape(n * p, h)
+    src = torch.randint(0, n * p, (n * p // 5,), generator=g, device=eng.device)
+    dst = torch.randint(0, n * p, (n * p // 5,), generator=g, device=eng.device)
+    flat[dst] = flat[src].clone()
+elif kind == "twins":                      # in every frame patches 1, 3, 5 are copies of 0, 2, 4: a fifth of all arg-mins are exact ties
+    ds = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+    ds[:, 1] = ds[:, 0]; ds[:, 3] = ds[:, 2]; ds[:, 5] = ds[:, 4]
 else:
     ds = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
 score = eng.distinctive_score(ds, 0.5, 0.2)

@@ -588,9 +588,12 @@ def test_similarity_filter_equals_fp64_gram_route(eng, monkeypatch):
             src = torch.from_numpy(rng.randint(0, n * p, size=n * p // 3 + 1)).to(eng.device)
             dst = torch.from_numpy(rng.randint(0, n * p, size=n * p // 3 + 1)).to(eng.device)
             dup[dst] = dup[src].clone()
+        twins = sat.clone()                           # copies INSIDE every frame: exact ties in a fifth of the arg-mins,
+        if p >= 6:                                    # resolved by the rows' content hashes without reading a row
+            twins[:, 1] = twins[:, 0]; twins[:, 3] = twins[:, 2]; twins[:, 5] = twins[:, 4]
         for name, ds in (("uniform", torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)),
                          ("normal", 3.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64) - 1.0),
-                         ("saturated", sat), ("duplicates", dup.reshape(n, p, h))):
+                         ("saturated", sat), ("duplicates", dup.reshape(n, p, h)), ("twins", twins)):
             (f_ref, i_ref), (f_got, i_got) = both(ds)
             assert torch.equal(f_got, f_ref) and torch.equal(i_got, i_ref), (name, n, p, h)
     (f_ref, i_ref), (f_got, i_got) = both(torch.full((5, 30, 64), 0.25, device=eng.device, dtype=torch.float64))
