@@ -1,5 +1,5 @@
 """The SDAV similarity matrix at the reference's size (1063 frames x 30 patches x 2500) a few times, for rocprofv3:
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sim -- python3 scripts/prof_similarity.py [saturated|uniform|duplicates|twins] [library]"""
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sim -- python3 scripts/prof_similarity.py [saturated|uniform|duplicates|twins|binary] [library]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,6 +23,8 @@ elif kind == "duplicates":                 # every fifth patch a copy of another
 elif kind == "twins":                      # in every frame patches 1, 3, 5 are copies of 0, 2, 4: a fifth of all arg-mins are exact ties
     ds = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
     ds[:, 1] = ds[:, 0]; ds[:, 3] = ds[:, 2]; ds[:, 5] = ds[:, 4]
+elif kind == "binary":                     # zeros and ones only: every squared distance an integer, ties between DIFFERENT patches
+    ds = (torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64) < 0.5).double()
 else:
     ds = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
 score = eng.distinctive_score(ds, 0.5, 0.2)
