@@ -476,12 +476,17 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
             // (1) all 64 lanes on each candidate's 2 H doubles: squared distances to ~5e-15 (relative); lane b keeps
             // candidate b's
             double mine = INFINITY, emin = INFINITY;
+            bool frac = false;                                  // some difference is not an integer below 2^18
             for (int b = 0; b < P; ++b) {
                 if (!((cm >> b) & 1)) continue;
                 const double* xb = xj + (long long)b * H;
                 double s_ = 0.0;
 #pragma unroll 8
-                for (int k = lane; k < H; k += 64) { const double d = xb[k] - xa[k]; s_ = fma(d, d, s_); }
+                for (int k = lane; k < H; k += 64) {
+                    const double d = xb[k] - xa[k];
+                    s_ = fma(d, d, s_);
+                    frac |= !(d == rint(d) && fabs(d) < 262144.0);
+                }
                 for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
                 if (lane == b) mine = s_;
                 emin = fmin(emin, s_);
@@ -489,6 +494,13 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
             unsigned long long close = __ballot(mine <= emin * (1.0 + 1e-11));
             int ebi = __ffsll((long long)close) - 1;
             bool same_rows = false;
+            if ((close & (close - 1)) && __ballot(frac) == 0) {
+                // (1a) integer differences (binary or integer-valued descriptors): squares and their sums below 2^51 are
+                // exact in any order, NumPy's included, and distinct sums have distinct roots -- the first smallest sum
+                close = __ballot(mine == emin);
+                ebi = __ffsll((long long)close) - 1;
+                close = 0;
+            }
             if (close & (close - 1)) {
                 // (1b) the commonest tie: the close candidates are the SAME patch (a key-point found twice, a blank patch
                 // repeated) -- bit-identical rows have identical norms however they are summed, the first one wins

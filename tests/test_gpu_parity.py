@@ -554,8 +554,11 @@ def test_similarity_tiny_descriptors_follow_the_reference(dlc, monkeypatch):
         assert np.abs(got[fin] - ref[fin]).max() <= 1e-9 * max(1.0, np.abs(ref[fin]).max()), (n, p, h)
     # zeros and ones with 1e-13 of noise: every squared distance an integer up to the last bits, ties among the
     # candidates of nearly every arg-min, at widths of one, several and many leaves of the pairwise summation
-    for n, p, h in [(10, 25, 78), (6, 20, 300), (4, 30, 2500), (5, 11, 129), (5, 8, 1031)]:
-        ds = (rng.uniform(size=(n, p, h)) < 0.5).astype(np.float64) + 1e-13 * rng.uniform(size=(n, p, h))
+    for n, p, h, noise in [(10, 25, 78, 1e-13), (6, 20, 300, 1e-13), (4, 30, 2500, 1e-13), (5, 11, 129, 1e-13), (5, 8, 1031, 1e-13),
+                           (8, 30, 64, 0.0), (5, 20, 300, 0.0), (6, 32, 17, 0.0)]:     # noise 0: purely binary (integer sums: exact in any order)
+        ds = (rng.uniform(size=(n, p, h)) < 0.5).astype(np.float64) + noise * rng.uniform(size=(n, p, h))
+        if noise == 0.0:
+            ds *= rng.randint(1, 4)                       # ... and small integers
         got = dlc.SimilarityCalculator(ds).similarity_matrix(as_int64=False)
         ref = osim.similarity_matrix_f64(ds)
         fin = np.isfinite(ref)
