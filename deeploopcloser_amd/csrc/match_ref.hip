@@ -357,6 +357,9 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
     }
 }
 
+// doubles of LDS per wave of pair_score_filter_kernel: |u|^2 and hashes of 2 P columns, P rows of (2 P | 1) accumulators
+__host__ __device__ constexpr size_t pf_wave_doubles(int P) { return (size_t)(3 * 2 * P) + ((size_t)P * ((2 * P) | 1) * 4 + 15) / 16 * 2; }
+
 // The filter form (gram_i8.hip): G holds the exact integer products of the descriptors' 21-bit fixed-point values,
 // acc 2^-14 <= u_a . u_b <= acc 2^-14 + E.  Thread (jj, a) takes the arg-min of |u_b|^2 - 2 acc 2^-14 over the P
 // patches b; when the runner-up lies within 2 E of it, the bound cannot tell them apart and the wave evaluates the
@@ -371,58 +374,54 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                                                                 long long* __restrict__ out_i64, const int2* __restrict__ prog,
                                                                 const unsigned long long* __restrict__ rowhash) {
     extern __shared__ double ps_lds_all[];
-    double* ps_lds = ps_lds_all + PF_STACK_BYTES / 8;            // in front: the value stacks of the summation program
+    // Every wave works on its own: frame i against runs of TWO frames j (its two half-waves take one each, lane a of a
+    // half the patch a), staged through a region of LDS that only this wave touches -- no workgroup barrier, so a wave
+    // that has to evaluate candidates directly holds up nobody else (with the workgroup staging 8 frames together, one
+    // such arg-min stopped four waves at the barrier: binary descriptors 27.9 ms).
     unsigned long long* n_fallback = keys + 4;              // a count of the direct evaluations (DLC_SIM_DEBUG)
     const int prog_len = (int)keys[5];
     const long long i = i_lo + blockIdx.y;
     if (i >= i_hi) return;
     const int tid = threadIdx.x;
-    const int width = PS_JT * P, row = width | 1;
-    double* nb = ps_lds;                                         // [PS_JT * P] |u_b|^2 of the frames' patches
-    unsigned long long* hb = (unsigned long long*)(ps_lds + width);      // [PS_JT * P][2] their content hashes
-    int* g = (int*)(ps_lds + 3 * width);                         // [P][row]
     const int w = tid >> 6, lane = tid & 63;
-    const int jj = tid >> 5, a = tid & 31;
+    const int width = 2 * P, row = width | 1;                    // the run's columns; odd row pitch: 32 patches a read 32 banks
+    double* wl = ps_lds_all + PF_STACK_BYTES / 8 + (size_t)w * pf_wave_doubles(P);   // in front: the summation program's value stacks
+    double* nb = wl;                                             // [2 P] |u_b|^2 of the two frames' patches
+    unsigned long long* hb = (unsigned long long*)(wl + width);  // [2 P][2] their content hashes
+    int* g = (int*)(wl + 3 * width);                             // [P][row]
+    const int jj = lane >> 5, a = lane & 31;
     const long long ra = i * P + (a < P ? a : 0);
     const double pa = proj[ra];
     const bool flat = !(dlc_f64_unkey(keys[1]) > dlc_f64_unkey(keys[0]));      // every descriptor value the same: all distances 0
     const double E = 0x1p-20 * dlc_f64_unkey(keys[3]) + (double)H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
     const double window = 2.0 * E + 1e-8;
     const int* grow0 = G + (i * P - row_base) * ldg - col0;      // G[0][0]: patches (row_base, col0), the panels' 16-row groups
-    int v[8][4];
-    double nbv = 0.0;                                            // this thread's |u_b|^2 of the run in flight (width <= 256)
-    unsigned long long hv0 = 0, hv1 = 0;                         // ... and its hash
+    int v[32];                                                   // row a of the run in flight: this lane's column
+    double nbv = 0.0;                                            // ... and that column's |u_b|^2 and hash
+    unsigned long long hv0 = 0, hv1 = 0;
     auto fetch = [&](long long j0) {
-        const bool in_ = tid < width && j0 * P + tid < N * P;
-        nbv = in_ ? nu2[j0 * P + tid] : 0.0;
-        hv0 = in_ ? rowhash[2 * (j0 * P + tid)] : 0;
-        hv1 = in_ ? rowhash[2 * (j0 * P + tid) + 1] : 0;
-        const long long jlo = j0 > i + 1 ? j0 : i + 1;
-        const long long jhi = j0 + PS_JT < N ? j0 + PS_JT : N;
-        const int c_lo = (int)((jlo - j0) * P), c_hi = (int)((jhi - j0) * P);
-        const int* gb = grow0 + j0 * P;
+        const bool in_ = lane < width && j0 * P + lane < N * P;
+        nbv = in_ ? nu2[j0 * P + lane] : 0.0;
+        hv0 = in_ ? rowhash[2 * (j0 * P + lane)] : 0;
+        hv1 = in_ ? rowhash[2 * (j0 * P + lane) + 1] : 0;
+        const long long jlo = j0 > i + 1 ? j0 : i + 1;           // first frame of the run that is wanted
+        const long long jhi = j0 + 2 < N ? j0 + 2 : N;           // one past the last
+        const bool col_ok = lane >= (int)((jlo - j0) * P) && lane < (int)((jhi - j0) * P);
+        const int* gb = grow0 + j0 * P + lane;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int ar = w + 4 * r, c = lane + 64 * cc;
-                v[r][cc] = (ar < P && c >= c_lo && c < c_hi) ? gb[(long long)ar * ldg + c] : 0;
-            }
+        for (int r = 0; r < 32; ++r) v[r] = (r < P && col_ok) ? gb[(long long)r * ldg] : 0;
     };
-    long long j0 = ((i + 1) / PS_JT + blockIdx.x) * PS_JT;
+    const long long nwaves = (long long)PS_GX * 4;               // waves per frame i: wave q takes the runs q, q + nwaves, ..
+    long long j0 = ((i + 1) / 2 + blockIdx.x * 4 + w) * 2;       // counted from the run that holds frame i + 1
     if (j0 < N) fetch(j0);
     unsigned long long fallbacks = 0;
-    for (; j0 < N; j0 += (long long)PS_GX * PS_JT) {
+    for (; j0 < N; j0 += nwaves * 2) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int ar = w + 4 * r, c = lane + 64 * cc;
-                if (ar < P && c < width) g[ar * row + c] = v[r][cc];
-            }
-        if (tid < width) { nb[tid] = nbv; hb[2 * tid] = hv0; hb[2 * tid + 1] = hv1; }
-        __syncthreads();
-        const long long jn = j0 + (long long)PS_GX * PS_JT;
+        for (int r = 0; r < 32; ++r)
+            if (r < P && lane < width) g[r * row + lane] = v[r];
+        if (lane < width) { nb[lane] = nbv; hb[2 * lane] = hv0; hb[2 * lane + 1] = hv1; }
+        __builtin_amdgcn_wave_barrier();                         // (one wave: its LDS operations execute in order)
+        const long long jn = j0 + nwaves * 2;
         if (jn < N) fetch(jn);
         const long long j = j0 + jj;
         const bool pair_ok = j > i && j < N;
@@ -470,7 +469,7 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
             todo &= todo - 1;
             const unsigned cm = (unsigned)__shfl((int)cand, src);
             const int a_s = src & 31;
-            const long long j_s = j0 + (w * 2 + (src >> 5));
+            const long long j_s = j0 + (src >> 5);
             const double* xa = desc + (i * P + a_s) * H;
             const double* xj = desc + j_s * P * H;
             // (1) all 64 lanes on each candidate's 2 H doubles: squared distances to ~5e-15 (relative); lane b keeps
@@ -520,7 +519,7 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                 // (np.linalg.norm: sqrt(np.add.reduce((x - m) ** 2)) with pairwise summation), eight candidates at a
                 // time -- 8 lanes per candidate, one per strided accumulator of a leaf
                 const int grp = lane >> 3, q = lane & 7;
-                double* stack = ps_lds_all + (w * 8 + grp) * PF_STACK_DEPTH;
+                double* stack = ps_lds_all + (w * 8 + grp) * PF_STACK_DEPTH;      // (this wave's eight)
                 double nbest = 0.0;
                 bool first = true;
                 while (close) {
@@ -609,7 +608,7 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                 out_i64[j * N + i] = t;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();                         // g / nb / hb are rewritten for the next run
     }
     if (n_fallback && lane == 0 && fallbacks) atomicAdd(n_fallback, fallbacks);
 }
@@ -799,7 +798,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         DLC_HIP_CHECK(ctx, hipStreamSynchronize(st));
         if (bad) filter = false;
         else {
-            const size_t tile_lds = PF_STACK_BYTES + (size_t)PS_JT * P * (sizeof(double) + 16) + (size_t)P * ((PS_JT * P) | 1) * sizeof(int);
+            const size_t tile_lds = PF_STACK_BYTES + 4 * pf_wave_doubles((int)P) * sizeof(double);
             for (long long i_lo = 0; i_lo + 1 < N; i_lo += w.chunk_frames_i8) {
                 long long i_hi = i_lo + w.chunk_frames_i8;
                 if (i_hi > N - 1) i_hi = N - 1;
