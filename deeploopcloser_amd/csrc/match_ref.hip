@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
     const int w = tid >> 6, lane = tid & 63;
     const int width = 2 * P, row = width | 1;                    // the run's columns; odd row pitch: 32 patches a read 32 banks
     double* wl = ps_lds_all + PF_STACK_BYTES / 8 + (size_t)w * pf_wave_doubles(P);   // in front: the summation program's value stacks
-    double* nb = wl;                                             // [2 P] |u_b|^2 of the two frames' patches
+    int* nb = (int*)wl;                                          // [2 P] |u_b|^2 of the two frames' patches, in units of 2^-13
     unsigned long long* hb = (unsigned long long*)(wl + width);  // [2 P][2] their content hashes
     int* g = (int*)(wl + 3 * width);                             // [P][row]
     const int jj = lane >> 5, a = lane & 31;
@@ -394,7 +394,9 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
     const double pa = proj[ra];
     const bool flat = !(dlc_f64_unkey(keys[1]) > dlc_f64_unkey(keys[0]));      // every descriptor value the same: all distances 0
     const double E = 0x1p-20 * dlc_f64_unkey(keys[3]) + (double)H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
-    const double window = 2.0 * E + 1e-8;
+    // |u_b|^2 - 2 acc 2^-14 in units of 2^-13, as int32 (|u_b|^2 <= H <= 32768, acc < 2^29): rounding |u_b|^2 moves a
+    // value by half a unit, so two of them compare to within one -- the window grows by that (and 1 for its own rounding)
+    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
     const int* grow0 = G + (i * P - row_base) * ldg - col0;      // G[0][0]: patches (row_base, col0), the panels' 16-row groups
     int v[32];                                                   // row a of the run in flight: this lane's column
     double nbv = 0.0;                                            // ... and that column's |u_b|^2 and hash
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
 #pragma unroll
         for (int r = 0; r < 32; ++r)
             if (r < P && lane < width) g[r * row + lane] = v[r];
-        if (lane < width) { nb[lane] = nbv; hb[2 * lane] = hv0; hb[2 * lane + 1] = hv1; }
+        if (lane < width) { nb[lane] = (int)llrint(nbv * 8192.0); hb[2 * lane] = hv0; hb[2 * lane + 1] = hv1; }
         __builtin_amdgcn_wave_barrier();                         // (one wave: its LDS operations execute in order)
         const long long jn = j0 + nwaves * 2;
         if (jn < N) fetch(jn);
@@ -430,14 +432,14 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
         unsigned cand = 0;
         if (live && !flat) {
             const int* grow = g + a * row + jj * P;
-            const double* nbj = nb + jj * P;
-            double best = 0.0, second = INFINITY;
-            auto scan = [&](int b) {
-                const double d2 = nbj[b] - 0x1p-13 * (double)grow[b];
+            const int* nbj = nb + jj * P;
+            int best = 0, second = 0x7fffffff;
+            auto scan = [&](int b) {                            // integer min / max: a quarter of the fp64 forms' issue cycles
+                const int d2 = nbj[b] - grow[b];
                 if (b == 0) { best = d2; bi = 0; return; }
-                second = fmin(second, fmax(best, d2));
-                bi = d2 < best ? b : bi;
-                best = fmin(best, d2);
+                second = min(second, max(best, d2));            // the smaller of the two that are not the new minimum
+                bi = d2 < best ? b : bi;                        // strict: the first minimum keeps its index
+                best = min(best, d2);
             };
             if (P == 30) {
 #pragma unroll
@@ -446,10 +448,10 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
 #pragma unroll 4
                 for (int b = 0; b < P; ++b) scan(b);
             }
-            if (second <= best + window) {
+            if ((long long)second - best <= window) {
                 const unsigned long long* hbj = hb + 2 * jj * P;
                 for (int b = 0; b < P; ++b) {
-                    if (!(nbj[b] - 0x1p-13 * (double)grow[b] <= best + window)) continue;
+                    if (!((long long)(nbj[b] - grow[b]) - best <= window)) continue;
                     // a copy of an earlier candidate (equal content hashes: sim_mix64) has that candidate's distance
                     // and a later index: np.argmin never takes it
                     bool copy = false;
