@@ -16,7 +16,7 @@ DLC_BF16, DLC_F16, DLC_F32, DLC_F64, DLC_I8 = 0, 1, 2, 3, 4
 DLC_ACT_NONE, DLC_ACT_SIGMOID, DLC_ACT_RELU = 0, 1, 2
 DLC_B_KN, DLC_B_NK = 0, 1
 DLC_MAX_K = 128
-DLC_ABI_VERSION = 4          # include/dlc.h; load() refuses a library built from another header
+DLC_ABI_VERSION = 5          # include/dlc.h; load() refuses a library built from another header
 DLC_SELECT_COOP = 1
 
 _vp, _i64, _int, _sz, _dbl, _flt = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_double, C.c_float
@@ -56,17 +56,21 @@ SIGNATURES = {
     "dlc_cnnvtl_distance_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dlc_l2_normalize_rows": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
     "dlc_cosine_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
-    "dlc_cosine_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "dlc_cosine_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz,
+                              _vp]),
+    "dlc_cosine_score_error_bound": (_dbl, [_i64, _i64, _i64, _int]),
     "dlc_cosine_score_groups": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _vp, _sz, _vp]),
-    "dlc_cosine_select_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _sz,
-                                     _int, _vp]),
+    "dlc_cosine_select_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp,
+                                     _sz, _int, _vp]),
     "dlc_cosine_groups_per_query": (_int, [_int]),
     "dlc_cosine_select_groups": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _vp, _sz, _vp, _vp, _int,
                                        _vp]),
     "dlc_cosine_rescore_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _int,
-                                      _vp, _vp, _int, _vp]),
-    "dlc_topk_merge_strided": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp]),
-    "dlc_topk_merge": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp]),
+                                      _vp, _vp, _vp, _int, _vp]),
+    "dlc_cosine_exhaustive_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _i64, _dbl,
+                                         _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dlc_topk_merge_strided": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _i64, _int, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]),
+    "dlc_topk_merge": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp]),
     "dlc_topk_keep_older": (_int, [_vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp]),
     "dlc_cosine_scores_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dlc_cosine_scores": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _sz, _vp]),

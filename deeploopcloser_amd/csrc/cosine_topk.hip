@@ -54,7 +54,7 @@ constexpr int LDS_BYTES = A_STAGES * A_TILE + 2 * B_TILE;
 constexpr int GROUP = 8;         // database rows per group
 constexpr int HALF = 128;        // database rows per half tile
 constexpr int GROUPS_PER_HALF = HALF / GROUP;
-constexpr int SLACK = 4;         // extra groups kept beyond k (fp32 re-score order vs MFMA order)
+constexpr int SLACK = 4;         // extra groups kept beyond k: how crowded the k-th score may be before the exhaustive pass has to run
 
 template <typename Tag> struct Mfma16;
 template <> struct Mfma16<dlc_bf16_tag> {
@@ -525,17 +525,38 @@ __global__ __launch_bounds__(256) void score_gemv_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------
-// selection on packed 64-bit keys: (monotone score key << 32) | ~id32, so "larger key" ==
-// "higher score, then lower id".  key 0 = empty.
+// Selection.  Two kinds of keys:
+//   * the fp32 (MFMA-order) scores of the score pass only CHOOSE CANDIDATES: packed 64-bit keys
+//     (monotone score key << 32) | ~id32, so "larger key" == "higher score, then lower id"; key 0 = empty;
+//   * the ORDER of every result is decided on fp64 re-scores of the candidates (rescore8_f64 below):
+//     key = round(S64 * 2^40), larger key first, ties -> lower database index.  The same two rules hold in
+//     every plan, in the exhaustive pass and in the merge of per-shard results, so the indices a call returns do
+//     not depend on the plan, the shard count or the batch a query is part of.
+// A selection is CERTIFIED when the k-th fp64 score exceeds, by more than the score pass's error bound tau,
+// the largest fp32 score any row outside the candidate set can have; otherwise the exhaustive pass re-scores
+// every group that could still hold a top-k row.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned f32_key(float x) {   // monotone: larger float -> larger key
     unsigned u = __float_as_uint(x);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ __forceinline__ float key_f32(unsigned k) {   // inverse of f32_key
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
 __device__ __forceinline__ unsigned long long pack_key(float score, unsigned id) {
     return ((unsigned long long)f32_key(score) << 32) | (unsigned long long)(~id);
 }
 __device__ __forceinline__ unsigned key_id(unsigned long long key) { return ~(unsigned)key; }
+
+// Ordering key of an fp64 score: quantised to 2^-40 (oracle/cosine.py: order_key), so that two rows whose exact
+// scores are equal but whose fp64 sums differ in the last bits (the same products in another order) still tie.
+constexpr long long KEY64_EMPTY = (long long)0x8000000000000000ull;
+__device__ __forceinline__ long long f64_key(double s) {
+    const double x = s * 1099511627776.0;                 // 2^40
+    if (!(x > -4.0e18)) return KEY64_EMPTY + 1;           // -inf, NaN, absurdly negative: last
+    if (x > 4.0e18) return 0x7fffffffffffffffll;
+    return __double2ll_rn(x);                             // round half to even, as np.round
+}
 
 // wave-wide unsigned max through DPP (row_shr 1,2,4,8 + row_bcast 15 / 31), result in every lane
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
@@ -551,81 +572,170 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-constexpr int FIN_THREADS = 512;            // merge workgroup; finish workgroup of the stand-alone variant
-// finish kernel LDS carve (bytes) for kg selected groups: keys | re-scored rows | two index lists
-__host__ __device__ inline size_t fin_lds_fixed(int kg) { return (size_t)kg * (GROUPS_PER_HALF * 8 + GROUP * 4 + 8); }
+constexpr int FIN_THREADS = 512;            // merge / exhaustive workgroup; finish workgroup of the stand-alone variant
+// finish kernel LDS carve (bytes) for kg selected groups:
+//   ckey u64 [kg*16] | ck64 i64 [kg*8] | cs64 f64 [kg*8] | crow i32 [kg*8] | sel i32 [kg+1] | sel2 i32 [kg+1] | misc 64 B
+__host__ __device__ inline size_t fin_lds_fixed(int kg) {
+    return (size_t)kg * (GROUPS_PER_HALF * 8 + GROUP * (8 + 8 + 4)) + (size_t)(kg + 1) * 8 + 64;
+}
 
-// Rank-by-counting on unique keys in LDS: out[rank] = element index, for rank < k.
+// Rank-by-counting on unique packed keys in LDS: out[rank] = element index, for rank < k -- and for rank == k when
+// `plus_one` (the best element that was NOT selected: its score bounds everything left behind).
 // Every thread walks the keys in the same order (LDS broadcast reads).
-__device__ __forceinline__ void rank_select(const unsigned long long* keys, int m, int k, int* out) {
+__device__ __forceinline__ void rank_select(const unsigned long long* keys, int m, int k, int* out, bool plus_one = false) {
+    const int lim = plus_one ? k + 1 : k;
     for (int e = threadIdx.x; e < m; e += blockDim.x) {
         const unsigned long long ke = keys[e];
         if (ke == 0ull) continue;
         int rank = 0;
 #pragma unroll 8
         for (int j = 0; j < m; ++j) rank += keys[j] > ke ? 1 : 0;
+        if (rank < lim) out[rank] = e;
+    }
+}
+// The same on (fp64 ordering key, id) pairs: larger key first, then the lower id; KEY64_EMPTY = no element.
+template <typename Id>
+__device__ __forceinline__ void rank_select64(const long long* keys, const Id* ids, int m, int k, int* out) {
+    for (int e = threadIdx.x; e < m; e += blockDim.x) {
+        const long long ke = keys[e];
+        if (ke == KEY64_EMPTY) continue;
+        const Id ie = ids[e];
+        int rank = 0;
+#pragma unroll 4
+        for (int j = 0; j < m; ++j) {
+            const long long kj = keys[j];
+            rank += (kj > ke || (kj == ke && kj != KEY64_EMPTY && ids[j] < ie)) ? 1 : 0;
+        }
         if (rank < k) out[rank] = e;
     }
 }
 
-// One workgroup per query: half-tile selection -> group selection -> exact fp32 re-score of
-// the selected groups' rows -> final top-k.
-// THREADS / RS_UNROLL pick the footprint: (512, 4) is the fastest stand-alone form (246 VGPRs);
-// (256, 1) needs ~70 VGPRs and a few KiB of LDS so that its workgroups can share a CU with a
-// resident score-GEMM workgroup (128 KiB LDS, 2 x 198 VGPRs per SIMD) when the two run on
-// different streams.
+// fp64 dot products of one stored query row with GROUP = 8 stored database rows: the ONE definition of a score's
+// value in this library (include/dlc.h).  bf16 / fp16 -> fp64 conversions are exact, so every product is exact and
+// only the additions round.  Lane l takes the 16-byte pieces l, l + 64, ... of the rows in ascending order, one fp64
+// fma chain per row; the 64 chains are then combined by a butterfly (xor 32, 16, ..., 1; every lane ends with the
+// sum).  The value depends on (query row, database row, d) only -- not on the plan, the shard, the kernel's thread
+// count or RS_UNROLL (which only batches the loads: RS_UNROLL * (GROUP + 1) 16-byte loads in flight per lane).
+template <typename Tag, int RS_UNROLL>
+__device__ __forceinline__ void rescore8_f64(const char* qrow, const char* const (&rows)[GROUP], int d, int lane,
+                                             double (&acc)[GROUP]) {
+#pragma unroll
+    for (int r = 0; r < GROUP; ++r) acc[r] = 0.0;
+    for (int d0 = lane * 8; d0 < d; d0 += 512 * RS_UNROLL) {
+        uint4 qv[RS_UNROLL], rv[RS_UNROLL][GROUP];
+#pragma unroll
+        for (int u = 0; u < RS_UNROLL; ++u) {
+            const int dd = d0 + u * 512;
+            const bool ok = dd < d;
+            qv[u] = ok ? *(const uint4*)(qrow + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r)
+                rv[u][r] = ok ? *(const uint4*)(rows[r] + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < RS_UNROLL; ++u) {
+            const unsigned qw[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
+            double qd[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                qd[2 * e] = (double)Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu));
+                qd[2 * e + 1] = (double)Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16));
+            }
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r) {
+                const unsigned w4[4] = {rv[u][r].x, rv[u][r].y, rv[u][r].z, rv[u][r].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[r] = fma(qd[2 * e], (double)Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc[r]);
+                    acc[r] = fma(qd[2 * e + 1], (double)Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < GROUP; ++r) {
+        double v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        acc[r] = v;
+    }
+}
+
+// One workgroup per query: half-tile selection -> group selection -> fp64 re-score of the candidates' rows ->
+// final top-k -> certification.
+// THREADS / RS_UNROLL pick the footprint: (512, 4) is the fastest stand-alone form; (256, 1) stays under 96 VGPRs
+// and a few KiB of LDS so that its workgroups can share a CU with a resident score-GEMM workgroup (128 KiB LDS,
+// 2 x 198 VGPRs per SIMD) when the two run on different streams.
 // MODE: FIN_FUSED  all of it;
-//       FIN_GROUPS stops after the group selection and writes the kg selected groups of every query
-//                  (grp_ids, -1 = none; grp_max, their maxima, in rank order);
-//       FIN_RESCORE starts from such a list.  With parts > 0 it first drops every own group that
-//                  cannot be among the kg best groups of the WHOLE database: all_max holds the
-//                  lists of all `parts` shards ([parts, q, kg], an all-gather of grp_max), and a
-//                  group with kg or more strictly larger maxima anywhere is out.  Each shard then
-//                  re-scores ~kg/parts groups per query instead of kg.
+//       FIN_GROUPS stops after the group selection and writes the kg selected groups of every query (grp_ids, -1 =
+//                  none; grp_max [q, kg + 1]: their maxima in rank order, and in column kg the largest maximum among
+//                  the shard's groups that are NOT listed, -inf if there is none);
+//       FIN_RESCORE starts from such a list.  With parts > 0 it first drops every own group that cannot be among
+//                  the kg best groups of the WHOLE database: all_max holds the lists of all `parts` shards
+//                  ([parts, q, kg + 1], an all-gather of grp_max), and a group with kg or more strictly larger
+//                  maxima anywhere is out.  Each shard then re-scores ~kg/parts groups per query instead of kg, and
+//                  writes to bound_out[q] the largest fp32 score a row outside the surviving groups of ALL shards
+//                  can have (the same value on every shard): the merge certifies against it.
 enum { FIN_FUSED = 0, FIN_GROUPS = 1, FIN_RESCORE = 2 };
-struct FinishExtra {
-    int* grp_ids;             // [q, kg]
-    float* grp_max;           // [q, kg]
-    const float* all_max;     // [parts, q, kg] or null
+struct FinishArgs {
+    float* tmax; long long ldt; int nh; int tv_in_lds;
+    const float* gmax; long long ldg; long long ng;
+    int kg;                       // groups kept per query (k + SLACK)
+    const char* Q; long long ldq_b; const char* DB; long long lddb_b;
+    long long n; int d; int k; long long row_offset;
+    float* out_s;                 // [q, k] fp32 (the fp64 score rounded once); may be null in FIN_RESCORE
+    double* out_s64;              // [q, k] fp64, never null inside the kernels (the workspace lends one)
+    long long* out_i;             // [q, k]
+    int* status;                  // FIN_FUSED: [q] 0 = certified, 1 = the exhaustive pass has to run
+    double tau;                   // error bound of the score pass's fp32 scores against the fp64 re-score
+    int* grp_ids;                 // [q, kg]
+    float* grp_max;               // [q, kg + 1]
+    const float* all_max;         // [parts, q, kg + 1] or null
     int parts;
     long long nq;
-    int gparts;               // FIN_RESCORE: > 1 = grid.y workgroups per query, workgroup y re-scores the listed
-                              // groups e with e % gparts == y and writes its top-k at [y][q][k]
-    const float* dense_S;     // small-database plan: the score matrix itself [q, ld_s] is in the workspace, so the
-    long long ld_s;           // selected groups' scores are READ from it instead of re-computed from gathered rows
+    int gparts;                   // FIN_RESCORE: > 1 = grid.y workgroups per query, workgroup y re-scores the listed
+                                  // groups e with e % gparts == y and writes its top-k at [y][q][k]
+    float* bound_out;             // FIN_RESCORE: [q] or null
+    const float* dense_S;         // small-database plan: the fp32 score matrix [q, ld_s] is in the workspace, so the
+    long long ld_s;               // candidates are ROWS: the k + rslack best fp32 scores of the selected groups
+    int rslack;
 };
 
 // The 256-thread forms are meant to sit beside a resident score-GEMM workgroup (2 x 200 VGPRs per
-// SIMD): 5 waves per SIMD caps them at 96 VGPRs.  (Left to itself the compiler chose 116-118 for two
-// of them -- more loads in flight, but no room beside the GEMM.)
+// SIMD): 5 waves per SIMD caps them at 96 VGPRs.
 template <typename Tag, int THREADS, int RS_UNROLL, int MODE>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 5 : 1)))
-void finish_topk_kernel(
-    float* __restrict__ tmax, long long ldt, int nh, int tv_in_lds, const float* __restrict__ gmax, long long ldg,
-    long long ng, int kg, const char* __restrict__ Q, long long ldq_b, const char* __restrict__ DB, long long lddb_b,
-    long long n, int d, int k, long long row_offset, float* __restrict__ out_s, long long* __restrict__ out_i,
-    FinishExtra x) {
+void finish_topk_kernel(FinishArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int FIN_WAVES = THREADS / 64;
     constexpr int FIN_THREADS = THREADS;      // shadows the namespace constant inside this kernel
     constexpr int GPH = GROUPS_PER_HALF;
-    unsigned long long* ckey = (unsigned long long*)dsm;                       // [kg * GPH]
-    float* cval = (float*)(dsm + (size_t)kg * GPH * 8);                        // [kg * GROUP] re-scored rows
-    int* sel = (int*)(dsm + (size_t)kg * (GPH * 8 + GROUP * 4));               // [kg] half tiles; later the winners
-    int* sel2 = sel + kg;                                                      // [kg] selected groups
+    const int kg = a.kg, k = a.k;
+    const long long n = a.n;
+    unsigned long long* ckey = (unsigned long long*)dsm;                       // [kg * GPH] packed fp32 keys
+    long long* ck64 = (long long*)(dsm + (size_t)kg * GPH * 8);                // [kg * GROUP] fp64 ordering keys
+    double* cs64 = (double*)(dsm + (size_t)kg * (GPH * 8 + GROUP * 8));        // [kg * GROUP] fp64 scores
+    int* crow = (int*)(dsm + (size_t)kg * (GPH * 8 + GROUP * 16));             // [kg * GROUP] candidate rows (shard-local)
+    int* sel = (int*)(dsm + (size_t)kg * (GPH * 8 + GROUP * 20));              // [kg + 1]
+    int* sel2 = sel + kg + 1;                                                  // [kg + 1]
+    unsigned* misc = (unsigned*)(sel2 + kg + 1);                               // [16]
     const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // [nh] half-tile maxima of this query: staged in LDS, or consumed in place in the workspace
     // row (which the next GEMM rewrites anyway) when LDS is to be kept small or the shard is huge
-    float* tv = tv_in_lds ? (float*)(dsm + fin_lds_fixed(kg)) : tmax + (long long)qi * ldt;
-    if (tv_in_lds)
-        for (int e = tid; e < nh; e += FIN_THREADS) tv[e] = tmax[(long long)qi * ldt + e];
-    for (int e = tid; e < kg; e += FIN_THREADS) { sel[e] = -1; sel2[e] = -1; }
+    float* tv = a.tv_in_lds ? (float*)(dsm + fin_lds_fixed(kg)) : a.tmax + (long long)qi * a.ldt;
+    if (a.tv_in_lds)
+        for (int e = tid; e < a.nh; e += FIN_THREADS) tv[e] = a.tmax[(long long)qi * a.ldt + e];
+    for (int e = tid; e <= kg; e += FIN_THREADS) { sel[e] = -1; sel2[e] = -1; }
+    if (tid < 16) misc[tid] = 0u;
     __syncthreads();
     int kg2;
+    unsigned bkey = 0u;      // fp32 key of the largest group maximum left behind by the selection; 0 = nothing left behind
     if constexpr (MODE != FIN_RESCORE) {
     // ---- level 1: the kt half tiles with the largest maximum (ties -> lower tile).
     // Each wave extracts the kt best of its slice by repeated wave arg-max (DPP, no barrier);
-    // the FIN_WAVES * kt survivors are ranked together.
+    // the FIN_WAVES * kt survivors are ranked together.  What a wave has left after its kt extractions
+    // (misc[w]) and the survivor of rank kt bound every half tile that is not selected.
+    const int nh = a.nh;
     const int kt = min(kg, nh);
     {
         const int chunk = (nh + FIN_WAVES - 1) / FIN_WAVES;
@@ -685,30 +795,38 @@ void finish_topk_kernel(
             }
         }
         }
+        const unsigned rest = wave_max_u32(bh);          // the best half tile this wave did not hand in
+        if (lane == 0) misc[w] = rest;
     }
     __syncthreads();
-    rank_select(ckey, FIN_WAVES * kt, kt, sel);          // sel[rank] = slot in ckey
+    rank_select(ckey, FIN_WAVES * kt, kt, sel, true);    // sel[rank] = slot in ckey
     __syncthreads();
+#pragma unroll
+    for (int ww = 0; ww < FIN_WAVES; ++ww) bkey = max(bkey, misc[ww]);
+    if (sel[kt] >= 0) bkey = max(bkey, (unsigned)(ckey[sel[kt]] >> 32));
     if (tid < kt) { const int c = sel[tid]; sel[tid] = c < 0 ? -1 : (int)key_id(ckey[c]); }   // -> half-tile index
     __syncthreads();
 
-    // ---- level 2: among their groups, the kg2 groups with the largest maximum
+    // ---- level 2: among their groups, the kg2 groups with the largest maximum (+ the best one left behind)
     const int m2 = kt * GPH;
     for (int e = tid; e < m2; e += FIN_THREADS) {
         const int ht = sel[e / GPH];
         const long long g = (long long)ht * GPH + (e % GPH);
-        ckey[e] = (ht >= 0 && g < ng) ? pack_key(gmax[(long long)qi * ldg + g], (unsigned)g) : 0ull;
+        ckey[e] = (ht >= 0 && g < a.ng) ? pack_key(a.gmax[(long long)qi * a.ldg + g], (unsigned)g) : 0ull;
     }
     __syncthreads();
     kg2 = min(kg, m2);
-    rank_select(ckey, m2, kg2, sel2);
+    rank_select(ckey, m2, kg2, sel2, true);
     __syncthreads();
+    if (sel2[kg2] >= 0) bkey = max(bkey, (unsigned)(ckey[sel2[kg2]] >> 32));
     if constexpr (MODE == FIN_GROUPS) {
+        const long long W = kg + 1;
         for (int e = tid; e < kg; e += FIN_THREADS) {
             const int c = e < kg2 ? sel2[e] : -1;
-            x.grp_ids[(long long)qi * kg + e] = c < 0 ? -1 : (int)key_id(ckey[c]);
-            x.grp_max[(long long)qi * kg + e] = c < 0 ? -INFINITY : gmax[(long long)qi * ldg + key_id(ckey[c])];
+            a.grp_ids[(long long)qi * kg + e] = c < 0 ? -1 : (int)key_id(ckey[c]);
+            a.grp_max[(long long)qi * W + e] = c < 0 ? -INFINITY : a.gmax[(long long)qi * a.ldg + key_id(ckey[c])];
         }
+        if (tid == 0) a.grp_max[(long long)qi * W + kg] = bkey ? key_f32(bkey) : -INFINITY;
         return;
     }
     if (tid < kg2) { const int c = sel2[tid]; sel2[tid] = c < 0 ? -1 : (int)key_id(ckey[c]); }   // -> group index
@@ -716,157 +834,283 @@ void finish_topk_kernel(
     } else {
         // ---- start from a group list; optionally filter it against the other shards' maxima
         kg2 = kg;
-        for (int e = tid; e < kg; e += FIN_THREADS) {
-            int g = x.grp_ids[(long long)qi * kg + e];
-            if (g >= 0 && x.parts > 0) {
-                const float v = x.grp_max[(long long)qi * kg + e];
+        const long long W = kg + 1;
+        if (a.parts > 0) {
+            // what ALL shards leave behind: every shard's own rest bound (column kg) and every listed group that the
+            // filter drops, here or elsewhere -- the same number on every shard
+            unsigned bk = 0u;
+            for (int e = tid; e < a.parts * (int)W; e += FIN_THREADS) {
+                const int pp = e / (int)W, j = e % (int)W;
+                const float v = a.all_max[((long long)pp * a.nq + qi) * W + j];
+                if (v == -INFINITY) continue;
+                if (j == kg) { bk = max(bk, f32_key(v)); continue; }
                 int greater = 0;
-                for (int pp = 0; pp < x.parts; ++pp) {
-                    const float* av = x.all_max + ((long long)pp * x.nq + qi) * kg;
+                for (int p2 = 0; p2 < a.parts; ++p2) {
+                    const float* av = a.all_max + ((long long)p2 * a.nq + qi) * W;
+                    for (int j2 = 0; j2 < kg; ++j2) greater += av[j2] > v ? 1 : 0;
+                }
+                if (greater >= kg) bk = max(bk, f32_key(v));
+            }
+            if (bk) atomicMax(&misc[8], bk);
+        }
+        for (int e = tid; e < kg; e += FIN_THREADS) {
+            int g = a.grp_ids[(long long)qi * kg + e];
+            if (g >= 0 && a.parts > 0) {
+                const float v = a.grp_max[(long long)qi * W + e];
+                int greater = 0;
+                for (int pp = 0; pp < a.parts; ++pp) {
+                    const float* av = a.all_max + ((long long)pp * a.nq + qi) * W;
                     for (int j = 0; j < kg; ++j) greater += av[j] > v ? 1 : 0;
                 }
                 if (greater >= kg) g = -1;
             }
-            if (x.gparts > 1 && e % x.gparts != (int)blockIdx.y) g = -1;
+            if (a.gparts > 1 && e % a.gparts != (int)blockIdx.y) g = -1;
             sel2[e] = g;
         }
         __syncthreads();
+        if (a.parts > 0) bkey = misc[8];
+        else {
+            const float v = a.grp_max[(long long)qi * W + kg];
+            bkey = v == -INFINITY ? 0u : f32_key(v);
+        }
+        if (a.bound_out && blockIdx.y == 0 && tid == 0) a.bound_out[qi] = bkey ? key_f32(bkey) : -INFINITY;
     }
 
-    // ---- re-score: wave w takes groups w, w+8, ...; GROUP exact fp32 dot products each
-    const char* qrow = Q + (long long)qi * ldq_b;
-    for (int s = w; s < kg2; s += FIN_WAVES) {
-        const int g = sel2[s];
-        if (g < 0) {
-            if (lane < GROUP) cval[s * GROUP + lane] = -INFINITY;
-            continue;
+    // ---- candidate rows
+    int m3;
+    if (a.dense_S) {
+        // small-database plan: the selected groups' fp32 scores are in the workspace -- keep their k + rslack best
+        // ROWS (and remember the best row left behind)
+        const int m = kg2 * GROUP;
+        for (int e = tid; e < m; e += FIN_THREADS) {
+            const int g = sel2[e / GROUP];
+            const long long row = (long long)g * GROUP + (e % GROUP);
+            ckey[e] = (g >= 0 && row < n) ? pack_key(a.dense_S[(long long)qi * a.ld_s + row], (unsigned)row) : 0ull;
         }
-        const long long row0 = (long long)g * GROUP;
-        if (x.dense_S) {                                  // the group's 8 scores are already there
-            if (lane < GROUP)
-                cval[s * GROUP + lane] = (row0 + lane < n) ? x.dense_S[(long long)qi * x.ld_s + row0 + lane] : -INFINITY;
-            continue;
+        m3 = min(k + a.rslack, m);
+        for (int e = tid; e <= m3 && e < kg * GROUP; e += FIN_THREADS) crow[e] = -1;
+        __syncthreads();
+        if (m3 < m) rank_select(ckey, m, m3, crow, true);
+        else rank_select(ckey, m, m3, crow, false);
+        __syncthreads();
+        if (m3 < m && crow[m3] >= 0) bkey = max(bkey, (unsigned)(ckey[crow[m3]] >> 32));
+        __syncthreads();
+        for (int e = tid; e < m3; e += FIN_THREADS) { const int c = crow[e]; crow[e] = c < 0 ? -1 : (int)key_id(ckey[c]); }
+    } else {
+        m3 = kg2 * GROUP;
+        for (int e = tid; e < m3; e += FIN_THREADS) {
+            const int g = sel2[e / GROUP];
+            const long long row = (long long)g * GROUP + (e % GROUP);
+            crow[e] = (g >= 0 && row < n) ? (int)row : -1;
         }
+    }
+    __syncthreads();
+
+    // ---- fp64 re-score: wave w takes candidates 8w .. 8w + 7, then 8 (w + FIN_WAVES) ...
+    const char* qrow = a.Q + (long long)qi * a.ldq_b;
+    for (int s = w; s * GROUP < m3; s += FIN_WAVES) {
+        int ids[GROUP];
+        bool any = false;
         const char* rows[GROUP];
 #pragma unroll
         for (int r = 0; r < GROUP; ++r) {
-            long long rr = row0 + r;
-            if (rr > n - 1) rr = n - 1;
-            rows[r] = DB + rr * lddb_b;
+            ids[r] = s * GROUP + r < m3 ? crow[s * GROUP + r] : -1;
+            any |= ids[r] >= 0;
+            rows[r] = a.DB + (long long)(ids[r] < 0 ? 0 : ids[r]) * a.lddb_b;
         }
-        float acc[GROUP];
+        double acc[GROUP] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (any) rescore8_f64<Tag, RS_UNROLL>(qrow, rows, a.d, lane, acc);
 #pragma unroll
-        for (int r = 0; r < GROUP; ++r) acc[r] = 0.f;
-        // RS_UNROLL chunks of 512 elements per trip: all their row loads are issued before the
-        // first use, so RS_UNROLL * GROUP + RS_UNROLL 16-byte loads are in flight per lane.
-        for (int d0 = lane * 8; d0 < d; d0 += 512 * RS_UNROLL) {
-            uint4 qv[RS_UNROLL], rv[RS_UNROLL][GROUP];
-#pragma unroll
-            for (int u = 0; u < RS_UNROLL; ++u) {
-                const int dd = d0 + u * 512;
-                const bool ok = dd < d;
-                qv[u] = ok ? *(const uint4*)(qrow + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < GROUP; ++r)
-                    rv[u][r] = ok ? *(const uint4*)(rows[r] + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
+        for (int r = 0; r < GROUP; ++r)
+            if (lane == r && s * GROUP + r < m3) {
+                cs64[s * GROUP + r] = ids[r] < 0 ? -INFINITY : acc[r];
+                ck64[s * GROUP + r] = ids[r] < 0 ? KEY64_EMPTY : f64_key(acc[r]);
             }
-#pragma unroll
-            for (int u = 0; u < RS_UNROLL; ++u) {
-                const unsigned qw[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
-                float qf[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    qf[2 * e] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu));
-                    qf[2 * e + 1] = Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16));
-                }
-#pragma unroll
-                for (int r = 0; r < GROUP; ++r) {
-                    const unsigned w4[4] = {rv[u][r].x, rv[u][r].y, rv[u][r].z, rv[u][r].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[r] = fmaf(qf[2 * e], Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc[r]);
-                        acc[r] = fmaf(qf[2 * e + 1], Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc[r]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < GROUP; ++r) {
-            float v = acc[r];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == r) cval[s * GROUP + r] = (row0 + r < n) ? v : -INFINITY;
-        }
     }
-    const long long oq = (long long)blockIdx.y * x.nq + qi;      // blockIdx.y > 0 only with gparts > 1
+    const long long oq = (long long)blockIdx.y * a.nq + qi;      // blockIdx.y > 0 only with gparts > 1
     for (int e = tid; e < k; e += FIN_THREADS) {          // defaults for slots past the candidates
-        out_s[oq * k + e] = -INFINITY;
-        out_i[oq * k + e] = -1;
+        if (a.out_s) a.out_s[oq * k + e] = -INFINITY;
+        a.out_s64[oq * k + e] = -INFINITY;
+        a.out_i[oq * k + e] = -1;
     }
-    for (int e = tid; e < kg; e += FIN_THREADS) sel[e] = -1;
+    for (int e = tid; e <= kg; e += FIN_THREADS) sel[e] = -1;
     __syncthreads();
 
-    // ---- final top-k of the kg2*GROUP re-scored rows (id = database row inside the shard)
-    const int m3 = kg2 * GROUP;
-    for (int e = tid; e < m3; e += FIN_THREADS) {
-        const float v = cval[e];
-        const int g = sel2[e / GROUP];
-        ckey[e] = (g < 0 || v == -INFINITY) ? 0ull : pack_key(v, (unsigned)((long long)g * GROUP + (e % GROUP)));
-    }
-    __syncthreads();
-    rank_select(ckey, m3, k, sel);
+    // ---- final top-k of the re-scored rows: fp64 key descending, ties -> lower row
+    rank_select64(ck64, crow, m3, k, sel);
     __syncthreads();
     for (int e = tid; e < k; e += FIN_THREADS) {
         const int c = sel[e];
         if (c >= 0) {
-            out_s[oq * k + e] = cval[c];
-            out_i[oq * k + e] = (long long)key_id(ckey[c]) + row_offset;
+            if (a.out_s) a.out_s[oq * k + e] = (float)cs64[c];
+            a.out_s64[oq * k + e] = cs64[c];
+            a.out_i[oq * k + e] = (long long)crow[c] + a.row_offset;
+        }
+    }
+    if constexpr (MODE == FIN_FUSED) {
+        // certified: nothing was left behind, or the k-th fp64 score clears everything left behind by more than tau
+        if (tid == 0) {
+            const int c = sel[k - 1];
+            const bool cert = bkey == 0u || (c >= 0 && cs64[c] > (double)key_f32(bkey) + a.tau);
+            a.status[qi] = cert ? 0 : 1;
         }
     }
 }
 
+// Exhaustive pass of the queries a selection could not certify (status[q] == 1; every other workgroup leaves at once).
+// L = the k-th fp64 score found so far (lower[q * lower_stride]; -inf: fewer than k rows found) is a lower bound of
+// the true k-th score, so every top-k row has an fp32 score >= L - tau and lies in a group whose maximum is >= L - tau:
+// all such groups are re-scored in fp64, 64 groups at a time, against a running top-k (L only rises on the way).
+// The result REPLACES the query's top-k; status becomes 2.  In the degenerate case (all scores within tau of each
+// other) this is an fp64 brute force over the shard for that query -- slow, finite and exact.
+struct ExhaustiveArgs {
+    const float* gmax; long long ldg; long long ng;
+    const char* Q; long long ldq_b; const char* DB; long long lddb_b;
+    long long n; int d; int k; long long row_offset;
+    const double* lower; long long lower_stride;
+    float* out_s; double* out_s64; long long* out_i;     // [q, k]; out_s / out_s64 may be null
+    int* status;
+    double tau;
+};
+constexpr int EXH_BATCH = 64;                               // groups per re-score batch
+constexpr int EXH_POOL = EXH_BATCH * GROUP + DLC_MAX_K;     // running top-k in front of the batch's rows
+
+template <typename Tag>
+__global__ __launch_bounds__(FIN_THREADS) void exhaustive_topk_kernel(ExhaustiveArgs a) {
+    const int qi = blockIdx.x;
+    if (a.status[qi] != 1) return;
+    __shared__ long long pk[EXH_POOL];
+    __shared__ double ps[EXH_POOL];
+    __shared__ int pid[EXH_POOL];
+    __shared__ int qlist[FIN_THREADS];
+    __shared__ int wcnt[FIN_THREADS / 64];
+    __shared__ int sel[DLC_MAX_K];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = a.k;
+    double theta = a.lower[(long long)qi * a.lower_stride] - a.tau;      // -inf - tau = -inf: everything qualifies
+    int cnt = 0;                                                         // rows in the running top-k (pool[0 .. cnt))
+    const char* qrow = a.Q + (long long)qi * a.ldq_b;
+    for (long long c0 = 0; c0 < a.ng; c0 += FIN_THREADS) {
+        const long long g = c0 + tid;
+        const bool qual = g < a.ng && (double)a.gmax[(long long)qi * a.ldg + g] >= theta;
+        const unsigned long long bal = __ballot(qual);
+        if (lane == 0) wcnt[w] = __popcll(bal);
+        __syncthreads();
+        int base = 0, nqual = 0;
+#pragma unroll
+        for (int ww = 0; ww < FIN_THREADS / 64; ++ww) {
+            base += ww < w ? wcnt[ww] : 0;
+            nqual += wcnt[ww];
+        }
+        if (qual) qlist[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)g;
+        __syncthreads();
+        for (int b0 = 0; b0 < nqual; b0 += EXH_BATCH) {
+            const int nb = min(EXH_BATCH, nqual - b0);
+            for (int s = w; s < nb; s += FIN_THREADS / 64) {
+                const long long row0 = (long long)qlist[b0 + s] * GROUP;
+                const char* rows[GROUP];
+#pragma unroll
+                for (int r = 0; r < GROUP; ++r) rows[r] = a.DB + (row0 + r < a.n ? row0 + r : a.n - 1) * a.lddb_b;
+                double acc[GROUP];
+                rescore8_f64<Tag, 4>(qrow, rows, a.d, lane, acc);
+#pragma unroll
+                for (int r = 0; r < GROUP; ++r)
+                    if (lane == r) {
+                        const bool ok = row0 + r < a.n;
+                        ps[cnt + s * GROUP + r] = ok ? acc[r] : -INFINITY;
+                        pk[cnt + s * GROUP + r] = ok ? f64_key(acc[r]) : KEY64_EMPTY;
+                        pid[cnt + s * GROUP + r] = (int)(row0 + r);
+                    }
+            }
+            for (int e = tid; e < k; e += FIN_THREADS) sel[e] = -1;
+            __syncthreads();
+            const int m = cnt + nb * GROUP;
+            rank_select64(pk, pid, m, k, sel);
+            __syncthreads();
+            // compact the winners to the front of the pool (through registers: k <= 128 < FIN_THREADS)
+            long long tk = KEY64_EMPTY; double ts = -INFINITY; int ti = -1;
+            if (tid < k && sel[tid] >= 0) { const int c = sel[tid]; tk = pk[c]; ts = ps[c]; ti = pid[c]; }
+            const unsigned long long have = __ballot(tid < k && sel[tid] >= 0);
+            if (lane == 0) wcnt[w] = __popcll(have);
+            __syncthreads();
+            if (tid < k) { pk[tid] = tk; ps[tid] = ts; pid[tid] = ti; }
+            cnt = 0;
+#pragma unroll
+            for (int ww = 0; ww < FIN_THREADS / 64; ++ww) cnt += wcnt[ww];
+            __syncthreads();
+            if (cnt == k && ps[k - 1] - a.tau > theta) theta = ps[k - 1] - a.tau;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < k; e += FIN_THREADS) {
+        const bool ok = e < cnt;
+        if (a.out_s) a.out_s[(long long)qi * k + e] = ok ? (float)ps[e] : -INFINITY;
+        if (a.out_s64) a.out_s64[(long long)qi * k + e] = ok ? ps[e] : -INFINITY;
+        a.out_i[(long long)qi * k + e] = ok ? (long long)pid[e] + a.row_offset : -1;
+    }
+    if (tid == 0) a.status[qi] = 2;
+}
+
 // Global top-k from [parts, q, k] per-shard results (the all-gather layout); idx < 0 = empty slot.
-// Rank-by-counting on (score key, id): ids are unique, so the order is total.
-__global__ __launch_bounds__(FIN_THREADS) void merge_topk_kernel(const float* __restrict__ pscores,
+// Rank-by-counting on (fp64 ordering key, id): ids are unique, so the order is total -- and it is the order every
+// shard used for its own list.  With `bound` (the largest fp32 score a row outside all shards' candidates can have,
+// dlc_cosine_rescore_topk) the merge also certifies: status[q] = 0 when the k-th score clears bound[q] by more
+// than tau, 1 otherwise.
+__global__ __launch_bounds__(FIN_THREADS) void merge_topk_kernel(const double* __restrict__ pscores,
                                                                  long long s_stride,
                                                                  const long long* __restrict__ pidx,
                                                                  long long i_stride, int parts, long long nq, int k,
+                                                                 const float* __restrict__ bound, double tau,
                                                                  float* __restrict__ out_s,
-                                                                 long long* __restrict__ out_i) {
+                                                                 double* __restrict__ out_s64,
+                                                                 long long* __restrict__ out_i,
+                                                                 int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
+    __shared__ double kth;
+    __shared__ int have_kth;
     const int qi = blockIdx.x, tid = threadIdx.x;
     const int m = parts * k;
     long long* ci = (long long*)dsm;
-    unsigned* sk = (unsigned*)(dsm + (size_t)m * 8);
-    float* cs = (float*)(dsm + (size_t)m * 12);
+    long long* ck = (long long*)(dsm + (size_t)m * 8);
+    double* cs = (double*)(dsm + (size_t)m * 16);
+    if (tid == 0) { kth = -INFINITY; have_kth = 0; }
     for (int e = tid; e < m; e += FIN_THREADS) {
         const long long o = (long long)qi * k + (e % k);
         const long long id = pidx[(long long)(e / k) * i_stride + o];
-        const float s = pscores[(long long)(e / k) * s_stride + o];
+        const double s = pscores[(long long)(e / k) * s_stride + o];
         ci[e] = id; cs[e] = s;
-        sk[e] = id < 0 ? 0u : f32_key(s);
+        ck[e] = id < 0 ? KEY64_EMPTY : f64_key(s);
     }
     for (int e = tid; e < k; e += FIN_THREADS) {
-        out_s[(long long)qi * k + e] = -INFINITY;
+        if (out_s) out_s[(long long)qi * k + e] = -INFINITY;
+        if (out_s64) out_s64[(long long)qi * k + e] = -INFINITY;
         out_i[(long long)qi * k + e] = -1;
     }
     __syncthreads();
     for (int e = tid; e < m; e += FIN_THREADS) {
-        const unsigned se = sk[e];
+        const long long ke = ck[e];
         const long long ie = ci[e];
-        if (ie < 0) continue;
+        if (ke == KEY64_EMPTY) continue;
         int rank = 0;
         for (int j = 0; j < m; ++j) {
-            const unsigned sj = sk[j];
-            const long long ij = ci[j];
-            rank += (ij >= 0 && (sj > se || (sj == se && ij < ie))) ? 1 : 0;
+            const long long kj = ck[j];
+            rank += (kj > ke || (kj == ke && kj != KEY64_EMPTY && ci[j] < ie)) ? 1 : 0;
         }
         if (rank < k) {
-            out_s[(long long)qi * k + rank] = cs[e];
+            if (out_s) out_s[(long long)qi * k + rank] = (float)cs[e];
+            if (out_s64) out_s64[(long long)qi * k + rank] = cs[e];
             out_i[(long long)qi * k + rank] = ie;
+            if (rank == k - 1) { kth = cs[e]; have_kth = 1; }
+        }
+    }
+    if (status) {
+        __syncthreads();
+        if (tid == 0) {
+            const float b = bound ? bound[qi] : -INFINITY;
+            status[qi] = (b == -INFINITY || (have_kth && kth > (double)b + tau)) ? 0 : 1;
         }
     }
 }
+
 
 // Row L2 normalisation into the stored descriptor format.
 template <typename Src, typename Tag>
@@ -1011,7 +1255,7 @@ __global__ __launch_bounds__(256) void l2_normalize_regs_kernel(const Src* __res
     }
 }
 
-// Split-K second pass.  Sums the chunk partials in chunk order (deterministic) and applies the
+// Split-K second pass.  Sums the chunk partials in chunk order (deterministic; in fp64, rounded once) and applies the
 // epilogue of the one-pass kernel: GROUPS -> gmax / tmax, DENSE -> the score matrix.
 // grid (q, ceil(groups / 256)), 256 threads: one thread per group of 8 rows.
 // keep_sum: also store the summed scores over chunk 0's slot (thread-private elements, so in place):
@@ -1024,14 +1268,17 @@ __global__ __launch_bounds__(256) void splitk_groups_kernel(float* __restrict__ 
     const long long g = (long long)blockIdx.y * 256 + threadIdx.x;
     float m = -INFINITY;
     if (g < ng) {
-        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        // chunk partials summed in fp64 and rounded ONCE: the error of a split score against the fp64 re-score is then
+        // that of one chunk's MFMA chain (the tau of the selection's certificate), not of the whole row's
+        f64x4_t a64 = {0., 0., 0., 0.}, b64 = {0., 0., 0., 0.};
         float* dst0 = P + (long long)qi * ldp + g * GROUP;
         const float* src = dst0;
         for (int c = 0; c < nsplit; ++c) {
-            a += *(const f32x4_t*)(src);
-            b += *(const f32x4_t*)(src + 4);
+            a64 += __builtin_convertvector(*(const f32x4_t*)(src), f64x4_t);
+            b64 += __builtin_convertvector(*(const f32x4_t*)(src + 4), f64x4_t);
             src += (long long)q * ldp;
         }
+        const f32x4_t a = __builtin_convertvector(a64, f32x4_t), b = __builtin_convertvector(b64, f32x4_t);
         if (keep_sum && nsplit > 1) {
             *(f32x4_t*)dst0 = a;
             *(f32x4_t*)(dst0 + 4) = b;
@@ -1054,12 +1301,13 @@ __global__ __launch_bounds__(256) void splitk_dense_kernel(const float* __restri
     const int qi = blockIdx.x;
     const long long r0 = ((long long)blockIdx.y * 256 + threadIdx.x) * 4;
     if (r0 >= n) return;
-    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+    f64x4_t a64 = {0., 0., 0., 0.};                       // as splitk_groups_kernel: fp64 sum of the chunks, one rounding
     const float* src = P + (long long)qi * ldp + r0;
     for (int c = 0; c < nsplit; ++c) {
-        a += *(const f32x4_t*)src;
+        a64 += __builtin_convertvector(*(const f32x4_t*)src, f64x4_t);
         src += (long long)q * ldp;
     }
+    const f32x4_t a = __builtin_convertvector(a64, f32x4_t);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (r0 + r < n) S[(long long)qi * lds + r0 + r] = a[r];
@@ -1104,12 +1352,13 @@ SplitPlan split_plan(int64_t q, int64_t n, int64_t d) {
 }
 
 struct WsLayout {
-    size_t gmax, tmax, part, rs_ids, rs_max, rs_scores, rs_idx, total;
+    size_t gmax, tmax, part, status, s64, rs_ids, rs_max, rs_scores, rs_idx, rs_bound, total;
     long long ldg, ldt, ldp;
     int kg;
     SplitPlan sp;
     int rparts;     // > 1: dlc_cosine_topk re-scores with this many workgroups per query (few queries, long rows)
-    bool dense;     // small database: the score matrix itself is kept (chunk 0 of `part`) and the top-k is read off it
+    bool dense;     // small database: the score matrix itself is kept (chunk 0 of `part`) and the candidates are ROWS
+    double tau;     // error bound of the score pass against the fp64 re-score (score_error_bound below)
 };
 
 // Few queries take the bandwidth kernel (stored queries in LDS: q <= 4 and q * d * 2 bytes <= 64 KiB).
@@ -1119,17 +1368,15 @@ inline bool gemv_shape(int64_t q, int64_t nk) {
 }
 
 // Small-database plan.  The standard plan never writes the score matrix: it keeps group maxima and
-// re-scores the kg * 8 rows of the selected groups exactly -- a gather of kg * 8 * d * 2 bytes per
+// re-scores the kg * 8 rows of the selected groups in fp64 -- a gather of kg * 8 * d * 2 bytes per
 // query whatever the database size.  Against a small database (the reference's own scale: 1063
 // key-frames x 75 000-d, where that gather is 192 of the 1063 rows, 29 MB per query, 30 GB per
-// call) the whole score matrix is cheaper than the gather: q * n * 4 bytes.  The score pass then
-// writes its tile(s) to the workspace, the reducing pass keeps the sum, and the selection reads the
-// scores of its groups from it.  Scores are the MFMA-order fp32 sums (chunk-ordered when split).
+// call) the whole fp32 score matrix is cheap (q * n * 4 bytes) and lets the selection pick its
+// candidates by ROW: the k + DENSE_ROW_SLACK best fp32 scores of the selected groups are re-scored
+// (24 rows per query at k = 20 instead of 192).
 constexpr int64_t DENSE_MAX_ROWS = 16384;
+constexpr int DENSE_ROW_SLACK = 4;
 inline bool dense_plan(int64_t q, int64_t n, int64_t d) {
-#ifdef DLC_EXPERIMENT_NO_DENSE   // perf experiment build only (scripts/)
-    return false;
-#endif
     return n <= DENSE_MAX_ROWS && !gemv_shape(q, d / BK);
 }
 
@@ -1137,7 +1384,22 @@ inline bool dense_plan(int64_t q, int64_t n, int64_t d) {
 // 75 000-d: 29 MB through one CU, 300 us) the re-score is spread over one workgroup per selected group.
 int rescore_parts(int64_t q, int64_t d, int kg, int k) {
     if (q > 32 || (int64_t)kg * GROUP * d * 2 < (2 << 20)) return 1;
-    return std::min(kg, 3072 / k);            // the merge of the parts keeps parts * k 16-byte keys in 48 KiB of LDS
+    return std::min(kg, 2048 / k);            // the merge of the parts keeps parts * k 24-byte entries in 48 KiB of LDS
+}
+
+// |fp32 score of the score pass - fp64 re-score| <= tau for stored rows of norm <= 1.005 (what dlc_l2_normalize_rows
+// writes: unit rows rounded to bf16 / fp16).  One MFMA step (32 exact products added to the accumulator) or one v_dot2
+// step (2 products) is taken to err by at most SCORE_STEP_EPS * (|accumulator| + sum |products|) -- twice the
+// half-ulp of a single correctly rounded fp32 result, measured on the device by tests/test_gpu_parity.py::
+// test_score_error_bound_holds; partial sums are bounded by sum |q_i x_i| <= |q| |x| <= 1.01 (Cauchy-Schwarz), a
+// chain of s steps therefore errs by at most (s + 1) * SCORE_STEP_EPS * 1.01, split-K chunks are summed in fp64 and
+// rounded once (+1 step), and 2^-38 covers the quantisation of the ordering key.
+constexpr double SCORE_STEP_EPS = 1.1920928955078125e-07;     // 2^-23
+double score_error_bound(int64_t q, int64_t nk, const SplitPlan& sp, bool dense) {
+    double steps;
+    if (!dense && gemv_shape(q, nk)) steps = (double)nk * 0.5 + 8.0;   // a lane's chain of nk/2 v_dot2 steps + 6 butterfly adds
+    else steps = 2.0 * (double)sp.kchunk + 2.0;                        // two MFMA k-slices per K tile of the chunk
+    return SCORE_STEP_EPS * 1.01 * steps + 3.7e-12;
 }
 
 WsLayout ws_layout(int64_t q, int64_t n, int64_t d, int k) {
@@ -1151,16 +1413,20 @@ WsLayout ws_layout(int64_t q, int64_t n, int64_t d, int k) {
     w.tmax = o; o += dlc::align_up((size_t)q * w.ldt * 4, 256);
     w.sp = split_plan(q, n, d);
     w.dense = dense_plan(q, n, d);
+    w.tau = score_error_bound(q, d / BK, w.sp, w.dense);
     w.ldp = ntiles * BM;
     w.part = o;
     if (w.sp.nsplit > 1 || w.dense) o += dlc::align_up((size_t)w.sp.nsplit * q * w.ldp * 4, 256);
+    w.status = o; o += dlc::align_up((size_t)q * 4, 256);
+    w.s64 = o; o += dlc::align_up((size_t)q * k * 8, 256);        // fp64 scores when the caller does not ask for them
     w.rparts = w.dense ? 1 : rescore_parts(q, d, w.kg, k);
-    w.rs_ids = w.rs_max = w.rs_scores = w.rs_idx = o;
+    w.rs_ids = w.rs_max = w.rs_scores = w.rs_idx = w.rs_bound = o;
     if (w.rparts > 1) {
         w.rs_ids = o; o += dlc::align_up((size_t)q * w.kg * 4, 256);
-        w.rs_max = o; o += dlc::align_up((size_t)q * w.kg * 4, 256);
-        w.rs_scores = o; o += dlc::align_up((size_t)w.rparts * q * k * 4, 256);
+        w.rs_max = o; o += dlc::align_up((size_t)q * (w.kg + 1) * 4, 256);
+        w.rs_scores = o; o += dlc::align_up((size_t)w.rparts * q * k * 8, 256);
         w.rs_idx = o; o += dlc::align_up((size_t)w.rparts * q * k * 8, 256);
+        w.rs_bound = o; o += dlc::align_up((size_t)q * 4, 256);
     }
     w.total = o;
     return w;
@@ -1330,47 +1596,118 @@ int run_score(dlc_ctx* ctx, int dtype, MatchCall& mc, hipStream_t st) {
     return DLC_OK;
 }
 
+// Arguments every selection kernel of a prepared match shares.
+FinishArgs finish_args(const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset) {
+    const GemmArgs& g = mc.a;
+    FinishArgs f{};
+    f.tmax = g.tmax; f.ldt = g.ldt; f.nh = (int)g.nh;
+    f.gmax = g.gmax; f.ldg = g.ldg; f.ng = g.ng;
+    f.kg = mc.w.kg;
+    f.Q = g.Q; f.ldq_b = g.ldq_b; f.DB = g.DB; f.lddb_b = g.lddb_b;
+    f.n = n; f.d = (int)d; f.k = k; f.row_offset = row_offset;
+    f.tau = mc.w.tau;
+    f.nq = q;
+    return f;
+}
+
 template <typename Tag, int THREADS, int RS_UNROLL, int MODE>
-int launch_finish(dlc_ctx* ctx, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
-                  float* out_scores, int64_t* out_idx, bool small_lds, const FinishExtra& x, hipStream_t st) {
-    const GemmArgs& a = mc.a;
-    size_t dsm = fin_lds_fixed(mc.w.kg);
-    const int tv_in_lds = MODE != FIN_RESCORE && !small_lds && (size_t)a.nh * 4 <= 96 * 1024;
-    if (tv_in_lds) dsm += (size_t)a.nh * 4;
+int launch_finish(dlc_ctx* ctx, FinishArgs f, int64_t q, bool small_lds, hipStream_t st) {
+    size_t dsm = fin_lds_fixed(f.kg);
+    f.tv_in_lds = MODE != FIN_RESCORE && !small_lds && (size_t)f.nh * 4 <= 96 * 1024;
+    if (f.tv_in_lds) dsm += (size_t)f.nh * 4;
     dsm = dlc::align_up(dsm, 16);
     auto fk = finish_topk_kernel<Tag, THREADS, RS_UNROLL, MODE>;
     if (dsm > 48 * 1024)
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm));
-    hipLaunchKernelGGL(fk, dim3((unsigned)q, (unsigned)(MODE == FIN_RESCORE && x.gparts > 1 ? x.gparts : 1)), dim3(THREADS), dsm, st, a.tmax, a.ldt, (int)a.nh, tv_in_lds, a.gmax, a.ldg,
-                       a.ng, mc.w.kg, a.Q, a.ldq_b, a.DB, a.lddb_b, (long long)n, (int)d, k, (long long)row_offset,
-                       out_scores, (long long*)out_idx, x);
+    hipLaunchKernelGGL(fk, dim3((unsigned)q, (unsigned)(MODE == FIN_RESCORE && f.gparts > 1 ? f.gparts : 1)), dim3(THREADS),
+                       dsm, st, f);
     DLC_LAUNCH_CHECK(ctx, "finish_topk_kernel");
     return DLC_OK;
 }
 
-// FinishExtra of a fused selection: under the small-database plan the scores are read from the workspace
-inline FinishExtra fused_extra(const MatchCall& mc) {
-    FinishExtra x{};
-    if (mc.w.dense) { x.dense_S = mc.a.P; x.ld_s = mc.a.ldp; }
-    return x;
-}
-
 template <int MODE>
-int run_select(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
-               float* out_scores, int64_t* out_idx, int flags, const FinishExtra& x, hipStream_t st) {
+int run_select(dlc_ctx* ctx, int dtype, const FinishArgs& f, int64_t q, int flags, hipStream_t st) {
     const bool coop = (flags & DLC_SELECT_COOP) != 0;
     if (dtype == DLC_BF16)
-        return coop ? launch_finish<dlc_bf16_tag, 256, 1, MODE>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, true, x, st)
-                    : launch_finish<dlc_bf16_tag, 512, 4, MODE>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, false, x, st);
-    return coop ? launch_finish<dlc_f16_tag, 256, 1, MODE>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, true, x, st)
-                : launch_finish<dlc_f16_tag, 512, 4, MODE>(ctx, mc, k, n, d, q, row_offset, out_scores, out_idx, false, x, st);
+        return coop ? launch_finish<dlc_bf16_tag, 256, 1, MODE>(ctx, f, q, true, st)
+                    : launch_finish<dlc_bf16_tag, 512, 4, MODE>(ctx, f, q, false, st);
+    return coop ? launch_finish<dlc_f16_tag, 256, 1, MODE>(ctx, f, q, true, st)
+                : launch_finish<dlc_f16_tag, 512, 4, MODE>(ctx, f, q, false, st);
+}
+
+// The exhaustive pass behind a certifying kernel: every workgroup whose query is certified leaves at once.
+int run_exhaustive(dlc_ctx* ctx, int dtype, const FinishArgs& f, int64_t q, const double* lower, int64_t lower_stride,
+                   float* out_s, double* out_s64, int64_t* out_i, int* status, hipStream_t st) {
+    ExhaustiveArgs e{};
+    e.gmax = f.gmax; e.ldg = f.ldg; e.ng = f.ng;
+    e.Q = f.Q; e.ldq_b = f.ldq_b; e.DB = f.DB; e.lddb_b = f.lddb_b;
+    e.n = f.n; e.d = f.d; e.k = f.k; e.row_offset = f.row_offset;
+    e.lower = lower; e.lower_stride = lower_stride;
+    e.out_s = out_s; e.out_s64 = out_s64; e.out_i = (long long*)out_i;
+    e.status = status; e.tau = f.tau;
+    if (dtype == DLC_BF16)
+        hipLaunchKernelGGL(exhaustive_topk_kernel<dlc_bf16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, e);
+    else
+        hipLaunchKernelGGL(exhaustive_topk_kernel<dlc_f16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, e);
+    DLC_LAUNCH_CHECK(ctx, "exhaustive_topk_kernel");
+    return DLC_OK;
+}
+
+int launch_merge(dlc_ctx* ctx, const double* scores, int64_t score_part_stride, const int64_t* idx, int64_t idx_part_stride,
+                 int parts, int64_t q, int k, const float* bound, double tau, float* out_scores, double* out_scores_f64,
+                 int64_t* out_idx, int* status, hipStream_t st) {
+    const size_t m = (size_t)parts * k;
+    const size_t dsm = m * 24;
+    if (dsm > 48 * 1024) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "topk_merge: parts*k=%zu too large (max 2048)", m);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)q), dim3(FIN_THREADS), dsm, st, scores, (long long)score_part_stride,
+                       (const long long*)idx, (long long)idx_part_stride, parts, (long long)q, k, bound, tau, out_scores,
+                       out_scores_f64, (long long*)out_idx, status);
+    DLC_LAUNCH_CHECK(ctx, "merge_topk_kernel");
+    return DLC_OK;
+}
+
+// Stage 2 of a match from a filled workspace: selection, fp64 re-score, final top-k, certification, exhaustive pass.
+int run_finish(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
+               float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status, void* workspace, int flags,
+               hipStream_t st) {
+    char* ws = (char*)workspace;
+    FinishArgs f = finish_args(mc, k, n, d, q, row_offset);
+    int* status = out_status ? out_status : (int*)(ws + mc.w.status);
+    double* s64 = out_scores_f64 ? out_scores_f64 : (double*)(ws + mc.w.s64);
+    int rc;
+    if (mc.w.rparts <= 1) {
+        f.out_s = out_scores; f.out_s64 = s64; f.out_i = (long long*)out_idx; f.status = status;
+        if (mc.w.dense) { f.dense_S = mc.a.P; f.ld_s = mc.a.ldp; f.rslack = DENSE_ROW_SLACK; }
+        rc = run_select<FIN_FUSED>(ctx, dtype, f, q, flags, st);
+        if (rc != DLC_OK) return rc;
+    } else {
+        // few queries, long rows: group selection, re-score with one workgroup per selected group, certifying merge
+        f.grp_ids = (int*)(ws + mc.w.rs_ids); f.grp_max = (float*)(ws + mc.w.rs_max);
+        rc = run_select<FIN_GROUPS>(ctx, dtype, f, q, 0, st);
+        if (rc != DLC_OK) return rc;
+        double* ps = (double*)(ws + mc.w.rs_scores);
+        int64_t* pi = (int64_t*)(ws + mc.w.rs_idx);
+        float* pb = (float*)(ws + mc.w.rs_bound);
+        f.gparts = mc.w.rparts; f.out_s = nullptr; f.out_s64 = ps; f.out_i = (long long*)pi; f.bound_out = pb;
+        rc = run_select<FIN_RESCORE>(ctx, dtype, f, q, DLC_SELECT_COOP, st);
+        if (rc != DLC_OK) return rc;
+        rc = launch_merge(ctx, ps, q * k, pi, q * k, mc.w.rparts, q, k, pb, mc.w.tau, out_scores, s64, out_idx, status, st);
+        if (rc != DLC_OK) return rc;
+    }
+    return run_exhaustive(ctx, dtype, f, q, s64 + (k - 1), k, out_scores, s64, out_idx, status, st);
 }
 
 }  // namespace
 
+extern "C" double dlc_cosine_score_error_bound(int64_t q, int64_t n, int64_t d, int k) {
+    if (q < 1 || n < 1 || d < BK || k < 1 || k > DLC_MAX_K) return 0.0;
+    return ws_layout(q, n, d, k).tau;
+}
+
 extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
                                int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, float* out_scores,
-                               int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+                               double* out_scores_f64, int64_t* out_idx, int32_t* out_status, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk: null output");
     MatchCall mc;
@@ -1380,20 +1717,8 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     rc = run_score(ctx, dtype, mc, (hipStream_t)stream);
     if (rc != DLC_OK) return rc;
-    if (mc.w.rparts <= 1)
-        return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, 0, fused_extra(mc), (hipStream_t)stream);
-    // few queries, long rows: group selection, re-score with one workgroup per selected group, merge
-    char* ws = (char*)workspace;
-    FinishExtra x{};
-    x.grp_ids = (int*)(ws + mc.w.rs_ids); x.grp_max = (float*)(ws + mc.w.rs_max); x.nq = q;
-    rc = run_select<FIN_GROUPS>(ctx, dtype, mc, k, n, d, q, 0, nullptr, nullptr, 0, x, (hipStream_t)stream);
-    if (rc != DLC_OK) return rc;
-    x.gparts = mc.w.rparts;
-    float* ps = (float*)(ws + mc.w.rs_scores);
-    int64_t* pi = (int64_t*)(ws + mc.w.rs_idx);
-    rc = run_select<FIN_RESCORE>(ctx, dtype, mc, k, n, d, q, row_offset, ps, pi, DLC_SELECT_COOP, x, (hipStream_t)stream);
-    if (rc != DLC_OK) return rc;
-    return dlc_topk_merge_strided(ctx, ps, q * k, pi, q * k, mc.w.rparts, q, k, out_scores, out_idx, stream);
+    return run_finish(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_scores_f64, out_idx, out_status, workspace, 0,
+                      (hipStream_t)stream);
 }
 
 extern "C" int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
@@ -1410,8 +1735,8 @@ extern "C" int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, i
 
 extern "C" int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
                                       int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, float* out_scores,
-                                      int64_t* out_idx, void* workspace, size_t workspace_bytes, int flags,
-                                      void* stream) {
+                                      double* out_scores_f64, int64_t* out_idx, int32_t* out_status, void* workspace,
+                                      size_t workspace_bytes, int flags, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_select_topk: null output");
     MatchCall mc;
@@ -1419,7 +1744,8 @@ extern "C" int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, in
     if (rc != DLC_OK) return rc;
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    return run_select<FIN_FUSED>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, flags, fused_extra(mc), (hipStream_t)stream);
+    return run_finish(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_scores_f64, out_idx, out_status, workspace, flags,
+                      (hipStream_t)stream);
 }
 
 extern "C" int dlc_cosine_groups_per_query(int k) { return (k < 1 || k > DLC_MAX_K) ? 0 : k + SLACK; }
@@ -1435,34 +1761,64 @@ extern "C" int dlc_cosine_select_groups(dlc_ctx* ctx, int dtype, const void* Q, 
     if (rc != DLC_OK) return rc;
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    FinishExtra x{};
-    x.grp_ids = group_ids; x.grp_max = group_max; x.nq = q;
-    return run_select<FIN_GROUPS>(ctx, dtype, mc, k, n, d, q, 0, nullptr, nullptr, flags, x, (hipStream_t)stream);
+    FinishArgs f = finish_args(mc, k, n, d, q, 0);
+    f.grp_ids = group_ids; f.grp_max = group_max;
+    return run_select<FIN_GROUPS>(ctx, dtype, f, q, flags, (hipStream_t)stream);
 }
+
+namespace {
+// A MatchCall for the calls that need the operands and the plan's constants but no workspace.
+int operands_only(dlc_ctx* ctx, const char* what, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB, int64_t n,
+                  int64_t lddb, int64_t d, int k, MatchCall* mc) {
+    int rc = check_operands(ctx, dtype, Q, q, ldq, DB, n, lddb, d);
+    if (rc != DLC_OK) return rc;
+    if (k < 1 || k > DLC_MAX_K) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "%s: k=%d outside 1..%d", what, k, DLC_MAX_K);
+    mc->w = ws_layout(q, n, d, k);
+    mc->a = GemmArgs{};
+    mc->a.Q = (const char*)Q; mc->a.DB = (const char*)DB;
+    mc->a.ldq_b = ldq * 2; mc->a.lddb_b = lddb * 2;
+    mc->a.q = (int)q; mc->a.n = n; mc->a.nk = (int)(d / BK);
+    mc->a.ng = dlc::cdiv(n, GROUP); mc->a.nh = dlc::cdiv(n, HALF);
+    return DLC_OK;
+}
+}  // namespace
 
 extern "C" int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
                                        int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
                                        const int32_t* group_ids, const float* group_max, const float* all_group_max,
-                                       int parts, float* out_scores, int64_t* out_idx, int flags, void* stream) {
+                                       int parts, double* out_scores_f64, int64_t* out_idx, float* out_bound, int flags,
+                                       void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
-    if (!out_scores || !out_idx || !group_ids || !group_max || parts < 0 || (parts > 0 && !all_group_max))
+    if (!out_scores_f64 || !out_idx || !group_ids || !group_max || parts < 0 || (parts > 0 && !all_group_max))
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_rescore_topk: bad argument");
-    int rc = check_operands(ctx, dtype, Q, q, ldq, DB, n, lddb, d);
+    MatchCall mc;
+    int rc = operands_only(ctx, "cosine_rescore_topk", dtype, Q, q, ldq, DB, n, lddb, d, k, &mc);
     if (rc != DLC_OK) return rc;
-    if (k < 1 || k > DLC_MAX_K) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_rescore_topk: k=%d outside 1..%d", k, DLC_MAX_K);
-    MatchCall mc;                                   // no workspace needed: only the operands and kg
-    mc.w = ws_layout(q, n, d, k);
-    mc.a = GemmArgs{};
-    mc.a.Q = (const char*)Q; mc.a.DB = (const char*)DB;
-    mc.a.ldq_b = ldq * 2; mc.a.lddb_b = lddb * 2;
-    mc.a.q = (int)q; mc.a.n = n; mc.a.nk = (int)(d / BK);
-    mc.a.ng = dlc::cdiv(n, GROUP); mc.a.nh = dlc::cdiv(n, HALF);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    FinishExtra x{};
-    x.grp_ids = const_cast<int32_t*>(group_ids); x.grp_max = const_cast<float*>(group_max);
-    x.all_max = all_group_max; x.parts = parts; x.nq = q;
-    return run_select<FIN_RESCORE>(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_idx, flags, x, (hipStream_t)stream);
+    FinishArgs f = finish_args(mc, k, n, d, q, row_offset);
+    f.grp_ids = const_cast<int32_t*>(group_ids); f.grp_max = const_cast<float*>(group_max);
+    f.all_max = all_group_max; f.parts = parts;
+    f.out_s = nullptr; f.out_s64 = out_scores_f64; f.out_i = (long long*)out_idx; f.bound_out = out_bound;
+    return run_select<FIN_RESCORE>(ctx, dtype, f, q, flags, (hipStream_t)stream);
+}
+
+extern "C" int dlc_cosine_exhaustive_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                                          int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
+                                          const double* lower, int64_t lower_stride, double tau, int32_t* status,
+                                          float* out_scores, double* out_scores_f64, int64_t* out_idx, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!lower || lower_stride < 0 || !status || !out_idx || !(tau >= 0.0))
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_exhaustive_topk: bad argument");
+    MatchCall mc;
+    int rc = prepare_match(ctx, "cosine_exhaustive_topk", dtype, Q, q, ldq, DB, n, lddb, d, k, workspace, workspace_bytes, &mc);
+    if (rc != DLC_OK) return rc;
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    FinishArgs f = finish_args(mc, k, n, d, q, row_offset);
+    f.tau = tau;
+    return run_exhaustive(ctx, dtype, f, q, lower, lower_stride, out_scores, out_scores_f64, out_idx, status, (hipStream_t)stream);
 }
 
 namespace {
@@ -1507,28 +1863,24 @@ extern "C" int dlc_topk_keep_older(dlc_ctx* ctx, const float* scores, const int6
     return DLC_OK;
 }
 
-extern "C" int dlc_topk_merge_strided(dlc_ctx* ctx, const float* scores, int64_t score_part_stride, const int64_t* idx,
-                                      int64_t idx_part_stride, int parts, int64_t q, int k, float* out_scores,
-                                      int64_t* out_idx, void* stream) {
+extern "C" int dlc_topk_merge_strided(dlc_ctx* ctx, const double* scores_f64, int64_t score_part_stride, const int64_t* idx,
+                                      int64_t idx_part_stride, int parts, int64_t q, int k, const float* bound, double tau,
+                                      float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
+                                      void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
-    if (!scores || !idx || !out_scores || !out_idx || parts < 1 || q < 1 || k < 1 || k > DLC_MAX_K ||
-        score_part_stride < q * k || idx_part_stride < q * k)
+    if (!scores_f64 || !idx || !out_idx || parts < 1 || q < 1 || k < 1 || k > DLC_MAX_K ||
+        score_part_stride < q * k || idx_part_stride < q * k || !(tau >= 0.0))
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "topk_merge: bad argument");
-    const size_t m = (size_t)parts * k;
-    const size_t dsm = m * 16;
-    if (dsm > 48 * 1024) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "topk_merge: parts*k=%zu too large", m);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)q), dim3(FIN_THREADS), dsm, (hipStream_t)stream, scores,
-                       (long long)score_part_stride, (const long long*)idx, (long long)idx_part_stride, parts,
-                       (long long)q, k, out_scores, (long long*)out_idx);
-    DLC_LAUNCH_CHECK(ctx, "merge_topk_kernel");
-    return DLC_OK;
+    return launch_merge(ctx, scores_f64, score_part_stride, idx, idx_part_stride, parts, q, k, bound, tau, out_scores,
+                        out_scores_f64, out_idx, out_status, (hipStream_t)stream);
 }
 
-extern "C" int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* idx, int parts, int64_t q, int k,
-                              float* out_scores, int64_t* out_idx, void* stream) {
-    return dlc_topk_merge_strided(ctx, scores, q * k, idx, q * k, parts, q, k, out_scores, out_idx, stream);
+extern "C" int dlc_topk_merge(dlc_ctx* ctx, const double* scores_f64, const int64_t* idx, int parts, int64_t q, int k,
+                              float* out_scores, double* out_scores_f64, int64_t* out_idx, void* stream) {
+    return dlc_topk_merge_strided(ctx, scores_f64, q * k, idx, q * k, parts, q, k, nullptr, 0.0, out_scores, out_scores_f64,
+                                  out_idx, nullptr, stream);
 }
 
 extern "C" size_t dlc_cosine_scores_workspace_bytes(int64_t q, int64_t n, int64_t d) {

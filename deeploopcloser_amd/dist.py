@@ -1,12 +1,13 @@
 """Multi-GPU match: the key-frame database is row-sharded over the ranks of one
 node (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI),
-queries are replicated, every rank runs the fused top-k on its shard with
-global row offsets, and ONE all-gather of the per-shard [Q,k] (score, index)
-pairs (Q*k*12 bytes per rank, latency-bound) is followed by a k-way merge with
-the same ordering rule.  No other collective is on the data path.
-
-The shard arithmetic and the merge are also exercised on CPU with the gloo
-backend (tests/test_dist_cpu.py) using a pluggable `local_topk`.
+queries are replicated, every rank matches against its shard with global row
+offsets, and the per-shard parts are all-gathered and merged with the same
+ordering rule (fp64 score key, then the lower global row).  On GPUs there is ONE
+implementation of the exchange -- matching.MatchPipeline (group maxima first,
+then the packed parts, a certifying merge): ShardedKeyframeDatabase.from_database
+delegates to it.  The shard arithmetic and the merge rule are also exercised on
+CPU with the gloo backend (tests/test_dist_cpu.py) through a pluggable
+`local_topk`.
 """
 import torch
 import torch.distributed as dist
@@ -37,11 +38,12 @@ def merge_topk_torch(scores, idx, k):
 
 
 class ShardedKeyframeDatabase:
-    """Rank-local shard + the all-gather / merge step.
+    """Rank-local shard + the exchange.
 
-    local_topk(queries, k) -> (scores [Q,k] f32, idx [Q,k] i64 GLOBAL) runs the
-    shard-local match; on GPUs it is KeyframeDatabase.match_topk, and the merge
-    is the HIP dlc_topk_merge kernel.
+    from_database(db): the GPU form -- match_topk() is one MatchPipeline batch (submit + result).
+    ShardedKeyframeDatabase(local_topk): local_topk(queries, k) -> (scores [Q,k], idx [Q,k] i64 GLOBAL)
+    runs the shard-local match (scores in the precision the order is to be decided in); one all-gather
+    each of scores and rows and merge_topk_torch follow -- the CPU / gloo form.
     """
 
     def __init__(self, local_topk, merge=None, group=None):
@@ -52,13 +54,22 @@ class ShardedKeyframeDatabase:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._gather_s = None
         self._gather_i = None
+        self._db = None
+        self._pipes = {}
 
     @classmethod
     def from_database(cls, db, group=None):
-        eng = db.engine
-        return cls(lambda q, k: db.match_topk(q, k), merge=lambda s, i, k: eng.topk_merge(s, i), group=group)
+        obj = cls(None, group=group)
+        obj._db = db
+        return obj
 
     def match_topk(self, queries, k):
+        if self._db is not None:
+            from .matching import MatchPipeline
+            pipe = self._pipes.get(k)
+            if pipe is None:
+                pipe = self._pipes[k] = MatchPipeline(self._db, k, depth=1, group=self.group)
+            return pipe.result(pipe.submit(queries))
         s, i = self.local_topk(queries, k)
         if self.world == 1:
             return s, i

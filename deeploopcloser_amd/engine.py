@@ -3,6 +3,7 @@ device pointers + the current HIP stream to libdlc_hip.so.  PyTorch is used for
 device memory, streams and torch.distributed only; every computation below
 runs in the hand-written HIP kernels.
 """
+import collections
 import contextlib
 import ctypes as C
 
@@ -19,6 +20,9 @@ _NAME_TO_TORCH = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f16": tor
 
 SCRATCH_BYTES = 256 << 20   # default split-K scratch per engine (Engine.set_scratch)
 K_STEP = 64   # the score GEMM's K step: stored descriptor rows are padded to a multiple of it
+
+
+TopK = collections.namedtuple("TopK", "scores idx scores_f64 status")
 
 
 def torch_dtype(name):
@@ -389,9 +393,11 @@ class Engine:
         if q.stride(1) != 1 or db.stride(1) != 1:
             raise ValueError("stored descriptor rows must be contiguous")
 
-    def match_topk(self, q, db, k, row_offset=0, out=None):
+    def match_topk(self, q, db, k, row_offset=0, out=None, details=False):
         """Top-k cosine match of stored queries q [Q,d] against stored db [N,d].
-        Returns (scores [Q,k] float32, idx [Q,k] int64 with row_offset added)."""
+        Returns (scores [Q,k] float32, idx [Q,k] int64 with row_offset added); with details=True a
+        TopK(scores, idx, scores_f64, status): the fp64 scores the order was decided on and, per query,
+        0 = certified by the selection, 2 = resolved by the exhaustive pass (include/dlc.h)."""
         self._check_stored(q, db)
         nq, d = q.shape
         n = db.shape[0]
@@ -405,16 +411,22 @@ class Engine:
         else:
             scores = self._check_out("out[0] (scores)", out[0], (nq, k), torch.float32)
             idx = self._check_out("out[1] (idx)", out[1], (nq, k), torch.int64)
+        s64 = torch.empty((nq, k), dtype=torch.float64, device=self.device) if details else None
+        status = torch.empty((nq,), dtype=torch.int32, device=self.device) if details else None
         self._check(self.lib.dlc_cosine_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
-                                              db.stride(0), d, k, row_offset, _ptr(scores), _ptr(idx), _ptr(ws),
-                                              ws.numel(), self._stream()))
-        return scores, idx
+                                              db.stride(0), d, k, row_offset, _ptr(scores), _ptr(s64), _ptr(idx),
+                                              _ptr(status), _ptr(ws), ws.numel(), self._stream()))
+        return TopK(scores, idx, s64, status) if details else (scores, idx)
 
     def topk_workspace_bytes(self, nq, n, d, k):
         need = self.lib.dlc_cosine_topk_workspace_bytes(nq, n, d, k)
         if need == 0:
             raise ValueError("k=%d outside 1..%d (or empty operand)" % (k, L.DLC_MAX_K))
         return need
+
+    def score_error_bound(self, nq, n, d, k):
+        """tau of the plan a [nq, d] x [n, d] top-k match takes: |fp32 score of the score pass - fp64 score| <= tau."""
+        return float(self.lib.dlc_cosine_score_error_bound(nq, n, d, k))
 
     def score_groups(self, q, db, k, ws, stream=None):
         """Stage 1 of match_topk (the MFMA score GEMM) into the caller's workspace tensor."""
@@ -425,17 +437,21 @@ class Engine:
                                                       _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, _ptr(ws),
                                                       ws.numel(), st))
 
-    def select_topk(self, q, db, k, ws, scores, idx, row_offset=0, coop=False, stream=None):
-        """Stage 2 of match_topk (selection, exact re-score, final top-k) from the workspace."""
+    def select_topk(self, q, db, k, ws, scores, idx, row_offset=0, coop=False, stream=None, scores_f64=None, status=None):
+        """Stage 2 of match_topk (selection, fp64 re-score, final top-k, certificate, exhaustive pass) from the workspace."""
         self._check_stored(q, db)
         self._check_ws(ws)
         self._check_out("scores", scores, (q.shape[0], k), torch.float32)
         self._check_out("idx", idx, (q.shape[0], k), torch.int64)
+        if scores_f64 is not None:
+            self._check_out("scores_f64", scores_f64, (q.shape[0], k), torch.float64)
+        if status is not None:
+            self._check_out("status", status, (q.shape[0],), torch.int32)
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         self._check(self.lib.dlc_cosine_select_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
                                                      _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, row_offset,
-                                                     _ptr(scores), _ptr(idx), _ptr(ws), ws.numel(),
-                                                     L.DLC_SELECT_COOP if coop else 0, st))
+                                                     _ptr(scores), _ptr(scores_f64), _ptr(idx), _ptr(status), _ptr(ws),
+                                                     ws.numel(), L.DLC_SELECT_COOP if coop else 0, st))
 
     def _check_ws(self, ws):
         if not isinstance(ws, torch.Tensor) or ws.dtype != torch.uint8 or not ws.is_contiguous() or ws.device != self.device:
@@ -448,49 +464,77 @@ class Engine:
         return kg
 
     def select_groups(self, q, db, k, ws, grp_ids, grp_max, coop=False, stream=None):
-        """Stage 2a: the kg best groups of every query (shard-local ids + their maxima)."""
+        """Stage 2a: the kg best groups of every query: shard-local ids [Q,kg] and grp_max [Q,kg+1] = their maxima +
+        (last column) the best maximum among the groups that are not listed."""
         self._check_stored(q, db)
         self._check_ws(ws)
         kg = self.groups_per_query(k)
         self._check_out("grp_ids", grp_ids, (q.shape[0], kg), torch.int32)
-        self._check_out("grp_max", grp_max, (q.shape[0], kg), torch.float32)
+        self._check_out("grp_max", grp_max, (q.shape[0], kg + 1), torch.float32)
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         self._check(self.lib.dlc_cosine_select_groups(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
                                                        _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, _ptr(ws),
                                                        ws.numel(), _ptr(grp_ids), _ptr(grp_max),
                                                        L.DLC_SELECT_COOP if coop else 0, st))
 
-    def rescore_topk(self, q, db, k, grp_ids, grp_max, scores, idx, all_max=None, row_offset=0, coop=False, stream=None):
-        """Stage 2b: exact re-score of the listed groups (filtered against all shards' maxima
-        when all_max [parts, Q, kg] is given) and the shard's top-k."""
+    def rescore_topk(self, q, db, k, grp_ids, grp_max, scores_f64, idx, bound=None, all_max=None, row_offset=0, coop=False,
+                     stream=None):
+        """Stage 2b: fp64 re-score of the listed groups (filtered against all shards' maxima when all_max
+        [parts, Q, kg+1] is given): the shard's part of the top-k (fp64 scores, rows) and bound [Q] = the best fp32
+        score any row outside the surviving groups of all shards can have."""
         self._check_stored(q, db)
         kg = self.groups_per_query(k)
         self._check_out("grp_ids", grp_ids, (q.shape[0], kg), torch.int32)
-        self._check_out("grp_max", grp_max, (q.shape[0], kg), torch.float32)
-        self._check_out("scores", scores, (q.shape[0], k), torch.float32)
+        self._check_out("grp_max", grp_max, (q.shape[0], kg + 1), torch.float32)
+        self._check_out("scores_f64", scores_f64, (q.shape[0], k), torch.float64)
         self._check_out("idx", idx, (q.shape[0], k), torch.int64)
+        if bound is not None:
+            self._check_out("bound", bound, (q.shape[0],), torch.float32)
         if all_max is not None:
-            self._check_out("all_max", all_max, (all_max.shape[0], q.shape[0], kg), torch.float32)
+            self._check_out("all_max", all_max, (all_max.shape[0], q.shape[0], kg + 1), torch.float32)
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         parts = 0 if all_max is None else all_max.shape[0]
         self._check(self.lib.dlc_cosine_rescore_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
                                                       _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, row_offset,
-                                                      _ptr(grp_ids), _ptr(grp_max), _ptr(all_max), parts, _ptr(scores),
-                                                      _ptr(idx), L.DLC_SELECT_COOP if coop else 0, st))
+                                                      _ptr(grp_ids), _ptr(grp_max), _ptr(all_max), parts, _ptr(scores_f64),
+                                                      _ptr(idx), _ptr(bound), L.DLC_SELECT_COOP if coop else 0, st))
 
-    def topk_merge_packed(self, gathered, nq, k, out):
-        """Merge an all-gather of packed per-shard results: gathered is uint8 [parts, nq*k*12],
-        each part = int64 idx [nq,k] followed by float32 scores [nq,k]."""
+    def exhaustive_topk(self, q, db, k, ws, lower, tau, status, scores_f64, idx, scores=None, row_offset=0, stream=None):
+        """The exhaustive pass of the sharded protocol for the queries with status == 1: lower [Q] fp64 = the k-th score
+        found so far; this shard's exact top-k over every group whose maximum (in `ws`, the workspace of the score
+        pass) is >= lower - tau replaces scores_f64 / idx (and scores) of those queries; their status becomes 2."""
+        self._check_stored(q, db)
+        self._check_ws(ws)
+        nq = q.shape[0]
+        self._check_out("lower", lower, (nq,), torch.float64)
+        self._check_out("status", status, (nq,), torch.int32)
+        self._check_out("scores_f64", scores_f64, (nq, k), torch.float64)
+        self._check_out("idx", idx, (nq, k), torch.int64)
+        if scores is not None:
+            self._check_out("scores", scores, (nq, k), torch.float32)
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        self._check(self.lib.dlc_cosine_exhaustive_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db),
+                                                         db.shape[0], db.stride(0), q.shape[1], k, row_offset, _ptr(lower), 1,
+                                                         float(tau), _ptr(status), _ptr(scores), _ptr(scores_f64), _ptr(idx),
+                                                         _ptr(ws), ws.numel(), st))
+
+    def topk_merge_packed(self, gathered, nq, k, out, bound=None, tau=0.0, scores_f64=None, status=None):
+        """Merge an all-gather of packed per-shard results: gathered is uint8 [parts, nq*k*16], each part = int64 idx
+        [nq,k] followed by float64 scores [nq,k].  With bound [nq] / tau the merge certifies into status [nq]."""
         parts = gathered.shape[0]
-        if (nq * k) % 2:
-            raise ValueError("packed merge needs an even nq*k")
-        self._check_out("gathered", gathered, (parts, nq * k * 12), torch.uint8)
+        self._check_out("gathered", gathered, (parts, nq * k * 16), torch.uint8)
         base = gathered.data_ptr()
         o_s = self._check_out("out[0] (scores)", out[0], (nq, k), torch.float32)
         o_i = self._check_out("out[1] (idx)", out[1], (nq, k), torch.int64)
-        self._check(self.lib.dlc_topk_merge_strided(self.ctx, C.c_void_p(base + nq * k * 8), nq * k * 3,
-                                                     C.c_void_p(base), nq * k * 3 // 2, parts, nq, k, _ptr(o_s),
-                                                     _ptr(o_i), self._stream()))
+        if bound is not None:
+            self._check_out("bound", bound, (nq,), torch.float32)
+        if scores_f64 is not None:
+            self._check_out("scores_f64", scores_f64, (nq, k), torch.float64)
+        if status is not None:
+            self._check_out("status", status, (nq,), torch.int32)
+        self._check(self.lib.dlc_topk_merge_strided(self.ctx, C.c_void_p(base + nq * k * 8), nq * k * 2,
+                                                     C.c_void_p(base), nq * k * 2, parts, nq, k, _ptr(bound), float(tau),
+                                                     _ptr(o_s), _ptr(scores_f64), _ptr(o_i), _ptr(status), self._stream()))
         return o_s, o_i
 
     def topk_keep_older(self, scores, idx, limit0, k):
@@ -505,21 +549,24 @@ class Engine:
                                                   _ptr(o_i), self._stream()))
         return o_s, o_i
 
-    def topk_merge(self, scores, idx, out=None):
-        """Merge [parts, Q, k] per-shard results into the global [Q, k]."""
-        scores, idx = scores.contiguous(), idx.contiguous()
-        if scores.dim() != 3 or idx.shape != scores.shape or scores.dtype != torch.float32 or idx.dtype != torch.int64:
-            raise ValueError("topk_merge: scores float32 / idx int64 of one shape [parts, Q, k]")
-        parts, nq, k = scores.shape
+    def topk_merge(self, scores_f64, idx, out=None, details=False):
+        """Merge [parts, Q, k] per-shard results (fp64 scores: the order is decided on them) into the global [Q, k]:
+        (scores float32, idx); with details=True a TopK with the merged fp64 scores too."""
+        scores_f64, idx = scores_f64.contiguous(), idx.contiguous()
+        if scores_f64.dim() != 3 or idx.shape != scores_f64.shape or scores_f64.dtype != torch.float64 or \
+                idx.dtype != torch.int64:
+            raise ValueError("topk_merge: scores float64 / idx int64 of one shape [parts, Q, k]")
+        parts, nq, k = scores_f64.shape
         if out is None:
             o_s = torch.empty((nq, k), dtype=torch.float32, device=self.device)
             o_i = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         else:
             o_s = self._check_out("out[0] (scores)", out[0], (nq, k), torch.float32)
             o_i = self._check_out("out[1] (idx)", out[1], (nq, k), torch.int64)
-        self._check(self.lib.dlc_topk_merge(self.ctx, _ptr(scores), _ptr(idx), parts, nq, k, _ptr(o_s), _ptr(o_i),
-                                             self._stream()))
-        return o_s, o_i
+        o_64 = torch.empty((nq, k), dtype=torch.float64, device=self.device) if details else None
+        self._check(self.lib.dlc_topk_merge(self.ctx, _ptr(scores_f64), _ptr(idx), parts, nq, k, _ptr(o_s), _ptr(o_64),
+                                             _ptr(o_i), self._stream()))
+        return TopK(o_s, o_i, o_64, None) if details else (o_s, o_i)
 
     def cosine_scores(self, q, db):
         self._check_stored(q, db)

@@ -146,16 +146,24 @@ class MatchPipeline:
     more than it hides (measured -3 %), so plain KeyframeDatabase.match_topk calls are the faster form there.
 
     The score GEMM of batch i+1 runs on the submitting stream while the selection /
-    re-score / final top-k of batch i (and, when sharded, the RCCL all-gather of the
+    re-score / final top-k of batch i (and, when sharded, the RCCL all-gathers of the
     per-shard results and the merge) run on a second stream: the selection is a
     latency-bound gather whose small-footprint kernel shares the CUs with the GEMM, and
-    the collectives' latency leaves the critical path.  Sharded: the ranks first all-gather the
-    maxima of their selected groups (Q*kg floats each) so that each rank re-scores only the
-    groups that can be among the best of the whole database, then all-gather the packed
-    per-shard top-k ([Q,k] int64 + fp32, one collective) and merge.  `depth` batches are in flight,
-    each with its own workspace and output buffers; submit() returns a ticket,
-    result(ticket) waits for that batch only.  A result must be fetched before `depth`
-    further batches are submitted (its buffers are then reused).
+    the collectives' latency leaves the critical path.  Sharded (the protocol of include/dlc.h):
+      1. every rank selects its kg best groups per query and all-gathers their maxima + the best
+         maximum it leaves behind ([Q, kg+1] floats);
+      2. it re-scores in fp64 only the groups that can be among the kg best of the WHOLE database
+         (~kg/world per query) and learns the bound B of everything all ranks left behind;
+      3. the packed per-shard parts ([Q,k] int64 rows + fp64 scores, one collective) are all-gathered
+         and merged in fp64 order; the merge certifies each query (k-th score > B + tau);
+      4. if any query is not certified -- the same queries on every rank, the inputs of the merge
+         are identical -- result() runs the exhaustive pass on every shard for those queries and
+         one more all-gather + merge.  The flag reaches the host through pinned memory behind the
+         batch's `done` event: no extra synchronisation on the common path.
+    `depth` batches are in flight, each with its own workspace and output buffers; submit() returns
+    a ticket, result(ticket) waits for that batch only.  A result must be fetched before `depth`
+    further batches are submitted (its buffers are then reused), and all ranks must call submit() /
+    result() in the same order (they carry collectives).
     """
 
     def __init__(self, db, k, depth=2, group=None, queries_per_batch=None):
@@ -169,6 +177,9 @@ class MatchPipeline:
         self._slots = []
         self._count = 0
         self._nq = queries_per_batch
+        self.resolved_batches = 0          # batches that needed the exhaustive round (sharded)
+        self.time_collectives = False      # record events around the two all-gathers of every batch (collective_us())
+        self._coll_events = []
 
     def _slot(self, i, nq, d):
         while len(self._slots) <= i:
@@ -178,23 +189,28 @@ class MatchPipeline:
             if s is not None and s["busy"]:
                 s["done"].synchronize()             # its buffers are still in use on the second stream
             dev = self.engine.device
-            need = self.engine.topk_workspace_bytes(nq, len(self.db), d, self.k)
+            eng, k = self.engine, self.k
+            need = eng.topk_workspace_bytes(nq, len(self.db), d, k)
             s = {"nq": nq, "n": len(self.db), "ws": torch.empty(need, dtype=torch.uint8, device=dev),
-                 "scores": torch.empty((nq, self.k), dtype=torch.float32, device=dev),
-                 "idx": torch.empty((nq, self.k), dtype=torch.int64, device=dev),
+                 "scores": torch.empty((nq, k), dtype=torch.float32, device=dev),
+                 "idx": torch.empty((nq, k), dtype=torch.int64, device=dev),
                  "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "q": None, "rows": None}
             if self.world > 1:
-                kg = self.engine.groups_per_query(self.k)
-                nb = nq * self.k * 12                      # packed result: int64 idx [nq,k] | float32 scores [nq,k]
+                kg = eng.groups_per_query(k)
+                nb = nq * k * 16                           # packed part: int64 rows [nq,k] | float64 scores [nq,k]
                 s["pack"] = torch.empty(nb, dtype=torch.uint8, device=dev)
-                s["idx"] = s["pack"][:nq * self.k * 8].view(torch.int64).view(nq, self.k)
-                s["scores"] = s["pack"][nq * self.k * 8:].view(torch.float32).view(nq, self.k)
+                s["p_idx"] = s["pack"][:nq * k * 8].view(torch.int64).view(nq, k)
+                s["p_s64"] = s["pack"][nq * k * 8:].view(torch.float64).view(nq, k)
                 s["g_pack"] = torch.empty((self.world, nb), dtype=torch.uint8, device=dev)
                 s["grp_ids"] = torch.empty((nq, kg), dtype=torch.int32, device=dev)
-                s["grp_max"] = torch.empty((nq, kg), dtype=torch.float32, device=dev)
-                s["g_max"] = torch.empty((self.world, nq, kg), dtype=torch.float32, device=dev)
-                s["m_scores"] = torch.empty((nq, self.k), dtype=torch.float32, device=dev)
-                s["m_idx"] = torch.empty((nq, self.k), dtype=torch.int64, device=dev)
+                s["grp_max"] = torch.empty((nq, kg + 1), dtype=torch.float32, device=dev)
+                s["g_max"] = torch.empty((self.world, nq, kg + 1), dtype=torch.float32, device=dev)
+                s["bound"] = torch.empty((nq,), dtype=torch.float32, device=dev)
+                s["m_s64"] = torch.empty((nq, k), dtype=torch.float64, device=dev)
+                s["status"] = torch.empty((nq,), dtype=torch.int32, device=dev)
+                s["flag"] = torch.zeros((1,), dtype=torch.int32).pin_memory()
+                # every shard's score pass errs by at most its plan's tau; the unsplit plan's is the largest
+                s["tau"] = max(eng.score_error_bound(nq, len(self.db), d, k), eng.score_error_bound(nq, 1 << 30, d, k))
             self._slots[i] = s
         return s
 
@@ -219,29 +235,65 @@ class MatchPipeline:
                 eng.select_topk(q, rows, self.k, s["ws"], s["scores"], s["idx"],
                                 row_offset=self.db.row_offset, coop=True, stream=self.s_select)
             else:
-                # exchange the selected groups' maxima first, so that every shard re-scores only the
-                # groups that can be among the best of the WHOLE database (~kg/world per query)
                 eng.select_groups(q, rows, self.k, s["ws"], s["grp_ids"], s["grp_max"], coop=True,
                                   stream=self.s_select)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.time_collectives else None
+                if ev:
+                    ev[0].record(self.s_select)
                 dist.all_gather_into_tensor(s["g_max"].view(-1, s["g_max"].shape[-1]), s["grp_max"], group=self.group)
-                eng.rescore_topk(q, rows, self.k, s["grp_ids"], s["grp_max"], s["scores"], s["idx"],
+                if ev:
+                    ev[1].record(self.s_select)
+                eng.rescore_topk(q, rows, self.k, s["grp_ids"], s["grp_max"], s["p_s64"], s["p_idx"], bound=s["bound"],
                                  all_max=s["g_max"], row_offset=self.db.row_offset, coop=True, stream=self.s_select)
+                if ev:
+                    ev[2].record(self.s_select)
                 dist.all_gather_into_tensor(s["g_pack"].view(-1), s["pack"], group=self.group)
-                eng.topk_merge_packed(s["g_pack"], q.shape[0], self.k, out=(s["m_scores"], s["m_idx"]))
+                if ev:
+                    ev[3].record(self.s_select)
+                    self._coll_events.append(ev)
+                eng.topk_merge_packed(s["g_pack"], q.shape[0], self.k, out=(s["scores"], s["idx"]), bound=s["bound"],
+                                      tau=s["tau"], scores_f64=s["m_s64"], status=s["status"])
+                s["flag"].copy_(s["status"].max().reshape(1), non_blocking=True)
             s["done"].record(self.s_select)
         s["busy"] = True
         self._count += 1
         return self._count - 1
 
+    def _resolve(self, s):
+        """The exhaustive round for the queries the merge could not certify (collective: every rank sees the same flags)."""
+        import torch.distributed as dist
+        eng, q, k = self.engine, s["q"], self.k
+        with torch.cuda.stream(self.s_select):
+            lower = s["m_s64"][:, k - 1].contiguous()
+            eng.exhaustive_topk(q, s["rows"], k, s["ws"], lower, s["tau"], s["status"], s["p_s64"], s["p_idx"],
+                                row_offset=self.db.row_offset, stream=self.s_select)
+            dist.all_gather_into_tensor(s["g_pack"].view(-1), s["pack"], group=self.group)
+            eng.topk_merge_packed(s["g_pack"], q.shape[0], k, out=(s["scores"], s["idx"]), scores_f64=s["m_s64"])
+            s["done"].record(self.s_select)
+        s["done"].synchronize()
+        self.resolved_batches += 1
+
     def result(self, ticket):
         s = self._slots[ticket % self.depth]
         s["done"].synchronize()
-        if self.world > 1:
-            return s["m_scores"], s["m_idx"]
+        if self.world > 1 and int(s["flag"][0]) != 0:
+            s["flag"][0] = 0
+            self._resolve(s)
         return s["scores"], s["idx"]
 
     def drain(self):
         self.s_select.synchronize()
+
+    def collective_us(self):
+        """Mean device time (microseconds, stream events around them) of the two all-gathers over the batches
+        submitted while time_collectives was on: {"group_maxima": ..., "packed_topk": ..., "batches": n}; a gloo group
+        stages through the host, so its figures are host round trips."""
+        self.s_select.synchronize()
+        ev, self._coll_events = self._coll_events, []
+        if not ev:
+            return None
+        return {"group_maxima": float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e3,
+                "packed_topk": float(np.mean([e[2].elapsed_time(e[3]) for e in ev])) * 1e3, "batches": len(ev)}
 
 
 def match(desc_q, desc_db, dtype="bf16", center=False):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DLC_ABI_VERSION 4
+#define DLC_ABI_VERSION 5
 
 typedef struct dlc_ctx dlc_ctx;
 
@@ -292,46 +292,60 @@ int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* src, int64_t 
                           int center, int dst_dtype, void* dst, int64_t ldd, void* stream);
 /*
  * Top-k cosine match of q query rows against n database rows of width d
- * (both stored normalised in `dtype` = DLC_BF16 / DLC_F16, row strides
- * ldq / lddb in elements, d a multiple of 64, rows 16-byte aligned).
- * Scores are fp32-accumulated dot products of the stored rows; per query the k
- * best (score descending, ties -> lower index) go to out_scores[q,k] (fp32) and
- * out_idx[q,k] (int64, row_offset added -- the shard's first global row).
- * Slots past min(k,n) get -inf / -1.  1 <= k <= DLC_MAX_K.
- * The call picks its plan from the shape (the workspace size reflects it): one score pass for
- * databases of >= 256 tiles of 256 rows; split-K partial score tiles + a reducing pass for few
- * rows with long descriptors; for <= 32 queries with long rows the exact re-score is spread over
- * one workgroup per selected group and merged; for databases of <= 16384 rows (and more than 4
- * queries) the score matrix itself is kept in the workspace and the top-k is read off it -- no
- * re-score gather (the reference's own scale, 1063 key-frames x 75 000-d: 0.3 instead of 4 ms).
- * Ordering rule and outputs are the same for every plan.  The reported fp32 scores are
- * sequential-order dot products under the re-scoring plans and MFMA-order (chunk-ordered when K
- * is split) sums under the small-database plan: they agree to fp32 rounding (~1e-7), identical
- * rows always tie exactly, and two DIFFERENT rows can change places between plans only when their
- * exact scores are closer than that rounding.
- * Exactness of the re-scoring plans: groups are ranked by their MFMA-order maxima and kg =
- * dlc_cosine_groups_per_query(k) = k + 4 groups are re-scored, so the result is the exact top-k
- * of the sequential-order scores unless MORE THAN 4 groups that do not hold a top-k row have a
- * maximum within fp32 rounding (~1e-7 relative) of the k-th best score AND rank above a group
- * that does -- e.g. five or more near-duplicates (not exact copies: those tie) of the k-th match
- * spread over distinct 8-row groups.
+ * (both stored normalised in `dtype` = DLC_BF16 / DLC_F16 -- row norms <= 1.005, what
+ * dlc_l2_normalize_rows writes; row strides ldq / lddb in elements, d a multiple of 64, rows
+ * 16-byte aligned).
+ *
+ * THE SCORE of a (query, row) pair is one number, whatever call, plan, shard or batch computes it:
+ * the fp64 sum of the exact products of the stored elements (bf16 / fp16 products are exact in
+ * fp64; the additions follow one fixed order that depends on d only).  THE ORDER of every result is
+ * score descending on the key round(score * 2^40), ties -> lower global row index: the order of
+ * oracle/cosine.py.  out_scores_f64[q,k] (may be NULL) receives the fp64 scores, out_scores[q,k]
+ * the same values rounded once to fp32, out_idx[q,k] the rows (int64, row_offset added -- the
+ * shard's first global row).  Slots past min(k,n) get -inf / -1.  1 <= k <= DLC_MAX_K.
+ *
+ * How the rows are found.  The score pass (bf16/fp16 MFMA, fp32 accumulate; a v_dot2 bandwidth
+ * kernel for <= 4 queries) only chooses CANDIDATES: it keeps the maximum of every 8 database rows
+ * (and, for databases of <= 16384 rows, the fp32 score matrix itself in the workspace).  The
+ * selection takes the kg = dlc_cosine_groups_per_query(k) = k + 4 groups with the largest maxima
+ * (under the small-database plan the k + 4 best rows of those groups), re-scores them in fp64,
+ * ranks them, and CERTIFIES the result: every row left behind has an fp32 score <= B (the best
+ * group / row not taken), fp32 scores err by at most tau = dlc_cosine_score_error_bound(...)
+ * against the fp64 score, so the result is the exact top-k when the k-th fp64 score > B + tau.
+ * Queries that fail the test (crowded scores: more near-ties at the k-th place than the slack
+ * holds) go through an exhaustive pass in the same call: every group whose maximum is >= (k-th
+ * score found) - tau is re-scored in fp64 against a running top-k.  out_status[q] (int32, may be
+ * NULL): 0 = certified at once, 2 = resolved by the exhaustive pass.  Either way the result is the
+ * top-k of the fp64 scores; the pass costs time only (in the degenerate case of a database of
+ * near-identical rows it is an fp64 brute force for that query).
+ * Plans (picked from the shape; the workspace size reflects them): one score pass for databases of
+ * >= 256 tiles of 256 rows; split-K partial score tiles + a reducing pass (chunks summed in fp64)
+ * for few rows with long descriptors; for <= 32 queries with long rows the re-score is spread over
+ * one workgroup per selected group and merged.  Results are identical across plans.
  */
 #define DLC_MAX_K 128
 size_t dlc_cosine_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int k);
 int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
                     const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
-                    float* out_scores, int64_t* out_idx,
+                    float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
                     void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * tau of the plan dlc_cosine_topk takes for this shape: |fp32 score of the score pass - fp64 score|
+ * <= tau for rows of norm <= 1.005.  (s MFMA / v_dot2 accumulation steps of at most 2^-23 *
+ * (|accumulator| + sum |products|) each, partial sums <= |q| |x| <= 1.01: tau = 2^-23 * 1.01 *
+ * (s + 2) + 2^-38; s = 2 * (K tiles of 64 per split-K chunk).  4096-d one pass: 1.6e-5.)
+ * A caller that merges shards of different shapes certifies with the largest of their taus.
+ */
+double dlc_cosine_score_error_bound(int64_t q, int64_t n, int64_t d, int k);
 /*
  * The two stages of dlc_cosine_topk as separate calls, for callers that pipeline batches
  * over two streams (stage 2 of batch i overlapping stage 1 of batch i+1, each batch with its
  * own workspace):
- *   dlc_cosine_score_groups  -- the MFMA score GEMM; fills the workspace (per-query maxima of
- *                               every 8 / 128 database rows), reads Q and DB;
- *   dlc_cosine_select_topk   -- group selection, exact fp32 re-score, final top-k; reads the
- *                               workspace (and consumes it), Q and DB.
+ *   dlc_cosine_score_groups  -- the score pass; fills the workspace, reads Q and DB;
+ *   dlc_cosine_select_topk   -- selection, fp64 re-score, final top-k, certificate, exhaustive
+ *                               pass; reads the workspace (and consumes it), Q and DB.
  * Same operand rules, same workspace size (dlc_cosine_topk_workspace_bytes), same results.
- * flags: DLC_SELECT_COOP selects a small-footprint kernel (256 threads, ~70 VGPRs, a few KiB
+ * flags: DLC_SELECT_COOP selects a small-footprint kernel (256 threads, < 96 VGPRs, a few KiB
  * of LDS) whose workgroups can share a CU with a running score GEMM.
  */
 #define DLC_SELECT_COOP 1
@@ -340,7 +354,7 @@ int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, i
                             void* workspace, size_t workspace_bytes, void* stream);
 int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
                            const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
-                           float* out_scores, int64_t* out_idx,
+                           float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
                            void* workspace, size_t workspace_bytes, int flags, void* stream);
 /*
  * Stage 2 split once more, for a database sharded over several GPUs.  Each shard would
@@ -348,12 +362,27 @@ int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, in
  * the shard size; exchanging the groups' MAXIMA first lets every shard skip the groups that
  * cannot be among the kg best of the whole database:
  *   dlc_cosine_select_groups -- from the workspace: group_ids [q,kg] (int32 shard-local group
- *                               index, -1 = none) and group_max [q,kg] (fp32), in rank order;
- *   (caller: all-gather group_max over the `parts` shards -> all_group_max [parts,q,kg])
+ *                               index, -1 = none) and group_max [q,kg+1] (fp32): the groups'
+ *                               maxima in rank order and, in column kg, the largest maximum among
+ *                               the shard's groups that are NOT listed (-inf: none);
+ *   (caller: all-gather group_max over the `parts` shards -> all_group_max [parts,q,kg+1])
  *   dlc_cosine_rescore_topk  -- drops every own group with >= kg strictly larger maxima in
- *                               all_group_max (parts = 0: no filter), re-scores the rest in
- *                               exact fp32 and returns the shard's top-k as dlc_cosine_topk does.
- * The union of the shards' results still contains the global top-k (merge with dlc_topk_merge).
+ *                               all_group_max (parts = 0: no filter), re-scores the rest in fp64
+ *                               and writes the shard's part of the top-k (fp64 scores + rows) and,
+ *                               to out_bound[q] (may be NULL), the largest fp32 score a row outside
+ *                               the surviving groups of ALL shards can have -- the same value on
+ *                               every shard;
+ *   (caller: all-gather the parts; dlc_topk_merge_strided with bound = out_bound and tau = the
+ *    largest dlc_cosine_score_error_bound of the shards: out_status[q] = 0 certified / 1 not)
+ *   dlc_cosine_exhaustive_topk -- for the queries with status[q] == 1 (others are skipped on the
+ *                               device): lower[q * lower_stride] = the k-th merged fp64 score (-inf:
+ *                               fewer than k rows found); every group of THIS shard whose maximum
+ *                               (still in the workspace of the score pass) is >= lower - tau is
+ *                               re-scored in fp64; the shard's exact top-k over those rows REPLACES
+ *                               out_*[q] and status[q] becomes 2.  Merging these per-shard lists
+ *                               (taking, per query, the new list where status == 2) gives the exact
+ *                               global top-k.  dlc_cosine_topk / dlc_cosine_select_topk run it
+ *                               themselves; a sharded caller runs it when any status is 1.
  */
 int dlc_cosine_groups_per_query(int k);
 int dlc_cosine_select_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
@@ -364,7 +393,12 @@ int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, i
                             const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
                             const int32_t* group_ids, const float* group_max,
                             const float* all_group_max, int parts,
-                            float* out_scores, int64_t* out_idx, int flags, void* stream);
+                            double* out_scores_f64, int64_t* out_idx, float* out_bound, int flags, void* stream);
+int dlc_cosine_exhaustive_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
+                               const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
+                               const double* lower, int64_t lower_stride, double tau, int32_t* status,
+                               float* out_scores, double* out_scores_f64, int64_t* out_idx,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /*
  * Streaming loop-closure queries: a batch of B new frames is matched in one dlc_cosine_topk call with
  * kk = k + B - 1 candidates per frame; frame b may only see key-frames older than limit0 + b.  Row b of the best-first
@@ -374,16 +408,20 @@ int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, i
 int dlc_topk_keep_older(dlc_ctx* ctx, const float* scores, const int64_t* idx, int64_t rows, int kk,
                         int64_t limit0, int k, float* out_scores, int64_t* out_idx, void* stream);
 /*
- * Merge `parts` per-shard results ([parts, q, k], as an all-gather leaves
- * them) into the global top-k with the same ordering rule.
+ * Merge `parts` per-shard results ([parts, q, k] fp64 scores + int64 rows, as an all-gather leaves
+ * them; idx < 0 = empty slot) into the global top-k with the same ordering rule (fp64 key, then the
+ * lower row).  out_scores (fp32) / out_scores_f64 may be NULL, not both.
  */
-int dlc_topk_merge(dlc_ctx* ctx, const float* scores, const int64_t* idx, int parts, int64_t q, int k,
-                   float* out_scores, int64_t* out_idx, void* stream);
+int dlc_topk_merge(dlc_ctx* ctx, const double* scores_f64, const int64_t* idx, int parts, int64_t q, int k,
+                   float* out_scores, double* out_scores_f64, int64_t* out_idx, void* stream);
 /* Same with explicit distances (in elements) between consecutive parts, for results that were
- * gathered as one packed buffer per shard. */
-int dlc_topk_merge_strided(dlc_ctx* ctx, const float* scores, int64_t score_part_stride,
+ * gathered as one packed buffer per shard, and with the certificate of the sharded protocol above:
+ * bound [q] (may be NULL: nothing left behind) and tau -> out_status[q] (may be NULL).  parts * k <= 2048. */
+int dlc_topk_merge_strided(dlc_ctx* ctx, const double* scores_f64, int64_t score_part_stride,
                            const int64_t* idx, int64_t idx_part_stride, int parts, int64_t q, int k,
-                           float* out_scores, int64_t* out_idx, void* stream);
+                           const float* bound, double tau,
+                           float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
+                           void* stream);
 /*
  * Dense score block S[q, n] (fp32) = Q . DB^T for the all-vs-all cosine
  * matrix of config 2 (small N); same operand rules as dlc_cosine_topk.

@@ -7,8 +7,11 @@ Tolerances (stated here, used below):
   * fp64 kernels (SDAV / DA / conv GEMMs, SDAV similarity): the reference is
     fp64 and so are the kernels; only the summation order differs -> abs 1e-10
     on sigmoid outputs, rel 1e-9 on similarity scores;
-  * cosine scores: fp32 accumulation of bf16/fp16 products vs the fp64 oracle
-    on the SAME stored values -> abs 2e-5 (north_star asks 1e-4).
+  * cosine top-k: the order is decided on fp64 scores of the stored values (as the oracle's) -> IDENTICAL
+    indices, in every test including the fuzz loops; reported fp64 scores vs the oracle's BLAS fp64 -> abs
+    1e-12; their fp32 roundings -> equal to the oracle's score rounded to fp32 within 1 ulp (6e-8);
+    the dense fp32 MFMA score matrix (dlc_cosine_scores) -> within dlc_cosine_score_error_bound (north_star
+    asks 1e-4).
 """
 import numpy as np
 import pytest
@@ -35,13 +38,10 @@ def stored(eng, x, dtype):
     return eng.normalize(torch.from_numpy(np.ascontiguousarray(x)).to(eng.device), dtype)
 
 
-FLIPS = {"slots": 0, "flipped": 0}          # over the fuzz loops of this module (printed at the end of the session)
-
-
-def assert_topk_matches(s, i, q_st, db_st, k, row_offset=0, exact=True):
-    """Compare a GPU top-k with the fp64 oracle on the stored values: IDENTICAL indices (north_star).
-    exact=False (fuzz loops over random shapes only): positions may differ where the oracle's own
-    scores are closer than fp32 can resolve (2e-6), at most 0.1 % of the slots; the count is recorded."""
+def assert_topk_matches(s, i, q_st, db_st, k, row_offset=0, s64=None):
+    """Compare a GPU top-k with the fp64 oracle on the stored values: IDENTICAL indices (north_star), everywhere --
+    the GPU decides the order on fp64 scores with the oracle's tie rule.  Scores: fp64 to 1e-12 (summation order),
+    fp32 = one rounding of it."""
     from oracle import cosine as ocos
     qn, dbn = q_st.float().cpu().numpy().astype(np.float64), db_st.float().cpu().numpy().astype(np.float64)
     es, ei = ocos.cosine_topk(qn, dbn, k, row_offset=row_offset)
@@ -49,19 +49,10 @@ def assert_topk_matches(s, i, q_st, db_st, k, row_offset=0, exact=True):
     kk = es.shape[1]
     assert np.all(i[:, kk:] == -1) and np.all(np.isneginf(s[:, kk:]))
     s, i = s[:, :kk], i[:, :kk]
-    assert np.abs(s - es).max() < 2e-5
-    if exact:
-        assert np.array_equal(i, ei)
-        return
-    diff = i != ei
-    FLIPS["slots"] += diff.size
-    FLIPS["flipped"] += int(diff.sum())
-    if diff.any():
-        full = qn @ dbn.T
-        rows, cols = np.nonzero(diff)
-        got_true = full[rows, i[rows, cols] - row_offset]
-        assert np.abs(got_true - es[rows, cols]).max() < 2e-6, "index differs where scores are not tied"
-        assert diff.mean() < 1e-3
+    assert np.array_equal(i, ei)
+    assert np.abs(s - es).max() < 1.2e-7
+    if s64 is not None:
+        assert np.abs(s64.cpu().numpy()[:, :kk] - es).max() < 1e-12
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -155,9 +146,7 @@ def test_cosine_topk_plan_boundaries_fuzz(eng):
         if n > 3:
             assert i[0, 0].item() == n // 2 + 3, (nq, n, d, k)
             assert k < 2 or i[0, 1].item() == n - 1 + 3, (nq, n, d, k)
-        assert_topk_matches(s, i, q_st, db_st, k, row_offset=3, exact=False)
-    print("plan-boundary fuzz: %d of %d top-k slots differ from the oracle (near-ties below fp32 resolution)"
-          % (FLIPS["flipped"], FLIPS["slots"]))
+        assert_topk_matches(s, i, q_st, db_st, k, row_offset=3)
 
 
 def test_cosine_topk_planted_neighbours_exact(eng):
@@ -186,12 +175,93 @@ def test_cosine_topk_duplicates_break_ties_to_lower_index(eng):
     db_st, q_st = stored(eng, db, "bf16"), stored(eng, q, "bf16")
     s, i = eng.match_topk(q_st, db_st, 20)
     assert i[0].cpu().tolist() == sorted(dup.tolist())[:20]
-    assert_topk_matches(s, i, q_st, db_st, 20, exact=True)
+    assert_topk_matches(s, i, q_st, db_st, 20)
     # whole database identical: top-k must be rows 0..k-1
     same = np.repeat(db[:1], 3000, axis=0)
     st = stored(eng, same, "bf16")
     s, i = eng.match_topk(st[:4], st, 33)
     assert i.cpu().tolist() == [list(range(33))] * 4
+
+
+def test_cosine_topk_crowded_scores_take_the_exhaustive_pass(eng):
+    """More near-ties at the k-th place than the selection's slack holds: 300 key-frames that differ from one another by
+    ONE bf16 ulp in one element (score differences ~1e-6, below the score pass's error bound tau), spread over 300
+    distinct 8-row groups.  The certificate must refuse (status 2 = resolved by the exhaustive pass) and the result must
+    still be the fp64 oracle's, index for index -- in the fused call, the two-stage call, the multi-workgroup re-score
+    plan (1 query x long rows) and the small-database plan."""
+    rng = np.random.RandomState(77)
+    for nq, n, d, k, dtype in ((6, 40000, 1024, 20, "bf16"), (3, 40000, 1024, 20, "f16"), (1, 3000, 16384, 10, "bf16"),
+                               (8, 9000, 4096, 20, "bf16")):
+        db = rng.standard_normal((n, d)).astype(np.float32)
+        db_st = stored(eng, db, dtype)
+        base = db_st[17].clone()
+        where = rng.choice(n // 8, 300, replace=False) * 8 + rng.randint(0, 8, 300)      # one row in each of 300 groups
+        bits = db_st.view(torch.int16)
+        for j, r in enumerate(where.tolist()):
+            bits[r] = base.view(torch.int16)
+            bits[r, (37 * j) % d] += 1 if j % 2 else -1                                  # one ulp up / down in one element
+        q_st = db_st[torch.tensor([17] + list(range(100, 100 + nq - 1)), device=eng.device)].clone()
+        top = eng.match_topk(q_st, db_st, k, row_offset=5, details=True)
+        torch.cuda.synchronize()
+        assert int(top.status[0]) == 2, (nq, n, d)                 # the crowded query went through the exhaustive pass
+        assert set(top.status.cpu().tolist()) <= {0, 2}
+        assert_topk_matches(top.scores, top.idx, q_st, db_st, k, row_offset=5, s64=top.scores_f64)
+        if nq > 4:                                                 # the two-stage form, both kernel footprints
+            for coop in (False, True):
+                ws = torch.empty(eng.topk_workspace_bytes(nq, n, d, k), dtype=torch.uint8, device=eng.device)
+                s2 = torch.empty((nq, k), dtype=torch.float32, device=eng.device)
+                i2 = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
+                eng.score_groups(q_st, db_st, k, ws)
+                eng.select_topk(q_st, db_st, k, ws, s2, i2, row_offset=5, coop=coop)
+                assert torch.equal(i2, top.idx) and torch.equal(s2, top.scores)
+
+
+def test_score_error_bound_holds(eng):
+    """dlc_cosine_score_error_bound is what the certificate of every selection rests on: |fp32 score of the score pass -
+    fp64 score| <= tau.  Checked on every element of dense MFMA score matrices (one pass and split-K) for random,
+    all-positive (partial sums grow monotonically: the worst case of the bound's model) and cancelling data, and for the
+    q <= 4 bandwidth kernel through its group maxima; the worst observed fraction of tau is printed."""
+    rng = np.random.RandomState(5)
+    worst = 0.0
+    for nq, n, d, dtype in ((64, 700, 64, "bf16"), (64, 700, 4096, "bf16"), (64, 700, 4096, "f16"), (32, 300, 16384, "bf16"),
+                            (16, 520, 75008, "bf16")):
+        for kind in ("normal", "positive", "cancel"):
+            x = rng.standard_normal((n, d)).astype(np.float32)
+            y = rng.standard_normal((nq, d)).astype(np.float32)
+            if kind == "positive":
+                x, y = np.abs(x), np.abs(y)
+            elif kind == "cancel":                                  # +a, -a pairs: products cancel, partial sums do not
+                x[:, 1::2] = -x[:, 0::2]
+                y[:, 1::2] = y[:, 0::2]
+            db_st, q_st = stored(eng, x, dtype), stored(eng, y, dtype)
+            tau = eng.score_error_bound(nq, n, db_st.shape[1], 20)
+            s = eng.cosine_scores(q_st, db_st).double()
+            ref = q_st.double() @ db_st.double().T
+            err = float((s - ref).abs().max())
+            worst = max(worst, err / tau)
+            assert err <= tau, (nq, n, d, dtype, kind, err, tau)
+    # q <= 4: v_dot2 chains; the group maxima of select_groups are the kernel's fp32 scores
+    for nq, n, d, dtype in ((1, 3000, 4096, "bf16"), (4, 3000, 8192, "f16"), (2, 3000, 64, "bf16")):
+        x = np.abs(rng.standard_normal((n, d))).astype(np.float32)
+        db_st = stored(eng, x, dtype)
+        q_st = stored(eng, np.abs(rng.standard_normal((nq, d))).astype(np.float32), dtype)
+        k = 20
+        kg = eng.groups_per_query(k)
+        tau = eng.score_error_bound(nq, n, db_st.shape[1], k)
+        ws = torch.empty(eng.topk_workspace_bytes(nq, n, db_st.shape[1], k), dtype=torch.uint8, device=eng.device)
+        gi = torch.empty((nq, kg), dtype=torch.int32, device=eng.device)
+        gm = torch.empty((nq, kg + 1), dtype=torch.float32, device=eng.device)
+        eng.score_groups(q_st, db_st, k, ws)
+        eng.select_groups(q_st, db_st, k, ws, gi, gm)
+        ref = (q_st.double() @ db_st.double().T)[:, :n // 8 * 8].reshape(nq, n // 8, 8).max(dim=2).values   # exact group maxima
+        got = gm[:, :kg].double()
+        want = torch.gather(ref, 1, gi.long().clamp(min=0))
+        err = float((got - want).abs().max())
+        worst = max(worst, err / tau)
+        assert err <= tau, (nq, n, d, dtype, err, tau)
+        # and the listed groups are the best ones up to tau: nothing left behind beats the last listed maximum by more
+        assert float((ref.max(dim=1).values - got[:, 0]).abs().max()) <= tau
+    print("score error bound: worst observed error = %.3f of tau" % worst)
 
 
 def test_cosine_topk_row_stride_and_padding(eng):
@@ -227,40 +297,38 @@ def test_topk_merge_vs_oracle(eng):
     from oracle import cosine as ocos
     rng = np.random.RandomState(4)
     parts, nq, k = 8, 50, 20
-    s = rng.standard_normal((parts, nq, k)).astype(np.float32)
+    s = rng.uniform(-1, 1, (parts, nq, k))
     s[3, :, 5] = s[1, :, 2]
+    s[4, :, 0] = s[2, :, 7] + 2.0 ** -45                       # closer than the 2^-40 key: a tie, the lower row wins
+    s[5, :, 1] = np.float32(s[6, :, 3]).astype(np.float64)     # equal after rounding to fp32, not in fp64: NOT a tie
     i = rng.permutation(parts * nq * k).reshape(parts, nq, k).astype(np.int64)
     i[7, :, -3:] = -1
-    ms, mi = eng.topk_merge(torch.from_numpy(s).to(eng.device), torch.from_numpy(i).to(eng.device))
-    cs = np.transpose(s, (1, 0, 2)).reshape(nq, parts * k).astype(np.float64)
+    r = eng.topk_merge(torch.from_numpy(s).to(eng.device), torch.from_numpy(i).to(eng.device), details=True)
+    cs = np.transpose(s, (1, 0, 2)).reshape(nq, parts * k)
     ci = np.transpose(i, (1, 0, 2)).reshape(nq, parts * k)
     cs = np.where(ci < 0, -np.inf, cs)
     es, ei = ocos.merge_topk(cs, np.where(ci < 0, np.iinfo(np.int64).max, ci), k)
-    assert np.array_equal(mi.cpu().numpy(), ei) and np.array_equal(ms.cpu().numpy(), es.astype(np.float32))
+    assert np.array_equal(r.idx.cpu().numpy(), ei) and np.array_equal(r.scores_f64.cpu().numpy(), es)
+    assert np.array_equal(r.scores.cpu().numpy(), es.astype(np.float32))
 
 
 @pytest.mark.parametrize("n", [80000, 40000, 12000])
 def test_sharded_equals_unsharded(eng, dlc, n):
-    """Size-independent property: 4 row shards + merge == one shard.  Bit for bit when the shards and the
-    whole database take the same plan (80 000: all re-scored; 12 000: all read off the score matrix);
-    at 40 000 the 10 000-row shards take the small-database plan and the whole the re-scoring one:
-    same indices, scores equal to fp32 rounding."""
+    """Size-independent property: 4 row shards + merge == one shard, BIT FOR BIT (indices, fp64 and fp32 scores),
+    whatever plans the shards and the whole database take (80 000: all gather their groups' rows; 12 000: all pick
+    rows off the fp32 score matrix; 40 000: the 10 000-row shards do the latter, the whole the former)."""
     rng = np.random.RandomState(9)
     d, nq, k = 256, 128, 20
     db_st = stored(eng, rng.standard_normal((n, d)).astype(np.float32), "bf16")
     q_st = stored(eng, rng.standard_normal((nq, d)).astype(np.float32), "bf16")
-    s0, i0 = eng.match_topk(q_st, db_st, k)
+    r0 = eng.match_topk(q_st, db_st, k, details=True)
     ps, pi = [], []
     for r in range(4):
         lo, hi = dlc.shard_bounds(n, 4, r)
-        s, i = eng.match_topk(q_st, db_st[lo:hi], k, row_offset=lo)
-        ps.append(s.clone()), pi.append(i.clone())
-    ms, mi = eng.topk_merge(torch.stack(ps), torch.stack(pi))
-    assert torch.equal(mi, i0)
-    if n == 40000:
-        assert float((ms - s0).abs().max()) < 1e-6
-    else:
-        assert torch.equal(ms, s0)
+        t = eng.match_topk(q_st, db_st[lo:hi], k, row_offset=lo, details=True)
+        ps.append(t.scores_f64.clone()), pi.append(t.idx.clone())
+    m = eng.topk_merge(torch.stack(ps), torch.stack(pi), details=True)
+    assert torch.equal(m.idx, r0.idx) and torch.equal(m.scores_f64, r0.scores_f64) and torch.equal(m.scores, r0.scores)
 
 
 def test_match_errors(eng):
@@ -931,49 +999,74 @@ def test_group_exchange_protocol_equals_unsharded(eng, dlc, n):
     x[[100, 20000, 20001, 40000]] = x[7]                       # exact ties across shards
     db = stored(eng, x, "bf16")
     q = stored(eng, np.concatenate([x[[7, 9]], rng.standard_normal((nq - 2, d)).astype(np.float32)]), "bf16")
-    want_s, want_i = eng.match_topk(q, db, k)
+    want = eng.match_topk(q, db, k, details=True)
     kg = eng.groups_per_query(k)
-    ids, mx, shards = [], [], []
+    ids, mx, shards, wss = [], [], [], []
     for r in range(parts):
         lo, hi = dlc.shard_bounds(n, parts, r)
         ws = torch.empty(eng.topk_workspace_bytes(nq, hi - lo, d, k), dtype=torch.uint8, device=eng.device)
         gi = torch.empty((nq, kg), dtype=torch.int32, device=eng.device)
-        gm = torch.empty((nq, kg), dtype=torch.float32, device=eng.device)
+        gm = torch.empty((nq, kg + 1), dtype=torch.float32, device=eng.device)
         eng.score_groups(q, db[lo:hi], k, ws)
         eng.select_groups(q, db[lo:hi], k, ws, gi, gm, coop=(r % 2 == 1))
-        ids.append(gi), mx.append(gm), shards.append((lo, hi))
-    all_max = torch.stack(mx)
-    gathered = torch.empty((parts, nq * k * 12), dtype=torch.uint8, device=eng.device)
+        ids.append(gi), mx.append(gm), shards.append((lo, hi)), wss.append(ws)
+    all_max = torch.stack(mx)                                  # [parts, nq, kg + 1]; column kg = what a shard leaves behind
+    lists = all_max[:, :, :kg]
+    gathered = torch.empty((parts, nq * k * 16), dtype=torch.uint8, device=eng.device)
+    bounds = []
     kept = 0
     for r, (lo, hi) in enumerate(shards):
         idx = gathered[r, :nq * k * 8].view(torch.int64).view(nq, k)
-        sc = gathered[r, nq * k * 8:].view(torch.float32).view(nq, k)
-        eng.rescore_topk(q, db[lo:hi], k, ids[r], mx[r], sc, idx, all_max=all_max, row_offset=lo, coop=(r % 2 == 0))
+        sc = gathered[r, nq * k * 8:].view(torch.float64).view(nq, k)
+        bound = torch.empty((nq,), dtype=torch.float32, device=eng.device)
+        eng.rescore_topk(q, db[lo:hi], k, ids[r], mx[r], sc, idx, bound=bound, all_max=all_max, row_offset=lo, coop=(r % 2 == 0))
+        bounds.append(bound)
         # no returned row may come from a group the filter must drop, and the filter must bite
         grp = torch.div(idx - lo, 8, rounding_mode="floor")                                 # [nq, k]
         pos = (ids[r].long().unsqueeze(1) == grp.unsqueeze(2))                              # [nq, k, kg]
         valid = idx >= 0                                                                    # empty slots: too few survivors
         assert bool((pos.any(dim=2) | ~valid).all())
-        gval = (mx[r].unsqueeze(1) * pos).sum(dim=2)                                        # that group's maximum
-        greater = (all_max.permute(1, 0, 2).reshape(nq, 1, -1) > gval.unsqueeze(2)).sum(dim=2)
+        gval = (mx[r][:, :kg].unsqueeze(1) * pos).sum(dim=2)                                # that group's maximum
+        greater = (lists.permute(1, 0, 2).reshape(nq, 1, -1) > gval.unsqueeze(2)).sum(dim=2)
         assert bool(((greater < kg) | ~valid).all())
-        own = (all_max.permute(1, 0, 2).reshape(nq, 1, -1) > mx[r].unsqueeze(2)).sum(dim=2) < kg   # [nq, kg]
+        own = (lists.permute(1, 0, 2).reshape(nq, 1, -1) > mx[r][:, :kg].unsqueeze(2)).sum(dim=2) < kg   # [nq, kg]
         kept += int(own.sum())
-        # unfiltered re-score of the same list == the fused one-shot result of that shard
-        s2 = torch.empty((nq, k), dtype=torch.float32, device=eng.device)
+        # unfiltered re-score of the same list == the fused one-shot result of that shard, bit for bit
+        s2 = torch.empty((nq, k), dtype=torch.float64, device=eng.device)
         i2 = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
         eng.rescore_topk(q, db[lo:hi], k, ids[r], mx[r], s2, i2, all_max=None, row_offset=lo)
-        s1, i1 = eng.match_topk(q, db[lo:hi], k, row_offset=lo)
-        assert torch.equal(i1, i2)
-        if hi - lo > 16384:
-            assert torch.equal(s1, s2)
-        else:       # one-shot call under the small-database plan: MFMA-order scores, equal to fp32 rounding
-            assert float((s1 - s2).abs().max()) < 1e-6
+        one = eng.match_topk(q, db[lo:hi], k, row_offset=lo, details=True)
+        assert torch.equal(one.idx, i2) and torch.equal(one.scores_f64, s2)
+    # every shard computes the same bound: the best maximum left behind anywhere (dropped groups + the shards' rests)
+    assert all(torch.equal(b, bounds[0]) for b in bounds)
+    flat = lists.permute(1, 0, 2).reshape(nq, -1)
+    cnt = (flat.unsqueeze(1) > flat.unsqueeze(2)).sum(dim=2)                                # strictly larger maxima per entry
+    dropped = torch.where(cnt >= kg, flat, torch.full_like(flat, float("-inf"))).max(dim=1).values
+    assert torch.equal(bounds[0], torch.maximum(dropped, all_max[:, :, kg].max(dim=0).values))
     o_s = torch.empty((nq, k), dtype=torch.float32, device=eng.device)
     o_i = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
-    eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i))
-    assert torch.equal(o_i, want_i) and torch.equal(o_s, want_s)
+    o_64 = torch.empty((nq, k), dtype=torch.float64, device=eng.device)
+    status = torch.full((nq,), -1, dtype=torch.int32, device=eng.device)
+    tau = max(eng.score_error_bound(nq, hi - lo, d, k) for lo, hi in shards)
+    eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i), bound=bounds[0], tau=tau, scores_f64=o_64, status=status)
+    assert torch.equal(o_i, want.idx) and torch.equal(o_s, want.scores) and torch.equal(o_64, want.scores_f64)
+    assert int(status.min()) >= 0 and int(status.max()) <= 1
+    # certificate of the merge == the definition, on the host
+    kth = o_64[:, k - 1]
+    assert torch.equal(status == 0, kth > bounds[0].double() + tau)
     assert kept <= nq * (kg + 4) and kept < parts * nq * kg * 0.5        # ~kg groups survive per query in total
+    # the exhaustive round of the protocol, forced for EVERY query: each shard's exact list over all groups within tau of
+    # the merged k-th score, merged again == the same result
+    forced = torch.ones((nq,), dtype=torch.int32, device=eng.device)
+    lower = kth.contiguous()
+    for r, (lo, hi) in enumerate(shards):
+        idx = gathered[r, :nq * k * 8].view(torch.int64).view(nq, k)
+        sc = gathered[r, nq * k * 8:].view(torch.float64).view(nq, k)
+        st = forced.clone()
+        eng.exhaustive_topk(q, db[lo:hi], k, wss[r], lower, tau, st, sc, idx, row_offset=lo)
+        assert int(st.min()) == 2 and int(st.max()) == 2
+    eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i), scores_f64=o_64)
+    assert torch.equal(o_i, want.idx) and torch.equal(o_64, want.scores_f64)
 
 
 def test_error_paths_raise_value_error(eng, dlc):
@@ -1035,12 +1128,13 @@ def test_row_stride_bound_and_buffer_validation(eng, dlc):
     big = (1 << 32) // (2 * 255) // 8 * 8 + 8                       # elements: 255 rows x 2 bytes >= 4 GiB
     for ldq, lddb in ((64, big), (big, 64)):
         rc = eng.lib.dlc_cosine_topk(eng.ctx, L.DLC_BF16, C.c_void_p(q.data_ptr()), 4, ldq, C.c_void_p(q.data_ptr()), 1, lddb,
-                                     64, 2, 0, C.c_void_p(s.data_ptr()), C.c_void_p(i.data_ptr()), C.c_void_p(ws.data_ptr()),
-                                     ws.numel(), None)
+                                     64, 2, 0, C.c_void_p(s.data_ptr()), None, C.c_void_p(i.data_ptr()), None,
+                                     C.c_void_p(ws.data_ptr()), ws.numel(), None)
         assert rc == L.DLC_ERR_BAD_SHAPE and b"stride" in eng.lib.dlc_last_error(eng.ctx)
     ok = (1 << 32) // (2 * 255) // 8 * 8 - 64                       # just below the bound: accepted (one row: the stride is unused)
     rc = eng.lib.dlc_cosine_topk(eng.ctx, L.DLC_BF16, C.c_void_p(q.data_ptr()), 1, ok, C.c_void_p(q.data_ptr()), 1, ok, 64, 1, 0,
-                                 C.c_void_p(s.data_ptr()), C.c_void_p(i.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), None)
+                                 C.c_void_p(s.data_ptr()), None, C.c_void_p(i.data_ptr()), None, C.c_void_p(ws.data_ptr()),
+                                 ws.numel(), None)
     torch.cuda.synchronize()
     assert rc == L.DLC_OK
     for bad in ((s[:, :1], i), (s, i.to(torch.int32)), (s.t().contiguous().t(), i), (s.cpu(), i)):
@@ -1049,8 +1143,10 @@ def test_row_stride_bound_and_buffer_validation(eng, dlc):
     with pytest.raises(ValueError):
         eng.select_topk(q, q, 2, ws, s[:2], i)
     with pytest.raises(ValueError):
-        eng.topk_merge(torch.zeros((2, 4, 2), device=eng.device), torch.zeros((2, 4, 2), dtype=torch.int64, device=eng.device),
-                       out=(s[:3], i))
+        eng.topk_merge(torch.zeros((2, 4, 2), dtype=torch.float64, device=eng.device),
+                       torch.zeros((2, 4, 2), dtype=torch.int64, device=eng.device), out=(s[:3], i))
+    with pytest.raises(ValueError):                                # the order is decided in fp64: fp32 parts are refused
+        eng.topk_merge(torch.zeros((2, 4, 2), device=eng.device), torch.zeros((2, 4, 2), dtype=torch.int64, device=eng.device))
     with pytest.raises(ValueError):
         eng.gemm_bias_act(torch.zeros((4, 5), dtype=torch.float64, device=eng.device),
                           torch.zeros((5, 7), dtype=torch.float64, device=eng.device),
