@@ -65,6 +65,8 @@ class ShardedKeyframeDatabase:
 
     def match_topk(self, queries, k):
         if self._db is not None:
+            if self.world == 1:                      # nothing to exchange: the one-shot call (faster than the pipeline on one GPU)
+                return self._db.match_topk(queries, k)
             from .matching import MatchPipeline
             pipe = self._pipes.get(k)
             if pipe is None:
