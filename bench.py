@@ -394,7 +394,7 @@ def bench_paths(eng, n_frames):
                                  "literal_ms_per_pair": t_lit * 1e3},
                 "note": "fp64 in, fp64 / int64 out, every value that reaches the result computed in fp64; the int8 kernel only "
                         "decides which patch is nearest, with a rigorous error bound, and hands undecided cases to fp64 "
-                        "(DESIGN.md 4.4; DLC_SIM_GRAM=f64 runs the fp64 Gram form: the same matrix, 38.9 ms)",
+                        "(DESIGN.md 4.4; DLC_SIM_FORCE_F64 in the call's flags runs the fp64 Gram form: the same matrix, 38.9 ms)",
                 "max_rel_err_vs_oracle": err})
     del mf, mi, sub, ref, dsn
 

@@ -18,6 +18,7 @@ DLC_B_KN, DLC_B_NK = 0, 1
 DLC_MAX_K = 128
 DLC_ABI_VERSION = 5          # include/dlc.h; load() refuses a library built from another header
 DLC_SELECT_COOP = 1
+DLC_SIM_FORCE_F64, DLC_SIM_NO_HOST_SYNC = 1, 2
 
 _vp, _i64, _int, _sz, _dbl, _flt = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_double, C.c_float
 
@@ -51,8 +52,9 @@ SIGNATURES = {
                                          _int, _int, _vp, _vp, _vp]),
     "dlc_quant_gather_i8": (_int, [_vp, C.POINTER(_vp), C.POINTER(_i64), _int, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dlc_sdav_distinctive_score": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _vp, _vp]),
-    "dlc_sdav_similarity_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "dlc_sdav_similarity_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp, _sz, _vp]),
+    "dlc_sdav_similarity_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _i64]),
+    "dlc_sdav_similarity_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _int, _i64, _vp, _vp, _vp,
+                                         _sz, _vp]),
     "dlc_cnnvtl_distance_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dlc_l2_normalize_rows": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
     "dlc_cosine_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),

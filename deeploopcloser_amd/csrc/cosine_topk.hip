@@ -1326,9 +1326,6 @@ SplitPlan split_plan(int64_t q, int64_t n, int64_t d) {
     const int64_t base = dlc::cdiv(ntiles, (int64_t)8) * 8 * dlc::cdiv(q, BNQ);   // workgroups of one pass
     const int64_t nk = d / BK;
     SplitPlan best{1, (int)nk};
-#ifdef DLC_EXPERIMENT_NO_SPLIT   // perf experiment build only (scripts/)
-    return best;
-#endif
     if (base >= 256 || nk < 8) return best;
     const double t_k = 1.6, t_fix = 8.0, t_launch = 5.0, bytes_per_us = 3.0e6;
     const double part_bytes = (double)q * (double)ntiles * BM * 4.0;             // one chunk's partial scores
@@ -1581,9 +1578,6 @@ int prepare_match(dlc_ctx* ctx, const char* what, int dtype, const void* Q, int6
 }
 
 int run_score(dlc_ctx* ctx, int dtype, MatchCall& mc, hipStream_t st) {
-#ifdef DLC_EXPERIMENT_ALIAS_ROWS   // perf experiment build only (scripts/): every database row aliases row 0
-    mc.a.lddb_b = 0;
-#endif
     const int slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[slot], st));
     int rc = (dtype == DLC_BF16) ? launch_scores<dlc_bf16_tag>(ctx, mc.a, false, st, mc.w.dense)

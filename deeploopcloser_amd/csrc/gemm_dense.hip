@@ -112,12 +112,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
             if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;      // block padding (before any barrier)
         }
     }
-#ifdef DLC_EXP_GEMM_PRIO      // experiment: static priority for every other workgroup of an XCD's queue (bit DLC_EXP_GEMM_PRIO of its position)
-    if ((blockIdx.x >> (3 + DLC_EXP_GEMM_PRIO)) & 1) __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef DLC_EXP_GEMM_STAGGER   // experiment: delay every other workgroup by about half a K tile
-    if ((blockIdx.x >> (3 + DLC_EXP_GEMM_STAGGER)) & 1) for (int s_ = 0; s_ < 4; ++s_) __builtin_amdgcn_s_sleep(8);
-#endif
     const long long m0 = tile_m * TM, n0 = tile_n * TN;
     if (p.tri_p > 0 && (p.tri_col0 + n0 + TN - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;   // no (row frame < column frame) pair
     const long long kb = (long long)chunk * p.kchunk;               // this workgroup's K range [kb, kend)
@@ -311,7 +305,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
     if (nkt > 1) load_tile(kb + TK);
     __syncthreads();
     long long kt = 0;
-#ifndef DLC_EXP_GEMM_NO_FAST
     if (CONV != 2 && rows_full && cols_full) {
         // iterations whose load (K tile kt+2) is a whole tile inside this workgroup's K range: one basic block each
         const long long n_fast = (kend - kb) / TK - 2;
@@ -343,22 +336,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(Args<T> p) {
             __syncthreads();
         }
     }
-#endif
     for (; kt < nkt; ++kt) {
         const int cur = (int)(kt & 1);
         const T* as = As + cur * A_ELEMS;
         const T* bs = Bs + cur * B_ELEMS;
         compute(as, bs, 0);
         compute(as, bs, 1);
-#ifndef DLC_EXP_GEMM_NO_STAGING     // timing experiments only (wrong results): what the loop costs without its operand traffic
         if (kt + 1 < nkt) store_tile(cur ^ 1);
         if (kt + 2 < nkt) load_tile(kb + (kt + 2) * TK);
-#endif
         compute(as, bs, 2);
         compute(as, bs, 3);
-#ifndef DLC_EXP_GEMM_NO_BARRIER
         __syncthreads();
-#endif
     }
 
     if (p.P) {                                  // split-K: this chunk's raw partial tile
@@ -636,9 +624,6 @@ static size_t elem_size(int dtype) { return dtype == DLC_F64 ? 8 : (dtype == DLC
 // LDS-DMA kernel; for batches large enough for that kernel the input is first copied into zero-padded rows of a
 // multiple of 16 columns (one extra pass over x, ~1 % of the layer's time).
 static int64_t sdav_pad_width(int64_t rows, const int64_t* dims, int dtype) {
-#ifdef DLC_EXP_NO_SDAV_PAD      // experiment build
-    return 0;
-#endif
     if (dtype != DLC_F64 || (dims[0] & 1) == 0 || (dims[1] & 1) || rows * dims[1] < (int64_t)512 * 256 * 128) return 0;
     return (dims[0] + 15) / 16 * 16;
 }

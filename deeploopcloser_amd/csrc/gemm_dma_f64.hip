@@ -97,12 +97,6 @@ typedef __attribute__((address_space(3))) const char* lcptr_t;
 // rate of ds_read_b64 and sees 32 banks): 37 % slower, every read followed by a full wait.
 #define DLC_SLICE_FENCE() do { if constexpr (!CONV) __builtin_amdgcn_sched_barrier(0); } while (0)
 
-#ifdef DLC_EXP_DMA_STAMPS       // diagnostic build only: where a wave's cycles go, summed over its K tiles (s_memtime ticks)
-__device__ unsigned long long dlc_exp_stamps[256][8][4];   // [workgroup < 256][wave][wait for DMA, barrier, tile body, tiles]
-#endif
-#ifdef DLC_EXP_DMA_PLACEMENT    // diagnostic build only: where and when each workgroup of the LAST launch ran
-__device__ unsigned long long dlc_exp_place[8192][4];      // [workgroup id][HW_ID | XCC_ID << 32, start, end (s_memrealtime), did work]
-#endif
 
 // LDS-DMA wave-instructions of one K tile: four 1 KiB pieces of the A stage (dma_a4), two of the B stage (dma_b2).
 // Inline asm so that hipcc does not count them in vmcnt (it would wait for vmcnt(0) in front of every LDS read); M0
@@ -300,17 +294,6 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1;
-#ifdef DLC_EXP_DMA_PLACEMENT
-    if (tid == 0 && blockIdx.x < 8192) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        dlc_exp_place[blockIdx.x][0] = hw | ((unsigned long long)xcc << 32);
-        dlc_exp_place[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
-        dlc_exp_place[blockIdx.x][2] = 0;
-        dlc_exp_place[blockIdx.x][3] = 0;
-    }
-#endif
     // ---- workgroup id -> tile: blocks of br x bc = 32 tiles, one block per XCD at a time (gemm_dense.hip, tile order)
     long long tile_m, tile_n;
     {
@@ -425,11 +408,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
 
     // The A part (4 instructions) and the B part (2) of K tile t's DMA.
     auto issue_a = [&](int t, int stage) {
-#ifdef DLC_EXP_DMA_SAME_TILE       // timing experiments only (wrong results): every DMA re-reads K tile 0 (L2-resident)
-        const int tt = 0;
-#else
         const int tt = t;
-#endif
         const unsigned lds_a = lds_base + stage * STAGE + w * (MI * 1024);
         if constexpr (CONV) {
             // (Keeping the rows' validity as four SGPR lane masks and selecting the offsets with one v_cndmask per row and
@@ -471,11 +450,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         }
     };
     auto issue_b = [&](int t, int stage) {
-#ifdef DLC_EXP_DMA_SAME_TILE
-        const int tt = 0;
-#else
         const int tt = t;
-#endif
         const unsigned lds_b = lds_base + stage * STAGE + A_STAGE + w * 2048;
         const char* base = uniform_ptr(b_base + (long long)tt * b_step);
         if (b_tail && tt == nkt - 1) {
@@ -533,9 +508,6 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     // the 16 MFMAs of a buffer.  A slice's reads are always issued before the MFMAs of the slice in front of it.
     double fa[2][MI], fb[2][NJ];
     auto rd = [&](int kk, int b) {
-#ifdef DLC_EXP_DMA_NO_LDS_READ     // timing experiments only (wrong results): MFMAs on whatever the registers hold
-        if (kk >= 0) { asm volatile("" : "+v"(fa[b][0]), "+v"(fb[b][0])); return; }
-#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i) fa[b][i] = *(const __attribute__((address_space(3))) double*)(fa_addr[kk] + i * 2048);
 #pragma unroll
@@ -552,33 +524,12 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     };
     // wait for this wave's DMA pieces (all that are in flight belong to the tile about to become readable), then the
     // workgroup barrier: behind it that tile is visible to every wave and the stage of the tile two back is free
-#ifdef DLC_EXP_DMA_STAMPS
-    unsigned long long st_wait = 0, st_bar = 0, st_body = 0, st_n = 0, st_last = __builtin_amdgcn_s_memtime();
-#endif
     auto arrive = [&]() {
-#ifdef DLC_EXP_DMA_STAMPS
-        const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-        st_body += s0 - st_last;
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef DLC_EXP_DMA_STAMPS
-        const unsigned long long s1 = __builtin_amdgcn_s_memtime();
-        st_wait += s1 - s0;
-#endif
-#ifndef DLC_EXP_DMA_NO_BARRIER      // timing experiments only (wrong results)
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
-#ifdef DLC_EXP_DMA_STAMPS
-        st_last = __builtin_amdgcn_s_memtime();
-        st_bar += st_last - s1;
-        ++st_n;
-#endif
     };
     auto issue = [&](int t, int stage) {
-#ifdef DLC_EXP_DMA_NO_ISSUE        // timing experiments only (wrong results): only the first tile is ever loaded
-        if (t > 0) return;
-#endif
         issue_a(t, stage);
         issue_b(t, stage);
     };
@@ -635,19 +586,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
         mm(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup's LDS
-#ifdef DLC_EXP_DMA_STAMPS
-    if (blockIdx.x < 256 * 8 && (blockIdx.x & 7) == 0 && lane == 0) {   // the workgroups of XCD 0 among the first ids
-        unsigned long long* o = dlc_exp_stamps[blockIdx.x >> 3][w];
-        o[0] = st_wait; o[1] = st_bar; o[2] = st_body; o[3] = st_n;
-    }
-#endif
 
-#ifdef DLC_EXP_DMA_PLACEMENT
-    if (tid == 0 && blockIdx.x < 8192) {
-        dlc_exp_place[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
-        dlc_exp_place[blockIdx.x][3] = 1;
-    }
-#endif
     // ---- epilogue: bias + activation, C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
     // CONV with mm_keys: the minimum / maximum of every image's outputs is folded into ordered keys on the way out
     // (the CnnVtl descriptor's per-frame range, cnn_vtl.py:110-112: a separate pass over the five layers' outputs read
@@ -729,9 +668,6 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
                            const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
                            const ConvGeom* cv, const TriSkip* tri, int64_t Kb, int64_t m_base, int force_tm, bool dry) {
     if (Kb <= 0 || Kb > K) Kb = K;
-#ifdef DLC_EXP_NO_DMA_GEMM      // experiment build: always the register-staged kernel
-    return 1;
-#endif
     // 16-byte pieces: operand rows must start on 16-byte boundaries and K, N be even (a piece = 2 doubles)
     if (!ctx->zero_page || (K & 1) || (N & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 1)) return 1;
     if (Kb != K && blayout != DLC_B_KN) return 1;          // a shorter B is a [K,N] operand with fewer rows
@@ -751,9 +687,6 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
     // tile height: the caller's choice (launch_dma_f64); triangular launches and the 96-column form keep the large tile
     int tm = (((force_tm == TM3 / 2 && !tri) || force_tm == TM3 / 4) && !narrow) ? force_tm : TM3;
     // (conv1's 96-column form on 64-row tiles, two workgroups per CU: CnnVtl.transform 29.1 against 28.75 ms -- not kept)
-#ifdef DLC_EXP_FORCE_HALF_TILE   // timing experiment: what a 128-row (or, = 4, a 64-row) tile costs when it fills the chip
-    if ((!tri || DLC_EXP_FORCE_HALF_TILE == 4) && !narrow) tm = TM3 / DLC_EXP_FORCE_HALF_TILE;
-#endif
     const int64_t tiles_m = dlc::cdiv(M, (int64_t)tm), tiles_n = dlc::cdiv(N, (int64_t)tn);
     // From 16 tiles on, and with more than 3/4 of a tile's rows real (scripts/exp_dma_threshold.py: below that the
     // register-staged 128 x 128 kernel's twice as many workgroups win; above it this kernel wins at every size once the
@@ -879,19 +812,13 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
                    const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
                    const ConvGeom* cv, const TriSkip* tri, int64_t Kb) {
     int tm = TM3;
-#if !defined(DLC_EXP_NO_HALF_TILE)
     if (!tri && N > 96) {
         constexpr double HALF = 0.51;
         const int64_t tn_ = dlc::cdiv(N, (int64_t)TN3), t4 = dlc::cdiv(M, (int64_t)TM3) * tn_;
         const int64_t t2 = dlc::cdiv(M, (int64_t)(TM3 / 2)) * tn_;
         const double whole4 = (double)dlc::cdiv(t4, (int64_t)256);
         const double whole2 = HALF * (double)dlc::cdiv(t2, (int64_t)256) + 0.01;
-#ifndef DLC_EXP_NO_QUARTER_TILE
         const double quarter = (cv ? 0.27 : 0.248) * (double)dlc::cdiv(dlc::cdiv(M, (int64_t)(TM3 / 4)) * tn_, (int64_t)256) + 0.02;
-#else
-        const double quarter = 1e30;
-#endif
-#if !defined(DLC_EXP_NO_TAIL_SPLIT)
         if (t4 > 256 && t4 % 256 != 0) {
             const int64_t rm = (t4 / 256) * 256 / tn_;                    // row tiles of the main launch
             const int64_t m1 = rm * TM3, m2 = M - m1;
@@ -908,9 +835,7 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
                 }
             }
         }
-#endif
         if (whole2 < whole4 - 0.1) tm = TM3 / 2;
-#ifndef DLC_EXP_NO_QUARTER_TILE
         // 64-row tiles (two workgroups fit a CU) while they leave the chip under one round: the K loop of a workgroup is
         // what a small launch waits for, and a quarter of the MFMAs per K tile shortens it
         // ... and, for plain operands, whenever their round count comes out lower: two 64-row workgroups share a CU
@@ -920,25 +845,11 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
         const int64_t t1 = dlc::cdiv(M, (int64_t)(TM3 / 4)) * tn_;
         const double whole1 = (cv ? 0.27 : 0.248) * (double)dlc::cdiv(t1, (int64_t)256) + 0.02;
         if (whole1 < whole4 - 0.1 && whole1 < whole2 - 0.05) tm = TM3 / 4;
-#endif
     }
-#endif
-#ifndef DLC_EXP_NO_QUARTER_TILE
     // the Gram blocks of the similarity: 64-row tiles for the same reason (similarity of 1063 frames 39.8 -> 39.0 ms)
     if (tri && N > 96 && dlc::cdiv(M, (int64_t)TM3) * dlc::cdiv(N, (int64_t)TN3) > 512) tm = TM3 / 4;
-#endif
     return launch_dma_part(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, tm, false);
 }
 
-#ifdef DLC_EXP_DMA_PLACEMENT
-extern "C" int dlc_exp_read_placement(unsigned long long* host, size_t bytes) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dlc_gemm::dlc_exp_place), bytes < sizeof(dlc_gemm::dlc_exp_place) ? bytes : sizeof(dlc_gemm::dlc_exp_place));
-}
-#endif
-#ifdef DLC_EXP_DMA_STAMPS
-extern "C" int dlc_exp_read_stamps(unsigned long long* host, size_t bytes) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dlc_gemm::dlc_exp_stamps), bytes < sizeof(dlc_gemm::dlc_exp_stamps) ? bytes : sizeof(dlc_gemm::dlc_exp_stamps));
-}
-#endif
 
 }  // namespace dlc_gemm

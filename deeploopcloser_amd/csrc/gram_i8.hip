@@ -142,13 +142,7 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
     int is_t = 0, is_x = 0, is_y = 0, is_wrap = 3 * n64, is_ybase = n64 * 1024;
     auto issue = [&]() {
         const unsigned dst = lds_w + (is_t & (GI_NSTAGE - 1)) * GI_STAGE;
-#ifdef GI_EXP_NO_DMA            // timing experiments only (wrong results): what the loop costs without its operand traffic
-        if (is_t >= GI_NSTAGE) return;
-#endif
         dma2(voff, xb + is_x, xb1 + is_x, dst);
-#ifdef GI_EXP_HALF_DMA          // ... and with half of it
-        if (is_t >= GI_NSTAGE) return;
-#endif
         dma2(voff, yb + is_y, yb1 + is_y, dst + GI_HALF);
         ++is_t; is_x += 1024; is_y += 1024;                                 // k-step blocks of 1 KiB
         if (is_t == is_wrap) {                                              // the next segment: X from its start, Y one slice on
@@ -185,18 +179,7 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
     // s_waitcnt immediates (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
     // builtin, not inline asm, so that hipcc's own wait insertion knows the LDS reads are done
     constexpr int GI_WAIT_VM8 = 0x0078, GI_WAIT_VM4 = 0x0074, GI_WAIT_VM0 = 0x0070;
-#ifdef GI_EXP_STAMPS             // diagnostic build only: where a wave's cycles go (s_memtime ticks), printed for a few workgroups
-    unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_body = 0, st_wait = 0, st_bar = 0, st_mark = 0;
-#define GI_STAMP(K)                                                                                                        \
-    {                                                                                                                      \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                      \
-        if ((K) == 0) { st_body += now_ - st_last; st_mark = now_; }                                                      \
-        if ((K) == 1) { st_wait += now_ - st_mark; st_mark = now_; }                                                      \
-        if ((K) == 2) { st_bar += now_ - st_mark; st_last = now_; }                                                       \
-    }
-#else
 #define GI_STAMP(K)
-#endif
     // (a macro: through a generic lambda hipcc kept the fragment and accumulator arrays in scratch memory; and the steady
     // state has no branch in it -- with the tail's conditions inside, hipcc moved accumulators between register files
     // in every iteration)
@@ -276,11 +259,6 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
 #undef GI_RUN
 #undef GI_BODY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef GI_EXP_STAMPS
-    if (lane == 0 && (blockIdx.x % 1501) == 7)
-        printf("wg %d wave %d: body %llu  wait-dma %llu  barrier %llu  per stage of %d\n", (int)blockIdx.x, w, st_body / nst, st_wait / nst,
-               st_bar / nst, nst);
-#endif
 
     // D[m][n] of MFMA (j, i): m = column patch (wc * 4 + j) * 16 + (lane / 16) * 4 + v, n = row patch (wr * 8 + i) * 16 + lane % 16
 #pragma unroll

@@ -372,13 +372,15 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                                                                 int H, long long i_lo, long long i_hi, long long row_base,
                                                                 double ca, double cb, double* __restrict__ out_f64,
                                                                 long long* __restrict__ out_i64, const int2* __restrict__ prog,
-                                                                const unsigned long long* __restrict__ rowhash) {
+                                                                const unsigned long long* __restrict__ rowhash,
+                                                                unsigned char* __restrict__ direct_map) {
     extern __shared__ double ps_lds_all[];
     // Every wave works on its own: frame i against runs of TWO frames j (its two half-waves take one each, lane a of a
     // half the patch a), staged through a region of LDS that only this wave touches -- no workgroup barrier, so a wave
     // that has to evaluate candidates directly holds up nobody else (with the workgroup staging 8 frames together, one
     // such arg-min stopped four waves at the barrier: binary descriptors 27.9 ms).
-    unsigned long long* n_fallback = keys + 4;              // a count of the direct evaluations (DLC_SIM_DEBUG)
+    unsigned long long* n_fallback = keys + 4;              // a count of the direct evaluations (-> stats[0] of the call)
+    if (keys[2]) return;                                    // a NaN / infinity in the dataset: this form does not apply
     const int prog_len = (int)keys[5];
     const long long i = i_lo + blockIdx.y;
     if (i >= i_hi) return;
@@ -492,13 +494,17 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                 if (lane == b) mine = s_;
                 emin = fmin(emin, s_);
             }
-            unsigned long long close = __ballot(mine <= emin * (1.0 + 1e-11));
+            // (only the candidates take part: the other lanes hold +inf, which would pass the test when every candidate's
+            // squared distance overflows -- finite descriptors ~1e154 apart -- and send stages 1b / 2 to rows past the frame;
+            // with no finite distance at all np.argmin takes the first candidate)
+            unsigned long long close = __ballot(mine <= emin * (1.0 + 1e-11)) & (unsigned long long)cm;
+            if (!(emin < INFINITY)) close = (unsigned long long)cm & (0ull - (unsigned long long)cm);
             int ebi = __ffsll((long long)close) - 1;
             bool same_rows = false;
             if ((close & (close - 1)) && __ballot(frac) == 0) {
                 // (1a) integer differences (binary or integer-valued descriptors): squares and their sums below 2^51 are
                 // exact in any order, NumPy's included, and distinct sums have distinct roots -- the first smallest sum
-                close = __ballot(mine == emin);
+                close = __ballot(mine == emin) & (unsigned long long)cm;
                 ebi = __ffsll((long long)close) - 1;
                 close = 0;
             }
@@ -574,15 +580,15 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                     for (int c = 0; c < nb_; ++c) {
                         const double dc = __shfl(dist, c * 8);
                         const int bc = __shfl(b_mine, c * 8);
-#ifdef DLC_EXP_PF_PRINT
-                        if (lane == 0 && N == 6) printf("i=%lld j=%lld a=%d cm=%x cand b=%d dist=%.17g sum=%.17g proglen=%d\n", i, j_s, a_s, cm, bc, dc, __shfl(stack[0], c * 8) , prog_len);
-#endif
                         if (first || dc < nbest) { nbest = dc; ebi = bc; first = false; }    // np.argmin: first minimum
                     }
                 }
             }
             if (lane == src) bi = ebi;
-            if (lane == 0) ++fallbacks;
+            if (lane == 0) {
+                ++fallbacks;
+                if (direct_map) direct_map[i * N + j_s] = 1;
+            }
         }
         double term = 0.0, wd = 1.0;
         long long rb = 0;
@@ -640,23 +646,33 @@ struct SimWs {
     long long chunk_frames, chunk_frames_i8;
 };
 
+// keys[2] (non-finite flag) and keys[4] (direct evaluations) of a finished call -> the caller's stats; and, for a call
+// that may not read the flag on the host (DLC_SIM_NO_HOST_SYNC), NaN over the matrix when the filter form did not apply.
+__global__ __launch_bounds__(256) void sim_finish_kernel(const unsigned long long* __restrict__ keys, long long* __restrict__ stats,
+                                                         long long nn, double* __restrict__ out_f64,
+                                                         long long* __restrict__ out_i64, int poison) {
+    const bool bad = keys[2] != 0;
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = (long long)keys[4]; stats[1] = bad ? 1 : 0; }
+    if (!poison || !bad) return;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nn; e += (long long)gridDim.x * 256) {
+        out_f64[e] = __longlong_as_double(0x7ff8000000000000ll);
+        if (out_i64) out_i64[e] = (long long)0x8000000000000000ull;
+    }
+}
+
 // The arg-min filter (gram_i8.hip) takes the call when the tiled pair kernel does (P <= 32) and the integer
-// accumulators cannot overflow; DLC_SIM_GRAM=f64 / i8 in the environment forces one form (experiments, tests).
-bool sim_use_filter(int64_t P, int64_t H) {
-    const char* e = getenv("DLC_SIM_GRAM");
-    if (e && !strcmp(e, "f64")) return false;
+// accumulators cannot overflow; DLC_SIM_FORCE_F64 in the call's flags forces the fp64 Gram form.
+bool sim_use_filter(int64_t P, int64_t H, int flags) {
+    if (flags & DLC_SIM_FORCE_F64) return false;
     return P <= 32 && H <= 32768;
 }
 
-long long sim_chunk(int64_t N, int64_t P, size_t row_bytes) {
+long long sim_chunk(int64_t N, int64_t P, size_t row_bytes, int64_t chunk_bytes) {
     // Gram row chunk: at most ~8 GiB of the 288 GB (the work is triangular, so every chunk's launch is smaller than
     // the one before and each pays its own last partial round of the chip: 1063 frames in 9 chunks of <= 1 GiB lost
     // ~5 % to that; 8 GiB holds all of them in one), at least one frame
     size_t cap = 8ull << 30;
-    if (const char* e = getenv("DLC_SIM_CHUNK_BYTES")) {      // tests: several chunks at small sizes
-        const unsigned long long v = strtoull(e, nullptr, 10);
-        if (v >= (1ull << 16)) cap = (size_t)v;
-    }
+    if (chunk_bytes >= (1ll << 16)) cap = (size_t)chunk_bytes;     // the caller's bound (tests: several chunks at small sizes)
     long long cf = (long long)(cap / (row_bytes * (size_t)P));
     if (cf < 1) cf = 1;
     if (cf >= N - 1) {
@@ -670,16 +686,16 @@ long long sim_chunk(int64_t N, int64_t P, size_t row_bytes) {
     return cf;
 }
 
-SimWs sim_ws(int64_t N, int64_t P, int64_t H) {
+SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     SimWs w;
     size_t o = 0;
     w.nrm2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
     w.proj = o; o += dlc::align_up((size_t)N * P * 8, 256);
-    const bool filter = sim_use_filter(P, H);
+    const bool filter = sim_use_filter(P, H, flags);
     const size_t row_bytes = (size_t)N * P * 8;
     const size_t row_bytes_i8 = ((size_t)N * P + 20) * 4;       // int32 accumulators; the block starts at a 16-patch group, its leading dimension is a multiple of 4
-    w.chunk_frames = sim_chunk(N, P, row_bytes);
-    w.chunk_frames_i8 = sim_chunk(N, P, row_bytes_i8);
+    w.chunk_frames = sim_chunk(N, P, row_bytes, chunk_bytes);
+    w.chunk_frames_i8 = sim_chunk(N, P, row_bytes_i8, chunk_bytes);
     const size_t gram_f64 = (size_t)w.chunk_frames * P * row_bytes, gram_i8 = ((size_t)w.chunk_frames_i8 * P + 16) * row_bytes_i8;
     // (the filter's region holds at least one frame's fp64 rows: a dataset with a NaN / infinity in it takes the fp64
     // route after all, in as many chunks as that needs and without the transposed copy)
@@ -723,9 +739,6 @@ extern "C" int dlc_cnnvtl_distance_matrix(dlc_ctx* ctx, const int8_t* desc, int6
     if (z > steps / 4) z = steps / 4;
     if (z < 1) z = 1;
     if (z > 64) z = 64;
-#ifdef DLC_EXP_DIST_Z       // experiment build: fixed number of descriptor chunks
-    z = DLC_EXP_DIST_Z;
-#endif
     const long long kchunk = dlc::cdiv(steps, z) * DCH;
     z = dlc::cdiv(D, kchunk);
     DLC_HIP_CHECK(ctx, hipMemsetAsync(out, 0, (size_t)N * (size_t)N * 8, (hipStream_t)stream));
@@ -740,9 +753,9 @@ extern "C" int dlc_cnnvtl_distance_matrix(dlc_ctx* ctx, const int8_t* desc, int6
     return DLC_OK;
 }
 
-extern "C" size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int64_t H) {
+extern "C" size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     if (N < 1 || P < 1 || H < 1) return 0;
-    return sim_ws(N, P, H).total;
+    return sim_ws(N, P, H, flags, chunk_bytes).total;
 }
 
 extern "C" int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows, int64_t H, double mu,
@@ -760,13 +773,14 @@ extern "C" int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, i
 
 extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H,
                                           const double* score, double a, double b, double* out_f64, int64_t* out_i64,
+                                          int flags, int64_t chunk_bytes, int64_t* stats, uint8_t* direct_pairs,
                                           void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
-    if (!desc || !score || !out_f64 || N < 1 || P < 1 || H < 1)
+    if (!desc || !score || !out_f64 || N < 1 || P < 1 || H < 1 || (flags & ~(DLC_SIM_FORCE_F64 | DLC_SIM_NO_HOST_SYNC)))
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "similarity_matrix: bad argument");
     if (P > 64) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "similarity_matrix: P=%lld patches per frame > 64", (long long)P);
     if (H > 0x7fffffff || N > 65535) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "similarity_matrix: N or H too large");
-    const SimWs w = sim_ws(N, P, H);
+    const SimWs w = sim_ws(N, P, H, flags, chunk_bytes);
     if (!workspace || workspace_bytes < w.total)
         return dlc::fail(ctx, DLC_ERR_WORKSPACE, "similarity_matrix: workspace %zu < %zu bytes", workspace_bytes, w.total);
     dlc::DeviceGuard guard(ctx->device);
@@ -777,7 +791,9 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
     double* proj = (double*)(ws + w.proj);
     double* gram = (double*)(ws + w.gram);
     const long long rows = N * P;
-    bool filter = sim_use_filter(P, H);
+    bool filter = sim_use_filter(P, H, flags);
+    if (!filter && stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
+    if (direct_pairs) DLC_HIP_CHECK(ctx, hipMemsetAsync(direct_pairs, 0, (size_t)N * (size_t)N, st));
 
     hipLaunchKernelGGL(fill_diag_kernel, dim3((unsigned)dlc::cdiv(N, 256)), dim3(256), 0, st, (long long)N, out_f64,
                        (long long*)out_i64);
@@ -792,14 +808,20 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         unsigned long long* rowhash = (unsigned long long*)(ws + w.rowhash);
         int rc = dlc_gemm::sim_filter_prepare(ctx, desc, rows, H, score, keys, qx, qy, nu2, proj, rowhash, prog, st);
         if (rc != DLC_OK) return rc;
-        // the one host read of this call: did the range pass meet a NaN or an infinity?  (Their distances are NaN in the
-        // reference too, np.argmin then takes the first of them: the fp64 kernels reproduce that, a fixed-point
-        // fraction cannot.)
+        // did the range pass meet a NaN or an infinity?  (Their distances are NaN in the reference too, np.argmin then
+        // takes the first of them: the fp64 kernels reproduce that, a fixed-point fraction cannot.)  The ONE host read of
+        // this library's stream-ordered calls -- unless the caller rules it out (DLC_SIM_NO_HOST_SYNC): the filter form's
+        // kernels then leave at once on such data and the matrix comes back as NaN / INT64_MIN with stats[1] = 1.
+        const bool no_sync = (flags & DLC_SIM_NO_HOST_SYNC) != 0;
         unsigned long long bad = 0;
-        DLC_HIP_CHECK(ctx, hipMemcpyAsync(&bad, keys + 2, sizeof(bad), hipMemcpyDeviceToHost, st));
-        DLC_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        if (bad) filter = false;
-        else {
+        if (!no_sync) {
+            DLC_HIP_CHECK(ctx, hipMemcpyAsync(&bad, keys + 2, sizeof(bad), hipMemcpyDeviceToHost, st));
+            DLC_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        }
+        if (bad) {
+            filter = false;
+            if (stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
+        } else {
             const size_t tile_lds = PF_STACK_BYTES + 4 * pf_wave_doubles((int)P) * sizeof(double);
             for (long long i_lo = 0; i_lo + 1 < N; i_lo += w.chunk_frames_i8) {
                 long long i_hi = i_lo + w.chunk_frames_i8;
@@ -814,14 +836,13 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
                 if (rc != DLC_OK) return rc;
                 hipLaunchKernelGGL(pair_score_filter_kernel, dim3(PS_GX, (unsigned)(i_hi - i_lo)), dim3(256), tile_lds, st, desc,
                                    (const int*)gram, ldo, col_base, nu2, proj, score, keys, (long long)N, (int)P, (int)H, i_lo, i_hi,
-                                   row_base, a, b, out_f64, (long long*)out_i64, prog, rowhash);
+                                   row_base, a, b, out_f64, (long long*)out_i64, prog, rowhash, direct_pairs);
                 DLC_LAUNCH_CHECK(ctx, "pair_score_filter_kernel");
             }
-            if (getenv("DLC_SIM_DEBUG")) {       // experiments: how many arg-mins went to the direct evaluation
-                unsigned long long k[5] = {0, 0, 0, 0, 0};
-                DLC_HIP_CHECK(ctx, hipMemcpyAsync(k, keys, sizeof(k), hipMemcpyDeviceToHost, st));
-                DLC_HIP_CHECK(ctx, hipStreamSynchronize(st));
-                fprintf(stderr, "similarity filter: %llu of %lld arg-mins evaluated directly\n", k[4], (long long)N * (N - 1) / 2 * P);
+            if (stats || no_sync) {
+                hipLaunchKernelGGL(sim_finish_kernel, dim3(no_sync ? 256u : 1u), dim3(256), 0, st, keys, (long long*)stats,
+                                   (long long)N * N, out_f64, (long long*)out_i64, no_sync ? 1 : 0);
+                DLC_LAUNCH_CHECK(ctx, "sim_finish_kernel");
             }
             return DLC_OK;
         }
@@ -834,7 +855,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
     }
     long long chunk_frames = w.chunk_frames;
     bool use_t = (rows & 1) == 0;
-    if (sim_use_filter(P, H)) {                  // the filter's workspace: no transposed copy, the chunk that fits its Gram region
+    if (sim_use_filter(P, H, flags)) {           // the filter's workspace: no transposed copy, the chunk that fits its Gram region
         use_t = false;
         chunk_frames = (long long)(w.gram_bytes / ((size_t)P * rows * 8));
     }

@@ -334,15 +334,27 @@ class Engine:
                                                          float(sigma), _ptr(score), self._stream()))
         return score
 
-    def sdav_similarity_matrix(self, desc, score, a=10.0, b=-10.0, want_int64=True):
+    def sdav_similarity_matrix(self, desc, score, a=10.0, b=-10.0, want_int64=True, force_f64=False, no_host_sync=False,
+                               chunk_bytes=0, stats=None, direct_pairs=None):
+        """All-vs-all SDAV similarity of desc [N,P,H] (fp64) -> (out fp64 [N,N], out int64 [N,N] or None).
+        force_f64: the fp64 Gram form instead of the int8 arg-min filter (same matrix); no_host_sync: never read the
+        non-finite flag back (graph-capturable; a dataset with NaN / inf then yields NaN and stats[1] = 1);
+        chunk_bytes: bound of one product block (0 = 8 GiB); stats: int64 [2] device tensor, direct_pairs: uint8 [N,N]
+        device tensor marking the frame pairs with a directly evaluated arg-min (include/dlc.h)."""
         desc = desc.contiguous()
         n, p, h = desc.shape
+        flags = (L.DLC_SIM_FORCE_F64 if force_f64 else 0) | (L.DLC_SIM_NO_HOST_SYNC if no_host_sync else 0)
+        if stats is not None:
+            self._check_out("stats", stats, (2,), torch.int64)
+        if direct_pairs is not None:
+            self._check_out("direct_pairs", direct_pairs, (n, n), torch.uint8)
         out = torch.empty((n, n), dtype=torch.float64, device=self.device)
         out_i = torch.empty((n, n), dtype=torch.int64, device=self.device) if want_int64 else None
-        need = self.lib.dlc_sdav_similarity_workspace_bytes(n, p, h)
+        need = self.lib.dlc_sdav_similarity_workspace_bytes(n, p, h, flags, int(chunk_bytes))
         ws = self.workspace("sim", need)
         self._check(self.lib.dlc_sdav_similarity_matrix(self.ctx, _ptr(desc), n, p, h, _ptr(score), float(a), float(b),
-                                                         _ptr(out), _ptr(out_i), _ptr(ws), ws.numel(), self._stream()))
+                                                         _ptr(out), _ptr(out_i), flags, int(chunk_bytes), _ptr(stats),
+                                                         _ptr(direct_pairs), _ptr(ws), ws.numel(), self._stream()))
         return out, out_i
 
     def cnnvtl_distance_matrix(self, desc):

@@ -16,7 +16,9 @@
  *     callers pass a workspace whose size the *_workspace_bytes() functions
  *     give;
  *   - every call is asynchronous on the caller's hipStream_t (`stream`,
- *     passed as void*; NULL = the null stream) and never synchronises;
+ *     passed as void*; NULL = the null stream) and never synchronises -- with ONE
+ *     exception, stated at dlc_sdav_similarity_matrix (an 8-byte flag read, which
+ *     DLC_SIM_NO_HOST_SYNC rules out) -- and dlc_profile_gemm_ms, which waits by design;
  *   - matrices are row-major with explicit leading dimensions in ELEMENTS;
  *   - return value: DLC_OK (0) or a negative dlc_status; dlc_last_error()
  *     returns a human-readable message for the last failure on that context.
@@ -259,19 +261,33 @@ int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows
  * the descriptors' 21-bit fixed-point values (int8 MFMA, csrc/gram_i8.hip), whose error bound says
  * which candidates it cannot separate; those are evaluated directly in fp64, and where that is
  * still a tie to 1e-11, as np.linalg.norm forms them (NumPy's pairwise summation order).  Other
- * shapes, a dataset with a NaN or an infinity in it, or DLC_SIM_GRAM=f64 in the environment take
- * the fp64 Gram matrix (|a|^2 + |b|^2 - 2 a.b).  The call is stream-ordered except for ONE blocking
- * 8-byte device-to-host read in the filter form (the NaN / infinity flag of the range pass).
+ * shapes, a dataset with a NaN or an infinity in it, or DLC_SIM_FORCE_F64 in `flags` take the fp64
+ * Gram matrix (|a|^2 + |b|^2 - 2 a.b).
+ * flags:
+ *   DLC_SIM_FORCE_F64     the fp64 Gram form whatever the shape (same matrix; checker / experiments);
+ *   DLC_SIM_NO_HOST_SYNC  the filter form reads ONE 8-byte flag back to the host (did the range pass
+ *                         meet a NaN / infinity? -- it then has to take the fp64 form): the only
+ *                         blocking read of this library's stream-ordered calls.  With this flag the
+ *                         call never synchronises (and can be captured in a hipGraph); on a dataset
+ *                         with a NaN / infinity the matrix then comes back as NaN / INT64_MIN and
+ *                         stats[1] = 1, and the caller repeats the call with DLC_SIM_FORCE_F64.
+ * chunk_bytes: upper bound of one patch-product block in the workspace (0 = 8 GiB: all 1063 frames
+ * of the reference's dataset in one launch); pass the same value to the workspace-size function.
+ * stats (DEVICE, 2 int64, may be NULL): [0] arg-mins the integer bound could not decide (evaluated
+ * directly in fp64), [1] 1 when the dataset held a NaN / infinity.  direct_pairs (DEVICE, [N,N]
+ * bytes, may be NULL): 1 at [i, j], i < j, when at least one arg-min of that frame pair was evaluated
+ * directly (the pairs a checker wants to look at first), 0 elsewhere.
  * The workspace holds the quantised descriptors (or their fp64 transpose) and the patch-to-patch
- * product blocks, in row chunks of at most 8 GiB: sized for 288 GB of HBM, it is 4.6 GB at the
- * reference's 1063 frames (one chunk; 8.7 GB in the fp64 form) and stays below 9.5 GB + N*P*H*8
- * bytes for any N.
+ * product blocks: sized for 288 GB of HBM, it is 4.6 GB at the reference's 1063 frames (one chunk;
+ * 8.7 GB in the fp64 form) and stays below 9.5 GB + N*P*H*8 bytes for any N.
  */
-size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int64_t H);
+#define DLC_SIM_FORCE_F64 1
+#define DLC_SIM_NO_HOST_SYNC 2
+size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes);
 int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H,
                                const double* score, double a, double b,
-                               double* out_f64, int64_t* out_i64,
-                               void* workspace, size_t workspace_bytes, void* stream);
+                               double* out_f64, int64_t* out_i64, int flags, int64_t chunk_bytes, int64_t* stats,
+                               uint8_t* direct_pairs, void* workspace, size_t workspace_bytes, void* stream);
 /*
  * All-vs-all cnn_vtl distance: DistanceCalculator.calculate_distance
  * (src/cnn_vtl/similarity/DistanceCalculator.py:4-12) = sum_k popcount(|a_k ^ b_k|)

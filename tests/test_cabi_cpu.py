@@ -52,25 +52,16 @@ def test_host_only_entry_points(lib):
     assert lib.dlc_cosine_topk_workspace_bytes(256, 1000, 4096, _lib.DLC_MAX_K + 1) == 0
     dims = (C.c_int64 * 6)(1681, 2500, 2500, 2500, 2500, 2500)
     assert lib.dlc_sdav_encode_workspace_bytes(300, dims, 5, _lib.DLC_F64) >= 2 * 300 * 2500 * 8
-    assert lib.dlc_sdav_similarity_workspace_bytes(20, 30, 2500) > 0
+    assert lib.dlc_sdav_similarity_workspace_bytes(20, 30, 2500, 0, 0) > 0
     # the similarity's two forms (include/dlc.h): the int8 arg-min filter at the reference's shape -- quantised panels twice,
     # int32 product block, 4.6 GB -- and the fp64 Gram form (transpose + fp64 block, 8.7 GB) for P > 32 or on request
-    old = os.environ.pop("DLC_SIM_GRAM", None)
-    try:
-        w_i8 = lib.dlc_sdav_similarity_workspace_bytes(1063, 30, 2500)
-        os.environ["DLC_SIM_GRAM"] = "f64"
-        w_f64 = lib.dlc_sdav_similarity_workspace_bytes(1063, 30, 2500)
-        assert 4.4e9 < w_i8 < 4.8e9 and 8.5e9 < w_f64 < 9.0e9
-        del os.environ["DLC_SIM_GRAM"]
-        rows = 300 * 40
-        assert lib.dlc_sdav_similarity_workspace_bytes(300, 40, 64) >= rows * rows * 8 // 2      # 40 patches: fp64 form
-        os.environ["DLC_SIM_CHUNK_BYTES"] = str(1 << 20)
-        assert lib.dlc_sdav_similarity_workspace_bytes(1063, 30, 2500) < 1.0e9                     # one frame per chunk
-    finally:
-        os.environ.pop("DLC_SIM_CHUNK_BYTES", None)
-        os.environ.pop("DLC_SIM_GRAM", None)
-        if old is not None:
-            os.environ["DLC_SIM_GRAM"] = old
+    w_i8 = lib.dlc_sdav_similarity_workspace_bytes(1063, 30, 2500, 0, 0)
+    w_f64 = lib.dlc_sdav_similarity_workspace_bytes(1063, 30, 2500, _lib.DLC_SIM_FORCE_F64, 0)
+    assert 4.4e9 < w_i8 < 4.8e9 and 8.5e9 < w_f64 < 9.0e9
+    assert lib.dlc_sdav_similarity_workspace_bytes(1063, 30, 2500, _lib.DLC_SIM_NO_HOST_SYNC, 0) == w_i8
+    rows = 300 * 40
+    assert lib.dlc_sdav_similarity_workspace_bytes(300, 40, 64, 0, 0) >= rows * rows * 8 // 2      # 40 patches: fp64 form
+    assert lib.dlc_sdav_similarity_workspace_bytes(1063, 30, 2500, 0, 1 << 20) < 1.0e9            # one frame per chunk
     assert lib.dlc_last_error(None) == b"null context"
 
 

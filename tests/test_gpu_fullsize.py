@@ -56,7 +56,7 @@ def test_similarity_matrix_kennedylong_properties(dlc, descriptors):
     score = osim.distinctive_score(osim.average_response(dsn))
     np.testing.assert_allclose(calc._score.cpu().numpy(), score, rtol=1e-12)
     rng = np.random.RandomState(0)
-    for _ in range(12):
+    for _ in range(40):
         i, j = sorted(rng.choice(N_FRAMES, 2, replace=False))
         idx = osim.match_features(dsn[i], dsn[j])
         d = osim.weighted_distances(dsn[i], dsn[j], idx, score)
@@ -70,6 +70,104 @@ def test_similarity_matrix_kennedylong_properties(dlc, descriptors):
     for lo, hi in ((0, 500), (300, 1000), (563, N_FRAMES)):
         sub, _ = eng.sdav_similarity_matrix(ds[lo:hi], calc._score, 10.0, -10.0, want_int64=False)
         assert np.array_equal(sub.cpu().numpy(), mf[lo:hi, lo:hi]), (lo, hi)
+
+
+def _oracle_pair(dsn, sc, i, j):
+    from oracle import similarity as osim
+    d = osim.weighted_distances(dsn[i], dsn[j], osim.match_features(dsn[i], dsn[j]), sc)
+    with np.errstate(divide="ignore"):
+        return np.sum(10 - 10 * np.log(d))
+
+
+def _both_routes_and_oracle(eng, ds, n_oracle, seed):
+    """The arg-min filter (int8 MFMA products + direct fp64 evaluations) and the fp64 Gram form of
+    dlc_sdav_similarity_matrix on the same dataset: equal bit for bit; and the oracle (SimilarityCalculator.py:30-49
+    restated) on n_oracle frame pairs -- FIRST the pairs the filter reports as holding a directly evaluated arg-min
+    (direct_pairs), then random ones.  Returns (direct evaluations, pairs that had one, oracle pairs of that kind)."""
+    from oracle import similarity as osim
+    n = ds.shape[0]
+    score = eng.distinctive_score(ds, 0.5, 0.2)
+    stats = torch.zeros((2,), dtype=torch.int64, device=eng.device)
+    dmap = torch.empty((n, n), dtype=torch.uint8, device=eng.device)
+    f_i8, i_i8 = (t.clone() for t in eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, stats=stats, direct_pairs=dmap))
+    f_64, i_64 = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, force_f64=True)
+    assert torch.equal(f_i8.isnan(), f_64.isnan()) and torch.equal(torch.nan_to_num(f_i8), torch.nan_to_num(f_64))
+    assert torch.equal(i_i8, i_64)
+    assert int(stats[1]) == 0
+    mf = f_i8.cpu().numpy()
+    direct = np.argwhere(dmap.cpu().numpy() != 0)
+    assert np.all(direct[:, 0] < direct[:, 1]) if len(direct) else True
+    rng = np.random.RandomState(seed)
+    pairs = [tuple(p) for p in direct[rng.permutation(len(direct))[:n_oracle * 2 // 3]]]
+    n_direct = len(pairs)
+    while len(pairs) < n_oracle:
+        i, j = sorted(rng.choice(n, 2, replace=False))
+        pairs.append((i, j))
+    dsn, sc = ds.cpu().numpy(), score.cpu().numpy()
+    np.testing.assert_allclose(sc, osim.distinctive_score(osim.average_response(dsn)), rtol=1e-12)
+    for i, j in pairs:
+        want = _oracle_pair(dsn, sc, i, j)
+        assert (np.isinf(want) and mf[i, j] == want) or abs(mf[i, j] - want) <= 1e-9 * abs(want), (i, j, mf[i, j], want)
+    return int(stats[0]), len(direct), n_direct
+
+
+@pytest.mark.parametrize("kind", ["encoder", "saturated", "uniform", "twins"])
+def test_similarity_filter_equals_fp64_route_full_size(dlc, descriptors, kind):
+    """configs[1] at the reference's full shape, 1063 x 30 x 2500 (564 453 frame pairs, 508 M arg-mins): the int8 arg-min
+    filter == the fp64 Gram form bit for bit, and == the oracle on 300 pairs led by the ones with a directly evaluated
+    arg-min -- on encoder outputs, sigmoid-saturated values (most entries within 1e-9 of 0 or 1), uniform values, and
+    saturated data with copies of patches inside frames and of whole frames (exact ties: hashes, first index)."""
+    eng = dlc.default_engine()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1000 + len(kind))
+    shape = (N_FRAMES, 30, 2500)
+    if kind == "encoder":
+        ds = descriptors[2].reshape(shape)
+    elif kind == "uniform":
+        ds = torch.rand(shape, generator=g, device="cuda", dtype=torch.float64)
+    else:
+        ds = torch.sigmoid(35.0 * torch.randn(shape, generator=g, device="cuda", dtype=torch.float64))
+        if kind == "twins":
+            ds[:, 1] = ds[:, 0]; ds[:, 7] = ds[:, 6]; ds[::3, 29] = ds[::3, 11]       # copies inside frames
+            ds[100] = ds[5]; ds[1062] = ds[1061]; ds[500, :10] = ds[20, :10]          # copies of frames / half frames
+            ds[300:310, 4] = 0.0; ds[300:310, 5] = 0.0; ds[700, 2] = 1.0              # blank patches
+    direct, pairs, checked = _both_routes_and_oracle(eng, ds, 300, seed=len(kind))
+    print("similarity filter, %s data: %d of %d arg-mins evaluated directly, in %d frame pairs (%d of them among the 300 "
+          "oracle pairs)" % (kind, direct, N_FRAMES * (N_FRAMES - 1) // 2 * 30, pairs, checked))
+
+
+def test_similarity_filter_real_frames_tiled(dlc):
+    """The 20 real frames of datasets/test (tests/golden) tiled to 220 frames: exact copies of whole frames (identical
+    descriptors: +inf scores, every arg-min a tie of bit-identical rows), copies with a few pixels moved by 1/255, and
+    frames with blank and repeated patches -- through the GPU front-end (grey, Harris, patches) and SDAV.transform with the
+    reference's N(0,1) initialiser, where real images saturate the encoder; filter == fp64 form bit for bit, oracle on 300
+    pairs led by the directly evaluated ones."""
+    import config1_common as c1
+    eng = dlc.default_engine()
+    paths = c1.frame_paths()
+    parser = dlc.CvInputParser(30, 41)
+    x = parser.parse_batch(np.stack([dlc.read_ppm(p) for p in paths]))            # [20, 30, 1681] on the device
+    rng = np.random.RandomState(8)
+    tiles = [x]
+    for c in range(10):
+        t = x.clone()
+        if c >= 2:                                                                 # (copies 0 and 1 stay exact duplicates)
+            for f in range(20):
+                for _ in range(1 + c):
+                    t[f, rng.randint(30), rng.randint(1681)] += (1.0 if rng.rand() < 0.5 else -1.0) / 255.0
+            t.clamp_(0.0, 1.0)
+        if c >= 6:
+            t[:, 3] = 0.0; t[:, 4] = 0.0; t[::2, 9] = t[::2, 8]                    # blank patches, a key-point found twice
+        tiles.append(t)
+    xs = torch.cat(tiles)
+    n = xs.shape[0]
+    assert n == 220
+    for scale in ("reference", "fan_in"):
+        net = dlc.SDAV(seed=c1.SEED, weight_scale=scale)
+        ds = net.transform_tensor(xs).reshape(n, 30, 2500)
+        direct, pairs, checked = _both_routes_and_oracle(eng, ds, 300, seed=3)
+        print("similarity filter, %d tiled real frames, %s weights: %d arg-mins evaluated directly in %d frame pairs "
+              "(%d among the oracle pairs)" % (n, scale, direct, pairs, checked))
 
 
 def test_similarity_matrix_two_gram_chunks(dlc):

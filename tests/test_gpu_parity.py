@@ -592,7 +592,6 @@ def test_similarity_near_ties_follow_the_reference(dlc, monkeypatch):
     below what a Gram-matrix distance |a|^2 + |b|^2 - 2 a.b resolves.  The arg-min filter (csrc/gram_i8.hip) sends
     such candidates to a direct evaluation of |b - a|, which orders them as the reference's np.linalg.norm does."""
     from oracle import similarity as osim
-    monkeypatch.delenv("DLC_SIM_GRAM", raising=False)
     rng = np.random.RandomState(17)
     for n, p, h in [(6, 30, 64), (9, 30, 250), (5, 32, 2500), (12, 7, 129)]:
         x = 1.0 / (1.0 + np.exp(-35.0 * rng.standard_normal((n * p, h))))
@@ -611,7 +610,6 @@ def test_similarity_tiny_descriptors_follow_the_reference(dlc, monkeypatch):
     (values 0, 1 and 1 - 1e-12 in every combination), so nearly every arg-min is one the integer products cannot decide
     and many are ties only NumPy's own summation order resolves.  The matrix must still be the reference's."""
     from oracle import similarity as osim
-    monkeypatch.delenv("DLC_SIM_GRAM", raising=False)
     rng = np.random.RandomState(23)
     for n, p, h in [(12, 6, 3), (9, 30, 2), (14, 5, 1), (7, 32, 9), (10, 17, 8)]:
         ds = 1.0 / (1.0 + np.exp(-35.0 * rng.standard_normal((n, p, h))))
@@ -645,11 +643,9 @@ def test_similarity_filter_equals_fp64_gram_route(eng, monkeypatch):
     def both(ds):
         score = eng.distinctive_score(ds, 0.5, 0.2)
         out = []
-        for mode in ("f64", "i8"):
-            monkeypatch.setenv("DLC_SIM_GRAM", mode)
-            mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+        for force in (True, False):                    # DLC_SIM_FORCE_F64: the fp64 Gram form; then the arg-min filter
+            mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, force_f64=force)
             out.append((mf.clone(), mi.clone()))
-        monkeypatch.delenv("DLC_SIM_GRAM")
         return out
 
     for n, p, h in [(2, 1, 8), (3, 7, 64), (6, 30, 8), (20, 30, 250), (40, 32, 2500), (70, 13, 129), (300, 30, 256), (150, 5, 1000)]:
@@ -674,22 +670,31 @@ def test_similarity_filter_equals_fp64_gram_route(eng, monkeypatch):
     (f_ref, i_ref), (f_got, i_got) = both(bad)
     assert torch.equal(i_got, i_ref) and torch.equal(f_got.isnan(), f_ref.isnan())
     assert torch.equal(torch.nan_to_num(f_got), torch.nan_to_num(f_ref))
+    # ... and under DLC_SIM_NO_HOST_SYNC (no flag read on the host, graph-capturable) the call SAYS that it could not:
+    # NaN / INT64_MIN everywhere and stats[1] = 1; on finite data it is the same matrix, stats[0] = the direct evaluations
+    stats = torch.full((2,), -7, dtype=torch.int64, device=eng.device)
+    score = eng.distinctive_score(bad, 0.5, 0.2)
+    f_ns, i_ns = eng.sdav_similarity_matrix(bad, score, 10.0, -10.0, no_host_sync=True, stats=stats)
+    assert bool(f_ns.isnan().all()) and bool((i_ns == torch.iinfo(torch.int64).min).all()) and stats.tolist()[1] == 1
+    good = torch.rand((6, 30, 64), generator=g, device=eng.device, dtype=torch.float64)
+    score = eng.distinctive_score(good, 0.5, 0.2)
+    f_a, i_a = (t.clone() for t in eng.sdav_similarity_matrix(good, score, 10.0, -10.0))
+    f_b, i_b = eng.sdav_similarity_matrix(good, score, 10.0, -10.0, no_host_sync=True, stats=stats)
+    assert torch.equal(f_a, f_b) and torch.equal(i_a, i_b) and stats.tolist()[1] == 0 and stats.tolist()[0] >= 0
 
 
 def test_similarity_filter_in_row_chunks(eng, monkeypatch):
-    """The product block in several row chunks (DLC_SIM_CHUNK_BYTES shrinks the 8 GiB cap): chunk origins that are not
+    """The product block in several row chunks (chunk_bytes shrinks the 8 GiB cap): chunk origins that are not
     multiples of the panels' 16-patch groups, for patch counts that are and are not; the same matrix as in one chunk."""
     g = torch.Generator(device=eng.device); g.manual_seed(11)
     for n, p, h in [(150, 30, 64), (90, 7, 130), (64, 32, 256), (200, 13, 40)]:
         ds = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
         score = eng.distinctive_score(ds, 0.5, 0.2)
-        monkeypatch.delenv("DLC_SIM_CHUNK_BYTES", raising=False)
         f_one, i_one = (t.clone() for t in eng.sdav_similarity_matrix(ds, score, 10.0, -10.0))
         for frames_per_chunk in (1, 3, 17):
-            monkeypatch.setenv("DLC_SIM_CHUNK_BYTES", str(max(1 << 16, frames_per_chunk * p * (n * p + 20) * 4 + 64)))
-            f_c, i_c = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+            cb = max(1 << 16, frames_per_chunk * p * (n * p + 20) * 4 + 64)
+            f_c, i_c = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, chunk_bytes=cb)
             assert torch.equal(f_c, f_one) and torch.equal(i_c, i_one), (n, p, h, frames_per_chunk)
-        monkeypatch.delenv("DLC_SIM_CHUNK_BYTES")
 
 
 def test_similarity_filter_accumulator_extremes(eng, monkeypatch):
@@ -701,11 +706,9 @@ def test_similarity_filter_accumulator_extremes(eng, monkeypatch):
     def both(ds):
         score = eng.distinctive_score(ds, 0.5, 0.2)
         out = []
-        for mode in ("f64", "i8"):
-            monkeypatch.setenv("DLC_SIM_GRAM", mode)
-            mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+        for force in (True, False):                    # DLC_SIM_FORCE_F64: the fp64 Gram form; then the arg-min filter
+            mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, force_f64=force)
             out.append((mf.clone(), mi.clone()))
-        monkeypatch.delenv("DLC_SIM_GRAM")
         return out
 
     h = 32768
