@@ -40,8 +40,9 @@ int gemm_bias_act_padded_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_
 size_t sim_filter_panel_bytes(int64_t rows, int64_t H);
 int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, unsigned long long* keys,
                        char* X, char* Y, double* nu2, double* proj, unsigned long long* rowhash, void* prog, hipStream_t st);
+size_t sim_pairwise_program_bytes(int64_t H);
 int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
-                 hipStream_t st);
+                 unsigned long long* rowhash, void* prog, unsigned long long* prog_len, hipStream_t st);
 int gram_upper_i8(dlc_ctx* ctx, int64_t mrows, int64_t ncols, int64_t H, const char* X, const char* Y, int* out, int64_t ldo,
                   int patches, int64_t row0, int64_t col0, hipStream_t st);
 

@@ -367,10 +367,12 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
         auto put = [&](int e, double v, double sc) {
             n2 = fma(v, v, n2);
             pr = fma(sc, v, pr);
-            if constexpr (QUANT) {
+            if (rowhash) {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(v), pos = (unsigned long long)(k0 + e);
                 h1 += sim_mix64(bits + pos * 0x9e3779b97f4a7c15ull);
                 h2 += sim_mix64((bits ^ 0xd6e8feb86659fd93ull) + pos * 0xc2b2ae3d27d4eb4full);
+            }
+            if constexpr (QUANT) {
                 const double u = sim_unit(v, lo, inv);
                 su += u; s2 = fma(u, u, s2);
                 const int q = sim_fixed(u);
@@ -405,10 +407,8 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
     }
     for (int o = 16; o <= 32; o <<= 1) {
         n2 += __shfl_xor(n2, o); pr += __shfl_xor(pr, o);
-        if constexpr (QUANT) {
-            su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o);
-            h1 += __shfl_xor(h1, o); h2 += __shfl_xor(h2, o);
-        }
+        if constexpr (QUANT) { su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o); }
+        h1 += __shfl_xor(h1, o); h2 += __shfl_xor(h2, o);
     }
     if (chunk == 0) {
         red[w][rr][0] = n2; red[w][rr][1] = pr; red[w][rr][2] = su; red[w][rr][3] = s2;
@@ -424,6 +424,8 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
         if constexpr (QUANT) {
             nu2[r] = t[3];
             atomicMax(&keys[3], dlc_f64_key(t[2]));
+        }
+        if (rowhash) {
             rowhash[2 * r] = redh[0][rr][0] + redh[1][rr][0] + redh[2][rr][0] + redh[3][rr][0];
             rowhash[2 * r + 1] = redh[0][rr][1] + redh[1][rr][1] + redh[2][rr][1] + redh[3][rr][1];
         }
@@ -477,12 +479,17 @@ int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H
     return DLC_OK;
 }
 
-// |x|^2 and dot(score, x) of every patch row (the fp64 Gram form; the filter's prepare computes the same projections)
+// |x|^2, dot(score, x) and the content hash of every patch row (the fp64 Gram form; the filter's prepare computes the same
+// projections and hashes), and NumPy's pairwise-summation program for rows of H elements (prog: sim_pairwise_program_bytes,
+// its length to *prog_len) -- what the pair kernels need to decide the arg-mins the Gram matrix cannot.
+size_t sim_pairwise_program_bytes(int64_t H) { return dlc::align_up((size_t)(H / 32 + 64) * 8, 256); }
+
 int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
-                 hipStream_t st) {
+                 unsigned long long* rowhash, void* prog, unsigned long long* prog_len, hipStream_t st) {
+    hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, prog_len);
     hipLaunchKernelGGL(sim_rows_kernel<false>, dim3((unsigned)dlc::cdiv(rows, (int64_t)16)), dim3(256), 0, st, desc, (long long)rows,
                        (int)H, 0, score, (unsigned long long*)nullptr, (char*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj,
-                       (unsigned long long*)nullptr);
+                       rowhash);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }

@@ -188,6 +188,135 @@ __device__ __forceinline__ double weighted_diff_wave(const double* __restrict__ 
     return s_;
 }
 
+// How close two squared distances |a|^2 + |b|^2 - 2 a.b of the fp64 Gram form may be before their order is not to be
+// trusted: each of the three terms is an fp64 sum of H products, off by at most H 2^-53 times the sum of the products'
+// magnitudes whatever the order (<= |a|^2, |b|^2, |a||b|), so one distance is off by at most ~2 H 2^-53 (|a|^2 + |b|^2) and two
+// of them compare to within twice that (nb: the largest |b|^2 of the frame); 2^-50 relative covers roots that round to
+// one double.  Candidates inside the window are evaluated directly (direct_argmin_wave).
+__device__ __forceinline__ double gram_window(int H, double na, double nb, double best) {
+    return 4.1 * (double)H * 0x1p-53 * (na + nb) + best * 0x1p-49;
+}
+
+// The arg-min of |x_b - x_a| over the candidate patches b of one frame (bit b of cm), decided as the reference decides
+// it (SimilarityCalculator.py:30-37: np.argmin of np.linalg.norm, first minimum) when products of the descriptors -- the
+// filter's integers or the fp64 Gram matrix -- cannot tell the candidates apart.  Called by a whole wave (uniform
+// arguments); every lane returns the index.  stacks: 8 * PF_STACK_DEPTH doubles of LDS owned by this wave.
+constexpr int PF_STACK_DEPTH = 16;                           // value stack of the pairwise-summation program (H <= 4 M: 16 levels)
+constexpr int PF_STACK_BYTES = 4 * 8 * PF_STACK_DEPTH * 8;  // one per 8-lane group of each of a workgroup's 4 waves
+__device__ __forceinline__ int direct_argmin_wave(const double* __restrict__ xa, const double* __restrict__ xj,
+                                                  unsigned long long cm, int P, int H, int lane,
+                                                  const int2* __restrict__ prog, int prog_len, double* stacks) {
+    // (1) all 64 lanes on each candidate's 2 H doubles: squared distances to ~5e-15 (relative); lane b keeps
+    // candidate b's
+    double mine = INFINITY, emin = INFINITY;
+    bool frac = false;                                  // some difference is not an integer below 2^18
+    for (int b = 0; b < P; ++b) {
+        if (!((cm >> b) & 1)) continue;
+        const double* xb = xj + (long long)b * H;
+        double s_ = 0.0;
+#pragma unroll 8
+        for (int k = lane; k < H; k += 64) {
+            const double d = xb[k] - xa[k];
+            s_ = fma(d, d, s_);
+            frac |= !(d == rint(d) && fabs(d) < 262144.0);
+        }
+        for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
+        if (lane == b) mine = s_;
+        emin = fmin(emin, s_);
+    }
+    // (only the candidates take part: the other lanes hold +inf, which would pass the test when every candidate's
+    // squared distance overflows -- finite descriptors ~1e154 apart -- and send stages 1b / 2 to rows past the frame;
+    // with no finite distance at all np.argmin takes the first candidate)
+    unsigned long long close = __ballot(mine <= emin * (1.0 + 1e-11)) & cm;
+    if (!(emin < INFINITY)) close = cm & (0ull - cm);
+    int ebi = __ffsll((long long)close) - 1;
+    bool same_rows = false;
+    if ((close & (close - 1)) && __ballot(frac) == 0) {
+        // (1a) integer differences (binary or integer-valued descriptors): squares and their sums below 2^51 are
+        // exact in any order, NumPy's included, and distinct sums have distinct roots -- the first smallest sum
+        close = __ballot(mine == emin) & cm;
+        ebi = __ffsll((long long)close) - 1;
+        close = 0;
+    }
+    if (close & (close - 1)) {
+        // (1b) the commonest tie: the close candidates are the SAME patch (a key-point found twice, a blank patch
+        // repeated) -- bit-identical rows have identical norms however they are summed, the first one wins
+        const double* x0 = xj + (long long)ebi * H;
+        bool differ = false;
+        for (unsigned long long m = close & (close - 1); m && !differ; m &= m - 1) {
+            const double* xb = xj + (long long)(__ffsll((long long)m) - 1) * H;
+            bool d_ = false;
+#pragma unroll 8
+            for (int k = lane; k < H; k += 64) d_ |= __double_as_longlong(xb[k]) != __double_as_longlong(x0[k]);
+            differ = __ballot(d_) != 0;
+        }
+        same_rows = !differ;
+    }
+    if ((close & (close - 1)) && !same_rows) {
+        // (2) still closer than either summation resolves: the candidates' norms exactly as NumPy forms them
+        // (np.linalg.norm: sqrt(np.add.reduce((x - m) ** 2)) with pairwise summation), eight candidates at a
+        // time -- 8 lanes per candidate, one per strided accumulator of a leaf
+        const int grp = lane >> 3, q = lane & 7;
+        double* stack = stacks + grp * PF_STACK_DEPTH;                    // (this wave's eight)
+        double nbest = 0.0;
+        bool first = true;
+        while (close) {
+            int b_mine = -1, b_first = __ffsll((long long)close) - 1, nb_ = 0;
+            for (int c = 0; c < 8 && close; ++c) {
+                const int b = __ffsll((long long)close) - 1;
+                close &= close - 1;
+                if (grp == c) b_mine = b;
+                ++nb_;
+            }
+            const double* xb = xj + (long long)(b_mine >= 0 ? b_mine : b_first) * H;
+            // (HIP's __dmul_rn / __dadd_rn are plain * and + that hipcc contracts into fma: the pragma is what
+            // keeps every product and every sum rounded on its own, as NumPy's are)
+            auto sq = [&](int k) {
+#pragma clang fp contract(off)
+                const double d = xb[k] - xa[k];
+                const double d2 = d * d;
+                return d2;
+            };
+            int sp = 0;
+            for (int e = 0; e < prog_len; ++e) {
+#pragma clang fp contract(off)
+                const int2 op = prog[e];
+                if (op.x < 0) {
+                    const double rhs = stack[sp - 1], lhs = stack[sp - 2];
+                    sp -= 2;
+                    const double r = __dadd_rn(lhs, rhs);
+                    if (q == 0) stack[sp] = r;
+                    ++sp;
+                    continue;
+                }
+                double r;
+                if (op.y < 8) {
+                    r = 0.0;
+                    for (int t = 0; t < op.y; ++t) r = __dadd_rn(r, sq(op.x + t));
+                } else {
+                    const int m = op.y - (op.y & 7);
+                    r = sq(op.x + q);
+#pragma unroll 4
+                    for (int t = 8; t < m; t += 8) r = __dadd_rn(r, sq(op.x + t + q));
+                    r = __dadd_rn(r, __shfl_xor(r, 1));
+                    r = __dadd_rn(r, __shfl_xor(r, 2));
+                    r = __dadd_rn(r, __shfl_xor(r, 4));
+                    for (int t = m; t < op.y; ++t) r = __dadd_rn(r, sq(op.x + t));
+                }
+                if (q == 0) stack[sp] = r;
+                ++sp;
+            }
+            const double dist = sqrt(0.0 + stack[0]);
+            for (int c = 0; c < nb_; ++c) {
+                const double dc = __shfl(dist, c * 8);
+                const int bc = __shfl(b_mine, c * 8);
+                if (first || dc < nbest) { nbest = dc; ebi = bc; first = false; }    // np.argmin: first minimum
+            }
+        }
+    }
+    return ebi;
+}
+
 // One wave per frame pair (i, j), i in [i_lo, i_hi), j in (i, N).  G is the Gram
 // block  desc[i_lo*P .. i_hi*P) . desc[col0 ..)^T  with leading dimension ldg.
 __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restrict__ desc, const double* __restrict__ G,
@@ -195,26 +324,52 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
                                                          const double* __restrict__ proj,
                                                          const double* __restrict__ score, long long N, int P, int H,
                                                          long long i_lo, long long i_hi, double ca, double cb,
-                                                         double* __restrict__ out_f64, long long* __restrict__ out_i64) {
-    const int lane = threadIdx.x & 63;
-    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                         double* __restrict__ out_f64, long long* __restrict__ out_i64,
+                                                         const int2* __restrict__ prog, const unsigned long long* __restrict__ prog_len,
+                                                         const unsigned long long* __restrict__ rowhash) {
+    __shared__ double stacks[4][8 * PF_STACK_DEPTH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long j = (long long)blockIdx.x * 4 + w;
     const long long i = i_lo + blockIdx.y;
     if (i >= i_hi || j >= N || j <= i) return;
     double term = 0.0, wd = 1.0;
     long long rb = 0;
     bool redo = false;
+    int bi = 0;
+    unsigned long long cand = 0;
+    const long long ra = i * P + (lane < P ? lane : 0);
     if (lane < P) {
-        const long long ra = i * P + lane;
         const double* grow = G + (ra - i_lo * P) * ldg + (j * P - col0);
         const double na = nrm2[ra];
-        double best = 0.0;
-        int bi = 0;
+        double best = INFINITY, nbmax = 0.0;
         for (int b = 0; b < P; ++b) {
-            double d2 = na + nrm2[j * P + b] - 2.0 * grow[b];
-            d2 = d2 > 0.0 ? d2 : 0.0;
-            const double dist = sqrt(d2);                       // np.linalg.norm, :34
-            if (b == 0 || dist < best) { best = dist; bi = b; } // np.argmin: first minimum
+            const double nbb = nrm2[j * P + b];
+            const double d2 = fmax(na + nbb - 2.0 * grow[b], 0.0);
+            nbmax = fmax(nbmax, nbb);
+            if (d2 < best) { best = d2; bi = b; }               // strict: the first minimum keeps its index
         }
+        // what the Gram form resolves: each of |a|^2, |b|^2, a.b is an fp64 sum of H products
+        const double win = gram_window(H, na, nbmax, best);
+        for (int b = 0; b < P; ++b) {
+            const double d2 = fmax(na + nrm2[j * P + b] - 2.0 * grow[b], 0.0);
+            if (!(d2 - best <= win)) continue;
+            bool copy = false;                                  // a copy of an earlier candidate: np.argmin never takes it
+            for (unsigned long long m = cand; m; m &= m - 1) {
+                const long long e = j * P + (__ffsll((long long)m) - 1);
+                copy |= rowhash[2 * e] == rowhash[2 * (j * P + b)] && rowhash[2 * e + 1] == rowhash[2 * (j * P + b) + 1];
+            }
+            if (!copy) cand |= 1ull << b;
+        }
+        if (!(cand & (cand - 1))) { bi = cand ? __ffsll((long long)cand) - 1 : bi; cand = 0; }
+    }
+    for (unsigned long long todo = __ballot(cand != 0); todo; todo &= todo - 1) {
+        const int src = __ffsll((long long)todo) - 1;
+        const unsigned long long cm = ((unsigned long long)(unsigned)__shfl((int)(cand >> 32), src) << 32) |
+                                      (unsigned long long)(unsigned)__shfl((int)cand, src);
+        const int ebi = direct_argmin_wave(desc + (i * P + src) * H, desc + j * P * H, cm, P, H, lane, prog, (int)*prog_len, stacks[w]);
+        if (lane == src) bi = ebi;
+    }
+    if (lane < P) {
         rb = j * P + bi;
         wd = fabs(proj[ra] - proj[rb]);                         // |dot(score, m_i - m_j*)|, :42-43
         redo = wd < 1e-6 * (fabs(proj[ra]) + fabs(proj[rb]));   // cancellation: evaluate the difference directly
@@ -245,15 +400,17 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
 // minimum and every rounding are the same -- and the 32-lane xor tree sums the P terms of a pair.
 constexpr int PS_JT = 8;
 constexpr int PS_GX = 8;        // workgroups per frame i: each walks every PS_GX-th run of PS_JT frames
-constexpr int PF_STACK_DEPTH = 16;                           // value stack of the pairwise-summation program (H <= 32768: 9 levels)
-constexpr int PF_STACK_BYTES = 4 * 8 * PF_STACK_DEPTH * 8;  // one per 8-lane group of each wave
 __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __restrict__ desc, const double* __restrict__ G,
                                                               long long ldg, long long col0, const double* __restrict__ nrm2,
                                                               const double* __restrict__ proj,
                                                               const double* __restrict__ score, long long N, int P, int H,
                                                               long long i_lo, long long i_hi, double ca, double cb,
-                                                              double* __restrict__ out_f64, long long* __restrict__ out_i64) {
-    extern __shared__ double ps_lds[];
+                                                              double* __restrict__ out_f64, long long* __restrict__ out_i64,
+                                                              const int2* __restrict__ prog,
+                                                              const unsigned long long* __restrict__ prog_len,
+                                                              const unsigned long long* __restrict__ rowhash) {
+    extern __shared__ double ps_lds_raw[];
+    double* ps_lds = ps_lds_raw + PF_STACK_BYTES / 8;            // in front: the summation program's value stacks, 8 per wave
     const long long i = i_lo + blockIdx.y;
     if (i >= i_hi) return;
     const int tid = threadIdx.x;
@@ -300,17 +457,20 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
         long long rb = 0;
         bool redo = false;
         const bool pair_ok = j > i && j < N;
+        int bi = 0;
+        unsigned cand = 0;
         if (pair_ok && a < P) {
             const double* grow = g + a * row + jj * P;
             const double* nbj = nb + jj * P;
             // np.argmin(np.linalg.norm(..)) (:34-35) without 30 square roots: sqrt is monotone, so the first minimum of
             // the distances is the first minimum of the SQUARED distances unless another patch's square lies so close
-            // above the smallest that the two roots round to one double.  One pass keeps the two smallest squares; only
-            // when the second is within 2^-50 (relative) of the first are the roots taken and compared as the reference does.
-            double best = 0.0, second = INFINITY;
-            int bi = 0;
+            // above the smallest that the Gram form cannot order them (gram_window).  One pass keeps the two smallest
+            // squares; only when the second is inside the window are the candidates collected -- copies of an earlier
+            // candidate dropped by their content hashes -- and handed to the direct evaluation.
+            double best = 0.0, second = INFINITY, nbmax = 0.0;
             auto scan = [&](int b) {                            // min / max instructions instead of compare-select chains
                 const double d2 = fmax(na + nbj[b] - 2.0 * grow[b], 0.0);
+                nbmax = fmax(nbmax, nbj[b]);
                 if (b == 0) { best = d2; bi = 0; return; }
                 second = fmin(second, fmax(best, d2));          // the smaller of the two that are not the new minimum
                 bi = d2 < best ? b : bi;                        // strict: the first minimum keeps its index
@@ -323,14 +483,30 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
 #pragma unroll 4
                 for (int b = 0; b < P; ++b) scan(b);
             }
-            if (second <= best * (1.0 + 0x1p-50)) {             // (best = 0: second = 0 too -- equal roots, first index wins)
+            const double win = gram_window(H, na, nbmax, best);
+            if (second - best <= win) {
+                const unsigned long long* hbj = rowhash + 2 * (j * P);
                 for (int b = 0; b < P; ++b) {
-                    double d2 = na + nbj[b] - 2.0 * grow[b];
-                    d2 = d2 > 0.0 ? d2 : 0.0;
-                    const double dist = sqrt(d2);               // np.linalg.norm, :34
-                    if (b == 0 || dist < best) { best = dist; bi = b; }     // np.argmin: first minimum
+                    if (!(fmax(na + nbj[b] - 2.0 * grow[b], 0.0) - best <= win)) continue;
+                    bool copy = false;
+                    for (unsigned m = cand; m; m &= m - 1) {
+                        const int e = __ffs((int)m) - 1;
+                        copy |= hbj[2 * e] == hbj[2 * b] && hbj[2 * e + 1] == hbj[2 * b + 1];
+                    }
+                    if (!copy) cand |= 1u << b;
                 }
+                if (!(cand & (cand - 1))) { bi = __ffs((int)cand) - 1; cand = 0; }       // one patch left: decided
             }
+        }
+        for (unsigned long long todo = __ballot(cand != 0); todo; todo &= todo - 1) {    // this wave's undecided arg-mins
+            const int src = __ffsll((long long)todo) - 1;
+            const unsigned cm = (unsigned)__shfl((int)cand, src);
+            const long long j_s = j0 + w * 2 + (src >> 5);
+            const int ebi = direct_argmin_wave(desc + (i * P + (src & 31)) * H, desc + j_s * P * H, (unsigned long long)cm, P, H, lane,
+                                               prog, (int)*prog_len, ps_lds_raw + (size_t)w * 8 * PF_STACK_DEPTH);
+            if (lane == src) bi = ebi;
+        }
+        if (pair_ok && a < P) {
             rb = j * P + bi;
             const double pb = proj[rb];
             wd = fabs(pa - pb);                                 // |dot(score, m_i - m_j*)|, :42-43
@@ -474,116 +650,8 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
             const unsigned cm = (unsigned)__shfl((int)cand, src);
             const int a_s = src & 31;
             const long long j_s = j0 + (src >> 5);
-            const double* xa = desc + (i * P + a_s) * H;
-            const double* xj = desc + j_s * P * H;
-            // (1) all 64 lanes on each candidate's 2 H doubles: squared distances to ~5e-15 (relative); lane b keeps
-            // candidate b's
-            double mine = INFINITY, emin = INFINITY;
-            bool frac = false;                                  // some difference is not an integer below 2^18
-            for (int b = 0; b < P; ++b) {
-                if (!((cm >> b) & 1)) continue;
-                const double* xb = xj + (long long)b * H;
-                double s_ = 0.0;
-#pragma unroll 8
-                for (int k = lane; k < H; k += 64) {
-                    const double d = xb[k] - xa[k];
-                    s_ = fma(d, d, s_);
-                    frac |= !(d == rint(d) && fabs(d) < 262144.0);
-                }
-                for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
-                if (lane == b) mine = s_;
-                emin = fmin(emin, s_);
-            }
-            // (only the candidates take part: the other lanes hold +inf, which would pass the test when every candidate's
-            // squared distance overflows -- finite descriptors ~1e154 apart -- and send stages 1b / 2 to rows past the frame;
-            // with no finite distance at all np.argmin takes the first candidate)
-            unsigned long long close = __ballot(mine <= emin * (1.0 + 1e-11)) & (unsigned long long)cm;
-            if (!(emin < INFINITY)) close = (unsigned long long)cm & (0ull - (unsigned long long)cm);
-            int ebi = __ffsll((long long)close) - 1;
-            bool same_rows = false;
-            if ((close & (close - 1)) && __ballot(frac) == 0) {
-                // (1a) integer differences (binary or integer-valued descriptors): squares and their sums below 2^51 are
-                // exact in any order, NumPy's included, and distinct sums have distinct roots -- the first smallest sum
-                close = __ballot(mine == emin) & (unsigned long long)cm;
-                ebi = __ffsll((long long)close) - 1;
-                close = 0;
-            }
-            if (close & (close - 1)) {
-                // (1b) the commonest tie: the close candidates are the SAME patch (a key-point found twice, a blank patch
-                // repeated) -- bit-identical rows have identical norms however they are summed, the first one wins
-                const double* x0 = xj + (long long)ebi * H;
-                bool differ = false;
-                for (unsigned long long m = close & (close - 1); m && !differ; m &= m - 1) {
-                    const double* xb = xj + (long long)(__ffsll((long long)m) - 1) * H;
-                    bool d_ = false;
-#pragma unroll 8
-                    for (int k = lane; k < H; k += 64) d_ |= __double_as_longlong(xb[k]) != __double_as_longlong(x0[k]);
-                    differ = __ballot(d_) != 0;
-                }
-                same_rows = !differ;
-            }
-            if ((close & (close - 1)) && !same_rows) {
-                // (2) still closer than either summation resolves: the candidates' norms exactly as NumPy forms them
-                // (np.linalg.norm: sqrt(np.add.reduce((x - m) ** 2)) with pairwise summation), eight candidates at a
-                // time -- 8 lanes per candidate, one per strided accumulator of a leaf
-                const int grp = lane >> 3, q = lane & 7;
-                double* stack = ps_lds_all + (w * 8 + grp) * PF_STACK_DEPTH;      // (this wave's eight)
-                double nbest = 0.0;
-                bool first = true;
-                while (close) {
-                    int b_mine = -1, b_first = __ffsll((long long)close) - 1, nb_ = 0;
-                    for (int c = 0; c < 8 && close; ++c) {
-                        const int b = __ffsll((long long)close) - 1;
-                        close &= close - 1;
-                        if (grp == c) b_mine = b;
-                        ++nb_;
-                    }
-                    const double* xb = xj + (long long)(b_mine >= 0 ? b_mine : b_first) * H;
-                    // (HIP's __dmul_rn / __dadd_rn are plain * and + that hipcc contracts into fma: the pragma is what
-                    // keeps every product and every sum rounded on its own, as NumPy's are)
-                    auto sq = [&](int k) {
-#pragma clang fp contract(off)
-                        const double d = xb[k] - xa[k];
-                        const double d2 = d * d;
-                        return d2;
-                    };
-                    int sp = 0;
-                    for (int e = 0; e < prog_len; ++e) {
-#pragma clang fp contract(off)
-                        const int2 op = prog[e];
-                        if (op.x < 0) {
-                            const double rhs = stack[sp - 1], lhs = stack[sp - 2];
-                            sp -= 2;
-                            const double r = __dadd_rn(lhs, rhs);
-                            if (q == 0) stack[sp] = r;
-                            ++sp;
-                            continue;
-                        }
-                        double r;
-                        if (op.y < 8) {
-                            r = 0.0;
-                            for (int t = 0; t < op.y; ++t) r = __dadd_rn(r, sq(op.x + t));
-                        } else {
-                            const int m = op.y - (op.y & 7);
-                            r = sq(op.x + q);
-#pragma unroll 4
-                            for (int t = 8; t < m; t += 8) r = __dadd_rn(r, sq(op.x + t + q));
-                            r = __dadd_rn(r, __shfl_xor(r, 1));
-                            r = __dadd_rn(r, __shfl_xor(r, 2));
-                            r = __dadd_rn(r, __shfl_xor(r, 4));
-                            for (int t = m; t < op.y; ++t) r = __dadd_rn(r, sq(op.x + t));
-                        }
-                        if (q == 0) stack[sp] = r;
-                        ++sp;
-                    }
-                    const double dist = sqrt(0.0 + stack[0]);
-                    for (int c = 0; c < nb_; ++c) {
-                        const double dc = __shfl(dist, c * 8);
-                        const int bc = __shfl(b_mine, c * 8);
-                        if (first || dc < nbest) { nbest = dc; ebi = bc; first = false; }    // np.argmin: first minimum
-                    }
-                }
-            }
+            const int ebi = direct_argmin_wave(desc + (i * P + a_s) * H, desc + j_s * P * H, (unsigned long long)cm, P, H, lane,
+                                               prog, prog_len, ps_lds_all + (size_t)w * 8 * PF_STACK_DEPTH);
             if (lane == src) bi = ebi;
             if (lane == 0) {
                 ++fallbacks;
@@ -701,21 +769,25 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     // route after all, in as many chunks as that needs and without the transposed copy)
     w.gram_bytes = filter ? (gram_i8 > (size_t)P * row_bytes ? gram_i8 : (size_t)P * row_bytes) : gram_f64;
     w.gram = o; o += dlc::align_up(w.gram_bytes, 256);
+    // both forms: the range / flag / program-length words, NumPy's pairwise-summation program for rows of H elements and
+    // the rows' content hashes (the direct evaluation of arg-mins that products of the descriptors cannot decide)
+    w.keys = o; o += 256;
+    const size_t prog_bytes = dlc_gemm::sim_pairwise_program_bytes(H);
+    w.prog = o; o += prog_bytes > 8192 ? prog_bytes : 8192;
+    w.rowhash = o; o += dlc::align_up((size_t)N * P * 16, 256);
     // the descriptors transposed [H, N*P] (one extra pass over them): the fp64 Gram blocks then read their B operand as
     // [K,N] -- 1 KiB contiguous per k-row and tile instead of 128 scattered 128-byte row segments (an even N*P keeps
     // the rows 16-byte aligned for the LDS-DMA kernel; an odd one falls back to the [N,K] form)
-    w.desc_t = o;
-    w.keys = w.prog = w.nu2 = w.rowhash = w.qx = w.qy = 0;
+    w.nu2 = w.qx = w.qy = 0;
     if (filter) {
         const size_t panel = dlc_gemm::sim_filter_panel_bytes(N * P, H);
-        w.keys = o; o += 256;
-        w.prog = o; o += 8192;
         w.nu2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
-        w.rowhash = o; o += dlc::align_up((size_t)N * P * 16, 256);
         w.qx = o; o += dlc::align_up(panel, 256);
         w.qy = o; o += dlc::align_up(panel, 256);
-    } else if (((N * P) & 1) == 0) {
-        o += dlc::align_up((size_t)N * P * H * 8, 256);
+        w.desc_t = o;
+    } else {
+        w.desc_t = o;
+        if (((N * P) & 1) == 0) o += dlc::align_up((size_t)N * P * H * 8, 256);
     }
     w.total = o;
     return w;
@@ -850,7 +922,8 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
 
     // the fp64 Gram route
     {
-        const int rc = dlc_gemm::sim_row_sums(ctx, desc, rows, H, score, nrm2, proj, st);
+        const int rc = dlc_gemm::sim_row_sums(ctx, desc, rows, H, score, nrm2, proj, (unsigned long long*)(ws + w.rowhash),
+                                              ws + w.prog, (unsigned long long*)(ws + w.keys) + 5, st);
         if (rc != DLC_OK) return rc;
     }
     long long chunk_frames = w.chunk_frames;
@@ -880,19 +953,22 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
                                                   ncols, (int)P, i_lo * P, col0, st);
         if (rc != DLC_OK) return rc;
         dim3 grid((unsigned)dlc::cdiv(N, 4), (unsigned)(i_hi - i_lo));
-        const size_t tile_lds = ((size_t)P * ((PS_JT * P) | 1) + (size_t)PS_JT * P) * sizeof(double);
+        const size_t tile_lds = PF_STACK_BYTES + ((size_t)P * ((PS_JT * P) | 1) + (size_t)PS_JT * P) * sizeof(double);
         const bool tiled = P <= 32;
         if (tiled) {
             if (tile_lds > 48 * 1024 && !(ctx->func_attr_set & (1ull << DLC_ATTR_PAIR_TILE))) {
-                DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)pair_score_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+                DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)pair_score_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024));
                 ctx->func_attr_set |= 1ull << DLC_ATTR_PAIR_TILE;
             }
             hipLaunchKernelGGL(pair_score_tile_kernel, dim3(PS_GX, (unsigned)(i_hi - i_lo)), dim3(256), tile_lds,
                                st, desc, gram, ncols, col0, nrm2, proj, score, (long long)N, (int)P, (int)H, i_lo, i_hi, a, b,
-                               out_f64, (long long*)out_i64);
+                               out_f64, (long long*)out_i64, (const int2*)(ws + w.prog),
+                               (const unsigned long long*)(ws + w.keys) + 5, (const unsigned long long*)(ws + w.rowhash));
         } else
             hipLaunchKernelGGL(pair_score_kernel, grid, dim3(256), 0, st, desc, gram, ncols, col0, nrm2, proj, score,
-                               (long long)N, (int)P, (int)H, i_lo, i_hi, a, b, out_f64, (long long*)out_i64);
+                               (long long)N, (int)P, (int)H, i_lo, i_hi, a, b, out_f64, (long long*)out_i64,
+                               (const int2*)(ws + w.prog), (const unsigned long long*)(ws + w.keys) + 5,
+                               (const unsigned long long*)(ws + w.rowhash));
         DLC_LAUNCH_CHECK(ctx, "pair_score_kernel");
     }
     return DLC_OK;
