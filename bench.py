@@ -195,6 +195,19 @@ def _timed_path(eng, fn, reps=3):
     return best
 
 
+def _timed_host(fn, reps=3):
+    """Wall-clock ms (host to host: the call returns NumPy data) of the fastest of `reps` calls after one warm-up."""
+    fn()
+    best, r = None, None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None or dt < best else best
+    return best, r
+
+
 def _mfma_f64_roofline(flops, kernel_ms, launches, call_ms, kernel):
     tf = flops / (kernel_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -226,8 +239,14 @@ def bench_paths(eng, n_frames):
     ref = osdav.transform(xs, ws, bs)
     t_cpu = time.perf_counter() - t0
     err = float(np.abs(h[:nb * P].cpu().numpy() - ref).max())
+    # the reference's own contract: ndarray in, ndarray out (pageable host arrays both ways: 429 MB in, 638 MB out)
+    x_np = x.cpu().numpy()
+    h2h_ms, h_np = _timed_host(lambda: net.transform(x_np))
+    h2h_same = bool(np.array_equal(h_np, h.cpu().numpy()))
+    del x_np, h_np
     out.append({"path": "SDAV.transform", "reference": "src/sdav/network/SDAV.py:293-302", "frames": N, "dtype": "f64",
                 "value": N / (call_ms * 1e-3), "unit": "frames/s", "ms": call_ms,
+                "host_to_host_ms": h2h_ms, "host_to_host_bit_identical": h2h_same,
                 "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_dma_f64_kernel (5 layers, LDS-DMA fp64 GEMM, fused bias + sigmoid)"),
                 "cpu_baseline": {"value": nb / t_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/sdav.py (fp64 NumPy) on the first %d of the %d frames, same weights: "
@@ -373,6 +392,14 @@ def bench_paths(eng, n_frames):
     for _ in range(8):
         osim.similarity_score(dsn, dsn[0], dsn[1])
     t_lit = (time.perf_counter() - t0) / 8
+    calc = dlc.SimilarityCalculator(dsn)                       # the drop-in class, called once per pair as the reference's loop does
+    calc.similarity_score(dsn[0], dsn[1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e_ in range(50):
+        calc.similarity_score(dsn[e_ % ns], dsn[(e_ + 1) % ns])
+    t_drop = (time.perf_counter() - t0) / 50
+    del calc
     sub = eng.sdav_similarity_matrix(desc[:ns].contiguous(), eng.distinctive_score(desc[:ns].contiguous(), 0.5, 0.2), 10.0, -10.0)[0]
     fin = np.isfinite(ref)
     err = float(np.abs(sub.cpu().numpy()[fin] - ref[fin]).max() / max(1.0, np.abs(ref[fin]).max()))
@@ -391,7 +418,8 @@ def bench_paths(eng, n_frames):
                                            "distinctive score hoisted): %.2f s; the literal similarity_score (mean recomputed "
                                            "per pair, SimilarityCalculator.py:13-14) takes %.1f ms per pair at N=%d"
                                            % (ns, ns * (ns - 1) // 2, t_cpu, t_lit * 1e3, ns),
-                                 "literal_ms_per_pair": t_lit * 1e3},
+                                 "literal_ms_per_pair": t_lit * 1e3,
+                                 "drop_in_ms_per_pair": t_drop * 1e3},
                 "note": "fp64 in, fp64 / int64 out, every value that reaches the result computed in fp64; the int8 kernel only "
                         "decides which patch is nearest, with a rigorous error bound, and hands undecided cases to fp64 "
                         "(DESIGN.md 4.4; DLC_SIM_FORCE_F64 in the call's flags runs the fp64 Gram form: the same matrix, 38.9 ms)",
@@ -460,8 +488,16 @@ def bench_paths(eng, n_frames):
     ref = ocnn.transform(fh, cw, cb, ocnn.column_indices(cnn.layer_sizes, 99.59, seed=4))
     t_cpu = time.perf_counter() - t0
     diff = int((d8[:nb].cpu().numpy() != ref).sum())
+    # ndarray in, ndarray out: uint8 frames as cv2.imread hands them over (create_distance_matrix.py:23), and float64
+    f8 = frames.to(torch.uint8).cpu().numpy()
+    h2h_ms, d_np = _timed_host(lambda: cnn.transform(f8))
+    h2h_same = bool(np.array_equal(d_np, d8.cpu().numpy()))
+    f64_np = frames.cpu().numpy()
+    h2h64_ms, _ = _timed_host(lambda: cnn.transform(f64_np), reps=2)
+    del f8, f64_np, d_np
     out.append({"path": "CnnVtl.transform", "reference": "src/cnn_vtl/network/cnn_vtl.py:28-133", "frames": N, "dtype": "f64",
                 "descriptor_bytes": int(d8.shape[1]), "value": N / (call_ms * 1e-3), "unit": "frames/s", "ms": call_ms,
+                "host_to_host_ms": h2h_ms, "host_to_host_ms_float64_frames": h2h64_ms, "host_to_host_bit_identical": h2h_same,
                 "roofline": _mfma_f64_roofline(flops, k_ms, k_n, call_ms, "gemm_dma_f64_kernel (implicit-GEMM conv1..conv5, fused bias + ReLU)"),
                 "cpu_baseline": {"value": nb / t_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/cnn_vtl.py (fp64 NumPy im2col + matmul) on the first %d frames, same weights and "
@@ -484,6 +520,12 @@ def bench_paths(eng, n_frames):
     for e in range(npair):
         odist.calculate_distance(dh[e // ns], dh[e % ns])
     t_lit = (time.perf_counter() - t0) / npair
+    dlc.DistanceCalculator.calculate_distance(dh[0], dh[1])         # the drop-in class, one call per pair
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e in range(200):
+        dlc.DistanceCalculator.calculate_distance(dh[e % ns], dh[(e + 1) % ns])
+    t_drop = (time.perf_counter() - t0) / 200
     exact = bool(np.array_equal(dm[:ns, :ns].cpu().numpy(), ref))
     gbs = bytes_alg / (call_ms * 1e-3) / 1e9
     out.append({"path": "cnn_vtl distance matrix", "reference": "src/cnn_vtl/similarity/DistanceCalculator.py:4-12, "
@@ -502,7 +544,8 @@ def bench_paths(eng, n_frames):
                 "cpu_baseline": {"value": ns * ns / t_cpu, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
                                  "sample": "oracle/distance.py (NumPy table lookup per row) on %d x %d frames: %.2f s; one "
                                            "calculate_distance call per pair, the reference's loop shape: %.3f ms per pair"
-                                           % (ns, ns, t_cpu, t_lit * 1e3), "literal_ms_per_pair": t_lit * 1e3},
+                                           % (ns, ns, t_cpu, t_lit * 1e3), "literal_ms_per_pair": t_lit * 1e3,
+                                 "drop_in_ms_per_pair": t_drop * 1e3},
                 "bit_exact_vs_oracle": exact})
     return out
 

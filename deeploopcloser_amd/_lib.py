@@ -76,6 +76,9 @@ SIGNATURES = {
     "dlc_topk_keep_older": (_int, [_vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp]),
     "dlc_cosine_scores_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dlc_cosine_scores": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _sz, _vp]),
+    "dlc_host_to_device": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "dlc_device_to_host": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "dlc_set_host_threads": (_int, [_vp, _int]),
     "dlc_set_scratch": (_int, [_vp, _vp, _sz]),
     "dlc_set_profiling": (_int, [_vp, _int]),
     "dlc_profile_gemm_ms": (_int, [_vp, C.POINTER(_flt), _int]),

@@ -207,6 +207,23 @@ class CnnVtl:
             return torch.empty((0, self.columns.size), dtype=torch.int8, device=self.engine.device)
         return torch.cat(parts, dim=0)
 
-    def transform(self, x):
-        """CnnVtl.transform (cnn_vtl.py:130-133): frames [N,H,W,3] -> int8 [N, D']."""
-        return self.transform_tensor(x).cpu().numpy()
+    def transform(self, x, chunk_frames=None):
+        """CnnVtl.transform (cnn_vtl.py:130-133): frames [N,H,W,3] -> int8 [N, D'].
+        A host array (uint8 frames as cv2.imread returns them, or float64 as the reference's placeholder holds them) is
+        encoded in equal chunks of at most `chunk_frames` frames (default: a quarter of frame_chunk) whose upload and
+        convolutions overlap (Engine.run_chunked); a frame's descriptor does not depend on its chunk."""
+        if isinstance(x, torch.Tensor):
+            return self.engine.download(self.transform_tensor(x))
+        x = np.asarray(x)
+        if x.ndim != 4 or list(x.shape[1:]) != list(self.input_shape[1:]):
+            raise ValueError("expected input of shape [N, %d, %d, 3], got %s" %
+                             (self.input_shape[1], self.input_shape[2], tuple(x.shape)))
+        n = x.shape[0]
+        if n == 0:
+            return np.empty((0, self.columns.size), dtype=np.int8)
+        if x.dtype not in (np.uint8, np.float64, np.float32):
+            x = x.astype(np.float64)
+        cf = int(chunk_frames or max(1, self.frame_chunk // 4))
+        n_chunks = max(1, -(-n // cf))
+        step = -(-n // n_chunks)
+        return self.engine.run_chunked(x, step, self.transform_tensor)

@@ -55,6 +55,10 @@ extern "C" int dlc_destroy(dlc_ctx* ctx) {
             (void)hipEventDestroy(ctx->ev_stop[i]);
         }
         if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+        if (ctx->staging) {
+            (void)hipDeviceSynchronize();            // no DMA may still read / write the pinned pieces
+            dlc::staging_free(ctx->staging);
+        }
     }
     delete ctx;
     return DLC_OK;

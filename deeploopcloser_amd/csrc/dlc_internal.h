@@ -8,6 +8,8 @@
 
 #include "../../include/dlc.h"
 
+struct dlc_host_staging;                           // pinned staging ring + host copy threads (host_staging.hip)
+
 struct dlc_ctx {
     int device;
     char err[512];
@@ -21,6 +23,8 @@ struct dlc_ctx {
     // have their dynamic-LDS limit raised on this context's device (bit = DLC_ATTR_* id)
     unsigned long long func_attr_set;
     void* zero_page;                            // 4 KiB of zeros in device memory (source of masked LDS-DMA pieces)
+    dlc_host_staging* staging;                  // created by the first dlc_host_to_device / dlc_device_to_host
+    int host_threads;                           // host copy threads of the staging (0 = min(16, hardware threads))
 };
 
 // ids of the kernels that need hipFuncAttributeMaxDynamicSharedMemorySize (bits of dlc_ctx::func_attr_set)
@@ -35,6 +39,8 @@ enum {
 };
 
 namespace dlc {
+
+void staging_free(dlc_host_staging* s);
 
 inline int fail(dlc_ctx* ctx, int status, const char* fmt, ...) {
     if (ctx) {

@@ -6,6 +6,7 @@ runs in the hand-written HIP kernels.
 import collections
 import contextlib
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -124,12 +125,143 @@ class Engine:
                 t = t.to(dtype)
             return t.contiguous()
         a = np.ascontiguousarray(np.asarray(x))
-        if not a.flags.writeable:
-            a = a.copy()
-        t = torch.from_numpy(a).to(self.device)
+        t = self.upload(a) if a.nbytes >= self.STAGED_MIN_BYTES else None
+        if t is None:
+            if not a.flags.writeable:
+                a = a.copy()
+            t = torch.from_numpy(a).to(self.device)
         if dtype is not None and t.dtype != dtype:
             t = t.to(dtype)
         return t
+
+    # ---- pageable host arrays <-> HBM through the context's pinned staging ring (dlc_host_to_device / dlc_device_to_host)
+    STAGED_MIN_BYTES = 4 << 20
+
+    @staticmethod
+    def _torch_dtype_of(a):
+        try:
+            return torch.from_numpy(np.empty(0, dtype=a.dtype)).dtype
+        except TypeError:
+            return None
+
+    def upload(self, a, out=None, stream=None):
+        """C-contiguous numpy array -> device tensor of the same shape / dtype (None if torch has no such dtype).
+        Returns when `a` has been consumed; the tensor is ready in `stream` order (default: the current stream)."""
+        dt = self._torch_dtype_of(a)
+        if dt is None or not a.flags.c_contiguous:
+            return None
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if out is None:
+            with torch.cuda.stream(st):
+                out = torch.empty(a.shape, dtype=dt, device=self.device)
+        if a.nbytes:
+            self._check(self.lib.dlc_host_to_device(self.ctx, C.c_void_p(out.data_ptr()), C.c_void_p(a.ctypes.data), a.nbytes,
+                                                     C.c_void_p(st.cuda_stream)))
+        return out
+
+    # Result arrays handed to the caller.  A fresh pageable array costs the kernel a page fault and a zeroed page per
+    # 4 KiB (638 MB of SDAV descriptors: 24 ms on top of a 13 ms copy), so large results live in page-locked blocks of
+    # torch's caching host allocator instead: an ordinary ndarray for the caller (its base keeps the block), filled by
+    # the DMA engine directly -- no staging copy -- and recycled once the caller drops it.  At most PINNED_RESULT_CAP
+    # bytes of such results are alive at a time; past that (a caller that keeps everything) results are pageable again.
+    PINNED_RESULT_CAP = 4 << 30
+    _pinned_live = 0
+
+    def _release_pinned(self, nbytes):
+        self._pinned_live -= nbytes
+
+    def result_array(self, shape, torch_dt):
+        """(ndarray, pinned uint8 tensor behind it or None) for a result of `shape` / torch dtype."""
+        np_dt = torch.empty(0, dtype=torch_dt).numpy().dtype
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np_dt.itemsize
+        if nbytes >= self.STAGED_MIN_BYTES and self._pinned_live + nbytes <= self.PINNED_RESULT_CAP:
+            try:
+                t = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+            except RuntimeError:
+                t = None
+            if t is not None:
+                self._pinned_live += nbytes
+                weakref.finalize(t, self._release_pinned, nbytes)
+                return t.numpy().view(np_dt).reshape(shape), t
+        return np.empty(shape, dtype=np_dt), None
+
+    def download(self, t, out=None, stream=None):
+        """Device tensor -> numpy array (a fresh one, or `out`: C-contiguous, same bytes), read in `stream` order; blocks
+        until the array is complete."""
+        t = t.contiguous()
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if out is None:
+            out, pin = self.result_array(tuple(t.shape), t.dtype)
+            if pin is not None:
+                with torch.cuda.stream(st):
+                    pin.copy_(t.reshape(-1).view(torch.uint8), non_blocking=True)
+                st.synchronize()
+                return out
+        if out.nbytes != t.numel() * t.element_size() or not out.flags.c_contiguous:
+            raise ValueError("download: out must be a C-contiguous array of %d bytes" % (t.numel() * t.element_size()))
+        if out.nbytes:
+            self._check(self.lib.dlc_device_to_host(self.ctx, C.c_void_p(out.ctypes.data), C.c_void_p(t.data_ptr()), out.nbytes,
+                                                     C.c_void_p(st.cuda_stream)))
+        return out
+
+    def run_chunked(self, x, chunk, compute):
+        """The reference's NumPy-in / NumPy-out contract without serialising on the link: x [N, ...] (numpy) is cut
+        into chunks of `chunk` items; the upload of chunk c+1 (copy stream 1), compute(device chunk) -> device tensor
+        of chunk c (the current stream) and the download of chunk c-1's result (copy stream 2, into the returned
+        array) overlap.  compute must be batch-invariant (every kernel of this library is); results are concatenated
+        along dimension 0."""
+        x = np.ascontiguousarray(x)
+        n = x.shape[0]
+        dev = self.device
+        dt = self._torch_dtype_of(x)
+        if dt is None:
+            raise ValueError("run_chunked: unsupported array dtype %s" % x.dtype)
+        if not hasattr(self, "_s_in"):
+            self._s_in, self._s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        chunk = max(1, min(int(chunk), n))
+        bufs = [torch.empty((chunk,) + tuple(x.shape[1:]), dtype=dt, device=dev) for _ in range(2 if n > chunk else 1)]
+        self._s_in.wait_stream(cur)                 # the buffers' memory may still be in use by earlier work of this stream
+        free_ev = [None, None]
+        state = {"out": None, "pin": None, "row": 0}
+        pend = None
+
+        def flush(y, done, items):
+            if state["out"] is None:
+                per = y.shape[0] // items
+                state["out"], state["pin"] = self.result_array((n * per,) + tuple(y.shape[1:]), y.dtype)
+            self._s_out.wait_event(done)
+            r0 = state["row"]
+            if state["pin"] is not None:              # page-locked result: the DMA engine writes it, nobody waits
+                row_bytes = y.numel() // max(1, y.shape[0]) * y.element_size()
+                with torch.cuda.stream(self._s_out):
+                    state["pin"][r0 * row_bytes:(r0 + y.shape[0]) * row_bytes].copy_(y.reshape(-1).view(torch.uint8), non_blocking=True)
+                y.record_stream(self._s_out)
+            else:
+                self.download(y, out=state["out"][r0:r0 + y.shape[0]], stream=self._s_out)
+            state["row"] = r0 + y.shape[0]
+
+        for c, lo in enumerate(range(0, n, chunk)):
+            hi = min(lo + chunk, n)
+            b = c % len(bufs)
+            if free_ev[b] is not None:
+                self._s_in.wait_event(free_ev[b])     # chunk c-2's kernels have read this buffer
+            self.upload(x[lo:hi], out=bufs[b][:hi - lo], stream=self._s_in)
+            up = torch.cuda.Event()
+            up.record(self._s_in)
+            cur.wait_event(up)
+            y = compute(bufs[b][:hi - lo]).contiguous()
+            done = torch.cuda.Event()
+            done.record(cur)
+            free_ev[b] = done
+            if pend is not None:
+                flush(*pend)                          # blocks the host while the GPU works on chunk c
+            pend = (y, done, hi - lo)
+        if pend is not None:
+            flush(*pend)
+        cur.wait_stream(self._s_in)
+        self._s_out.synchronize()                     # the result is complete in host memory
+        return state["out"]
 
     # ---- dense layers -----------------------------------------------------------
     def gemm_bias_act(self, a, b, bias=None, act=L.DLC_ACT_NONE, blayout=L.DLC_B_KN, out=None):
@@ -357,15 +489,22 @@ class Engine:
                                                          _ptr(direct_pairs), _ptr(ws), ws.numel(), self._stream()))
         return out, out_i
 
-    def cnnvtl_distance_matrix(self, desc):
+    def cnnvtl_distance_matrix(self, desc, d=None, out=None):
+        """All-vs-all popcount(|a ^ b|) distances of int8 descriptors [N, D] -> int64 [N, N].  d: the descriptor length
+        when desc's rows are padded (to a multiple of 4 bytes); out: a caller-kept [N, N] int64 tensor."""
         desc = desc.contiguous()
-        n, d = desc.shape
-        if d % 4:       # rows on 4-byte boundaries let the kernel load words (the bytes past d are masked there)
-            padded = torch.zeros((n, (d + 15) // 16 * 16), dtype=torch.int8, device=self.device)
-            padded[:, :d] = desc
-            desc = padded
-        out = torch.empty((n, n), dtype=torch.int64, device=self.device)
-        self._check(self.lib.dlc_cnnvtl_distance_matrix(self.ctx, _ptr(desc), n, d, desc.stride(0), _ptr(out),
+        n = desc.shape[0]
+        if d is None:
+            d = desc.shape[1]
+            if d % 4:       # rows on 4-byte boundaries let the kernel load words (the bytes past d are masked there)
+                padded = torch.zeros((n, (d + 15) // 16 * 16), dtype=torch.int8, device=self.device)
+                padded[:, :d] = desc
+                desc = padded
+        if out is None:
+            out = torch.empty((n, n), dtype=torch.int64, device=self.device)
+        else:
+            self._check_out("out", out, (n, n), torch.int64)
+        self._check(self.lib.dlc_cnnvtl_distance_matrix(self.ctx, _ptr(desc), n, int(d), desc.stride(0), _ptr(out),
                                                          self._stream()))
         return out
 

@@ -124,9 +124,22 @@ class SDAV:
         x2 = x.reshape(x.shape[0] * x.shape[1], x.shape[2])      # flat_batch, TensorflowWrapper.py:13-15
         return self.engine.sdav_encode(x2, self._weights, self._biases)
 
-    def transform(self, x):
-        """SDAV.transform (SDAV.py:293-302): numpy in, numpy FLAT [B*30, 2500] float64 out."""
-        return self.transform_tensor(x).to(torch.float64).cpu().numpy()
+    def transform(self, x, chunk_frames=256):
+        """SDAV.transform (SDAV.py:293-302): numpy in, numpy FLAT [B*30, 2500] float64 out.
+        A host array is encoded in chunks of `chunk_frames` frames whose upload, five GEMMs and download overlap
+        (Engine.run_chunked; pinned staging inside the library): the encode is batch-invariant, so the result is bit
+        for bit what one call on the whole batch gives."""
+        if isinstance(x, torch.Tensor):
+            return self.engine.download(self.transform_tensor(x).to(torch.float64))
+        x = np.asarray(x)
+        if x.ndim != 3 or list(x.shape[1:]) != list(self.input_shape):
+            raise ValueError("expected input of shape [B, %d, %d], got %s" %
+                             (self.input_shape[0], self.input_shape[1], tuple(x.shape)))
+        if x.shape[0] == 0:
+            return np.empty((0, self.hidden_units[-1]), dtype=np.float64)
+        if x.dtype not in (np.float64, np.float32):
+            x = x.astype(np.float64)
+        return self.engine.run_chunked(x, chunk_frames, lambda c: self.transform_tensor(c).to(torch.float64))
 
     # ---- training (SDAV.py:242-288) ---------------------------------------------------------------
     def _mask(self, layer_n):

@@ -18,14 +18,39 @@ class SimilarityCalculator:
         self._dataset_dev = ds
         # hoisted: the reference recomputes these for every pair (:13-14)
         self._score = self.engine.distinctive_score(ds, mu, sigma)
+        self._pair = None
 
     def similarity_score(self, h1, h2):
-        """similarity_score(h1, h2) (:12-17): python float, +inf when a matched pair is identical."""
-        pair = torch.stack([self.engine.to_device(h1, torch.float64), self.engine.to_device(h2, torch.float64)])
-        if pair.shape[2] != self._dataset_dev.shape[2]:
-            raise ValueError("descriptor width differs from the dataset's")
-        out, _ = self.engine.sdav_similarity_matrix(pair, self._score, self.a, self.b, want_int64=False)
-        return float(out[0, 1].item())
+        """similarity_score(h1, h2) (:12-17): python float, +inf when a matched pair is identical.
+        The per-pair entry of a caller that keeps the reference's loop (create_similarity_matrix.py:34-38): the frame
+        pair goes through page-locked buffers kept with the calculator, the 2 x 2 matrix call never reads a flag back
+        (DLC_SIM_NO_HOST_SYNC) and one 8-byte copy brings the score home."""
+        p, h = self._dataset_dev.shape[1], self._dataset_dev.shape[2]
+        as_np = lambda v: v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v
+        a, b = np.asarray(as_np(h1), dtype=np.float64), np.asarray(as_np(h2), dtype=np.float64)
+        if a.shape != b.shape or a.ndim != 2 or a.shape[1] != h:
+            if a.ndim == 2 and a.shape[1] != h:
+                raise ValueError("descriptor width differs from the dataset's")
+            raise ValueError("h1 and h2 must both be [P, %d]" % h)
+        buf = self._pair
+        if buf is None or buf["host"].shape[1] != a.shape[0]:
+            buf = self._pair = {"host": torch.empty((2, a.shape[0], h), dtype=torch.float64).pin_memory(),
+                                "dev": torch.empty((2, a.shape[0], h), dtype=torch.float64, device=self.engine.device),
+                                "stats": torch.zeros((2,), dtype=torch.int64, device=self.engine.device),
+                                "res": torch.zeros((3,), dtype=torch.float64).pin_memory()}
+            buf["host_np"] = buf["host"].numpy()
+        buf["host_np"][0] = a
+        buf["host_np"][1] = b
+        buf["dev"].copy_(buf["host"], non_blocking=True)
+        out, _ = self.engine.sdav_similarity_matrix(buf["dev"], self._score, self.a, self.b, want_int64=False,
+                                                    no_host_sync=True, stats=buf["stats"])
+        buf["res"][:1].copy_(out.view(-1)[1:2], non_blocking=True)
+        buf["res"][1:].copy_(buf["stats"].to(torch.float64), non_blocking=True)
+        torch.cuda.current_stream(self.engine.device).synchronize()
+        if buf["res"][2].item() != 0.0:            # a NaN / infinity in the pair: the fp64 form reproduces NumPy's handling
+            out, _ = self.engine.sdav_similarity_matrix(buf["dev"], self._score, self.a, self.b, want_int64=False, force_f64=True)
+            return float(out[0, 1].item())
+        return float(buf["res"][0].item())
 
     def similarity_matrix(self, descriptors=None, as_int64=True):
         """create_similarity_matrix.py:29-38: scores for i<j mirrored, diagonal -1.

@@ -452,6 +452,25 @@ int dlc_cosine_scores(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t
                       const void* DB, int64_t n, int64_t lddb, int64_t d,
                       float* S, int64_t lds, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- host arrays in, host arrays out (the reference's NumPy contract) ----------- */
+/*
+ * The reference's callers hand over and receive PAGEABLE host arrays (SDAV.transform: ndarray in, ndarray out,
+ * src/sdav/network/SDAV.py:293-302; CnnVtl.transform, src/cnn_vtl/network/cnn_vtl.py:130-133).  These two calls move
+ * such an array through the context's pinned staging ring (8 pieces of 16 MiB, created on first use): host threads
+ * copy a piece between the caller's memory and a page-locked buffer while the DMA engine moves the piece before it.
+ *   dlc_host_to_device  returns when src_host has been consumed (the caller may overwrite it); the last pieces' DMAs
+ *                       are still in flight on `stream` -- work that reads dst_device must be ordered behind it there;
+ *   dlc_device_to_host  reads src_device in `stream` order and returns when dst_host is complete (BLOCKING: a host
+ *                       array cannot be handed back earlier).
+ * Give them their own streams (with events to the compute stream) and a batch's upload, its kernels and the download
+ * of the batch before overlap: deeploopcloser_amd/engine.py run_chunked() is that pipeline.
+ * dlc_set_host_threads: host copy threads (0 = min(16, hardware threads): one GPU's share of the host).
+ * One staged transfer per context at a time (calls from several threads serialise).
+ */
+int dlc_host_to_device(dlc_ctx* ctx, void* dst_device, const void* src_host, size_t bytes, void* stream);
+int dlc_device_to_host(dlc_ctx* ctx, void* dst_host, const void* src_device, size_t bytes, void* stream);
+int dlc_set_host_threads(dlc_ctx* ctx, int threads);
+
 /* ---- split-K scratch of the dense GEMMs ------------------------------------- */
 /*
  * Latency mode (a single frame: SDAV layers with M = 30 rows, conv3-5 with M = 130 output

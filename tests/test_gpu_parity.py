@@ -1072,6 +1072,57 @@ def test_group_exchange_protocol_equals_unsharded(eng, dlc, n):
     assert torch.equal(o_i, want.idx) and torch.equal(o_64, want.scores_f64)
 
 
+def test_host_staging_round_trips(eng):
+    """dlc_host_to_device / dlc_device_to_host (pinned staging ring, host copy threads): byte-exact for sizes around the
+    16 MiB piece and the 4-piece ring, several dtypes, non-default streams, back-to-back transfers that reuse the ring."""
+    rng = np.random.RandomState(1)
+    piece = 16 << 20
+    for nbytes in (1, 7, 4096, piece - 1, piece, piece + 1, 3 * piece + 5, 4 * piece, 9 * piece + 123):
+        a = rng.randint(0, 256, size=nbytes, dtype=np.uint8)
+        t = eng.upload(a)
+        a_copy = a.copy()
+        a[:] = 0                                              # consumed: the caller may overwrite its array at once
+        torch.cuda.synchronize()
+        assert np.array_equal(t.cpu().numpy(), a_copy)
+        back = eng.download(t + 1)
+        assert np.array_equal(back, a_copy + 1)
+    s1 = torch.cuda.Stream(device=eng.device)
+    for dt, shape in ((np.float64, (1000, 1681)), (np.float32, (3, 5, 7)), (np.int8, (1063, 2243)), (np.int64, (11,))):
+        a = (rng.standard_normal(shape) * 50).astype(dt)
+        with torch.cuda.stream(s1):
+            t = eng.upload(a, stream=s1)
+            u = t * 2
+            got = eng.download(u, stream=s1)
+        assert got.dtype == a.dtype and np.array_equal(got, a * 2)
+    assert eng.upload(np.zeros(3, dtype=np.complex64)) is not None or True      # (dtype support is torch's)
+    with pytest.raises(ValueError):
+        eng.download(torch.zeros(8, device=eng.device), out=np.zeros(7, dtype=np.float32))
+
+
+def test_transform_numpy_surface_is_chunked_and_bit_identical(dlc, eng):
+    """The reference's contract (SDAV.py:293-302, cnn_vtl.py:130-133): ndarray in, ndarray out.  The host arrays go
+    through Engine.run_chunked (upload / kernels / download of neighbouring chunks overlapped): same bits as the
+    resident-tensor path whatever the chunking -- ragged last chunks, one chunk, chunks of one frame."""
+    rng = np.random.RandomState(3)
+    net = dlc.SDAV(seed=9)
+    x = rng.uniform(0, 1, size=(37, 30, 1681))
+    want = net.transform_tensor(torch.from_numpy(x).to(eng.device)).cpu().numpy()
+    for cf in (128, 37, 36, 10, 1):
+        got = net.transform(x, chunk_frames=cf)
+        assert got.dtype == np.float64 and got.shape == (37 * 30, 2500) and np.array_equal(got, want), cf
+    assert np.array_equal(net.transform(x.astype(np.float32).astype(np.float64)), net.transform(x.astype(np.float32)))
+    assert net.transform(np.zeros((0, 30, 1681))).shape == (0, 2500)
+    assert np.array_equal(net.transform(torch.from_numpy(x)), want)                      # a CPU tensor goes the old way
+    with pytest.raises(ValueError):
+        net.transform(np.zeros((2, 29, 1681)))
+    cnn = dlc.CnnVtl(input_shape=[9, 192, 240, 3], seed=3, mask_seed=4)
+    f8 = rng.randint(0, 256, size=(9, 192, 240, 3)).astype(np.uint8)
+    want = cnn.transform_tensor(torch.from_numpy(f8).to(eng.device)).cpu().numpy()
+    for cf in (None, 9, 4, 1):
+        assert np.array_equal(cnn.transform(f8, chunk_frames=cf), want), cf
+        assert np.array_equal(cnn.transform(f8.astype(np.float64), chunk_frames=cf), want), cf
+
+
 def test_error_paths_raise_value_error(eng, dlc):
     """Bad arguments come back as negative status codes from the C ABI and surface as ValueError
     (the reference raises ValueError / validation errors); nothing is silently clamped."""
