@@ -65,18 +65,21 @@ __global__ __launch_bounds__(256) void xent_grad_kernel(const double* __restrict
         if (dlab) dlab[r * cols + c] = -logsm * inv_rows;
     }
     cd = block_sum(cd, red);
-    if (threadIdx.x == 0) atomicAdd(&acc[0], cd * inv_rows);
+    if (threadIdx.x == 0) acc[r] = cd * inv_rows;             // cd_part[r]: summed in order by finalize_loss_kernel
 }
 
+constexpr int FN_MAX_SLICES = 64;
 // n_t = || H_t - H_{t+1} ||_F over a frame's P x N block (SDAV.py:176-183); also cs (:174):
 // sum |h - s| / cs_den, where cs_den is the number of entries reduce_mean sees after the axis-1
 // norm -- batch*N at layer 0 (h is 3-D [B,P,N] there: axis 1 = patches), batch*P afterwards.
 __global__ __launch_bounds__(256) void frame_norm_kernel(const double* __restrict__ h, int batch, long long frame_elems,
-                                                         double sparse_level, double cs_den, double* __restrict__ nrm,
+                                                         double sparse_level, double cs_den, double* __restrict__ nrm_part,
                                                          double* __restrict__ acc) {
     // Per frame t: its share of the sparsity term and the squared distance to frame t + 1 (the consecutive-frame term).
     // A frame is cut into gridDim.y slices (one workgroup per frame walked 75 000 elements alone: 97 us of a 790 us
-    // step); the slices meet in nrm[t] (zeroed by the caller), frame_norm_finish_kernel takes the roots.
+    // step); slice y leaves its part in nrm_part[t * 64 + y] and frame_norm_finish_kernel adds the parts IN ORDER and takes
+    // the roots: nrm feeds the consecutive-frame gradient, so the SGD trajectory is the same bits run after run (an
+    // atomicAdd here made it depend on the order the workgroups finished).
     __shared__ double red[4];
     const int t = blockIdx.x;                                   // 0 .. batch-1
     const double* a = h + (long long)t * frame_elems;
@@ -89,19 +92,29 @@ __global__ __launch_bounds__(256) void frame_norm_kernel(const double* __restric
     s2 = block_sum(s2, red);
     l1 = block_sum(l1, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&acc[1], l1 / cs_den);
-        if (t + 1 < batch) atomicAdd(&nrm[t], s2);
+        acc[(long long)t * FN_MAX_SLICES + blockIdx.y] = l1 / cs_den;        // l1_part, as nrm_part
+        nrm_part[(long long)t * FN_MAX_SLICES + blockIdx.y] = s2;
     }
 }
-__global__ void frame_norm_finish_kernel(int batch, double* __restrict__ nrm, double* __restrict__ acc) {
+__global__ void frame_norm_finish_kernel(int batch, int slices, const double* __restrict__ nrm_part,
+                                         const double* __restrict__ l1_part, double* __restrict__ nrm,
+                                         double* __restrict__ acc) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s = 0.0;
-    for (int t = 0; t + 1 < batch; ++t) {
-        const double n = sqrt(nrm[t]);
-        nrm[t] = n;
-        s += n / (double)(batch - 1);
+    double s = 0.0, l1 = 0.0;
+    for (int t = 0; t < batch; ++t) {
+        double n2 = 0.0;
+        for (int y = 0; y < slices; ++y) {
+            n2 += nrm_part[(long long)t * FN_MAX_SLICES + y];
+            l1 += l1_part[(long long)t * FN_MAX_SLICES + y];
+        }
+        if (t + 1 < batch) {
+            const double n = sqrt(n2);
+            nrm[t] = n;
+            s += n / (double)(batch - 1);
+        }
     }
-    acc[2] += s;
+    acc[1] = l1;
+    acc[2] = s;
 }
 
 // dh += sparse_penalty*sign(h - s)/cs_den + consecutive term;  dz1 = dh * h(1-h)
@@ -180,12 +193,21 @@ __global__ __launch_bounds__(256) void sgd_kernel(double* __restrict__ p, const 
         p[e] -= lr * (g2 ? g1[e] + g2[e] : g1[e]);
 }
 
-__global__ void finalize_loss_kernel(const double* acc, double sparse_penalty, double consecutive_penalty,
-                                     double* loss_out) {
-    loss_out[0] = acc[0] + sparse_penalty * acc[1] + consecutive_penalty * acc[2];
-    loss_out[1] = acc[0];
-    loss_out[2] = acc[1];
-    loss_out[3] = acc[2];
+// {loss, cd, cs, cc}; cd = the rows' cross-entropies added in row order by one workgroup (a fixed tree: the reported loss is
+// the same bits run after run, like the parameters)
+__global__ __launch_bounds__(256) void finalize_loss_kernel(const double* __restrict__ cd_part, long long rows,
+                                                            const double* __restrict__ acc, double sparse_penalty,
+                                                            double consecutive_penalty, double* __restrict__ loss_out) {
+    __shared__ double red[4];
+    double cd = 0.0;
+    for (long long r = threadIdx.x; r < rows; r += 256) cd += cd_part[r];
+    cd = block_sum(cd, red);
+    if (threadIdx.x == 0) {
+        loss_out[0] = cd + sparse_penalty * acc[1] + consecutive_penalty * acc[2];
+        loss_out[1] = cd;
+        loss_out[2] = acc[1];
+        loss_out[3] = acc[2];
+    }
 }
 
 inline unsigned grid_for(long long n) {
@@ -195,7 +217,7 @@ inline unsigned grid_for(long long n) {
 
 struct TrainWs {
     size_t xt[8], h[8], gw[8], gbe[8];     // per layer 0..layer
-    size_t y, dz2, dlab, dh, dz1a, dz1b, dxt, tr, gw2, gbd, nrm, acc, total;
+    size_t y, dz2, dlab, dh, dz1a, dz1b, dxt, tr, gw2, gbd, nrm, nrm_part, l1_part, cd_part, acc, total;
 };
 
 TrainWs train_ws(int64_t rows, int batch, const int64_t* dims, int layer) {
@@ -221,6 +243,9 @@ TrainWs train_ws(int64_t rows, int batch, const int64_t* dims, int layer) {
     w.gw2 = take((size_t)dims[layer] * dims[layer + 1]);
     w.gbd = take((size_t)dims[layer]);
     w.nrm = take((size_t)batch);
+    w.nrm_part = take((size_t)batch * FN_MAX_SLICES);
+    w.l1_part = take((size_t)batch * FN_MAX_SLICES);
+    w.cd_part = take((size_t)rows);
     w.acc = take(4);
     w.total = o;
     return w;
@@ -281,18 +306,17 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
     const double* labels = layer == 0 ? x : P(w.xt[layer]);
 
     // ---- loss pieces and the gradient at the trained layer
-    DLC_HIP_CHECK(ctx, hipMemsetAsync(P(w.acc), 0, 32, st));
     hipLaunchKernelGGL(xent_grad_kernel, dim3((unsigned)rows), dim3(256), 0, st, P(w.y), labels, rows, (int)K, P(w.dz2),
-                       layer > 0 ? P(w.dlab) : (double*)nullptr, P(w.acc));
+                       layer > 0 ? P(w.dlab) : (double*)nullptr, P(w.cd_part));
     // tf.norm(h - s, axis=1, ord=1) + reduce_mean (SDAV.py:174): h is [B,P,N] at layer 0, [B*P,N] afterwards
     const double cs_den = layer == 0 ? (double)batch * (double)N : (double)rows;
-    DLC_HIP_CHECK(ctx, hipMemsetAsync(P(w.nrm), 0, (size_t)batch * 8, st));
     {
         long long slices = dlc::cdiv((long long)patches * N, (long long)256 * 16);      // >= 16 elements per thread
-        if (slices > 64) slices = 64;
+        if (slices > FN_MAX_SLICES) slices = FN_MAX_SLICES;
         hipLaunchKernelGGL(frame_norm_kernel, dim3((unsigned)batch, (unsigned)slices), dim3(256), 0, st, h, (int)batch,
-                           (long long)patches * N, sparse_level, cs_den, P(w.nrm), P(w.acc));
-        hipLaunchKernelGGL(frame_norm_finish_kernel, dim3(1), dim3(64), 0, st, (int)batch, P(w.nrm), P(w.acc));
+                           (long long)patches * N, sparse_level, cs_den, P(w.nrm_part), P(w.l1_part));
+        hipLaunchKernelGGL(frame_norm_finish_kernel, dim3(1), dim3(64), 0, st, (int)batch, (int)slices, P(w.nrm_part),
+                           P(w.l1_part), P(w.nrm), P(w.acc));
     }
     GEMM(DLC_B_KN, DLC_ACT_NONE, rows, N, K, P(w.dz2), K, W[layer], N, nullptr, P(w.dh), N);      // dh = dz2 W
     hipLaunchKernelGGL(hidden_grad_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, h, P(w.dh), P(w.nrm), (int)batch,
@@ -330,8 +354,8 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(K)), dim3(256), 0, st, b_dec, P(w.gbd), (const double*)nullptr, K,
                        learning_rate);
     if (loss_out)
-        hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, st, P(w.acc), sparse_penalty, consecutive_penalty,
-                           loss_out);
+        hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(256), 0, st, P(w.cd_part), (long long)rows, P(w.acc),
+                           sparse_penalty, consecutive_penalty, loss_out);
 #undef GEMM
     DLC_LAUNCH_CHECK(ctx, "sdav_train_step kernels");
     return DLC_OK;

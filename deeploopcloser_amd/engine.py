@@ -325,9 +325,20 @@ class Engine:
                                               _ptr(out), _ptr(ws), ws.numel(), self._stream()))
         return out
 
+    def train_workspace(self, layer, batch, patches, weights):
+        """A workspace tensor of dlc_sdav_train_step's size for this shape (for a caller that keeps its own)."""
+        n_layers = len(weights)
+        dims = [weights[0].shape[0]] + [w.shape[1] for w in weights]
+        dims_c = (C.c_int64 * (n_layers + 1))(*dims)
+        need = self.lib.dlc_sdav_train_workspace_bytes(batch, patches, dims_c, n_layers, layer)
+        if need == 0:
+            raise ValueError("sdav_train_step: batch must be >= 2 frames, layer in range")
+        return torch.empty(int(need), dtype=torch.uint8, device=self.device)
+
     def sdav_train_step(self, layer, x2d, batch, patches, masks, weights, b_enc, b_dec, sparse_level, sparse_penalty,
-                        consecutive_penalty, learning_rate, loss_out=None):
-        """One in-place SGD step of `layer` (fp64 tensors on this device); loss_out: 4 doubles."""
+                        consecutive_penalty, learning_rate, loss_out=None, ws=None):
+        """One in-place SGD step of `layer` (fp64 tensors on this device); loss_out: 4 doubles; ws: the caller's own
+        workspace (train_workspace) instead of the engine's."""
         n_layers = len(weights)
         dims = [weights[0].shape[0]] + [w.shape[1] for w in weights]
         dims_c = (C.c_int64 * (n_layers + 1))(*dims)
@@ -340,7 +351,10 @@ class Engine:
         need = self.lib.dlc_sdav_train_workspace_bytes(batch, patches, dims_c, n_layers, layer)
         if need == 0:
             raise ValueError("sdav_train_step: batch must be >= 2 frames, layer in range")
-        ws = self.workspace("train", need)
+        if ws is None:
+            ws = self.workspace("train", need)
+        else:
+            self._check_ws(ws)
         self._check(self.lib.dlc_sdav_train_step(self.ctx, layer, batch, patches, n_layers, dims_c, _ptr(x2d), m_c, w_c,
                                                   b_c, _ptr(b_dec), float(sparse_level), float(sparse_penalty),
                                                   float(consecutive_penalty), float(learning_rate), _ptr(loss_out),

@@ -53,6 +53,7 @@ class SDAV:
         self._mask_gen = torch.Generator(device=self.engine.device)
         self._mask_gen.manual_seed(int(seed) + 1)
         self.global_step = 0
+        self._step_graphs = {}
         self.checkpoint_file = None                 # set to a path prefix to save after each layer (:273-275)
         logging.info("Done initializing sdav")
 
@@ -172,6 +173,73 @@ class SDAV:
         self.global_step += 1
         return loss
 
+    def _fill_mask(self, m, layer_n):
+        """random_mask into an existing [P, K] tensor (same draw as _mask)."""
+        n = m.numel()
+        n_zeros = int(np.round(n * float(self.corruption_level)))
+        perm = torch.randperm(n, generator=self._mask_gen, device=self.engine.device)
+        flat = m.view(-1)
+        flat.fill_(1.0)
+        flat[perm[:n_zeros]] = 0.0
+
+    def train_steps(self, layer_n, x, n_steps):
+        """n_steps consecutive sess.run(self.train_steps[layer_n]) on ONE batch (the inner loop of SDAV.fit_dataset /
+        SDAV.fit, SDAV.py:257-263: `for step in range(epochs)`), fresh masking noise for every step as the reference's
+        corrupt() draws it per run.  The step -- ~20 launches of a few microseconds of work each at the reference's batch of
+        10 frames -- is captured ONCE as a HIP graph over fixed buffers (batch, masks, workspace, loss) and replayed:
+        what is left per step is the masks' regeneration in place and one graph launch.  Returns the loss tensor
+        {loss, cd, cs, cc} of the last step (before its update), as train_step does; same arithmetic, same results."""
+        if self.dtype != torch.float64:
+            raise ValueError("training runs in float64, like the reference")
+        x = self.engine.to_device(x, torch.float64)
+        if x.dim() != 3 or list(x.shape[1:]) != list(self.input_shape):
+            raise ValueError("expected input of shape [B, %d, %d]" % tuple(self.input_shape))
+        if x.shape[0] < 2:
+            raise ValueError("a training batch needs at least 2 frames (the consecutive-frame loss term)")
+        eng = self.engine
+        # everything the captured launches point at: the parameters, the split-K scratch of latency_mode
+        sig = (tuple(w.data_ptr() for w in self._weights), tuple(b.data_ptr() for b in self._biases),
+               self._biases_dec[layer_n].data_ptr(), eng._scratch.data_ptr() if eng._scratch is not None else 0)
+        key = (layer_n, x.shape[0])
+        g = self._step_graphs.get(key)
+        if g is None or g["sig"] != sig:
+            if len(self._step_graphs) > 8:
+                self._step_graphs.clear()
+            g = {"sig": sig, "x": torch.empty_like(x),
+                 "masks": [torch.empty(tuple(self.get_layer_input_shape(l)), dtype=torch.float64, device=eng.device)
+                           for l in range(layer_n + 1)],
+                 "loss": torch.zeros(4, dtype=torch.float64, device=eng.device), "graph": None,
+                 "ws": eng.train_workspace(layer_n, x.shape[0], x.shape[1], self._weights)}     # its own: the graph keeps pointing at it
+            self._step_graphs[key] = g
+        g["x"].copy_(x)
+
+        def one_step():
+            eng.sdav_train_step(layer_n, g["x"].reshape(-1, x.shape[2]), x.shape[0], x.shape[1], g["masks"], self._weights,
+                                self._biases, self._biases_dec[layer_n], self.sparse_level, self.sparse_penalty,
+                                self.consecutive_penalty, self.learning_rate, loss_out=g["loss"], ws=g["ws"])
+
+        done = 0
+        if g["graph"] is None and n_steps >= 3:
+            # one eager step first: kernel attributes and the allocator's pools exist before the capture
+            for l, m in enumerate(g["masks"]):
+                self._fill_mask(m, l)
+            one_step()
+            done = 1
+            torch.cuda.synchronize(eng.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):                    # (a capture records the launches, it does not run them)
+                one_step()
+            g["graph"] = graph
+        for _ in range(done, n_steps):
+            for l, m in enumerate(g["masks"]):
+                self._fill_mask(m, l)
+            if g["graph"] is not None:
+                g["graph"].replay()
+            else:
+                one_step()
+        self.global_step += n_steps
+        return g["loss"]
+
     def get_dataset(self, file_pattern: str, key_points_fn=None):
         """Generator of parsed frames [30, 1681] (SDAV.py:219-221, InputGenerator.py:17-27)."""
         from glob import glob
@@ -202,11 +270,13 @@ class SDAV:
                         logging.warning("skipping a batch of %d frame(s): the loss needs >= 2" % b.shape[0])
                         continue
                     xb = self.engine.to_device(b, torch.float64)
-                    for step in range(self.epochs):
-                        loss = self.train_step(i, xb)
-                        if self.logger.isEnabledFor(logging.INFO):
+                    if self.logger.isEnabledFor(logging.INFO):       # a loss line per step (the reference's log): step by step
+                        for step in range(self.epochs):
+                            loss = self.train_step(i, xb)
                             logging.info("    Layer:%d Batch:%d fit, Epoch:%d/%d, Loss:%s" %
                                          (i, batch_n, step + 1, self.epochs, float(loss[0].item())))
+                    else:
+                        self.train_steps(i, xb, self.epochs)         # the same steps, replayed as one HIP graph each
                 if self.checkpoint_file:
                     self.save_weights("%s-%d.npz" % (self.checkpoint_file, self.global_step))
 
@@ -215,8 +285,7 @@ class SDAV:
         xb = self.engine.to_device(x, torch.float64)
         with self.engine.latency_mode():
             for i in range(len(self.hidden_units)):
-                for step in range(self.epochs):
-                    self.train_step(i, xb)
+                self.train_steps(i, xb, self.epochs)
 
 
 class DA:

@@ -87,3 +87,48 @@ def test_sdav_train_step_real_shape_and_fit_surface(tmp_path):
         net2.train_step(0, x[:1])
     net2.fit(x)                                    # 5 layers x epochs steps on one batch
     assert net2.global_step == 10
+
+
+@pytest.mark.parametrize("layer", [0, 2])
+def test_train_steps_graph_replay_equals_eager_steps(layer):
+    """SDAV.train_steps (the inner loop of fit / fit_dataset as ONE captured HIP graph replayed per step, masks redrawn in
+    place) == the same number of train_step calls with the same mask draws: same parameters, same losses, bit for bit --
+    also run after run (the frame norms are summed in a fixed order), inside latency mode (split-K scratch captured) and
+    after the parameters are replaced (the capture is redone)."""
+    import deeploopcloser_amd as dlc
+    rng = np.random.RandomState(11)
+    x = rng.uniform(0, 1, size=(10, 30, 1681))
+    eng = dlc.default_engine()
+
+    def run(graph, latency, n=6):
+        net = dlc.SDAV(seed=4, weight_scale="fan_in")
+        ctx = eng.latency_mode() if latency else __import__("contextlib").nullcontext()
+        with ctx:
+            if graph:
+                loss = net.train_steps(layer, x, n).clone()
+            else:
+                xd = eng.to_device(x, torch.float64)
+                for _ in range(n):
+                    loss = net.train_step(layer, xd)            # draws its masks from the same generator, in the same order
+        torch.cuda.synchronize()
+        assert net.global_step == n
+        return [w.clone() for w in net._weights], [b.clone() for b in net._biases], net._biases_dec[layer].clone(), loss.clone()
+
+    for latency in (False, True):
+        a, b, c = run(True, latency), run(False, latency), run(True, latency)
+        for got in (a, c):
+            for l in range(5):
+                assert torch.equal(got[0][l], b[0][l]) and torch.equal(got[1][l], b[1][l]), (latency, l)
+            assert torch.equal(got[2], b[2]) and torch.equal(got[3], b[3])
+    # parameters replaced between calls: the graph must not keep writing the old tensors
+    net = dlc.SDAV(seed=4, weight_scale="fan_in")
+    net.train_steps(layer, x, 4)
+    ws, bs = net.get_weights()
+    net.set_weights([w * 0.5 for w in ws], bs)
+    before = [w.clone() for w in net._weights]
+    net.train_steps(layer, x, 4)
+    ref = dlc.SDAV(seed=4, weight_scale="fan_in")
+    ref.set_weights([w * 0.5 for w in ws], bs)
+    ref._biases_dec = [b.clone() for b in net._biases_dec]
+    assert not torch.equal(net._weights[layer], before[layer])
+    assert net.global_step == 8
