@@ -37,6 +37,7 @@ SIGNATURES = {
     "dlc_sdav_train_workspace_bytes": (_sz, [_i64, _i64, C.POINTER(_i64), _int, _int]),
     "dlc_sdav_train_step": (_int, [_vp, _int, _i64, _i64, _int, C.POINTER(_i64), _vp, C.POINTER(_vp), C.POINTER(_vp),
                                   C.POINTER(_vp), _vp, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _sz, _vp]),
+    "dlc_random_mask_f64": (_int, [_vp, _vp, _i64, _i64, C.c_uint64, C.c_uint64, _vp]),
     "dlc_rgb_to_gray_u8": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "dlc_harris_keypoints_workspace_bytes": (_sz, [_i64, _int, _int]),
     "dlc_harris_keypoints_u8": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -38,6 +38,124 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(const double* __restrict
     }
 }
 
+// random_mask (TensorflowWrapper.py:148-156): EXACTLY n_zeros zeros among n ones, every subset equally likely (the
+// reference concatenates zeros and ones and tf.random.shuffle's them).  Element i draws the 32-bit key
+// hash(seed, counter, i); the n_zeros smallest (key, index) pairs become the zeros -- found by one workgroup with a
+// three-pass radix select over the keys (11 + 11 + 10 bits, histograms in LDS; keys are recomputed, never stored) and a
+// fourth pass that writes the mask; equal keys at the threshold go by index (thread t owns a contiguous index range, so
+// a prefix sum over the threads orders them).  ~5 us for the 50 430 elements of the reference's first layer, where a
+// device randperm (a sort) took 83 us of a 470 us training step.
+__device__ __forceinline__ unsigned mask_key(unsigned s0, unsigned s1, unsigned i) {
+    // two rounds of murmur3's 32-bit finaliser over (index, seed, counter): 32-bit multiplies only (the 64-bit mix this
+    // replaced cost ~250 cycles a key, and the kernel is one workgroup)
+    unsigned h = i * 0x9e3779b1u + s0;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    h += s1;
+    h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+    return h;
+}
+
+constexpr int RM_THREADS = 1024;
+constexpr int RM_PER = 80;                   // keys a thread keeps in registers: n <= 81 920 draws every key once
+#define IDX(j) ((long long)tid + (long long)(j) * RM_THREADS)
+template <bool CACHED>
+__global__ __launch_bounds__(RM_THREADS) void random_mask_kernel(double* __restrict__ mask, long long n, long long n_zeros,
+                                                                 unsigned long long seed, unsigned long long counter) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned sel_bin, sel_below;
+    __shared__ unsigned eq_cnt[RM_THREADS];
+    const int tid = threadIdx.x;
+    const unsigned s0 = (unsigned)seed ^ (unsigned)(counter >> 32) * 0x27d4eb2fu;
+    const unsigned s1 = (unsigned)(seed >> 32) + (unsigned)counter * 0x165667b1u;
+    // thread t owns the indices t, t + 1024, ...: its keys stay in registers between the passes, and the mask is written
+    // in coalesced rows (a contiguous range per thread wrote 50 000 scattered doubles from one CU: 30 us)
+    unsigned keys[CACHED ? RM_PER : 1];
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int j = 0; j < RM_PER; ++j) keys[j] = IDX(j) < n ? mask_key(s0, s1, (unsigned)IDX(j)) : 0u;
+    }
+    auto key_at = [&](int j) { return CACHED ? keys[CACHED ? j : 0] : mask_key(s0, s1, (unsigned)IDX(j)); };
+    unsigned prefix = 0, pmask = 0;          // the bits of the threshold key found so far, and which bits they are
+    long long want = n_zeros;                // how many of the keys matching the prefix are still to be taken
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3 && want > 0 && want < n; ++pass) {
+        const int nb = 1 << widths[pass];
+        for (int b = tid; b < nb; b += RM_THREADS) hist[b] = 0;
+        __syncthreads();
+        if constexpr (CACHED) {
+#pragma unroll
+            for (int j = 0; j < RM_PER; ++j)
+                if (IDX(j) < n && (keys[j] & pmask) == prefix) atomicAdd(&hist[(keys[j] >> shifts[pass]) & (nb - 1)], 1u);
+        } else {
+            for (int j = 0; IDX(j) < n; ++j) {
+                const unsigned k = key_at(j);
+                if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shifts[pass]) & (nb - 1)], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {                      // the bin that holds the want-th smallest key: lane sums of nb / 64 bins, a
+            const int per = nb / 64;         // wave scan over them, then the one lane whose range holds it walks its bins
+            unsigned sum = 0;                // (one thread walking 2048 bins paid an LDS round trip per bin: 0.2 ms)
+            for (int j = 0; j < per; ++j) sum += hist[tid * per + j];
+            unsigned inc = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = __shfl_up(inc, o);
+                if (tid >= o) inc += v;
+            }
+            const unsigned exc = inc - sum;
+            if ((long long)exc < want && want <= (long long)inc) {
+                unsigned below = exc;
+                int b = tid * per;
+                for (; b < tid * per + per - 1 && (long long)(below + hist[b]) < want; ++b) below += hist[b];
+                sel_bin = (unsigned)b; sel_below = below;
+            }
+        }
+        __syncthreads();
+        prefix |= sel_bin << shifts[pass];
+        pmask |= (unsigned)(nb - 1) << shifts[pass];
+        want -= sel_below;
+        __syncthreads();
+    }
+    // keys < prefix: zeros; keys == prefix: the first `want` of them in (thread, j) order -- any fixed rule does: the keys are random
+    const bool all = n_zeros >= n, none = n_zeros <= 0;
+    unsigned mine = 0;
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int j = 0; j < RM_PER; ++j) mine += (IDX(j) < n && keys[j] == prefix) ? 1u : 0u;
+    } else {
+        for (int j = 0; IDX(j) < n; ++j) mine += key_at(j) == prefix ? 1u : 0u;
+    }
+    eq_cnt[tid] = mine;
+    __syncthreads();
+    // exclusive prefix of the threads' counts (keys equal to the threshold are a handful: 32-bit keys rarely collide)
+    if (tid < 64) {
+        unsigned sum = 0;
+        for (int j = 0; j < RM_THREADS / 64; ++j) sum += eq_cnt[tid * (RM_THREADS / 64) + j];
+        unsigned inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(inc, o);
+            if (tid >= o) inc += v;
+        }
+        hist[tid] = inc - sum;               // what lies in front of this lane's 16 threads
+    }
+    __syncthreads();
+    long long before = hist[tid / (RM_THREADS / 64)];
+    for (int t = tid / (RM_THREADS / 64) * (RM_THREADS / 64); t < tid; ++t) before += eq_cnt[t];
+    auto put = [&](int j, unsigned k) {
+        bool zero = k < prefix;
+        if (k == prefix) { zero = before < want; ++before; }
+        mask[IDX(j)] = (all || (zero && !none)) ? 0.0 : 1.0;
+    };
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int j = 0; j < RM_PER; ++j)
+            if (IDX(j) < n) put(j, keys[j]);
+    } else {
+        for (int j = 0; IDX(j) < n; ++j) put(j, key_at(j));
+    }
+}
+#undef IDX
+
 // softmax_cross_entropy_with_logits_v2(labels, logits = y) per row (SDAV.py:172), mean over rows.
 // dz2 = d(cd)/d(y) * y(1-y);  dlab (optional) = d(cd)/d(labels) = -log_softmax(y)/rows.
 __global__ __launch_bounds__(256) void xent_grad_kernel(const double* __restrict__ y, const double* __restrict__ lab,
@@ -99,22 +217,34 @@ __global__ __launch_bounds__(256) void frame_norm_kernel(const double* __restric
 __global__ void frame_norm_finish_kernel(int batch, int slices, const double* __restrict__ nrm_part,
                                          const double* __restrict__ l1_part, double* __restrict__ nrm,
                                          double* __restrict__ acc) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s = 0.0, l1 = 0.0;
-    for (int t = 0; t < batch; ++t) {
-        double n2 = 0.0;
-        for (int y = 0; y < slices; ++y) {
-            n2 += nrm_part[(long long)t * FN_MAX_SLICES + y];
-            l1 += l1_part[(long long)t * FN_MAX_SLICES + y];
+    // one thread per frame adds its slices in slice order, thread 0 then the frames in frame order: a fixed tree
+    __shared__ double fn2[256], fl1[256];
+    if (blockIdx.x != 0) return;
+    for (int t0 = 0; t0 < batch; t0 += 256) {           // (batches of more than 256 frames: in rounds, still in order)
+        const int t = t0 + threadIdx.x;
+        double n2 = 0.0, l1 = 0.0;
+        if (t < batch)
+            for (int y = 0; y < slices; ++y) {
+                n2 += nrm_part[(long long)t * FN_MAX_SLICES + y];
+                l1 += l1_part[(long long)t * FN_MAX_SLICES + y];
+            }
+        fn2[threadIdx.x] = n2; fl1[threadIdx.x] = l1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = t0 == 0 ? 0.0 : acc[2], l = t0 == 0 ? 0.0 : acc[1];
+            for (int u = 0; u < 256 && t0 + u < batch; ++u) {
+                l += fl1[u];
+                if (t0 + u + 1 < batch) {
+                    const double n = sqrt(fn2[u]);
+                    nrm[t0 + u] = n;
+                    s += n / (double)(batch - 1);
+                }
+            }
+            acc[1] = l;
+            acc[2] = s;
         }
-        if (t + 1 < batch) {
-            const double n = sqrt(n2);
-            nrm[t] = n;
-            s += n / (double)(batch - 1);
-        }
+        __syncthreads();
     }
-    acc[1] = l1;
-    acc[2] = s;
 }
 
 // dh += sparse_penalty*sign(h - s)/cs_den + consecutive term;  dz1 = dh * h(1-h)
@@ -152,8 +282,10 @@ __global__ __launch_bounds__(256) void backprop_input_kernel(const double* __res
     }
 }
 
+// out[c * ldo + r] = in[r, c]  (ldo >= rows: two transposes side by side make the K-stacked operand of the fused
+// weight-gradient product)
 __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, long long rows, long long cols,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ out, long long ldo) {
     __shared__ double tile[32][33];
     const long long r0 = (long long)blockIdx.y * 32, c0 = (long long)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
@@ -161,7 +293,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
         if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(r0 + i) * cols + c0 + tx];
     __syncthreads();
     for (int i = ty; i < 32; i += 8)
-        if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * rows + r0 + tx] = tile[tx][i];
+        if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * ldo + r0 + tx] = tile[tx][i];
 }
 
 // out[c] = sum_r in[r, c]   (rows are few hundred: one thread per column, coalesced across columns)
@@ -217,7 +349,7 @@ inline unsigned grid_for(long long n) {
 
 struct TrainWs {
     size_t xt[8], h[8], gw[8], gbe[8];     // per layer 0..layer
-    size_t y, dz2, dlab, dh, dz1a, dz1b, dxt, tr, gw2, gbd, nrm, nrm_part, l1_part, cd_part, acc, total;
+    size_t y, dz2, dlab, dh, dz1a, dz1b, dxt, tr, gbd, nrm, nrm_part, l1_part, cd_part, acc, total;   // (gw2 is gone: one product makes both uses of the tied weight)
 };
 
 TrainWs train_ws(int64_t rows, int batch, const int64_t* dims, int layer) {
@@ -228,7 +360,9 @@ TrainWs train_ws(int64_t rows, int batch, const int64_t* dims, int layer) {
     for (int l = 0; l <= layer + 1; ++l) wmax = dims[l] > wmax ? dims[l] : wmax;
     for (int l = 0; l <= layer; ++l) {
         w.xt[l] = take((size_t)rows * dims[l]);
-        w.h[l] = take((size_t)rows * dims[l + 1]);
+        // behind the trained layer's h: the first dz1 (hidden_grad_kernel's output) -- [h ; dz1] is the K-stacked B operand
+        // of the fused weight-gradient product
+        w.h[l] = take((size_t)rows * dims[l + 1] * (l == layer ? 2 : 1));
         w.gw[l] = take((size_t)dims[l] * dims[l + 1]);
         w.gbe[l] = take((size_t)dims[l + 1]);
     }
@@ -239,8 +373,7 @@ TrainWs train_ws(int64_t rows, int batch, const int64_t* dims, int layer) {
     w.dz1a = take((size_t)rows * wmax);
     w.dz1b = take((size_t)rows * wmax);
     w.dxt = take((size_t)rows * wmax);
-    w.tr = take((size_t)rows * wmax);
-    w.gw2 = take((size_t)dims[layer] * dims[layer + 1]);
+    w.tr = take((size_t)rows * wmax * 2);
     w.gbd = take((size_t)dims[layer]);
     w.nrm = take((size_t)batch);
     w.nrm_part = take((size_t)batch * FN_MAX_SLICES);
@@ -315,39 +448,46 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
         if (slices > FN_MAX_SLICES) slices = FN_MAX_SLICES;
         hipLaunchKernelGGL(frame_norm_kernel, dim3((unsigned)batch, (unsigned)slices), dim3(256), 0, st, h, (int)batch,
                            (long long)patches * N, sparse_level, cs_den, P(w.nrm_part), P(w.l1_part));
-        hipLaunchKernelGGL(frame_norm_finish_kernel, dim3(1), dim3(64), 0, st, (int)batch, (int)slices, P(w.nrm_part),
+        hipLaunchKernelGGL(frame_norm_finish_kernel, dim3(1), dim3(256), 0, st, (int)batch, (int)slices, P(w.nrm_part),
                            P(w.l1_part), P(w.nrm), P(w.acc));
     }
     GEMM(DLC_B_KN, DLC_ACT_NONE, rows, N, K, P(w.dz2), K, W[layer], N, nullptr, P(w.dh), N);      // dh = dz2 W
+    double* dz1 = P(w.h[layer]) + rows * N;                   // right behind h
     hipLaunchKernelGGL(hidden_grad_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, h, P(w.dh), P(w.nrm), (int)batch,
-                       (long long)patches * N, cs_den, sparse_level, sparse_penalty, consecutive_penalty, P(w.dz1a));
-    // decoder use of the tied weight: gw2 = dz2^T h ; b_dec gradient
+                       (long long)patches * N, cs_den, sparse_level, sparse_penalty, consecutive_penalty, dz1);
+    // The tied weight's two gradients in ONE product (they were two of 1681 x 300 x 2500, each too short a K loop to run
+    // well: 80 us apiece): d/dW = dz2^T h (decoder use) + x~^T dz1 (encoder use) = [dz2^T | x~^T] . [h ; dz1], K = 2 rows.
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0, st,
-                       P(w.dz2), rows, K, P(w.tr));
-    GEMM(DLC_B_KN, DLC_ACT_NONE, K, N, rows, P(w.tr), rows, h, N, nullptr, P(w.gw2), N);
+                       P(w.dz2), rows, K, P(w.tr), 2 * rows);
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0, st,
+                       P(w.xt[layer]), rows, K, P(w.tr) + rows, 2 * rows);
+    GEMM(DLC_B_KN, DLC_ACT_NONE, K, N, 2 * rows, P(w.tr), 2 * rows, h, N, nullptr, P(w.gw[layer]), N);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)dlc::cdiv(K, 32)), dim3(256), 0, st, P(w.dz2), rows, K, P(w.gbd));
 
     // ---- backward through the encoders layer .. 0
-    double* dz1 = P(w.dz1a);
-    double* dz1_other = P(w.dz1b);
+    double* spare[2] = {P(w.dz1a), P(w.dz1b)};
+    int which = 0;
     for (int l = layer; l >= 0; --l) {
         const long long Kl = dims[l], Nl = dims[l + 1];
-        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(Kl, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0,
-                           st, P(w.xt[l]), rows, Kl, P(w.tr));
-        GEMM(DLC_B_KN, DLC_ACT_NONE, Kl, Nl, rows, P(w.tr), rows, dz1, Nl, nullptr, P(w.gw[l]), Nl);   // x~^T dz1
+        if (l < layer) {
+            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(Kl, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0,
+                               st, P(w.xt[l]), rows, Kl, P(w.tr), rows);
+            GEMM(DLC_B_KN, DLC_ACT_NONE, Kl, Nl, rows, P(w.tr), rows, dz1, Nl, nullptr, P(w.gw[l]), Nl);   // x~^T dz1
+        }
         hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)dlc::cdiv(Nl, 32)), dim3(256), 0, st, dz1, rows, Nl, P(w.gbe[l]));
         if (l == 0) break;
         GEMM(DLC_B_NK, DLC_ACT_NONE, rows, Kl, Nl, dz1, Nl, W[l], Nl, nullptr, P(w.dxt), Kl);          // dz1 W^T
         hipLaunchKernelGGL(backprop_input_kernel, dim3(grid_for(rows * Kl)), dim3(256), 0, st, P(w.dxt),
                            l == layer ? P(w.dlab) : (const double*)nullptr, masks[l], P(w.h[l - 1]), rows, Pn, Kl,
-                           dz1_other);
-        double* t = dz1; dz1 = dz1_other; dz1_other = t;
+                           spare[which]);
+        dz1 = spare[which];
+        which ^= 1;
     }
 
     // ---- plain gradient descent on everything the loss reached (SDAV.py:223-226)
     for (int l = 0; l <= layer; ++l) {
         hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(dims[l] * dims[l + 1])), dim3(256), 0, st, W[l], P(w.gw[l]),
-                           l == layer ? P(w.gw2) : (const double*)nullptr, (long long)(dims[l] * dims[l + 1]), learning_rate);
+                           (const double*)nullptr, (long long)(dims[l] * dims[l + 1]), learning_rate);
         hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(dims[l + 1])), dim3(256), 0, st, b_enc[l], P(w.gbe[l]),
                            (const double*)nullptr, (long long)dims[l + 1], learning_rate);
     }
@@ -358,5 +498,22 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
                            sparse_penalty, consecutive_penalty, loss_out);
 #undef GEMM
     DLC_LAUNCH_CHECK(ctx, "sdav_train_step kernels");
+    return DLC_OK;
+}
+
+extern "C" int dlc_random_mask_f64(dlc_ctx* ctx, double* mask, int64_t n, int64_t n_zeros, uint64_t seed, uint64_t counter,
+                                   void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!mask || n < 1 || n_zeros < 0 || n_zeros > n) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "random_mask: bad argument");
+    if (n > (1ll << 26)) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "random_mask: n=%lld too large (one workgroup walks the keys)", (long long)n);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    if (n <= (long long)RM_THREADS * RM_PER)
+        hipLaunchKernelGGL(random_mask_kernel<true>, dim3(1), dim3(RM_THREADS), 0, (hipStream_t)stream, mask, (long long)n,
+                           (long long)n_zeros, (unsigned long long)seed, (unsigned long long)counter);
+    else
+        hipLaunchKernelGGL(random_mask_kernel<false>, dim3(1), dim3(RM_THREADS), 0, (hipStream_t)stream, mask, (long long)n,
+                           (long long)n_zeros, (unsigned long long)seed, (unsigned long long)counter);
+    DLC_LAUNCH_CHECK(ctx, "random_mask_kernel");
     return DLC_OK;
 }

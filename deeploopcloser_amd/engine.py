@@ -99,15 +99,24 @@ class Engine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    WORKSPACE_STREAMS = 4      # per name: the workspaces of at most this many streams are kept (least recently used out)
+
     def workspace(self, key, nbytes):
-        """Named scratch tensor of at least nbytes, one per (name, current stream): calls on different
-        streams must not share a workspace (a match keeps its group maxima there between its kernels)."""
+        """Named scratch tensor of at least nbytes, one per (name, current stream): calls on different streams must not
+        share a workspace (a match keeps its group maxima there between its kernels).  A caller that rotates streams
+        does not grow memory without bound: per name the WORKSPACE_STREAMS most recently used streams keep theirs, an
+        evicted one is released once its stream has finished with it (the caching allocator's record_stream)."""
         nbytes = max(int(nbytes), 256)
-        key = (key, torch.cuda.current_stream(self.device).cuda_stream)
-        t = self._ws.get(key)
+        stream = torch.cuda.current_stream(self.device)
+        k = (key, stream.cuda_stream)
+        t = self._ws.pop(k, None)
         if t is None or t.numel() < nbytes:
             t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._ws[key] = t
+        self._ws[k] = t                                   # (re-)inserted last: dicts keep insertion order
+        same = [kk for kk in self._ws if kk[0] == key]
+        for kk in same[:max(0, len(same) - self.WORKSPACE_STREAMS)]:
+            old = self._ws.pop(kk)
+            old.record_stream(torch.cuda.ExternalStream(kk[1], device=self.device) if kk[1] else torch.cuda.default_stream(self.device))
         return t
 
     def _check_out(self, name, t, shape, dtype):
@@ -359,6 +368,14 @@ class Engine:
                                                   b_c, _ptr(b_dec), float(sparse_level), float(sparse_penalty),
                                                   float(consecutive_penalty), float(learning_rate), _ptr(loss_out),
                                                   _ptr(ws), ws.numel(), self._stream()))
+
+    def random_mask(self, out, n_zeros, seed, counter):
+        """Exactly n_zeros zeros among ones, uniformly placed, into the fp64 tensor `out` (dlc_random_mask_f64)."""
+        if out.dtype != torch.float64 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("random_mask: contiguous float64 tensor on %s expected" % (self.device,))
+        self._check(self.lib.dlc_random_mask_f64(self.ctx, _ptr(out), out.numel(), int(n_zeros), int(seed) & (2 ** 64 - 1),
+                                                  int(counter) & (2 ** 64 - 1), self._stream()))
+        return out
 
     # ---- SDAV patch front-end --------------------------------------------------------------
     def rgb_to_gray(self, rgb):

@@ -50,8 +50,7 @@ class SDAV:
         dims = [self.input_shape[1]] + list(self.hidden_units)
         self._weights, self._biases = _init_weights(dims, seed, self.dtype, self.engine.device, weight_scale)
         self._biases_dec = [torch.zeros(k, dtype=self.dtype, device=self.engine.device) for k in dims[:-1]]   # :193-217
-        self._mask_gen = torch.Generator(device=self.engine.device)
-        self._mask_gen.manual_seed(int(seed) + 1)
+        self._mask_seed, self._mask_counter = int(seed) + 1, 0
         self.global_step = 0
         self._step_graphs = {}
         self.checkpoint_file = None                 # set to a path prefix to save after each layer (:273-275)
@@ -144,14 +143,11 @@ class SDAV:
 
     # ---- training (SDAV.py:242-288) ---------------------------------------------------------------
     def _mask(self, layer_n):
-        """random_mask (TensorflowWrapper.py:148-156): round(P*K*level) zeros, shuffled, [P, K]."""
+        """random_mask (TensorflowWrapper.py:148-156): round(P*K*level) zeros, shuffled, [P, K] -- a new draw per call."""
         p, k = self.get_layer_input_shape(layer_n)
-        n = p * k
-        n_zeros = int(np.round(n * float(self.corruption_level)))
-        m = torch.ones(n, dtype=torch.float64, device=self.engine.device)
-        perm = torch.randperm(n, generator=self._mask_gen, device=self.engine.device)
-        m[perm[:n_zeros]] = 0.0
-        return m.reshape(p, k)
+        m = torch.empty((p, k), dtype=torch.float64, device=self.engine.device)
+        self._fill_mask(m, layer_n)
+        return m
 
     def train_step(self, layer_n, x, masks=None):
         """One sess.run(self.train_steps[layer_n]) (SDAV.py:262) on batch x [B,30,1681]; returns
@@ -174,13 +170,12 @@ class SDAV:
         return loss
 
     def _fill_mask(self, m, layer_n):
-        """random_mask into an existing [P, K] tensor (same draw as _mask)."""
+        """A fresh random_mask into an existing [P, K] tensor: one HIP kernel (exact count, uniform placement), the draw a
+        function of (the network's seed, a counter stepped per mask)."""
         n = m.numel()
         n_zeros = int(np.round(n * float(self.corruption_level)))
-        perm = torch.randperm(n, generator=self._mask_gen, device=self.engine.device)
-        flat = m.view(-1)
-        flat.fill_(1.0)
-        flat[perm[:n_zeros]] = 0.0
+        self.engine.random_mask(m, n_zeros, self._mask_seed, self._mask_counter)
+        self._mask_counter += 1
 
     def train_steps(self, layer_n, x, n_steps):
         """n_steps consecutive sess.run(self.train_steps[layer_n]) on ONE batch (the inner loop of SDAV.fit_dataset /

@@ -130,6 +130,14 @@ int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64_t patches,
                         double learning_rate, double* loss_out, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/*
+ * tw.random_mask / TensorWrapper.corrupt's mask (src/utils/TensorflowWrapper.py:34-38,148-156): n_zeros zeros among n
+ * ones in random order -- every placement equally likely, the count exact (the reference rounds P*K*level and shuffles).
+ * The draw is a function of (seed, counter): a caller steps the counter once per mask.  mask: DEVICE fp64 [n].
+ */
+int dlc_random_mask_f64(dlc_ctx* ctx, double* mask, int64_t n, int64_t n_zeros, uint64_t seed, uint64_t counter,
+                        void* stream);
+
 /* ---- encode: SDAV patch front-end after key-point detection -------------------------------- */
 /*
  * cv2.imread(path, IMREAD_GRAYSCALE) of a colour frame (src/sdav/input/CvInputParser.py:32):

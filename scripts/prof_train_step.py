@@ -1,17 +1,13 @@
-"""Workload for a kernel trace of one SDAV training step (layer 0, the reference's batch of 10 frames), as SDAV.fit
-runs it (split-K scratch on):  rocprofv3 --kernel-trace --stats -- python3 scripts/prof_train_step.py"""
+"""rocprofv3 target: 60 layer-0 training steps at the reference's batch of 10 frames (SDAV.train_steps)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deeploopcloser_amd as dlc
 eng = dlc.default_engine()
-g = torch.Generator(device=eng.device); g.manual_seed(0)
-layer = int(os.environ.get("DLC_LAYER", "0"))
-x = torch.rand((10, 30, 1681), generator=g, device=eng.device, dtype=torch.float64)
 net = dlc.SDAV(seed=3)
-masks = [net._mask(l) for l in range(layer + 1)]
+x = torch.rand((10, 30, 1681), dtype=torch.float64, device=eng.device)
+masks = [net._mask(0)]
 with eng.latency_mode():
-    for _ in range(int(os.environ.get("DLC_STEPS", "20"))):
-        net.train_step(layer, x, masks)
-    torch.cuda.synchronize()
-print("done")
+    for _ in range(60):
+        net.train_step(0, x, masks)
+torch.cuda.synchronize()

@@ -1337,3 +1337,14 @@ def test_space_to_depth_and_conv1_equivalence(eng, dlc):
     assert outs[0].shape == (2, 46, 58, 96) and np.abs(outs[0].cpu().numpy() - ref1).max() < 1e-9 * np.abs(ref1).max()
     direct = eng.conv2d(torch.from_numpy(x).to(eng.device), net._w[0], net._b[0], 11, 11, 4, 0, 0, 46, 58, L.DLC_ACT_RELU)
     assert float((direct - outs[0]).abs().max()) < 1e-9 * np.abs(ref1).max()
+
+
+def test_engine_workspaces_are_bounded_per_name(eng):
+    """Engine.workspace keeps one tensor per (name, stream); a caller that rotates streams must not accumulate them."""
+    streams = [torch.cuda.Stream(device=eng.device) for _ in range(12)]
+    q = torch.zeros((4, 64), dtype=torch.bfloat16, device=eng.device)
+    for s in streams:
+        with torch.cuda.stream(s):
+            eng.match_topk(q, q, 2)
+    torch.cuda.synchronize()
+    assert sum(1 for k in eng._ws if k[0] == "topk") <= eng.WORKSPACE_STREAMS

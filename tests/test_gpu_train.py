@@ -132,3 +132,40 @@ def test_train_steps_graph_replay_equals_eager_steps(layer):
     ref._biases_dec = [b.clone() for b in net._biases_dec]
     assert not torch.equal(net._weights[layer], before[layer])
     assert net.global_step == 8
+
+
+def test_random_mask_kernel_counts_and_uniformity():
+    """dlc_random_mask_f64 (TensorflowWrapper.py:148-156): the zero count is EXACT for every size and level, a draw is a
+    function of (seed, counter), different counters give different masks, and every position is zero with the same
+    frequency (400 draws of 3000 elements at level 0.3: per-position frequency within 5 sigma of 0.3, mean exact)."""
+    import deeploopcloser_amd as dlc
+    eng = dlc.default_engine()
+    for n, nz in ((1, 0), (1, 1), (7, 3), (1024, 1024), (1025, 0), (50430, 15129), (75000, 22500), (200001, 1), (3000, 2999)):
+        m = torch.empty(n, dtype=torch.float64, device=eng.device)
+        eng.random_mask(m, nz, seed=5, counter=n)
+        assert int((m == 0).sum()) == nz and int((m == 1).sum()) == n - nz, (n, nz)
+        m2 = torch.empty_like(m)
+        eng.random_mask(m2, nz, seed=5, counter=n)
+        assert torch.equal(m, m2)
+        if 0 < nz < n and n > 100:
+            eng.random_mask(m2, nz, seed=5, counter=n + 1)
+            assert not torch.equal(m, m2)
+            eng.random_mask(m2, nz, seed=6, counter=n)
+            assert not torch.equal(m, m2)
+    n, nz, draws = 3000, 900, 400
+    acc = torch.zeros(n, dtype=torch.float64, device=eng.device)
+    m = torch.empty(n, dtype=torch.float64, device=eng.device)
+    for c in range(draws):
+        eng.random_mask(m, nz, seed=77, counter=c)
+        acc += 1.0 - m
+    freq = (acc / draws).cpu().numpy()
+    assert abs(freq.mean() - 0.3) < 1e-12
+    sigma = np.sqrt(0.3 * 0.7 / draws)
+    assert np.abs(freq - 0.3).max() < 5 * sigma, np.abs(freq - 0.3).max() / sigma
+    # neighbouring positions are not correlated (a hash of the index, not a stride pattern)
+    net = dlc.SDAV(seed=1)
+    a, b = net._mask(0), net._mask(0)
+    assert a.shape == (30, 1681) and int((a == 0).sum()) == int(np.round(30 * 1681 * 0.3)) and not torch.equal(a, b)
+    z = (a.view(-1) == 0).double()
+    corr = float(((z[:-1] - 0.3) * (z[1:] - 0.3)).mean() / (0.3 * 0.7))
+    assert abs(corr) < 0.02, corr
