@@ -17,12 +17,18 @@
 // frames), and the result is the arg-min of the true distances either way.
 // Test infrastructure never enters: the oracle (oracle/similarity.py) only checks the outcome in tests/.
 //
-// Layout: X = (q1 | q2 | q3), Y = (q3 | q2 | q1) along K (Kp = H rounded up to 256, zero padded); then class 4 is
-// X[:, 0:3Kp] . Y[:, 0:3Kp]^T, class 3 is X[:, 0:2Kp] . Y[:, Kp:3Kp]^T, class 2 is X[:, 0:Kp] . Y[:, 2Kp:3Kp]^T: one NT
-// int8 GEMM over three K segments with the accumulators shifted right by 7 between them.  In memory both are tiled the
-// way the MFMA reads them: [16-row group][k-step of 64 bytes][lane l: row l % 16, bytes (l / 16) * 16 .. + 15] -- every
-// LDS-DMA piece is then 1 KiB of consecutive bytes, eight whole cache lines.  (Row-major slices made each piece 16
-// half lines; every line crossed the L2 -> L1 path twice, once per k-step, and the kernel sat at 12 B / clock / CU.)
+// Layout: one panel, X = (q1 | q2 | q3) along K (Kp = H rounded up to 256, zero padded), tiled the way the MFMA reads
+// it: [16-row group][k-step of 64 bytes: slice-major, 3 Kp / 64 of them][lane l: row l % 16, bytes (l / 16) * 16 .. + 15] --
+// every LDS-DMA piece is 1 KiB of consecutive bytes, eight whole cache lines.  Row patches and column patches are groups
+// of the same panel.  (Row-major slices made each piece 16 half lines; every line crossed the L2 -> L1 path twice, once
+// per k-step, and the kernel sat at 12 B / clock / CU.)
+//
+// r03: ONE sweep over K with three accumulator sets.  A k-step brings the 64 bytes of all three slices of the tile's rows
+// and columns and feeds the six slice products of the three classes at once -- C2 += q1.q1', C3 += q2.q1' + q1.q2',
+// C4 += q3.q1' + q2.q2' + q1.q3' -- and the epilogue forms acc = C2 + ((C3 + (C4 >> 7)) >> 7), the same integer as
+// before.  The r02 kernel had one accumulator set and walked K three times (classes 4, 3, 2 with a shift in between):
+// 240 k-steps of 32 MFMAs per wave instead of 40 of 96, every slice streamed again per class (18.6 GB over the fabric
+// for 0.49 GB of panels, profiles/r02i), 12 LDS fragment reads per 32 MFMAs instead of 24 per 96.
 #include "gemm_internal.h"
 
 namespace dlc_gemm {
@@ -31,16 +37,17 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) int v4i;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int GI_T = 256;                 // tile: 256 row patches x 256 column patches, 8 waves of 128 x 64
-constexpr int GI_KS = 64;                 // bytes of K per LDS stage = one MFMA k-step
-constexpr int GI_KPAD = 256;              // the slices' padded length is a multiple of this: every segment an even number of stages, at least 4
-constexpr int GI_HALF = GI_T * GI_KS;     // one operand's part of a stage: 16 KiB
-constexpr int GI_STAGE = 2 * GI_HALF;
-constexpr int GI_NSTAGE = 4;              // 128 KiB: three stages in flight behind the one being read
+constexpr int GI_T = 128;                 // tile: 128 row patches x 128 column patches, 4 waves of 64 x 64
+constexpr int GI_KS = 64;                 // bytes of K (per slice) per LDS stage = one MFMA k-step
+constexpr int GI_KPAD = 256;              // the slices' padded length is a multiple of this
+constexpr int GI_HALF = GI_T * GI_KS * 3; // one operand's part of a stage: 8 groups x 3 slices x 1 KiB = 24 KiB
+constexpr int GI_STAGE = 2 * GI_HALF;     // 48 KiB
+constexpr int GI_NSTAGE = 3;              // 144 KiB: two stages in flight behind the one being read
+constexpr int GI_BR = 4, GI_BC = 8;       // an XCD's 32 resident workgroups take one block of 4 x 8 tiles
 
 struct GramI8Args {
     const char* X;                        // row panel: the group of row patch row0 (a multiple of 16)
-    const char* Y;                        // column panel: the group of column patch col0 (a multiple of 16)
+    const char* Y;                        // column panel: the group of column patch col0 (a multiple of 16); the same layout
     int* out;                             // [mrows, ldo] accumulators (units of 2^-14 in u . u)
     long long ldo, mrows, ncols;
     long long gpitch;                     // bytes of one 16-row group: 3 Kp / 64 k-steps of 1 KiB
@@ -50,34 +57,17 @@ struct GramI8Args {
     long long tri_row0, tri_col0;
 };
 
-// two 1 KiB LDS-DMA pieces (two 16-row groups: wave-uniform bases b0, b1; lane l fetches bytes l * 16 .. + 15).  Inline
-// asm so that hipcc does not count them in vmcnt; M0 carries the wave-uniform LDS destination and is saved / restored
-// because the compiler owns it.
-__device__ __forceinline__ void dma2(unsigned voff, const char* b0, const char* b1, unsigned lds) {
-    unsigned keep;
-    asm volatile(
-        "s_nop 4\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_add_u32 m0, %4, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(b0), "s"(b1), "s"(lds)
-        : "memory", "scc");
-}
-
-// ... and one piece, the one the K loop issues.  Here M0 is declared clobbered instead of saved and restored, and the
-// leading s_nop is gone (base and destination are scalar-ALU results): 6.25 -> 6.11 ms.  hipcc warns that M0 is a
-// reserved register it may not preserve across the statement -- nothing else in this kernel reads or writes M0 (checked
-// in the ISA: every M0 access lies inside these asm statements), which is what makes it safe HERE and only here.
+// One 1 KiB LDS-DMA piece: lane l fetches bytes l * 16 .. + 15 behind the wave-uniform base `src` (+ voff, which carries
+// the k-step) into LDS at `lds` + l * 16.  Inline asm so that hipcc does not count it in vmcnt (it would wait for
+// vmcnt(0) in front of every LDS read).  M0 carries the LDS destination and is declared CLOBBERED, not saved and restored
+// (two more instructions per piece, twelve pieces per k-step of a wave that has nothing else to hide them behind): hipcc
+// warns that M0 is a reserved register it may not preserve across the statement, so the BUILD checks what the claim rests
+// on -- `make` runs csrc/check_m0.py, which disassembles this kernel and fails if any instruction outside these asm
+// statements reads or writes M0.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void dma1(unsigned voff, const char* b0, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(b0), "s"(lds) : "memory", "m0");
+__device__ __forceinline__ void dma1(unsigned voff, const char* src, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(lds) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 
@@ -87,20 +77,19 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 
-// LDS stage: the row panel's 16 groups of 16 rows, a 1 KiB block each in MFMA operand order -- lane l of a block holds
-// row l % 16, bytes (l / 16) * 16 .. + 15 of the k-step -- then the column panel's the same.  A fragment read is one
-// ds_read_b128 at block + lane * 16.
+// LDS stage (48 KiB): the row panel's 8 groups of 16 rows x 3 slices, a 1 KiB block each in MFMA operand order -- block
+// (g * 3 + s), lane l of a block holds row l % 16, bytes (l / 16) * 16 .. + 15 of the k-step of slice s -- then the
+// column panel's the same.  A fragment read is one ds_read_b128 at block + lane * 16.
 //
-// Pipeline: four stages; iteration t multiplies the fragments of stage t, which it read from LDS during iteration t-1,
-// while it reads those of stage t+1 -- one wave per SIMD (256 accumulators per lane), so nothing else hides the LDS
-// latency.  Barrier t therefore says "stage t+1 has landed everywhere and everybody is through reading stage t", and
-// behind it stage t+4 goes into stage t's slot: three k-steps for a piece to arrive.
-__global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
+// Pipeline: three stages; iteration t multiplies the fragments of stage t, which it read from LDS during iteration t-1,
+// while it reads those of stage t+1 and issues the DMA of stage t+3 into stage t's slot -- ONE wave per SIMD (192
+// accumulators + two fragment buffers of 96 registers), so the interleaving inside the wave is what hides the LDS and
+// DMA latencies.  Barrier t says "stage t+1 has landed everywhere and everybody is through reading stage t".
+__global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem_i8[];
-    // workgroup -> tile: ids go round-robin to the 8 XCDs; an XCD's 32 resident workgroups take one 4 x 8 block of
-    // tiles (12 panels feed 32 tiles out of that XCD's L2).  Only blocks with a wanted tile are numbered, row by row, and
-    // dealt to the XCDs in turn: dealt by block column, the triangle gave XCD 7 2.4 times the work of XCD 0 (a third of
-    // the chip's wave time idle, profiles/r02i).
+    // workgroup -> tile: ids go round-robin to the 8 XCDs; an XCD's 32 resident workgroups take one GI_BR x GI_BC block
+    // of tiles (12 panels feed 32 tiles out of that XCD's L2).  Only blocks with a wanted tile are numbered, row by row,
+    // and dealt to the XCDs in turn: dealt by block column, the triangle gave XCD 7 2.4 times the work of XCD 0.
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3, local = slot & 31;
     int want = (slot >> 5) * 8 + xcd;                 // index among the wanted blocks
@@ -108,168 +97,148 @@ __global__ __launch_bounds__(512) void gram_i8_kernel(const GramI8Args p) {
     bool found = false;
     for (; si < p.nsm; ++si) {
         // first block column of block row si with a tile that holds a (row frame < column frame) entry
-        const long long row_frame = (p.tri_row0 + (long long)si * 4 * GI_T) / p.tri_p;
+        const long long row_frame = (p.tri_row0 + (long long)si * GI_BR * GI_T) / p.tri_p;
         long long c_need = (row_frame + 1) * p.tri_p - p.tri_col0;      // first wanted column patch (relative)
         if (c_need < 0) c_need = 0;
-        const int sj_min = (int)(c_need / (8 * GI_T));
+        const int sj_min = (int)(c_need / (GI_BC * GI_T));
         const int cnt = p.nsn - sj_min;
         if (cnt <= 0) continue;
         if (want < cnt) { sj = sj_min + want; found = true; break; }
         want -= cnt;
     }
     if (!found) return;
-    const int tile_m = si * 4 + (local >> 3), tile_n = sj * 8 + (local & 7);
+    const int tile_m = si * GI_BR + (local >> 3), tile_n = sj * GI_BC + (local & 7);
     if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
     const long long m0 = (long long)tile_m * GI_T, n0 = (long long)tile_n * GI_T;
     if ((p.tri_col0 + n0 + GI_T - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;   // no (row frame < column frame) entry
 
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int wr = w >> 2, wc = w & 3;              // 128 row patches x 64 column patches per wave
+    const int wr = w >> 1, wc = w & 1;              // 64 row patches x 64 column patches per wave
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem_i8;
-    const unsigned voff = lane * 16;
-    // this wave's two groups of each panel (groups 2 w, 2 w + 1 of the tile's 16)
-    const char* xb = uniform_ptr(p.X + (m0 / 16 + w * 2) * p.gpitch);
-    const char* yb = uniform_ptr(p.Y + (n0 / 16 + w * 2) * p.gpitch);
-    const int n64 = p.kp / GI_KS;
-    const int nst = 6 * n64;
-
-    // The next stage to fetch and where it lies, kept as running scalars: worked out from the stage number (two
-    // compares, selects, a multiply, a readfirstlane) the address arithmetic of an issue was ~30 scalar and 2 vector
-    // instructions in front of its four DMA instructions, in the gap of every iteration.
-    const char* xb1 = xb + p.gpitch;
-    const char* yb1 = yb + p.gpitch;
-    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_base + w * 2048);
-    int is_t = 0, is_x = 0, is_y = 0, is_wrap = 3 * n64, is_ybase = n64 * 1024;
-    auto issue = [&]() {
-        const unsigned dst = lds_w + (is_t & (GI_NSTAGE - 1)) * GI_STAGE;
-        dma2(voff, xb + is_x, xb1 + is_x, dst);
-        dma2(voff, yb + is_y, yb1 + is_y, dst + GI_HALF);
-        ++is_t; is_x += 1024; is_y += 1024;                                 // k-step blocks of 1 KiB
-        if (is_t == is_wrap) {                                              // the next segment: X from its start, Y one slice on
-            is_x = 0; is_y = is_ybase;
-            is_ybase += n64 * 1024; is_wrap += 2 * n64;                     // 3 n64, then 5 n64
-        }
+    const int n64 = p.kp / GI_KS;                   // k-steps (per slice): a multiple of 4, at least 4
+    // this wave's DMA share of a stage: groups 2 w, 2 w + 1 of each panel, three slices each = 12 pieces.  Piece b:
+    // panel b / 6, group (b % 6) / 3, slice b % 3; its source base is wave-uniform, the k-step rides in the lanes' offset.
+    const char* src[12];
+#pragma unroll
+    for (int b = 0; b < 12; ++b) {
+        const char* panel = b < 6 ? p.X + (m0 / 16) * p.gpitch : p.Y + (n0 / 16) * p.gpitch;
+        src[b] = uniform_ptr(panel + (long long)(w * 2 + (b % 6) / 3) * p.gpitch + (long long)(b % 3) * n64 * 1024);
+    }
+    // its LDS destination inside a stage: block ((2 w + group) * 3 + slice) of the panel's half
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_base + w * 6 * 1024);
+    unsigned voff_issue = lane * 16;                // lanes' offset of the next stage to fetch: + 1 KiB per k-step
+    int is_slot = 0;                                // ... and the slot it goes to
+    auto issue_piece = [&](int b) {
+        dma1(voff_issue, src[b], lds_w + is_slot * GI_STAGE + (b / 6) * GI_HALF + (b % 6) * 1024);
+    };
+    auto issue_done = [&]() {
+        voff_issue += 1024;
+        is_slot = is_slot == GI_NSTAGE - 1 ? 0 : is_slot + 1;
     };
 
-    // the same, a piece at a time (piece 0..3: X group 0, X group 1, Y group 0, Y group 1): between the MFMAs of an iteration
-    auto issue_piece = [&](int piece) {
-        const unsigned dst = lds_w + (is_t & (GI_NSTAGE - 1)) * GI_STAGE + (piece >> 1) * GI_HALF + (piece & 1) * 1024;
-        const char* src = (piece >> 1) ? ((piece & 1) ? yb1 : yb) + is_y : ((piece & 1) ? xb1 : xb) + is_x;
-        dma1(voff, src, dst);
-        if (piece == 3) {
-            ++is_t; is_x += 1024; is_y += 1024;
-            if (is_t == is_wrap) {
-                is_x = 0; is_y = is_ybase;
-                is_ybase += n64 * 1024; is_wrap += 2 * n64;
-            }
-        }
-    };
-
-    v4i acc[4][8];                          // [column group j of this wave][row group i]
+    v4i c2[4][4], c3[4][4], c4[4][4];               // [column group j][row group i] of the three classes
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = v4i{0, 0, 0, 0};
-    v4i fx[2][8], fy[2][4];
+        for (int i = 0; i < 4; ++i) { c2[j][i] = v4i{0, 0, 0, 0}; c3[j][i] = v4i{0, 0, 0, 0}; c4[j][i] = v4i{0, 0, 0, 0}; }
+    v4i fx[3][4], fy[3][4];                         // [slice][group]: ONE set (96 registers), reloaded in place (below)
 
-    const char* sx = smem_i8 + (wr * 8) * 1024 + lane * 16;
-    const char* sy = smem_i8 + GI_HALF + (wc * 4) * 1024 + lane * 16;
-    // (Measured and not kept: the two waves of a SIMD issuing their DMA at opposite ends of the iteration -- 6.35 -> 6.58 ms;
-    // a fifth LDS stage, all 160 KiB, four k-steps for a piece to arrive -- 6.15 vs 6.17 ms: its latency is covered.)
+    // fragment (slice s, group g) of this wave: row panel block ((wr * 4 + g) * 3 + s), column panel the same with wc
+    const char* sx = smem_i8 + (wr * 4) * 3 * 1024 + lane * 16;
+    const char* sy = smem_i8 + GI_HALF + (wc * 4) * 3 * 1024 + lane * 16;
+#define GI_RDX(S, SO) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) fx[S][g_] = *(const v4i*)(sx + (SO) + (g_ * 3 + (S)) * 1024)
+#define GI_RDY(S, SO) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) fy[S][g_] = *(const v4i*)(sy + (SO) + (g_ * 3 + (S)) * 1024)
+    // The MFMA as inline asm with the accumulator PINNED to the AGPR file ("+a"): through the builtin hipcc kept part of
+    // the 192 accumulators in VGPRs and moved them across at the loop's back edge -- 276 v_accvgpr_read / _write per k-step
+    // beside 96 MFMAs.  volatile: the asm statements (these and the DMA pieces) keep their source order.
+#define GI_MFMA(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+    // sixteen MFMAs of one slice product: column slice SY against row slice SX into class accumulator ACC
+#define GI_PROD(ACC, SY, SX)                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+            GI_MFMA(ACC[j][i], fy[SY][j], fx[SX][i]);
+    // ... with four DMA pieces of the stage three ahead, one behind every fourth MFMA: a piece is three instructions, which
+    // fit in the shadow of the MFMA in front of them (two five-instruction pieces behind every fourth MFMA left the matrix
+    // pipe idle for their issue time: the "no DMA" build was 1.0 ms of 6.3 faster)
+#define GI_PROD_DMA(ACC, SY, SX, B0, ISSUE)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+            GI_MFMA(ACC[j][i], fy[SY][j], fx[SX][i]);                                                            \
+        if (ISSUE) issue_piece((B0) + j);                                                                       \
+    }
     // s_waitcnt immediates (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
     // builtin, not inline asm, so that hipcc's own wait insertion knows the LDS reads are done
-    constexpr int GI_WAIT_VM8 = 0x0078, GI_WAIT_VM4 = 0x0074, GI_WAIT_VM0 = 0x0070;
-#define GI_STAMP(K)
-    // (a macro: through a generic lambda hipcc kept the fragment and accumulator arrays in scratch memory; and the steady
-    // state has no branch in it -- with the tail's conditions inside, hipcc moved accumulators between register files
-    // in every iteration)
-#define GI_BODY(T, CUR, NXT, WAIT, ISSUE)                                                                                  \
-    {                                                                                                                      \
-        const int t_ = (T);                                                                                                \
-        /* this wave's pieces of stage t+1 (4 instructions per stage; stages up to t+3 are in flight) and its LDS reads */ \
-        /* of stage t, whose slot is about to be overwritten */                                                            \
-        GI_STAMP(0)                                                                                                        \
-        __builtin_amdgcn_s_waitcnt(WAIT);                                                                                  \
-        asm volatile("" ::: "memory");                                                                                     \
-        GI_STAMP(1)                                                                                                        \
-        __builtin_amdgcn_s_barrier();                                                                                      \
-        asm volatile("" ::: "memory");                                                                                     \
-        GI_STAMP(2)                                                                                                        \
-        const int so = ((t_ + 1) & (GI_NSTAGE - 1)) * GI_STAGE;                                                            \
-        /* MFMAs first (their fragments are in registers), the 12 reads of stage t+1 one per pair of MFMAs, the DMA of  */ \
-        /* stage t+4 behind them: all eight waves leave the barrier together, and whatever stands between the barrier    */ \
-        /* and a wave's first MFMA is time both matrix-pipe users of a SIMD spend idle (reads + DMA first: 6.8 ms)       */ \
-        /* (the last iteration reads a slot nobody writes any more: unused) */                                            \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
-            fx[NXT][2 * j] = *(const v4i*)(sx + so + (2 * j) * 1024);                                                      \
-            fx[NXT][2 * j + 1] = *(const v4i*)(sx + so + (2 * j + 1) * 1024);                                              \
-            fy[NXT][j] = *(const v4i*)(sy + so + j * 1024);                                                                \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                  \
-                acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fy[CUR][j], fx[CUR][i], acc[j][i], 0, 0, 0);           \
-            _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) {                                                             \
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                         \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                         \
-            }                                                                                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            /* one DMA piece of stage t+4 behind each quarter of the MFMAs (all four behind the last MFMA measured the   */  \
-            /* same: cycle stamps -- GI_EXP_STAMPS -- put a stage at 1490 cycles for 1024 of MFMA per SIMD, none of it    */  \
-            /* waiting for DMA data; the first wave of a SIMD is through its body after 920 and stands 530 at the barrier, */  \
-            /* the second takes 1285: about 60 cycles per DMA piece that neither wave of the SIMD issues MFMAs in)        */  \
-            if (ISSUE) issue_piece(j);                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-        }                                                                                                                  \
+    constexpr int GI_WAIT_VM12 = 0x007c, GI_WAIT_VM0 = 0x0070;
+    // One k-step.  The six slice products run in the order (y0 x0) (y0 x1) (y0 x2) | (y1 x0) (y2 x0) (y1 x1): behind the
+    // third one slice 0 of the columns and slice 2 of the rows are dead, behind the fifth slice 0 of the rows and slice 2
+    // of the columns -- their registers take the NEXT stage's fragments at those points, and slice 1 of both is fetched at
+    // the start of its own k-step (sixteen MFMAs ahead of its first use).  The workgroup's one barrier sits behind the
+    // third product: it says "stage t+1 has landed everywhere, and everybody has read the last of stage t" (slice 1, at
+    // the start of this k-step), so behind it the DMA of stage t+3 may overwrite stage t's slot.
+    int cur = 0, nxt = 1;                           // LDS slots of stage t and stage t+1
+#define GI_STEP(WAIT, ISSUE)                                                                                    \
+    {                                                                                                           \
+        const int so_c = cur * GI_STAGE, so_n = nxt * GI_STAGE;                                                 \
+        GI_RDX(1, so_c); GI_RDY(1, so_c);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        GI_PROD(c2, 0, 0)                                                                                       \
+        GI_PROD(c3, 0, 1)                                                                                       \
+        GI_PROD(c4, 0, 2)                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        __builtin_amdgcn_s_waitcnt(WAIT);           /* this wave's pieces of stage t+1 */                        \
+        asm volatile("" ::: "memory");                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        asm volatile("" ::: "memory");                                                                          \
+        GI_RDY(0, so_n); GI_RDX(2, so_n);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        GI_PROD_DMA(c3, 1, 0, 0, ISSUE)                                                                         \
+        GI_PROD_DMA(c4, 2, 0, 4, ISSUE)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        GI_RDX(0, so_n); GI_RDY(2, so_n);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        GI_PROD_DMA(c4, 1, 1, 8, ISSUE)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        if (ISSUE) issue_done();                                                                                \
+        cur = nxt;                                                                                              \
+        nxt = nxt == GI_NSTAGE - 1 ? 0 : nxt + 1;                                                               \
     }
-    // the K stages of one segment, two per trip (the fragment buffers alternate)
-#define GI_RUN(T_LO, T_HI)                                                                                                 \
-    for (int t = (T_LO); t < (T_HI); t += 2) {                                                                             \
-        GI_BODY(t, 0, 1, GI_WAIT_VM8, true)                                                          \
-        GI_BODY(t + 1, 1, 0, GI_WAIT_VM8, true)                                                       \
+    // prologue: stages 0 .. 2 in flight; of stage 0 everything but slice 1 into the registers
+#pragma unroll
+    for (int t = 0; t < GI_NSTAGE; ++t) {
+#pragma unroll
+        for (int b = 0; b < 12; ++b) issue_piece(b);
+        issue_done();
     }
-    auto shift = [&]() {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[j][i] = acc[j][i] >> 7;
-    };
-#pragma unroll
-    for (int t = 0; t < GI_NSTAGE; ++t) issue();                         // nst >= 24
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                    // stage 0
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                    // stage 0 (12 pieces per stage and wave)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < 8; ++j) fx[0][j] = *(const v4i*)(sx + j * 1024);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fy[0][j] = *(const v4i*)(sy + j * 1024);
-    // (iteration 0's barrier finds stage 0's readers done only because every wave reads it before that barrier)
-    // (one copy of the steady-state loop for the three segments: as three loops in a row, hipcc gave the first one a
-    // register assignment that moved 200 accumulators between the register files in every trip)
+    GI_RDY(0, 0); GI_RDX(2, 0); GI_RDX(0, 0); GI_RDY(2, 0);
+    // steady state: k-steps 0 .. n64 - 4 fetch the stage three ahead; the last three fetch nothing
 #pragma unroll 1
-    for (int seg = 0; seg < 3; ++seg) {
-        const int t_lo = seg == 0 ? 0 : seg == 1 ? 3 * n64 : 5 * n64;
-        const int t_hi = seg == 0 ? 3 * n64 : seg == 1 ? 5 * n64 : nst - GI_NSTAGE;     // n64 >= 4: the last segment holds the tail
-        GI_RUN(t_lo, t_hi)
-        if (seg < 2) shift();
-    }
-    GI_BODY(nst - 4, 0, 1, GI_WAIT_VM8, false)       // stages nst-3 .. nst-1 in flight
-    GI_BODY(nst - 3, 1, 0, GI_WAIT_VM4, false)
-    GI_BODY(nst - 2, 0, 1, GI_WAIT_VM0, false)
-    GI_BODY(nst - 1, 1, 0, GI_WAIT_VM0, false)
-#undef GI_STAMP
-#undef GI_RUN
-#undef GI_BODY
+    for (int t = 0; t < n64 - GI_NSTAGE; ++t) GI_STEP(GI_WAIT_VM12, true)
+    GI_STEP(GI_WAIT_VM12, false)
+    GI_STEP(GI_WAIT_VM0, false)
+    GI_STEP(GI_WAIT_VM0, false)                     // (its reads of "stage n64" fetch a slot nobody writes any more: unused)
+#undef GI_STEP
+#undef GI_PROD_DMA
+#undef GI_PROD
+#undef GI_MFMA
+#undef GI_RDX
+#undef GI_RDY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // D[m][n] of MFMA (j, i): m = column patch (wc * 4 + j) * 16 + (lane / 16) * 4 + v, n = row patch (wr * 8 + i) * 16 + lane % 16
+    // acc = C2 + floor((C3 + floor(C4 / 128)) / 128): non-negative integers, arithmetic shifts
+    // D[m][n] of MFMA (j, i): m = column patch (wc * 4 + j) * 16 + (lane / 16) * 4 + v, n = row patch (wr * 4 + i) * 16 + lane % 16
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const long long r = m0 + (wr * 8 + i) * 16 + (lane & 15);
+    for (int i = 0; i < 4; ++i) {
+        const long long r = m0 + (wr * 4 + i) * 16 + (lane & 15);
         if (r >= p.mrows) continue;
         int* orow = p.out + r * p.ldo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long long c = n0 + (wc * 4 + j) * 16 + (lane >> 4) * 4;
-            if (c + 3 < p.ldo) *(v4i*)(orow + c) = acc[j][i];          // ldo is a multiple of 4 >= ncols
+            const v4i acc = c2[j][i] + ((c3[j][i] + (c4[j][i] >> 7)) >> 7);
+            if (c + 3 < p.ldo) *(v4i*)(orow + c) = acc;                  // ldo is a multiple of 4 >= ncols
         }
     }
 }
@@ -400,9 +369,11 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
             *(uint4*)(xg + (0ll * nks + ks) * 1024) = v1;
             *(uint4*)(xg + (1ll * nks + ks) * 1024) = v2;
             *(uint4*)(xg + (2ll * nks + ks) * 1024) = v3;
-            *(uint4*)(yg + (0ll * nks + ks) * 1024) = v3;
-            *(uint4*)(yg + (1ll * nks + ks) * 1024) = v2;
-            *(uint4*)(yg + (2ll * nks + ks) * 1024) = v1;
+            if (Y) {                            // (the r02 kernel's column panel, slices reversed; the r03 kernel reads X for both)
+                *(uint4*)(yg + (0ll * nks + ks) * 1024) = v3;
+                *(uint4*)(yg + (1ll * nks + ks) * 1024) = v2;
+                *(uint4*)(yg + (2ll * nks + ks) * 1024) = v1;
+            }
         }
     }
     for (int o = 16; o <= 32; o <<= 1) {
@@ -506,14 +477,14 @@ int gram_upper_i8(dlc_ctx* ctx, int64_t mrows, int64_t ncols, int64_t H, const c
     a.Y = Y + (col0 / 16) * a.gpitch;
     a.out = out; a.ldo = ldo; a.mrows = mrows; a.ncols = ncols;
     a.tiles_m = (int)dlc::cdiv(mrows, (int64_t)GI_T); a.tiles_n = (int)dlc::cdiv(ncols, (int64_t)GI_T);
-    a.nsm = (a.tiles_m + 3) / 4;
-    a.nsn = (a.tiles_n + 7) / 8;
+    a.nsm = (a.tiles_m + GI_BR - 1) / GI_BR;
+    a.nsn = (a.tiles_n + GI_BC - 1) / GI_BC;
     a.nsup = 0;                               // blocks with a wanted tile (the kernel numbers them the same way)
     for (int si = 0; si < a.nsm; ++si) {
-        const long long row_frame = (row0 + (long long)si * 4 * GI_T) / patches;
+        const long long row_frame = (row0 + (long long)si * GI_BR * GI_T) / patches;
         long long c_need = (row_frame + 1) * patches - col0;
         if (c_need < 0) c_need = 0;
-        const int cnt = a.nsn - (int)(c_need / (8 * GI_T));
+        const int cnt = a.nsn - (int)(c_need / (GI_BC * GI_T));
         if (cnt > 0) a.nsup += cnt;
     }
     if (a.nsup == 0) return DLC_OK;
@@ -527,7 +498,7 @@ int gram_upper_i8(dlc_ctx* ctx, int64_t mrows, int64_t ncols, int64_t H, const c
     // bench.py's kernel-only timing (dlc_set_profiling): an event pair around the kernel on its stream
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
-    hipLaunchKernelGGL(gram_i8_kernel, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(gram_i8_kernel, dim3(grid), dim3(256), lds, st, a);
     DLC_LAUNCH_CHECK(ctx, "gram_i8_kernel");
     if (ctx->profiling) {
         DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[prof_slot], st));

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __rest
 }
 
 struct SimWs {
-    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, qy, total;
+    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, total;
     long long chunk_frames, chunk_frames_i8;
 };
 
@@ -778,12 +778,11 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     // the descriptors transposed [H, N*P] (one extra pass over them): the fp64 Gram blocks then read their B operand as
     // [K,N] -- 1 KiB contiguous per k-row and tile instead of 128 scattered 128-byte row segments (an even N*P keeps
     // the rows 16-byte aligned for the LDS-DMA kernel; an odd one falls back to the [N,K] form)
-    w.nu2 = w.qx = w.qy = 0;
+    w.nu2 = w.qx = 0;
     if (filter) {
         const size_t panel = dlc_gemm::sim_filter_panel_bytes(N * P, H);
         w.nu2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
-        w.qx = o; o += dlc::align_up(panel, 256);
-        w.qy = o; o += dlc::align_up(panel, 256);
+        w.qx = o; o += dlc::align_up(panel, 256);        // ONE panel: row and column patches are groups of it
         w.desc_t = o;
     } else {
         w.desc_t = o;
@@ -875,10 +874,9 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         unsigned long long* keys = (unsigned long long*)(ws + w.keys);
         double* nu2 = (double*)(ws + w.nu2);
         char* qx = ws + w.qx;
-        char* qy = ws + w.qy;
         int2* prog = (int2*)(ws + w.prog);
         unsigned long long* rowhash = (unsigned long long*)(ws + w.rowhash);
-        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, rows, H, score, keys, qx, qy, nu2, proj, rowhash, prog, st);
+        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, rows, H, score, keys, qx, nullptr, nu2, proj, rowhash, prog, st);
         if (rc != DLC_OK) return rc;
         // did the range pass meet a NaN or an infinity?  (Their distances are NaN in the reference too, np.argmin then
         // takes the first of them: the fp64 kernels reproduce that, a fixed-point fraction cannot.)  The ONE host read of
@@ -904,7 +902,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
                 const long long ncols = rows - col_base;
                 const long long ldo = (ncols + 3) / 4 * 4;
                 const long long mrows = i_hi * P - row_base;
-                rc = dlc_gemm::gram_upper_i8(ctx, mrows, ncols, H, qx, qy, (int*)gram, ldo, (int)P, row_base, col_base, st);
+                rc = dlc_gemm::gram_upper_i8(ctx, mrows, ncols, H, qx, qx, (int*)gram, ldo, (int)P, row_base, col_base, st);
                 if (rc != DLC_OK) return rc;
                 hipLaunchKernelGGL(pair_score_filter_kernel, dim3(PS_GX, (unsigned)(i_hi - i_lo)), dim3(256), tile_lds, st, desc,
                                    (const int*)gram, ldo, col_base, nu2, proj, score, keys, (long long)N, (int)P, (int)H, i_lo, i_hi,
