@@ -43,6 +43,12 @@ int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H
 size_t sim_pairwise_program_bytes(int64_t H);
 int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
                  unsigned long long* rowhash, void* prog, unsigned long long* prog_len, hipStream_t st);
+// the streaming form: a resident append-only panel quantised over a fixed range (match_ref.hip: dlc_sdav_stream_*)
+int sim_stream_init(dlc_ctx* ctx, unsigned long long* keys, void* prog, int64_t H, double lo, double hi, hipStream_t st);
+int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, int64_t H, const double* score,
+                        unsigned long long* keys, char* X, double* nu2, double* proj, unsigned long long* rowhash,
+                        int64_t g_first, int64_t g_count, hipStream_t st);
+size_t sim_stream_panel_bytes(int64_t rows, int64_t H);
 int gram_upper_i8(dlc_ctx* ctx, int64_t mrows, int64_t ncols, int64_t H, const char* X, const char* Y, int* out, int64_t ldo,
                   int patches, int64_t row0, int64_t col0, hipStream_t st);
 

@@ -310,11 +310,12 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
                                                        const double* __restrict__ score, unsigned long long* keys,
                                                        char* __restrict__ X, char* __restrict__ Y, double* __restrict__ nrm2,
                                                        double* __restrict__ nu2, double* __restrict__ proj,
-                                                       unsigned long long* __restrict__ rowhash) {
+                                                       unsigned long long* __restrict__ rowhash, long long g0) {
     __shared__ double red[4][16][4];
     __shared__ unsigned long long redh[4][16][2];
     unsigned long long h1 = 0, h2 = 0;
-    const long long g = blockIdx.x;
+    const long long g = g0 + blockIdx.x;          // (g0 > 0: the groups a stream's new frames touch)
+    bool outside = false;                         // a value outside [lo, hi]: only possible with a FIXED range (streams)
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, rr = lane & 15, chunk = lane >> 4;
     double lo = 0.0, inv = 0.0;
     if constexpr (QUANT) {
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
             }
             if constexpr (QUANT) {
                 const double u = sim_unit(v, lo, inv);
+                outside |= !((v - lo) * inv >= 0.0 && (v - lo) * inv <= 1.0);
                 su += u; s2 = fma(u, u, s2);
                 const int q = sim_fixed(u);
                 w1[e >> 2] |= (unsigned)(q >> 14) << (8 * (e & 3));
@@ -380,6 +382,9 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
         n2 += __shfl_xor(n2, o); pr += __shfl_xor(pr, o);
         if constexpr (QUANT) { su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o); }
         h1 += __shfl_xor(h1, o); h2 += __shfl_xor(h2, o);
+    }
+    if constexpr (QUANT) {
+        if (__ballot(outside) != 0 && lane == 0) atomicMax(&keys[2], 1ull);
     }
     if (chunk == 0) {
         red[w][rr][0] = n2; red[w][rr][1] = pr; red[w][rr][2] = su; red[w][rr][3] = s2;
@@ -445,9 +450,40 @@ int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H
     hipLaunchKernelGGL(sim_range_kernel, dim3(2048), dim3(256), 0, st, desc, (long long)(rows * H), keys);
     DLC_LAUNCH_CHECK(ctx, "sim_range_kernel");
     hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(256), 0, st, desc, (long long)rows,
-                       (int)H, kp, score, keys, X, Y, (double*)nullptr, nu2, proj, rowhash);
+                       (int)H, kp, score, keys, X, Y, (double*)nullptr, nu2, proj, rowhash, 0ll);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
+}
+
+// ---- the streaming form (match_ref.hip: dlc_sdav_stream_*): a resident, append-only panel with a range FIXED at creation
+__global__ void sim_stream_keys_kernel(unsigned long long* keys, double lo, double hi) {
+    if (threadIdx.x < 8) keys[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) { keys[0] = dlc_f64_key(lo); keys[1] = dlc_f64_key(hi); }
+}
+
+int sim_stream_init(dlc_ctx* ctx, unsigned long long* keys, void* prog, int64_t H, double lo, double hi, hipStream_t st) {
+    hipLaunchKernelGGL(sim_stream_keys_kernel, dim3(1), dim3(64), 0, st, keys, lo, hi);
+    hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
+    DLC_LAUNCH_CHECK(ctx, "sim_stream_keys_kernel");
+    return DLC_OK;
+}
+
+// quantise the 16-row groups g_first .. g_first + g_count - 1 of desc[rows_total, H] into the panel and the per-row arrays
+// (a group shared with older rows is rewritten with the same values)
+int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, int64_t H, const double* score,
+                        unsigned long long* keys, char* X, double* nu2, double* proj, unsigned long long* rowhash,
+                        int64_t g_first, int64_t g_count, hipStream_t st) {
+    const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
+    if (g_count < 1) return DLC_OK;
+    hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)g_count), dim3(256), 0, st, desc, (long long)rows_total, (int)H, kp, score,
+                       keys, X, (char*)nullptr, (double*)nullptr, nu2, proj, rowhash, (long long)g_first);
+    DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
+    return DLC_OK;
+}
+
+size_t sim_stream_panel_bytes(int64_t rows, int64_t H) {
+    const size_t kp = dlc::align_up((size_t)H, (size_t)GI_KPAD);
+    return (size_t)(dlc::cdiv(rows, (int64_t)16) + 4) * 3 * kp * 16;      // whole groups + the query's three-group window past the end
 }
 
 // |x|^2, dot(score, x) and the content hash of every patch row (the fp64 Gram form; the filter's prepare computes the same
@@ -460,7 +496,7 @@ int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, cons
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, prog_len);
     hipLaunchKernelGGL(sim_rows_kernel<false>, dim3((unsigned)dlc::cdiv(rows, (int64_t)16)), dim3(256), 0, st, desc, (long long)rows,
                        (int)H, 0, score, (unsigned long long*)nullptr, (char*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj,
-                       rowhash);
+                       rowhash, 0ll);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }

@@ -709,6 +709,228 @@ __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __rest
         if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming form of the similarity (SimilarityCalculator.similarity_score for ONE new frame, the shape the loop of
+// create_similarity_matrix.py:34-38 takes when a robot adds a frame): frame f against every OLDER resident frame j < f --
+// row[j] = score(h_j, h_f) = entry [j, f] of the matrix call, bit for bit.  The database side is resident: descriptors
+// [capacity, P, H] fp64 and their quantised panel, |u|^2, projections and hashes, appended frame by frame over a range
+// FIXED at creation (no re-quantisation of older frames).  Two kernels per query:
+//   stream_argmin_kernel  every wave streams two 16-patch groups of the database panel ONCE (245 MB at 1063 frames: the
+//                         HBM-bound part, plain 16-byte loads in MFMA operand order -- no LDS) against the three groups
+//                         that hold frame f's patches (L2-resident), three class accumulators, and decides for each of
+//                         its 32 database patches a which patch b of frame f is nearest -- the filter's rule: integer
+//                         arg-min, candidates inside the error window evaluated directly (direct_argmin_wave);
+//   stream_score_kernel   the P terms of every older frame and their sum in the pair kernels' order.
+typedef __attribute__((ext_vector_type(4))) int sr_v4i;
+constexpr int SR_G = 2;                 // database groups per wave
+
+__device__ __forceinline__ void sr_merge(int& best, int& bidx, int& second, int ob, int oi, int os) {
+    // (best, index of the FIRST minimum, runner-up) of two disjoint candidate sets
+    const bool take = ob < best || (ob == best && oi < bidx);
+    const int lose = take ? best : ob;
+    second = min(min(second, os), lose);
+    if (take) { best = ob; bidx = oi; }
+}
+
+__global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restrict__ X, long long gpitch, int n64,
+                                                            const double* __restrict__ desc, const double* __restrict__ nu2,
+                                                            const unsigned long long* __restrict__ rowhash,
+                                                            unsigned long long* __restrict__ keys, long long f, int P, int H,
+                                                            unsigned char* __restrict__ bi_out, const int2* __restrict__ prog) {
+    __shared__ double stacks[4][8 * PF_STACK_DEPTH];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, quad = lane >> 4, an = lane & 15;
+    const long long rows_old = f * P;                              // database patches: rows 0 .. rows_old - 1
+    const long long gd0 = ((long long)blockIdx.x * 4 + w) * SR_G;
+    // (the count of direct evaluations, keys[4], is zeroed by a memset in front of this kernel)
+    if (gd0 * 16 >= rows_old) return;                              // (whole wave)
+    const long long gq0 = rows_old / 16;                           // frame f's patches lie in groups gq0 .. gq0 + 2
+    const int boff = (int)(rows_old - gq0 * 16);
+    const char* xq = X + gq0 * gpitch + lane * 16;
+    const char* xd = X + gd0 * gpitch + lane * 16;
+    sr_v4i c2[3][SR_G], c3[3][SR_G], c4[3][SR_G];
+#pragma unroll
+    for (int jq = 0; jq < 3; ++jq)
+#pragma unroll
+        for (int ig = 0; ig < SR_G; ++ig) { c2[jq][ig] = sr_v4i{0, 0, 0, 0}; c3[jq][ig] = sr_v4i{0, 0, 0, 0}; c4[jq][ig] = sr_v4i{0, 0, 0, 0}; }
+    // The database fragments come from HBM (a wave's 6 KiB per k-step, read once, non-temporal), the query's from L2
+    // (9 KiB per k-step, the same for every wave); both are fetched THREE k-steps ahead through a ring of four register
+    // buffers -- one k-step ahead, a wave finished a k-step per memory round trip: 25 us for the K loop alone.
+    sr_v4i q[4][3][3], d[4][3][SR_G];                              // [ring buffer][slice][group]
+    auto fetch = [&](int buf, int t) {
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+            const long long ko = ((long long)s_ * n64 + t) * 1024;
+#pragma unroll
+            for (int ig = 0; ig < SR_G; ++ig) d[buf][s_][ig] = __builtin_nontemporal_load((const sr_v4i*)(xd + ig * gpitch + ko));
+#pragma unroll
+            for (int jq = 0; jq < 3; ++jq) q[buf][s_][jq] = *(const sr_v4i*)(xq + jq * gpitch + ko);
+        }
+    };
+#define SR_STEP(B)                                                                                                        \
+    _Pragma("unroll") for (int jq = 0; jq < 3; ++jq)                                                                      \
+        _Pragma("unroll") for (int ig = 0; ig < SR_G; ++ig) {                                                             \
+            c2[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][0][jq], d[B][0][ig], c2[jq][ig], 0, 0, 0);            \
+            c3[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][1][jq], d[B][0][ig], c3[jq][ig], 0, 0, 0);            \
+            c3[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][0][jq], d[B][1][ig], c3[jq][ig], 0, 0, 0);            \
+            c4[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][2][jq], d[B][0][ig], c4[jq][ig], 0, 0, 0);            \
+            c4[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][1][jq], d[B][1][ig], c4[jq][ig], 0, 0, 0);            \
+            c4[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][0][jq], d[B][2][ig], c4[jq][ig], 0, 0, 0);            \
+        }
+    fetch(0, 0); fetch(1, 1); fetch(2, 2);                         // n64 >= 4
+    for (int t = 0; t < n64; t += 4) {                             // n64 is a multiple of 4
+        if (t + 3 < n64) fetch(3, t + 3);
+        SR_STEP(0)
+        if (t + 4 < n64) fetch(0, t + 4);
+        SR_STEP(1)
+        if (t + 5 < n64) fetch(1, t + 5);
+        SR_STEP(2)
+        if (t + 6 < n64) fetch(2, t + 6);
+        SR_STEP(3)
+    }
+#undef SR_STEP
+    // D[m][n] of MFMA (jq, ig): m = query-side patch jq * 16 + quad * 4 + v (b = that - boff), n = database patch an of group ig
+    const double E = 0x1p-20 * dlc_f64_unkey(keys[3]) + (double)H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
+    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
+    const int prog_len = (int)keys[5];
+    int nbv[3][4];                                                 // |u_b|^2 of this lane's twelve query patches, units of 2^-13
+#pragma unroll
+    for (int jq = 0; jq < 3; ++jq)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int b = jq * 16 + quad * 4 + v - boff;
+            nbv[jq][v] = (b >= 0 && b < P) ? (int)llrint(nu2[rows_old + b] * 8192.0) : 0;
+        }
+    unsigned long long directs = 0;
+#pragma unroll
+    for (int ig = 0; ig < SR_G; ++ig) {
+        const long long a = (gd0 + ig) * 16 + an;
+        const bool a_ok = a < rows_old;
+        int best = 0x7fffffff, second = 0x7fffffff, bidx = 0x7fffffff;
+        int d2v[3][4];
+#pragma unroll
+        for (int jq = 0; jq < 3; ++jq) {
+            const sr_v4i acc = c2[jq][ig] + ((c3[jq][ig] + (c4[jq][ig] >> 7)) >> 7);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int b = jq * 16 + quad * 4 + v - boff;
+                d2v[jq][v] = nbv[jq][v] - acc[v];
+                if (b >= 0 && b < P) sr_merge(best, bidx, second, d2v[jq][v], b, 0x7fffffff);
+            }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {                       // the four quads hold the rest of patch a's row
+            const int ob = __shfl_xor(best, o), oi = __shfl_xor(bidx, o), os = __shfl_xor(second, o);
+            sr_merge(best, bidx, second, ob, oi, os);
+        }
+        int bi = bidx < P ? bidx : 0;
+        unsigned cand = 0;
+        if ((long long)second - best <= window) {
+#pragma unroll
+            for (int jq = 0; jq < 3; ++jq)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int b = jq * 16 + quad * 4 + v - boff;
+                    if (b >= 0 && b < P && (long long)d2v[jq][v] - best <= window) cand |= 1u << b;
+                }
+        }
+        cand |= (unsigned)__shfl_xor((int)cand, 16);
+        cand |= (unsigned)__shfl_xor((int)cand, 32);
+        if (cand & (cand - 1)) {
+            // a copy of an earlier candidate (equal content hashes) has that candidate's distance and a later index
+            const unsigned long long* hb = rowhash + 2 * rows_old;
+            unsigned kept = 0;
+            for (unsigned m = cand; m; m &= m - 1) {
+                const int b = __ffs((int)m) - 1;
+                bool copy = false;
+                for (unsigned k2 = kept; k2; k2 &= k2 - 1) {
+                    const int e = __ffs((int)k2) - 1;
+                    copy |= hb[2 * e] == hb[2 * b] && hb[2 * e + 1] == hb[2 * b + 1];
+                }
+                if (!copy) kept |= 1u << b;
+            }
+            cand = kept;
+            if (!(cand & (cand - 1))) { bi = __ffs((int)cand) - 1; cand = 0; }
+        } else cand = 0;
+        for (unsigned long long todo = __ballot(cand != 0 && quad == 0 && a_ok); todo; todo &= todo - 1) {
+            const int src = __ffsll((long long)todo) - 1;
+            const unsigned cm = (unsigned)__shfl((int)cand, src);
+            const long long a_s = (gd0 + ig) * 16 + (src & 15);
+            const int ebi = direct_argmin_wave(desc + a_s * H, desc + rows_old * H, (unsigned long long)cm, P, H, lane, prog,
+                                               prog_len, stacks[w]);
+            if (lane == src) bi = ebi;
+            if (lane == 0) ++directs;
+        }
+        if (quad == 0 && a_ok) bi_out[a] = (unsigned char)bi;
+    }
+    if (lane == 0 && directs) atomicAdd(&keys[4], directs);
+}
+
+// row[j] = sum over the P patches a of frame j of  ca + cb log | dot(score, m_a - m_b*) |  (SimilarityCalculator.py:40-49),
+// b* = bi[j P + a] the patch of frame f nearest to a: the tail of the pair kernels, term for term and in their summation
+// order (32-lane xor tree), so the row equals the matrix call's column f bit for bit.
+__global__ __launch_bounds__(256) void stream_score_kernel(const double* __restrict__ desc, const double* __restrict__ proj,
+                                                           const double* __restrict__ score,
+                                                           const unsigned char* __restrict__ bi_in,
+                                                           const unsigned long long* __restrict__ keys, long long f, int P, int H,
+                                                           double ca, double cb, double* __restrict__ row,
+                                                           long long* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jj = lane >> 5, a = lane & 31;
+    const long long j = ((long long)blockIdx.x * 4 + w) * 2 + jj;
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = (long long)keys[4]; stats[1] = keys[2] ? 1 : 0; }
+    const bool pair_ok = j < f, live = pair_ok && a < P;       // (keys[4], this query's count, is zeroed by the next query's first kernel)
+    double term = 0.0, wd = 1.0, pa = 0.0;
+    long long rb = 0;
+    bool redo = false;
+    if (live) {
+        const long long ra = j * P + a;
+        rb = f * P + bi_in[ra];
+        pa = proj[ra];
+        const double pb = proj[rb];
+        wd = fabs(pa - pb);                                     // |dot(score, m_i - m_j*)|, :42-43
+        redo = wd < 1e-6 * (fabs(pa) + fabs(pb));               // cancellation: evaluate the difference directly
+    }
+    for (unsigned long long m = __ballot(redo); m; m &= m - 1) {
+        const int src = __ffsll((long long)m) - 1;
+        const long long rb_s = __shfl(rb, src);
+        const long long j_s = ((long long)blockIdx.x * 4 + w) * 2 + (src >> 5);
+        const double s_ = weighted_diff_wave(desc + (j_s * P + (src & 31)) * H, desc + rb_s * H, score, H, lane);
+        if (lane == src) wd = fabs(s_);
+    }
+    if (live) term = ca + cb * log(wd);                         // :48
+    for (int o = 16; o > 0; o >>= 1) term += __shfl_xor(term, o);
+    if (pair_ok && a == 0) row[j] = keys[2] ? __longlong_as_double(0x7ff8000000000000ll) : term;
+}
+
+struct StreamWs {
+    size_t keys, prog, nu2, proj, rowhash, bi, panel, total;
+};
+StreamWs stream_ws(int64_t capacity, int64_t P, int64_t H) {
+    StreamWs w;
+    size_t o = 0;
+    const size_t rows = (size_t)capacity * P;
+    w.keys = o; o += 256;
+    w.prog = o; o += 8192;
+    w.nu2 = o; o += dlc::align_up(rows * 8, 256);
+    w.proj = o; o += dlc::align_up(rows * 8, 256);
+    w.rowhash = o; o += dlc::align_up(rows * 16, 256);
+    w.bi = o; o += dlc::align_up(rows, 256);
+    w.panel = o; o += dlc::align_up(dlc_gemm::sim_stream_panel_bytes(rows, H), 256);
+    w.total = o;
+    return w;
+}
+
+int stream_check(dlc_ctx* ctx, const char* what, const void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!state || capacity < 1 || P < 1 || H < 1) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "%s: bad argument", what);
+    if (P > 32 || H > 32768)
+        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "%s: the streaming form takes P <= 32 patches and H <= 32768 (the filter's shapes)", what);
+    if (capacity * P > 0x7fffffffll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "%s: capacity too large", what);
+    if (state_bytes < stream_ws(capacity, P, H).total)
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "%s: state %zu < %zu bytes", what, state_bytes, stream_ws(capacity, P, H).total);
+    if ((uintptr_t)state & 255) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "%s: state must be 256-byte aligned", what);
+    return DLC_OK;
+}
+
 struct SimWs {
     size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, total;
     long long chunk_frames, chunk_frames_i8;
@@ -969,5 +1191,74 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
                                (const unsigned long long*)(ws + w.rowhash));
         DLC_LAUNCH_CHECK(ctx, "pair_score_kernel");
     }
+    return DLC_OK;
+}
+
+// ---- the streaming similarity (include/dlc.h) ----------------------------------------------------------------------
+extern "C" size_t dlc_sdav_stream_state_bytes(int64_t capacity, int64_t P, int64_t H) {
+    if (capacity < 1 || P < 1 || P > 32 || H < 1 || H > 32768) return 0;
+    return stream_ws(capacity, P, H).total;
+}
+
+extern "C" int dlc_sdav_stream_init(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                                    double lo, double hi, void* stream) {
+    int rc = stream_check(ctx, "sdav_stream_init", state, state_bytes, capacity, P, H);
+    if (rc != DLC_OK) return rc;
+    if (!(hi > lo)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_init: need lo < hi");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    const StreamWs w = stream_ws(capacity, P, H);
+    char* ws = (char*)state;
+    return dlc_gemm::sim_stream_init(ctx, (unsigned long long*)(ws + w.keys), ws + w.prog, H, lo, hi, (hipStream_t)stream);
+}
+
+extern "C" int dlc_sdav_stream_append(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                                      const double* desc, int64_t n_old, int64_t n_total, const double* score, void* stream) {
+    int rc = stream_check(ctx, "sdav_stream_append", state, state_bytes, capacity, P, H);
+    if (rc != DLC_OK) return rc;
+    if (!desc || !score || n_old < 0 || n_total < n_old || n_total > capacity)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_append: frames [%lld, %lld) outside the capacity %lld", (long long)n_old,
+                         (long long)n_total, (long long)capacity);
+    if (n_total == n_old) return DLC_OK;
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    const StreamWs w = stream_ws(capacity, P, H);
+    char* ws = (char*)state;
+    const int64_t g_first = n_old * P / 16, g_last = dlc::cdiv(n_total * P, (int64_t)16);
+    return dlc_gemm::sim_stream_quantise(ctx, desc, n_total * P, H, score, (unsigned long long*)(ws + w.keys), ws + w.panel,
+                                         (double*)(ws + w.nu2), (double*)(ws + w.proj), (unsigned long long*)(ws + w.rowhash),
+                                         g_first, g_last - g_first, (hipStream_t)stream);
+}
+
+extern "C" int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                                     const double* desc, int64_t f, const double* score, double a, double b, double* row_out,
+                                     int64_t* stats, void* stream) {
+    int rc = stream_check(ctx, "sdav_stream_query", state, state_bytes, capacity, P, H);
+    if (rc != DLC_OK) return rc;
+    if (!desc || !score || (!row_out && f > 0) || f < 0 || f >= capacity)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_query: bad argument");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const StreamWs w = stream_ws(capacity, P, H);
+    char* ws = (char*)state;
+    unsigned long long* keys = (unsigned long long*)(ws + w.keys);
+    if (f == 0) {
+        if (stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
+        return DLC_OK;
+    }
+    const long long kp = (long long)dlc::align_up((size_t)H, (size_t)256);
+    const long long gpitch = 3 * kp * 16;
+    const long long groups = dlc::cdiv(f * P, (int64_t)16);
+    DLC_HIP_CHECK(ctx, hipMemsetAsync(keys + 4, 0, 8, st));
+    hipLaunchKernelGGL(stream_argmin_kernel, dim3((unsigned)dlc::cdiv(groups, (long long)(4 * SR_G))), dim3(256), 0, st,
+                       (const char*)(ws + w.panel), gpitch, (int)(kp / 64), desc, (const double*)(ws + w.nu2),
+                       (const unsigned long long*)(ws + w.rowhash), keys, (long long)f, (int)P, (int)H,
+                       (unsigned char*)(ws + w.bi), (const int2*)(ws + w.prog));
+    DLC_LAUNCH_CHECK(ctx, "stream_argmin_kernel");
+    hipLaunchKernelGGL(stream_score_kernel, dim3((unsigned)dlc::cdiv(f, (int64_t)8)), dim3(256), 0, st, desc,
+                       (const double*)(ws + w.proj), score, (const unsigned char*)(ws + w.bi), keys, (long long)f, (int)P, (int)H, a,
+                       b, row_out, (long long*)stats);
+    DLC_LAUNCH_CHECK(ctx, "stream_score_kernel");
     return DLC_OK;
 }

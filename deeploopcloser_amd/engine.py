@@ -520,6 +520,31 @@ class Engine:
                                                          _ptr(direct_pairs), _ptr(ws), ws.numel(), self._stream()))
         return out, out_i
 
+    # ---- streaming similarity: one new frame against the resident older ones (dlc_sdav_stream_*) ----
+    def sdav_stream_state(self, capacity, p, h, lo=0.0, hi=1.0):
+        need = self.lib.dlc_sdav_stream_state_bytes(int(capacity), int(p), int(h))
+        if need == 0:
+            raise ValueError("streaming similarity: P <= 32 patches and H <= 32768 (got %d, %d)" % (p, h))
+        state = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.dlc_sdav_stream_init(self.ctx, _ptr(state), state.numel(), int(capacity), int(p), int(h), float(lo),
+                                                   float(hi), self._stream()))
+        return state
+
+    def sdav_stream_append(self, state, desc, n_old, n_total, score):
+        cap, p, h = desc.shape
+        self._check(self.lib.dlc_sdav_stream_append(self.ctx, _ptr(state), state.numel(), cap, p, h, _ptr(desc), int(n_old),
+                                                     int(n_total), _ptr(score), self._stream()))
+
+    def sdav_stream_query(self, state, desc, f, score, a=10.0, b=-10.0, out=None, stats=None):
+        cap, p, h = desc.shape
+        if out is None:
+            out = torch.empty((max(int(f), 0),), dtype=torch.float64, device=self.device)
+        if stats is not None:
+            self._check_out("stats", stats, (2,), torch.int64)
+        self._check(self.lib.dlc_sdav_stream_query(self.ctx, _ptr(state), state.numel(), cap, p, h, _ptr(desc), int(f), _ptr(score),
+                                                    float(a), float(b), _ptr(out), _ptr(stats), self._stream()))
+        return out
+
     def cnnvtl_distance_matrix(self, desc, d=None, out=None):
         """All-vs-all popcount(|a ^ b|) distances of int8 descriptors [N, D] -> int64 [N, N].  d: the descriptor length
         when desc's rows are padded (to a multiple of 4 bytes); out: a caller-kept [N, N] int64 tensor."""

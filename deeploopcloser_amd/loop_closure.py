@@ -102,6 +102,52 @@ class LoopClosureDetector:
         return out
 
 
+class SdavLoopClosureDetector:
+    """The same question asked with the REFERENCE's similarity (SimilarityCalculator.similarity_score,
+    src/sdav/similarity/SimilarityCalculator.py:12-49) instead of the cosine of flattened descriptors: every new frame's
+    [P, H] SDAV descriptors are scored against all resident frames more than `exclusion` frames older through the
+    streaming filter (similarity.SimilarityStream: the older frames' panel is resident, nothing is re-quantised), and the
+    k best (score descending, ties -> the older frame) at or above `threshold` are the loop candidates."""
+
+    def __init__(self, score_source, patches=30, width=2500, k=5, threshold=float("-inf"), exclusion=30, capacity=1024,
+                 device=None, **stream_args):
+        from .similarity import SimilarityStream
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        if exclusion < 0:
+            raise ValueError("exclusion must be >= 0")
+        self.k, self.threshold, self.exclusion = int(k), float(threshold), int(exclusion)
+        self.stream = SimilarityStream(score_source, patches=patches, width=width, capacity=capacity, device=device,
+                                       **stream_args)
+
+    def __len__(self):
+        return len(self.stream)
+
+    def query_and_insert(self, frames):
+        """frames [B, P, H] (ids len(self) .. + B - 1) -> (scores [B, k] float64, ids [B, k] int64) on the device, best first,
+        (-inf, -1) where fewer than k frames are old enough; the frames are resident afterwards."""
+        x = self.stream.engine.to_device(frames, torch.float64)
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        dev, k = self.stream.engine.device, self.k
+        out_s = torch.full((x.shape[0], k), float("-inf"), dtype=torch.float64, device=dev)
+        out_i = torch.full((x.shape[0], k), -1, dtype=torch.int64, device=dev)
+        for r in range(x.shape[0]):
+            row = self.stream.query_and_insert(x[r])
+            n_see = len(self.stream) - 1 - self.exclusion
+            if n_see <= 0:
+                continue
+            s, i = torch.sort(row[:n_see], descending=True, stable=True)       # ties: the lower (older) index first
+            m = min(k, n_see)
+            out_s[r, :m], out_i[r, :m] = s[:m], i[:m]
+        return out_s, out_i
+
+    def loops(self, scores, ids, first_id):
+        s, i = scores.cpu().numpy(), ids.cpu().numpy()
+        return [(first_id + r, int(i[r, c]), float(s[r, c])) for r in range(s.shape[0]) for c in range(s.shape[1])
+                if i[r, c] >= 0 and s[r, c] >= self.threshold]
+
+
 def _frame_files(dataset_path, pattern):
     files = sorted(glob.glob(os.path.join(dataset_path, pattern)))
     if not files:

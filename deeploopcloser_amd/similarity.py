@@ -58,3 +58,79 @@ class SimilarityCalculator:
         d = self._dataset_dev if descriptors is None else self.engine.to_device(descriptors, torch.float64)
         f, i = self.engine.sdav_similarity_matrix(d, self._score, self.a, self.b, want_int64=as_int64)
         return (i if as_int64 else f).cpu().numpy()
+
+
+class SimilarityStream:
+    """The reference's similarity for frames that ARRIVE ONE BY ONE (a robot adding key-frames): each new frame is scored
+    against every older one -- row[j] = SimilarityCalculator.similarity_score(h_j, h_new) (SimilarityCalculator.py:12-49),
+    the entries the loop of create_similarity_matrix.py:34-38 would add to its matrix for that frame, bit for bit -- without
+    touching the older frames again: their descriptors and the filter's fixed-point panel stay resident in HBM and are
+    appended to (dlc_sdav_stream_* in include/dlc.h).
+
+    score_source: the dataset [N, P, H] whose distinctive score weights the distances (what SimilarityCalculator(dataset)
+    computes, :20-27), or that score vector [H] itself; it is fixed for the life of the stream.  value_range: the range the
+    descriptors live in (SDAV outputs are sigmoid values: (0, 1)); a value outside it poisons the stream (queries return
+    NaN and say so in .stats) -- the filter's error bound is stated for that range."""
+
+    def __init__(self, score_source, patches=30, width=2500, capacity=1024, value_range=(0.0, 1.0), mu=0.5, sigma=0.2, a=10,
+                 b=-10, device=None):
+        self.engine = default_engine(device)
+        eng = self.engine
+        self.a, self.b = a, b
+        self.p, self.h = int(patches), int(width)
+        self.range = (float(value_range[0]), float(value_range[1]))
+        src = eng.to_device(score_source, torch.float64)
+        if src.dim() == 1:
+            if src.shape[0] != self.h:
+                raise ValueError("score vector must have the descriptor width %d" % self.h)
+            self.score = src.contiguous()
+        elif src.dim() == 3 and src.shape[2] == self.h:
+            self.score = eng.distinctive_score(src, mu, sigma)
+        else:
+            raise ValueError("score_source must be a dataset [N, P, %d] or a score vector [%d]" % (self.h, self.h))
+        self.stats = torch.zeros((2,), dtype=torch.int64, device=eng.device)
+        self._n = 0
+        self._alloc(int(capacity))
+
+    def _alloc(self, capacity):
+        eng = self.engine
+        desc = torch.zeros((capacity, self.p, self.h), dtype=torch.float64, device=eng.device)
+        state = eng.sdav_stream_state(capacity, self.p, self.h, *self.range)
+        if self._n:
+            desc[:self._n] = self.desc[:self._n]
+            eng.sdav_stream_append(state, desc, 0, self._n, self.score)      # growing re-quantises once (amortised)
+        self.desc, self.state, self.capacity = desc, state, capacity
+
+    def __len__(self):
+        return self._n
+
+    def append(self, frames):
+        """Frames [B, P, H] (or one [P, H]) become resident; returns the index of the first."""
+        x = self.engine.to_device(frames, torch.float64)
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        if x.dim() != 3 or x.shape[1] != self.p or x.shape[2] != self.h:
+            raise ValueError("frames must be [B, %d, %d]" % (self.p, self.h))
+        first, b = self._n, x.shape[0]
+        if first + b > self.capacity:
+            self._alloc(max(2 * self.capacity, first + b))
+        self.desc[first:first + b] = x
+        self.engine.sdav_stream_append(self.state, self.desc, first, first + b, self.score)
+        self._n = first + b
+        return first
+
+    def query(self, f=None):
+        """Device tensor [f] of score(h_j, h_f), j < f, for the resident frame f (default: the newest)."""
+        f = self._n - 1 if f is None else int(f)
+        if not 0 <= f < self._n:
+            raise ValueError("frame %d is not resident (0..%d)" % (f, self._n - 1))
+        return self.engine.sdav_stream_query(self.state, self.desc, f, self.score, self.a, self.b, stats=self.stats)
+
+    def query_and_insert(self, frame):
+        """One new frame [P, H]: it becomes resident and its row against all older frames comes back (device, fp64)."""
+        self.append(frame)
+        return self.query()
+
+    def similarity_row(self, frame):
+        """Alias of query_and_insert, as a NumPy row (the reference's scores are host floats)."""
+        return self.engine.download(self.query_and_insert(frame)) if self._n > 0 else np.empty(0)

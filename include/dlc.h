@@ -297,6 +297,31 @@ int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int6
                                double* out_f64, int64_t* out_i64, int flags, int64_t chunk_bytes, int64_t* stats,
                                uint8_t* direct_pairs, void* workspace, size_t workspace_bytes, void* stream);
 /*
+ * The same similarity for ONE NEW FRAME against a resident, growing set of older frames -- the shape the reference's
+ * loop (src/sdav/create_similarity_matrix.py:34-38) takes when a robot adds a frame: row[j] = similarity_score(h_j, h_f)
+ * (SimilarityCalculator.py:12-49) for every older frame j < f, equal to entry [j, f] of dlc_sdav_similarity_matrix bit for
+ * bit (same arg-min rule, same terms, same summation order).  P <= 32, H <= 32768.
+ * The caller keeps the descriptors desc[capacity, P, H] (fp64, frames in arrival order) and an opaque `state` of
+ * dlc_sdav_stream_state_bytes() bytes (256-byte aligned) holding what the filter needs of every resident frame: the
+ * 21-bit fixed-point panel, |u|^2, projections on `score`, content hashes.  The fixed-point range [lo, hi] is FIXED at
+ * init (SDAV descriptors are sigmoid outputs: 0, 1), so appending never re-quantises older frames.
+ *   dlc_sdav_stream_init    once (and again after growing: init + append of everything);
+ *   dlc_sdav_stream_append  frames [n_old, n_total) of desc have arrived: quantise them (`score` = the distinctive
+ *                           score the rows are projected on; it must stay the same for the life of the state);
+ *   dlc_sdav_stream_query   row_out[0 .. f-1] for the resident frame f (normally the newest).  stats (DEVICE, 2 int64,
+ *                           may be NULL): [0] arg-mins evaluated directly, [1] 1 when some appended value lay outside
+ *                           [lo, hi] or was not finite -- the error bound does not hold then and row_out is NaN.
+ * All three are stream-ordered and never synchronise.  A query reads the panel once (245 MB at 1063 frames).
+ */
+size_t dlc_sdav_stream_state_bytes(int64_t capacity, int64_t P, int64_t H);
+int dlc_sdav_stream_init(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                         double lo, double hi, void* stream);
+int dlc_sdav_stream_append(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                           const double* desc, int64_t n_old, int64_t n_total, const double* score, void* stream);
+int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                          const double* desc, int64_t f, const double* score, double a, double b, double* row_out,
+                          int64_t* stats, void* stream);
+/*
  * All-vs-all cnn_vtl distance: DistanceCalculator.calculate_distance
  * (src/cnn_vtl/similarity/DistanceCalculator.py:4-12) = sum_k popcount(|a_k ^ b_k|)
  * on signed int8, for the full N x N loop incl. the diagonal

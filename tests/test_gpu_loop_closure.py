@@ -133,3 +133,75 @@ def test_keep_older_kernel_equals_torch_form(dlc):
         gs, gi = eng.topk_keep_older(sc, idx, limit0, k)
         assert torch.equal(gi, wi) and torch.equal(gs, ws), (b, kk, k, limit0)
 
+
+
+# ---------------------------------------------------------------------------------- reference-semantics streaming query
+def test_similarity_stream_rows_equal_matrix_columns():
+    """SimilarityStream (dlc_sdav_stream_*): for every frame f that arrives, row[j] = score(h_j, h_f) for all older j ==
+    column f of the all-vs-all matrix call above the diagonal, BIT FOR BIT -- arg-min decided by the same filter (a resident
+    panel quantised over the fixed range (0, 1), never re-quantised), same terms, same summation order.  Saturated data
+    with copies of patches and of frames (+inf scores, exact ties), near-ties one ulp apart, several shapes; frames appended
+    singly and in batches, with the stream growing past its capacity on the way."""
+    import deeploopcloser_amd as dlc
+    eng = dlc.default_engine()
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(4)
+    for n, p, h in ((60, 30, 250), (45, 30, 2500), (70, 7, 129), (40, 32, 64), (33, 13, 1000)):
+        ds = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+        ds[5] = ds[2]; ds[n - 1] = ds[n - 3]                       # copies of whole frames
+        ds[7, 1] = ds[7, 0]                                        # a patch twice inside a frame
+        if p > 4:
+            ds[9, 3] = ds[9, 2]; ds[9, 3, 0] += 1e-9                # two patches one step apart: a near-tie for everybody
+        ds.clamp_(0.0, 1.0)
+        score = eng.distinctive_score(ds, 0.5, 0.2)
+        mf, _ = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, want_int64=False)
+        st = dlc.SimilarityStream(score, patches=p, width=h, capacity=16)
+        f = 0
+        for b in (1, 1, 3, 1, 8, 1, n):                             # arrival pattern: singles and batches
+            take = min(b, n - f)
+            if take <= 0:
+                break
+            st.append(ds[f:f + take])
+            for q in range(f, f + take):
+                row = st.query(q)
+                assert row.shape == (q,)
+                assert torch.equal(torch.nan_to_num(row, posinf=1e300), torch.nan_to_num(mf[:q, q], posinf=1e300)), (n, p, h, q)
+                assert torch.equal(row.isinf(), mf[:q, q].isinf())
+            f += take
+        assert len(st) == n and st.capacity >= n and int(st.stats[1]) == 0
+        one = st.query()                                           # default: the newest frame
+        assert torch.equal(torch.nan_to_num(one, posinf=1e300), torch.nan_to_num(mf[:n - 1, n - 1], posinf=1e300))
+
+
+def test_similarity_stream_vs_oracle_on_real_frames_and_poison():
+    """The 20 real frames of datasets/test through the GPU front-end and SDAV.transform, fed to the stream one by one:
+    every row against the oracle's similarity_score (the reference's arithmetic restated, oracle/similarity.py); the
+    detector's top-k; and a frame with a value outside the stream's range poisons it LOUDLY (NaN + stats[1])."""
+    import deeploopcloser_amd as dlc
+    import config1_common as c1
+    from oracle import similarity as osim
+    eng = dlc.default_engine()
+    paths = c1.frame_paths()
+    x = dlc.CvInputParser(30, 41).parse_batch(np.stack([dlc.read_ppm(p_) for p_ in paths]))
+    h = dlc.SDAV(seed=c1.SEED).transform_tensor(x).reshape(len(paths), 30, 2500)
+    hn = h.cpu().numpy()
+    sc = osim.distinctive_score(osim.average_response(hn))
+    det = dlc.SdavLoopClosureDetector(h, k=3, exclusion=2, capacity=4)
+    np.testing.assert_allclose(det.stream.score.cpu().numpy(), sc, rtol=1e-12)
+    for f in range(len(paths)):
+        s, i = det.query_and_insert(h[f])
+        want = np.array([np.sum(10 - 10 * np.log(osim.weighted_distances(hn[j], hn[f], osim.match_features(hn[j], hn[f]), sc)))
+                         for j in range(f)])
+        row = det.stream.query(f).cpu().numpy()
+        assert row.shape == want.shape and (f == 0 or np.abs(row - want).max() <= 1e-9 * np.abs(want).max())
+        n_see = f - 2
+        if n_see > 0:
+            order = np.lexsort((np.arange(n_see), -want[:n_see]))[:3]
+            assert i[0, :len(order)].cpu().tolist() == order.tolist()
+            assert np.allclose(s[0, :len(order)].cpu().numpy(), want[order], rtol=1e-9)
+        else:
+            assert int(i.max()) == -1
+    bad = h[3].clone()
+    bad[4, 7] = 1.25                                              # outside (0, 1): the fixed-point bound does not cover it
+    row = det.stream.query_and_insert(bad)
+    assert bool(row.isnan().all()) and int(det.stream.stats[1]) == 1
