@@ -101,6 +101,11 @@ class CnnVtl:
         self.compress_factor = compress_factor
         self.frame_chunk = int(frame_chunk)
         self.engine = default_engine(device)
+        # cnn_vtl.py:30,128 keep the graph's placeholder and output TENSORS as attributes (basic_example.py never reads
+        # them; a caller could only sess.run them).  There is no graph here -- transform() is the eager equivalent -- so
+        # the names exist and hold None: code that merely touches net.x / net.y keeps importing and running.
+        self.x = None
+        self.y = None
         self._define_model(seed, mask_seed)
 
     def _define_model(self, seed, mask_seed):
