@@ -829,7 +829,29 @@ void finish_topk_kernel(FinishArgs a) {
         if (tid == 0) a.grp_max[(long long)qi * W + kg] = bkey ? key_f32(bkey) : -INFINITY;
         return;
     }
-    if (tid < kg2) { const int c = sel2[tid]; sel2[tid] = c < 0 ? -1 : (int)key_id(ckey[c]); }   // -> group index
+    // Slack groups that cannot hold a top-k row are not gathered: with u' = the k-th largest group maximum (k groups hold a
+    // row with an fp32 score >= u', so the k-th best fp64 score is >= u' - tau), a group whose maximum is below u' - 2 tau
+    // has no row with an fp64 score above u' - tau.  Ranks k .. kg-1 are usually such groups (they are there for the crowded
+    // case): dropping them saves their 8 rows' gather each.  They join what is left behind -- and cannot fail the
+    // certificate (s_k >= u' - tau > their maximum + tau).
+    if (tid < kg2) {
+        const int c = sel2[tid];
+        int g = c < 0 ? -1 : (int)key_id(ckey[c]);
+        if (tid >= k && g >= 0 && sel2[k - 1] >= 0) {
+            const double uk = (double)key_f32((unsigned)(ckey[sel2[k - 1]] >> 32));
+            if ((double)key_f32((unsigned)(ckey[c] >> 32)) < uk - 2.0 * a.tau) g = -2;          // pruned (after the reads below)
+        }
+        misc[9] = 0u;                                       // (benign: every writer stores the same value)
+        crow[tid] = g;                                      // staged: sel2 / ckey are still being read by the other threads
+    }
+    __syncthreads();
+    if (tid < kg2) {
+        const int g = crow[tid];
+        if (g == -2) atomicMax(&misc[9], (unsigned)(ckey[sel2[tid]] >> 32));
+    }
+    __syncthreads();
+    if (tid < kg2) sel2[tid] = crow[tid] < 0 ? -1 : crow[tid];                                 // -> group index
+    bkey = max(bkey, misc[9]);
     __syncthreads();
     } else {
         // ---- start from a group list; optionally filter it against the other shards' maxima
