@@ -38,8 +38,13 @@ int gemm_bias_act_padded_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_
 // The SDAV similarity's arg-min filter (gram_i8.hip): descriptors as three 7-bit fixed-point slices, their exact integer
 // products, and the bound of what the truncation misses.
 size_t sim_filter_panel_bytes(int64_t rows, int64_t H);
-int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, unsigned long long* keys,
-                       char* X, char* Y, double* nu2, double* proj, unsigned long long* rowhash, void* prog, hipStream_t st);
+int sim_frames_per_unit(int64_t P);
+int64_t sim_col_rows(int64_t N, int64_t P);
+int64_t sim_col_frames(int64_t N, int64_t P);
+size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H);
+int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H, const double* score,
+                       unsigned long long* keys, char* X, char* Y, int* nbp, double* nu2, double* proj,
+                       unsigned long long* rowhash, void* prog, hipStream_t st);
 size_t sim_pairwise_program_bytes(int64_t H);
 int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
                  unsigned long long* rowhash, void* prog, unsigned long long* prog_len, hipStream_t st);
@@ -49,8 +54,8 @@ int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, in
                         unsigned long long* keys, char* X, double* nu2, double* proj, unsigned long long* rowhash,
                         int64_t g_first, int64_t g_count, hipStream_t st);
 size_t sim_stream_panel_bytes(int64_t rows, int64_t H);
-int gram_upper_i8(dlc_ctx* ctx, int64_t mrows, int64_t ncols, int64_t H, const char* X, const char* Y, int* out, int64_t ldo,
-                  int patches, int64_t row0, int64_t col0, hipStream_t st);
+int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const char* Y, const int* nbp,
+                   const unsigned long long* keys, unsigned char* abi, unsigned* acand, hipStream_t st);
 
 }  // namespace dlc_gemm
 

@@ -46,16 +46,27 @@ constexpr int GI_NSTAGE = 3;              // 144 KiB: two stages in flight behin
 constexpr int GI_BR = 4, GI_BC = 8;       // an XCD's 32 resident workgroups take one block of 4 x 8 tiles
 
 struct GramI8Args {
-    const char* X;                        // row panel: the group of row patch row0 (a multiple of 16)
-    const char* Y;                        // column panel: the group of column patch col0 (a multiple of 16); the same layout
-    int* out;                             // [mrows, ldo] accumulators (units of 2^-14 in u . u)
-    long long ldo, mrows, ncols;
+    const char* X;                        // row panel: patch rows in order, groups of 16
+    const char* Y;                        // column panel: the same data in UNITS of 64 columns = fpu whole frames + zero rows, so
+                                          // that every frame's P columns lie inside one wave's 64-column block
+    const int* nbp;                       // |u_b|^2 of the column panel's rows, units of 2^-13 (padded like Y)
+    const unsigned long long* keys;       // [3]: largest row sum of u (the error bound), [2]: non-finite flag
+    unsigned char* abi;                   // out [nrows, nfp]: the nearest patch b of column frame j to row patch a
+    unsigned* acand;                      // out [nrows, nfp]: 0 = decided; else the patches inside the error window (bit b)
+    long long nfp;                        // frames per row of abi / acand (padded: whole tiles)
+    long long nrows, nframes;
     long long gpitch;                     // bytes of one 16-row group: 3 Kp / 64 k-steps of 1 KiB
-    int kp;
+    int kp, H, P, fpu;
     int tiles_m, tiles_n, nsm, nsn, nsup;
-    int tri_p;
-    long long tri_row0, tri_col0;
 };
+
+// (best, index of the FIRST minimum, runner-up) of two disjoint candidate sets
+__device__ __forceinline__ void gi_merge(int& best, int& bidx, int& second, int ob, int oi, int os) {
+    const bool take = ob < best || (ob == best && oi < bidx);
+    const int lose = take ? best : ob;
+    second = min(min(second, os), lose);
+    if (take) { best = ob; bidx = oi; }
+}
 
 // One 1 KiB LDS-DMA piece: lane l fetches bytes l * 16 .. + 15 behind the wave-uniform base `src` (+ voff, which carries
 // the k-step) into LDS at `lds` + l * 16.  Inline asm so that hipcc does not count it in vmcnt (it would wait for
@@ -96,11 +107,10 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     int si = 0, sj = 0;
     bool found = false;
     for (; si < p.nsm; ++si) {
-        // first block column of block row si with a tile that holds a (row frame < column frame) entry
-        const long long row_frame = (p.tri_row0 + (long long)si * GI_BR * GI_T) / p.tri_p;
-        long long c_need = (row_frame + 1) * p.tri_p - p.tri_col0;      // first wanted column patch (relative)
-        if (c_need < 0) c_need = 0;
-        const int sj_min = (int)(c_need / (GI_BC * GI_T));
+        // first block column of block row si with a tile that holds a (row frame < column frame) entry: the column tile of
+        // frame (first row frame of the block row) + 1 -- a unit holds fpu frames, a tile two units
+        const long long row_frame = ((long long)si * GI_BR * GI_T) / p.P;
+        const int sj_min = (int)(((row_frame + 1) / p.fpu / 2) / GI_BC);
         const int cnt = p.nsn - sj_min;
         if (cnt <= 0) continue;
         if (want < cnt) { sj = sj_min + want; found = true; break; }
@@ -110,7 +120,9 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     const int tile_m = si * GI_BR + (local >> 3), tile_n = sj * GI_BC + (local & 7);
     if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
     const long long m0 = (long long)tile_m * GI_T, n0 = (long long)tile_n * GI_T;
-    if ((p.tri_col0 + n0 + GI_T - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;   // no (row frame < column frame) entry
+    // the tile's last frame must lie behind its first row's frame, and its first frame must exist
+    if ((long long)(2 * tile_n + 2) * p.fpu - 1 <= m0 / p.P || (long long)2 * tile_n * p.fpu >= p.nframes) return;
+    if (p.keys[2]) return;                          // a NaN / infinity in the dataset: this form does not apply
 
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wr = w >> 1, wc = w & 1;              // 64 row patches x 64 column patches per wave
@@ -227,19 +239,61 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
 #undef GI_RDY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // acc = C2 + floor((C3 + floor(C4 / 128)) / 128): non-negative integers, arithmetic shifts
-    // D[m][n] of MFMA (j, i): m = column patch (wc * 4 + j) * 16 + (lane / 16) * 4 + v, n = row patch (wr * 4 + i) * 16 + lane % 16
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long long r = m0 + (wr * 4 + i) * 16 + (lane & 15);
-        if (r >= p.mrows) continue;
-        int* orow = p.out + r * p.ldo;
+    // ---- epilogue: the patch arg-min of every (row patch, column frame) of the tile, decided here -- the products never
+    // leave the chip (r02 / early r03 wrote them out, 2 GB, for a second kernel to read back).
+    // acc = C2 + floor((C3 + floor(C4 / 128)) / 128) in units of 2^-14 of u . u; d2 = |u_b|^2 - 2 acc 2^-14 in units of 2^-13.
+    // D[m][n] of MFMA (j, i): m = column j * 16 + (lane / 16) * 4 + v of this wave's unit, n = row patch (wr * 4 + i) * 16 + lane % 16.
+    // A row patch's columns are spread over four lanes and sixteen registers; rather than merge (best, index, runner-up)
+    // triples across lanes -- a chain of 64 dependent cross-lane moves per tile, 7 us -- the wave turns its 64 x 64 block
+    // of d2 through LDS (the stages are dead by now) so that lane r owns row r: one sequential scan per frame, as the pair
+    // kernels of the fp64 form do it.
+    __syncthreads();                                                     // every wave is through its last fragment reads
+    constexpr int DP = 65;                                               // row pitch (ints): lanes on different rows, same column -> different banks
+    int* d2s = (int*)smem_i8 + w * 64 * DP;
+    const int quad = lane >> 4;
+    const long long unit = (long long)tile_n * 2 + wc;                   // this wave's 64 columns: frames unit * fpu .. + fpu - 1
+    {
+        int nbl[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long long c = n0 + (wc * 4 + j) * 16 + (lane >> 4) * 4;
-            const v4i acc = c2[j][i] + ((c3[j][i] + (c4[j][i] >> 7)) >> 7);
-            if (c + 3 < p.ldo) *(v4i*)(orow + c) = acc;                  // ldo is a multiple of 4 >= ncols
+            const v4i t4 = *(const v4i*)(p.nbp + unit * 64 + j * 16 + quad * 4);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) nbl[j][v] = t4[v];
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4i acc = c2[j][i] + ((c3[j][i] + (c4[j][i] >> 7)) >> 7);
+                int* dst = d2s + (i * 16 + (lane & 15)) * DP + j * 16 + quad * 4;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dst[v] = nbl[j][v] - acc[v];
+            }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);                                  // lgkmcnt(0): this wave's LDS writes (its own region)
+    __builtin_amdgcn_wave_barrier();
+    const double E = 0x1p-20 * dlc_f64_unkey(p.keys[3]) + (double)p.H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
+    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
+    const long long a = m0 + wr * 64 + lane;                             // lane r owns row patch r of the wave's 64
+    const int* drow = d2s + lane * DP;
+    for (int fs = 0; fs < p.fpu; ++fs) {
+        const long long fj = unit * p.fpu + fs;
+        if (!(a < p.nrows && fj < p.nframes && a < fj * p.P)) continue;  // (row frame < column frame)  <=>  a < fj * P
+        const int* dv = drow + fs * p.P;
+        int best = dv[0], second = 0x7fffffff, bi = 0;
+        for (int b = 1; b < p.P; ++b) {
+            const int d2 = dv[b];
+            second = min(second, max(best, d2));                         // the smaller of the two that are not the new minimum
+            bi = d2 < best ? b : bi;                                     // strict: the first minimum keeps its index
+            best = min(best, d2);
+        }
+        unsigned cand = 0;
+        if ((long long)second - best <= window) {
+            for (int b = 0; b < p.P; ++b)
+                if ((long long)dv[b] - best <= window) cand |= 1u << b;
+        }
+        p.abi[a * p.nfp + fj] = (unsigned char)bi;
+        p.acand[a * p.nfp + fj] = cand;                                  // 0 = decided (one patch inside the window)
     }
 }
 
@@ -310,7 +364,8 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
                                                        const double* __restrict__ score, unsigned long long* keys,
                                                        char* __restrict__ X, char* __restrict__ Y, double* __restrict__ nrm2,
                                                        double* __restrict__ nu2, double* __restrict__ proj,
-                                                       unsigned long long* __restrict__ rowhash, long long g0) {
+                                                       unsigned long long* __restrict__ rowhash, long long g0, int P, int fpu,
+                                                       int* __restrict__ nbp) {
     __shared__ double red[4][16][4];
     __shared__ unsigned long long redh[4][16][2];
     unsigned long long h1 = 0, h2 = 0;
@@ -329,7 +384,10 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
     const double* x = desc + (row_ok ? r : 0) * H;
     const bool vec = (H & 1) == 0 && ((unsigned long long)desc & 15) == 0 && ((unsigned long long)score & 15) == 0;
     char* xg = X + g * (3ll * nks * 1024) + lane * 16;
-    char* yg = Y + g * (3ll * nks * 1024) + lane * 16;
+    // the column panel (Y, may be null): row r = patch pp of frame f sits at row (f / fpu) * 64 + (f % fpu) * P + pp
+    long long prow = 0;
+    if (QUANT && Y) { const long long f = r / P; prow = (f / fpu) * 64 + (f % fpu) * P + (r - f * P); }
+    char* yg = Y + (prow >> 4) * (3ll * nks * 1024) + (chunk * 16 + (int)(prow & 15)) * 16;
     double n2 = 0.0, pr = 0.0, su = 0.0, s2 = 0.0;
     for (int ks = w; ks < nks; ks += 4) {
         const int k0 = ks * 64 + chunk * 16;
@@ -371,10 +429,10 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
             *(uint4*)(xg + (0ll * nks + ks) * 1024) = v1;
             *(uint4*)(xg + (1ll * nks + ks) * 1024) = v2;
             *(uint4*)(xg + (2ll * nks + ks) * 1024) = v3;
-            if (Y) {                            // (the r02 kernel's column panel, slices reversed; the r03 kernel reads X for both)
-                *(uint4*)(yg + (0ll * nks + ks) * 1024) = v3;
+            if (Y && row_ok) {                  // (its padding rows are zeros: the caller clears the panel)
+                *(uint4*)(yg + (0ll * nks + ks) * 1024) = v1;
                 *(uint4*)(yg + (1ll * nks + ks) * 1024) = v2;
-                *(uint4*)(yg + (2ll * nks + ks) * 1024) = v1;
+                *(uint4*)(yg + (2ll * nks + ks) * 1024) = v3;
             }
         }
     }
@@ -400,6 +458,7 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
         if constexpr (QUANT) {
             nu2[r] = t[3];
             atomicMax(&keys[3], dlc_f64_key(t[2]));
+            if (nbp) { const long long f = r / P; nbp[(f / fpu) * 64 + (f % fpu) * P + (r - f * P)] = (int)llrint(t[3] * 8192.0); }
         }
         if (rowhash) {
             rowhash[2 * r] = redh[0][rr][0] + redh[1][rr][0] + redh[2][rr][0] + redh[3][rr][0];
@@ -432,7 +491,7 @@ __global__ void sim_pairwise_program_kernel(int H, int2* prog, unsigned long lon
 
 }  // namespace
 
-// rows of a panel: whole tiles, 256 rows of slack behind the last one (a tile of the column panel starts at any group)
+// rows of the row panel: whole tiles and a tile of slack
 static int64_t sim_panel_rows(int64_t rows) { return (int64_t)dlc::align_up((size_t)rows, (size_t)GI_T) + GI_T + 16; }
 
 size_t sim_filter_panel_bytes(int64_t rows, int64_t H) {
@@ -440,17 +499,31 @@ size_t sim_filter_panel_bytes(int64_t rows, int64_t H) {
     return (size_t)sim_panel_rows(rows) * 3 * kp;
 }
 
+// The column panel: units of 64 rows = fpu = 64 / P whole frames + zero rows; whole tiles of two units.
+int sim_frames_per_unit(int64_t P) { return (int)(64 / P); }
+static int64_t sim_col_tiles(int64_t N, int64_t P) { return dlc::cdiv(dlc::cdiv(N, (int64_t)sim_frames_per_unit(P)), (int64_t)2); }
+int64_t sim_col_rows(int64_t N, int64_t P) { return sim_col_tiles(N, P) * GI_T; }                      // rows of Y, entries of nbp
+int64_t sim_col_frames(int64_t N, int64_t P) { return sim_col_tiles(N, P) * 2 * sim_frames_per_unit(P); }   // nfp: frames per row of abi / acand
+size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H) {
+    const size_t kp = dlc::align_up((size_t)H, (size_t)GI_KPAD);
+    return (size_t)sim_col_rows(N, P) * 3 * kp;
+}
+
 // keys[6]: min key, max key, non-finite flag, max row sum key, direct evaluations (a count), length of prog (up to
-// 1023 int2 entries for H <= 32768).  X / Y: sim_filter_panel_bytes each.
-int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, unsigned long long* keys,
-                       char* X, char* Y, double* nu2, double* proj, unsigned long long* rowhash, void* prog, hipStream_t st) {
+// 1023 int2 entries for H <= 32768).  X: sim_filter_panel_bytes; Y: sim_filter_colpanel_bytes; nbp: sim_col_rows ints.
+int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H, const double* score,
+                       unsigned long long* keys, char* X, char* Y, int* nbp, double* nu2, double* proj,
+                       unsigned long long* rowhash, void* prog, hipStream_t st) {
+    const int64_t rows = N * P;
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     hipLaunchKernelGGL(sim_keys_init_kernel, dim3(1), dim3(64), 0, st, keys);
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
     hipLaunchKernelGGL(sim_range_kernel, dim3(2048), dim3(256), 0, st, desc, (long long)(rows * H), keys);
     DLC_LAUNCH_CHECK(ctx, "sim_range_kernel");
+    DLC_HIP_CHECK(ctx, hipMemsetAsync(Y, 0, sim_filter_colpanel_bytes(N, P, H), st));        // the units' padding rows
+    DLC_HIP_CHECK(ctx, hipMemsetAsync(nbp, 0, (size_t)sim_col_rows(N, P) * 4, st));
     hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(256), 0, st, desc, (long long)rows,
-                       (int)H, kp, score, keys, X, Y, (double*)nullptr, nu2, proj, rowhash, 0ll);
+                       (int)H, kp, score, keys, X, Y, (double*)nullptr, nu2, proj, rowhash, 0ll, (int)P, sim_frames_per_unit(P), nbp);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
@@ -476,7 +549,7 @@ int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, in
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     if (g_count < 1) return DLC_OK;
     hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)g_count), dim3(256), 0, st, desc, (long long)rows_total, (int)H, kp, score,
-                       keys, X, (char*)nullptr, (double*)nullptr, nu2, proj, rowhash, (long long)g_first);
+                       keys, X, (char*)nullptr, (double*)nullptr, nu2, proj, rowhash, (long long)g_first, 1, 1, (int*)nullptr);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
@@ -496,35 +569,32 @@ int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, cons
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, prog_len);
     hipLaunchKernelGGL(sim_rows_kernel<false>, dim3((unsigned)dlc::cdiv(rows, (int64_t)16)), dim3(256), 0, st, desc, (long long)rows,
                        (int)H, 0, score, (unsigned long long*)nullptr, (char*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj,
-                       rowhash, 0ll);
+                       rowhash, 0ll, 1, 1, (int*)nullptr);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
 
-// out[r, c] = acc of (row patch row0 + r, column patch col0 + c), r < mrows, c < ncols; row0 and col0 multiples of 16
-// (the panels' groups), ldo a multiple of 4 >= ncols; tiles without a (row frame < column frame) entry are skipped
-int gram_upper_i8(dlc_ctx* ctx, int64_t mrows, int64_t ncols, int64_t H, const char* X, const char* Y, int* out, int64_t ldo,
-                  int patches, int64_t row0, int64_t col0, hipStream_t st) {
+// The patch arg-min of every (row patch a, column frame j) with frame(a) < j, for all N frames at once: abi / acand are
+// [N * P, sim_col_frames(N, P)] (bytes / 32-bit words); entries with frame(a) >= j are not written.
+int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const char* Y, const int* nbp,
+                   const unsigned long long* keys, unsigned char* abi, unsigned* acand, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
-    if ((row0 & 15) || (col0 & 15)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "gram_upper_i8: panel origins must be multiples of 16");
     GramI8Args a;
-    a.gpitch = 3ll * kp * 16; a.kp = kp;
-    a.X = X + (row0 / 16) * a.gpitch;
-    a.Y = Y + (col0 / 16) * a.gpitch;
-    a.out = out; a.ldo = ldo; a.mrows = mrows; a.ncols = ncols;
-    a.tiles_m = (int)dlc::cdiv(mrows, (int64_t)GI_T); a.tiles_n = (int)dlc::cdiv(ncols, (int64_t)GI_T);
+    a.gpitch = 3ll * kp * 16; a.kp = kp; a.H = (int)H; a.P = (int)P; a.fpu = sim_frames_per_unit(P);
+    a.X = X; a.Y = Y; a.nbp = nbp; a.keys = keys; a.abi = abi; a.acand = acand;
+    a.nfp = sim_col_frames(N, P); a.nrows = N * P; a.nframes = N;
+    a.tiles_m = (int)dlc::cdiv((N - 1) * P, (int64_t)GI_T);              // the last frame's patches have no later frame
+    a.tiles_n = (int)sim_col_tiles(N, P);
+    if (a.tiles_m < 1) return DLC_OK;
     a.nsm = (a.tiles_m + GI_BR - 1) / GI_BR;
     a.nsn = (a.tiles_n + GI_BC - 1) / GI_BC;
     a.nsup = 0;                               // blocks with a wanted tile (the kernel numbers them the same way)
     for (int si = 0; si < a.nsm; ++si) {
-        const long long row_frame = (row0 + (long long)si * GI_BR * GI_T) / patches;
-        long long c_need = (row_frame + 1) * patches - col0;
-        if (c_need < 0) c_need = 0;
-        const int cnt = a.nsn - (int)(c_need / (GI_BC * GI_T));
+        const long long row_frame = ((long long)si * GI_BR * GI_T) / P;
+        const int cnt = a.nsn - (int)(((row_frame + 1) / a.fpu / 2) / GI_BC);
         if (cnt > 0) a.nsup += cnt;
     }
     if (a.nsup == 0) return DLC_OK;
-    a.tri_p = patches; a.tri_row0 = row0; a.tri_col0 = col0;
     const size_t lds = (size_t)GI_NSTAGE * GI_STAGE;
     if (!(ctx->func_attr_set & (1ull << DLC_ATTR_GRAM_I8))) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gram_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -533,112 +533,62 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
     }
 }
 
-// doubles of LDS per wave of pair_score_filter_kernel: |u|^2 and hashes of 2 P columns, P rows of (2 P | 1) accumulators
-__host__ __device__ constexpr size_t pf_wave_doubles(int P) { return (size_t)(3 * 2 * P) + ((size_t)P * ((2 * P) | 1) * 4 + 15) / 16 * 2; }
-
-// The filter form (gram_i8.hip): G holds the exact integer products of the descriptors' 21-bit fixed-point values,
-// acc 2^-14 <= u_a . u_b <= acc 2^-14 + E.  Thread (jj, a) takes the arg-min of |u_b|^2 - 2 acc 2^-14 over the P
-// patches b; when the runner-up lies within 2 E of it, the bound cannot tell them apart and the wave evaluates the
-// candidates inside that window directly: |x_b - x_a| in fp64 from the descriptors, square roots compared as the
-// reference compares them (np.argmin of np.linalg.norm, first minimum).
-__global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __restrict__ desc, const int* __restrict__ G,
-                                                                long long ldg, long long col0, const double* __restrict__ nu2,
-                                                                const double* __restrict__ proj, const double* __restrict__ score,
-                                                                unsigned long long* __restrict__ keys, long long N, int P,
-                                                                int H, long long i_lo, long long i_hi, long long row_base,
-                                                                double ca, double cb, double* __restrict__ out_f64,
-                                                                long long* __restrict__ out_i64, const int2* __restrict__ prog,
-                                                                const unsigned long long* __restrict__ rowhash,
-                                                                unsigned char* __restrict__ direct_map) {
-    extern __shared__ double ps_lds_all[];
-    // Every wave works on its own: frame i against runs of TWO frames j (its two half-waves take one each, lane a of a
-    // half the patch a), staged through a region of LDS that only this wave touches -- no workgroup barrier, so a wave
-    // that has to evaluate candidates directly holds up nobody else (with the workgroup staging 8 frames together, one
-    // such arg-min stopped four waves at the barrier: binary descriptors 27.9 ms).
+// The filter form (gram_i8.hip): the int8 product kernel has decided, for every row patch a and every later frame j, which
+// patch b of frame j is nearest -- exact integer products of the descriptors' 21-bit fixed-point values, acc 2^-14 <=
+// u_a . u_b <= acc 2^-14 + E, arg-min of |u_b|^2 - 2 acc 2^-14 -- and left in abi / acand [N P, nfp] the index and, where
+// the runner-up lay within 2 E, the set of patches inside that window.  This kernel turns them into scores: undecided sets
+// lose the copies of an earlier member (equal content hashes: the same distance, a later index) and what is left is
+// evaluated directly -- |x_b - x_a| in fp64 from the descriptors, square roots compared as the reference compares them
+// (np.argmin of np.linalg.norm, first minimum: direct_argmin_wave) -- then the P terms of the pair and their sum.
+// Every wave works on its own: frame i against runs of TWO frames j (its two half-waves take one each, lane a of a half
+// the patch a) -- no workgroup barrier, so a wave that has to evaluate candidates directly holds up nobody else.
+__global__ __launch_bounds__(256) void pair_score_amin_kernel(const double* __restrict__ desc,
+                                                              const unsigned char* __restrict__ abi,
+                                                              const unsigned* __restrict__ acand, long long nfp,
+                                                              const double* __restrict__ proj, const double* __restrict__ score,
+                                                              unsigned long long* __restrict__ keys, long long N, int P, int H,
+                                                              double ca, double cb, double* __restrict__ out_f64,
+                                                              long long* __restrict__ out_i64, const int2* __restrict__ prog,
+                                                              const unsigned long long* __restrict__ rowhash,
+                                                              unsigned char* __restrict__ direct_map) {
+    extern __shared__ double ps_lds_all[];                  // the summation program's value stacks, 8 per wave
     unsigned long long* n_fallback = keys + 4;              // a count of the direct evaluations (-> stats[0] of the call)
     if (keys[2]) return;                                    // a NaN / infinity in the dataset: this form does not apply
     const int prog_len = (int)keys[5];
-    const long long i = i_lo + blockIdx.y;
-    if (i >= i_hi) return;
+    const long long i = blockIdx.y;
+    if (i >= N - 1) return;
     const int tid = threadIdx.x;
     const int w = tid >> 6, lane = tid & 63;
-    const int width = 2 * P, row = width | 1;                    // the run's columns; odd row pitch: 32 patches a read 32 banks
-    double* wl = ps_lds_all + PF_STACK_BYTES / 8 + (size_t)w * pf_wave_doubles(P);   // in front: the summation program's value stacks
-    int* nb = (int*)wl;                                          // [2 P] |u_b|^2 of the two frames' patches, in units of 2^-13
-    unsigned long long* hb = (unsigned long long*)(wl + width);  // [2 P][2] their content hashes
-    int* g = (int*)(wl + 3 * width);                             // [P][row]
     const int jj = lane >> 5, a = lane & 31;
     const long long ra = i * P + (a < P ? a : 0);
     const double pa = proj[ra];
     const bool flat = !(dlc_f64_unkey(keys[1]) > dlc_f64_unkey(keys[0]));      // every descriptor value the same: all distances 0
-    const double E = 0x1p-20 * dlc_f64_unkey(keys[3]) + (double)H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
-    // |u_b|^2 - 2 acc 2^-14 in units of 2^-13, as int32 (|u_b|^2 <= H <= 32768, acc < 2^29): rounding |u_b|^2 moves a
-    // value by half a unit, so two of them compare to within one -- the window grows by that (and 1 for its own rounding)
-    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
-    const int* grow0 = G + (i * P - row_base) * ldg - col0;      // G[0][0]: patches (row_base, col0), the panels' 16-row groups
-    int v[32];                                                   // row a of the run in flight: this lane's column
-    double nbv = 0.0;                                            // ... and that column's |u_b|^2 and hash
-    unsigned long long hv0 = 0, hv1 = 0;
-    auto fetch = [&](long long j0) {
-        const bool in_ = lane < width && j0 * P + lane < N * P;
-        nbv = in_ ? nu2[j0 * P + lane] : 0.0;
-        hv0 = in_ ? rowhash[2 * (j0 * P + lane)] : 0;
-        hv1 = in_ ? rowhash[2 * (j0 * P + lane) + 1] : 0;
-        const long long jlo = j0 > i + 1 ? j0 : i + 1;           // first frame of the run that is wanted
-        const long long jhi = j0 + 2 < N ? j0 + 2 : N;           // one past the last
-        const bool col_ok = lane >= (int)((jlo - j0) * P) && lane < (int)((jhi - j0) * P);
-        const int* gb = grow0 + j0 * P + lane;
-#pragma unroll
-        for (int r = 0; r < 32; ++r) v[r] = (r < P && col_ok) ? gb[(long long)r * ldg] : 0;
-    };
     const long long nwaves = (long long)PS_GX * 4;               // waves per frame i: wave q takes the runs q, q + nwaves, ..
-    long long j0 = ((i + 1) / 2 + blockIdx.x * 4 + w) * 2;       // counted from the run that holds frame i + 1
-    if (j0 < N) fetch(j0);
     unsigned long long fallbacks = 0;
-    for (; j0 < N; j0 += nwaves * 2) {
-#pragma unroll
-        for (int r = 0; r < 32; ++r)
-            if (r < P && lane < width) g[r * row + lane] = v[r];
-        if (lane < width) { nb[lane] = (int)llrint(nbv * 8192.0); hb[2 * lane] = hv0; hb[2 * lane + 1] = hv1; }
-        __builtin_amdgcn_wave_barrier();                         // (one wave: its LDS operations execute in order)
-        const long long jn = j0 + nwaves * 2;
-        if (jn < N) fetch(jn);
+    for (long long j0 = ((i + 1) / 2 + blockIdx.x * 4 + w) * 2; j0 < N; j0 += nwaves * 2) {
         const long long j = j0 + jj;
         const bool pair_ok = j > i && j < N;
         const bool live = pair_ok && a < P;
         int bi = 0;
         unsigned cand = 0;
         if (live && !flat) {
-            const int* grow = g + a * row + jj * P;
-            const int* nbj = nb + jj * P;
-            int best = 0, second = 0x7fffffff;
-            auto scan = [&](int b) {                            // integer min / max: a quarter of the fp64 forms' issue cycles
-                const int d2 = nbj[b] - grow[b];
-                if (b == 0) { best = d2; bi = 0; return; }
-                second = min(second, max(best, d2));            // the smaller of the two that are not the new minimum
-                bi = d2 < best ? b : bi;                        // strict: the first minimum keeps its index
-                best = min(best, d2);
-            };
-            if (P == 30) {
-#pragma unroll
-                for (int b = 0; b < 30; ++b) scan(b);
-            } else {
-#pragma unroll 4
-                for (int b = 0; b < P; ++b) scan(b);
-            }
-            if ((long long)second - best <= window) {
-                const unsigned long long* hbj = hb + 2 * jj * P;
-                for (int b = 0; b < P; ++b) {
-                    if (!((long long)(nbj[b] - grow[b]) - best <= window)) continue;
-                    // a copy of an earlier candidate (equal content hashes: sim_mix64) has that candidate's distance
-                    // and a later index: np.argmin never takes it
+            bi = abi[ra * nfp + j];
+            cand = acand[ra * nfp + j];
+            if (cand) {
+                // a copy of an earlier candidate (equal content hashes: sim_mix64) has that candidate's distance and a
+                // later index: np.argmin never takes it
+                const unsigned long long* hbj = rowhash + 2 * (j * P);
+                unsigned kept = 0;
+                for (unsigned m = cand; m; m &= m - 1) {
+                    const int b = __ffs((int)m) - 1;
                     bool copy = false;
-                    for (unsigned m = cand; m; m &= m - 1) {
-                        const int e = __ffs((int)m) - 1;
+                    for (unsigned k2 = kept; k2; k2 &= k2 - 1) {
+                        const int e = __ffs((int)k2) - 1;
                         copy |= hbj[2 * e] == hbj[2 * b] && hbj[2 * e + 1] == hbj[2 * b + 1];
                     }
-                    if (!copy) cand |= 1u << b;
+                    if (!copy) kept |= 1u << b;
                 }
+                cand = kept;
                 if (!(cand & (cand - 1))) { bi = __ffs((int)cand) - 1; cand = 0; }       // one patch left: decided
             }
         }
@@ -684,9 +634,8 @@ __global__ __launch_bounds__(256) void pair_score_filter_kernel(const double* __
                 out_i64[j * N + i] = t;
             }
         }
-        __builtin_amdgcn_wave_barrier();                         // g / nb / hb are rewritten for the next run
     }
-    if (n_fallback && lane == 0 && fallbacks) atomicAdd(n_fallback, fallbacks);
+    if (lane == 0 && fallbacks) atomicAdd(n_fallback, fallbacks);
 }
 
 __global__ void fill_diag_kernel(long long N, double* out_f64, long long* out_i64) {
@@ -931,11 +880,6 @@ int stream_check(dlc_ctx* ctx, const char* what, const void* state, size_t state
     return DLC_OK;
 }
 
-struct SimWs {
-    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, total;
-    long long chunk_frames, chunk_frames_i8;
-};
-
 // keys[2] (non-finite flag) and keys[4] (direct evaluations) of a finished call -> the caller's stats; and, for a call
 // that may not read the flag on the host (DLC_SIM_NO_HOST_SYNC), NaN over the matrix when the filter form did not apply.
 __global__ __launch_bounds__(256) void sim_finish_kernel(const unsigned long long* __restrict__ keys, long long* __restrict__ stats,
@@ -950,6 +894,11 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const unsigned long lon
     }
 }
 
+struct SimWs {
+    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, qy, nbp, abi, acand, total;
+    long long chunk_frames, nfp;
+};
+
 // The arg-min filter (gram_i8.hip) takes the call when the tiled pair kernel does (P <= 32) and the integer
 // accumulators cannot overflow; DLC_SIM_FORCE_F64 in the call's flags forces the fp64 Gram form.
 bool sim_use_filter(int64_t P, int64_t H, int flags) {
@@ -958,9 +907,8 @@ bool sim_use_filter(int64_t P, int64_t H, int flags) {
 }
 
 long long sim_chunk(int64_t N, int64_t P, size_t row_bytes, int64_t chunk_bytes) {
-    // Gram row chunk: at most ~8 GiB of the 288 GB (the work is triangular, so every chunk's launch is smaller than
-    // the one before and each pays its own last partial round of the chip: 1063 frames in 9 chunks of <= 1 GiB lost
-    // ~5 % to that; 8 GiB holds all of them in one), at least one frame
+    // fp64 Gram row chunk: at most ~8 GiB of the 288 GB (the work is triangular, so every chunk's launch is smaller than
+    // the one before and each pays its own last partial round of the chip), at least one frame
     size_t cap = 8ull << 30;
     if (chunk_bytes >= (1ll << 16)) cap = (size_t)chunk_bytes;     // the caller's bound (tests: several chunks at small sizes)
     long long cf = (long long)(cap / (row_bytes * (size_t)P));
@@ -983,13 +931,12 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     w.proj = o; o += dlc::align_up((size_t)N * P * 8, 256);
     const bool filter = sim_use_filter(P, H, flags);
     const size_t row_bytes = (size_t)N * P * 8;
-    const size_t row_bytes_i8 = ((size_t)N * P + 20) * 4;       // int32 accumulators; the block starts at a 16-patch group, its leading dimension is a multiple of 4
     w.chunk_frames = sim_chunk(N, P, row_bytes, chunk_bytes);
-    w.chunk_frames_i8 = sim_chunk(N, P, row_bytes_i8, chunk_bytes);
-    const size_t gram_f64 = (size_t)w.chunk_frames * P * row_bytes, gram_i8 = ((size_t)w.chunk_frames_i8 * P + 16) * row_bytes_i8;
-    // (the filter's region holds at least one frame's fp64 rows: a dataset with a NaN / infinity in it takes the fp64
-    // route after all, in as many chunks as that needs and without the transposed copy)
-    w.gram_bytes = filter ? (gram_i8 > (size_t)P * row_bytes ? gram_i8 : (size_t)P * row_bytes) : gram_f64;
+    // (the filter's workspace keeps a small fp64 Gram region -- up to 64 frames' rows: a dataset with a NaN / infinity in
+    // it takes the fp64 route after all, in as many chunks as that needs and without the transposed copy)
+    const size_t small = (size_t)(N < 64 ? N : 64) * P * row_bytes;
+    w.gram_bytes = filter ? (small < (size_t)w.chunk_frames * P * row_bytes ? small : (size_t)w.chunk_frames * P * row_bytes)
+                          : (size_t)w.chunk_frames * P * row_bytes;
     w.gram = o; o += dlc::align_up(w.gram_bytes, 256);
     // both forms: the range / flag / program-length words, NumPy's pairwise-summation program for rows of H elements and
     // the rows' content hashes (the direct evaluation of arg-mins that products of the descriptors cannot decide)
@@ -997,16 +944,23 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     const size_t prog_bytes = dlc_gemm::sim_pairwise_program_bytes(H);
     w.prog = o; o += prog_bytes > 8192 ? prog_bytes : 8192;
     w.rowhash = o; o += dlc::align_up((size_t)N * P * 16, 256);
-    // the descriptors transposed [H, N*P] (one extra pass over them): the fp64 Gram blocks then read their B operand as
-    // [K,N] -- 1 KiB contiguous per k-row and tile instead of 128 scattered 128-byte row segments (an even N*P keeps
-    // the rows 16-byte aligned for the LDS-DMA kernel; an odd one falls back to the [N,K] form)
-    w.nu2 = w.qx = 0;
+    w.nu2 = w.qx = w.qy = w.nbp = w.abi = w.acand = 0;
+    w.nfp = 0;
     if (filter) {
-        const size_t panel = dlc_gemm::sim_filter_panel_bytes(N * P, H);
+        // the two fixed-point panels (rows in order; columns in units of whole frames), |u|^2, and the product kernel's
+        // verdicts: nearest patch + undecided set per (row patch, later frame) -- 5 bytes where r02 kept 120 of products
+        w.nfp = dlc_gemm::sim_col_frames(N, P);
         w.nu2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
-        w.qx = o; o += dlc::align_up(panel, 256);        // ONE panel: row and column patches are groups of it
+        w.qx = o; o += dlc::align_up(dlc_gemm::sim_filter_panel_bytes(N * P, H), 256);
+        w.qy = o; o += dlc::align_up(dlc_gemm::sim_filter_colpanel_bytes(N, P, H), 256);
+        w.nbp = o; o += dlc::align_up((size_t)dlc_gemm::sim_col_rows(N, P) * 4, 256);
+        w.abi = o; o += dlc::align_up((size_t)N * P * w.nfp, 256);
+        w.acand = o; o += dlc::align_up((size_t)N * P * w.nfp * 4, 256);
         w.desc_t = o;
     } else {
+        // the descriptors transposed [H, N*P] (one extra pass over them): the fp64 Gram blocks then read their B operand as
+        // [K,N] -- 1 KiB contiguous per k-row and tile instead of 128 scattered 128-byte row segments (an even N*P keeps
+        // the rows 16-byte aligned for the LDS-DMA kernel; an odd one falls back to the [N,K] form)
         w.desc_t = o;
         if (((N * P) & 1) == 0) o += dlc::align_up((size_t)N * P * H * 8, 256);
     }
@@ -1096,9 +1050,13 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         unsigned long long* keys = (unsigned long long*)(ws + w.keys);
         double* nu2 = (double*)(ws + w.nu2);
         char* qx = ws + w.qx;
+        char* qy = ws + w.qy;
+        int* nbp = (int*)(ws + w.nbp);
+        unsigned char* abi = (unsigned char*)(ws + w.abi);
+        unsigned* acand = (unsigned*)(ws + w.acand);
         int2* prog = (int2*)(ws + w.prog);
         unsigned long long* rowhash = (unsigned long long*)(ws + w.rowhash);
-        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, rows, H, score, keys, qx, nullptr, nu2, proj, rowhash, prog, st);
+        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, N, P, H, score, keys, qx, qy, nbp, nu2, proj, rowhash, prog, st);
         if (rc != DLC_OK) return rc;
         // did the range pass meet a NaN or an infinity?  (Their distances are NaN in the reference too, np.argmin then
         // takes the first of them: the fp64 kernels reproduce that, a fixed-point fraction cannot.)  The ONE host read of
@@ -1114,22 +1072,15 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
             filter = false;
             if (stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
         } else {
-            const size_t tile_lds = PF_STACK_BYTES + 4 * pf_wave_doubles((int)P) * sizeof(double);
-            for (long long i_lo = 0; i_lo + 1 < N; i_lo += w.chunk_frames_i8) {
-                long long i_hi = i_lo + w.chunk_frames_i8;
-                if (i_hi > N - 1) i_hi = N - 1;
-                if (i_hi <= i_lo) break;
-                // the panels are stored in groups of 16 patches: the block starts at the groups of its first row / column
-                const long long row_base = (i_lo * P) & ~15ll, col_base = ((i_lo + 1) * P) & ~15ll;
-                const long long ncols = rows - col_base;
-                const long long ldo = (ncols + 3) / 4 * 4;
-                const long long mrows = i_hi * P - row_base;
-                rc = dlc_gemm::gram_upper_i8(ctx, mrows, ncols, H, qx, qx, (int*)gram, ldo, (int)P, row_base, col_base, st);
+            if (N > 1) {
+                // all frames in ONE launch: the product kernel keeps its 31 890 x 31 890 products on the chip and emits
+                // the arg-mins (r02: row chunks of an 8 GiB int32 block)
+                rc = dlc_gemm::gram_argmin_i8(ctx, N, P, H, qx, qy, nbp, keys, abi, acand, st);
                 if (rc != DLC_OK) return rc;
-                hipLaunchKernelGGL(pair_score_filter_kernel, dim3(PS_GX, (unsigned)(i_hi - i_lo)), dim3(256), tile_lds, st, desc,
-                                   (const int*)gram, ldo, col_base, nu2, proj, score, keys, (long long)N, (int)P, (int)H, i_lo, i_hi,
-                                   row_base, a, b, out_f64, (long long*)out_i64, prog, rowhash, direct_pairs);
-                DLC_LAUNCH_CHECK(ctx, "pair_score_filter_kernel");
+                hipLaunchKernelGGL(pair_score_amin_kernel, dim3(PS_GX, (unsigned)(N - 1)), dim3(256), PF_STACK_BYTES, st, desc,
+                                   (const unsigned char*)abi, (const unsigned*)acand, (long long)w.nfp, proj, score, keys,
+                                   (long long)N, (int)P, (int)H, a, b, out_f64, (long long*)out_i64, prog, rowhash, direct_pairs);
+                DLC_LAUNCH_CHECK(ctx, "pair_score_amin_kernel");
             }
             if (stats || no_sync) {
                 hipLaunchKernelGGL(sim_finish_kernel, dim3(no_sync ? 256u : 1u), dim3(256), 0, st, keys, (long long*)stats,
