@@ -361,9 +361,9 @@ def bench_paths(eng, n_frames):
     # ---- M1/M2: SDAV similarity matrix (SimilarityCalculator.py:12-49 + create_similarity_matrix.py:29-38) ----
     desc = h.reshape(N, P, H)
 
-    def sim():
-        score = eng.distinctive_score(desc, 0.5, 0.2)
-        return eng.sdav_similarity_matrix(desc, score, 10.0, -10.0)
+    def sim():                                                    # what SimilarityCalculator(dataset).similarity_matrix() runs
+        score, rng = eng.distinctive_score(desc, 0.5, 0.2, with_range=True)
+        return eng.sdav_similarity_matrix(desc, score, 10.0, -10.0, range=rng)
     call_ms, k_ms, k_n, (mf, mi) = _timed_path(eng, sim, reps=2)
     # The patch products as dlc_sdav_similarity_matrix launches them (match_ref.hip sim_ws): row chunks of <= 8 GiB of
     # int32 accumulators, frames [i_lo, i_hi) against every later frame; tiles under the diagonal are skipped, so the

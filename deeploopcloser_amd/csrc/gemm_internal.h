@@ -44,7 +44,7 @@ int64_t sim_col_frames(int64_t N, int64_t P);
 size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H);
 int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H, const double* score,
                        unsigned long long* keys, char* X, char* Y, int* nbp, double* nu2, double* proj,
-                       unsigned long long* rowhash, void* prog, hipStream_t st);
+                       unsigned long long* rowhash, void* prog, const unsigned long long* range, hipStream_t st);
 size_t sim_pairwise_program_bytes(int64_t H);
 int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
                  unsigned long long* rowhash, void* prog, unsigned long long* prog_len, hipStream_t st);

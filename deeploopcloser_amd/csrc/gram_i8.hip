@@ -299,8 +299,11 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
 
 // ---- range, quantisation -------------------------------------------------------------------------------------------
 
-__global__ void sim_keys_init_kernel(unsigned long long* keys) {
-    if (threadIdx.x < 6) keys[threadIdx.x] = threadIdx.x == 0 ? ~0ull : 0ull;     // [4]: direct evaluations (a count for experiments)
+__global__ void sim_keys_init_kernel(unsigned long long* keys, const unsigned long long* range) {
+    // [4]: direct evaluations (a count); [0..2]: the dataset's range and flag -- from the caller's distinctive-score pass
+    // over the same descriptors when it kept them, else sim_range_kernel fills them in
+    if (threadIdx.x < 6) keys[threadIdx.x] = threadIdx.x == 0 ? ~0ull : 0ull;
+    if (range && threadIdx.x < 3) keys[threadIdx.x] = range[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void sim_range_kernel(const double* __restrict__ x, long long n, unsigned long long* keys) {
@@ -513,12 +516,12 @@ size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H) {
 // 1023 int2 entries for H <= 32768).  X: sim_filter_panel_bytes; Y: sim_filter_colpanel_bytes; nbp: sim_col_rows ints.
 int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H, const double* score,
                        unsigned long long* keys, char* X, char* Y, int* nbp, double* nu2, double* proj,
-                       unsigned long long* rowhash, void* prog, hipStream_t st) {
+                       unsigned long long* rowhash, void* prog, const unsigned long long* range, hipStream_t st) {
     const int64_t rows = N * P;
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
-    hipLaunchKernelGGL(sim_keys_init_kernel, dim3(1), dim3(64), 0, st, keys);
+    hipLaunchKernelGGL(sim_keys_init_kernel, dim3(1), dim3(64), 0, st, keys, range);
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
-    hipLaunchKernelGGL(sim_range_kernel, dim3(2048), dim3(256), 0, st, desc, (long long)(rows * H), keys);
+    if (!range) hipLaunchKernelGGL(sim_range_kernel, dim3(2048), dim3(256), 0, st, desc, (long long)(rows * H), keys);
     DLC_LAUNCH_CHECK(ctx, "sim_range_kernel");
     DLC_HIP_CHECK(ctx, hipMemsetAsync(Y, 0, sim_filter_colpanel_bytes(N, P, H), st));        // the units' padding rows
     DLC_HIP_CHECK(ctx, hipMemsetAsync(nbp, 0, (size_t)sim_col_rows(N, P) * 4, st));

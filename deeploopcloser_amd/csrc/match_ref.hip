@@ -129,9 +129,18 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __re
 constexpr int DS_COLS = 16;               // columns per workgroup
 constexpr int DS_U = 16;                  // rows per thread and batch
 constexpr int DS_ROWS = 16 * DS_U;        // rows per batch
+// range (may be null): the pass sees every element once, so it also folds what the similarity's filter form needs to know
+// about the dataset -- ordered keys of its minimum and maximum, and whether it holds a NaN / infinity -- into range[0..2]
+// (initialised by range_init_kernel): dlc_sdav_similarity_matrix then skips its own pass over the 638 MB.
+__global__ void range_init_kernel(unsigned long long* range) {
+    if (threadIdx.x == 0) { range[0] = ~0ull; range[1] = 0ull; range[2] = 0ull; }
+}
 __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __restrict__ desc, long long rows, int H,
-                                                                double mu, double sigma, double* __restrict__ score) {
+                                                                double mu, double sigma, double* __restrict__ score,
+                                                                unsigned long long* __restrict__ range) {
     __shared__ double buf[2][DS_ROWS][DS_COLS];
+    double lo = INFINITY, hi = -INFINITY;
+    bool bad = false;
     const int tid = threadIdx.x, c = tid & 15, g = tid >> 4;
     const int col = blockIdx.x * DS_COLS + c;
     const bool col_ok = col < H;
@@ -141,7 +150,9 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
 #pragma unroll
         for (int u = 0; u < DS_U; ++u) {
             const long long r = r0 + u * 16 + g;
-            v[u] = (col_ok && r < rows) ? src[r * H] : 0.0;
+            const bool in_ = col_ok && r < rows;
+            v[u] = in_ ? src[r * H] : 0.0;
+            if (in_) { bad |= !(fabs(v[u]) < INFINITY); lo = fmin(lo, v[u]); hi = fmax(hi, v[u]); }
         }
     };
     double s = 0.0;
@@ -167,6 +178,14 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
         const double avg = s / (double)rows;
         const double e = -((avg - mu) * (avg - mu)) / (2.0 * sigma * sigma);
         score[col] = exp(e);
+    }
+    if (range) {
+        for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+        const bool any_bad = __ballot(bad) != 0;
+        if ((tid & 63) == 0) {
+            if (lo <= hi) { atomicMin(&range[0], dlc_f64_key(lo)); atomicMax(&range[1], dlc_f64_key(hi)); }
+            if (any_bad) atomicMax(&range[2], 1ull);
+        }
     }
 }
 
@@ -1006,22 +1025,23 @@ extern "C" size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int6
 }
 
 extern "C" int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows, int64_t H, double mu,
-                                         double sigma, double* score, void* stream) {
+                                         double sigma, double* score, uint64_t* range, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!dataset || !score || rows < 1 || H < 1 || H > 0x7fffffff)
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "distinctive_score: bad argument");
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    if (range) hipLaunchKernelGGL(range_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)range);
     hipLaunchKernelGGL(distinctive_score_kernel, dim3((unsigned)dlc::cdiv(H, DS_COLS)), dim3(256), 0, (hipStream_t)stream,
-                       dataset, (long long)rows, (int)H, mu, sigma, score);
+                       dataset, (long long)rows, (int)H, mu, sigma, score, (unsigned long long*)range);
     DLC_LAUNCH_CHECK(ctx, "distinctive_score_kernel");
     return DLC_OK;
 }
 
 extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H,
                                           const double* score, double a, double b, double* out_f64, int64_t* out_i64,
-                                          int flags, int64_t chunk_bytes, int64_t* stats, uint8_t* direct_pairs,
-                                          void* workspace, size_t workspace_bytes, void* stream) {
+                                          int flags, int64_t chunk_bytes, const uint64_t* range, int64_t* stats,
+                                          uint8_t* direct_pairs, void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!desc || !score || !out_f64 || N < 1 || P < 1 || H < 1 || (flags & ~(DLC_SIM_FORCE_F64 | DLC_SIM_NO_HOST_SYNC)))
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "similarity_matrix: bad argument");
@@ -1056,7 +1076,8 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         unsigned* acand = (unsigned*)(ws + w.acand);
         int2* prog = (int2*)(ws + w.prog);
         unsigned long long* rowhash = (unsigned long long*)(ws + w.rowhash);
-        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, N, P, H, score, keys, qx, qy, nbp, nu2, proj, rowhash, prog, st);
+        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, N, P, H, score, keys, qx, qy, nbp, nu2, proj, rowhash, prog,
+                                              (const unsigned long long*)range, st);
         if (rc != DLC_OK) return rc;
         // did the range pass meet a NaN or an infinity?  (Their distances are NaN in the reference too, np.argmin then
         // takes the first of them: the fp64 kernels reproduce that, a fixed-point fraction cannot.)  The ONE host read of

@@ -490,15 +490,19 @@ class Engine:
         return out
 
     # ---- reference-semantics match ---------------------------------------------------
-    def distinctive_score(self, dataset, mu, sigma):
+    def distinctive_score(self, dataset, mu, sigma, with_range=False):
+        """Distinctive score [H] of a dataset [..., H]; with_range=True: (score, range) where range (3 x int64 on the
+        device) is what the pass learned about the dataset's extremes -- pass it to sdav_similarity_matrix(range=) for the
+        SAME tensor and that call does not read the descriptors again to find them."""
         d2 = dataset.reshape(-1, dataset.shape[-1]).contiguous()
         score = torch.empty(d2.shape[1], dtype=torch.float64, device=self.device)
+        rng = torch.empty(3, dtype=torch.int64, device=self.device) if with_range else None
         self._check(self.lib.dlc_sdav_distinctive_score(self.ctx, _ptr(d2), d2.shape[0], d2.shape[1], float(mu),
-                                                         float(sigma), _ptr(score), self._stream()))
-        return score
+                                                         float(sigma), _ptr(score), _ptr(rng), self._stream()))
+        return (score, rng) if with_range else score
 
     def sdav_similarity_matrix(self, desc, score, a=10.0, b=-10.0, want_int64=True, force_f64=False, no_host_sync=False,
-                               chunk_bytes=0, stats=None, direct_pairs=None):
+                               chunk_bytes=0, stats=None, direct_pairs=None, range=None):
         """All-vs-all SDAV similarity of desc [N,P,H] (fp64) -> (out fp64 [N,N], out int64 [N,N] or None).
         force_f64: the fp64 Gram form instead of the int8 arg-min filter (same matrix); no_host_sync: never read the
         non-finite flag back (graph-capturable; a dataset with NaN / inf then yields NaN and stats[1] = 1);
@@ -511,13 +515,15 @@ class Engine:
             self._check_out("stats", stats, (2,), torch.int64)
         if direct_pairs is not None:
             self._check_out("direct_pairs", direct_pairs, (n, n), torch.uint8)
+        if range is not None:
+            self._check_out("range", range, (3,), torch.int64)
         out = torch.empty((n, n), dtype=torch.float64, device=self.device)
         out_i = torch.empty((n, n), dtype=torch.int64, device=self.device) if want_int64 else None
         need = self.lib.dlc_sdav_similarity_workspace_bytes(n, p, h, flags, int(chunk_bytes))
         ws = self.workspace("sim", need)
         self._check(self.lib.dlc_sdav_similarity_matrix(self.ctx, _ptr(desc), n, p, h, _ptr(score), float(a), float(b),
-                                                         _ptr(out), _ptr(out_i), flags, int(chunk_bytes), _ptr(stats),
-                                                         _ptr(direct_pairs), _ptr(ws), ws.numel(), self._stream()))
+                                                         _ptr(out), _ptr(out_i), flags, int(chunk_bytes), _ptr(range),
+                                                         _ptr(stats), _ptr(direct_pairs), _ptr(ws), ws.numel(), self._stream()))
         return out, out_i
 
     # ---- streaming similarity: one new frame against the resident older ones (dlc_sdav_stream_*) ----

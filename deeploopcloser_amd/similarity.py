@@ -17,7 +17,8 @@ class SimilarityCalculator:
             raise ValueError("dataset must be [N, P, H]")
         self._dataset_dev = ds
         # hoisted: the reference recomputes these for every pair (:13-14)
-        self._score = self.engine.distinctive_score(ds, mu, sigma)
+        # ... and what that pass learned about the dataset's range serves similarity_matrix() over the same tensor
+        self._score, self._range = self.engine.distinctive_score(ds, mu, sigma, with_range=True)
         self._pair = None
 
     def similarity_score(self, h1, h2):
@@ -56,7 +57,8 @@ class SimilarityCalculator:
         """create_similarity_matrix.py:29-38: scores for i<j mirrored, diagonal -1.
         as_int64=True returns the reference's int64 matrix (truncated scores)."""
         d = self._dataset_dev if descriptors is None else self.engine.to_device(descriptors, torch.float64)
-        f, i = self.engine.sdav_similarity_matrix(d, self._score, self.a, self.b, want_int64=as_int64)
+        f, i = self.engine.sdav_similarity_matrix(d, self._score, self.a, self.b, want_int64=as_int64,
+                                                  range=self._range if descriptors is None else None)
         return (i if as_int64 else f).cpu().numpy()
 
 

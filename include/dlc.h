@@ -253,9 +253,12 @@ int dlc_quant_gather_i8(dlc_ctx* ctx, const double* const* segs, const int64_t* 
  * (src/sdav/similarity/SimilarityCalculator.py:20-27): column mean (rows
  * summed in order, as np.average does), then exp(-(avg-mu)^2 / (2 sigma^2)).
  * The reference recomputes this for every pair (:13-14); it is hoisted here.
+ * range (DEVICE, 3 x uint64, may be NULL): the pass sees every element once and can leave what the similarity's filter
+ * form needs to know about THIS dataset -- ordered keys of its minimum and maximum, a NaN / infinity flag; hand it to
+ * dlc_sdav_similarity_matrix called on the same descriptors and that call skips its own pass over them.
  */
 int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows, int64_t H,
-                               double mu, double sigma, double* score, void* stream);
+                               double mu, double sigma, double* score, uint64_t* range, void* stream);
 /*
  * All-vs-all SDAV similarity: SimilarityCalculator.similarity_score
  * (src/sdav/similarity/SimilarityCalculator.py:12-49) for every frame pair
@@ -279,23 +282,27 @@ int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows
  *                         call never synchronises (and can be captured in a hipGraph); on a dataset
  *                         with a NaN / infinity the matrix then comes back as NaN / INT64_MIN and
  *                         stats[1] = 1, and the caller repeats the call with DLC_SIM_FORCE_F64.
- * chunk_bytes: upper bound of one patch-product block in the workspace (0 = 8 GiB: all 1063 frames
- * of the reference's dataset in one launch); pass the same value to the workspace-size function.
+ * chunk_bytes: upper bound of one fp64 Gram block in the workspace (0 = 8 GiB; the filter form keeps no
+ * product block at all: its product kernel emits the arg-mins); pass the same value to the
+ * workspace-size function.
+ * range (DEVICE, may be NULL): what dlc_sdav_distinctive_score left for the SAME desc (pointer, N*P rows, H):
+ * the filter form then does not read the descriptors a second time to find their extremes.
  * stats (DEVICE, 2 int64, may be NULL): [0] arg-mins the integer bound could not decide (evaluated
  * directly in fp64), [1] 1 when the dataset held a NaN / infinity.  direct_pairs (DEVICE, [N,N]
  * bytes, may be NULL): 1 at [i, j], i < j, when at least one arg-min of that frame pair was evaluated
  * directly (the pairs a checker wants to look at first), 0 elsewhere.
- * The workspace holds the quantised descriptors (or their fp64 transpose) and the patch-to-patch
- * product blocks: sized for 288 GB of HBM, it is 4.6 GB at the reference's 1063 frames (one chunk;
- * 8.7 GB in the fp64 form) and stays below 9.5 GB + N*P*H*8 bytes for any N.
+ * The workspace holds the quantised descriptors and the product kernel's verdicts (filter form: 1.2 GB
+ * at the reference's 1063 frames) or the descriptors' fp64 transpose and the fp64 Gram blocks (8.7 GB
+ * there, below 9.5 GB + N*P*H*8 bytes for any N).
  */
 #define DLC_SIM_FORCE_F64 1
 #define DLC_SIM_NO_HOST_SYNC 2
 size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes);
 int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H,
                                const double* score, double a, double b,
-                               double* out_f64, int64_t* out_i64, int flags, int64_t chunk_bytes, int64_t* stats,
-                               uint8_t* direct_pairs, void* workspace, size_t workspace_bytes, void* stream);
+                               double* out_f64, int64_t* out_i64, int flags, int64_t chunk_bytes,
+                               const uint64_t* range, int64_t* stats, uint8_t* direct_pairs,
+                               void* workspace, size_t workspace_bytes, void* stream);
 /*
  * The same similarity for ONE NEW FRAME against a resident, growing set of older frames -- the shape the reference's
  * loop (src/sdav/create_similarity_matrix.py:34-38) takes when a robot adds a frame: row[j] = similarity_score(h_j, h_f)

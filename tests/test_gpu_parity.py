@@ -1348,3 +1348,29 @@ def test_engine_workspaces_are_bounded_per_name(eng):
             eng.match_topk(q, q, 2)
     torch.cuda.synchronize()
     assert sum(1 for k in eng._ws if k[0] == "topk") <= eng.WORKSPACE_STREAMS
+
+
+def test_similarity_range_from_the_distinctive_pass(eng, dlc):
+    """dlc_sdav_distinctive_score can leave the dataset's extremes and its NaN / infinity flag for dlc_sdav_similarity_matrix
+    (the filter form then reads the descriptors once less): same matrix as without; the flag routes a dataset with a NaN to
+    the fp64 form as before; the class uses it for its own dataset only."""
+    g = torch.Generator(device=eng.device); g.manual_seed(12)
+    ds = 3.0 * torch.randn((40, 30, 250), generator=g, device=eng.device, dtype=torch.float64) - 1.0
+    score, rng = eng.distinctive_score(ds, 0.5, 0.2, with_range=True)
+    assert torch.equal(score, eng.distinctive_score(ds, 0.5, 0.2))
+    lo, hi = float(ds.min()), float(ds.max())
+    key = lambda v: int(np.frombuffer(np.float64(v).tobytes(), dtype=np.uint64)[0])
+    okey = lambda v: (~key(v)) & (2 ** 64 - 1) if key(v) >> 63 else key(v) | (1 << 63)
+    got = [int(x) & (2 ** 64 - 1) for x in rng.cpu().tolist()]
+    assert got == [okey(lo), okey(hi), 0]
+    a = [t.clone() for t in eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)]
+    b = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, range=rng)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    bad = ds.clone(); bad[3, 4, 5] = float("inf")
+    score, rng = eng.distinctive_score(bad, 0.5, 0.2, with_range=True)
+    assert int(rng[2]) == 1
+    a = [t.clone() for t in eng.sdav_similarity_matrix(bad, score, 10.0, -10.0)]
+    b = eng.sdav_similarity_matrix(bad, score, 10.0, -10.0, range=rng)
+    assert torch.equal(torch.nan_to_num(a[0]), torch.nan_to_num(b[0])) and torch.equal(a[1], b[1])
+    calc = dlc.SimilarityCalculator(ds.cpu().numpy())
+    assert np.array_equal(calc.similarity_matrix(), calc.similarity_matrix(ds.cpu().numpy()))      # own dataset (range kept) == any descriptors
