@@ -150,9 +150,7 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
 #pragma unroll
         for (int u = 0; u < DS_U; ++u) {
             const long long r = r0 + u * 16 + g;
-            const bool in_ = col_ok && r < rows;
-            v[u] = in_ ? src[r * H] : 0.0;
-            if (in_) { bad |= !(fabs(v[u]) < INFINITY); lo = fmin(lo, v[u]); hi = fmax(hi, v[u]); }
+            v[u] = (col_ok && r < rows) ? src[r * H] : 0.0;
         }
     };
     double s = 0.0;
@@ -161,6 +159,11 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
     for (long long r0 = 0; r0 < rows; r0 += DS_ROWS, b ^= 1) {
 #pragma unroll
         for (int u = 0; u < DS_U; ++u) buf[b][u * 16 + g][c] = v[u];
+        if (range) {                                           // (here, where the loads have landed -- not where they are issued)
+#pragma unroll
+            for (int u = 0; u < DS_U; ++u)
+                if (col_ok && r0 + u * 16 + g < rows) { bad |= !(fabs(v[u]) < INFINITY); lo = fmin(lo, v[u]); hi = fmax(hi, v[u]); }
+        }
         __syncthreads();
         if (r0 + DS_ROWS < rows) fetch(r0 + DS_ROWS);          // in flight while the batch is added
         if (tid < DS_COLS) {

@@ -27,9 +27,9 @@ elif kind == "binary":                     # zeros and ones only: every squared 
     ds = (torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64) < 0.5).double()
 else:
     ds = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
-score = eng.distinctive_score(ds, 0.5, 0.2)
 for rep in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)
+    score, rng = eng.distinctive_score(ds, 0.5, 0.2, with_range=True)      # as SimilarityCalculator(dataset).similarity_matrix()
+    mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, range=rng)
     torch.cuda.synchronize()
     print("%s: %.2f ms" % (kind, (time.perf_counter() - t0) * 1e3), flush=True)
