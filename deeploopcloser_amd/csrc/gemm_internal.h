@@ -55,7 +55,8 @@ int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, in
                         int64_t g_first, int64_t g_count, hipStream_t st);
 size_t sim_stream_panel_bytes(int64_t rows, int64_t H);
 int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const char* Y, const int* nbp,
-                   const unsigned long long* keys, unsigned char* abi, unsigned* acand, hipStream_t st);
+                   const unsigned long long* keys, unsigned char* abi, unsigned* acand, void* blocks, hipStream_t st);
+size_t gram_blocks_bytes(int64_t N, int64_t P);
 
 }  // namespace dlc_gemm
 

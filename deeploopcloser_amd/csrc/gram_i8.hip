@@ -58,6 +58,7 @@ struct GramI8Args {
     long long gpitch;                     // bytes of one 16-row group: 3 Kp / 64 k-steps of 1 KiB
     int kp, H, P, fpu;
     int tiles_m, tiles_n, nsm, nsn, nsup;
+    const int2* blk;                                // [nsup] (block row, block column) of the wanted blocks, row by row
 };
 
 // (best, index of the FIRST minimum, runner-up) of two disjoint candidate sets
@@ -66,6 +67,33 @@ __device__ __forceinline__ void gi_merge(int& best, int& bidx, int& second, int 
     const int lose = take ? best : ob;
     second = min(min(second, os), lose);
     if (take) { best = ob; bidx = oi; }
+}
+
+// The triangle's wanted blocks.  Block row si (GI_BR tiles of rows) wants the block columns from the one that holds the
+// column tile of frame (first row frame of the block row) + 1 -- a unit holds fpu frames, a tile two units.
+__host__ __device__ inline int gi_first_block_col(int si, int P, int fpu) {
+    const long long row_frame = ((long long)si * GI_BR * GI_T) / P;
+    return (int)(((row_frame + 1) / fpu / 2) / GI_BC);
+}
+
+// blk[nsup]: the wanted blocks numbered row by row (the workgroups of gram_i8_kernel look theirs up: r03 first had every
+// workgroup walk the block rows itself -- up to nsm iterations of two 64-bit divisions on the scalar unit, ~10 us of a
+// 38 us tile).  rowstart: [nsm + 1] scratch.  One workgroup of 256 threads.
+__global__ void gram_blocks_kernel(int nsm, int nsn, int P, int fpu, int* rowstart, int2* blk) {
+    for (int si = threadIdx.x; si < nsm; si += blockDim.x) {
+        const int cnt = nsn - gi_first_block_col(si, P, fpu);
+        rowstart[si + 1] = cnt > 0 ? cnt : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        rowstart[0] = 0;
+        for (int si = 0; si < nsm; ++si) rowstart[si + 1] += rowstart[si];
+    }
+    __syncthreads();
+    for (int si = threadIdx.x; si < nsm; si += blockDim.x) {
+        const int first = gi_first_block_col(si, P, fpu), o = rowstart[si];
+        for (int sj = first; sj < nsn; ++sj) blk[o + sj - first] = make_int2(si, sj);
+    }
 }
 
 // One 1 KiB LDS-DMA piece: lane l fetches bytes l * 16 .. + 15 behind the wave-uniform base `src` (+ voff, which carries
@@ -103,20 +131,10 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     // and dealt to the XCDs in turn: dealt by block column, the triangle gave XCD 7 2.4 times the work of XCD 0.
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3, local = slot & 31;
-    int want = (slot >> 5) * 8 + xcd;                 // index among the wanted blocks
-    int si = 0, sj = 0;
-    bool found = false;
-    for (; si < p.nsm; ++si) {
-        // first block column of block row si with a tile that holds a (row frame < column frame) entry: the column tile of
-        // frame (first row frame of the block row) + 1 -- a unit holds fpu frames, a tile two units
-        const long long row_frame = ((long long)si * GI_BR * GI_T) / p.P;
-        const int sj_min = (int)(((row_frame + 1) / p.fpu / 2) / GI_BC);
-        const int cnt = p.nsn - sj_min;
-        if (cnt <= 0) continue;
-        if (want < cnt) { sj = sj_min + want; found = true; break; }
-        want -= cnt;
-    }
-    if (!found) return;
+    const int want = (slot >> 5) * 8 + xcd;           // index among the wanted blocks: p.blk (gram_blocks_kernel) names it
+    if (want >= p.nsup) return;
+    const int2 blk = p.blk[want];
+    const int si = blk.x, sj = blk.y;
     const int tile_m = si * GI_BR + (local >> 3), tile_n = sj * GI_BC + (local & 7);
     if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
     const long long m0 = (long long)tile_m * GI_T, n0 = (long long)tile_n * GI_T;
@@ -153,68 +171,72 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { c2[j][i] = v4i{0, 0, 0, 0}; c3[j][i] = v4i{0, 0, 0, 0}; c4[j][i] = v4i{0, 0, 0, 0}; }
-    v4i fx[3][4], fy[3][4];                         // [slice][group]: ONE set (96 registers), reloaded in place (below)
+    // fragments [slice][group]: ONE set of the row panel's and of the column panel's slice 2, reloaded in place where they
+    // die; the column panel's slices 0 and 1 double-buffered (yb[buffer][slice]) -- 128 registers
+    v4i fx[3][4], fy2[4], yb[2][2][4];
 
     // fragment (slice s, group g) of this wave: row panel block ((wr * 4 + g) * 3 + s), column panel the same with wc
     const char* sx = smem_i8 + (wr * 4) * 3 * 1024 + lane * 16;
     const char* sy = smem_i8 + GI_HALF + (wc * 4) * 3 * 1024 + lane * 16;
 #define GI_RDX(S, SO) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) fx[S][g_] = *(const v4i*)(sx + (SO) + (g_ * 3 + (S)) * 1024)
-#define GI_RDY(S, SO) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) fy[S][g_] = *(const v4i*)(sy + (SO) + (g_ * 3 + (S)) * 1024)
+#define GI_RDY2(SO) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) fy2[g_] = *(const v4i*)(sy + (SO) + (g_ * 3 + 2) * 1024)
+#define GI_RDYB(BUF, S, SO) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) yb[BUF][S][g_] = *(const v4i*)(sy + (SO) + (g_ * 3 + (S)) * 1024)
     // The MFMA as inline asm with the accumulator PINNED to the AGPR file ("+a"): through the builtin hipcc kept part of
     // the 192 accumulators in VGPRs and moved them across at the loop's back edge -- 276 v_accvgpr_read / _write per k-step
     // beside 96 MFMAs.  volatile: the asm statements (these and the DMA pieces) keep their source order.
 #define GI_MFMA(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
-    // sixteen MFMAs of one slice product: column slice SY against row slice SX into class accumulator ACC
-#define GI_PROD(ACC, SY, SX)                                                                                    \
+    // sixteen MFMAs of one slice product: column fragments FY (four groups) against row slice SX into class accumulator ACC
+#define GI_PROD(ACC, FY, SX)                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
-            GI_MFMA(ACC[j][i], fy[SY][j], fx[SX][i]);
+            GI_MFMA(ACC[j][i], FY[j], fx[SX][i]);
     // ... with four DMA pieces of the stage three ahead, one behind every fourth MFMA: a piece is three instructions, which
     // fit in the shadow of the MFMA in front of them (two five-instruction pieces behind every fourth MFMA left the matrix
     // pipe idle for their issue time: the "no DMA" build was 1.0 ms of 6.3 faster)
-#define GI_PROD_DMA(ACC, SY, SX, B0, ISSUE)                                                                     \
+#define GI_PROD_DMA(ACC, FY, SX, B0, ISSUE)                                                                     \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
-            GI_MFMA(ACC[j][i], fy[SY][j], fx[SX][i]);                                                            \
+            GI_MFMA(ACC[j][i], FY[j], fx[SX][i]);                                                                \
         if (ISSUE) issue_piece((B0) + j);                                                                       \
     }
     // s_waitcnt immediates (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
     // builtin, not inline asm, so that hipcc's own wait insertion knows the LDS reads are done
     constexpr int GI_WAIT_VM12 = 0x007c, GI_WAIT_VM0 = 0x0070;
-    // One k-step.  The six slice products run in the order (y0 x0) (y0 x1) (y0 x2) | (y1 x0) (y2 x0) (y1 x1): behind the
-    // third one slice 0 of the columns and slice 2 of the rows are dead, behind the fifth slice 0 of the rows and slice 2
-    // of the columns -- their registers take the NEXT stage's fragments at those points, and slice 1 of both is fetched at
-    // the start of its own k-step (sixteen MFMAs ahead of its first use).  The workgroup's one barrier sits behind the
-    // third product: it says "stage t+1 has landed everywhere, and everybody has read the last of stage t" (slice 1, at
-    // the start of this k-step), so behind it the DMA of stage t+3 may overwrite stage t's slot.
+    // One k-step.  The six slice products run in the order (y0 x0) (y1 x0) (y2 x0) | (y0 x1) (y0 x2) (y1 x1).  Behind the third
+    // one x0 and y2 are dead and take the NEXT stage's fragments in place; y0 and y1 of the next stage go to the other
+    // buffer of the pair; x2 is reloaded behind the fifth product and x1 at the start of its own k-step.  Every reload is
+    // issued at least 48 MFMAs (768 cycles) before its first use -- the first r03 schedule had two reloads per k-step only
+    // 16 MFMAs ahead, and a single wave per SIMD has nobody to cover an LDS read that comes back late.  The workgroup's one
+    // barrier sits behind the third product: "stage t+1 has landed everywhere, and everybody has read the last of stage t"
+    // (x1, at the start of this k-step), so behind it the DMA of stage t+3 may overwrite stage t's slot.
     int cur = 0, nxt = 1;                           // LDS slots of stage t and stage t+1
-#define GI_STEP(WAIT, ISSUE)                                                                                    \
+#define GI_STEP(C, N, WAIT, ISSUE)                                                                              \
     {                                                                                                           \
         const int so_c = cur * GI_STAGE, so_n = nxt * GI_STAGE;                                                 \
-        GI_RDX(1, so_c); GI_RDY(1, so_c);                                                                       \
+        GI_RDX(1, so_c);                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_PROD(c2, 0, 0)                                                                                       \
-        GI_PROD(c3, 0, 1)                                                                                       \
-        GI_PROD(c4, 0, 2)                                                                                       \
+        GI_PROD(c2, yb[C][0], 0)                                                                                \
+        GI_PROD(c3, yb[C][1], 0)                                                                                \
+        GI_PROD(c4, fy2, 0)                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         __builtin_amdgcn_s_waitcnt(WAIT);           /* this wave's pieces of stage t+1 */                        \
         asm volatile("" ::: "memory");                                                                          \
         __builtin_amdgcn_s_barrier();                                                                           \
         asm volatile("" ::: "memory");                                                                          \
-        GI_RDY(0, so_n); GI_RDX(2, so_n);                                                                       \
+        GI_RDX(0, so_n); GI_RDYB(N, 0, so_n); GI_RDYB(N, 1, so_n); GI_RDY2(so_n);                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_PROD_DMA(c3, 1, 0, 0, ISSUE)                                                                         \
-        GI_PROD_DMA(c4, 2, 0, 4, ISSUE)                                                                         \
+        GI_PROD_DMA(c3, yb[C][0], 1, 0, ISSUE)                                                                  \
+        GI_PROD_DMA(c4, yb[C][0], 2, 4, ISSUE)                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_RDX(0, so_n); GI_RDY(2, so_n);                                                                       \
+        GI_RDX(2, so_n);                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_PROD_DMA(c4, 1, 1, 8, ISSUE)                                                                         \
+        GI_PROD_DMA(c4, yb[C][1], 1, 8, ISSUE)                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         if (ISSUE) issue_done();                                                                                \
         cur = nxt;                                                                                              \
         nxt = nxt == GI_NSTAGE - 1 ? 0 : nxt + 1;                                                               \
     }
-    // prologue: stages 0 .. 2 in flight; of stage 0 everything but slice 1 into the registers
+    // prologue: stages 0 .. 2 in flight; of stage 0 everything but x1 into the registers
 #pragma unroll
     for (int t = 0; t < GI_NSTAGE; ++t) {
 #pragma unroll
@@ -224,19 +246,26 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                    // stage 0 (12 pieces per stage and wave)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    GI_RDY(0, 0); GI_RDX(2, 0); GI_RDX(0, 0); GI_RDY(2, 0);
-    // steady state: k-steps 0 .. n64 - 4 fetch the stage three ahead; the last three fetch nothing
+    GI_RDX(0, 0); GI_RDX(2, 0); GI_RDYB(0, 0, 0); GI_RDYB(0, 1, 0); GI_RDY2(0);
+    // steady state, two k-steps per trip (the y buffers alternate): k-steps 0 .. n64 - 4 fetch the stage three ahead, the last
+    // three fetch nothing; n64 is a multiple of 4, so the loop leaves exactly four k-steps
+    int t = 0;
 #pragma unroll 1
-    for (int t = 0; t < n64 - GI_NSTAGE; ++t) GI_STEP(GI_WAIT_VM12, true)
-    GI_STEP(GI_WAIT_VM12, false)
-    GI_STEP(GI_WAIT_VM0, false)
-    GI_STEP(GI_WAIT_VM0, false)                     // (its reads of "stage n64" fetch a slot nobody writes any more: unused)
+    for (; t + 2 <= n64 - GI_NSTAGE; t += 2) {
+        GI_STEP(0, 1, GI_WAIT_VM12, true)
+        GI_STEP(1, 0, GI_WAIT_VM12, true)
+    }
+    GI_STEP(0, 1, GI_WAIT_VM12, true)
+    GI_STEP(1, 0, GI_WAIT_VM12, false)
+    GI_STEP(0, 1, GI_WAIT_VM0, false)
+    GI_STEP(1, 0, GI_WAIT_VM0, false)               // (its reads of "stage n64" fetch a slot nobody writes any more: unused)
 #undef GI_STEP
 #undef GI_PROD_DMA
 #undef GI_PROD
 #undef GI_MFMA
 #undef GI_RDX
-#undef GI_RDY
+#undef GI_RDY2
+#undef GI_RDYB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: the patch arg-min of every (row patch, column frame) of the tile, decided here -- the products never
@@ -507,6 +536,12 @@ int sim_frames_per_unit(int64_t P) { return (int)(64 / P); }
 static int64_t sim_col_tiles(int64_t N, int64_t P) { return dlc::cdiv(dlc::cdiv(N, (int64_t)sim_frames_per_unit(P)), (int64_t)2); }
 int64_t sim_col_rows(int64_t N, int64_t P) { return sim_col_tiles(N, P) * GI_T; }                      // rows of Y, entries of nbp
 int64_t sim_col_frames(int64_t N, int64_t P) { return sim_col_tiles(N, P) * 2 * sim_frames_per_unit(P); }   // nfp: frames per row of abi / acand
+// the block table of gram_argmin_i8 (`blocks`)
+size_t gram_blocks_bytes(int64_t N, int64_t P) {
+    const size_t tiles_m = (size_t)dlc::cdiv((N > 1 ? N - 1 : 1) * P, (int64_t)GI_T), tiles_n = (size_t)sim_col_tiles(N, P);
+    const size_t nsm = (tiles_m + GI_BR - 1) / GI_BR, nsn = (tiles_n + GI_BC - 1) / GI_BC;
+    return dlc::align_up(nsm + 1, 2) * 4 + nsm * nsn * 8;
+}
 size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H) {
     const size_t kp = dlc::align_up((size_t)H, (size_t)GI_KPAD);
     return (size_t)sim_col_rows(N, P) * 3 * kp;
@@ -580,7 +615,7 @@ int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, cons
 // The patch arg-min of every (row patch a, column frame j) with frame(a) < j, for all N frames at once: abi / acand are
 // [N * P, sim_col_frames(N, P)] (bytes / 32-bit words); entries with frame(a) >= j are not written.
 int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const char* Y, const int* nbp,
-                   const unsigned long long* keys, unsigned char* abi, unsigned* acand, hipStream_t st) {
+                   const unsigned long long* keys, unsigned char* abi, unsigned* acand, void* blocks, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     GramI8Args a;
     a.gpitch = 3ll * kp * 16; a.kp = kp; a.H = (int)H; a.P = (int)P; a.fpu = sim_frames_per_unit(P);
@@ -591,13 +626,16 @@ int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X,
     if (a.tiles_m < 1) return DLC_OK;
     a.nsm = (a.tiles_m + GI_BR - 1) / GI_BR;
     a.nsn = (a.tiles_n + GI_BC - 1) / GI_BC;
-    a.nsup = 0;                               // blocks with a wanted tile (the kernel numbers them the same way)
+    a.nsup = 0;                               // blocks with a wanted tile (gram_blocks_kernel numbers them the same way)
     for (int si = 0; si < a.nsm; ++si) {
-        const long long row_frame = ((long long)si * GI_BR * GI_T) / P;
-        const int cnt = a.nsn - (int)(((row_frame + 1) / a.fpu / 2) / GI_BC);
+        const int cnt = a.nsn - gi_first_block_col(si, (int)P, a.fpu);
         if (cnt > 0) a.nsup += cnt;
     }
     if (a.nsup == 0) return DLC_OK;
+    int* rowstart = (int*)blocks;
+    a.blk = (const int2*)(rowstart + dlc::align_up((size_t)a.nsm + 1, 2));
+    hipLaunchKernelGGL(gram_blocks_kernel, dim3(1), dim3(256), 0, st, a.nsm, a.nsn, (int)P, a.fpu, rowstart, (int2*)a.blk);
+    DLC_LAUNCH_CHECK(ctx, "gram_blocks_kernel");
     const size_t lds = (size_t)GI_NSTAGE * GI_STAGE;
     if (!(ctx->func_attr_set & (1ull << DLC_ATTR_GRAM_I8))) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gram_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const unsigned long lon
 }
 
 struct SimWs {
-    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, qy, nbp, abi, acand, total;
+    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, qy, nbp, abi, acand, blk, total;
     long long chunk_frames, nfp;
 };
 
@@ -966,7 +966,7 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     const size_t prog_bytes = dlc_gemm::sim_pairwise_program_bytes(H);
     w.prog = o; o += prog_bytes > 8192 ? prog_bytes : 8192;
     w.rowhash = o; o += dlc::align_up((size_t)N * P * 16, 256);
-    w.nu2 = w.qx = w.qy = w.nbp = w.abi = w.acand = 0;
+    w.nu2 = w.qx = w.qy = w.nbp = w.abi = w.acand = w.blk = 0;
     w.nfp = 0;
     if (filter) {
         // the two fixed-point panels (rows in order; columns in units of whole frames), |u|^2, and the product kernel's
@@ -978,6 +978,7 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
         w.nbp = o; o += dlc::align_up((size_t)dlc_gemm::sim_col_rows(N, P) * 4, 256);
         w.abi = o; o += dlc::align_up((size_t)N * P * w.nfp, 256);
         w.acand = o; o += dlc::align_up((size_t)N * P * w.nfp * 4, 256);
+        w.blk = o; o += dlc::align_up(dlc_gemm::gram_blocks_bytes(N, P), 256);
         w.desc_t = o;
     } else {
         // the descriptors transposed [H, N*P] (one extra pass over them): the fp64 Gram blocks then read their B operand as
@@ -1099,7 +1100,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
             if (N > 1) {
                 // all frames in ONE launch: the product kernel keeps its 31 890 x 31 890 products on the chip and emits
                 // the arg-mins (r02: row chunks of an 8 GiB int32 block)
-                rc = dlc_gemm::gram_argmin_i8(ctx, N, P, H, qx, qy, nbp, keys, abi, acand, st);
+                rc = dlc_gemm::gram_argmin_i8(ctx, N, P, H, qx, qy, nbp, keys, abi, acand, ws + w.blk, st);
                 if (rc != DLC_OK) return rc;
                 hipLaunchKernelGGL(pair_score_amin_kernel, dim3(PS_GX, (unsigned)(N - 1)), dim3(256), PF_STACK_BYTES, st, desc,
                                    (const unsigned char*)abi, (const unsigned*)acand, (long long)w.nfp, proj, score, keys,

@@ -23,13 +23,15 @@ PY
     (cd $T/$name && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-function *.hip -o $R/exp_build/lib_gram_$name.so)
     echo built exp_build/lib_gram_$name.so
 }
-LOOP='for (int t = 0; t < n64 - GI_NSTAGE; ++t) GI_STEP(GI_WAIT_VM12, true)'
 BAR='        __builtin_amdgcn_s_barrier();                                                                           \\'
+NODMA="('if (ISSUE) issue_piece((B0) + j);', ''), ('if (ISSUE) issue_done();', '')"
+NOLDS="('GI_RDX(1, so_c);', ''), ('GI_RDX(0, so_n); GI_RDYB(N, 0, so_n); GI_RDYB(N, 1, so_n); GI_RDY2(so_n);', ''), ('GI_RDX(2, so_n);', '')"
+NOBAR="('''$BAR''', '        \\\\')"
 build base "[]" &
-build nodma "[('''$LOOP''', 'for (int t = 0; t < n64 - GI_NSTAGE; ++t) GI_STEP(GI_WAIT_VM0, false)')]" &
-build nobarrier "[('''$BAR''', '        \\\\')]" &
+build nodma "[$NODMA]" &
+build nobarrier "[$NOBAR]" &
 wait
-build nolds "[('GI_RDX(1, so_c); GI_RDY(1, so_c);', ''), ('GI_RDY(0, so_n); GI_RDX(2, so_n);', ''), ('GI_RDX(0, so_n); GI_RDY(2, so_n);', '')]" &
-build nodma_nobarrier "[('''$LOOP''', 'for (int t = 0; t < n64 - GI_NSTAGE; ++t) GI_STEP(GI_WAIT_VM0, false)'), ('''$BAR''', '        \\\\')]" &
+build nolds "[$NOLDS]" &
+build mfma_only "[$NODMA, $NOLDS, $NOBAR]" &
 wait
 rm -rf $T
