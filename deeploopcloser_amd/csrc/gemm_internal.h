@@ -41,6 +41,7 @@ size_t sim_filter_panel_bytes(int64_t rows, int64_t H);
 int sim_frames_per_unit(int64_t P);
 int64_t sim_col_rows(int64_t N, int64_t P);
 int64_t sim_col_frames(int64_t N, int64_t P);
+int64_t sim_argmin_pitch(int64_t N, int64_t P);
 size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H);
 int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H, const double* score,
                        unsigned long long* keys, char* X, char* Y, int* nbp, double* nu2, double* proj,

@@ -51,14 +51,16 @@ struct GramI8Args {
                                           // that every frame's P columns lie inside one wave's 64-column block
     const int* nbp;                       // |u_b|^2 of the column panel's rows, units of 2^-13 (padded like Y)
     const unsigned long long* keys;       // [3]: largest row sum of u (the error bound), [2]: non-finite flag
-    unsigned char* abi;                   // out [nrows, nfp]: the nearest patch b of column frame j to row patch a
-    unsigned* acand;                      // out [nrows, nfp]: 0 = decided; else the patches inside the error window (bit b)
-    long long nfp;                        // frames per row of abi / acand (padded: whole tiles)
+    unsigned char* abi;                   // out [nfp, rp]: the nearest patch b of column frame j to row patch a
+    unsigned* acand;                      // out [nfp, rp]: 0 = decided; else the patches inside the error window (bit b)
+    long long nfp, rp;                    // column frames of abi / acand (padded: whole tiles) and their pitch (row patches)
     long long nrows, nframes;
     long long gpitch;                     // bytes of one 16-row group: 3 Kp / 64 k-steps of 1 KiB
     int kp, H, P, fpu;
     int tiles_m, tiles_n, nsm, nsn, nsup;
-    const int2* blk;                                // [nsup] (block row, block column) of the wanted blocks, row by row
+    const int2* tiles;                              // the wanted tiles (row tile, column tile), block by block; *ntiles of them
+    const int* ntiles;
+    unsigned* sync;                                 // [8 * 32]: per XCD (128 bytes apart) how many tiles its workgroups have nearly finished
 };
 
 // (best, index of the FIRST minimum, runner-up) of two disjoint candidate sets
@@ -76,10 +78,21 @@ __host__ __device__ inline int gi_first_block_col(int si, int P, int fpu) {
     return (int)(((row_frame + 1) / fpu / 2) / GI_BC);
 }
 
-// blk[nsup]: the wanted blocks numbered row by row (the workgroups of gram_i8_kernel look theirs up: r03 first had every
-// workgroup walk the block rows itself -- up to nsm iterations of two 64-bit divisions on the scalar unit, ~10 us of a
-// 38 us tile).  rowstart: [nsm + 1] scratch.  One workgroup of 256 threads.
-__global__ void gram_blocks_kernel(int nsm, int nsn, int P, int fpu, int* rowstart, int2* blk) {
+// Is tile (tm, tn) wanted?  Its last frame must lie behind its first row's frame, and its first frame must exist.
+__host__ __device__ inline bool gi_tile_wanted(int tm, int tn, int tiles_m, int tiles_n, int P, int fpu, long long nframes) {
+    if (tm >= tiles_m || tn >= tiles_n) return false;
+    return !((long long)(2 * tn + 2) * fpu - 1 <= (long long)tm * GI_T / P || (long long)2 * tn * fpu >= nframes);
+}
+
+// tiles[0 .. *ntiles): the wanted tiles (row tile, column tile), block by block (the wanted blocks row by row, a block's
+// GI_BR x GI_BC tiles row by row) -- gram_i8_kernel's workgroups look theirs up.  (r03 first had every workgroup of a
+// one-tile-per-workgroup grid walk the block rows itself: up to nsm iterations of two 64-bit divisions on the scalar
+// unit, ~5 us of a 43 us tile.)  scratch: [nsm + 1 + nsm * nsn + 1] ints.  One workgroup of 256 threads.
+__global__ void gram_tiles_kernel(int nsm, int nsn, int tiles_m, int tiles_n, int P, int fpu, long long nframes, int* scratch,
+                                  int2* tiles, int* ntiles, unsigned* sync) {
+    sync[threadIdx.x] = 0u;                         // (256 threads: the 8 counters and their padding)
+    int* rowstart = scratch;                       // [nsm + 1]: first wanted block of every block row
+    int* tstart = scratch + nsm + 1;               // [nsup + 1]: first wanted tile of every wanted block
     for (int si = threadIdx.x; si < nsm; si += blockDim.x) {
         const int cnt = nsn - gi_first_block_col(si, P, fpu);
         rowstart[si + 1] = cnt > 0 ? cnt : 0;
@@ -91,8 +104,31 @@ __global__ void gram_blocks_kernel(int nsm, int nsn, int P, int fpu, int* rowsta
     }
     __syncthreads();
     for (int si = threadIdx.x; si < nsm; si += blockDim.x) {
-        const int first = gi_first_block_col(si, P, fpu), o = rowstart[si];
-        for (int sj = first; sj < nsn; ++sj) blk[o + sj - first] = make_int2(si, sj);
+        const int first = gi_first_block_col(si, P, fpu);
+        for (int sj = first; sj < nsn; ++sj) {
+            int cnt = 0;
+            for (int l = 0; l < GI_BR * GI_BC; ++l)
+                cnt += gi_tile_wanted(si * GI_BR + l / GI_BC, sj * GI_BC + l % GI_BC, tiles_m, tiles_n, P, fpu, nframes);
+            tstart[rowstart[si] + sj - first + 1] = cnt;
+        }
+    }
+    __syncthreads();
+    const int nsup = rowstart[nsm];
+    if (threadIdx.x == 0) {
+        tstart[0] = 0;
+        for (int b = 0; b < nsup; ++b) tstart[b + 1] += tstart[b];
+        *ntiles = tstart[nsup];
+    }
+    __syncthreads();
+    for (int si = threadIdx.x; si < nsm; si += blockDim.x) {
+        const int first = gi_first_block_col(si, P, fpu);
+        for (int sj = first; sj < nsn; ++sj) {
+            int o = tstart[rowstart[si] + sj - first];
+            for (int l = 0; l < GI_BR * GI_BC; ++l) {
+                const int tm = si * GI_BR + l / GI_BC, tn = sj * GI_BC + l % GI_BC;
+                if (gi_tile_wanted(tm, tn, tiles_m, tiles_n, P, fpu, nframes)) tiles[o++] = make_int2(tm, tn);
+            }
+        }
     }
 }
 
@@ -120,27 +156,37 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 // (g * 3 + s), lane l of a block holds row l % 16, bytes (l / 16) * 16 .. + 15 of the k-step of slice s -- then the
 // column panel's the same.  A fragment read is one ds_read_b128 at block + lane * 16.
 //
-// Pipeline: three stages; iteration t multiplies the fragments of stage t, which it read from LDS during iteration t-1,
-// while it reads those of stage t+1 and issues the DMA of stage t+3 into stage t's slot -- ONE wave per SIMD (192
-// accumulators + two fragment buffers of 96 registers), so the interleaving inside the wave is what hides the LDS and
-// DMA latencies.  Barrier t says "stage t+1 has landed everywhere and everybody is through reading stage t".
+// Pipeline: three stages; k-step t multiplies the fragments of stage t, which it read from LDS during k-step t-1, while
+// it reads those of stage t+1 and issues the DMA of stage t+3 into stage t's slot -- ONE wave per SIMD (192 accumulators +
+// 128 fragment registers), so the interleaving inside the wave is what hides the LDS and DMA latencies.
+//
+// PERSISTENT workgroups: 256 of them, one per CU.  Workgroup (xcd, local) takes tile `local` of the blocks xcd, xcd + 8,
+// xcd + 16, ... of p.blk -- the XCD's 32 workgroups walk the same block at the same time (12 panels feed 32 tiles out of
+// that XCD's L2), as the 33 000 one-tile workgroups of the first r03 kernel did, but the STAGES FORM ONE STREAM ACROSS THE
+// TILES: the last three k-steps of a tile fetch the first three stages of the next one, so a tile has no prologue of its
+// own and the chip no workgroup turnover (measured on the one-tile form with s_memtime, cycles per tile: block lookup 800,
+// prologue 4 100, k loop 82 300, epilogue 8 000, and 9 600 between the end of one workgroup and the start of the next on
+// the CU).  The epilogue therefore owns 16 KiB of LDS behind the three stages (160 KiB in all).
+constexpr int GI_EPI = 4 * 16 * 64 * 4;     // the epilogue's region: per wave 16 rows x 64 columns of d2 (ints)
+constexpr int GI_GRID = 256;
 __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem_i8[];
-    // workgroup -> tile: ids go round-robin to the 8 XCDs; an XCD's 32 resident workgroups take one GI_BR x GI_BC block
-    // of tiles (12 panels feed 32 tiles out of that XCD's L2).  Only blocks with a wanted tile are numbered, row by row,
-    // and dealt to the XCDs in turn: dealt by block column, the triangle gave XCD 7 2.4 times the work of XCD 0.
     const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3, local = slot & 31;
-    const int want = (slot >> 5) * 8 + xcd;           // index among the wanted blocks: p.blk (gram_blocks_kernel) names it
-    if (want >= p.nsup) return;
-    const int2 blk = p.blk[want];
-    const int si = blk.x, sj = blk.y;
-    const int tile_m = si * GI_BR + (local >> 3), tile_n = sj * GI_BC + (local & 7);
-    if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
-    const long long m0 = (long long)tile_m * GI_T, n0 = (long long)tile_n * GI_T;
-    // the tile's last frame must lie behind its first row's frame, and its first frame must exist
-    if ((long long)(2 * tile_n + 2) * p.fpu - 1 <= m0 / p.P || (long long)2 * tile_n * p.fpu >= p.nframes) return;
+    const int xcd = id & 7, local = (id >> 3) & 31;
     if (p.keys[2]) return;                          // a NaN / infinity in the dataset: this form does not apply
+    // this workgroup's tiles: entry `local` of every eighth group of 32 consecutive wanted tiles, from group xcd on
+    const int ntiles = *p.ntiles;
+    int round = -1, tile_m = 0, tile_n = 0, done = 0;
+    auto next_tile = [&]() -> bool {
+        ++round;
+        const int idx = (round * 8 + xcd) * 32 + local;
+        if (idx >= ntiles) return false;
+        const int2 t = p.tiles[idx];
+        tile_m = t.x;
+        tile_n = t.y;
+        return true;
+    };
+    if (!next_tile()) return;
 
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wr = w >> 1, wc = w & 1;              // 64 row patches x 64 column patches per wave
@@ -149,11 +195,14 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     // this wave's DMA share of a stage: groups 2 w, 2 w + 1 of each panel, three slices each = 12 pieces.  Piece b:
     // panel b / 6, group (b % 6) / 3, slice b % 3; its source base is wave-uniform, the k-step rides in the lanes' offset.
     const char* src[12];
+    auto set_src = [&](int tm, int tn) {
 #pragma unroll
-    for (int b = 0; b < 12; ++b) {
-        const char* panel = b < 6 ? p.X + (m0 / 16) * p.gpitch : p.Y + (n0 / 16) * p.gpitch;
-        src[b] = uniform_ptr(panel + (long long)(w * 2 + (b % 6) / 3) * p.gpitch + (long long)(b % 3) * n64 * 1024);
-    }
+        for (int b = 0; b < 12; ++b) {
+            const char* panel = b < 6 ? p.X + ((long long)tm * GI_T / 16) * p.gpitch : p.Y + ((long long)tn * GI_T / 16) * p.gpitch;
+            src[b] = uniform_ptr(panel + (long long)(w * 2 + (b % 6) / 3) * p.gpitch + (long long)(b % 3) * n64 * 1024);
+        }
+    };
+    set_src(tile_m, tile_n);
     // its LDS destination inside a stage: block ((2 w + group) * 3 + slice) of the panel's half
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_base + w * 6 * 1024);
     unsigned voff_issue = lane * 16;                // lanes' offset of the next stage to fetch: + 1 KiB per k-step
@@ -167,10 +216,6 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     };
 
     v4i c2[4][4], c3[4][4], c4[4][4];               // [column group j][row group i] of the three classes
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { c2[j][i] = v4i{0, 0, 0, 0}; c3[j][i] = v4i{0, 0, 0, 0}; c4[j][i] = v4i{0, 0, 0, 0}; }
     // fragments [slice][group]: ONE set of the row panel's and of the column panel's slice 2, reloaded in place where they
     // die; the column panel's slices 0 and 1 double-buffered (yb[buffer][slice]) -- 128 registers
     v4i fx[3][4], fy2[4], yb[2][2][4];
@@ -185,37 +230,46 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     // the 192 accumulators in VGPRs and moved them across at the loop's back edge -- 276 v_accvgpr_read / _write per k-step
     // beside 96 MFMAs.  volatile: the asm statements (these and the DMA pieces) keep their source order.
 #define GI_MFMA(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+    // one fragment read (a ds_read_b128), pinned where it stands between the MFMAs
+#define GI_RD(DST, PTR) { __builtin_amdgcn_sched_barrier(0); DST = *(const v4i*)(PTR); __builtin_amdgcn_sched_barrier(0); }
+#define GI_PX(S, G, SO) (sx + (SO) + ((G) * 3 + (S)) * 1024)
+#define GI_PY(S, G, SO) (sy + (SO) + ((G) * 3 + (S)) * 1024)
     // sixteen MFMAs of one slice product: column fragments FY (four groups) against row slice SX into class accumulator ACC
 #define GI_PROD(ACC, FY, SX)                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
             GI_MFMA(ACC[j][i], FY[j], fx[SX][i]);
-    // ... with four DMA pieces of the stage three ahead, one behind every fourth MFMA: a piece is three instructions, which
-    // fit in the shadow of the MFMA in front of them (two five-instruction pieces behind every fourth MFMA left the matrix
-    // pipe idle for their issue time: the "no DMA" build was 1.0 ms of 6.3 faster)
-#define GI_PROD_DMA(ACC, FY, SX, B0, ISSUE)                                                                     \
+    // ... with fragment reads and DMA pieces between them.  Behind every fourth MFMA a DMA piece of the stage three ahead (a
+    // piece is three instructions, which fit in the shadow of the MFMA in front of them; two five-instruction pieces behind
+    // every fourth MFMA left the matrix pipe idle for their issue time); behind the second (and, RD2, the fourth) MFMA of
+    // every four a fragment read of the next stage -- NOT in bursts between the products: the four waves leave the barrier
+    // together, sixteen reads each were 64 KiB queued at the LDS at once, and a wave whose read is not accepted yet cannot
+    // issue the MFMA behind it either.
+#define GI_PROD_IL(ACC, FY, SX, B0, ISSUE, RD1, RD2)                                                            \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
-            GI_MFMA(ACC[j][i], FY[j], fx[SX][i]);                                                                \
+        GI_MFMA(ACC[j][0], FY[j], fx[SX][0]);                                                                   \
+        GI_MFMA(ACC[j][1], FY[j], fx[SX][1]);                                                                   \
+        RD1;                                                                                                    \
+        GI_MFMA(ACC[j][2], FY[j], fx[SX][2]);                                                                   \
+        GI_MFMA(ACC[j][3], FY[j], fx[SX][3]);                                                                   \
+        RD2;                                                                                                    \
         if (ISSUE) issue_piece((B0) + j);                                                                       \
     }
-    // s_waitcnt immediates (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
+    // s_waitcnt immediate (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
     // builtin, not inline asm, so that hipcc's own wait insertion knows the LDS reads are done
-    constexpr int GI_WAIT_VM12 = 0x007c, GI_WAIT_VM0 = 0x0070;
+    constexpr int GI_WAIT_VM12 = 0x007c;
     // One k-step.  The six slice products run in the order (y0 x0) (y1 x0) (y2 x0) | (y0 x1) (y0 x2) (y1 x1).  Behind the third
     // one x0 and y2 are dead and take the NEXT stage's fragments in place; y0 and y1 of the next stage go to the other
-    // buffer of the pair; x2 is reloaded behind the fifth product and x1 at the start of its own k-step.  Every reload is
-    // issued at least 48 MFMAs (768 cycles) before its first use -- the first r03 schedule had two reloads per k-step only
-    // 16 MFMAs ahead, and a single wave per SIMD has nobody to cover an LDS read that comes back late.  The workgroup's one
-    // barrier sits behind the third product: "stage t+1 has landed everywhere, and everybody has read the last of stage t"
-    // (x1, at the start of this k-step), so behind it the DMA of stage t+3 may overwrite stage t's slot.
+    // buffer of the pair; x2 is reloaded during the sixth product and x1 during the first of its own k-step.  Every
+    // reload is issued at least 32 MFMAs (512 cycles) before its first use.  The workgroup's one barrier sits behind the
+    // third product: "stage t+1 has landed everywhere, and everybody has read the last of stage t" (x1, during the first
+    // product), so behind it the DMA of stage t+3 may overwrite stage t's slot.
     int cur = 0, nxt = 1;                           // LDS slots of stage t and stage t+1
 #define GI_STEP(C, N, WAIT, ISSUE)                                                                              \
     {                                                                                                           \
         const int so_c = cur * GI_STAGE, so_n = nxt * GI_STAGE;                                                 \
-        GI_RDX(1, so_c);                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_PROD(c2, yb[C][0], 0)                                                                                \
+        GI_PROD_IL(c2, yb[C][0], 0, 0, false, GI_RD(fx[1][j], GI_PX(1, j, so_c)), )                             \
         GI_PROD(c3, yb[C][1], 0)                                                                                \
         GI_PROD(c4, fy2, 0)                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -223,20 +277,16 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
         asm volatile("" ::: "memory");                                                                          \
         __builtin_amdgcn_s_barrier();                                                                           \
         asm volatile("" ::: "memory");                                                                          \
-        GI_RDX(0, so_n); GI_RDYB(N, 0, so_n); GI_RDYB(N, 1, so_n); GI_RDY2(so_n);                               \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_PROD_DMA(c3, yb[C][0], 1, 0, ISSUE)                                                                  \
-        GI_PROD_DMA(c4, yb[C][0], 2, 4, ISSUE)                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_RDX(2, so_n);                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_PROD_DMA(c4, yb[C][1], 1, 8, ISSUE)                                                                  \
+        GI_PROD_IL(c3, yb[C][0], 1, 0, ISSUE, GI_RD(yb[N][0][j], GI_PY(0, j, so_n)), GI_RD(fx[0][j], GI_PX(0, j, so_n))) \
+        GI_PROD_IL(c4, yb[C][0], 2, 4, ISSUE, GI_RD(yb[N][1][j], GI_PY(1, j, so_n)), GI_RD(fy2[j], GI_PY(2, j, so_n)))   \
+        GI_PROD_IL(c4, yb[C][1], 1, 8, ISSUE, GI_RD(fx[2][j], GI_PX(2, j, so_n)), )                             \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         if (ISSUE) issue_done();                                                                                \
         cur = nxt;                                                                                              \
         nxt = nxt == GI_NSTAGE - 1 ? 0 : nxt + 1;                                                               \
     }
-    // prologue: stages 0 .. 2 in flight; of stage 0 everything but x1 into the registers
+    // the stream's start: stages 0 .. 2 of the first tile in flight; of stage 0 everything but x1 into the registers
 #pragma unroll
     for (int t = 0; t < GI_NSTAGE; ++t) {
 #pragma unroll
@@ -247,83 +297,111 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     GI_RDX(0, 0); GI_RDX(2, 0); GI_RDYB(0, 0, 0); GI_RDYB(0, 1, 0); GI_RDY2(0);
-    // steady state, two k-steps per trip (the y buffers alternate): k-steps 0 .. n64 - 4 fetch the stage three ahead, the last
-    // three fetch nothing; n64 is a multiple of 4, so the loop leaves exactly four k-steps
-    int t = 0;
+
+    const double E = 0x1p-20 * dlc_f64_unkey(p.keys[3]) + (double)p.H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
+    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
+    const unsigned wu = window > 0xffffffffll ? 0xffffffffu : (unsigned)window, pmask = p.P >= 32 ? ~0u : (1u << p.P) - 1u;
+    for (;;) {
+        const int cur_m = tile_m, cur_n = tile_n;
+        const bool has_next = next_tile();          // (tile_m, tile_n) is the next tile from here on
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c2[j][i] = v4i{0, 0, 0, 0}; c3[j][i] = v4i{0, 0, 0, 0}; c4[j][i] = v4i{0, 0, 0, 0}; }
+        // two k-steps per trip (the y buffers alternate).  k-steps 0 .. n64 - 4 fetch this tile's stage three ahead, the last
+        // three the first three stages of the next tile (behind the last tile: of this one again, into slots nobody reads --
+        // one code path, and every k-step's wait is "all but the newest twelve pieces")
 #pragma unroll 1
-    for (; t + 2 <= n64 - GI_NSTAGE; t += 2) {
-        GI_STEP(0, 1, GI_WAIT_VM12, true)
-        GI_STEP(1, 0, GI_WAIT_VM12, true)
+        for (int t = 0; t < n64; t += 2) {
+            GI_STEP(0, 1, GI_WAIT_VM12, true)
+            if (t == n64 - 4) {                     // n64 is a multiple of 4: k-step n64 - 4 is the first of its pair
+                if (has_next) set_src(tile_m, tile_n);
+                voff_issue = lane * 16;
+                if (tid == 0) __hip_atomic_fetch_add(p.sync + xcd * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            GI_STEP(1, 0, GI_WAIT_VM12, true)       // (the last one's fragment reads are the next tile's stage 0: all but x1)
+        }
+
+        // ---- epilogue: the patch arg-min of every (row patch, column frame) of the tile, decided here -- the products never
+        // leave the chip (r02 / early r03 wrote them out, 2 GB, for a second kernel to read back).
+        // acc = C2 + floor((C3 + floor(C4 / 128)) / 128) in units of 2^-14 of u . u; d2 = |u_b|^2 - 2 acc 2^-14 in units of 2^-13.
+        // D[m][n] of MFMA (j, i): m = column j * 16 + (lane / 16) * 4 + v of this wave's unit, n = row patch (wr * 4 + i) * 16 + lane % 16.
+        // A row patch's columns are spread over four lanes and sixteen registers; rather than merge (best, index, runner-up)
+        // triples across lanes -- a chain of 64 dependent cross-lane moves per tile, 7 us -- the wave turns its block of d2
+        // through LDS, one group of 16 row patches at a time (its own 4 KiB: the stages already hold the next tile), so that
+        // a lane owns a (row patch, frame) pair: one sequential scan, as the pair kernels of the fp64 form do it.  Element
+        // (row n, column c) lives at int n * 64 + (c + 4 n) % 64: the 16-byte writes stay whole, and lanes on different
+        // rows reading the same column hit different banks.
+        int* d2s = (int*)(smem_i8 + GI_NSTAGE * GI_STAGE) + w * 16 * 64;
+        const int quad = lane >> 4, ln = lane & 15;
+        const long long unit = (long long)cur_n * 2 + wc;               // this wave's 64 columns: frames unit * fpu .. + fpu - 1
+        v4i nbl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nbl[j] = *(const v4i*)(p.nbp + unit * 64 + j * 16 + quad * 4);
+        ++done;
+        unsigned seen = has_next ? __hip_atomic_load(p.sync + xcd * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4i acc = c2[j][i] + ((c3[j][i] + (c4[j][i] >> 7)) >> 7);
+                *(v4i*)(d2s + ln * 64 + ((j * 16 + quad * 4 + 4 * ln) & 63)) = nbl[j] - acc;
+                __builtin_amdgcn_sched_barrier(0);                      // (the next tile's fragments are live: no room to hoist all the accumulator reads)
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);                          // lgkmcnt(0): this wave's LDS writes (its own region)
+            __builtin_amdgcn_wave_barrier();
+            for (int task = lane; task < 16 * p.fpu; task += 64) {       // (row patch r of the group, frame fs of the unit)
+                const int r = task & 15, fs = task >> 4;
+                const long long a = (long long)cur_m * GI_T + wr * 64 + i * 16 + r, fj = unit * p.fpu + fs;
+                if (!(a < p.nrows && fj < p.nframes && a < fj * p.P)) continue;     // (row frame < column frame)  <=>  a < fj * P
+                const int* drow = d2s + r * 64;
+                const int c0 = fs * p.P + 4 * r;
+                int dv[32];                                              // P <= 32 (sim_use_filter): all reads in flight at once
+#pragma unroll
+                for (int b = 0; b < 32; ++b) dv[b] = drow[(c0 + b) & 63];   // (columns behind the frame's P: read, not used)
+#pragma unroll
+                for (int b = 1; b < 32; ++b) dv[b] = b < p.P ? dv[b] : 0x7fffffff;
+                int best = dv[0], second = 0x7fffffff, bi = 0;
+#pragma unroll
+                for (int b = 1; b < 32; ++b) {
+                    second = min(second, max(best, dv[b]));              // the smaller of the two that are not the new minimum
+                    bi = dv[b] < best ? b : bi;                          // strict: the first minimum keeps its index
+                    best = min(best, dv[b]);
+                }
+                unsigned cand = 0;
+                if ((unsigned)second - (unsigned)best <= wu) {           // (every dv >= best: the unsigned difference is exact)
+#pragma unroll
+                    for (int b = 0; b < 32; ++b) cand |= ((unsigned)dv[b] - (unsigned)best <= wu ? 1u : 0u) << b;
+                    cand &= pmask;
+                    if ((cand & (cand - 1)) == 0) cand = 0;              // P = 1, or a window wider than the padding's distance
+                }
+                p.abi[fj * p.rp + a] = (unsigned char)bi;          // [frame][row patch]: a wave's lanes write neighbours
+                p.acand[fj * p.rp + a] = cand;                          // 0 = decided (one patch inside the window)
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);                          // the scans are through before the next group's writes
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!has_next) break;
+        // The XCD's 32 workgroups stay within a few k-steps of each other (a panel line one of them fetched is still in that
+        // XCD's L2 when the other 3 or 7 that share it come for it): nobody starts tile d + 1 before all of them have signed
+        // off k-step n64 - 4 of their tile d.  Every one of the 32 has a tile d when anyone has a tile d + 1 (the tile list is
+        // dealt 32 at a time), and the wait is BOUNDED -- it is a hint about timing, nothing depends on it.
+        for (int spin = 0; seen < 32u * (unsigned)done && spin < 2048; ++spin) {
+            __builtin_amdgcn_s_sleep(8);
+            seen = __hip_atomic_load(p.sync + xcd * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    GI_STEP(0, 1, GI_WAIT_VM12, true)
-    GI_STEP(1, 0, GI_WAIT_VM12, false)
-    GI_STEP(0, 1, GI_WAIT_VM0, false)
-    GI_STEP(1, 0, GI_WAIT_VM0, false)               // (its reads of "stage n64" fetch a slot nobody writes any more: unused)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the stream's last three stages land before the LDS goes
 #undef GI_STEP
-#undef GI_PROD_DMA
+#undef GI_PROD_IL
+#undef GI_RD
+#undef GI_PX
+#undef GI_PY
 #undef GI_PROD
 #undef GI_MFMA
 #undef GI_RDX
 #undef GI_RDY2
 #undef GI_RDYB
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // ---- epilogue: the patch arg-min of every (row patch, column frame) of the tile, decided here -- the products never
-    // leave the chip (r02 / early r03 wrote them out, 2 GB, for a second kernel to read back).
-    // acc = C2 + floor((C3 + floor(C4 / 128)) / 128) in units of 2^-14 of u . u; d2 = |u_b|^2 - 2 acc 2^-14 in units of 2^-13.
-    // D[m][n] of MFMA (j, i): m = column j * 16 + (lane / 16) * 4 + v of this wave's unit, n = row patch (wr * 4 + i) * 16 + lane % 16.
-    // A row patch's columns are spread over four lanes and sixteen registers; rather than merge (best, index, runner-up)
-    // triples across lanes -- a chain of 64 dependent cross-lane moves per tile, 7 us -- the wave turns its 64 x 64 block
-    // of d2 through LDS (the stages are dead by now) so that lane r owns row r: one sequential scan per frame, as the pair
-    // kernels of the fp64 form do it.
-    __syncthreads();                                                     // every wave is through its last fragment reads
-    constexpr int DP = 65;                                               // row pitch (ints): lanes on different rows, same column -> different banks
-    int* d2s = (int*)smem_i8 + w * 64 * DP;
-    const int quad = lane >> 4;
-    const long long unit = (long long)tile_n * 2 + wc;                   // this wave's 64 columns: frames unit * fpu .. + fpu - 1
-    {
-        int nbl[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const v4i t4 = *(const v4i*)(p.nbp + unit * 64 + j * 16 + quad * 4);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) nbl[j][v] = t4[v];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const v4i acc = c2[j][i] + ((c3[j][i] + (c4[j][i] >> 7)) >> 7);
-                int* dst = d2s + (i * 16 + (lane & 15)) * DP + j * 16 + quad * 4;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) dst[v] = nbl[j][v] - acc[v];
-            }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0070);                                  // lgkmcnt(0): this wave's LDS writes (its own region)
-    __builtin_amdgcn_wave_barrier();
-    const double E = 0x1p-20 * dlc_f64_unkey(p.keys[3]) + (double)p.H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
-    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
-    const long long a = m0 + wr * 64 + lane;                             // lane r owns row patch r of the wave's 64
-    const int* drow = d2s + lane * DP;
-    for (int fs = 0; fs < p.fpu; ++fs) {
-        const long long fj = unit * p.fpu + fs;
-        if (!(a < p.nrows && fj < p.nframes && a < fj * p.P)) continue;  // (row frame < column frame)  <=>  a < fj * P
-        const int* dv = drow + fs * p.P;
-        int best = dv[0], second = 0x7fffffff, bi = 0;
-        for (int b = 1; b < p.P; ++b) {
-            const int d2 = dv[b];
-            second = min(second, max(best, d2));                         // the smaller of the two that are not the new minimum
-            bi = d2 < best ? b : bi;                                     // strict: the first minimum keeps its index
-            best = min(best, d2);
-        }
-        unsigned cand = 0;
-        if ((long long)second - best <= window) {
-            for (int b = 0; b < p.P; ++b)
-                if ((long long)dv[b] - best <= window) cand |= 1u << b;
-        }
-        p.abi[a * p.nfp + fj] = (unsigned char)bi;
-        p.acand[a * p.nfp + fj] = cand;                                  // 0 = decided (one patch inside the window)
-    }
 }
 
 // ---- range, quantisation -------------------------------------------------------------------------------------------
@@ -535,12 +613,13 @@ size_t sim_filter_panel_bytes(int64_t rows, int64_t H) {
 int sim_frames_per_unit(int64_t P) { return (int)(64 / P); }
 static int64_t sim_col_tiles(int64_t N, int64_t P) { return dlc::cdiv(dlc::cdiv(N, (int64_t)sim_frames_per_unit(P)), (int64_t)2); }
 int64_t sim_col_rows(int64_t N, int64_t P) { return sim_col_tiles(N, P) * GI_T; }                      // rows of Y, entries of nbp
-int64_t sim_col_frames(int64_t N, int64_t P) { return sim_col_tiles(N, P) * 2 * sim_frames_per_unit(P); }   // nfp: frames per row of abi / acand
+int64_t sim_col_frames(int64_t N, int64_t P) { return sim_col_tiles(N, P) * 2 * sim_frames_per_unit(P); }   // nfp: column frames of abi / acand
+int64_t sim_argmin_pitch(int64_t N, int64_t P) { return (int64_t)dlc::align_up((size_t)(N * P), 64); }     // rp: their pitch in row patches
 // the block table of gram_argmin_i8 (`blocks`)
 size_t gram_blocks_bytes(int64_t N, int64_t P) {
     const size_t tiles_m = (size_t)dlc::cdiv((N > 1 ? N - 1 : 1) * P, (int64_t)GI_T), tiles_n = (size_t)sim_col_tiles(N, P);
     const size_t nsm = (tiles_m + GI_BR - 1) / GI_BR, nsn = (tiles_n + GI_BC - 1) / GI_BC;
-    return dlc::align_up(nsm + 1, 2) * 4 + nsm * nsn * 8;
+    return 1024 + dlc::align_up(nsm + 1 + nsm * nsn + 1 + 1, 2) * 4 + nsm * nsn * GI_BR * GI_BC * 8;
 }
 size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H) {
     const size_t kp = dlc::align_up((size_t)H, (size_t)GI_KPAD);
@@ -613,14 +692,14 @@ int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, cons
 }
 
 // The patch arg-min of every (row patch a, column frame j) with frame(a) < j, for all N frames at once: abi / acand are
-// [N * P, sim_col_frames(N, P)] (bytes / 32-bit words); entries with frame(a) >= j are not written.
+// [sim_col_frames(N, P), sim_argmin_pitch(N, P)] (bytes / 32-bit words); entries with frame(a) >= j are not written.
 int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const char* Y, const int* nbp,
                    const unsigned long long* keys, unsigned char* abi, unsigned* acand, void* blocks, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     GramI8Args a;
     a.gpitch = 3ll * kp * 16; a.kp = kp; a.H = (int)H; a.P = (int)P; a.fpu = sim_frames_per_unit(P);
     a.X = X; a.Y = Y; a.nbp = nbp; a.keys = keys; a.abi = abi; a.acand = acand;
-    a.nfp = sim_col_frames(N, P); a.nrows = N * P; a.nframes = N;
+    a.nfp = sim_col_frames(N, P); a.rp = sim_argmin_pitch(N, P); a.nrows = N * P; a.nframes = N;
     a.tiles_m = (int)dlc::cdiv((N - 1) * P, (int64_t)GI_T);              // the last frame's patches have no later frame
     a.tiles_n = (int)sim_col_tiles(N, P);
     if (a.tiles_m < 1) return DLC_OK;
@@ -632,16 +711,20 @@ int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X,
         if (cnt > 0) a.nsup += cnt;
     }
     if (a.nsup == 0) return DLC_OK;
-    int* rowstart = (int*)blocks;
-    a.blk = (const int2*)(rowstart + dlc::align_up((size_t)a.nsm + 1, 2));
-    hipLaunchKernelGGL(gram_blocks_kernel, dim3(1), dim3(256), 0, st, a.nsm, a.nsn, (int)P, a.fpu, rowstart, (int2*)a.blk);
-    DLC_LAUNCH_CHECK(ctx, "gram_blocks_kernel");
-    const size_t lds = (size_t)GI_NSTAGE * GI_STAGE;
+    a.sync = (unsigned*)blocks;
+    int* scratch = (int*)blocks + 256;
+    const size_t nscratch = dlc::align_up((size_t)a.nsm + 1 + (size_t)a.nsm * a.nsn + 1 + 1, 2);
+    a.ntiles = scratch + nscratch - 1;
+    a.tiles = (const int2*)(scratch + nscratch);
+    hipLaunchKernelGGL(gram_tiles_kernel, dim3(1), dim3(256), 0, st, a.nsm, a.nsn, a.tiles_m, a.tiles_n, (int)P, a.fpu, (long long)a.nframes,
+                       scratch, (int2*)a.tiles, scratch + nscratch - 1, a.sync);
+    DLC_LAUNCH_CHECK(ctx, "gram_tiles_kernel");
+    const size_t lds = (size_t)GI_NSTAGE * GI_STAGE + GI_EPI;
     if (!(ctx->func_attr_set & (1ull << DLC_ATTR_GRAM_I8))) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gram_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->func_attr_set |= 1ull << DLC_ATTR_GRAM_I8;
     }
-    const unsigned grid = (unsigned)(((a.nsup + 7) / 8) * 8 * 32);
+    const unsigned grid = GI_GRID;              // persistent: 8 XCDs x 32 tiles of a block
     // bench.py's kernel-only timing (dlc_set_profiling): an event pair around the kernel on its stream
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));

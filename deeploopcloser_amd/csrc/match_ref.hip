@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
 
 // The filter form (gram_i8.hip): the int8 product kernel has decided, for every row patch a and every later frame j, which
 // patch b of frame j is nearest -- exact integer products of the descriptors' 21-bit fixed-point values, acc 2^-14 <=
-// u_a . u_b <= acc 2^-14 + E, arg-min of |u_b|^2 - 2 acc 2^-14 -- and left in abi / acand [N P, nfp] the index and, where
+// u_a . u_b <= acc 2^-14 + E, arg-min of |u_b|^2 - 2 acc 2^-14 -- and left in abi / acand [nfp, rp] the index and, where
 // the runner-up lay within 2 E, the set of patches inside that window.  This kernel turns them into scores: undecided sets
 // lose the copies of an earlier member (equal content hashes: the same distance, a later index) and what is left is
 // evaluated directly -- |x_b - x_a| in fp64 from the descriptors, square roots compared as the reference compares them
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
 // the patch a) -- no workgroup barrier, so a wave that has to evaluate candidates directly holds up nobody else.
 __global__ __launch_bounds__(256) void pair_score_amin_kernel(const double* __restrict__ desc,
                                                               const unsigned char* __restrict__ abi,
-                                                              const unsigned* __restrict__ acand, long long nfp,
+                                                              const unsigned* __restrict__ acand, long long rp,
                                                               const double* __restrict__ proj, const double* __restrict__ score,
                                                               unsigned long long* __restrict__ keys, long long N, int P, int H,
                                                               double ca, double cb, double* __restrict__ out_f64,
@@ -594,8 +594,8 @@ __global__ __launch_bounds__(256) void pair_score_amin_kernel(const double* __re
         int bi = 0;
         unsigned cand = 0;
         if (live && !flat) {
-            bi = abi[ra * nfp + j];
-            cand = acand[ra * nfp + j];
+            bi = abi[j * rp + ra];
+            cand = acand[j * rp + ra];
             if (cand) {
                 // a copy of an earlier candidate (equal content hashes: sim_mix64) has that candidate's distance and a
                 // later index: np.argmin never takes it
@@ -976,8 +976,9 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
         w.qx = o; o += dlc::align_up(dlc_gemm::sim_filter_panel_bytes(N * P, H), 256);
         w.qy = o; o += dlc::align_up(dlc_gemm::sim_filter_colpanel_bytes(N, P, H), 256);
         w.nbp = o; o += dlc::align_up((size_t)dlc_gemm::sim_col_rows(N, P) * 4, 256);
-        w.abi = o; o += dlc::align_up((size_t)N * P * w.nfp, 256);
-        w.acand = o; o += dlc::align_up((size_t)N * P * w.nfp * 4, 256);
+        const size_t rp = (size_t)dlc_gemm::sim_argmin_pitch(N, P);
+        w.abi = o; o += dlc::align_up(rp * w.nfp, 256);
+        w.acand = o; o += dlc::align_up(rp * w.nfp * 4, 256);
         w.blk = o; o += dlc::align_up(dlc_gemm::gram_blocks_bytes(N, P), 256);
         w.desc_t = o;
     } else {
@@ -1103,7 +1104,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
                 rc = dlc_gemm::gram_argmin_i8(ctx, N, P, H, qx, qy, nbp, keys, abi, acand, ws + w.blk, st);
                 if (rc != DLC_OK) return rc;
                 hipLaunchKernelGGL(pair_score_amin_kernel, dim3(PS_GX, (unsigned)(N - 1)), dim3(256), PF_STACK_BYTES, st, desc,
-                                   (const unsigned char*)abi, (const unsigned*)acand, (long long)w.nfp, proj, score, keys,
+                                   (const unsigned char*)abi, (const unsigned*)acand, (long long)dlc_gemm::sim_argmin_pitch(N, P), proj, score, keys,
                                    (long long)N, (int)P, (int)H, a, b, out_f64, (long long*)out_i64, prog, rowhash, direct_pairs);
                 DLC_LAUNCH_CHECK(ctx, "pair_score_amin_kernel");
             }
