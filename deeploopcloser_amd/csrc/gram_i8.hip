@@ -58,9 +58,7 @@ struct GramI8Args {
     long long gpitch;                     // bytes of one 16-row group: 3 Kp / 64 k-steps of 1 KiB
     int kp, H, P, fpu;
     int tiles_m, tiles_n, nsm, nsn, nsup;
-    const int2* tiles;                              // the wanted tiles (row tile, column tile), block by block; *ntiles of them
-    const int* ntiles;
-    unsigned* sync;                                 // [8 * 32]: per XCD (128 bytes apart) how many tiles its workgroups have nearly finished
+    const int2* blk;                                // [nsup] (block row, block column) of the wanted blocks, row by row
 };
 
 // (best, index of the FIRST minimum, runner-up) of two disjoint candidate sets
@@ -78,21 +76,10 @@ __host__ __device__ inline int gi_first_block_col(int si, int P, int fpu) {
     return (int)(((row_frame + 1) / fpu / 2) / GI_BC);
 }
 
-// Is tile (tm, tn) wanted?  Its last frame must lie behind its first row's frame, and its first frame must exist.
-__host__ __device__ inline bool gi_tile_wanted(int tm, int tn, int tiles_m, int tiles_n, int P, int fpu, long long nframes) {
-    if (tm >= tiles_m || tn >= tiles_n) return false;
-    return !((long long)(2 * tn + 2) * fpu - 1 <= (long long)tm * GI_T / P || (long long)2 * tn * fpu >= nframes);
-}
-
-// tiles[0 .. *ntiles): the wanted tiles (row tile, column tile), block by block (the wanted blocks row by row, a block's
-// GI_BR x GI_BC tiles row by row) -- gram_i8_kernel's workgroups look theirs up.  (r03 first had every workgroup of a
-// one-tile-per-workgroup grid walk the block rows itself: up to nsm iterations of two 64-bit divisions on the scalar
-// unit, ~5 us of a 43 us tile.)  scratch: [nsm + 1 + nsm * nsn + 1] ints.  One workgroup of 256 threads.
-__global__ void gram_tiles_kernel(int nsm, int nsn, int tiles_m, int tiles_n, int P, int fpu, long long nframes, int* scratch,
-                                  int2* tiles, int* ntiles, unsigned* sync) {
-    sync[threadIdx.x] = 0u;                         // (256 threads: the 8 counters and their padding)
-    int* rowstart = scratch;                       // [nsm + 1]: first wanted block of every block row
-    int* tstart = scratch + nsm + 1;               // [nsup + 1]: first wanted tile of every wanted block
+// blk[nsup]: the wanted blocks numbered row by row (the workgroups of gram_i8_kernel look theirs up: r03 first had every
+// workgroup walk the block rows itself -- up to nsm iterations of two 64-bit divisions on the scalar unit, ~10 us of a
+// 38 us tile).  rowstart: [nsm + 1] scratch.  One workgroup of 256 threads.
+__global__ void gram_blocks_kernel(int nsm, int nsn, int P, int fpu, int* rowstart, int2* blk) {
     for (int si = threadIdx.x; si < nsm; si += blockDim.x) {
         const int cnt = nsn - gi_first_block_col(si, P, fpu);
         rowstart[si + 1] = cnt > 0 ? cnt : 0;
@@ -104,33 +91,51 @@ __global__ void gram_tiles_kernel(int nsm, int nsn, int tiles_m, int tiles_n, in
     }
     __syncthreads();
     for (int si = threadIdx.x; si < nsm; si += blockDim.x) {
-        const int first = gi_first_block_col(si, P, fpu);
-        for (int sj = first; sj < nsn; ++sj) {
-            int cnt = 0;
-            for (int l = 0; l < GI_BR * GI_BC; ++l)
-                cnt += gi_tile_wanted(si * GI_BR + l / GI_BC, sj * GI_BC + l % GI_BC, tiles_m, tiles_n, P, fpu, nframes);
-            tstart[rowstart[si] + sj - first + 1] = cnt;
-        }
-    }
-    __syncthreads();
-    const int nsup = rowstart[nsm];
-    if (threadIdx.x == 0) {
-        tstart[0] = 0;
-        for (int b = 0; b < nsup; ++b) tstart[b + 1] += tstart[b];
-        *ntiles = tstart[nsup];
-    }
-    __syncthreads();
-    for (int si = threadIdx.x; si < nsm; si += blockDim.x) {
-        const int first = gi_first_block_col(si, P, fpu);
-        for (int sj = first; sj < nsn; ++sj) {
-            int o = tstart[rowstart[si] + sj - first];
-            for (int l = 0; l < GI_BR * GI_BC; ++l) {
-                const int tm = si * GI_BR + l / GI_BC, tn = sj * GI_BC + l % GI_BC;
-                if (gi_tile_wanted(tm, tn, tiles_m, tiles_n, P, fpu, nframes)) tiles[o++] = make_int2(tm, tn);
-            }
-        }
+        const int first = gi_first_block_col(si, P, fpu), o = rowstart[si];
+        for (int sj = first; sj < nsn; ++sj) blk[o + sj - first] = make_int2(si, sj);
     }
 }
+
+// ---- the accumulators: FIXED accumulation registers a0 .. a191, named in the instructions themselves ---------------------
+// Class c (0: C2, 1: C3, 2: C4), column group j, row group i: a[B : B + 3], B = ((c * 4 + j) * 4 + i) * 4.  hipcc neither
+// allocates nor moves them: as "+a" operands of the inline-asm MFMAs it did both -- at the seams between the k loop and the
+// steps behind it it shuffled accumulators between registers (v_accvgpr_read / _mov / _write) DIRECTLY behind the MFMAs that
+// wrote them.  An MFMA in inline asm is opaque to hipcc's hazard recognizer, so no wait states went between them, and an
+// accumulator read that early returns the value from before the MFMA: a build whose allocation happened to do that to the
+// youngest accumulators lost part of the last k-step.  The wait states are now written out (gi_acc_settle), and `make`
+// checks the object code (check_m0.py): no v_accvgpr_* instruction in the kernel but the 192 zero writes and the 192 reads
+// of the epilogue.
+#define GI_CL10(d) "a" #d "0", "a" #d "1", "a" #d "2", "a" #d "3", "a" #d "4", "a" #d "5", "a" #d "6", "a" #d "7", "a" #d "8", "a" #d "9"
+#define GI_CL_ALL "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", GI_CL10(1), GI_CL10(2), GI_CL10(3), GI_CL10(4),  \
+    GI_CL10(5), GI_CL10(6), GI_CL10(7), GI_CL10(8), GI_CL10(9), GI_CL10(10), GI_CL10(11), GI_CL10(12), GI_CL10(13),            \
+    GI_CL10(14), GI_CL10(15), GI_CL10(16), GI_CL10(17), GI_CL10(18), "a190", "a191"
+template <int B> __device__ __forceinline__ void gi_mfma(const v4i& a, const v4i& b) {
+    asm volatile("v_mfma_i32_16x16x64_i8 a[%2:%3], %0, %1, a[%2:%3]" : : "v"(a), "v"(b), "n"(B), "n"(B + 3));
+}
+template <int B> __device__ __forceinline__ void gi_acc_zero16() {          // a[B : B + 15] = 0
+    asm volatile("v_accvgpr_write_b32 a[%0], 0\n\tv_accvgpr_write_b32 a[%1], 0\n\tv_accvgpr_write_b32 a[%2], 0\n\tv_accvgpr_write_b32 a[%3], 0\n\t"
+                 "v_accvgpr_write_b32 a[%4], 0\n\tv_accvgpr_write_b32 a[%5], 0\n\tv_accvgpr_write_b32 a[%6], 0\n\tv_accvgpr_write_b32 a[%7], 0\n\t"
+                 "v_accvgpr_write_b32 a[%8], 0\n\tv_accvgpr_write_b32 a[%9], 0\n\tv_accvgpr_write_b32 a[%10], 0\n\tv_accvgpr_write_b32 a[%11], 0\n\t"
+                 "v_accvgpr_write_b32 a[%12], 0\n\tv_accvgpr_write_b32 a[%13], 0\n\tv_accvgpr_write_b32 a[%14], 0\n\tv_accvgpr_write_b32 a[%15], 0"
+                 : : "n"(B), "n"(B + 1), "n"(B + 2), "n"(B + 3), "n"(B + 4), "n"(B + 5), "n"(B + 6), "n"(B + 7), "n"(B + 8), "n"(B + 9),
+                     "n"(B + 10), "n"(B + 11), "n"(B + 12), "n"(B + 13), "n"(B + 14), "n"(B + 15));
+}
+// all 192 to zero; the one statement whose clobber list tells hipcc that the kernel uses a0 .. a191 at all
+__device__ __forceinline__ void gi_acc_zero_all() {
+    asm volatile("s_nop 0" : : : GI_CL_ALL);
+    gi_acc_zero16<0>(); gi_acc_zero16<16>(); gi_acc_zero16<32>(); gi_acc_zero16<48>(); gi_acc_zero16<64>(); gi_acc_zero16<80>();
+    gi_acc_zero16<96>(); gi_acc_zero16<112>(); gi_acc_zero16<128>(); gi_acc_zero16<144>(); gi_acc_zero16<160>(); gi_acc_zero16<176>();
+    asm volatile("s_nop 7" : : : GI_CL_ALL);        // (v_accvgpr_write -> MFMA reading it as its C operand: wait states)
+}
+// behind the last MFMA, before the first accumulator read: longer than an MFMA's latency (4 passes = 16 cycles + write-back)
+__device__ __forceinline__ void gi_acc_settle() { asm volatile("s_nop 15\n\ts_nop 15" : : : GI_CL_ALL); }
+template <int B> __device__ __forceinline__ v4i gi_acc_read() {
+    v4i r;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : "n"(B), "n"(B + 1), "n"(B + 2), "n"(B + 3));
+    return r;
+}
+#define GI_ACC(C, J, I) ((((C) * 4 + (J)) * 4 + (I)) * 4)
 
 // One 1 KiB LDS-DMA piece: lane l fetches bytes l * 16 .. + 15 behind the wave-uniform base `src` (+ voff, which carries
 // the k-step) into LDS at `lds` + l * 16.  Inline asm so that hipcc does not count it in vmcnt (it would wait for
@@ -157,36 +162,31 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 // column panel's the same.  A fragment read is one ds_read_b128 at block + lane * 16.
 //
 // Pipeline: three stages; k-step t multiplies the fragments of stage t, which it read from LDS during k-step t-1, while
-// it reads those of stage t+1 and issues the DMA of stage t+3 into stage t's slot -- ONE wave per SIMD (192 accumulators +
-// 128 fragment registers), so the interleaving inside the wave is what hides the LDS and DMA latencies.
-//
-// PERSISTENT workgroups: 256 of them, one per CU.  Workgroup (xcd, local) takes tile `local` of the blocks xcd, xcd + 8,
-// xcd + 16, ... of p.blk -- the XCD's 32 workgroups walk the same block at the same time (12 panels feed 32 tiles out of
-// that XCD's L2), as the 33 000 one-tile workgroups of the first r03 kernel did, but the STAGES FORM ONE STREAM ACROSS THE
-// TILES: the last three k-steps of a tile fetch the first three stages of the next one, so a tile has no prologue of its
-// own and the chip no workgroup turnover (measured on the one-tile form with s_memtime, cycles per tile: block lookup 800,
-// prologue 4 100, k loop 82 300, epilogue 8 000, and 9 600 between the end of one workgroup and the start of the next on
-// the CU).  The epilogue therefore owns 16 KiB of LDS behind the three stages (160 KiB in all).
-constexpr int GI_EPI = 4 * 16 * 64 * 4;     // the epilogue's region: per wave 16 rows x 64 columns of d2 (ints)
-constexpr int GI_GRID = 256;
+// it reads those of stage t+1 and issues the DMA of stage t+3 into stage t's slot -- ONE wave per SIMD (192 accumulators in
+// a0 .. a191, 128 fragment registers), so the interleaving inside the wave is what hides the LDS and DMA latencies: one
+// fragment read behind every second MFMA, one DMA piece behind every fourth.  Barrier t says "stage t+1 has landed
+// everywhere and everybody is through reading stage t".
+// One workgroup per tile.  A persistent form (256 workgroups walking a tile list, the stages one stream across the tiles:
+// no prologue, no workgroup turnover) was built and measured in r03: per tile it saves 10 000 of 100 000 cycles and gives
+// them back -- the chip holds 2.22 GHz under it instead of 2.35 GHz, the epilogue has to work in 16 KiB instead of in the
+// dead stages (docs/LAB.md 9) -- 5.45 ms against this form's 5.27.
 __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem_i8[];
+    // workgroup -> tile: ids go round-robin to the 8 XCDs; an XCD's 32 resident workgroups take one GI_BR x GI_BC block
+    // of tiles (12 panels feed 32 tiles out of that XCD's L2).  Only blocks with a wanted tile are numbered, row by row,
+    // and dealt to the XCDs in turn: dealt by block column, the triangle gave XCD 7 2.4 times the work of XCD 0.
     const int id = blockIdx.x;
-    const int xcd = id & 7, local = (id >> 3) & 31;
+    const int xcd = id & 7, slot = id >> 3, local = slot & 31;
+    const int want = (slot >> 5) * 8 + xcd;           // index among the wanted blocks: p.blk (gram_blocks_kernel) names it
+    if (want >= p.nsup) return;
+    const int2 blk = p.blk[want];
+    const int si = blk.x, sj = blk.y;
+    const int tile_m = si * GI_BR + (local >> 3), tile_n = sj * GI_BC + (local & 7);
+    if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+    const long long m0 = (long long)tile_m * GI_T, n0 = (long long)tile_n * GI_T;
+    // the tile's last frame must lie behind its first row's frame, and its first frame must exist
+    if ((long long)(2 * tile_n + 2) * p.fpu - 1 <= m0 / p.P || (long long)2 * tile_n * p.fpu >= p.nframes) return;
     if (p.keys[2]) return;                          // a NaN / infinity in the dataset: this form does not apply
-    // this workgroup's tiles: entry `local` of every eighth group of 32 consecutive wanted tiles, from group xcd on
-    const int ntiles = *p.ntiles;
-    int round = -1, tile_m = 0, tile_n = 0, done = 0;
-    auto next_tile = [&]() -> bool {
-        ++round;
-        const int idx = (round * 8 + xcd) * 32 + local;
-        if (idx >= ntiles) return false;
-        const int2 t = p.tiles[idx];
-        tile_m = t.x;
-        tile_n = t.y;
-        return true;
-    };
-    if (!next_tile()) return;
 
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wr = w >> 1, wc = w & 1;              // 64 row patches x 64 column patches per wave
@@ -195,14 +195,11 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     // this wave's DMA share of a stage: groups 2 w, 2 w + 1 of each panel, three slices each = 12 pieces.  Piece b:
     // panel b / 6, group (b % 6) / 3, slice b % 3; its source base is wave-uniform, the k-step rides in the lanes' offset.
     const char* src[12];
-    auto set_src = [&](int tm, int tn) {
 #pragma unroll
-        for (int b = 0; b < 12; ++b) {
-            const char* panel = b < 6 ? p.X + ((long long)tm * GI_T / 16) * p.gpitch : p.Y + ((long long)tn * GI_T / 16) * p.gpitch;
-            src[b] = uniform_ptr(panel + (long long)(w * 2 + (b % 6) / 3) * p.gpitch + (long long)(b % 3) * n64 * 1024);
-        }
-    };
-    set_src(tile_m, tile_n);
+    for (int b = 0; b < 12; ++b) {
+        const char* panel = b < 6 ? p.X + (m0 / 16) * p.gpitch : p.Y + (n0 / 16) * p.gpitch;
+        src[b] = uniform_ptr(panel + (long long)(w * 2 + (b % 6) / 3) * p.gpitch + (long long)(b % 3) * n64 * 1024);
+    }
     // its LDS destination inside a stage: block ((2 w + group) * 3 + slice) of the panel's half
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_base + w * 6 * 1024);
     unsigned voff_issue = lane * 16;                // lanes' offset of the next stage to fetch: + 1 KiB per k-step
@@ -215,7 +212,7 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
         is_slot = is_slot == GI_NSTAGE - 1 ? 0 : is_slot + 1;
     };
 
-    v4i c2[4][4], c3[4][4], c4[4][4];               // [column group j][row group i] of the three classes
+    gi_acc_zero_all();                              // the three classes' accumulators: a0 .. a191 (GI_ACC above)
     // fragments [slice][group]: ONE set of the row panel's and of the column panel's slice 2, reloaded in place where they
     // die; the column panel's slices 0 and 1 double-buffered (yb[buffer][slice]) -- 128 registers
     v4i fx[3][4], fy2[4], yb[2][2][4];
@@ -226,38 +223,32 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
 #define GI_RDX(S, SO) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) fx[S][g_] = *(const v4i*)(sx + (SO) + (g_ * 3 + (S)) * 1024)
 #define GI_RDY2(SO) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) fy2[g_] = *(const v4i*)(sy + (SO) + (g_ * 3 + 2) * 1024)
 #define GI_RDYB(BUF, S, SO) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) yb[BUF][S][g_] = *(const v4i*)(sy + (SO) + (g_ * 3 + (S)) * 1024)
-    // The MFMA as inline asm with the accumulator PINNED to the AGPR file ("+a"): through the builtin hipcc kept part of
-    // the 192 accumulators in VGPRs and moved them across at the loop's back edge -- 276 v_accvgpr_read / _write per k-step
-    // beside 96 MFMAs.  volatile: the asm statements (these and the DMA pieces) keep their source order.
-#define GI_MFMA(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+    // four MFMAs: column group J of FY against the four row groups of slice SX, into class C
+#define GI_ROW2A(C, J, FY, SX) gi_mfma<GI_ACC(C, J, 0)>(FY[J], fx[SX][0]); gi_mfma<GI_ACC(C, J, 1)>(FY[J], fx[SX][1]);
+#define GI_ROW2B(C, J, FY, SX) gi_mfma<GI_ACC(C, J, 2)>(FY[J], fx[SX][2]); gi_mfma<GI_ACC(C, J, 3)>(FY[J], fx[SX][3]);
     // one fragment read (a ds_read_b128), pinned where it stands between the MFMAs
 #define GI_RD(DST, PTR) { __builtin_amdgcn_sched_barrier(0); DST = *(const v4i*)(PTR); __builtin_amdgcn_sched_barrier(0); }
 #define GI_PX(S, G, SO) (sx + (SO) + ((G) * 3 + (S)) * 1024)
 #define GI_PY(S, G, SO) (sy + (SO) + ((G) * 3 + (S)) * 1024)
-    // sixteen MFMAs of one slice product: column fragments FY (four groups) against row slice SX into class accumulator ACC
-#define GI_PROD(ACC, FY, SX)                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
-            GI_MFMA(ACC[j][i], FY[j], fx[SX][i]);
+#define GI_NONE(J)
+    // sixteen MFMAs of one slice product: column fragments FY (four groups) against row slice SX into class C
+#define GI_PROD(C, FY, SX)                                                                                      \
+    GI_ROW2A(C, 0, FY, SX) GI_ROW2B(C, 0, FY, SX) GI_ROW2A(C, 1, FY, SX) GI_ROW2B(C, 1, FY, SX)                 \
+    GI_ROW2A(C, 2, FY, SX) GI_ROW2B(C, 2, FY, SX) GI_ROW2A(C, 3, FY, SX) GI_ROW2B(C, 3, FY, SX)
     // ... with fragment reads and DMA pieces between them.  Behind every fourth MFMA a DMA piece of the stage three ahead (a
     // piece is three instructions, which fit in the shadow of the MFMA in front of them; two five-instruction pieces behind
     // every fourth MFMA left the matrix pipe idle for their issue time); behind the second (and, RD2, the fourth) MFMA of
     // every four a fragment read of the next stage -- NOT in bursts between the products: the four waves leave the barrier
     // together, sixteen reads each were 64 KiB queued at the LDS at once, and a wave whose read is not accepted yet cannot
-    // issue the MFMA behind it either.
-#define GI_PROD_IL(ACC, FY, SX, B0, ISSUE, RD1, RD2)                                                            \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
-        GI_MFMA(ACC[j][0], FY[j], fx[SX][0]);                                                                   \
-        GI_MFMA(ACC[j][1], FY[j], fx[SX][1]);                                                                   \
-        RD1;                                                                                                    \
-        GI_MFMA(ACC[j][2], FY[j], fx[SX][2]);                                                                   \
-        GI_MFMA(ACC[j][3], FY[j], fx[SX][3]);                                                                   \
-        RD2;                                                                                                    \
-        if (ISSUE) issue_piece((B0) + j);                                                                       \
-    }
+    // issue the MFMA behind it either (k loop 88 -> 77 thousand cycles per tile).  RD1 / RD2: macros of the group J.
+#define GI_PROD_IL1(C, J, FY, SX, B0, ISSUE, RD1, RD2)                                                          \
+    GI_ROW2A(C, J, FY, SX) RD1(J) GI_ROW2B(C, J, FY, SX) RD2(J) if (ISSUE) issue_piece((B0) + (J));
+#define GI_PROD_IL(C, FY, SX, B0, ISSUE, RD1, RD2)                                                              \
+    GI_PROD_IL1(C, 0, FY, SX, B0, ISSUE, RD1, RD2) GI_PROD_IL1(C, 1, FY, SX, B0, ISSUE, RD1, RD2)               \
+    GI_PROD_IL1(C, 2, FY, SX, B0, ISSUE, RD1, RD2) GI_PROD_IL1(C, 3, FY, SX, B0, ISSUE, RD1, RD2)
     // s_waitcnt immediate (gfx9: vmcnt [3:0] + [15:14], expcnt [6:4] left at 7, lgkmcnt [11:8]) with lgkmcnt(0); the
     // builtin, not inline asm, so that hipcc's own wait insertion knows the LDS reads are done
-    constexpr int GI_WAIT_VM12 = 0x007c;
+    constexpr int GI_WAIT_VM12 = 0x007c, GI_WAIT_VM0 = 0x0070;
     // One k-step.  The six slice products run in the order (y0 x0) (y1 x0) (y2 x0) | (y0 x1) (y0 x2) (y1 x1).  Behind the third
     // one x0 and y2 are dead and take the NEXT stage's fragments in place; y0 and y1 of the next stage go to the other
     // buffer of the pair; x2 is reloaded during the sixth product and x1 during the first of its own k-step.  Every
@@ -269,24 +260,38 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     {                                                                                                           \
         const int so_c = cur * GI_STAGE, so_n = nxt * GI_STAGE;                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_PROD_IL(c2, yb[C][0], 0, 0, false, GI_RD(fx[1][j], GI_PX(1, j, so_c)), )                             \
-        GI_PROD(c3, yb[C][1], 0)                                                                                \
-        GI_PROD(c4, fy2, 0)                                                                                     \
+        GI_PROD_IL(0, yb[C][0], 0, 0, false, GI_RD_X1, GI_NONE)                                                 \
+        GI_PROD(1, yb[C][1], 0)                                                                                 \
+        GI_PROD(2, fy2, 0)                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         __builtin_amdgcn_s_waitcnt(WAIT);           /* this wave's pieces of stage t+1 */                        \
         asm volatile("" ::: "memory");                                                                          \
         __builtin_amdgcn_s_barrier();                                                                           \
         asm volatile("" ::: "memory");                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        GI_PROD_IL(c3, yb[C][0], 1, 0, ISSUE, GI_RD(yb[N][0][j], GI_PY(0, j, so_n)), GI_RD(fx[0][j], GI_PX(0, j, so_n))) \
-        GI_PROD_IL(c4, yb[C][0], 2, 4, ISSUE, GI_RD(yb[N][1][j], GI_PY(1, j, so_n)), GI_RD(fy2[j], GI_PY(2, j, so_n)))   \
-        GI_PROD_IL(c4, yb[C][1], 1, 8, ISSUE, GI_RD(fx[2][j], GI_PX(2, j, so_n)), )                             \
+        if (N == 0) {                                                                                           \
+            GI_PROD_IL(1, yb[C][0], 1, 0, ISSUE, GI_RD_Y0A, GI_RD_X0)                                           \
+            GI_PROD_IL(2, yb[C][0], 2, 4, ISSUE, GI_RD_Y1A, GI_RD_Y2)                                           \
+        } else {                                                                                                \
+            GI_PROD_IL(1, yb[C][0], 1, 0, ISSUE, GI_RD_Y0B, GI_RD_X0)                                           \
+            GI_PROD_IL(2, yb[C][0], 2, 4, ISSUE, GI_RD_Y1B, GI_RD_Y2)                                           \
+        }                                                                                                       \
+        GI_PROD_IL(2, yb[C][1], 1, 8, ISSUE, GI_RD_X2, GI_NONE)                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         if (ISSUE) issue_done();                                                                                \
         cur = nxt;                                                                                              \
         nxt = nxt == GI_NSTAGE - 1 ? 0 : nxt + 1;                                                               \
     }
-    // the stream's start: stages 0 .. 2 of the first tile in flight; of stage 0 everything but x1 into the registers
+    // the reads of a k-step, by the group J they fetch (so_c / so_n: the LDS offsets of stage t / t+1 inside GI_STEP)
+#define GI_RD_X1(J) GI_RD(fx[1][J], GI_PX(1, J, so_c))
+#define GI_RD_X0(J) GI_RD(fx[0][J], GI_PX(0, J, so_n))
+#define GI_RD_X2(J) GI_RD(fx[2][J], GI_PX(2, J, so_n))
+#define GI_RD_Y2(J) GI_RD(fy2[J], GI_PY(2, J, so_n))
+#define GI_RD_Y0A(J) GI_RD(yb[0][0][J], GI_PY(0, J, so_n))
+#define GI_RD_Y1A(J) GI_RD(yb[0][1][J], GI_PY(1, J, so_n))
+#define GI_RD_Y0B(J) GI_RD(yb[1][0][J], GI_PY(0, J, so_n))
+#define GI_RD_Y1B(J) GI_RD(yb[1][1][J], GI_PY(1, J, so_n))
+    // prologue: stages 0 .. 2 in flight; of stage 0 everything but x1 into the registers
 #pragma unroll
     for (int t = 0; t < GI_NSTAGE; ++t) {
 #pragma unroll
@@ -297,111 +302,96 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     GI_RDX(0, 0); GI_RDX(2, 0); GI_RDYB(0, 0, 0); GI_RDYB(0, 1, 0); GI_RDY2(0);
-
-    const double E = 0x1p-20 * dlc_f64_unkey(p.keys[3]) + (double)p.H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
-    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
-    const unsigned wu = window > 0xffffffffll ? 0xffffffffu : (unsigned)window, pmask = p.P >= 32 ? ~0u : (1u << p.P) - 1u;
-    for (;;) {
-        const int cur_m = tile_m, cur_n = tile_n;
-        const bool has_next = next_tile();          // (tile_m, tile_n) is the next tile from here on
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { c2[j][i] = v4i{0, 0, 0, 0}; c3[j][i] = v4i{0, 0, 0, 0}; c4[j][i] = v4i{0, 0, 0, 0}; }
-        // two k-steps per trip (the y buffers alternate).  k-steps 0 .. n64 - 4 fetch this tile's stage three ahead, the last
-        // three the first three stages of the next tile (behind the last tile: of this one again, into slots nobody reads --
-        // one code path, and every k-step's wait is "all but the newest twelve pieces")
+    // steady state, two k-steps per trip (the y buffers alternate): k-steps 0 .. n64 - 4 fetch the stage three ahead, the last
+    // three fetch nothing; n64 is a multiple of 4, so the loop leaves exactly four k-steps
+    int t = 0;
 #pragma unroll 1
-        for (int t = 0; t < n64; t += 2) {
-            GI_STEP(0, 1, GI_WAIT_VM12, true)
-            if (t == n64 - 4) {                     // n64 is a multiple of 4: k-step n64 - 4 is the first of its pair
-                if (has_next) set_src(tile_m, tile_n);
-                voff_issue = lane * 16;
-                if (tid == 0) __hip_atomic_fetch_add(p.sync + xcd * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            GI_STEP(1, 0, GI_WAIT_VM12, true)       // (the last one's fragment reads are the next tile's stage 0: all but x1)
-        }
-
-        // ---- epilogue: the patch arg-min of every (row patch, column frame) of the tile, decided here -- the products never
-        // leave the chip (r02 / early r03 wrote them out, 2 GB, for a second kernel to read back).
-        // acc = C2 + floor((C3 + floor(C4 / 128)) / 128) in units of 2^-14 of u . u; d2 = |u_b|^2 - 2 acc 2^-14 in units of 2^-13.
-        // D[m][n] of MFMA (j, i): m = column j * 16 + (lane / 16) * 4 + v of this wave's unit, n = row patch (wr * 4 + i) * 16 + lane % 16.
-        // A row patch's columns are spread over four lanes and sixteen registers; rather than merge (best, index, runner-up)
-        // triples across lanes -- a chain of 64 dependent cross-lane moves per tile, 7 us -- the wave turns its block of d2
-        // through LDS, one group of 16 row patches at a time (its own 4 KiB: the stages already hold the next tile), so that
-        // a lane owns a (row patch, frame) pair: one sequential scan, as the pair kernels of the fp64 form do it.  Element
-        // (row n, column c) lives at int n * 64 + (c + 4 n) % 64: the 16-byte writes stay whole, and lanes on different
-        // rows reading the same column hit different banks.
-        int* d2s = (int*)(smem_i8 + GI_NSTAGE * GI_STAGE) + w * 16 * 64;
-        const int quad = lane >> 4, ln = lane & 15;
-        const long long unit = (long long)cur_n * 2 + wc;               // this wave's 64 columns: frames unit * fpu .. + fpu - 1
-        v4i nbl[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) nbl[j] = *(const v4i*)(p.nbp + unit * 64 + j * 16 + quad * 4);
-        ++done;
-        unsigned seen = has_next ? __hip_atomic_load(p.sync + xcd * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const v4i acc = c2[j][i] + ((c3[j][i] + (c4[j][i] >> 7)) >> 7);
-                *(v4i*)(d2s + ln * 64 + ((j * 16 + quad * 4 + 4 * ln) & 63)) = nbl[j] - acc;
-                __builtin_amdgcn_sched_barrier(0);                      // (the next tile's fragments are live: no room to hoist all the accumulator reads)
-            }
-            __builtin_amdgcn_s_waitcnt(0x0070);                          // lgkmcnt(0): this wave's LDS writes (its own region)
-            __builtin_amdgcn_wave_barrier();
-            for (int task = lane; task < 16 * p.fpu; task += 64) {       // (row patch r of the group, frame fs of the unit)
-                const int r = task & 15, fs = task >> 4;
-                const long long a = (long long)cur_m * GI_T + wr * 64 + i * 16 + r, fj = unit * p.fpu + fs;
-                if (!(a < p.nrows && fj < p.nframes && a < fj * p.P)) continue;     // (row frame < column frame)  <=>  a < fj * P
-                const int* drow = d2s + r * 64;
-                const int c0 = fs * p.P + 4 * r;
-                int dv[32];                                              // P <= 32 (sim_use_filter): all reads in flight at once
-#pragma unroll
-                for (int b = 0; b < 32; ++b) dv[b] = drow[(c0 + b) & 63];   // (columns behind the frame's P: read, not used)
-#pragma unroll
-                for (int b = 1; b < 32; ++b) dv[b] = b < p.P ? dv[b] : 0x7fffffff;
-                int best = dv[0], second = 0x7fffffff, bi = 0;
-#pragma unroll
-                for (int b = 1; b < 32; ++b) {
-                    second = min(second, max(best, dv[b]));              // the smaller of the two that are not the new minimum
-                    bi = dv[b] < best ? b : bi;                          // strict: the first minimum keeps its index
-                    best = min(best, dv[b]);
-                }
-                unsigned cand = 0;
-                if ((unsigned)second - (unsigned)best <= wu) {           // (every dv >= best: the unsigned difference is exact)
-#pragma unroll
-                    for (int b = 0; b < 32; ++b) cand |= ((unsigned)dv[b] - (unsigned)best <= wu ? 1u : 0u) << b;
-                    cand &= pmask;
-                    if ((cand & (cand - 1)) == 0) cand = 0;              // P = 1, or a window wider than the padding's distance
-                }
-                p.abi[fj * p.rp + a] = (unsigned char)bi;          // [frame][row patch]: a wave's lanes write neighbours
-                p.acand[fj * p.rp + a] = cand;                          // 0 = decided (one patch inside the window)
-            }
-            __builtin_amdgcn_s_waitcnt(0x0070);                          // the scans are through before the next group's writes
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (!has_next) break;
-        // The XCD's 32 workgroups stay within a few k-steps of each other (a panel line one of them fetched is still in that
-        // XCD's L2 when the other 3 or 7 that share it come for it): nobody starts tile d + 1 before all of them have signed
-        // off k-step n64 - 4 of their tile d.  Every one of the 32 has a tile d when anyone has a tile d + 1 (the tile list is
-        // dealt 32 at a time), and the wait is BOUNDED -- it is a hint about timing, nothing depends on it.
-        for (int spin = 0; seen < 32u * (unsigned)done && spin < 2048; ++spin) {
-            __builtin_amdgcn_s_sleep(8);
-            seen = __hip_atomic_load(p.sync + xcd * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    for (; t + 2 <= n64 - GI_NSTAGE; t += 2) {
+        GI_STEP(0, 1, GI_WAIT_VM12, true)
+        GI_STEP(1, 0, GI_WAIT_VM12, true)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the stream's last three stages land before the LDS goes
+    GI_STEP(0, 1, GI_WAIT_VM12, true)
+    GI_STEP(1, 0, GI_WAIT_VM12, false)
+    GI_STEP(0, 1, GI_WAIT_VM0, false)
+    GI_STEP(1, 0, GI_WAIT_VM0, false)               // (its reads of "stage n64" fetch a slot nobody writes any more: unused)
+    gi_acc_settle();                                // (wait states: see the accumulators' comment above the kernel)
 #undef GI_STEP
 #undef GI_PROD_IL
-#undef GI_RD
-#undef GI_PX
-#undef GI_PY
+#undef GI_PROD_IL1
+#undef GI_ROW2A
+#undef GI_ROW2B
+#undef GI_NONE
 #undef GI_PROD
-#undef GI_MFMA
 #undef GI_RDX
 #undef GI_RDY2
 #undef GI_RDYB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: the patch arg-min of every (row patch, column frame) of the tile, decided here -- the products never
+    // leave the chip (r02 / early r03 wrote them out, 2 GB, for a second kernel to read back).
+    // acc = C2 + floor((C3 + floor(C4 / 128)) / 128) in units of 2^-14 of u . u; d2 = |u_b|^2 - 2 acc 2^-14 in units of 2^-13.
+    // D[m][n] of MFMA (j, i): m = column j * 16 + (lane / 16) * 4 + v of this wave's unit, n = row patch (wr * 4 + i) * 16 + lane % 16.
+    // A row patch's columns are spread over four lanes and sixteen registers; rather than merge (best, index, runner-up)
+    // triples across lanes -- a chain of 64 dependent cross-lane moves per tile, 7 us -- the wave turns its 64 x 64 block
+    // of d2 through LDS (the stages are dead by now) so that lane r owns row r: one sequential scan per frame, as the pair
+    // kernels of the fp64 form do it.
+    __syncthreads();                                                     // every wave is through its last fragment reads
+    constexpr int DP = 65;                                               // row pitch (ints): lanes on different rows, same column -> different banks
+    int* d2s = (int*)smem_i8 + w * 64 * DP;
+    const int quad = lane >> 4;
+    const long long unit = (long long)tile_n * 2 + wc;                   // this wave's 64 columns: frames unit * fpu .. + fpu - 1
+    {
+        int nbl[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const v4i t4 = *(const v4i*)(p.nbp + unit * 64 + j * 16 + quad * 4);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) nbl[j][v] = t4[v];
+        }
+#define GI_EPI(I, J)                                                                                            \
+        {                                                                                                       \
+            const v4i a2 = gi_acc_read<GI_ACC(0, J, I)>(), a3 = gi_acc_read<GI_ACC(1, J, I)>(), a4 = gi_acc_read<GI_ACC(2, J, I)>(); \
+            const v4i acc = a2 + ((a3 + (a4 >> 7)) >> 7);                                                       \
+            int* dst = d2s + ((I) * 16 + (lane & 15)) * DP + (J) * 16 + quad * 4;                               \
+            _Pragma("unroll") for (int v = 0; v < 4; ++v) dst[v] = nbl[J][v] - acc[v];                          \
+        }
+        GI_EPI(0, 0) GI_EPI(0, 1) GI_EPI(0, 2) GI_EPI(0, 3) GI_EPI(1, 0) GI_EPI(1, 1) GI_EPI(1, 2) GI_EPI(1, 3)
+        GI_EPI(2, 0) GI_EPI(2, 1) GI_EPI(2, 2) GI_EPI(2, 3) GI_EPI(3, 0) GI_EPI(3, 1) GI_EPI(3, 2) GI_EPI(3, 3)
+#undef GI_EPI
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);                                  // lgkmcnt(0): this wave's LDS writes (its own region)
+    __builtin_amdgcn_wave_barrier();
+    const double E = 0x1p-20 * dlc_f64_unkey(p.keys[3]) + (double)p.H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
+    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
+    const unsigned wu = window > 0xffffffffll ? 0xffffffffu : (unsigned)window, pmask = p.P >= 32 ? ~0u : (1u << p.P) - 1u;
+    const long long a = m0 + wr * 64 + lane;                             // lane r owns row patch r of the wave's 64
+    const int* drow = d2s + lane * DP;
+    for (int fs = 0; fs < p.fpu; ++fs) {
+        const long long fj = unit * p.fpu + fs;
+        if (!(a < p.nrows && fj < p.nframes && a < fj * p.P)) continue;  // (row frame < column frame)  <=>  a < fj * P
+        const int* dr = drow + fs * p.P;
+        int dv[32];                                                      // P <= 32 (sim_use_filter): all reads in flight at once
+#pragma unroll
+        for (int b = 0; b < 32; ++b) dv[b] = dr[b < p.P ? b : 0];
+#pragma unroll
+        for (int b = 1; b < 32; ++b) dv[b] = b < p.P ? dv[b] : 0x7fffffff;
+        int best = dv[0], second = 0x7fffffff, bi = 0;
+#pragma unroll
+        for (int b = 1; b < 32; ++b) {
+            second = min(second, max(best, dv[b]));                      // the smaller of the two that are not the new minimum
+            bi = dv[b] < best ? b : bi;                                  // strict: the first minimum keeps its index
+            best = min(best, dv[b]);
+        }
+        unsigned cand = 0;
+        if ((unsigned)second - (unsigned)best <= wu) {                   // (every dv >= best: the unsigned difference is exact)
+#pragma unroll
+            for (int b = 0; b < 32; ++b) cand |= ((unsigned)dv[b] - (unsigned)best <= wu ? 1u : 0u) << b;
+            cand &= pmask;
+            if ((cand & (cand - 1)) == 0) cand = 0;                      // P = 1, or a window wider than the padding's distance
+        }
+        p.abi[fj * p.rp + a] = (unsigned char)bi;
+        p.acand[fj * p.rp + a] = cand;                                  // 0 = decided (one patch inside the window)
+    }
 }
 
 // ---- range, quantisation -------------------------------------------------------------------------------------------
@@ -613,13 +603,13 @@ size_t sim_filter_panel_bytes(int64_t rows, int64_t H) {
 int sim_frames_per_unit(int64_t P) { return (int)(64 / P); }
 static int64_t sim_col_tiles(int64_t N, int64_t P) { return dlc::cdiv(dlc::cdiv(N, (int64_t)sim_frames_per_unit(P)), (int64_t)2); }
 int64_t sim_col_rows(int64_t N, int64_t P) { return sim_col_tiles(N, P) * GI_T; }                      // rows of Y, entries of nbp
-int64_t sim_col_frames(int64_t N, int64_t P) { return sim_col_tiles(N, P) * 2 * sim_frames_per_unit(P); }   // nfp: column frames of abi / acand
-int64_t sim_argmin_pitch(int64_t N, int64_t P) { return (int64_t)dlc::align_up((size_t)(N * P), 64); }     // rp: their pitch in row patches
+int64_t sim_col_frames(int64_t N, int64_t P) { return sim_col_tiles(N, P) * 2 * sim_frames_per_unit(P); }
+int64_t sim_argmin_pitch(int64_t N, int64_t P) { return (int64_t)dlc::align_up((size_t)(N * P), 64); }   // nfp: frames per row of abi / acand
 // the block table of gram_argmin_i8 (`blocks`)
 size_t gram_blocks_bytes(int64_t N, int64_t P) {
     const size_t tiles_m = (size_t)dlc::cdiv((N > 1 ? N - 1 : 1) * P, (int64_t)GI_T), tiles_n = (size_t)sim_col_tiles(N, P);
     const size_t nsm = (tiles_m + GI_BR - 1) / GI_BR, nsn = (tiles_n + GI_BC - 1) / GI_BC;
-    return 1024 + dlc::align_up(nsm + 1 + nsm * nsn + 1 + 1, 2) * 4 + nsm * nsn * GI_BR * GI_BC * 8;
+    return dlc::align_up(nsm + 1, 2) * 4 + nsm * nsn * 8;
 }
 size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H) {
     const size_t kp = dlc::align_up((size_t)H, (size_t)GI_KPAD);
@@ -711,20 +701,16 @@ int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X,
         if (cnt > 0) a.nsup += cnt;
     }
     if (a.nsup == 0) return DLC_OK;
-    a.sync = (unsigned*)blocks;
-    int* scratch = (int*)blocks + 256;
-    const size_t nscratch = dlc::align_up((size_t)a.nsm + 1 + (size_t)a.nsm * a.nsn + 1 + 1, 2);
-    a.ntiles = scratch + nscratch - 1;
-    a.tiles = (const int2*)(scratch + nscratch);
-    hipLaunchKernelGGL(gram_tiles_kernel, dim3(1), dim3(256), 0, st, a.nsm, a.nsn, a.tiles_m, a.tiles_n, (int)P, a.fpu, (long long)a.nframes,
-                       scratch, (int2*)a.tiles, scratch + nscratch - 1, a.sync);
-    DLC_LAUNCH_CHECK(ctx, "gram_tiles_kernel");
-    const size_t lds = (size_t)GI_NSTAGE * GI_STAGE + GI_EPI;
+    int* rowstart = (int*)blocks;
+    a.blk = (const int2*)(rowstart + dlc::align_up((size_t)a.nsm + 1, 2));
+    hipLaunchKernelGGL(gram_blocks_kernel, dim3(1), dim3(256), 0, st, a.nsm, a.nsn, (int)P, a.fpu, rowstart, (int2*)a.blk);
+    DLC_LAUNCH_CHECK(ctx, "gram_blocks_kernel");
+    const size_t lds = (size_t)GI_NSTAGE * GI_STAGE;
     if (!(ctx->func_attr_set & (1ull << DLC_ATTR_GRAM_I8))) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gram_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->func_attr_set |= 1ull << DLC_ATTR_GRAM_I8;
     }
-    const unsigned grid = GI_GRID;              // persistent: 8 XCDs x 32 tiles of a block
+    const unsigned grid = (unsigned)(((a.nsup + 7) / 8) * 8 * 32);
     // bench.py's kernel-only timing (dlc_set_profiling): an event pair around the kernel on its stream
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));

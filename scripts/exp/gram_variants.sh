@@ -26,6 +26,7 @@ PY
 BAR='        __builtin_amdgcn_s_barrier();                                                                           \\'
 NODMA="('if (ISSUE) issue_piece((B0) + j);', ''), ('if (ISSUE) issue_done();', '')"
 NOLDS="('GI_RDX(1, so_c);', ''), ('GI_RDX(0, so_n); GI_RDYB(N, 0, so_n); GI_RDYB(N, 1, so_n); GI_RDY2(so_n);', ''), ('GI_RDX(2, so_n);', '')"
+NOLDS_IL="('#define GI_RD(DST, PTR) { __builtin_amdgcn_sched_barrier(0); DST = *(const v4i*)(PTR); __builtin_amdgcn_sched_barrier(0); }', '#define GI_RD(DST, PTR) {}')"
 NOBAR="('''$BAR''', '        \\\\')"
 PROF="('__global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {', '__device__ unsigned long long gi_prof[8];\n__global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {\n    unsigned TS = (unsigned)__builtin_amdgcn_s_memtime(), a1 = 0, a2 = 0, a3 = 0, nt = 0;'), \
 ('        const int cur_m = tile_m, cur_n = tile_n;', '        const unsigned T0 = (unsigned)__builtin_amdgcn_s_memtime();\n        const int cur_m = tile_m, cur_n = tile_n;'), \
@@ -36,6 +37,8 @@ PROF="('__global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p
 ('    DLC_LAUNCH_CHECK(ctx, \"gram_i8_kernel\");', '    DLC_LAUNCH_CHECK(ctx, \"gram_i8_kernel\");\n    { unsigned long long h[8], z[8] = {}; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(gi_prof), 64); (void)hipMemcpyToSymbol(HIP_SYMBOL(gi_prof), z, 64); fprintf(stderr, \"gi_prof tiles %llu: top %.0f loop %.0f epilogue %.0f cycles per tile; %llu workgroups of %.0f cycles (min %llu max %llu)\\\\n\", h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4], h[5], (double)h[0] / (h[5] ? h[5] : 1), 0xffffffffull - h[7], h[6]); }')"
 build prof "[$PROF]" &
 if [ "$1" = prof ]; then wait; rm -rf $T; exit 0; fi
+L2FED="('set_src(tile_m, tile_n);', 'set_src(0, 0);')"
+if [ "$1" = l2fed ]; then build l2fed "[$L2FED]"; build nodma "[$NODMA]"; build nolds "[$NOLDS_IL]"; rm -rf $T; exit 0; fi
 build base "[]" &
 build nodma "[$NODMA]" &
 build nobarrier "[$NOBAR]" &
