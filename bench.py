@@ -365,27 +365,11 @@ def bench_paths(eng, n_frames):
         score, rng = eng.distinctive_score(desc, 0.5, 0.2, with_range=True)
         return eng.sdav_similarity_matrix(desc, score, 10.0, -10.0, range=rng)
     call_ms, k_ms, k_n, (mf, mi) = _timed_path(eng, sim, reps=2)
-    # The patch products as dlc_sdav_similarity_matrix launches them (match_ref.hip sim_ws): row chunks of <= 8 GiB of
-    # int32 accumulators, frames [i_lo, i_hi) against every later frame; tiles under the diagonal are skipped, so the
-    # operations counted are the upper triangle's (what the similarity needs), not the launched rectangle's -- six int8
-    # products of length H per patch pair (csrc/gram_i8.hip: the 21-bit fixed-point slices' classes 2, 3 and 4)
-    cf = max(1, (8 << 30) // ((N * P + 20) * 4 * P))
-    if cf >= N - 1:
-        cf = max(N - 1, 1)
-    else:
-        for q_ in (256, 128, 64, 32, 16, 8):
-            if cf >= q_ and (q_ * P) % 256 == 0:
-                cf = cf // q_ * q_
-                break
-    cf = min(cf, N)
-    patch_pairs, i_lo = 0.0, 0
-    while i_lo + 1 < N:
-        i_hi = min(i_lo + cf, N - 1)
-        # rows of frames [i_lo, i_hi) x columns of frames > i_lo, minus the (skipped) lower triangle inside the chunk
-        rect = (i_hi - i_lo) * P * (N * P - (i_lo + 1) * P)
-        lower = (i_hi - i_lo - 1) * (i_hi - i_lo) / 2.0 * P * P
-        patch_pairs += rect - lower
-        i_lo += cf
+    # The patch products the similarity needs: row patches of frame i against the patches of every LATER frame j (the
+    # upper triangle; gram_i8_kernel launches the tiles that hold such a pair and decides the patch arg-min in its
+    # epilogue) -- six int8 products of length H per patch pair (csrc/gram_i8.hip: the 21-bit fixed-point slices' classes
+    # 2, 3 and 4).  Padding (K to 2560, whole-frame column units, diagonal tiles) is the kernel's cost, not counted here.
+    patch_pairs = (N * (N - 1) / 2.0) * P * P
     i8_ops = 6 * 2.0 * patch_pairs * H
     pairs = N * (N - 1) // 2
     ns = min(N, 20)                                           # the reference-literal per-pair loop at datasets/test size
@@ -415,7 +399,7 @@ def bench_paths(eng, n_frames):
                 "roofline": {"bound": "mfma", "achieved": i8_ops / (k_ms * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
                              "frac": i8_ops / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": None,
                              "kernel": "gram_i8_kernel (exact int8 products of the descriptors' 21-bit fixed-point slices, "
-                                       "wanted blocks only; they decide the patch arg-min, the rest is evaluated directly in fp64)",
+                                       "wanted tiles only; its epilogue decides the patch arg-min, undecided ones are evaluated directly in fp64)",
                              "kernel_ms": k_ms, "kernel_launches_timed": k_n, "call_ms": call_ms,
                              "algorithmic_ops_per_call": i8_ops,
                              "fp64_equivalent_tflops": 2.0 * patch_pairs * H / (k_ms * 1e-3) / 1e12},

@@ -122,10 +122,13 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __re
 //
 // The row-ordered fp64 add chain of a column IS the specification (bit parity with NumPy), the
 // serial LOAD chain is not: a workgroup owns DS_COLS = 16 columns (one 128-byte segment of every
-// row) and all of its 256 threads fetch -- 16 lane groups x DS_U rows each = 256 rows = 32 KiB in
-// flight per workgroup, 157 workgroups at H = 2500 -- while the first 16 lanes add the previous
-// batch out of LDS in row order.  One barrier per batch (double-buffered LDS).  HBM-bound
-// (rows*H*8 bytes read once) down to the latency of the add chain itself (rows x one v_add_f64).
+// row) and all of its 256 threads fetch -- 16 lane groups x DS_U rows each = a batch of 256 rows =
+// 32 KiB, and TWO batches ahead (two register sets): 64 KiB in flight per workgroup, 157 workgroups
+// at H = 2500 -- while the first 16 lanes add the batch that has landed out of LDS in row order.  One
+// barrier per batch (double-buffered LDS).  With one batch ahead a batch took as long as its loads
+// (3.2 us, the add chain 1 us): 2 TB/s.  (512 threads and one batch of 64 KiB ahead: slower still --
+// the same latency per batch, twice the batch.)  HBM-bound (rows*H*8 bytes read once) down to the
+// latency of the add chain itself (rows x one v_add_f64).
 constexpr int DS_COLS = 16;               // columns per workgroup
 constexpr int DS_U = 16;                  // rows per thread and batch
 constexpr int DS_ROWS = 16 * DS_U;        // rows per batch
@@ -145,8 +148,8 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
     const int col = blockIdx.x * DS_COLS + c;
     const bool col_ok = col < H;
     const double* src = desc + (col_ok ? col : 0);
-    double v[DS_U];
-    auto fetch = [&](long long r0) {
+    double va[DS_U], vb[DS_U];
+    auto fetch = [&](double (&v)[DS_U], long long r0) {
 #pragma unroll
         for (int u = 0; u < DS_U; ++u) {
             const long long r = r0 + u * 16 + g;
@@ -154,9 +157,8 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
         }
     };
     double s = 0.0;
-    fetch(0);
-    int b = 0;
-    for (long long r0 = 0; r0 < rows; r0 += DS_ROWS, b ^= 1) {
+    // one batch: its values (landed by now) into LDS, the fetch of the batch two ahead into the same registers, the add
+    auto batch = [&](double (&v)[DS_U], int b, long long r0) {
 #pragma unroll
         for (int u = 0; u < DS_U; ++u) buf[b][u * 16 + g][c] = v[u];
         if (range) {                                           // (here, where the loads have landed -- not where they are issued)
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
                 if (col_ok && r0 + u * 16 + g < rows) { bad |= !(fabs(v[u]) < INFINITY); lo = fmin(lo, v[u]); hi = fmax(hi, v[u]); }
         }
         __syncthreads();
-        if (r0 + DS_ROWS < rows) fetch(r0 + DS_ROWS);          // in flight while the batch is added
+        if (r0 + 2 * DS_ROWS < rows) fetch(v, r0 + 2 * DS_ROWS);
         if (tid < DS_COLS) {
             const long long left = rows - r0;
             const int m = left < DS_ROWS ? (int)left : DS_ROWS;
@@ -176,6 +178,12 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
                 for (int r = 0; r < m; ++r) s += buf[b][r][c];
             }
         }
+    };
+    fetch(va, 0);
+    if (DS_ROWS < rows) fetch(vb, DS_ROWS);
+    for (long long r0 = 0; r0 < rows; r0 += 2 * DS_ROWS) {
+        batch(va, 0, r0);
+        if (r0 + DS_ROWS < rows) batch(vb, 1, r0 + DS_ROWS);
     }
     if (tid < DS_COLS && col_ok) {
         const double avg = s / (double)rows;
