@@ -10,7 +10,7 @@ os.makedirs(dst, exist_ok=True)
 OURS = ("score_gemm_kernel", "finish_topk_kernel", "merge_topk_kernel", "l2_normalize_kernel", "l2_normalize_regs_kernel",
         "gemm_dma_f64_kernel", "gemm_bias_act_kernel", "distance_matrix_kernel", "distinctive_score_kernel",
         "pair_score_kernel", "pair_score_tile_kernel", "transpose_f64_kernel", "splitk_groups_kernel", "splitk_dense_kernel", "maxpool_kernel", "row_minmax_kernel",
-        "quant_gather_kernel", "row_stats_kernel", "gram_i8_kernel", "pair_score_filter_kernel", "sim_rows_kernel",
+        "quant_gather_kernel", "row_stats_kernel", "gram_i8_kernel", "pair_score_amin_kernel", "gram_blocks_kernel", "sim_rows_kernel",
         "sim_range_kernel", "sim_pairwise_program_kernel", "exhaustive_topk_kernel", "score_gemv_kernel", "stream_argmin_kernel",
         "stream_score_kernel", "random_mask_kernel", "xent_grad_kernel", "hidden_grad_kernel", "sgd_kernel")
 

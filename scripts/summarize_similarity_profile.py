@@ -7,7 +7,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02i"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_sim_" + tag)
 dst = os.path.join(root, "profiles")
-KERNELS = ("gram_i8_kernel", "pair_score_filter_kernel", "sim_rows_kernel", "sim_range_kernel",
+KERNELS = ("gram_i8_kernel", "pair_score_amin_kernel", "sim_rows_kernel", "sim_range_kernel",
            "sim_pairwise_program_kernel", "distinctive_score_kernel", "fill_diag_kernel")
 with open(os.path.join(src, "stats", "sim_kernel_stats.csv")) as f, open(os.path.join(dst, tag + "_similarity_kernel_stats.csv"), "w") as g:
     for i, line in enumerate(f):
@@ -26,7 +26,7 @@ for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     if not os.path.exists(path):
         continue
     for r in csv.DictReader(open(path)):
-        for k in ("gram_i8_kernel", "pair_score_filter_kernel"):
+        for k in ("gram_i8_kernel", "pair_score_amin_kernel"):
             if k + "(" in r["Kernel_Name"]:
                 pmc[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
