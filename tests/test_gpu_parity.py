@@ -648,7 +648,10 @@ def test_similarity_filter_equals_fp64_gram_route(eng, monkeypatch):
             out.append((mf.clone(), mi.clone()))
         return out
 
-    for n, p, h in [(2, 1, 8), (3, 7, 64), (6, 30, 8), (20, 30, 250), (40, 32, 2500), (70, 13, 129), (300, 30, 256), (150, 5, 1000)]:
+    # (H a multiple of 256: the LAST k-step of the product kernel is all data, not zero padding -- what an accumulator read
+    # too early behind the last MFMAs would lose, docs/LAB.md 9.2)
+    for n, p, h in [(2, 1, 8), (3, 7, 64), (6, 30, 8), (20, 30, 250), (40, 32, 2500), (70, 13, 129), (300, 30, 256), (150, 5, 1000),
+                    (40, 30, 768), (40, 31, 256), (40, 16, 1024)]:
         sat = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
         dup = sat.clone().reshape(n * p, h)
         if n * p > 4:
