@@ -38,7 +38,9 @@ extern "C" int dlc_create(int device, dlc_ctx** out) {
             return DLC_ERR_HIP;
         }
     }
-    if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+    if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess ||
+        hipHostMalloc((void**)&c->host_flag, 64, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_flag, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return DLC_ERR_HIP;
     }
@@ -55,6 +57,8 @@ extern "C" int dlc_destroy(dlc_ctx* ctx) {
             (void)hipEventDestroy(ctx->ev_stop[i]);
         }
         if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+        if (ctx->host_flag) (void)hipHostFree(ctx->host_flag);
+        if (ctx->ev_flag) (void)hipEventDestroy(ctx->ev_flag);
         if (ctx->staging) {
             (void)hipDeviceSynchronize();            // no DMA may still read / write the pinned pieces
             dlc::staging_free(ctx->staging);

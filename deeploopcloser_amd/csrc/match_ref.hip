@@ -1096,33 +1096,34 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         // takes the first of them: the fp64 kernels reproduce that, a fixed-point fraction cannot.)  The ONE host read of
         // this library's stream-ordered calls -- unless the caller rules it out (DLC_SIM_NO_HOST_SYNC): the filter form's
         // kernels then leave at once on such data and the matrix comes back as NaN / INT64_MIN with stats[1] = 1.
+        // The read does not hold the stream up: the word is copied to page-locked memory behind the quantisation pass, the
+        // filter form's kernels are enqueued right behind it (on such data they leave at once), and the host waits for
+        // the COPY's event only -- while the product kernel runs -- before it decides whether the fp64 form has to follow.
         const bool no_sync = (flags & DLC_SIM_NO_HOST_SYNC) != 0;
-        unsigned long long bad = 0;
         if (!no_sync) {
-            DLC_HIP_CHECK(ctx, hipMemcpyAsync(&bad, keys + 2, sizeof(bad), hipMemcpyDeviceToHost, st));
-            DLC_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            DLC_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_flag, keys + 2, 8, hipMemcpyDeviceToHost, st));
+            DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_flag, st));
         }
-        if (bad) {
-            filter = false;
-            if (stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
-        } else {
-            if (N > 1) {
-                // all frames in ONE launch: the product kernel keeps its 31 890 x 31 890 products on the chip and emits
-                // the arg-mins (r02: row chunks of an 8 GiB int32 block)
-                rc = dlc_gemm::gram_argmin_i8(ctx, N, P, H, qx, qy, nbp, keys, abi, acand, ws + w.blk, st);
-                if (rc != DLC_OK) return rc;
-                hipLaunchKernelGGL(pair_score_amin_kernel, dim3(PS_GX, (unsigned)(N - 1)), dim3(256), PF_STACK_BYTES, st, desc,
-                                   (const unsigned char*)abi, (const unsigned*)acand, (long long)dlc_gemm::sim_argmin_pitch(N, P), proj, score, keys,
-                                   (long long)N, (int)P, (int)H, a, b, out_f64, (long long*)out_i64, prog, rowhash, direct_pairs);
-                DLC_LAUNCH_CHECK(ctx, "pair_score_amin_kernel");
-            }
-            if (stats || no_sync) {
-                hipLaunchKernelGGL(sim_finish_kernel, dim3(no_sync ? 256u : 1u), dim3(256), 0, st, keys, (long long*)stats,
-                                   (long long)N * N, out_f64, (long long*)out_i64, no_sync ? 1 : 0);
-                DLC_LAUNCH_CHECK(ctx, "sim_finish_kernel");
-            }
-            return DLC_OK;
+        if (N > 1) {
+            // all frames in ONE launch: the product kernel keeps its 31 890 x 31 890 products on the chip and emits
+            // the arg-mins (r02: row chunks of an 8 GiB int32 block)
+            rc = dlc_gemm::gram_argmin_i8(ctx, N, P, H, qx, qy, nbp, keys, abi, acand, ws + w.blk, st);
+            if (rc != DLC_OK) return rc;
+            hipLaunchKernelGGL(pair_score_amin_kernel, dim3(PS_GX, (unsigned)(N - 1)), dim3(256), PF_STACK_BYTES, st, desc,
+                               (const unsigned char*)abi, (const unsigned*)acand, (long long)dlc_gemm::sim_argmin_pitch(N, P), proj, score, keys,
+                               (long long)N, (int)P, (int)H, a, b, out_f64, (long long*)out_i64, prog, rowhash, direct_pairs);
+            DLC_LAUNCH_CHECK(ctx, "pair_score_amin_kernel");
         }
+        if (stats || no_sync) {
+            hipLaunchKernelGGL(sim_finish_kernel, dim3(no_sync ? 256u : 1u), dim3(256), 0, st, keys, (long long*)stats,
+                               (long long)N * N, out_f64, (long long*)out_i64, no_sync ? 1 : 0);
+            DLC_LAUNCH_CHECK(ctx, "sim_finish_kernel");
+        }
+        if (no_sync) return DLC_OK;
+        DLC_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_flag));
+        if (!*(volatile unsigned long long*)ctx->host_flag) return DLC_OK;
+        filter = false;                                     // NaN / infinity in the data: the fp64 form after all
+        if (stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
     }
 
     // the fp64 Gram route
