@@ -364,7 +364,7 @@ def bench_paths(eng, n_frames):
     def sim():                                                    # what SimilarityCalculator(dataset).similarity_matrix() runs
         score, rng = eng.distinctive_score(desc, 0.5, 0.2, with_range=True)
         return eng.sdav_similarity_matrix(desc, score, 10.0, -10.0, range=rng)
-    call_ms, k_ms, k_n, (mf, mi) = _timed_path(eng, sim, reps=2)
+    call_ms, k_ms, k_n, (mf, mi) = _timed_path(eng, sim, reps=4)
     # The patch products the similarity needs: row patches of frame i against the patches of every LATER frame j (the
     # upper triangle; gram_i8_kernel launches the tiles that hold such a pair and decides the patch arg-min in its
     # epilogue) -- six int8 products of length H per patch pair (csrc/gram_i8.hip: the 21-bit fixed-point slices' classes
