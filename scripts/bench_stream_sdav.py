@@ -3,6 +3,9 @@ against 1062 resident frames of 30 x 2500 descriptors.  GPU box only."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 2:
+    import deeploopcloser_amd._lib as L
+    L.LIB_PATH = os.path.abspath(sys.argv[2])
 import deeploopcloser_amd as dlc
 eng = dlc.default_engine()
 g = torch.Generator(device=eng.device); g.manual_seed(3)
