@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restri
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, quad = lane >> 4, an = lane & 15;
     const long long rows_old = f * P;                              // database patches: rows 0 .. rows_old - 1
     const long long gd0 = ((long long)blockIdx.x * 4 + w) * SR_G;
-    // (the count of direct evaluations, keys[4], is zeroed by a memset in front of this kernel)
+    // (the count of direct evaluations, keys[4], is zero: the stream's creation and every query's last kernel leave it so)
     if (gd0 * 16 >= rows_old) return;                              // (whole wave)
     const long long gq0 = rows_old / 16;                           // frame f's patches lie in groups gq0 .. gq0 + 2
     const int boff = (int)(rows_old - gq0 * 16);
@@ -850,13 +850,16 @@ __global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restri
 __global__ __launch_bounds__(256) void stream_score_kernel(const double* __restrict__ desc, const double* __restrict__ proj,
                                                            const double* __restrict__ score,
                                                            const unsigned char* __restrict__ bi_in,
-                                                           const unsigned long long* __restrict__ keys, long long f, int P, int H,
+                                                           unsigned long long* __restrict__ keys, long long f, int P, int H,
                                                            double ca, double cb, double* __restrict__ row,
                                                            long long* __restrict__ stats) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jj = lane >> 5, a = lane & 31;
     const long long j = ((long long)blockIdx.x * 4 + w) * 2 + jj;
-    if (stats && blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = (long long)keys[4]; stats[1] = keys[2] ? 1 : 0; }
-    const bool pair_ok = j < f, live = pair_ok && a < P;       // (keys[4], this query's count, is zeroed by the next query's first kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                  // this query's count of direct evaluations: handed over and
+        if (stats) { stats[0] = (long long)keys[4]; stats[1] = keys[2] ? 1 : 0; }
+        keys[4] = 0ull;                                         // reset for the next query (no memset launch in front of it)
+    }
+    const bool pair_ok = j < f, live = pair_ok && a < P;
     double term = 0.0, wd = 1.0, pa = 0.0;
     long long rb = 0;
     bool redo = false;
@@ -1236,7 +1239,6 @@ extern "C" int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_byt
     const long long kp = (long long)dlc::align_up((size_t)H, (size_t)256);
     const long long gpitch = 3 * kp * 16;
     const long long groups = dlc::cdiv(f * P, (int64_t)16);
-    DLC_HIP_CHECK(ctx, hipMemsetAsync(keys + 4, 0, 8, st));
     hipLaunchKernelGGL(stream_argmin_kernel, dim3((unsigned)dlc::cdiv(groups, (long long)(4 * SR_G))), dim3(256), 0, st,
                        (const char*)(ws + w.panel), gpitch, (int)(kp / 64), desc, (const double*)(ws + w.nu2),
                        (const unsigned long long*)(ws + w.rowhash), keys, (long long)f, (int)P, (int)H,

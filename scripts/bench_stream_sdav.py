@@ -25,7 +25,7 @@ for f in (n - 1, n // 2):
     us = e0.elapsed_time(e1) / 50 * 1e3
     mb = f * 30 * 7680 / 1e6
     print("query of frame %d against %d older frames: %.1f us per query (%.0f MB of panel: %.2f TB/s), direct evaluations %d"
-          % (f, f, us, mb, mb / us / 1e6 * 1e6 / 1e6, int(st.stats[0])))
+          % (f, f, us, mb, mb / us, int(st.stats[0])))
 t0 = time.perf_counter()
 st2 = dlc.SimilarityStream(score, capacity=n)
 for f in range(64):
