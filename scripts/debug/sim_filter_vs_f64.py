@@ -7,7 +7,7 @@ if len(sys.argv) > 1:
     L.LIB_PATH = os.path.abspath(sys.argv[1])
 import deeploopcloser_amd as dlc
 eng = dlc.default_engine()
-for (n, p, h) in [(40, 30, 256), (40, 30, 768), (40, 30, 2500), (40, 16, 1024), (9, 32, 512), (70, 7, 333)]:
+for (n, p, h) in [(3000, 30, 256), (1500, 8, 192), (2, 1, 64), (2, 32, 64), (5, 32, 4096)]:
     g = torch.Generator(device=eng.device); g.manual_seed(n)
     ds = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
     score = eng.distinctive_score(ds, 0.5, 0.2)
