@@ -76,6 +76,19 @@ def test_no_gpu_fails_loudly(lib):
             make()
 
 
+def test_kernel_register_contracts_hold_in_the_object_code(lib):
+    """gram_i8_kernel relies on hipcc leaving two things alone: M0 around its LDS-DMA pieces and the fixed accumulation
+    registers a0..a191 around its inline-asm MFMAs (an accumulator hipcc moved on its own would carry no wait states behind
+    the MFMA that wrote it, docs/LAB.md 9.2).  `make` runs csrc/check_m0.py on the object; so does this test."""
+    csrc = os.path.join(ROOT, "deeploopcloser_amd", "csrc")
+    obj = os.path.join(csrc, "build", "gram_i8.o")
+    if not os.path.exists(obj):
+        subprocess.check_call(["make", "-C", csrc, "-j4"])
+    out = subprocess.run(["python3", os.path.join(csrc, "check_m0.py"), obj], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "192 zero writes" in out.stdout and "no other M0 access" in out.stdout
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "deeploopcloser_amd")
     for dirpath, _, files in os.walk(pkg):
