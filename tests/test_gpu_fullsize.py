@@ -136,6 +136,19 @@ def test_similarity_filter_equals_fp64_route_full_size(dlc, descriptors, kind):
           "oracle pairs)" % (kind, direct, N_FRAMES * (N_FRAMES - 1) // 2 * 30, pairs, checked))
 
 
+@pytest.mark.parametrize("n,p,h", [(500, 30, 2560), (700, 16, 1024), (400, 32, 2048)])
+def test_similarity_filter_equals_fp64_route_unpadded_k(dlc, n, p, h):
+    """Hundreds of frames with a descriptor width that is a multiple of 256: the product kernel's LAST k-step is all data
+    (at H = 2500 it is 60 columns of zero padding, which hides an accumulator read too early behind the last MFMAs --
+    docs/LAB.md 9.2), for 2, 4 and 2 frames per 64-column unit.  Filter == fp64 Gram form bit for bit, == the oracle on
+    60 pairs led by the directly evaluated ones."""
+    eng = dlc.default_engine()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n + p + h)
+    ds = torch.sigmoid(6.0 * torch.randn((n, p, h), generator=g, device="cuda", dtype=torch.float64))
+    _both_routes_and_oracle(eng, ds, 60, n)
+
+
 def test_similarity_filter_real_frames_tiled(dlc):
     """The 20 real frames of datasets/test (tests/golden) tiled to 220 frames: exact copies of whole frames (identical
     descriptors: +inf scores, every arg-min a tie of bit-identical rows), copies with a few pixels moved by 1/255, and
