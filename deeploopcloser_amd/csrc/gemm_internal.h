@@ -42,9 +42,9 @@ int sim_frames_per_unit(int64_t P);
 int64_t sim_col_rows(int64_t N, int64_t P);
 int64_t sim_col_frames(int64_t N, int64_t P);
 int64_t sim_argmin_pitch(int64_t N, int64_t P);
-size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H);
+bool sim_filter_fits(int64_t N, int64_t P, int64_t H);
 int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H, const double* score,
-                       unsigned long long* keys, char* X, char* Y, int* nbp, double* nu2, double* proj,
+                       unsigned long long* keys, char* X, int* nbp, double* nu2, double* proj,
                        unsigned long long* rowhash, void* prog, const unsigned long long* range, hipStream_t st);
 size_t sim_pairwise_program_bytes(int64_t H);
 int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
@@ -55,7 +55,7 @@ int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, in
                         unsigned long long* keys, char* X, double* nu2, double* proj, unsigned long long* rowhash,
                         int64_t g_first, int64_t g_count, hipStream_t st);
 size_t sim_stream_panel_bytes(int64_t rows, int64_t H);
-int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const char* Y, const int* nbp,
+int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const int* nbp,
                    const unsigned long long* keys, unsigned char* abi, unsigned* acand, void* blocks, hipStream_t st);
 size_t gram_blocks_bytes(int64_t N, int64_t P);
 

@@ -46,10 +46,12 @@ constexpr int GI_NSTAGE = 3;              // 144 KiB: two stages in flight behin
 constexpr int GI_BR = 4, GI_BC = 8;       // an XCD's 32 resident workgroups take one block of 4 x 8 tiles
 
 struct GramI8Args {
-    const char* X;                        // row panel: patch rows in order, groups of 16
-    const char* Y;                        // column panel: the same data in UNITS of 64 columns = fpu whole frames + zero rows, so
-                                          // that every frame's P columns lie inside one wave's 64-column block
-    const int* nbp;                       // |u_b|^2 of the column panel's rows, units of 2^-13 (padded like Y)
+    const char* X;                        // THE panel: patch rows in order, groups of 16 (+ at least one group of zero rows
+                                          // from row `zrow` on).  Row operands are its groups as they lie; COLUMN operands are
+                                          // gathered from it, lane by lane, in UNITS of 64 columns = fpu whole frames + zero
+                                          // rows, so that every frame's P columns lie inside one wave's 64-column block
+    long long zrow;                       // first row of an all-zero group of X
+    const int* nbp;                       // |u_b|^2 of the column units' rows, units of 2^-13 (unit layout)
     const unsigned long long* keys;       // [3]: largest row sum of u (the error bound), [2]: non-finite flag
     unsigned char* abi;                   // out [nfp, rp]: the nearest patch b of column frame j to row patch a
     unsigned* acand;                      // out [nfp, rp]: 0 = decided; else the patches inside the error window (bit b)
@@ -194,21 +196,39 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     const int n64 = p.kp / GI_KS;                   // k-steps (per slice): a multiple of 4, at least 4
     // this wave's DMA share of a stage: groups 2 w, 2 w + 1 of each panel, three slices each = 12 pieces.  Piece b:
     // panel b / 6, group (b % 6) / 3, slice b % 3; its source base is wave-uniform, the k-step rides in the lanes' offset.
-    const char* src[12];
+    // Row pieces (b < 6): one uniform base each, all lanes at lane * 16 behind it.  Column pieces (b >= 6): column c of the
+    // tile is row (c / 64) * fpu * P + c % 64 of the panel when c % 64 < fpu * P and its frame exists, a zero row otherwise
+    // -- 16 consecutive rows that begin anywhere in a group, so every lane carries its own offset from X (the panel is
+    // smaller than 4 GiB: sim_filter_fits): the same bytes serve as row and as column operands, there is no second panel.
+    const char* src[6];
 #pragma unroll
-    for (int b = 0; b < 12; ++b) {
-        const char* panel = b < 6 ? p.X + (m0 / 16) * p.gpitch : p.Y + (n0 / 16) * p.gpitch;
-        src[b] = uniform_ptr(panel + (long long)(w * 2 + (b % 6) / 3) * p.gpitch + (long long)(b % 3) * n64 * 1024);
+    for (int b = 0; b < 6; ++b)
+        src[b] = uniform_ptr(p.X + (m0 / 16) * p.gpitch + (long long)(w * 2 + b / 3) * p.gpitch + (long long)(b % 3) * n64 * 1024);
+    const char* xbase = uniform_ptr(p.X);
+    unsigned yoff[2];                               // this lane's offset of slice 0, k-step 0 for the wave's two column groups
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const long long c = n0 + (w * 2 + gi) * 16 + (lane & 15);
+        const long long u = c >> 6;
+        const int o = (int)(c & 63);
+        const bool valid = o < p.fpu * p.P && u * p.fpu + o / p.P < p.nframes;
+        const long long xr = valid ? u * p.fpu * p.P + o : p.zrow;
+        yoff[gi] = (unsigned)((xr >> 4) * p.gpitch + (((lane >> 4) * 16 + (int)(xr & 15)) * 16));
     }
+    const unsigned slice_bytes = (unsigned)n64 * 1024u;
     // its LDS destination inside a stage: block ((2 w + group) * 3 + slice) of the panel's half
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_base + w * 6 * 1024);
     unsigned voff_issue = lane * 16;                // lanes' offset of the next stage to fetch: + 1 KiB per k-step
+    unsigned kbytes = 0;                            // ... the same without the lane's part (uniform)
     int is_slot = 0;                                // ... and the slot it goes to
     auto issue_piece = [&](int b) {
-        dma1(voff_issue, src[b], lds_w + is_slot * GI_STAGE + (b / 6) * GI_HALF + (b % 6) * 1024);
+        const unsigned lds = lds_w + is_slot * GI_STAGE + (b / 6) * GI_HALF + (b % 6) * 1024;
+        if (b < 6) dma1(voff_issue, src[b], lds);
+        else dma1(yoff[(b - 6) / 3] + (unsigned)((b - 6) % 3) * slice_bytes + kbytes, xbase, lds);
     };
     auto issue_done = [&]() {
         voff_issue += 1024;
+        kbytes += 1024;
         is_slot = is_slot == GI_NSTAGE - 1 ? 0 : is_slot + 1;
     };
 
@@ -462,7 +482,7 @@ __device__ __forceinline__ unsigned long long sim_mix64(unsigned long long z) {
 template <bool QUANT>
 __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict__ desc, long long rows, int H, int kp,
                                                        const double* __restrict__ score, unsigned long long* keys,
-                                                       char* __restrict__ X, char* __restrict__ Y, double* __restrict__ nrm2,
+                                                       char* __restrict__ X, double* __restrict__ nrm2,
                                                        double* __restrict__ nu2, double* __restrict__ proj,
                                                        unsigned long long* __restrict__ rowhash, long long g0, int P, int fpu,
                                                        int* __restrict__ nbp) {
@@ -484,10 +504,6 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
     const double* x = desc + (row_ok ? r : 0) * H;
     const bool vec = (H & 1) == 0 && ((unsigned long long)desc & 15) == 0 && ((unsigned long long)score & 15) == 0;
     char* xg = X + g * (3ll * nks * 1024) + lane * 16;
-    // the column panel (Y, may be null): row r = patch pp of frame f sits at row (f / fpu) * 64 + (f % fpu) * P + pp
-    long long prow = 0;
-    if (QUANT && Y) { const long long f = r / P; prow = (f / fpu) * 64 + (f % fpu) * P + (r - f * P); }
-    char* yg = Y + (prow >> 4) * (3ll * nks * 1024) + (chunk * 16 + (int)(prow & 15)) * 16;
     double n2 = 0.0, pr = 0.0, su = 0.0, s2 = 0.0;
     for (int ks = w; ks < nks; ks += 4) {
         const int k0 = ks * 64 + chunk * 16;
@@ -529,11 +545,6 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
             *(uint4*)(xg + (0ll * nks + ks) * 1024) = v1;
             *(uint4*)(xg + (1ll * nks + ks) * 1024) = v2;
             *(uint4*)(xg + (2ll * nks + ks) * 1024) = v3;
-            if (Y && row_ok) {                  // (its padding rows are zeros: the caller clears the panel)
-                *(uint4*)(yg + (0ll * nks + ks) * 1024) = v1;
-                *(uint4*)(yg + (1ll * nks + ks) * 1024) = v2;
-                *(uint4*)(yg + (2ll * nks + ks) * 1024) = v3;
-            }
         }
     }
     for (int o = 16; o <= 32; o <<= 1) {
@@ -599,10 +610,10 @@ size_t sim_filter_panel_bytes(int64_t rows, int64_t H) {
     return (size_t)sim_panel_rows(rows) * 3 * kp;
 }
 
-// The column panel: units of 64 rows = fpu = 64 / P whole frames + zero rows; whole tiles of two units.
+// The column side of the products: units of 64 columns = fpu = 64 / P whole frames + zero rows; whole tiles of two units.
 int sim_frames_per_unit(int64_t P) { return (int)(64 / P); }
 static int64_t sim_col_tiles(int64_t N, int64_t P) { return dlc::cdiv(dlc::cdiv(N, (int64_t)sim_frames_per_unit(P)), (int64_t)2); }
-int64_t sim_col_rows(int64_t N, int64_t P) { return sim_col_tiles(N, P) * GI_T; }                      // rows of Y, entries of nbp
+int64_t sim_col_rows(int64_t N, int64_t P) { return sim_col_tiles(N, P) * GI_T; }                      // columns in unit layout: entries of nbp
 int64_t sim_col_frames(int64_t N, int64_t P) { return sim_col_tiles(N, P) * 2 * sim_frames_per_unit(P); }
 int64_t sim_argmin_pitch(int64_t N, int64_t P) { return (int64_t)dlc::align_up((size_t)(N * P), 64); }   // nfp: frames per row of abi / acand
 // the block table of gram_argmin_i8 (`blocks`)
@@ -611,15 +622,13 @@ size_t gram_blocks_bytes(int64_t N, int64_t P) {
     const size_t nsm = (tiles_m + GI_BR - 1) / GI_BR, nsn = (tiles_n + GI_BC - 1) / GI_BC;
     return dlc::align_up(nsm + 1, 2) * 4 + nsm * nsn * 8;
 }
-size_t sim_filter_colpanel_bytes(int64_t N, int64_t P, int64_t H) {
-    const size_t kp = dlc::align_up((size_t)H, (size_t)GI_KPAD);
-    return (size_t)sim_col_rows(N, P) * 3 * kp;
-}
+// the product kernel's column lanes address the panel with 32-bit offsets
+bool sim_filter_fits(int64_t N, int64_t P, int64_t H) { return sim_filter_panel_bytes(N * P, H) < (1ull << 32); }
 
 // keys[6]: min key, max key, non-finite flag, max row sum key, direct evaluations (a count), length of prog (up to
-// 1023 int2 entries for H <= 32768).  X: sim_filter_panel_bytes; Y: sim_filter_colpanel_bytes; nbp: sim_col_rows ints.
+// 1023 int2 entries for H <= 32768).  X: sim_filter_panel_bytes (its rows behind the last patch are zeros); nbp: sim_col_rows ints.
 int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H, const double* score,
-                       unsigned long long* keys, char* X, char* Y, int* nbp, double* nu2, double* proj,
+                       unsigned long long* keys, char* X, int* nbp, double* nu2, double* proj,
                        unsigned long long* rowhash, void* prog, const unsigned long long* range, hipStream_t st) {
     const int64_t rows = N * P;
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
@@ -627,10 +636,9 @@ int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, i
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
     if (!range) hipLaunchKernelGGL(sim_range_kernel, dim3(2048), dim3(256), 0, st, desc, (long long)(rows * H), keys);
     DLC_LAUNCH_CHECK(ctx, "sim_range_kernel");
-    DLC_HIP_CHECK(ctx, hipMemsetAsync(Y, 0, sim_filter_colpanel_bytes(N, P, H), st));        // the units' padding rows
     DLC_HIP_CHECK(ctx, hipMemsetAsync(nbp, 0, (size_t)sim_col_rows(N, P) * 4, st));
     hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(256), 0, st, desc, (long long)rows,
-                       (int)H, kp, score, keys, X, Y, (double*)nullptr, nu2, proj, rowhash, 0ll, (int)P, sim_frames_per_unit(P), nbp);
+                       (int)H, kp, score, keys, X, (double*)nullptr, nu2, proj, rowhash, 0ll, (int)P, sim_frames_per_unit(P), nbp);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
@@ -656,7 +664,7 @@ int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, in
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     if (g_count < 1) return DLC_OK;
     hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)g_count), dim3(256), 0, st, desc, (long long)rows_total, (int)H, kp, score,
-                       keys, X, (char*)nullptr, (double*)nullptr, nu2, proj, rowhash, (long long)g_first, 1, 1, (int*)nullptr);
+                       keys, X, (double*)nullptr, nu2, proj, rowhash, (long long)g_first, 1, 1, (int*)nullptr);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
@@ -675,7 +683,7 @@ int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, cons
                  unsigned long long* rowhash, void* prog, unsigned long long* prog_len, hipStream_t st) {
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, prog_len);
     hipLaunchKernelGGL(sim_rows_kernel<false>, dim3((unsigned)dlc::cdiv(rows, (int64_t)16)), dim3(256), 0, st, desc, (long long)rows,
-                       (int)H, 0, score, (unsigned long long*)nullptr, (char*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj,
+                       (int)H, 0, score, (unsigned long long*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj,
                        rowhash, 0ll, 1, 1, (int*)nullptr);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
@@ -683,12 +691,12 @@ int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, cons
 
 // The patch arg-min of every (row patch a, column frame j) with frame(a) < j, for all N frames at once: abi / acand are
 // [sim_col_frames(N, P), sim_argmin_pitch(N, P)] (bytes / 32-bit words); entries with frame(a) >= j are not written.
-int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const char* Y, const int* nbp,
+int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const int* nbp,
                    const unsigned long long* keys, unsigned char* abi, unsigned* acand, void* blocks, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     GramI8Args a;
     a.gpitch = 3ll * kp * 16; a.kp = kp; a.H = (int)H; a.P = (int)P; a.fpu = sim_frames_per_unit(P);
-    a.X = X; a.Y = Y; a.nbp = nbp; a.keys = keys; a.abi = abi; a.acand = acand;
+    a.X = X; a.zrow = (int64_t)dlc::align_up((size_t)(N * P), 16); a.nbp = nbp; a.keys = keys; a.abi = abi; a.acand = acand;
     a.nfp = sim_col_frames(N, P); a.rp = sim_argmin_pitch(N, P); a.nrows = N * P; a.nframes = N;
     a.tiles_m = (int)dlc::cdiv((N - 1) * P, (int64_t)GI_T);              // the last frame's patches have no later frame
     a.tiles_n = (int)sim_col_tiles(N, P);

@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const unsigned long lon
 }
 
 struct SimWs {
-    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, qy, nbp, abi, acand, blk, total;
+    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, nbp, abi, acand, blk, total;
     long long chunk_frames, nfp;
 };
 
@@ -937,6 +937,11 @@ struct SimWs {
 bool sim_use_filter(int64_t P, int64_t H, int flags) {
     if (flags & DLC_SIM_FORCE_F64) return false;
     return P <= 32 && H <= 32768;
+}
+// ... and, for the all-vs-all matrix, the fixed-point panel stays under 4 GiB (the product kernel's column lanes address
+// it with 32-bit offsets: 559 000 patches at H = 2500)
+bool sim_use_filter(int64_t N, int64_t P, int64_t H, int flags) {
+    return sim_use_filter(P, H, flags) && dlc_gemm::sim_filter_fits(N, P, H);
 }
 
 long long sim_chunk(int64_t N, int64_t P, size_t row_bytes, int64_t chunk_bytes) {
@@ -962,7 +967,7 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     size_t o = 0;
     w.nrm2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
     w.proj = o; o += dlc::align_up((size_t)N * P * 8, 256);
-    const bool filter = sim_use_filter(P, H, flags);
+    const bool filter = sim_use_filter(N, P, H, flags);
     const size_t row_bytes = (size_t)N * P * 8;
     w.chunk_frames = sim_chunk(N, P, row_bytes, chunk_bytes);
     // (the filter's workspace keeps a small fp64 Gram region -- up to 64 frames' rows: a dataset with a NaN / infinity in
@@ -977,15 +982,14 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     const size_t prog_bytes = dlc_gemm::sim_pairwise_program_bytes(H);
     w.prog = o; o += prog_bytes > 8192 ? prog_bytes : 8192;
     w.rowhash = o; o += dlc::align_up((size_t)N * P * 16, 256);
-    w.nu2 = w.qx = w.qy = w.nbp = w.abi = w.acand = w.blk = 0;
+    w.nu2 = w.qx = w.nbp = w.abi = w.acand = w.blk = 0;
     w.nfp = 0;
     if (filter) {
-        // the two fixed-point panels (rows in order; columns in units of whole frames), |u|^2, and the product kernel's
+        // the fixed-point panel (row operands as it lies, column operands gathered from it in units of whole frames), |u|^2, and the product kernel's
         // verdicts: nearest patch + undecided set per (row patch, later frame) -- 5 bytes where r02 kept 120 of products
         w.nfp = dlc_gemm::sim_col_frames(N, P);
         w.nu2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
         w.qx = o; o += dlc::align_up(dlc_gemm::sim_filter_panel_bytes(N * P, H), 256);
-        w.qy = o; o += dlc::align_up(dlc_gemm::sim_filter_colpanel_bytes(N, P, H), 256);
         w.nbp = o; o += dlc::align_up((size_t)dlc_gemm::sim_col_rows(N, P) * 4, 256);
         const size_t rp = (size_t)dlc_gemm::sim_argmin_pitch(N, P);
         w.abi = o; o += dlc::align_up(rp * w.nfp, 256);
@@ -1074,7 +1078,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
     double* proj = (double*)(ws + w.proj);
     double* gram = (double*)(ws + w.gram);
     const long long rows = N * P;
-    bool filter = sim_use_filter(P, H, flags);
+    bool filter = sim_use_filter(N, P, H, flags);
     if (!filter && stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
     if (direct_pairs) DLC_HIP_CHECK(ctx, hipMemsetAsync(direct_pairs, 0, (size_t)N * (size_t)N, st));
 
@@ -1086,13 +1090,12 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         unsigned long long* keys = (unsigned long long*)(ws + w.keys);
         double* nu2 = (double*)(ws + w.nu2);
         char* qx = ws + w.qx;
-        char* qy = ws + w.qy;
         int* nbp = (int*)(ws + w.nbp);
         unsigned char* abi = (unsigned char*)(ws + w.abi);
         unsigned* acand = (unsigned*)(ws + w.acand);
         int2* prog = (int2*)(ws + w.prog);
         unsigned long long* rowhash = (unsigned long long*)(ws + w.rowhash);
-        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, N, P, H, score, keys, qx, qy, nbp, nu2, proj, rowhash, prog,
+        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, N, P, H, score, keys, qx, nbp, nu2, proj, rowhash, prog,
                                               (const unsigned long long*)range, st);
         if (rc != DLC_OK) return rc;
         // did the range pass meet a NaN or an infinity?  (Their distances are NaN in the reference too, np.argmin then
@@ -1110,7 +1113,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         if (N > 1) {
             // all frames in ONE launch: the product kernel keeps its 31 890 x 31 890 products on the chip and emits
             // the arg-mins (r02: row chunks of an 8 GiB int32 block)
-            rc = dlc_gemm::gram_argmin_i8(ctx, N, P, H, qx, qy, nbp, keys, abi, acand, ws + w.blk, st);
+            rc = dlc_gemm::gram_argmin_i8(ctx, N, P, H, qx, nbp, keys, abi, acand, ws + w.blk, st);
             if (rc != DLC_OK) return rc;
             hipLaunchKernelGGL(pair_score_amin_kernel, dim3(PS_GX, (unsigned)(N - 1)), dim3(256), PF_STACK_BYTES, st, desc,
                                (const unsigned char*)abi, (const unsigned*)acand, (long long)dlc_gemm::sim_argmin_pitch(N, P), proj, score, keys,
@@ -1137,7 +1140,7 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
     }
     long long chunk_frames = w.chunk_frames;
     bool use_t = (rows & 1) == 0;
-    if (sim_use_filter(P, H, flags)) {           // the filter's workspace: no transposed copy, the chunk that fits its Gram region
+    if (sim_use_filter(N, P, H, flags)) {        // the filter's workspace: no transposed copy, the chunk that fits its Gram region
         use_t = false;
         chunk_frames = (long long)(w.gram_bytes / ((size_t)P * rows * 8));
     }

@@ -27,7 +27,7 @@ BAR='        __builtin_amdgcn_s_barrier();                                      
 NODMA="('if (ISSUE) issue_piece((B0) + (J));', ''), ('if (ISSUE) issue_done();', '')"
 NOLDS="('#define GI_RD(DST, PTR) { __builtin_amdgcn_sched_barrier(0); DST = *(const v4i*)(PTR); __builtin_amdgcn_sched_barrier(0); }', '#define GI_RD(DST, PTR) {}')"
 NOBAR="('''$BAR''', '        \\\\')"
-L2FED="('const char* panel = b < 6 ? p.X + (m0 / 16) * p.gpitch : p.Y + (n0 / 16) * p.gpitch;', 'const char* panel = b < 6 ? p.X : p.Y;')"
+L2FED="('src[b] = uniform_ptr(p.X + (m0 / 16) * p.gpitch + (long long)(w * 2 + b / 3) * p.gpitch + (long long)(b % 3) * n64 * 1024);', 'src[b] = uniform_ptr(p.X + (long long)(w * 2 + b / 3) * p.gpitch + (long long)(b % 3) * n64 * 1024);'), ('const long long c = n0 + (w * 2 + gi) * 16 + (lane & 15);', 'const long long c = (w * 2 + gi) * 16 + (lane & 15);')"
 # s_memtime stamps summed over the tiles (cycles per tile on stderr after every launch); the check of the object code does
 # not apply to patched copies (they are built without `make`)
 PROF="('__global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {', '__device__ unsigned long long gi_prof[8];\n__global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {\n    const unsigned long long TS = __builtin_amdgcn_s_memtime();'), \
