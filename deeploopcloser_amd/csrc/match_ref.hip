@@ -227,6 +227,31 @@ __device__ __forceinline__ double gram_window(int H, double na, double nb, doubl
     return 4.1 * (double)H * 0x1p-53 * (na + nb) + best * 0x1p-49;
 }
 
+// |x_c - x_a|^2 of NB candidate rows in ONE pass over k, all 64 lanes: per candidate the fma chain of a lane (k = lane,
+// lane + 64, ..) and the xor tree are the same whatever NB is.  frac: some difference is not an integer below 2^18.
+template <int NB>
+__device__ __forceinline__ void direct_pass(const double* __restrict__ xa, const double* const (&xs)[4], int H, int lane,
+                                            double (&ss)[4], bool& frac) {
+    double s_[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) s_[c] = 0.0;
+#pragma unroll 4
+    for (int k = lane; k < H; k += 64) {
+        const double av = xa[k];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const double d = xs[c][k] - av;
+            s_[c] = fma(d, d, s_[c]);
+            frac |= !(d == rint(d) && fabs(d) < 262144.0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        for (int o = 32; o > 0; o >>= 1) s_[c] += __shfl_xor(s_[c], o);
+        ss[c] = s_[c];
+    }
+}
+
 // The arg-min of |x_b - x_a| over the candidate patches b of one frame (bit b of cm), decided as the reference decides
 // it (SimilarityCalculator.py:30-37: np.argmin of np.linalg.norm, first minimum) when products of the descriptors -- the
 // filter's integers or the fp64 Gram matrix -- cannot tell the candidates apart.  Called by a whole wave (uniform
@@ -240,19 +265,29 @@ __device__ __forceinline__ int direct_argmin_wave(const double* __restrict__ xa,
     // candidate b's
     double mine = INFINITY, emin = INFINITY;
     bool frac = false;                                  // some difference is not an integer below 2^18
-    for (int b = 0; b < P; ++b) {
-        if (!((cm >> b) & 1)) continue;
-        const double* xb = xj + (long long)b * H;
-        double s_ = 0.0;
-#pragma unroll 8
-        for (int k = lane; k < H; k += 64) {
-            const double d = xb[k] - xa[k];
-            s_ = fma(d, d, s_);
-            frac |= !(d == rint(d) && fabs(d) < 262144.0);
+    // (four candidates per pass over k -- a candidate's sum is the same fma chain per lane and the same xor tree as if it
+    // went alone, but the passes' memory round trips are shared: an undecided arg-min has two or three candidates, and one
+    // pass each made a direct evaluation 15-25 us on its one wave, the tail of the pair kernels and of the streaming query)
+    for (unsigned long long rest = cm & (P >= 64 ? ~0ull : (1ull << P) - 1ull); rest;) {
+        int bs[4];
+        int nb = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bs[c] = bs[0];
+            if (rest) { bs[c] = __ffsll((long long)rest) - 1; rest &= rest - 1; nb = c + 1; }
         }
-        for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
-        if (lane == b) mine = s_;
-        emin = fmin(emin, s_);
+        const double* xs[4] = {xj + (long long)bs[0] * H, xj + (long long)bs[1] * H, xj + (long long)bs[2] * H, xj + (long long)bs[3] * H};
+        double ss[4] = {0.0, 0.0, 0.0, 0.0};
+        if (nb == 1) direct_pass<1>(xa, xs, H, lane, ss, frac);
+        else if (nb == 2) direct_pass<2>(xa, xs, H, lane, ss, frac);
+        else if (nb == 3) direct_pass<3>(xa, xs, H, lane, ss, frac);
+        else direct_pass<4>(xa, xs, H, lane, ss, frac);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < nb) {
+                if (lane == bs[c]) mine = ss[c];
+                emin = fmin(emin, ss[c]);
+            }
     }
     // (only the candidates take part: the other lanes hold +inf, which would pass the test when every candidate's
     // squared distance overflows -- finite descriptors ~1e154 apart -- and send stages 1b / 2 to rows past the frame;
