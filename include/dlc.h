@@ -22,7 +22,8 @@
  *   - matrices are row-major with explicit leading dimensions in ELEMENTS;
  *   - return value: DLC_OK (0) or a negative dlc_status; dlc_last_error()
  *     returns a human-readable message for the last failure on that context.
- *   - a context is bound to one device; use one context per GPU / rank.
+ *   - a context is bound to one device; use one context per GPU / rank, and one host thread per context at a time
+ *     (the profiling ring, the staging ring and the similarity call's flag word live in it).
  */
 #ifndef DLC_H_
 #define DLC_H_
