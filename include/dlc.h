@@ -279,7 +279,9 @@ int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows
  *   DLC_SIM_FORCE_F64     the fp64 Gram form whatever the shape (same matrix; checker / experiments);
  *   DLC_SIM_NO_HOST_SYNC  the filter form reads ONE 8-byte flag back to the host (did the range pass
  *                         meet a NaN / infinity? -- it then has to take the fp64 form): the only
- *                         blocking read of this library's stream-ordered calls.  With this flag the
+ *                         blocking read of this library's stream-ordered calls (the host waits for that
+ *                         copy alone, with the filter form's kernels already enqueued behind it: the call
+ *                         returns when the quantisation pass is done).  With this flag the
  *                         call never synchronises (and can be captured in a hipGraph); on a dataset
  *                         with a NaN / infinity the matrix then comes back as NaN / INT64_MIN and
  *                         stats[1] = 1, and the caller repeats the call with DLC_SIM_FORCE_F64.
