@@ -294,7 +294,7 @@ int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows
  * directly in fp64), [1] 1 when the dataset held a NaN / infinity.  direct_pairs (DEVICE, [N,N]
  * bytes, may be NULL): 1 at [i, j], i < j, when at least one arg-min of that frame pair was evaluated
  * directly (the pairs a checker wants to look at first), 0 elsewhere.
- * The workspace holds the quantised descriptors and the product kernel's verdicts (filter form: 1.2 GB
+ * The workspace holds the quantised descriptors and the product kernel's verdicts (filter form: 0.91 GB
  * at the reference's 1063 frames) or the descriptors' fp64 transpose and the fp64 Gram blocks (8.7 GB
  * there, below 9.5 GB + N*P*H*8 bytes for any N).
  */
