@@ -19,8 +19,8 @@
 //
 // Layout: one panel, X = (q1 | q2 | q3) along K (Kp = H rounded up to 256, zero padded), tiled the way the MFMA reads
 // it: [16-row group][k-step of 64 bytes: slice-major, 3 Kp / 64 of them][lane l: row l % 16, bytes (l / 16) * 16 .. + 15] --
-// every LDS-DMA piece is 1 KiB of consecutive bytes, eight whole cache lines.  Row patches and column patches are groups
-// of the same panel.  (Row-major slices made each piece 16 half lines; every line crossed the L2 -> L1 path twice, once
+// every row-side LDS-DMA piece is 1 KiB of consecutive bytes, eight whole cache lines.  Row patches and column patches are
+// rows of the same panel: a column-side piece gathers 16 consecutive rows that may begin inside a group (GramI8Args).  (Row-major slices made each piece 16 half lines; every line crossed the L2 -> L1 path twice, once
 // per k-step, and the kernel sat at 12 B / clock / CU.)
 //
 // r03: ONE sweep over K with three accumulator sets.  A k-step brings the 64 bytes of all three slices of the tile's rows
@@ -63,12 +63,6 @@ struct GramI8Args {
     const int2* blk;                                // [nsup] (block row, block column) of the wanted blocks, row by row
 };
 
-// (best, index of the FIRST minimum, runner-up) of two disjoint candidate sets
-__device__ __forceinline__ void gi_merge(int& best, int& bidx, int& second, int ob, int oi, int os) {
-    const bool take = ob < best || (ob == best && oi < bidx);
-    const int lose = take ? best : ob;
-    second = min(min(second, os), lose);
-    if (take) { best = ob; bidx = oi; }
 }
 
 // The triangle's wanted blocks.  Block row si (GI_BR tiles of rows) wants the block columns from the one that holds the
