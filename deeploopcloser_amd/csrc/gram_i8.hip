@@ -63,8 +63,6 @@ struct GramI8Args {
     const int2* blk;                                // [nsup] (block row, block column) of the wanted blocks, row by row
 };
 
-}
-
 // The triangle's wanted blocks.  Block row si (GI_BR tiles of rows) wants the block columns from the one that holds the
 // column tile of frame (first row frame of the block row) + 1 -- a unit holds fpu frames, a tile two units.
 __host__ __device__ inline int gi_first_block_col(int si, int P, int fpu) {
