@@ -44,5 +44,8 @@ build nobarrier "[$NOBAR]" &
 build nolds "[$NOLDS]" &
 build l2fed "[$L2FED]" &
 wait
+NOSTORE="('        p.abi[fj * p.rp + a] = (unsigned char)bi;', '        if (bi == 77) p.abi[fj * p.rp + a] = (unsigned char)bi;'), ('        p.acand[fj * p.rp + a] = cand;', '        if (bi == 77) p.acand[fj * p.rp + a] = cand;')"
+build nostore "[$NOSTORE]" &
 build mfma_only "[$NODMA, $NOLDS, $NOBAR]"
+wait
 rm -rf $T
