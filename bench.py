@@ -365,9 +365,14 @@ def bench_paths(eng, n_frames):
         score, rng = eng.distinctive_score(desc, 0.5, 0.2, with_range=True)
         return eng.sdav_similarity_matrix(desc, score, 10.0, -10.0, range=rng)
     call_ms, k_ms, k_n, (mf, mi) = _timed_path(eng, sim, reps=4)
+
+    def sim_direct(d_):                                            # [arg-mins evaluated directly, why the fp64 form ran (0: it did not)]
+        st_ = torch.zeros((2,), dtype=torch.int64, device=eng.device)
+        eng.sdav_similarity_matrix(d_, eng.distinctive_score(d_, 0.5, 0.2), 10.0, -10.0, stats=st_)
+        return [int(v) for v in st_.tolist()]
     # The patch products the similarity needs: row patches of frame i against the patches of every LATER frame j (the
     # upper triangle; gram_i8_kernel launches the tiles that hold such a pair and decides the patch arg-min in its
-    # epilogue) -- six int8 products of length H per patch pair (csrc/gram_i8.hip: the 21-bit fixed-point slices' classes
+    # epilogue) -- six int8 products of length H per patch pair (csrc/gram_i8.hip: the 24-bit fixed-point digits' classes
     # 2, 3 and 4).  Padding (K to 2560, whole-frame column units, diagonal tiles) is the kernel's cost, not counted here.
     patch_pairs = (N * (N - 1) / 2.0) * P * P
     i8_ops = 6 * 2.0 * patch_pairs * H
@@ -398,7 +403,7 @@ def bench_paths(eng, n_frames):
                 "value": pairs / (call_ms * 1e-3), "unit": "frame-pairs/s", "ms": call_ms,
                 "roofline": {"bound": "mfma", "achieved": i8_ops / (k_ms * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
                              "frac": i8_ops / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": None,
-                             "kernel": "gram_i8_kernel (exact int8 products of the descriptors' 21-bit fixed-point slices, "
+                             "kernel": "gram_i8_kernel (exact int8 products of the column-centred descriptors' 24-bit fixed-point digits, "
                                        "wanted tiles only; its epilogue decides the patch arg-min, undecided ones are evaluated directly in fp64)",
                              "kernel_ms": k_ms, "kernel_launches_timed": k_n, "call_ms": call_ms,
                              "algorithmic_ops_per_call": i8_ops,
@@ -415,6 +420,40 @@ def bench_paths(eng, n_frames):
                         "(DESIGN.md 4.4; DLC_SIM_FORCE_F64 in the call's flags runs the fp64 Gram form: the same matrix, 38.9 ms)",
                 "max_rel_err_vs_oracle": err})
     del mf, mi, sub, ref, dsn
+    out[-1]["direct_evaluations"] = sim_direct(desc)[0]
+
+    # ---- M1/M2 on real-image statistics: the repo's 20 real frames (tests/golden) tiled to N, through the GPU front-end and
+    # SDAV.transform with the reference's N(0,1) initialiser (real images saturate it) and with 1/sqrt(fan_in) weights
+    # (every descriptor column within 1e-3 of its own mean, the means spread over [0.15, 0.88]: low contrast) -------------
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import real_frames
+    xr = real_frames.tiled_patches(dlc, N)
+    for scale, label in (("reference", "N(0,1) weights"), ("fan_in", "1/sqrt(fan_in) weights")):
+        dr = dlc.SDAV(seed=4, weight_scale=scale).transform_tensor(xr).reshape(N, P, H)
+
+        def sim_r():
+            score, rng = eng.distinctive_score(dr, 0.5, 0.2, with_range=True)
+            return eng.sdav_similarity_matrix(dr, score, 10.0, -10.0, range=rng)
+        r_ms, rk_ms, rk_n, (rf, ri) = _timed_path(eng, sim_r, reps=4)
+        rf, ri = rf.clone(), ri.clone()
+        direct, why = sim_direct(dr)
+        f64_ms, _, _, (ff, fi) = _timed_path(eng, lambda: eng.sdav_similarity_matrix(dr, eng.distinctive_score(dr, 0.5, 0.2), 10.0, -10.0,
+                                                                                      force_f64=True), reps=2)
+        same = bool(torch.equal(torch.nan_to_num(rf, posinf=1e300), torch.nan_to_num(ff, posinf=1e300)) and torch.equal(ri, fi))
+        out.append({"path": "SDAV similarity matrix, real-frame statistics, " + label,
+                    "reference": "src/sdav/similarity/SimilarityCalculator.py:12-49, src/sdav/create_similarity_matrix.py:23-38",
+                    "frames": N, "dtype": "f64", "value": pairs / (r_ms * 1e-3), "unit": "frame-pairs/s", "ms": r_ms,
+                    "data": "tests/golden: the reference's 20 datasets/test frames tiled to %d (exact copies, copies with pixels "
+                            "moved by 1/255, blank and repeated patches), GPU front-end + SDAV.transform" % N,
+                    "stats": [direct, why], "direct_evaluations": direct, "arg_mins": pairs * P,
+                    "filter_took_the_call": why == 0, "fp64_route_ms": f64_ms, "equals_fp64_route_bit_for_bit": same,
+                    "roofline": {"bound": "mfma", "achieved": i8_ops / (rk_ms * 1e-3) / 1e12 if rk_ms else None, "peak": MFMA_I8_PEAK_TOPS,
+                                 "unit": "TOP/s", "frac": i8_ops / (rk_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS if rk_ms else None,
+                                 "traffic": None, "kernel": "gram_i8_kernel", "kernel_ms": rk_ms, "kernel_launches_timed": rk_n,
+                                 "call_ms": r_ms, "algorithmic_ops_per_call": i8_ops},
+                    "cpu_baseline": None})
+        del dr, rf, ri, ff, fi
+    del xr
 
     # ---- M5 at configs[1]: cosine matrix and top-20 over the flattened 75 000-d SDAV place descriptors --------
     db = dlc.KeyframeDatabase(h.reshape(N, P * H), dtype="bf16", center=True)

@@ -16,7 +16,7 @@ DLC_BF16, DLC_F16, DLC_F32, DLC_F64, DLC_I8 = 0, 1, 2, 3, 4
 DLC_ACT_NONE, DLC_ACT_SIGMOID, DLC_ACT_RELU = 0, 1, 2
 DLC_B_KN, DLC_B_NK = 0, 1
 DLC_MAX_K = 128
-DLC_ABI_VERSION = 5          # include/dlc.h; load() refuses a library built from another header
+DLC_ABI_VERSION = 6          # include/dlc.h; load() refuses a library built from another header
 DLC_SELECT_COOP = 1
 DLC_SIM_FORCE_F64, DLC_SIM_NO_HOST_SYNC = 1, 2
 
@@ -52,12 +52,13 @@ SIGNATURES = {
     "dlc_conv2d_nhwc_f64_stats": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp, _int, _int, _int, _int, _int, _int, _int,
                                          _int, _int, _vp, _vp, _vp]),
     "dlc_quant_gather_i8": (_int, [_vp, C.POINTER(_vp), C.POINTER(_i64), _int, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "dlc_sdav_range_words": (_sz, [_i64]),
     "dlc_sdav_distinctive_score": (_int, [_vp, _vp, _i64, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "dlc_sdav_similarity_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _i64]),
     "dlc_sdav_similarity_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _int, _i64, _vp, _vp, _vp,
                                          _vp, _sz, _vp]),
     "dlc_sdav_stream_state_bytes": (_sz, [_i64, _i64, _i64]),
-    "dlc_sdav_stream_init": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _dbl, _dbl, _vp]),
+    "dlc_sdav_stream_init": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _dbl, _dbl, _vp, _vp]),
     "dlc_sdav_stream_append": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     "dlc_sdav_stream_query": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _vp, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp]),
     "dlc_cnnvtl_distance_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),

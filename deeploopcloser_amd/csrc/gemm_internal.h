@@ -35,29 +35,41 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
 int gemm_bias_act_padded_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, int64_t Kpad, const double* A,
                              const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st);
 
-// The SDAV similarity's arg-min filter (gram_i8.hip): descriptors as three 7-bit fixed-point slices, their exact integer
-// products, and the bound of what the truncation misses.
+// The SDAV similarity's arg-min filter (gram_i8.hip): descriptors as three signed fixed-point digits of their offset from
+// the column's centre, their exact integer products, and the bound of what the rounding misses.
+constexpr int DLC_SIM_KEYS = 8;        // words of a call's `keys` (gram_i8.hip: sim_filter_prepare)
 size_t sim_filter_panel_bytes(int64_t rows, int64_t H);
+size_t sim_range_words(int64_t H);
 int sim_frames_per_unit(int64_t P);
 int64_t sim_col_rows(int64_t N, int64_t P);
 int64_t sim_col_frames(int64_t N, int64_t P);
 int64_t sim_argmin_pitch(int64_t N, int64_t P);
 bool sim_filter_fits(int64_t N, int64_t P, int64_t H);
 int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H, const double* score,
-                       unsigned long long* keys, char* X, int* nbp, double* nu2, double* proj,
-                       unsigned long long* rowhash, void* prog, const unsigned long long* range, hipStream_t st);
+                       unsigned long long* keys, double* cc, unsigned long long* ws_range, char* X, int* nbp, double* nu2,
+                       double* proj, unsigned long long* rowhash, void* prog, const unsigned long long* range, hipStream_t st);
 size_t sim_pairwise_program_bytes(int64_t H);
 int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
                  unsigned long long* rowhash, void* prog, unsigned long long* prog_len, hipStream_t st);
 // the streaming form: a resident append-only panel quantised over a fixed range (match_ref.hip: dlc_sdav_stream_*)
-int sim_stream_init(dlc_ctx* ctx, unsigned long long* keys, void* prog, int64_t H, double lo, double hi, hipStream_t st);
+int sim_stream_init(dlc_ctx* ctx, unsigned long long* keys, double* cc, void* prog, int64_t H, double lo, double hi,
+                    const double* centre, hipStream_t st);
 int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, int64_t H, const double* score,
-                        unsigned long long* keys, char* X, double* nu2, double* proj, unsigned long long* rowhash,
-                        int64_t g_first, int64_t g_count, hipStream_t st);
+                        unsigned long long* keys, const double* cc, char* X, double* nu2, double* proj,
+                        unsigned long long* rowhash, int64_t g_first, int64_t g_count, hipStream_t st);
 size_t sim_stream_panel_bytes(int64_t rows, int64_t H);
 int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const int* nbp,
                    const unsigned long long* keys, unsigned char* abi, unsigned* acand, void* blocks, hipStream_t st);
 size_t gram_blocks_bytes(int64_t N, int64_t P);
+
+// How far apart two d2 = |v_b|^2 - 2 v_a . v_b of the filter (units of 2^-15, gram_i8.hip's header) must be before their
+// order is the order of the true distances: twice the bound of one d2's error, + 1e-8 for the fp64 roundings of v and of
+// |v|^2, rounded up, + 2.  keys[3]: the ordered key of the largest row sum of |v|.
+__device__ __forceinline__ long long dlc_sim_window(const unsigned long long* __restrict__ keys, int H) {
+    const double sv = dlc_f64_unkey(keys[3]);
+    const double ed = 0x1p-23 * sv + (double)H * (0x1p-24 + 0x1p-33 + 0x1p-46) + 1.004 * 0x1p-15 + 0x1p-16;
+    return (long long)ceil((2.0 * ed + 1e-8) * 32768.0) + 2;
+}
 
 }  // namespace dlc_gemm
 

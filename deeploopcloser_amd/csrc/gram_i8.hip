@@ -4,29 +4,37 @@
 // patch b of frame j is nearest (np.argmin of the norms).  The distances themselves never reach the result.  So the
 // Gram matrix does not have to be an fp64 product -- it has to decide the arg-min, and say when it cannot:
 //
-//   u = (x - lo) / (hi - lo) in [0, 1]   (lo / hi: the dataset's extremes; arg-min of |u_a - u_b| = arg-min of |x_a - x_b|)
-//   q = floor(u * 2^21) as three 7-bit slices q1 q2 q3 (non-negative int8)
-//   acc = C2 + floor((C3 + floor(C4 / 128)) / 128),  Cc = sum over s + t = c of q_s . q_t    (v_mfma_i32_16x16x64_i8: exact)
+//   v_k = (x_k - c_k) * 0.996 / s in [-0.498, 0.498]   c_k: the midpoint of COLUMN k's extremes over the dataset, s: the
+//         largest column range.  |x_a - x_b| does not change under a per-column offset, so arg-min |v_a - v_b| = arg-min
+//         |x_a - x_b|, and the fixed-point bits go where the data varies.  (r03 spent them on (x - lo) / (hi - lo) of the
+//         WHOLE dataset: low-contrast descriptors -- every column within 1e-3 of its own mean, the means spread over
+//         [0.15, 0.88]: real frames through 1/sqrt(fan_in) weights -- had every one of their arg-mins inside the error
+//         window.)
+//   q = rint(v * 2^24) as three SIGNED 8-bit digits, q = s1 2^16 + s2 2^8 + s3, s_i in [-128, 127]
+//   acc = C2 + floor((C3 + floor(C4 / 256)) / 256),  Cc = sum over i + j = c of s_i . s_j'   (v_mfma_i32_16x16x64_i8: exact)
 //
-// acc * 2^-14 is a LOWER bound of u_a . u_b that misses at most
-//   E = 2^-21 (sum u_a + sum u_b)  [truncation of u]  +  H * 127^2 * (2^-34 + 2^-42)  [the dropped classes 5 and 6]  +  2^-13,
-// a rigorous bound with no rounding in it (integer accumulation).  The pair kernel takes the arg-min of
-// |u_b|^2 - 2 acc 2^-14 and accepts it when the runner-up is more than 2 E away; otherwise it evaluates the candidates
-// inside that window directly in fp64 from the descriptors, near-ties in NumPy's own summation order (match_ref.hip).
+// acc 2^-15 is 2 v_a . v_b to within
+//   2^-24 (sum |v_a| + sum |v_b|) + H 2^-46  [rounding of v]  +  H (2^-24 + 2^-33)  [the dropped classes s2 s3', s3 s3']
+//   + 1.004 2^-15  [the two floors],
+// a rigorous bound with no rounding in it (integer accumulation).  The product kernel takes the arg-min of
+// d2 = |v_b|^2 - acc 2^-15 (units of 2^-15; |v_b|^2 rounded to them: 2^-16 more) and accepts it when the runner-up is
+// more than twice that bound away (dlc_sim_window, gemm_internal.h); otherwise it leaves the candidates inside the window
+// to be evaluated directly in fp64 from the descriptors, near-ties in NumPy's own summation order (match_ref.hip).
+// Signed digits and the midpoint offset carry 24 bits in the three bytes r03 carried 21 in: the window is 6.8e-4 of the
+// unit square distance at H = 2500 where r03's was 7.4e-3.
 // Six int8 products of K = H replace one fp64 product: a sixth of its time as measured (6 ms against 36.5 at 1063
 // frames), and the result is the arg-min of the true distances either way.
 // Test infrastructure never enters: the oracle (oracle/similarity.py) only checks the outcome in tests/.
 //
-// Layout: one panel, X = (q1 | q2 | q3) along K (Kp = H rounded up to 256, zero padded), tiled the way the MFMA reads
+// Layout: one panel, X = (s1 | s2 | s3) along K (Kp = H rounded up to 256, zero padded), tiled the way the MFMA reads
 // it: [16-row group][k-step of 64 bytes: slice-major, 3 Kp / 64 of them][lane l: row l % 16, bytes (l / 16) * 16 .. + 15] --
 // every row-side LDS-DMA piece is 1 KiB of consecutive bytes, eight whole cache lines.  Row patches and column patches are
 // rows of the same panel: a column-side piece gathers 16 consecutive rows that may begin inside a group (GramI8Args).  (Row-major slices made each piece 16 half lines; every line crossed the L2 -> L1 path twice, once
 // per k-step, and the kernel sat at 12 B / clock / CU.)
 //
 // r03: ONE sweep over K with three accumulator sets.  A k-step brings the 64 bytes of all three slices of the tile's rows
-// and columns and feeds the six slice products of the three classes at once -- C2 += q1.q1', C3 += q2.q1' + q1.q2',
-// C4 += q3.q1' + q2.q2' + q1.q3' -- and the epilogue forms acc = C2 + ((C3 + (C4 >> 7)) >> 7), the same integer as
-// before.  The r02 kernel had one accumulator set and walked K three times (classes 4, 3, 2 with a shift in between):
+// and columns and feeds the six slice products of the three classes at once -- C2 += s1.s1', C3 += s2.s1' + s1.s2',
+// C4 += s3.s1' + s2.s2' + s1.s3' -- and the epilogue forms acc = C2 + ((C3 + (C4 >> 8)) >> 8) (arithmetic shifts: floors).  The r02 kernel had one accumulator set and walked K three times (classes 4, 3, 2 with a shift in between):
 // 240 k-steps of 32 MFMAs per wave instead of 40 of 96, every slice streamed again per class (18.6 GB over the fabric
 // for 0.49 GB of panels, profiles/r02i), 12 LDS fragment reads per 32 MFMAs instead of 24 per 96.
 #include "gemm_internal.h"
@@ -51,8 +59,8 @@ struct GramI8Args {
                                           // gathered from it, lane by lane, in UNITS of 64 columns = fpu whole frames + zero
                                           // rows, so that every frame's P columns lie inside one wave's 64-column block
     long long zrow;                       // first row of an all-zero group of X
-    const int* nbp;                       // |u_b|^2 of the column units' rows, units of 2^-13 (unit layout)
-    const unsigned long long* keys;       // [3]: largest row sum of u (the error bound), [2]: non-finite flag
+    const int* nbp;                       // |v_b|^2 of the column units' rows, units of 2^-15 (unit layout)
+    const unsigned long long* keys;       // [3]: largest row sum of |v| (the error bound), [2]: non-finite / exit flag
     unsigned char* abi;                   // out [nfp, rp]: the nearest patch b of column frame j to row patch a
     unsigned* acand;                      // out [nfp, rp]: 0 = decided; else the patches inside the error window (bit b)
     long long nfp, rp;                    // column frames of abi / acand (padded: whole tiles) and their pitch (row patches)
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     const long long m0 = (long long)tile_m * GI_T, n0 = (long long)tile_n * GI_T;
     // the tile's last frame must lie behind its first row's frame, and its first frame must exist
     if ((long long)(2 * tile_n + 2) * p.fpu - 1 <= m0 / p.P || (long long)2 * tile_n * p.fpu >= p.nframes) return;
-    if (p.keys[2]) return;                          // a NaN / infinity in the dataset: this form does not apply
+    if (p.keys[2]) return;                          // a NaN / infinity in the dataset, or the sample said "hopeless": not this form
 
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wr = w >> 1, wc = w & 1;              // 64 row patches x 64 column patches per wave
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
 
     // ---- epilogue: the patch arg-min of every (row patch, column frame) of the tile, decided here -- the products never
     // leave the chip (r02 / early r03 wrote them out, 2 GB, for a second kernel to read back).
-    // acc = C2 + floor((C3 + floor(C4 / 128)) / 128) in units of 2^-14 of u . u; d2 = |u_b|^2 - 2 acc 2^-14 in units of 2^-13.
+    // acc = C2 + floor((C3 + floor(C4 / 256)) / 256) in units of 2^-16 of v . v'; d2 = |v_b|^2 - 2 acc 2^-16 in units of 2^-15.
     // D[m][n] of MFMA (j, i): m = column j * 16 + (lane / 16) * 4 + v of this wave's unit, n = row patch (wr * 4 + i) * 16 + lane % 16.
     // A row patch's columns are spread over four lanes and sixteen registers; rather than merge (best, index, runner-up)
     // triples across lanes -- a chain of 64 dependent cross-lane moves per tile, 7 us -- the wave turns its 64 x 64 block
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
 #define GI_EPI(I, J)                                                                                            \
         {                                                                                                       \
             const v4i a2 = gi_acc_read<GI_ACC(0, J, I)>(), a3 = gi_acc_read<GI_ACC(1, J, I)>(), a4 = gi_acc_read<GI_ACC(2, J, I)>(); \
-            const v4i acc = a2 + ((a3 + (a4 >> 7)) >> 7);                                                       \
+            const v4i acc = a2 + ((a3 + (a4 >> 8)) >> 8);                                                       \
             int* dst = d2s + ((I) * 16 + (lane & 15)) * DP + (J) * 16 + quad * 4;                               \
             _Pragma("unroll") for (int v = 0; v < 4; ++v) dst[v] = nbl[J][v] - acc[v];                          \
         }
@@ -373,8 +381,7 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     }
     __builtin_amdgcn_s_waitcnt(0x0070);                                  // lgkmcnt(0): this wave's LDS writes (its own region)
     __builtin_amdgcn_wave_barrier();
-    const double E = 0x1p-20 * dlc_f64_unkey(p.keys[3]) + (double)p.H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
-    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
+    const long long window = dlc_sim_window(p.keys, p.H);
     const unsigned wu = window > 0xffffffffll ? 0xffffffffu : (unsigned)window, pmask = p.P >= 32 ? ~0u : (1u << p.P) - 1u;
     const long long a = m0 + wr * 64 + lane;                             // lane r owns row patch r of the wave's 64
     const int* drow = d2s + lane * DP;
@@ -406,49 +413,96 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     }
 }
 
-// ---- range, quantisation -------------------------------------------------------------------------------------------
+// ---- column extremes, centres, quantisation ------------------------------------------------------------------------
+// The dataset's column statistics travel as `range` words (include/dlc.h: dlc_sdav_distinctive_score leaves them when it
+// has walked the same descriptors, else sim_colrange_kernel does): [0], [1] reserved, [2] flag (a NaN / infinity seen),
+// [3 + k] ordered key of column k's minimum, [3 + H + k] of its maximum.
 
-__global__ void sim_keys_init_kernel(unsigned long long* keys, const unsigned long long* range) {
-    // [4]: direct evaluations (a count); [0..2]: the dataset's range and flag -- from the caller's distinctive-score pass
-    // over the same descriptors when it kept them, else sim_range_kernel fills them in
-    if (threadIdx.x < 6) keys[threadIdx.x] = threadIdx.x == 0 ? ~0ull : 0ull;
-    if (range && threadIdx.x < 3) keys[threadIdx.x] = range[threadIdx.x];
+__global__ void sim_range_init_kernel(unsigned long long* range, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 3) range[i] = 0ull;
+    if (i < H) { range[3 + i] = ~0ull; range[3 + H + i] = 0ull; }
 }
 
-__global__ __launch_bounds__(256) void sim_range_kernel(const double* __restrict__ x, long long n, unsigned long long* keys) {
-    double lo = INFINITY, hi = -INFINITY;
+// Column extremes of x [rows, H]: a workgroup takes 128 columns (a wave's row segment: 64 lanes x 16 bytes = 1 KiB) of one
+// chunk of rows, its four waves every fourth row, eight rows in flight per wave; ordered-key atomics fold the chunks.
+constexpr int CR_ROWS = 512;                // rows per workgroup
+__global__ __launch_bounds__(256) void sim_colrange_kernel(const double* __restrict__ x, long long rows, int H,
+                                                           unsigned long long* __restrict__ range) {
+    __shared__ double red[4][128][2];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * 128 + lane * 2;
+    const long long r0 = (long long)blockIdx.y * CR_ROWS, r1 = r0 + CR_ROWS < rows ? r0 + CR_ROWS : rows;
+    const bool two = c0 + 1 < H, one = c0 < H;
+    const bool vec = (H & 1) == 0 && ((unsigned long long)x & 15) == 0;
+    double lo0 = INFINITY, hi0 = -INFINITY, lo1 = INFINITY, hi1 = -INFINITY;
     bool bad = false;
-    auto take = [&](double v) { bad |= !(fabs(v) < INFINITY); lo = fmin(lo, v); hi = fmax(hi, v); };
-    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
-    long long head = ((16 - ((unsigned long long)x & 15)) & 15) / 8;      // doubles in front of the first 16-byte boundary
-    if (head > n) head = n;
-    const double2* x2 = (const double2*)(x + head);
-    const long long n2 = (n - head) / 2;
-    long long i = tid;
-    for (; i + 3 * nth < n2; i += 4 * nth) {                               // (eight loads per thread on 4096 workgroups: 0.24 -> 0.41 ms)
-        const double2 a = x2[i], b = x2[i + nth], c = x2[i + 2 * nth], d = x2[i + 3 * nth];
-        take(a.x); take(a.y); take(b.x); take(b.y); take(c.x); take(c.y); take(d.x); take(d.y);
+    auto take = [&](double a, double b) {
+        bad |= !(fabs(a) < INFINITY) || !(fabs(b) < INFINITY);
+        lo0 = fmin(lo0, a); hi0 = fmax(hi0, a); lo1 = fmin(lo1, b); hi1 = fmax(hi1, b);
+    };
+    if (one) {
+        long long r = r0 + w;
+        if (vec && two) {
+            for (; r + 28 < r1; r += 32) {
+                double2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const double2*)(x + (r + 4 * u) * H + c0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) take(v[u].x, v[u].y);
+            }
+            for (; r < r1; r += 4) { const double2 v = *(const double2*)(x + r * H + c0); take(v.x, v.y); }
+        } else {
+            for (; r < r1; r += 4) { const double a = x[r * H + c0]; take(a, two ? x[r * H + c0 + 1] : a); }
+        }
     }
-    for (; i < n2; i += nth) { const double2 a = x2[i]; take(a.x); take(a.y); }
-    if (tid < head) take(x[tid]);
-    if (tid == 0 && head + 2 * n2 < n) take(x[n - 1]);
-    for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+    red[w][lane * 2][0] = lo0; red[w][lane * 2][1] = hi0; red[w][lane * 2 + 1][0] = lo1; red[w][lane * 2 + 1][1] = hi1;
     const bool any_bad = __ballot(bad) != 0;
-    if ((threadIdx.x & 63) == 0) {
-        atomicMin(&keys[0], dlc_f64_key(lo));
-        atomicMax(&keys[1], dlc_f64_key(hi));
-        if (any_bad) atomicMax(&keys[2], 1ull);
+    if (lane == 0 && any_bad) atomicMax(&range[2], 1ull);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c = blockIdx.x * 128 + threadIdx.x;
+        const double lo = fmin(fmin(red[0][threadIdx.x][0], red[1][threadIdx.x][0]), fmin(red[2][threadIdx.x][0], red[3][threadIdx.x][0]));
+        const double hi = fmax(fmax(red[0][threadIdx.x][1], red[1][threadIdx.x][1]), fmax(red[2][threadIdx.x][1], red[3][threadIdx.x][1]));
+        if (c < H && lo <= hi) { atomicMin(&range[3 + c], dlc_f64_key(lo)); atomicMax(&range[3 + H + c], dlc_f64_key(hi)); }
     }
 }
 
-// u = clamp((x - lo) / (hi - lo)) and its 21-bit fixed-point value (a NaN lands on 0; such datasets take the fp64 route)
-__device__ __forceinline__ double sim_unit(double x, double lo, double inv) {
-    const double u = (x - lo) * inv;
-    return u > 0.0 ? (u < 1.0 ? u : 1.0) : 0.0;
+// keys (DLC_SIM_KEYS words) of a call and the columns' centres: cc[k] = the midpoint of column k's extremes, keys[0] = the
+// ordered key of the largest column range (0 when every column is constant: all rows the same, every distance 0).
+// One workgroup of 256 threads.
+__global__ __launch_bounds__(256) void sim_keys_init_kernel(unsigned long long* keys, const unsigned long long* __restrict__ range,
+                                                            int H, double* __restrict__ cc) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < H; k += 256) {
+        const double lo = dlc_f64_unkey(range[3 + k]), hi = dlc_f64_unkey(range[3 + H + k]);
+        const bool ok = lo <= hi && fabs(lo) < INFINITY && fabs(hi) < INFINITY;
+        cc[k] = ok ? lo + 0.5 * (hi - lo) : 0.0;
+        if (ok) s = fmax(s, hi - lo);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x < DLC_SIM_KEYS) keys[threadIdx.x] = 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (a range that overflows, two finite extremes 1e308 apart, cannot be scaled: the fp64 form takes such data)
+        keys[0] = dlc_f64_key(red[0] < INFINITY ? red[0] : 0.0);
+        keys[2] = (range[2] || !(red[0] < INFINITY)) ? 1ull : 0ull;
+    }
 }
-__device__ __forceinline__ int sim_fixed(double u) {
-    const int q = (int)(u * 2097152.0);                                 // floor (u >= 0)
-    return q > 2097151 ? 2097151 : q;
+
+// v = (x - c) * inv clamped to the digits' range (values outside it exist only in streams, whose range is fixed at
+// creation, and are flagged: `outside`), and its 24-bit fixed-point value
+constexpr double SIM_VMAX = 0.498;
+__device__ __forceinline__ double sim_centred(double x, double c, double inv, bool& outside) {
+    const double v = (x - c) * inv;
+    outside |= !(fabs(v) <= SIM_VMAX * (1.0 + 0x1p-40));
+    return v > -SIM_VMAX ? (v < SIM_VMAX ? v : SIM_VMAX) : -SIM_VMAX;       // (a NaN lands on -SIM_VMAX, flagged)
 }
 
 // A 128-bit content hash of a row: two sums over the elements of a strong 64-bit mix of (bit pattern, position) -- order
@@ -462,73 +516,106 @@ __device__ __forceinline__ unsigned long long sim_mix64(unsigned long long z) {
     return z ^ (z >> 31);
 }
 
+// The projections p = dot(score, row) are kept as double-double values (hi, lo): what the similarity takes from them is the
+// DIFFERENCE of two rows' projections, |dot(score, m_a - m_b)| (SimilarityCalculator.py:42-43), and for rows that lie close
+// together -- low-contrast descriptors, every column within 1e-3 of its mean: a quarter of the matched pairs of real
+// frames through 1/sqrt(fan_in) weights -- the difference of two fp64 sums of magnitude 600 had lost seven of its digits,
+// so the pair kernels re-evaluated it from the rows (one wave, 60 KB, per matched pair: 4 M of them, 20 of the call's
+// 33 ms).  With 106 bits in each projection the difference is good to 1e-20 of the projections whatever the rows are.
+struct dd_t { double hi, lo; };
+__device__ __forceinline__ void dd_add_prod(dd_t& s, double a, double b) {       // s += a * b (a * b exactly: fma)
+#pragma clang fp contract(off)
+    const double p = a * b;
+    const double e = fma(a, b, -p);
+    const double t = s.hi + p;
+    const double bb = t - s.hi;
+    const double err = (s.hi - (t - bb)) + (p - bb);
+    s.hi = t;
+    s.lo += err + e;
+}
+__device__ __forceinline__ dd_t dd_add(dd_t x, dd_t y) {
+#pragma clang fp contract(off)
+    const double t = x.hi + y.hi;
+    const double bb = t - x.hi;
+    const double err = (x.hi - (t - bb)) + (y.hi - bb);
+    dd_t r;
+    r.hi = t;
+    r.lo = (x.lo + y.lo) + err;
+    return r;
+}
+
 // The pass over the descriptors that both forms of the similarity share, a workgroup per group of 16 patch rows, a wave
 // per k-step of 64 elements (w, w + 4, ..), lane l on row l % 16, elements ks * 64 + (l / 16) * 16 .. + 15 -- 128
 // contiguous bytes per lane:
-//   |x|^2 (the fp64 Gram form's norms) and p = dot(score, row) for every row -- per lane in k order, then the row's four
-//   lanes (xor 16, 32), then its four waves in order: one fixed summation order for both forms, whose projections must
-//   agree bit for bit;
-//   QUANT (the filter): sum u (its largest value into keys[3], an ordered key), |u|^2, and the three 7-bit slices of
-//   the 21-bit fixed-point value, 16 bytes of each per lane at lane * 16 of that (group, slice, k-step) block -- 1 KiB per
+//   |x|^2 (the fp64 Gram form's norms) and p = dot(score, row) (double-double: proj[2 r], proj[2 r + 1]) for every row --
+//   per lane in k order, then the row's four lanes (xor 16, 32), then its four waves in order: one fixed summation order
+//   for both forms, whose projections must agree bit for bit;
+//   QUANT (the filter): sum |v| (its largest value into keys[3], an ordered key), |v|^2, and the three signed digits of
+//   the 24-bit fixed-point value, 16 bytes of each per lane at lane * 16 of that (group, slice, k-step) block -- 1 KiB per
 //   store instruction.  Rows past the last one and k >= H are zeros there and take no part in the sums.
 template <bool QUANT>
 __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict__ desc, long long rows, int H, int kp,
                                                        const double* __restrict__ score, unsigned long long* keys,
+                                                       const double* __restrict__ cc,
                                                        char* __restrict__ X, double* __restrict__ nrm2,
                                                        double* __restrict__ nu2, double* __restrict__ proj,
                                                        unsigned long long* __restrict__ rowhash, long long g0, int P, int fpu,
                                                        int* __restrict__ nbp) {
-    __shared__ double red[4][16][4];
+    __shared__ double red[4][16][5];
     __shared__ unsigned long long redh[4][16][2];
     unsigned long long h1 = 0, h2 = 0;
     const long long g = g0 + blockIdx.x;          // (g0 > 0: the groups a stream's new frames touch)
-    bool outside = false;                         // a value outside [lo, hi]: only possible with a FIXED range (streams)
+    bool outside = false;                         // a value outside the digits' range: only possible with a FIXED range (streams)
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, rr = lane & 15, chunk = lane >> 4;
-    double lo = 0.0, inv = 0.0;
+    double inv = 0.0;
     if constexpr (QUANT) {
-        const double hi = dlc_f64_unkey(keys[1]);
-        lo = dlc_f64_unkey(keys[0]);
-        inv = hi - lo > 0.0 ? 1.0 / (hi - lo) : 0.0;
+        const double s_ = dlc_f64_unkey(keys[0]);
+        inv = s_ > 0.0 ? 2.0 * SIM_VMAX / s_ : 0.0;
     }
     const long long r = g * 16 + rr;
     const bool row_ok = r < rows;
     const int nks = QUANT ? kp / 64 : (H + 63) / 64;
     const double* x = desc + (row_ok ? r : 0) * H;
-    const bool vec = (H & 1) == 0 && ((unsigned long long)desc & 15) == 0 && ((unsigned long long)score & 15) == 0;
+    const bool vec = (H & 1) == 0 && ((unsigned long long)desc & 15) == 0 && ((unsigned long long)score & 15) == 0 &&
+                     (!QUANT || ((unsigned long long)cc & 15) == 0);
     char* xg = X + g * (3ll * nks * 1024) + lane * 16;
-    double n2 = 0.0, pr = 0.0, su = 0.0, s2 = 0.0;
+    double n2 = 0.0, su = 0.0, s2 = 0.0;
+    dd_t pr = {0.0, 0.0};
     for (int ks = w; ks < nks; ks += 4) {
         const int k0 = ks * 64 + chunk * 16;
         unsigned w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0}, w3[4] = {0, 0, 0, 0};
-        auto put = [&](int e, double v, double sc) {
+        auto put = [&](int e, double v, double sc, double c) {
             n2 = fma(v, v, n2);
-            pr = fma(sc, v, pr);
+            dd_add_prod(pr, sc, v);
             if (rowhash) {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(v), pos = (unsigned long long)(k0 + e);
                 h1 += sim_mix64(bits + pos * 0x9e3779b97f4a7c15ull);
                 h2 += sim_mix64((bits ^ 0xd6e8feb86659fd93ull) + pos * 0xc2b2ae3d27d4eb4full);
             }
             if constexpr (QUANT) {
-                const double u = sim_unit(v, lo, inv);
-                outside |= !((v - lo) * inv >= 0.0 && (v - lo) * inv <= 1.0);
-                su += u; s2 = fma(u, u, s2);
-                const int q = sim_fixed(u);
-                w1[e >> 2] |= (unsigned)(q >> 14) << (8 * (e & 3));
-                w2[e >> 2] |= (unsigned)((q >> 7) & 127) << (8 * (e & 3));
-                w3[e >> 2] |= (unsigned)(q & 127) << (8 * (e & 3));
+                const double u = sim_centred(v, c, inv, outside);
+                su += fabs(u); s2 = fma(u, u, s2);
+                const int q = (int)rint(u * 16777216.0);                // |q| <= 0.498 * 2^24 = 8 355 054: digits in [-128, 127]
+                const int q1 = (q + 128) >> 8;                           // (q - s3) / 256, s3 = the signed low byte of q
+                w1[e >> 2] |= (unsigned)(((q1 + 128) >> 8) & 255) << (8 * (e & 3));
+                w2[e >> 2] |= (unsigned)(q1 & 255) << (8 * (e & 3));
+                w3[e >> 2] |= (unsigned)(q & 255) << (8 * (e & 3));
             }
         };
         if (row_ok) {
             if (vec && k0 + 16 <= H) {                                  // 128 contiguous, 16-byte aligned bytes per lane
-                double2 v[8], c[8];
+                double2 v[8], c[8], m[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] = *(const double2*)(x + k0 + 2 * e); c[e] = *(const double2*)(score + k0 + 2 * e); }
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = *(const double2*)(x + k0 + 2 * e); c[e] = *(const double2*)(score + k0 + 2 * e);
+                    if constexpr (QUANT) m[e] = *(const double2*)(cc + k0 + 2 * e); else m[e] = make_double2(0.0, 0.0);
+                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { put(2 * e, v[e].x, c[e].x); put(2 * e + 1, v[e].y, c[e].y); }
+                for (int e = 0; e < 8; ++e) { put(2 * e, v[e].x, c[e].x, m[e].x); put(2 * e + 1, v[e].y, c[e].y, m[e].y); }
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    if (k0 + e < H) put(e, x[k0 + e], score[k0 + e]);
+                    if (k0 + e < H) put(e, x[k0 + e], score[k0 + e], QUANT ? cc[k0 + e] : 0.0);
             }
         }
         if constexpr (QUANT) {
@@ -540,15 +627,18 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
         }
     }
     for (int o = 16; o <= 32; o <<= 1) {
-        n2 += __shfl_xor(n2, o); pr += __shfl_xor(pr, o);
+        n2 += __shfl_xor(n2, o);
+        dd_t other;
+        other.hi = __shfl_xor(pr.hi, o); other.lo = __shfl_xor(pr.lo, o);
+        pr = dd_add(pr, other);
         if constexpr (QUANT) { su += __shfl_xor(su, o); s2 += __shfl_xor(s2, o); }
         h1 += __shfl_xor(h1, o); h2 += __shfl_xor(h2, o);
     }
     if constexpr (QUANT) {
-        if (__ballot(outside) != 0 && lane == 0) atomicMax(&keys[2], 1ull);
+        if (__ballot(outside) != 0 && lane == 0) atomicOr(&keys[2], 1ull);
     }
     if (chunk == 0) {
-        red[w][rr][0] = n2; red[w][rr][1] = pr; red[w][rr][2] = su; red[w][rr][3] = s2;
+        red[w][rr][0] = n2; red[w][rr][1] = pr.hi; red[w][rr][2] = su; red[w][rr][3] = s2; red[w][rr][4] = pr.lo;
         redh[w][rr][0] = h1; redh[w][rr][1] = h2;
     }
     __syncthreads();
@@ -557,11 +647,19 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
 #pragma unroll
         for (int c = 0; c < 4; ++c) t[c] = ((red[0][rr][c] + red[1][rr][c]) + red[2][rr][c]) + red[3][rr][c];
         if (nrm2) nrm2[r] = t[0];
-        proj[r] = t[1];
+        dd_t pt = {red[0][rr][1], red[0][rr][4]};
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) { const dd_t o = {red[ww][rr][1], red[ww][rr][4]}; pt = dd_add(pt, o); }
+        {                                                                // normalised: hi = the sum rounded to fp64, lo = the rest
+#pragma clang fp contract(off)
+            const double hi = pt.hi + pt.lo;
+            proj[2 * r] = hi;
+            proj[2 * r + 1] = pt.lo - (hi - pt.hi);
+        }
         if constexpr (QUANT) {
             nu2[r] = t[3];
             atomicMax(&keys[3], dlc_f64_key(t[2]));
-            if (nbp) { const long long f = r / P; nbp[(f / fpu) * 64 + (f % fpu) * P + (r - f * P)] = (int)llrint(t[3] * 8192.0); }
+            if (nbp) { const long long f = r / P; nbp[(f / fpu) * 64 + (f % fpu) * P + (r - f * P)] = (int)llrint(t[3] * 32768.0); }
         }
         if (rowhash) {
             rowhash[2 * r] = redh[0][rr][0] + redh[1][rr][0] + redh[2][rr][0] + redh[3][rr][0];
@@ -617,32 +715,56 @@ size_t gram_blocks_bytes(int64_t N, int64_t P) {
 // the product kernel's column lanes address the panel with 32-bit offsets
 bool sim_filter_fits(int64_t N, int64_t P, int64_t H) { return sim_filter_panel_bytes(N * P, H) < (1ull << 32); }
 
-// keys[6]: min key, max key, non-finite flag, max row sum key, direct evaluations (a count), length of prog (up to
-// 1023 int2 entries for H <= 32768).  X: sim_filter_panel_bytes (its rows behind the last patch are zeros); nbp: sim_col_rows ints.
+// keys (DLC_SIM_KEYS words): [0] ordered key of the largest column range, [2] flag (1: a NaN / infinity or a value outside a
+// stream's fixed range, 2: the sample said the filter would not decide -- match_ref.hip), [3] ordered key of the largest
+// row sum of |v|, [4] direct evaluations (a count), [5] length of prog (up to 1023 int2 entries for H <= 32768), [6] / [7]
+// the sample's undecided / finished cells.  cc: H doubles (16-byte aligned), ws_range: sim_range_words(H) words for the
+// column extremes when the caller brings none.  X: sim_filter_panel_bytes (its rows behind the last patch are zeros);
+// nbp: sim_col_rows ints.
+size_t sim_range_words(int64_t H) { return 3 + 2 * (size_t)H; }
+
+static int sim_column_extremes(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, unsigned long long* range, hipStream_t st) {
+    hipLaunchKernelGGL(sim_range_init_kernel, dim3((unsigned)dlc::cdiv(H > 3 ? H : 3, (int64_t)256)), dim3(256), 0, st, range, (int)H);
+    hipLaunchKernelGGL(sim_colrange_kernel, dim3((unsigned)dlc::cdiv(H, (int64_t)128), (unsigned)dlc::cdiv(rows, (int64_t)CR_ROWS)), dim3(256),
+                       0, st, desc, (long long)rows, (int)H, range);
+    DLC_LAUNCH_CHECK(ctx, "sim_colrange_kernel");
+    return DLC_OK;
+}
+
 int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, int64_t H, const double* score,
-                       unsigned long long* keys, char* X, int* nbp, double* nu2, double* proj,
-                       unsigned long long* rowhash, void* prog, const unsigned long long* range, hipStream_t st) {
+                       unsigned long long* keys, double* cc, unsigned long long* ws_range, char* X, int* nbp, double* nu2,
+                       double* proj, unsigned long long* rowhash, void* prog, const unsigned long long* range, hipStream_t st) {
     const int64_t rows = N * P;
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
-    hipLaunchKernelGGL(sim_keys_init_kernel, dim3(1), dim3(64), 0, st, keys, range);
+    if (!range) {
+        const int rc = sim_column_extremes(ctx, desc, rows, H, ws_range, st);
+        if (rc != DLC_OK) return rc;
+        range = ws_range;
+    }
+    hipLaunchKernelGGL(sim_keys_init_kernel, dim3(1), dim3(256), 0, st, keys, range, (int)H, cc);
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
-    if (!range) hipLaunchKernelGGL(sim_range_kernel, dim3(2048), dim3(256), 0, st, desc, (long long)(rows * H), keys);
-    DLC_LAUNCH_CHECK(ctx, "sim_range_kernel");
+    DLC_LAUNCH_CHECK(ctx, "sim_keys_init_kernel");
     DLC_HIP_CHECK(ctx, hipMemsetAsync(nbp, 0, (size_t)sim_col_rows(N, P) * 4, st));
     hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(256), 0, st, desc, (long long)rows,
-                       (int)H, kp, score, keys, X, (double*)nullptr, nu2, proj, rowhash, 0ll, (int)P, sim_frames_per_unit(P), nbp);
+                       (int)H, kp, score, keys, (const double*)cc, X, (double*)nullptr, nu2, proj, rowhash, 0ll, (int)P,
+                       sim_frames_per_unit(P), nbp);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
 
-// ---- the streaming form (match_ref.hip: dlc_sdav_stream_*): a resident, append-only panel with a range FIXED at creation
-__global__ void sim_stream_keys_kernel(unsigned long long* keys, double lo, double hi) {
-    if (threadIdx.x < 8) keys[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) { keys[0] = dlc_f64_key(lo); keys[1] = dlc_f64_key(hi); }
+// ---- the streaming form (match_ref.hip: dlc_sdav_stream_*): a resident, append-only panel over a range FIXED at creation:
+// x - centre[k] in [lo, hi] for every column k (centre: DEVICE, H doubles, or null for zeros)
+__global__ __launch_bounds__(256) void sim_stream_keys_kernel(unsigned long long* keys, double lo, double hi,
+                                                              const double* __restrict__ centre, int H, double* __restrict__ cc) {
+    if (threadIdx.x < DLC_SIM_KEYS) keys[threadIdx.x] = 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) keys[0] = dlc_f64_key(hi - lo);
+    for (int k = threadIdx.x; k < H; k += 256) cc[k] = (centre ? centre[k] : 0.0) + (lo + 0.5 * (hi - lo));
 }
 
-int sim_stream_init(dlc_ctx* ctx, unsigned long long* keys, void* prog, int64_t H, double lo, double hi, hipStream_t st) {
-    hipLaunchKernelGGL(sim_stream_keys_kernel, dim3(1), dim3(64), 0, st, keys, lo, hi);
+int sim_stream_init(dlc_ctx* ctx, unsigned long long* keys, double* cc, void* prog, int64_t H, double lo, double hi,
+                    const double* centre, hipStream_t st) {
+    hipLaunchKernelGGL(sim_stream_keys_kernel, dim3(1), dim3(256), 0, st, keys, lo, hi, centre, (int)H, cc);
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
     DLC_LAUNCH_CHECK(ctx, "sim_stream_keys_kernel");
     return DLC_OK;
@@ -651,12 +773,12 @@ int sim_stream_init(dlc_ctx* ctx, unsigned long long* keys, void* prog, int64_t 
 // quantise the 16-row groups g_first .. g_first + g_count - 1 of desc[rows_total, H] into the panel and the per-row arrays
 // (a group shared with older rows is rewritten with the same values)
 int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, int64_t H, const double* score,
-                        unsigned long long* keys, char* X, double* nu2, double* proj, unsigned long long* rowhash,
-                        int64_t g_first, int64_t g_count, hipStream_t st) {
+                        unsigned long long* keys, const double* cc, char* X, double* nu2, double* proj,
+                        unsigned long long* rowhash, int64_t g_first, int64_t g_count, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     if (g_count < 1) return DLC_OK;
     hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)g_count), dim3(256), 0, st, desc, (long long)rows_total, (int)H, kp, score,
-                       keys, X, (double*)nullptr, nu2, proj, rowhash, (long long)g_first, 1, 1, (int*)nullptr);
+                       keys, cc, X, (double*)nullptr, nu2, proj, rowhash, (long long)g_first, 1, 1, (int*)nullptr);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
@@ -675,7 +797,7 @@ int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, cons
                  unsigned long long* rowhash, void* prog, unsigned long long* prog_len, hipStream_t st) {
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, prog_len);
     hipLaunchKernelGGL(sim_rows_kernel<false>, dim3((unsigned)dlc::cdiv(rows, (int64_t)16)), dim3(256), 0, st, desc, (long long)rows,
-                       (int)H, 0, score, (unsigned long long*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj,
+                       (int)H, 0, score, (unsigned long long*)nullptr, (const double*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj,
                        rowhash, 0ll, 1, 1, (int*)nullptr);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;

@@ -132,11 +132,12 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __re
 constexpr int DS_COLS = 16;               // columns per workgroup
 constexpr int DS_U = 16;                  // rows per thread and batch
 constexpr int DS_ROWS = 16 * DS_U;        // rows per batch
-// range (may be null): the pass sees every element once, so it also folds what the similarity's filter form needs to know
-// about the dataset -- ordered keys of its minimum and maximum, and whether it holds a NaN / infinity -- into range[0..2]
-// (initialised by range_init_kernel): dlc_sdav_similarity_matrix then skips its own pass over the 638 MB.
+// range (may be null): the pass sees every element once, so it also leaves what the similarity's filter form needs to know
+// about the dataset -- every COLUMN's minimum and maximum as ordered keys, and whether it holds a NaN / infinity: the layout
+// of gram_i8.hip's sim_colrange_kernel, 3 + 2 H words -- and dlc_sdav_similarity_matrix then skips its own pass over the
+// 638 MB.  A workgroup owns its columns, so the extremes are plain stores; only the flag is shared (range_init_kernel).
 __global__ void range_init_kernel(unsigned long long* range) {
-    if (threadIdx.x == 0) { range[0] = ~0ull; range[1] = 0ull; range[2] = 0ull; }
+    if (threadIdx.x < 3) range[threadIdx.x] = 0ull;
 }
 __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __restrict__ desc, long long rows, int H,
                                                                 double mu, double sigma, double* __restrict__ score,
@@ -191,11 +192,18 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
         score[col] = exp(e);
     }
     if (range) {
-        for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+        // thread (c, g) has seen rows g, g + 16, .. of column c: the 16 lane groups of a column through LDS (buf is free:
+        // the last batch's adds are behind the barrier)
+        __syncthreads();
+        buf[0][g][c] = lo; buf[1][g][c] = hi;
         const bool any_bad = __ballot(bad) != 0;
-        if ((tid & 63) == 0) {
-            if (lo <= hi) { atomicMin(&range[0], dlc_f64_key(lo)); atomicMax(&range[1], dlc_f64_key(hi)); }
-            if (any_bad) atomicMax(&range[2], 1ull);
+        if ((tid & 63) == 0 && any_bad) atomicOr(&range[2], 1ull);
+        __syncthreads();
+        if (tid < DS_COLS && col_ok) {
+            double l = buf[0][0][c], h = buf[1][0][c];
+            for (int q = 1; q < 16; ++q) { l = fmin(l, buf[0][q][c]); h = fmax(h, buf[1][q][c]); }
+            range[3 + col] = dlc_f64_key(l);
+            range[3 + H + col] = dlc_f64_key(h);
         }
     }
 }
@@ -205,17 +213,17 @@ __device__ __forceinline__ long long f64_to_i64_trunc(double v) {
     return (long long)v;   // truncation toward zero
 }
 
-// |dot(score, x_a - x_b)| evaluated directly (SimilarityCalculator.py:42-43) where the difference of the two projections
-// has cancelled: all 64 lanes of the wave on the two rows, lane-strided fma chains and the xor tree -- every lane
-// returns the same sum.  (One lane walking the H elements alone, two dependent loads per step, held its whole
-// workgroup for milliseconds: a handful of such patches set the duration of the pair kernels.)
-__device__ __forceinline__ double weighted_diff_wave(const double* __restrict__ xa, const double* __restrict__ xb,
-                                                     const double* __restrict__ score, int H, int lane) {
-    double s_ = 0.0;
-#pragma unroll 8
-    for (int k = lane; k < H; k += 64) s_ = fma(score[k], xa[k] - xb[k], s_);
-    for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
-    return s_;
+// |dot(score, m_a - m_b)| (SimilarityCalculator.py:42-43) from the two rows' double-double projections (gram_i8.hip:
+// sim_rows_kernel): good to 1e-20 of the projections however close the rows lie -- bit-identical rows (a frame seen twice,
+// a blank patch in both frames) have identical projections and give exactly 0 (log -> -inf, the score +inf, as the
+// reference's).  r03 kept plain fp64 projections and walked both rows again wherever their difference had cancelled.
+__device__ __forceinline__ double proj_diff(const double* __restrict__ proj, long long ra, long long rb) {
+#pragma clang fp contract(off)
+    const double2 a = *(const double2*)(proj + 2 * ra), b = *(const double2*)(proj + 2 * rb);
+    const double d = a.x - b.x;
+    const double bb = d - a.x;
+    const double err = (a.x - (d - bb)) + (-b.x - bb);
+    return fabs(d + (err + (a.y - b.y)));
 }
 
 // How close two squared distances |a|^2 + |b|^2 - 2 a.b of the fp64 Gram form may be before their order is not to be
@@ -399,7 +407,6 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
     if (i >= i_hi || j >= N || j <= i) return;
     double term = 0.0, wd = 1.0;
     long long rb = 0;
-    bool redo = false;
     int bi = 0;
     unsigned long long cand = 0;
     const long long ra = i * P + (lane < P ? lane : 0);
@@ -436,14 +443,7 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const double* __restric
     }
     if (lane < P) {
         rb = j * P + bi;
-        wd = fabs(proj[ra] - proj[rb]);                         // |dot(score, m_i - m_j*)|, :42-43
-        redo = wd < 1e-6 * (fabs(proj[ra]) + fabs(proj[rb]));   // cancellation: evaluate the difference directly
-    }
-    for (unsigned long long m = __ballot(redo); m; m &= m - 1) {
-        const int src = __ffsll((long long)m) - 1;
-        const long long rb_s = __shfl(rb, src);
-        const double s_ = weighted_diff_wave(desc + (i * P + src) * H, desc + rb_s * H, score, H, lane);
-        if (lane == src) wd = fabs(s_);
+        wd = proj_diff(proj, ra, rb);                           // |dot(score, m_i - m_j*)|, :42-43
     }
     if (lane < P) term = ca + cb * log(wd);                     // :48
     for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o);
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
     const int w = tid >> 6, lane = tid & 63;
     const int jj = tid >> 5, a = tid & 31;
     const long long ra = i * P + (a < P ? a : 0);
-    const double na = nrm2[ra], pa = proj[ra];
+    const double na = nrm2[ra];
     const double* grow0 = G + (i * P - i_lo * P) * ldg - col0;   // column 0 of the matrix in row a = 0 (left of the block: only frames > i are read)
     // wave w stages rows w, w + 4, ..; a lane columns lane, lane + 64, ..: the (up to 32) loads of a run are issued
     // together, and the NEXT run's are in flight while this one is scored
@@ -519,8 +519,6 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
         if (jn < N) fetch(jn);
         const long long j = j0 + jj;
         double term = 0.0, wd = 1.0;
-        long long rb = 0;
-        bool redo = false;
         const bool pair_ok = j > i && j < N;
         int bi = 0;
         unsigned cand = 0;
@@ -571,18 +569,7 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
                                                prog, (int)*prog_len, ps_lds_raw + (size_t)w * 8 * PF_STACK_DEPTH);
             if (lane == src) bi = ebi;
         }
-        if (pair_ok && a < P) {
-            rb = j * P + bi;
-            const double pb = proj[rb];
-            wd = fabs(pa - pb);                                 // |dot(score, m_i - m_j*)|, :42-43
-            redo = wd < 1e-6 * (fabs(pa) + fabs(pb));           // cancellation: evaluate the difference directly
-        }
-        for (unsigned long long m = __ballot(redo); m; m &= m - 1) {
-            const int src = __ffsll((long long)m) - 1;
-            const long long rb_s = __shfl(rb, src);
-            const double s_ = weighted_diff_wave(desc + (i * P + (src & 31)) * H, desc + rb_s * H, score, H, lane);
-            if (lane == src) wd = fabs(s_);
-        }
+        if (pair_ok && a < P) wd = proj_diff(proj, ra, j * P + bi);     // |dot(score, m_i - m_j*)|, :42-43
         if (pair_ok && a < P) term = ca + cb * log(wd);         // :48
         for (int o = 16; o > 0; o >>= 1) term += __shfl_xor(term, o);      // the 32 lanes of this pair (lanes >= P hold 0)
         if (pair_ok && a == 0) {
@@ -626,8 +613,7 @@ __global__ __launch_bounds__(256) void pair_score_amin_kernel(const double* __re
     const int w = tid >> 6, lane = tid & 63;
     const int jj = lane >> 5, a = lane & 31;
     const long long ra = i * P + (a < P ? a : 0);
-    const double pa = proj[ra];
-    const bool flat = !(dlc_f64_unkey(keys[1]) > dlc_f64_unkey(keys[0]));      // every descriptor value the same: all distances 0
+    const bool flat = !(dlc_f64_unkey(keys[0]) > 0.0);         // every column constant -- all patches the same row: all distances 0
     const long long nwaves = (long long)PS_GX * 4;               // waves per frame i: wave q takes the runs q, q + nwaves, ..
     unsigned long long fallbacks = 0;
     for (long long j0 = ((i + 1) / 2 + blockIdx.x * 4 + w) * 2; j0 < N; j0 += nwaves * 2) {
@@ -674,20 +660,7 @@ __global__ __launch_bounds__(256) void pair_score_amin_kernel(const double* __re
             }
         }
         double term = 0.0, wd = 1.0;
-        long long rb = 0;
-        bool redo = false;
-        if (live) {
-            rb = j * P + bi;
-            const double pb = proj[rb];
-            wd = fabs(pa - pb);                                 // |dot(score, m_i - m_j*)|, :42-43
-            redo = wd < 1e-6 * (fabs(pa) + fabs(pb));           // cancellation: evaluate the difference directly
-        }
-        for (unsigned long long m = __ballot(redo); m; m &= m - 1) {
-            const int src = __ffsll((long long)m) - 1;
-            const long long rb_s = __shfl(rb, src);
-            const double s_ = weighted_diff_wave(desc + (i * P + (src & 31)) * H, desc + rb_s * H, score, H, lane);
-            if (lane == src) wd = fabs(s_);
-        }
+        if (live) wd = proj_diff(proj, ra, j * P + bi);         // |dot(score, m_i - m_j*)|, :42-43
         if (live) term = ca + cb * log(wd);                     // :48
         for (int o = 16; o > 0; o >>= 1) term += __shfl_xor(term, o);
         if (pair_ok && a == 0) {
@@ -701,6 +674,68 @@ __global__ __launch_bounds__(256) void pair_score_amin_kernel(const double* __re
         }
     }
     if (lane == 0 && fallbacks) atomicAdd(n_fallback, fallbacks);
+}
+
+// The filter's EXIT.  The int8 products decide an arg-min when the runner-up lies outside the error window; data whose
+// distances sit inside it (one column with a range a thousand times the others', say) would send every arg-min to the
+// one-wave direct evaluation -- 15-25 us each, 17 M of them at 1063 frames -- where the fp64 Gram form takes 39 ms.
+// Before the product kernel starts, SIM_SAMPLES cells (row patch a, later frame j), picked by a fixed hash, are worked out
+// exactly -- |x_b - x_a|^2 in fp64 for the P patches of frame j, copies of an earlier patch dropped as the pair kernel
+// drops them -- and the gap between the two smallest is held against the window; when more than an eighth of the cells
+// would be undecided the last workgroup sets bit 1 of keys[2]: the filter's kernels leave at once, and the host, which
+// reads that word anyway (the NaN flag), sends the call down the fp64 route.  A workgroup per cell, eight candidates per
+// wave; 160 MB of descriptor rows, ~40 us.  (Not launched under DLC_SIM_NO_HOST_SYNC: nobody could act on the verdict.)
+constexpr int SIM_SAMPLES = 256;
+__global__ __launch_bounds__(256) void sim_sample_kernel(const double* __restrict__ desc,
+                                                         const unsigned long long* __restrict__ rowhash,
+                                                         unsigned long long* __restrict__ keys, long long N, int P, int H) {
+    __shared__ double d2s[32];
+    if (keys[2]) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long z = ((unsigned long long)blockIdx.x + 1) * 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    const long long i = (long long)(z % (unsigned long long)(N - 1));
+    const int a = (int)((z >> 24) % (unsigned)P);
+    const long long j = i + 1 + (long long)((z >> 40) % (unsigned long long)(N - 1 - i));
+    const double* xa = desc + (i * P + a) * H;
+    const double* xj = desc + j * P * H;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int b0 = w * 8 + pass * 4;
+        if (b0 >= P) break;                                       // (whole wave)
+        const double* xs[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xs[c] = xj + (long long)(b0 + c < P ? b0 + c : b0) * H;
+        double ss[4] = {0.0, 0.0, 0.0, 0.0};
+        bool frac = false;
+        direct_pass<4>(xa, xs, H, lane, ss, frac);
+        if (lane < 4 && b0 + lane < P) d2s[b0 + lane] = lane == 0 ? ss[0] : lane == 1 ? ss[1] : lane == 2 ? ss[2] : ss[3];
+    }
+    __syncthreads();
+    if (w != 0) return;
+    const double s_ = dlc_f64_unkey(keys[0]);
+    const double inv = s_ > 0.0 ? 0.996 / s_ : 0.0;
+    double d = lane < P ? d2s[lane] * inv * inv : INFINITY;       // in the filter's units (|v_b - v_a|^2)
+    if (lane < P) {
+        const unsigned long long* hb = rowhash + 2 * (j * P);
+        bool copy = false;
+        for (int e = 0; e < lane; ++e) copy |= hb[2 * e] == hb[2 * lane] && hb[2 * e + 1] == hb[2 * lane + 1];
+        if (copy) d = INFINITY;
+    }
+    double best = d;
+    for (int o = 32; o > 0; o >>= 1) best = fmin(best, __shfl_xor(best, o));
+    const int fb = __ffsll((long long)__ballot(d == best)) - 1;
+    double second = lane == fb ? INFINITY : d;
+    for (int o = 32; o > 0; o >>= 1) second = fmin(second, __shfl_xor(second, o));
+    const double window = (double)dlc_gemm::dlc_sim_window(keys, H) * 0x1p-15;
+    if (lane == 0) {
+        if (second - best <= window) atomicAdd(&keys[6], 1ull);
+        __threadfence();
+        const unsigned long long done = atomicAdd(&keys[7], 1ull);
+        if (done == (unsigned long long)gridDim.x - 1 && atomicAdd(&keys[6], 0ull) * 8 > (unsigned long long)gridDim.x)
+            atomicOr(&keys[2], 2ull);
+    }
 }
 
 __global__ void fill_diag_kernel(long long N, double* out_f64, long long* out_i64) {
@@ -803,16 +838,15 @@ __global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restri
     }
 #undef SR_STEP
     // D[m][n] of MFMA (jq, ig): m = query-side patch jq * 16 + quad * 4 + v (b = that - boff), n = database patch an of group ig
-    const double E = 0x1p-20 * dlc_f64_unkey(keys[3]) + (double)H * 16129.0 * (0x1p-34 + 0x1p-42) + 0x1p-13;
-    const long long window = (long long)ceil((2.0 * E + 1e-8) * 8192.0) + 2;
+    const long long window = dlc_gemm::dlc_sim_window(keys, H);
     const int prog_len = (int)keys[5];
-    int nbv[3][4];                                                 // |u_b|^2 of this lane's twelve query patches, units of 2^-13
+    int nbv[3][4];                                                 // |v_b|^2 of this lane's twelve query patches, units of 2^-15
 #pragma unroll
     for (int jq = 0; jq < 3; ++jq)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int b = jq * 16 + quad * 4 + v - boff;
-            nbv[jq][v] = (b >= 0 && b < P) ? (int)llrint(nu2[rows_old + b] * 8192.0) : 0;
+            nbv[jq][v] = (b >= 0 && b < P) ? (int)llrint(nu2[rows_old + b] * 32768.0) : 0;
         }
     unsigned long long directs = 0;
 #pragma unroll
@@ -823,7 +857,7 @@ __global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restri
         int d2v[3][4];
 #pragma unroll
         for (int jq = 0; jq < 3; ++jq) {
-            const sr_v4i acc = c2[jq][ig] + ((c3[jq][ig] + (c4[jq][ig] >> 7)) >> 7);
+            const sr_v4i acc = c2[jq][ig] + ((c3[jq][ig] + (c4[jq][ig] >> 8)) >> 8);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int b = jq * 16 + quad * 4 + v - boff;
@@ -895,23 +929,10 @@ __global__ __launch_bounds__(256) void stream_score_kernel(const double* __restr
         keys[4] = 0ull;                                         // reset for the next query (no memset launch in front of it)
     }
     const bool pair_ok = j < f, live = pair_ok && a < P;
-    double term = 0.0, wd = 1.0, pa = 0.0;
-    long long rb = 0;
-    bool redo = false;
+    double term = 0.0, wd = 1.0;
     if (live) {
         const long long ra = j * P + a;
-        rb = f * P + bi_in[ra];
-        pa = proj[ra];
-        const double pb = proj[rb];
-        wd = fabs(pa - pb);                                     // |dot(score, m_i - m_j*)|, :42-43
-        redo = wd < 1e-6 * (fabs(pa) + fabs(pb));               // cancellation: evaluate the difference directly
-    }
-    for (unsigned long long m = __ballot(redo); m; m &= m - 1) {
-        const int src = __ffsll((long long)m) - 1;
-        const long long rb_s = __shfl(rb, src);
-        const long long j_s = ((long long)blockIdx.x * 4 + w) * 2 + (src >> 5);
-        const double s_ = weighted_diff_wave(desc + (j_s * P + (src & 31)) * H, desc + rb_s * H, score, H, lane);
-        if (lane == src) wd = fabs(s_);
+        wd = proj_diff(proj, ra, f * P + bi_in[ra]);            // |dot(score, m_i - m_j*)|, :42-43
     }
     if (live) term = ca + cb * log(wd);                         // :48
     for (int o = 16; o > 0; o >>= 1) term += __shfl_xor(term, o);
@@ -919,7 +940,7 @@ __global__ __launch_bounds__(256) void stream_score_kernel(const double* __restr
 }
 
 struct StreamWs {
-    size_t keys, prog, nu2, proj, rowhash, bi, panel, total;
+    size_t keys, prog, cc, nu2, proj, rowhash, bi, panel, total;
 };
 StreamWs stream_ws(int64_t capacity, int64_t P, int64_t H) {
     StreamWs w;
@@ -927,8 +948,9 @@ StreamWs stream_ws(int64_t capacity, int64_t P, int64_t H) {
     const size_t rows = (size_t)capacity * P;
     w.keys = o; o += 256;
     w.prog = o; o += 8192;
+    w.cc = o; o += dlc::align_up((size_t)H * 8, 256);
     w.nu2 = o; o += dlc::align_up(rows * 8, 256);
-    w.proj = o; o += dlc::align_up(rows * 8, 256);
+    w.proj = o; o += dlc::align_up(rows * 16, 256);               // double-double projections
     w.rowhash = o; o += dlc::align_up(rows * 16, 256);
     w.bi = o; o += dlc::align_up(rows, 256);
     w.panel = o; o += dlc::align_up(dlc_gemm::sim_stream_panel_bytes(rows, H), 256);
@@ -948,13 +970,18 @@ int stream_check(dlc_ctx* ctx, const char* what, const void* state, size_t state
     return DLC_OK;
 }
 
-// keys[2] (non-finite flag) and keys[4] (direct evaluations) of a finished call -> the caller's stats; and, for a call
+// stats of a call that took the fp64 route after all: no direct evaluations of the filter's, and why (the flag bits)
+__global__ void sim_stats_kernel(long long* stats, long long why) {
+    if (threadIdx.x == 0) { stats[0] = 0; stats[1] = why; }
+}
+
+// keys[2] (flag bits) and keys[4] (direct evaluations) of a finished call -> the caller's stats; and, for a call
 // that may not read the flag on the host (DLC_SIM_NO_HOST_SYNC), NaN over the matrix when the filter form did not apply.
 __global__ __launch_bounds__(256) void sim_finish_kernel(const unsigned long long* __restrict__ keys, long long* __restrict__ stats,
                                                          long long nn, double* __restrict__ out_f64,
                                                          long long* __restrict__ out_i64, int poison) {
     const bool bad = keys[2] != 0;
-    if (stats && blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = (long long)keys[4]; stats[1] = bad ? 1 : 0; }
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = (long long)keys[4]; stats[1] = (long long)keys[2]; }
     if (!poison || !bad) return;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nn; e += (long long)gridDim.x * 256) {
         out_f64[e] = __longlong_as_double(0x7ff8000000000000ll);
@@ -963,7 +990,7 @@ __global__ __launch_bounds__(256) void sim_finish_kernel(const unsigned long lon
 }
 
 struct SimWs {
-    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, nbp, abi, acand, blk, total;
+    size_t nrm2, proj, gram, gram_bytes, desc_t, keys, prog, nu2, rowhash, qx, nbp, abi, acand, blk, cc, range, total;
     long long chunk_frames, nfp;
 };
 
@@ -1001,7 +1028,7 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     SimWs w;
     size_t o = 0;
     w.nrm2 = o; o += dlc::align_up((size_t)N * P * 8, 256);
-    w.proj = o; o += dlc::align_up((size_t)N * P * 8, 256);
+    w.proj = o; o += dlc::align_up((size_t)N * P * 16, 256);      // double-double projections
     const bool filter = sim_use_filter(N, P, H, flags);
     const size_t row_bytes = (size_t)N * P * 8;
     w.chunk_frames = sim_chunk(N, P, row_bytes, chunk_bytes);
@@ -1017,7 +1044,7 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
     const size_t prog_bytes = dlc_gemm::sim_pairwise_program_bytes(H);
     w.prog = o; o += prog_bytes > 8192 ? prog_bytes : 8192;
     w.rowhash = o; o += dlc::align_up((size_t)N * P * 16, 256);
-    w.nu2 = w.qx = w.nbp = w.abi = w.acand = w.blk = 0;
+    w.nu2 = w.qx = w.nbp = w.abi = w.acand = w.blk = w.cc = w.range = 0;
     w.nfp = 0;
     if (filter) {
         // the fixed-point panel (row operands as it lies, column operands gathered from it in units of whole frames), |u|^2, and the product kernel's
@@ -1030,6 +1057,8 @@ SimWs sim_ws(int64_t N, int64_t P, int64_t H, int flags, int64_t chunk_bytes) {
         w.abi = o; o += dlc::align_up(rp * w.nfp, 256);
         w.acand = o; o += dlc::align_up(rp * w.nfp * 4, 256);
         w.blk = o; o += dlc::align_up(dlc_gemm::gram_blocks_bytes(N, P), 256);
+        w.cc = o; o += dlc::align_up((size_t)H * 8, 256);                      // the columns' centres
+        w.range = o; o += dlc::align_up(dlc_gemm::sim_range_words(H) * 8, 256);  // their extremes, when the caller brings none
         w.desc_t = o;
     } else {
         // the descriptors transposed [H, N*P] (one extra pass over them): the fp64 Gram blocks then read their B operand as
@@ -1078,6 +1107,8 @@ extern "C" size_t dlc_sdav_similarity_workspace_bytes(int64_t N, int64_t P, int6
     if (N < 1 || P < 1 || H < 1) return 0;
     return sim_ws(N, P, H, flags, chunk_bytes).total;
 }
+
+extern "C" size_t dlc_sdav_range_words(int64_t H) { return H < 1 ? 0 : dlc_gemm::sim_range_words(H); }
 
 extern "C" int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows, int64_t H, double mu,
                                          double sigma, double* score, uint64_t* range, void* stream) {
@@ -1130,7 +1161,8 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         unsigned* acand = (unsigned*)(ws + w.acand);
         int2* prog = (int2*)(ws + w.prog);
         unsigned long long* rowhash = (unsigned long long*)(ws + w.rowhash);
-        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, N, P, H, score, keys, qx, nbp, nu2, proj, rowhash, prog,
+        int rc = dlc_gemm::sim_filter_prepare(ctx, desc, N, P, H, score, keys, (double*)(ws + w.cc),
+                                              (unsigned long long*)(ws + w.range), qx, nbp, nu2, proj, rowhash, prog,
                                               (const unsigned long long*)range, st);
         if (rc != DLC_OK) return rc;
         // did the range pass meet a NaN or an infinity?  (Their distances are NaN in the reference too, np.argmin then
@@ -1142,6 +1174,12 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         // the COPY's event only -- while the product kernel runs -- before it decides whether the fp64 form has to follow.
         const bool no_sync = (flags & DLC_SIM_NO_HOST_SYNC) != 0;
         if (!no_sync) {
+            // would the filter decide?  (sim_sample_kernel: bit 1 of the same word when it would not)
+            if (N > 1) {
+                hipLaunchKernelGGL(sim_sample_kernel, dim3(SIM_SAMPLES), dim3(256), 0, st, desc, (const unsigned long long*)rowhash, keys,
+                                   (long long)N, (int)P, (int)H);
+                DLC_LAUNCH_CHECK(ctx, "sim_sample_kernel");
+            }
             DLC_HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_flag, keys + 2, 8, hipMemcpyDeviceToHost, st));
             DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_flag, st));
         }
@@ -1162,9 +1200,10 @@ extern "C" int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int6
         }
         if (no_sync) return DLC_OK;
         DLC_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_flag));
-        if (!*(volatile unsigned long long*)ctx->host_flag) return DLC_OK;
-        filter = false;                                     // NaN / infinity in the data: the fp64 form after all
-        if (stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
+        const unsigned long long why = *(volatile unsigned long long*)ctx->host_flag;
+        if (!why) return DLC_OK;
+        filter = false;                 // NaN / infinity in the data, or distances the filter's window swallows: the fp64 form after all
+        if (stats) hipLaunchKernelGGL(sim_stats_kernel, dim3(1), dim3(64), 0, st, (long long*)stats, (long long)why);
     }
 
     // the fp64 Gram route
@@ -1228,15 +1267,16 @@ extern "C" size_t dlc_sdav_stream_state_bytes(int64_t capacity, int64_t P, int64
 }
 
 extern "C" int dlc_sdav_stream_init(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
-                                    double lo, double hi, void* stream) {
+                                    double lo, double hi, const double* col_centre, void* stream) {
     int rc = stream_check(ctx, "sdav_stream_init", state, state_bytes, capacity, P, H);
     if (rc != DLC_OK) return rc;
-    if (!(hi > lo)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_init: need lo < hi");
+    if (!(hi > lo) || !(hi - lo < INFINITY)) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_init: need lo < hi, both finite");
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     const StreamWs w = stream_ws(capacity, P, H);
     char* ws = (char*)state;
-    return dlc_gemm::sim_stream_init(ctx, (unsigned long long*)(ws + w.keys), ws + w.prog, H, lo, hi, (hipStream_t)stream);
+    return dlc_gemm::sim_stream_init(ctx, (unsigned long long*)(ws + w.keys), (double*)(ws + w.cc), ws + w.prog, H, lo, hi,
+                                     col_centre, (hipStream_t)stream);
 }
 
 extern "C" int dlc_sdav_stream_append(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
@@ -1252,7 +1292,8 @@ extern "C" int dlc_sdav_stream_append(dlc_ctx* ctx, void* state, size_t state_by
     const StreamWs w = stream_ws(capacity, P, H);
     char* ws = (char*)state;
     const int64_t g_first = n_old * P / 16, g_last = dlc::cdiv(n_total * P, (int64_t)16);
-    return dlc_gemm::sim_stream_quantise(ctx, desc, n_total * P, H, score, (unsigned long long*)(ws + w.keys), ws + w.panel,
+    return dlc_gemm::sim_stream_quantise(ctx, desc, n_total * P, H, score, (unsigned long long*)(ws + w.keys),
+                                         (const double*)(ws + w.cc), ws + w.panel,
                                          (double*)(ws + w.nu2), (double*)(ws + w.proj), (unsigned long long*)(ws + w.rowhash),
                                          g_first, g_last - g_first, (hipStream_t)stream);
 }
@@ -1283,8 +1324,8 @@ extern "C" int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_byt
                        (unsigned char*)(ws + w.bi), (const int2*)(ws + w.prog));
     DLC_LAUNCH_CHECK(ctx, "stream_argmin_kernel");
     hipLaunchKernelGGL(stream_score_kernel, dim3((unsigned)dlc::cdiv(f, (int64_t)8)), dim3(256), 0, st, desc,
-                       (const double*)(ws + w.proj), score, (const unsigned char*)(ws + w.bi), keys, (long long)f, (int)P, (int)H, a,
-                       b, row_out, (long long*)stats);
+                       (const double*)(ws + w.proj), score, (const unsigned char*)(ws + w.bi), keys, (long long)f, (int)P,
+                       (int)H, a, b, row_out, (long long*)stats);
     DLC_LAUNCH_CHECK(ctx, "stream_score_kernel");
     return DLC_OK;
 }

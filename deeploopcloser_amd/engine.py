@@ -491,12 +491,12 @@ class Engine:
 
     # ---- reference-semantics match ---------------------------------------------------
     def distinctive_score(self, dataset, mu, sigma, with_range=False):
-        """Distinctive score [H] of a dataset [..., H]; with_range=True: (score, range) where range (3 x int64 on the
-        device) is what the pass learned about the dataset's extremes -- pass it to sdav_similarity_matrix(range=) for the
-        SAME tensor and that call does not read the descriptors again to find them."""
+        """Distinctive score [H] of a dataset [..., H]; with_range=True: (score, range) where range (3 + 2 H int64 words on
+        the device) is what the pass learned about the columns' extremes -- pass it to sdav_similarity_matrix(range=) for
+        the SAME tensor and that call does not read the descriptors again to find them."""
         d2 = dataset.reshape(-1, dataset.shape[-1]).contiguous()
         score = torch.empty(d2.shape[1], dtype=torch.float64, device=self.device)
-        rng = torch.empty(3, dtype=torch.int64, device=self.device) if with_range else None
+        rng = torch.empty(self.lib.dlc_sdav_range_words(d2.shape[1]), dtype=torch.int64, device=self.device) if with_range else None
         self._check(self.lib.dlc_sdav_distinctive_score(self.ctx, _ptr(d2), d2.shape[0], d2.shape[1], float(mu),
                                                          float(sigma), _ptr(score), _ptr(rng), self._stream()))
         return (score, rng) if with_range else score
@@ -505,9 +505,11 @@ class Engine:
                                chunk_bytes=0, stats=None, direct_pairs=None, range=None):
         """All-vs-all SDAV similarity of desc [N,P,H] (fp64) -> (out fp64 [N,N], out int64 [N,N] or None).
         force_f64: the fp64 Gram form instead of the int8 arg-min filter (same matrix); no_host_sync: never read the
-        non-finite flag back (graph-capturable; a dataset with NaN / inf then yields NaN and stats[1] = 1);
-        chunk_bytes: bound of one product block (0 = 8 GiB); stats: int64 [2] device tensor, direct_pairs: uint8 [N,N]
-        device tensor marking the frame pairs with a directly evaluated arg-min (include/dlc.h)."""
+        flag word back (graph-capturable; a dataset with NaN / inf then yields NaN and stats[1] = 1, and no sample decides
+        whether the filter is worth running); chunk_bytes: bound of one product block (0 = 8 GiB); stats: int64 [2] device
+        tensor ([0] arg-mins evaluated directly, [1] why the fp64 form ran instead: bit 0 NaN / inf, bit 1 the sample's
+        verdict), direct_pairs: uint8 [N,N] device tensor marking the frame pairs with a directly evaluated arg-min
+        (include/dlc.h)."""
         desc = desc.contiguous()
         n, p, h = desc.shape
         flags = (L.DLC_SIM_FORCE_F64 if force_f64 else 0) | (L.DLC_SIM_NO_HOST_SYNC if no_host_sync else 0)
@@ -516,7 +518,7 @@ class Engine:
         if direct_pairs is not None:
             self._check_out("direct_pairs", direct_pairs, (n, n), torch.uint8)
         if range is not None:
-            self._check_out("range", range, (3,), torch.int64)
+            self._check_out("range", range, (self.lib.dlc_sdav_range_words(h),), torch.int64)
         out = torch.empty((n, n), dtype=torch.float64, device=self.device)
         out_i = torch.empty((n, n), dtype=torch.int64, device=self.device) if want_int64 else None
         need = self.lib.dlc_sdav_similarity_workspace_bytes(n, p, h, flags, int(chunk_bytes))
@@ -527,13 +529,17 @@ class Engine:
         return out, out_i
 
     # ---- streaming similarity: one new frame against the resident older ones (dlc_sdav_stream_*) ----
-    def sdav_stream_state(self, capacity, p, h, lo=0.0, hi=1.0):
+    def sdav_stream_state(self, capacity, p, h, lo=0.0, hi=1.0, col_centre=None):
+        """State of a similarity stream whose values satisfy lo <= x - col_centre[k] <= hi (col_centre: [h] fp64 on the
+        device, or None for zeros)."""
         need = self.lib.dlc_sdav_stream_state_bytes(int(capacity), int(p), int(h))
         if need == 0:
             raise ValueError("streaming similarity: P <= 32 patches and H <= 32768 (got %d, %d)" % (p, h))
+        if col_centre is not None:
+            self._check_out("col_centre", col_centre, (int(h),), torch.float64)
         state = torch.zeros(int(need), dtype=torch.uint8, device=self.device)
         self._check(self.lib.dlc_sdav_stream_init(self.ctx, _ptr(state), state.numel(), int(capacity), int(p), int(h), float(lo),
-                                                   float(hi), self._stream()))
+                                                   float(hi), _ptr(col_centre), self._stream()))
         return state
 
     def sdav_stream_append(self, state, desc, n_old, n_total, score):

@@ -72,15 +72,21 @@ class SimilarityStream:
     score_source: the dataset [N, P, H] whose distinctive score weights the distances (what SimilarityCalculator(dataset)
     computes, :20-27), or that score vector [H] itself; it is fixed for the life of the stream.  value_range: the range the
     descriptors live in (SDAV outputs are sigmoid values: (0, 1)); a value outside it poisons the stream (queries return
-    NaN and say so in .stats) -- the filter's error bound is stated for that range."""
+    NaN and say so in .stats) -- the filter's error bound is stated for that range.  column_centre ([H], optional): the
+    range then bounds x - column_centre[k] instead of x: low-contrast descriptors (every column close to its own mean)
+    want their column means here and a narrow value_range around 0, since the filter's error window is a fixed fraction of
+    the range's width squared."""
 
     def __init__(self, score_source, patches=30, width=2500, capacity=1024, value_range=(0.0, 1.0), mu=0.5, sigma=0.2, a=10,
-                 b=-10, device=None):
+                 b=-10, device=None, column_centre=None):
         self.engine = default_engine(device)
         eng = self.engine
         self.a, self.b = a, b
         self.p, self.h = int(patches), int(width)
         self.range = (float(value_range[0]), float(value_range[1]))
+        self.centre = None if column_centre is None else eng.to_device(column_centre, torch.float64).contiguous()
+        if self.centre is not None and tuple(self.centre.shape) != (self.h,):
+            raise ValueError("column_centre must have the descriptor width %d" % self.h)
         src = eng.to_device(score_source, torch.float64)
         if src.dim() == 1:
             if src.shape[0] != self.h:
@@ -97,7 +103,7 @@ class SimilarityStream:
     def _alloc(self, capacity):
         eng = self.engine
         desc = torch.zeros((capacity, self.p, self.h), dtype=torch.float64, device=eng.device)
-        state = eng.sdav_stream_state(capacity, self.p, self.h, *self.range)
+        state = eng.sdav_stream_state(capacity, self.p, self.h, *self.range, col_centre=self.centre)
         if self._n:
             desc[:self._n] = self.desc[:self._n]
             eng.sdav_stream_append(state, desc, 0, self._n, self.score)      # growing re-quantises once (amortised)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DLC_ABI_VERSION 5
+#define DLC_ABI_VERSION 6
 
 typedef struct dlc_ctx dlc_ctx;
 
@@ -254,10 +254,12 @@ int dlc_quant_gather_i8(dlc_ctx* ctx, const double* const* segs, const int64_t* 
  * (src/sdav/similarity/SimilarityCalculator.py:20-27): column mean (rows
  * summed in order, as np.average does), then exp(-(avg-mu)^2 / (2 sigma^2)).
  * The reference recomputes this for every pair (:13-14); it is hoisted here.
- * range (DEVICE, 3 x uint64, may be NULL): the pass sees every element once and can leave what the similarity's filter
- * form needs to know about THIS dataset -- ordered keys of its minimum and maximum, a NaN / infinity flag; hand it to
- * dlc_sdav_similarity_matrix called on the same descriptors and that call skips its own pass over them.
+ * range (DEVICE, dlc_sdav_range_words(H) = 3 + 2 H x uint64, may be NULL): the pass sees every element once and can leave
+ * what the similarity's filter form needs to know about THIS dataset -- every column's minimum and maximum (ordered
+ * keys) and a NaN / infinity flag; hand it to dlc_sdav_similarity_matrix called on the same descriptors and that call
+ * skips its own pass over them.
  */
+size_t dlc_sdav_range_words(int64_t H);
 int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows, int64_t H,
                                double mu, double sigma, double* score, uint64_t* range, void* stream);
 /*
@@ -270,28 +272,35 @@ int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, int64_t rows
  * the reference's int64 matrix (truncation toward zero, non-finite -> INT64_MIN).
  * What the reference takes from the patch-to-patch distances is the arg-min only (np.argmin of
  * np.linalg.norm, :30-37).  For P <= 32 and H <= 32768 it is decided by exact integer products of
- * the descriptors' 21-bit fixed-point values (int8 MFMA, csrc/gram_i8.hip), whose error bound says
+ * 24-bit fixed-point values of the descriptors' offsets from their COLUMN's centre (a per-column offset
+ * changes no distance; int8 MFMA on three signed digits, csrc/gram_i8.hip), whose error bound says
  * which candidates it cannot separate; those are evaluated directly in fp64, and where that is
  * still a tie to 1e-11, as np.linalg.norm forms them (NumPy's pairwise summation order).  Other
- * shapes, a dataset with a NaN or an infinity in it, or DLC_SIM_FORCE_F64 in `flags` take the fp64
- * Gram matrix (|a|^2 + |b|^2 - 2 a.b).
+ * shapes, a dataset with a NaN or an infinity in it, a dataset on which a sample of 256 (patch, frame)
+ * cells says the bound would leave more than an eighth of the arg-mins undecided (distances far below
+ * the largest column range: the direct evaluations would cost more than the fp64 form), or
+ * DLC_SIM_FORCE_F64 in `flags` take the fp64 Gram matrix (|a|^2 + |b|^2 - 2 a.b) -- the same matrix.
  * flags:
  *   DLC_SIM_FORCE_F64     the fp64 Gram form whatever the shape (same matrix; checker / experiments);
  *   DLC_SIM_NO_HOST_SYNC  the filter form reads ONE 8-byte flag back to the host (did the range pass
- *                         meet a NaN / infinity? -- it then has to take the fp64 form): the only
+ *                         meet a NaN / infinity, did the sample say "undecidable"? -- it then has to
+ *                         take the fp64 form): the only
  *                         blocking read of this library's stream-ordered calls (the host waits for that
  *                         copy alone, with the filter form's kernels already enqueued behind it: the call
  *                         returns when the quantisation pass is done).  With this flag the
- *                         call never synchronises (and can be captured in a hipGraph); on a dataset
- *                         with a NaN / infinity the matrix then comes back as NaN / INT64_MIN and
- *                         stats[1] = 1, and the caller repeats the call with DLC_SIM_FORCE_F64.
+ *                         call never synchronises (and can be captured in a hipGraph) and takes no
+ *                         sample (undecided arg-mins are evaluated directly however many there are:
+ *                         correct, possibly slow); on a dataset with a NaN / infinity the matrix then
+ *                         comes back as NaN / INT64_MIN and stats[1] = 1, and the caller repeats the
+ *                         call with DLC_SIM_FORCE_F64.
  * chunk_bytes: upper bound of one fp64 Gram block in the workspace (0 = 8 GiB; the filter form keeps no
  * product block at all: its product kernel emits the arg-mins); pass the same value to the
  * workspace-size function.
  * range (DEVICE, may be NULL): what dlc_sdav_distinctive_score left for the SAME desc (pointer, N*P rows, H):
  * the filter form then does not read the descriptors a second time to find their extremes.
  * stats (DEVICE, 2 int64, may be NULL): [0] arg-mins the integer bound could not decide (evaluated
- * directly in fp64), [1] 1 when the dataset held a NaN / infinity.  direct_pairs (DEVICE, [N,N]
+ * directly in fp64), [1] why the filter form did not take the call: 0 it did, bit 0 the dataset held a
+ * NaN / infinity, bit 1 the sample's verdict (both: the fp64 form ran, [0] = 0).  direct_pairs (DEVICE, [N,N]
  * bytes, may be NULL): 1 at [i, j], i < j, when at least one arg-min of that frame pair was evaluated
  * directly (the pairs a checker wants to look at first), 0 elsewhere.
  * The workspace holds the quantised descriptors and the product kernel's verdicts (filter form: 0.91 GB
@@ -313,19 +322,22 @@ int dlc_sdav_similarity_matrix(dlc_ctx* ctx, const double* desc, int64_t N, int6
  * bit (same arg-min rule, same terms, same summation order).  P <= 32, H <= 32768.
  * The caller keeps the descriptors desc[capacity, P, H] (fp64, frames in arrival order) and an opaque `state` of
  * dlc_sdav_stream_state_bytes() bytes (256-byte aligned) holding what the filter needs of every resident frame: the
- * 21-bit fixed-point panel, |u|^2, projections on `score`, content hashes.  The fixed-point range [lo, hi] is FIXED at
- * init (SDAV descriptors are sigmoid outputs: 0, 1), so appending never re-quantises older frames.
+ * 24-bit fixed-point panel, |v|^2, projections on `score`, content hashes.  The fixed-point range is FIXED at init, so
+ * appending never re-quantises older frames: every value x of column k must satisfy lo <= x - col_centre[k] <= hi
+ * (col_centre: DEVICE, H doubles, or NULL for zeros -- SDAV descriptors are sigmoid outputs: NULL, 0, 1; low-contrast
+ * descriptors, whose columns each stay close to their own mean, want that mean here and a narrow [lo, hi]: the filter's
+ * error window is a fixed fraction of (hi - lo)^2).
  *   dlc_sdav_stream_init    once (and again after growing: init + append of everything);
  *   dlc_sdav_stream_append  frames [n_old, n_total) of desc have arrived: quantise them (`score` = the distinctive
  *                           score the rows are projected on; it must stay the same for the life of the state);
  *   dlc_sdav_stream_query   row_out[0 .. f-1] for the resident frame f (normally the newest).  stats (DEVICE, 2 int64,
  *                           may be NULL): [0] arg-mins evaluated directly, [1] 1 when some appended value lay outside
- *                           [lo, hi] or was not finite -- the error bound does not hold then and row_out is NaN.
+ *                           that range or was not finite -- the error bound does not hold then and row_out is NaN.
  * All three are stream-ordered and never synchronise.  A query reads the panel once (245 MB at 1063 frames).
  */
 size_t dlc_sdav_stream_state_bytes(int64_t capacity, int64_t P, int64_t H);
 int dlc_sdav_stream_init(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
-                         double lo, double hi, void* stream);
+                         double lo, double hi, const double* col_centre, void* stream);
 int dlc_sdav_stream_append(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
                            const double* desc, int64_t n_old, int64_t n_total, const double* score, void* stream);
 int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,

@@ -1,5 +1,5 @@
 """The SDAV similarity matrix at the reference's size (1063 frames x 30 patches x 2500) a few times, for rocprofv3:
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sim -- python3 scripts/prof_similarity.py [saturated|uniform|duplicates|twins|binary] [library]"""
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_sim -- python3 scripts/prof_similarity.py [saturated|uniform|duplicates|twins|binary|real|real_fan_in] [library]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,6 +23,11 @@ elif kind == "duplicates":                 # every fifth patch a copy of another
 elif kind == "twins":                      # in every frame patches 1, 3, 5 are copies of 0, 2, 4: a fifth of all arg-mins are exact ties
     ds = torch.sigmoid(35.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
     ds[:, 1] = ds[:, 0]; ds[:, 3] = ds[:, 2]; ds[:, 5] = ds[:, 4]
+elif kind in ("real", "real_fan_in"):      # the repo's 20 real frames tiled to 1063, N(0,1) / 1/sqrt(fan_in) weights
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import real_frames
+    xs = real_frames.tiled_patches(dlc, n)
+    ds = dlc.SDAV(seed=4, weight_scale="fan_in" if kind == "real_fan_in" else "reference").transform_tensor(xs).reshape(n, p, h)
 elif kind == "binary":                     # zeros and ones only: every squared distance an integer, ties between DIFFERENT patches
     ds = (torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64) < 0.5).double()
 else:
@@ -30,6 +35,7 @@ else:
 for rep in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     score, rng = eng.distinctive_score(ds, 0.5, 0.2, with_range=True)      # as SimilarityCalculator(dataset).similarity_matrix()
-    mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, range=rng)
+    stats = torch.zeros((2,), dtype=torch.int64, device=eng.device)
+    mf, mi = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, range=rng, stats=stats)
     torch.cuda.synchronize()
-    print("%s: %.2f ms" % (kind, (time.perf_counter() - t0) * 1e3), flush=True)
+    print("%s: %.2f ms, stats %s" % (kind, (time.perf_counter() - t0) * 1e3, stats.tolist()), flush=True)

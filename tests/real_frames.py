@@ -1,0 +1,39 @@
+"""The 20 real frames of the reference's datasets/test (tests/golden/frames + tests/golden/datasets_test: data files) tiled
+to any number of frames -- real-image statistics at BASELINE configs[1]'s full size (the reference's
+outdoor_kennedylong is 1063 such frames; the repo carries 20).  Used by tests/test_gpu_fullsize.py and by bench.py's
+`paths` rows; no oracle import (bench.py's product legs load this)."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def frame_paths():
+    paths = glob.glob(os.path.join(GOLDEN, "frames", "*.ppm")) + glob.glob(os.path.join(GOLDEN, "datasets_test", "*.ppm"))
+    return sorted(paths, key=os.path.basename)
+
+
+def tiled_patches(dlc, n_frames):
+    """[n_frames, 30, 1681] fp64 on the device: the real frames through the GPU front-end (grey, Harris, patches), then copies:
+    copies 0 and 1 exact (identical descriptors: +inf scores, every arg-min a tie of bit-identical rows), later ones with a
+    few pixels moved by 1/255, every fifth one also with blank patches and a key-point found twice."""
+    import torch
+    parser = dlc.CvInputParser(30, 41)
+    x = parser.parse_batch(np.stack([dlc.read_ppm(p) for p in frame_paths()]))     # [20, 30, 1681] on the device
+    rng = np.random.RandomState(8)
+    tiles, have, c = [x], x.shape[0], 0
+    while have < n_frames:
+        t = x.clone()
+        if c >= 2:
+            for f in range(x.shape[0]):
+                for _ in range(1 + c % 10):
+                    t[f, rng.randint(30), rng.randint(1681)] += (1.0 if rng.rand() < 0.5 else -1.0) / 255.0
+            t.clamp_(0.0, 1.0)
+        if c >= 6 and c % 5 == 1:
+            t[:, 3] = 0.0; t[:, 4] = 0.0; t[::2, 9] = t[::2, 8]                    # blank patches, a key-point found twice
+        tiles.append(t)
+        have += t.shape[0]
+        c += 1
+    return torch.cat(tiles)[:n_frames]

@@ -686,6 +686,67 @@ def test_similarity_filter_equals_fp64_gram_route(eng, monkeypatch):
     assert torch.equal(f_a, f_b) and torch.equal(i_a, i_b) and stats.tolist()[1] == 0 and stats.tolist()[0] >= 0
 
 
+def _low_contrast(shape, g, device, spread=1e-3):
+    """Descriptors whose columns each stay within ~spread of their own mean while the means spread over [0.15, 0.88]: what
+    real frames give through 1/sqrt(fan_in) weights."""
+    n, p, h = shape
+    means = 0.15 + 0.73 * torch.rand((h,), generator=g, device=device, dtype=torch.float64)
+    return means + spread * torch.randn(shape, generator=g, device=device, dtype=torch.float64)
+
+
+def test_similarity_filter_low_contrast_columns(eng):
+    """The filter quantises x - centre of the COLUMN (a per-column offset changes no distance): low-contrast descriptors,
+    on which a global range left every arg-min inside the error window, are decided by the int8 products --
+    filter == fp64 form bit for bit, the filter keeps the call, and only a small fraction of arg-mins is evaluated directly;
+    also with a distinctive-score range handed over, and for columns that are constant (range 0) next to live ones."""
+    g = torch.Generator(device=eng.device); g.manual_seed(31)
+    for n, p, h in [(40, 30, 2500), (60, 13, 300), (30, 32, 1024)]:
+        ds = _low_contrast((n, p, h), g, eng.device)
+        ds[:, :, 5] = 0.321                                               # a constant column
+        score, rng = eng.distinctive_score(ds, 0.5, 0.2, with_range=True)
+        stats = torch.zeros((2,), dtype=torch.int64, device=eng.device)
+        f_ref, i_ref = (t.clone() for t in eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, force_f64=True))
+        for r in (None, rng):
+            f_got, i_got = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, stats=stats, range=r)
+            assert torch.equal(f_got, f_ref) and torch.equal(i_got, i_ref), (n, p, h)
+            direct, why = stats.tolist()
+            assert why == 0 and direct <= 0.02 * (n * (n - 1) // 2 * p), (n, p, h, direct, why)
+
+
+def test_similarity_filter_exit_to_fp64_route(eng):
+    """The filter's exit: one column with a range a million times the others' leaves every distance inside the error window
+    (the scale is the LARGEST column range).  The sample taken before the product kernel says so, the call takes the fp64
+    Gram form -- same matrix as DLC_SIM_FORCE_F64, == the oracle -- and reports it (stats = [0, 2]); under
+    DLC_SIM_NO_HOST_SYNC nobody can act on a verdict, the filter runs and evaluates its arg-mins directly: the same matrix."""
+    from oracle import similarity as osim
+    g = torch.Generator(device=eng.device); g.manual_seed(32)
+    n, p, h = 24, 30, 512
+    ds = 0.5 + 1e-7 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
+    ds[:, :, 0] = torch.rand((n, p), generator=g, device=eng.device, dtype=torch.float64) < 0.001   # a rare spike column: 0 / 1
+    ds[0, 0, 0] = 1.0
+    score = eng.distinctive_score(ds, 0.5, 0.2)
+    stats = torch.full((2,), -7, dtype=torch.int64, device=eng.device)
+    f_ref, i_ref = (t.clone() for t in eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, force_f64=True))
+    f_got, i_got = (t.clone() for t in eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, stats=stats))
+    assert stats.tolist() == [0, 2]
+    assert torch.equal(f_got, f_ref) and torch.equal(i_got, i_ref)
+    f_ns, i_ns = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, stats=stats, no_host_sync=True)
+    direct, why = stats.tolist()
+    assert why == 0 and direct > 0.5 * (n * (n - 1) // 2 * p)
+    assert torch.equal(f_ns, f_ref) and torch.equal(i_ns, i_ref)
+    dsn, sc, mf = ds.cpu().numpy(), score.cpu().numpy(), f_got.cpu().numpy()
+    rng = np.random.RandomState(3)
+    for _ in range(12):
+        i, j = sorted(rng.choice(n, 2, replace=False))
+        d = osim.weighted_distances(dsn[i], dsn[j], osim.match_features(dsn[i], dsn[j]), sc)
+        want = np.sum(10 - 10 * np.log(d))
+        assert abs(mf[i, j] - want) <= 1e-9 * abs(want), (i, j)
+    # benign data: the sample lets the filter keep the call
+    ok = torch.rand((n, p, h), generator=g, device=eng.device, dtype=torch.float64)
+    eng.sdav_similarity_matrix(ok, eng.distinctive_score(ok, 0.5, 0.2), 10.0, -10.0, stats=stats)
+    assert stats.tolist()[1] == 0
+
+
 def test_similarity_filter_in_row_chunks(eng, monkeypatch):
     """The product block in several row chunks (chunk_bytes shrinks the 8 GiB cap): chunk origins that are not
     multiples of the panels' 16-patch groups, for patch counts that are and are not; the same matrix as in one chunk."""
@@ -1354,18 +1415,19 @@ def test_engine_workspaces_are_bounded_per_name(eng):
 
 
 def test_similarity_range_from_the_distinctive_pass(eng, dlc):
-    """dlc_sdav_distinctive_score can leave the dataset's extremes and its NaN / infinity flag for dlc_sdav_similarity_matrix
-    (the filter form then reads the descriptors once less): same matrix as without; the flag routes a dataset with a NaN to
-    the fp64 form as before; the class uses it for its own dataset only."""
+    """dlc_sdav_distinctive_score can leave every column's extremes and the NaN / infinity flag for
+    dlc_sdav_similarity_matrix (the filter form then reads the descriptors once less): same matrix as without; the flag
+    routes a dataset with a NaN to the fp64 form as before; the class uses it for its own dataset only."""
     g = torch.Generator(device=eng.device); g.manual_seed(12)
     ds = 3.0 * torch.randn((40, 30, 250), generator=g, device=eng.device, dtype=torch.float64) - 1.0
     score, rng = eng.distinctive_score(ds, 0.5, 0.2, with_range=True)
     assert torch.equal(score, eng.distinctive_score(ds, 0.5, 0.2))
-    lo, hi = float(ds.min()), float(ds.max())
+    cols = ds.reshape(-1, 250).cpu().numpy()
     key = lambda v: int(np.frombuffer(np.float64(v).tobytes(), dtype=np.uint64)[0])
     okey = lambda v: (~key(v)) & (2 ** 64 - 1) if key(v) >> 63 else key(v) | (1 << 63)
     got = [int(x) & (2 ** 64 - 1) for x in rng.cpu().tolist()]
-    assert got == [okey(lo), okey(hi), 0]
+    assert len(got) == 3 + 2 * 250 and got[2] == 0
+    assert got[3:253] == [okey(v) for v in cols.min(0)] and got[253:] == [okey(v) for v in cols.max(0)]
     a = [t.clone() for t in eng.sdav_similarity_matrix(ds, score, 10.0, -10.0)]
     b = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, range=rng)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
