@@ -682,7 +682,12 @@ def main():
         # and complete before the closing fence (torch.cuda.synchronize waits for all streams).
         if pipe is None:
             return sharded.match_topk(queries, k)
-        last[0] = pipe.submit(queries)
+        t = last[0] = pipe.submit(queries)
+        # every batch's result is fetched, depth - 1 batches behind the submission (the pipeline stays full): an
+        # uncertified batch's exhaustive round (collectives + fp64 pass, MatchPipeline._resolve) runs inside result()
+        # and so inside the timed region, and resolved_batches counts them all
+        if t >= pipe.depth - 1:
+            pipe.result(t - (pipe.depth - 1))
         return None
 
     def fence():
@@ -741,6 +746,8 @@ def main():
             # digests of the timed result (the same database and queries whatever --gpus is): equal across rank counts
             "topk_idx_sha256": idx_sha, "topk_scores_sha256": scores_sha,
             "rccl_ranks": world if world > 1 else None, "rccl_smoke": smoke,
+            "pipeline": {"depth": pipe.depth, "resolved_batches": pipe.resolved_batches,
+                         "dropped_batches": pipe.dropped_batches} if pipe is not None else None,
             "collective_us": smoke["collective_us"] if smoke else None,
             # traffic: HBM bytes per launch from the rocprofv3 PMC passes of this same command, as committed under
             # profiles/ (bench.py cannot run the profiler on itself): a REPLAYED figure, not measured in this run

@@ -57,6 +57,7 @@ SIGNATURES = {
     "dlc_sdav_similarity_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _i64]),
     "dlc_sdav_similarity_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _int, _i64, _vp, _vp, _vp,
                                          _vp, _sz, _vp]),
+    "dlc_topk_rows_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
     "dlc_sdav_stream_state_bytes": (_sz, [_i64, _i64, _i64]),
     "dlc_sdav_stream_init": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _dbl, _dbl, _vp, _vp]),
     "dlc_sdav_stream_append": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),

@@ -939,6 +939,54 @@ __global__ __launch_bounds__(256) void stream_score_kernel(const double* __restr
     if (pair_ok && a == 0) row[j] = keys[2] ? __longlong_as_double(0x7ff8000000000000ll) : term;
 }
 
+// The k best entries of every row of an fp64 score matrix (the loop-closure candidates of a batch of streamed frames,
+// loop_closure.py: SdavLoopClosureDetector): row r offers its first limit0 + r * limit_step entries; order: score
+// descending, ties -> the lower index (the older frame); a NaN is never taken.  One workgroup per row, k rounds of
+// "the best entry after the last one taken" -- rows of a few thousand scores, k a handful: microseconds.
+__global__ __launch_bounds__(256) void topk_rows_f64_kernel(const double* __restrict__ scores, long long ld, long long limit0,
+                                                            long long limit_step, int k, double* __restrict__ out_s,
+                                                            long long* __restrict__ out_i) {
+    __shared__ unsigned long long red_k[4];
+    __shared__ long long red_i[4];
+    const long long r = blockIdx.x;
+    long long n = limit0 + r * limit_step;
+    if (n > ld) n = ld;
+    const double* row = scores + r * ld;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long last_k = ~0ull;                            // key of the last entry taken (keys order like the doubles)
+    long long last_i = -1;
+    for (int t = 0; t < k; ++t) {
+        unsigned long long bk = 0ull;                            // (0 is below every key of a number: "none")
+        long long bi = 0x7fffffffffffffffll;
+        for (long long i = threadIdx.x; i < n; i += 256) {
+            const double v = row[i];
+            if (v != v) continue;
+            const unsigned long long kk = dlc_f64_key(v);
+            const bool after = kk < last_k || (kk == last_k && i > last_i);
+            if (after && (kk > bk || (kk == bk && i < bi))) { bk = kk; bi = i; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ok = ((unsigned long long)(unsigned)__shfl_xor((int)(bk >> 32), o) << 32) | (unsigned)__shfl_xor((int)bk, o);
+            const long long oi = (long long)(((unsigned long long)(unsigned)__shfl_xor((int)((unsigned long long)bi >> 32), o) << 32) |
+                                             (unsigned)__shfl_xor((int)bi, o));
+            if (ok > bk || (ok == bk && oi < bi)) { bk = ok; bi = oi; }
+        }
+        __syncthreads();                                         // (the previous round's reads of red_* are done)
+        if (lane == 0) { red_k[w] = bk; red_i[w] = bi; }
+        __syncthreads();
+        bk = red_k[0]; bi = red_i[0];
+        for (int ww = 1; ww < 4; ++ww)
+            if (red_k[ww] > bk || (red_k[ww] == bk && red_i[ww] < bi)) { bk = red_k[ww]; bi = red_i[ww]; }
+        const bool none = bk == 0ull;
+        if (threadIdx.x == 0) {
+            out_s[r * k + t] = none ? -INFINITY : dlc_f64_unkey(bk);
+            out_i[r * k + t] = none ? -1 : bi;
+        }
+        if (none) { last_k = 0ull; last_i = 0x7fffffffffffffffll; }   // nothing is after "none": the remaining slots stay empty
+        else { last_k = bk; last_i = bi; }
+    }
+}
+
 struct StreamWs {
     size_t keys, prog, cc, nu2, proj, rowhash, bi, panel, total;
 };
@@ -1327,5 +1375,18 @@ extern "C" int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_byt
                        (const double*)(ws + w.proj), score, (const unsigned char*)(ws + w.bi), keys, (long long)f, (int)P,
                        (int)H, a, b, row_out, (long long*)stats);
     DLC_LAUNCH_CHECK(ctx, "stream_score_kernel");
+    return DLC_OK;
+}
+
+extern "C" int dlc_topk_rows_f64(dlc_ctx* ctx, const double* scores, int64_t rows, int64_t ld, int64_t limit0, int64_t limit_step,
+                                 int k, double* out_scores, int64_t* out_idx, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!scores || !out_scores || !out_idx || rows < 1 || ld < 1 || k < 1 || k > DLC_MAX_K || rows > 0x7fffffffll)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "topk_rows_f64: bad argument");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    hipLaunchKernelGGL(topk_rows_f64_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, scores, (long long)ld,
+                       (long long)limit0, (long long)limit_step, k, out_scores, (long long*)out_idx);
+    DLC_LAUNCH_CHECK(ctx, "topk_rows_f64_kernel");
     return DLC_OK;
 }

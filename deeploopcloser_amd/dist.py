@@ -71,7 +71,10 @@ class ShardedKeyframeDatabase:
             pipe = self._pipes.get(k)
             if pipe is None:
                 pipe = self._pipes[k] = MatchPipeline(self._db, k, depth=1, group=self.group)
-            return pipe.result(pipe.submit(queries))
+            # (the pipeline hands out its slot's reusable buffers; every branch of this method returns tensors the
+            # caller owns, so the next call must not overwrite them)
+            s, i = pipe.result(pipe.submit(queries))
+            return s.clone(), i.clone()
         s, i = self.local_topk(queries, k)
         if self.world == 1:
             return s, i

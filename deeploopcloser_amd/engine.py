@@ -557,6 +557,17 @@ class Engine:
                                                     float(a), float(b), _ptr(out), _ptr(stats), self._stream()))
         return out
 
+    def topk_rows_f64(self, scores, limit0, limit_step, k):
+        """(scores [rows, k] fp64, idx [rows, k] int64) of the k best of the first limit0 + r * limit_step entries of row r of
+        scores [rows, ld] (fp64): score descending, ties -> the lower index, NaN never; (-inf, -1) where fewer."""
+        self._check_out("scores", scores, tuple(scores.shape), torch.float64)
+        rows, ld = scores.shape
+        o_s = torch.empty((rows, k), dtype=torch.float64, device=self.device)
+        o_i = torch.empty((rows, k), dtype=torch.int64, device=self.device)
+        self._check(self.lib.dlc_topk_rows_f64(self.ctx, _ptr(scores), rows, ld, int(limit0), int(limit_step), int(k), _ptr(o_s),
+                                                _ptr(o_i), self._stream()))
+        return o_s, o_i
+
     def cnnvtl_distance_matrix(self, desc, d=None, out=None):
         """All-vs-all popcount(|a ^ b|) distances of int8 descriptors [N, D] -> int64 [N, N].  d: the descriptor length
         when desc's rows are padded (to a multiple of 4 bytes); out: a caller-kept [N, N] int64 tensor."""

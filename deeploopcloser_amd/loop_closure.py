@@ -126,24 +126,32 @@ class SdavLoopClosureDetector:
     def query_and_insert(self, frames):
         """frames [B, P, H] (ids len(self) .. + B - 1) -> (scores [B, k] float64, ids [B, k] int64) on the device, best first,
         (-inf, -1) where fewer than k frames are old enough; the frames are resident afterwards."""
-        x = self.stream.engine.to_device(frames, torch.float64)
+        st = self.stream
+        eng = st.engine
+        x = eng.to_device(frames, torch.float64)
         if x.dim() == 2:
             x = x.unsqueeze(0)
-        dev, k = self.stream.engine.device, self.k
-        out_s = torch.full((x.shape[0], k), float("-inf"), dtype=torch.float64, device=dev)
-        out_i = torch.full((x.shape[0], k), -1, dtype=torch.int64, device=dev)
-        for r in range(x.shape[0]):
-            row = self.stream.query_and_insert(x[r])
-            n_see = len(self.stream) - 1 - self.exclusion
-            if n_see <= 0:
-                continue
-            s, i = torch.sort(row[:n_see], descending=True, stable=True)       # ties: the lower (older) index first
-            m = min(k, n_see)
-            out_s[r, :m], out_i[r, :m] = s[:m], i[:m]
-        return out_s, out_i
+        b = x.shape[0]
+        first = st.append(x)                                          # all B frames become resident: one quantisation launch
+        rows = torch.empty((b, first + b), dtype=torch.float64, device=eng.device)
+        for r in range(b):                                            # frame first + r against every older frame: rows[r, :first + r]
+            if first + r > 0:
+                st.query(first + r, out=rows[r, :first + r])
+        # the k best of the frames old enough -- one launch for the batch (dlc_topk_rows_f64: score descending, ties ->
+        # the older frame; a poisoned stream's NaN rows yield nothing here and loops() raises)
+        return eng.topk_rows_f64(rows, first - self.exclusion, 1, self.k)
+
+    def _check_poison(self):
+        if int(self.stream.stats[1]) != 0:
+            raise RuntimeError("SdavLoopClosureDetector: a descriptor value outside the stream's fixed range (or a NaN / "
+                               "infinity) was appended -- the filter's error bound does not hold, every later row is NaN; "
+                               "create the stream with a value_range / column_centre that covers the data")
 
     def loops(self, scores, ids, first_id):
+        """[(frame id, older frame id, score)] at or above the threshold; raises when the stream has been poisoned (a value
+        outside its fixed range: SimilarityStream.stats[1])."""
         s, i = scores.cpu().numpy(), ids.cpu().numpy()
+        self._check_poison()
         return [(first_id + r, int(i[r, c]), float(s[r, c])) for r in range(s.shape[0]) for c in range(s.shape[1])
                 if i[r, c] >= 0 and s[r, c] >= self.threshold]
 

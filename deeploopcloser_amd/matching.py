@@ -163,7 +163,9 @@ class MatchPipeline:
     `depth` batches are in flight, each with its own workspace and output buffers; submit() returns
     a ticket, result(ticket) waits for that batch only.  A result must be fetched before `depth`
     further batches are submitted (its buffers are then reused), and all ranks must call submit() /
-    result() in the same order (they carry collectives).
+    result() in the same order (they carry collectives).  A batch whose ticket is never fetched is DROPPED when its
+    slot comes round again -- the exhaustive round of an uncertified batch runs only inside result() -- and counted in
+    `dropped_batches`; (scores, idx) of result() alias the slot's buffers until then.
     """
 
     def __init__(self, db, k, depth=2, group=None, queries_per_batch=None):
@@ -178,6 +180,7 @@ class MatchPipeline:
         self._count = 0
         self._nq = queries_per_batch
         self.resolved_batches = 0          # batches that needed the exhaustive round (sharded)
+        self.dropped_batches = 0           # batches whose slot was reused before result() fetched them
         self.time_collectives = False      # record events around the two all-gathers of every batch (collective_us())
         self._coll_events = []
 
@@ -194,7 +197,8 @@ class MatchPipeline:
             s = {"nq": nq, "n": len(self.db), "ws": torch.empty(need, dtype=torch.uint8, device=dev),
                  "scores": torch.empty((nq, k), dtype=torch.float32, device=dev),
                  "idx": torch.empty((nq, k), dtype=torch.int64, device=dev),
-                 "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "q": None, "rows": None}
+                 "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "fetched": True, "q": None,
+                 "rows": None}
             if self.world > 1:
                 kg = eng.groups_per_query(k)
                 nb = nq * k * 16                           # packed part: int64 rows [nq,k] | float64 scores [nq,k]
@@ -208,7 +212,7 @@ class MatchPipeline:
                 s["bound"] = torch.empty((nq,), dtype=torch.float32, device=dev)
                 s["m_s64"] = torch.empty((nq, k), dtype=torch.float64, device=dev)
                 s["status"] = torch.empty((nq,), dtype=torch.int32, device=dev)
-                s["flag"] = torch.zeros((1,), dtype=torch.int32).pin_memory()
+                s["flag"] = torch.zeros((nq,), dtype=torch.int32).pin_memory()       # the merge's per-query status, on the host
                 # every shard's score pass errs by at most its plan's tau; the unsplit plan's is the largest
                 s["tau"] = max(eng.score_error_bound(nq, len(self.db), d, k), eng.score_error_bound(nq, 1 << 30, d, k))
             self._slots[i] = s
@@ -223,6 +227,8 @@ class MatchPipeline:
         main = torch.cuda.current_stream(eng.device)
         if s["busy"]:
             main.wait_event(s["done"])          # the workspace / outputs of this slot are free again
+            if not s["fetched"]:
+                self.dropped_batches += 1       # (its exhaustive round, if it needed one, never ran: nobody asked for the result)
         s["q"] = q                              # keep the stored queries alive until the batch is done
         # ... and the database rows: append() may replace the store (reserve) while this batch's
         # selection / re-score still gathers rows from the old one on the second stream
@@ -253,9 +259,10 @@ class MatchPipeline:
                     self._coll_events.append(ev)
                 eng.topk_merge_packed(s["g_pack"], q.shape[0], self.k, out=(s["scores"], s["idx"]), bound=s["bound"],
                                       tau=s["tau"], scores_f64=s["m_s64"], status=s["status"])
-                s["flag"].copy_(s["status"].max().reshape(1), non_blocking=True)
+                s["flag"].copy_(s["status"], non_blocking=True)
             s["done"].record(self.s_select)
         s["busy"] = True
+        s["fetched"] = False
         self._count += 1
         return self._count - 1
 
@@ -274,10 +281,14 @@ class MatchPipeline:
         self.resolved_batches += 1
 
     def result(self, ticket):
+        if not self._count - self.depth <= ticket < self._count:
+            raise ValueError("MatchPipeline.result: ticket %d is not in flight (last submitted: %d, depth %d)"
+                             % (ticket, self._count - 1, self.depth))
         s = self._slots[ticket % self.depth]
         s["done"].synchronize()
-        if self.world > 1 and int(s["flag"][0]) != 0:
-            s["flag"][0] = 0
+        s["fetched"] = True
+        if self.world > 1 and bool(s["flag"].any()):
+            s["flag"].zero_()
             self._resolve(s)
         return s["scores"], s["idx"]
 

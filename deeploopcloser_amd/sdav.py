@@ -192,9 +192,12 @@ class SDAV:
         if x.shape[0] < 2:
             raise ValueError("a training batch needs at least 2 frames (the consecutive-frame loss term)")
         eng = self.engine
-        # everything the captured launches point at: the parameters, the split-K scratch of latency_mode
+        # everything the captured launches point at -- the parameters, the split-K scratch of latency_mode -- and every
+        # scalar they carry: the hyper-parameters are kernel arguments baked into the captured graph, so a change
+        # (a learning-rate decay between batches) must force a new capture, as the eager train_step would honour it
         sig = (tuple(w.data_ptr() for w in self._weights), tuple(b.data_ptr() for b in self._biases),
-               self._biases_dec[layer_n].data_ptr(), eng._scratch.data_ptr() if eng._scratch is not None else 0)
+               self._biases_dec[layer_n].data_ptr(), eng._scratch.data_ptr() if eng._scratch is not None else 0,
+               float(self.learning_rate), float(self.sparse_level), float(self.sparse_penalty), float(self.consecutive_penalty))
         key = (layer_n, x.shape[0])
         g = self._step_graphs.get(key)
         if g is None or g["sig"] != sig:

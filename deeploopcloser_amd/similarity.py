@@ -127,12 +127,15 @@ class SimilarityStream:
         self._n = first + b
         return first
 
-    def query(self, f=None):
-        """Device tensor [f] of score(h_j, h_f), j < f, for the resident frame f (default: the newest)."""
+    def query(self, f=None, out=None):
+        """Device tensor [f] of score(h_j, h_f), j < f, for the resident frame f (default: the newest); out: a contiguous
+        fp64 device tensor of f entries to write into."""
         f = self._n - 1 if f is None else int(f)
         if not 0 <= f < self._n:
             raise ValueError("frame %d is not resident (0..%d)" % (f, self._n - 1))
-        return self.engine.sdav_stream_query(self.state, self.desc, f, self.score, self.a, self.b, stats=self.stats)
+        if out is not None and (out.dtype != torch.float64 or out.numel() != f or not out.is_contiguous()):
+            raise ValueError("query: out must be a contiguous float64 tensor of %d entries" % f)
+        return self.engine.sdav_stream_query(self.state, self.desc, f, self.score, self.a, self.b, out=out, stats=self.stats)
 
     def query_and_insert(self, frame):
         """One new frame [P, H]: it becomes resident and its row against all older frames comes back (device, fp64)."""

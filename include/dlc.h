@@ -344,6 +344,14 @@ int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t
                           const double* desc, int64_t f, const double* score, double a, double b, double* row_out,
                           int64_t* stats, void* stream);
 /*
+ * The k best entries of every row of an fp64 score matrix scores [rows, ld] -- the loop-closure candidates of a batch of
+ * streamed frames (rows of dlc_sdav_stream_query): row r offers its first min(ld, limit0 + r * limit_step) entries (none
+ * when that is <= 0); order: score descending, ties -> the lower index (the older frame); a NaN is never taken.
+ * out_scores / out_idx [rows, k]: (-inf, -1) where a row offers fewer than k.  1 <= k <= DLC_MAX_K.
+ */
+int dlc_topk_rows_f64(dlc_ctx* ctx, const double* scores, int64_t rows, int64_t ld, int64_t limit0, int64_t limit_step,
+                      int k, double* out_scores, int64_t* out_idx, void* stream);
+/*
  * All-vs-all cnn_vtl distance: DistanceCalculator.calculate_distance
  * (src/cnn_vtl/similarity/DistanceCalculator.py:4-12) = sum_k popcount(|a_k ^ b_k|)
  * on signed int8, for the full N x N loop incl. the diagonal

@@ -232,3 +232,48 @@ def test_similarity_stream_vs_oracle_on_real_frames_and_poison():
     bad[4, 7] = 1.25                                              # outside (0, 1): the fixed-point bound does not cover it
     row = det.stream.query_and_insert(bad)
     assert bool(row.isnan().all()) and int(det.stream.stats[1]) == 1
+    s, i = det.query_and_insert(h[5])                             # ... and the detector refuses to report loops from it
+    assert int(i.max()) == -1
+    with pytest.raises(RuntimeError, match="outside the stream's fixed range"):
+        det.loops(s, i, len(det) - 1)
+
+
+def test_topk_rows_f64_and_batched_detector():
+    """dlc_topk_rows_f64 (the detector's ranking: score descending, ties -> the older frame, NaN never, per-row limits)
+    against a stable sort; and SdavLoopClosureDetector.query_and_insert of a BATCH == frame by frame."""
+    import deeploopcloser_amd as dlc
+    eng = dlc.default_engine()
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(12)
+    rows, ld, k = 37, 1500, 7
+    sc = torch.randn((rows, ld), generator=g, device=eng.device, dtype=torch.float64)
+    sc[:, ::5] = sc[:, 1::5][:, :sc[:, ::5].shape[1]]              # exact ties
+    sc[3, :] = 2.5                                                  # a whole row of ties
+    sc[4, 10:900] = float("nan"); sc[5, :] = float("nan"); sc[6, 17] = float("inf"); sc[7, 3] = float("-inf")
+    for limit0, step in ((ld, 0), (-3, 1), (4, 40), (0, 0)):
+        s, i = eng.topk_rows_f64(sc, limit0, step, k)
+        for r in range(rows):
+            n = max(0, min(ld, limit0 + r * step))
+            v = sc[r, :n].cpu().numpy()
+            ok = np.nonzero(~np.isnan(v))[0]
+            order = ok[np.lexsort((ok, -v[ok]))][:k]
+            want_i = np.full(k, -1, dtype=np.int64); want_i[:len(order)] = order
+            want_s = np.full(k, -np.inf); want_s[:len(order)] = v[order]
+            assert np.array_equal(i[r].cpu().numpy(), want_i) and np.array_equal(s[r].cpu().numpy(), want_s), (limit0, step, r)
+    n, p, h = 40, 30, 250
+    ds = torch.sigmoid(4.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+    ds[9] = ds[2]
+    one = dlc.SdavLoopClosureDetector(ds, patches=p, width=h, k=4, exclusion=3, capacity=8)
+    bat = dlc.SdavLoopClosureDetector(ds, patches=p, width=h, k=4, exclusion=3, capacity=8)
+    parts = [one.query_and_insert(ds[f]) for f in range(n)]
+    s1, i1 = torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts])
+    outs, f = [], 0
+    for b in (1, 6, 1, 17, n):
+        take = min(b, n - f)
+        if take > 0:
+            outs.append(bat.query_and_insert(ds[f:f + take]))
+            f += take
+    s2, i2 = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+    assert int(i1[9, 0]) == 2 and bool(torch.isinf(s1[9, 0]))       # the repeated frame finds its first sighting
+    assert one.loops(s1, i1, 0) == bat.loops(s2, i2, 0)
