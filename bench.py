@@ -252,6 +252,25 @@ def bench_paths(eng, n_frames):
                                  "sample": "oracle/sdav.py (fp64 NumPy) on the first %d of the %d frames, same weights: "
                                            "%.1f s of CPU work" % (nb, N, t_cpu)},
                 "max_abs_err_vs_oracle": err})
+    # ---- E1/E2 in the TOLERANCE mode (opt-in): three fp16 MFMA products of two-piece splits per layer, fp32 accumulate
+    # (csrc/gemm_split_f16.hip); same weights, same frames; error against the fp64 encoder above
+    net16 = dlc.SDAV(seed=1, dtype="f16x2")
+    net16.transform_tensor(x[:2])                                        # (prepares the weight panels once)
+    s_ms, sk_ms, sk_n, h16 = _timed_path(eng, lambda: net16.transform_tensor(x))
+    l2 = (h16 - h).norm(dim=1) / h.norm(dim=1)
+    sflops = 3.0 * flops                                                 # three 16-bit products per fp64-equivalent product
+    out.append({"path": "SDAV.transform (f16x2 split, tolerance mode)", "reference": "src/sdav/network/SDAV.py:126-163,293-302",
+                "frames": N, "dtype": "f16x2 (two fp16 pieces per operand, fp32 accumulate, fp64 in / out)",
+                "value": N / (s_ms * 1e-3), "unit": "frames/s", "ms": s_ms,
+                "rel_l2_vs_fp64_encoder_max": float(l2.max()), "rel_l2_vs_fp64_encoder_median": float(l2.median()),
+                "tolerance": "north_star: descriptor L2 within 1e-4", "speedup_vs_fp64_mode": call_ms / s_ms,
+                "roofline": {"bound": "mfma", "achieved": sflops / (sk_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": sflops / (sk_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+                             "kernel": "gemm_split_f16_kernel (5 layers x 3 fp16 products, LDS-DMA rings, fused bias + sigmoid + re-split)",
+                             "kernel_ms": sk_ms, "kernel_launches_timed": sk_n, "call_ms": s_ms,
+                             "algorithmic_flops_per_call": sflops, "fp64_equivalent_tflops": flops / (sk_ms * 1e-3) / 1e12},
+                "cpu_baseline": out[-1]["cpu_baseline"]})
+    del net16, h16, l2
     del ws, bs, xs, ref
 
     # ---- f-2: one SDAV training step (sess.run(train_steps[0]), SDAV.py:262) on the reference's default batch -------

@@ -34,6 +34,10 @@ SIGNATURES = {
     "dlc_sdav_encode_workspace_bytes": (_sz, [_i64, C.POINTER(_i64), _int, _int]),
     "dlc_sdav_encode": (_int, [_vp, _int, _i64, _int, C.POINTER(_i64), _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp,
                                _sz, _vp]),
+    "dlc_sdav_split_panels_bytes": (_sz, [_int, C.POINTER(_i64)]),
+    "dlc_sdav_split_prepare": (_int, [_vp, _int, C.POINTER(_i64), C.POINTER(_vp), _vp, _sz, _vp]),
+    "dlc_sdav_encode_split_workspace_bytes": (_sz, [_i64, C.POINTER(_i64), _int]),
+    "dlc_sdav_encode_split": (_int, [_vp, _i64, _int, C.POINTER(_i64), _vp, _vp, C.POINTER(_vp), _vp, _vp, _sz, _vp]),
     "dlc_sdav_train_workspace_bytes": (_sz, [_i64, _i64, C.POINTER(_i64), _int, _int]),
     "dlc_sdav_train_step": (_int, [_vp, _int, _i64, _i64, _int, C.POINTER(_i64), _vp, C.POINTER(_vp), C.POINTER(_vp),
                                   C.POINTER(_vp), _vp, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _sz, _vp]),

@@ -334,6 +334,38 @@ class Engine:
                                               _ptr(out), _ptr(ws), ws.numel(), self._stream()))
         return out
 
+    def sdav_split_panels(self, weights):
+        """The tolerance-mode encoder's prepared weights (dlc_sdav_split_prepare): fp64 weights [dims[l], dims[l+1]] -> one
+        uint8 device tensor holding, per layer, the two transposed fp16 pieces of W 2^s and 2^s."""
+        n_layers = len(weights)
+        dims = [weights[0].shape[0]] + [w.shape[1] for w in weights]
+        for l, w in enumerate(weights):
+            if w.dtype != torch.float64 or w.shape[0] != dims[l] or not w.is_contiguous() or w.device != self.device:
+                raise ValueError("sdav_split_panels: W[%d] must be a contiguous float64 [%d, *] tensor on %s" % (l, dims[l], self.device))
+        dims_c = (C.c_int64 * (n_layers + 1))(*dims)
+        need = self.lib.dlc_sdav_split_panels_bytes(n_layers, dims_c)
+        panels = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        w_c = (C.c_void_p * n_layers)(*[w.data_ptr() for w in weights])
+        self._check(self.lib.dlc_sdav_split_prepare(self.ctx, n_layers, dims_c, w_c, _ptr(panels), panels.numel(), self._stream()))
+        return panels
+
+    def sdav_encode_split(self, x2d, dims, panels, biases):
+        """The sigmoid chain on x2d [rows, dims[0]] (fp64) in the tolerance mode (three fp16 MFMA products per layer,
+        include/dlc.h: dlc_sdav_encode_split) -> fp64 [rows, dims[-1]]."""
+        if x2d.dtype != torch.float64 or x2d.dim() != 2 or x2d.shape[1] != dims[0]:
+            raise ValueError("sdav_encode_split: x must be float64 [rows, %d]" % dims[0])
+        x2d = x2d.contiguous()
+        n_layers = len(dims) - 1
+        rows = x2d.shape[0]
+        dims_c = (C.c_int64 * (n_layers + 1))(*dims)
+        b_c = (C.c_void_p * n_layers)(*[(b.data_ptr() if b is not None else 0) for b in biases])
+        need = self.lib.dlc_sdav_encode_split_workspace_bytes(rows, dims_c, n_layers)
+        ws = self.workspace("sdav_split", need)
+        out = torch.empty((rows, dims[-1]), dtype=torch.float64, device=self.device)
+        self._check(self.lib.dlc_sdav_encode_split(self.ctx, rows, n_layers, dims_c, _ptr(x2d), _ptr(panels), b_c, _ptr(out),
+                                                    _ptr(ws), ws.numel(), self._stream()))
+        return out
+
     def train_workspace(self, layer, batch, patches, weights):
         """A workspace tensor of dlc_sdav_train_step's size for this shape (for a caller that keeps its own)."""
         n_layers = len(weights)

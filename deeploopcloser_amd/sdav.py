@@ -46,7 +46,12 @@ class SDAV:
         self._define_params()
         self.losses = []
         self.engine = default_engine(device)
-        self.dtype = {"float64": torch.float64, "float32": torch.float32}[dtype]
+        # "f16x2": the tolerance mode -- parameters and results stay float64, transform() runs every layer as three fp16 MFMA
+        # products of two-piece splits (descriptor relative L2 <= 2e-5 against the fp64 chain; include/dlc.h:
+        # dlc_sdav_encode_split); training always runs the fp64 kernels
+        self.mode = "f16x2" if dtype == "f16x2" else "exact"
+        self.dtype = {"float64": torch.float64, "float32": torch.float32, "f16x2": torch.float64}[dtype]
+        self._panels = None                         # the tolerance mode's prepared weights, rebuilt when the weights change
         dims = [self.input_shape[1]] + list(self.hidden_units)
         self._weights, self._biases = _init_weights(dims, seed, self.dtype, self.engine.device, weight_scale)
         self._biases_dec = [torch.zeros(k, dtype=self.dtype, device=self.engine.device) for k in dims[:-1]]   # :193-217
@@ -122,6 +127,12 @@ class SDAV:
         if x.shape[0] == 0:
             return torch.empty((0, self.hidden_units[-1]), dtype=self.dtype, device=self.engine.device)
         x2 = x.reshape(x.shape[0] * x.shape[1], x.shape[2])      # flat_batch, TensorflowWrapper.py:13-15
+        if self.mode == "f16x2":
+            sig = tuple((w.data_ptr(), w._version) for w in self._weights)
+            if self._panels is None or self._panels[0] != sig:
+                self._panels = (sig, self.engine.sdav_split_panels(self._weights))
+            dims = [self.input_shape[1]] + list(self.hidden_units)
+            return self.engine.sdav_encode_split(x2, dims, self._panels[1], self._biases)
         return self.engine.sdav_encode(x2, self._weights, self._biases)
 
     def transform(self, x, chunk_frames=256):

@@ -112,6 +112,30 @@ int dlc_sdav_encode(dlc_ctx* ctx, int dtype, int64_t rows, int n_layers, const i
                     const void* x, const void* const* W, const void* const* b,
                     void* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * SDAV.transform in a TOLERANCE mode on the 16-bit matrix cores (opt-in; dlc_sdav_encode in DLC_F64 stays the parity mode):
+ * the same chain h_l = sigmoid(h_{l-1} . W_l + b_l) (src/sdav/network/SDAV.py:126-163,293-302;
+ * src/utils/TensorflowWrapper.py:57-78) with every operand carried as two fp16 pieces of a power-of-two multiple of its
+ * value and a layer computed as three v_mfma_f32_16x16x32_f16 products into fp32 accumulators (csrc/gemm_split_f16.hip),
+ * bias + sigmoid in fp32, the activations handed from layer to layer as fp16 pieces.  Accuracy (measured against the fp64
+ * oracle, tests/test_gpu_parity.py): descriptor relative L2 <= 2e-5 with the reference's N(0,1) initialiser, 1e-7 with
+ * 1/sqrt(fan_in) weights -- inside north_star's "descriptor L2 within 1e-4"; NOT bit parity.  x must lie in [-16, 16]
+ * (the reference feeds pixel / 255): larger values overflow fp16 and come out as NaN.
+ *   dlc_sdav_split_prepare   once per set of weights: W_l (DEVICE fp64 [dims[l], dims[l+1]] row-major; W a HOST array of
+ *                            DEVICE pointers) -> `panels` (DEVICE, dlc_sdav_split_panels_bytes(), 256-byte aligned): per
+ *                            layer the two fp16 pieces of W_l 2^s, transposed and zero-padded, and 2^s;
+ *   dlc_sdav_encode_split    x [rows, dims[0]] fp64 -> out [rows, dims[n_layers]] fp64 (the FLAT array of SDAV.py:163);
+ *                            b: HOST array of n_layers DEVICE pointers (fp64 [dims[l+1]], entries or b itself may be NULL).
+ * Both are stream-ordered.  Workspace: dlc_sdav_encode_split_workspace_bytes (256-byte aligned).
+ */
+size_t dlc_sdav_split_panels_bytes(int n_layers, const int64_t* dims);
+int dlc_sdav_split_prepare(dlc_ctx* ctx, int n_layers, const int64_t* dims, const double* const* W, void* panels,
+                           size_t panels_bytes, void* stream);
+size_t dlc_sdav_encode_split_workspace_bytes(int64_t rows, const int64_t* dims, int n_layers);
+int dlc_sdav_encode_split(dlc_ctx* ctx, int64_t rows, int n_layers, const int64_t* dims, const double* x,
+                          const void* panels, const double* const* b, double* out, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* ---- SDAV training step (the surface train.py drives: SDAV.fit / fit_dataset) ----------------- */
 /*
  * One `sess.run(train_steps[layer])` (src/sdav/network/SDAV.py:223-226,257-263): forward of

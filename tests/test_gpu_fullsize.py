@@ -41,6 +41,26 @@ def test_sdav_encode_kennedylong_batch_invariance(dlc, descriptors):
     assert torch.isfinite(h).all() and float(h.min()) >= 0.0 and float(h.max()) <= 1.0
 
 
+@pytest.mark.parametrize("scale", ["reference", "fan_in"])
+def test_sdav_encode_split_mode_kennedylong(dlc, scale):
+    """The tolerance mode at the reference's full size, 1063 frames (31 890 rows), both weight regimes, on tiled REAL frames
+    and on random ones: descriptor relative L2 against the fp64 encoder (itself held to 1e-10 of the oracle above) below
+    north_star's 1e-4; chunks == one batch bit for bit."""
+    import real_frames
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    exact = dlc.SDAV(seed=9, weight_scale=scale)
+    fast = dlc.SDAV(seed=9, dtype="f16x2", weight_scale=scale)
+    for name, x in (("real", real_frames.tiled_patches(dlc, N_FRAMES)),
+                    ("random", torch.rand((N_FRAMES, 30, 1681), generator=g, device="cuda", dtype=torch.float64))):
+        ref = exact.transform_tensor(x)
+        got = fast.transform_tensor(x)
+        assert got.shape == ref.shape and got.dtype == torch.float64
+        l2 = (got - ref).norm(dim=1) / ref.norm(dim=1)
+        print("SDAV f16x2 at 1063 %s frames, %s weights: relative L2 max %.3g median %.3g" % (name, scale, float(l2.max()), float(l2.median())))
+        assert float(l2.max()) < 1e-4
+        assert torch.equal(fast.transform_tensor(x[500:517]), got[500 * 30:517 * 30])
+
+
 def test_similarity_matrix_kennedylong_properties(dlc, descriptors):
     from oracle import similarity as osim
     _, _, h = descriptors
