@@ -459,6 +459,12 @@ def bench_paths(eng, n_frames):
         f64_ms, _, _, (ff, fi) = _timed_path(eng, lambda: eng.sdav_similarity_matrix(dr, eng.distinctive_score(dr, 0.5, 0.2), 10.0, -10.0,
                                                                                       force_f64=True), reps=2)
         same = bool(torch.equal(torch.nan_to_num(rf, posinf=1e300), torch.nan_to_num(ff, posinf=1e300)) and torch.equal(ri, fi))
+        nr = min(N, 12)                                            # the oracle's all-vs-all loop on the first frames of THIS data
+        drn = dr[:nr].cpu().numpy()
+        t0 = time.perf_counter()
+        with np.errstate(divide="ignore"):
+            osim.similarity_matrix_f64(drn)
+        tr_cpu = time.perf_counter() - t0
         out.append({"path": "SDAV similarity matrix, real-frame statistics, " + label,
                     "reference": "src/sdav/similarity/SimilarityCalculator.py:12-49, src/sdav/create_similarity_matrix.py:23-38",
                     "frames": N, "dtype": "f64", "value": pairs / (r_ms * 1e-3), "unit": "frame-pairs/s", "ms": r_ms,
@@ -470,7 +476,9 @@ def bench_paths(eng, n_frames):
                                  "unit": "TOP/s", "frac": i8_ops / (rk_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS if rk_ms else None,
                                  "traffic": None, "kernel": "gram_i8_kernel", "kernel_ms": rk_ms, "kernel_launches_timed": rk_n,
                                  "call_ms": r_ms, "algorithmic_ops_per_call": i8_ops},
-                    "cpu_baseline": None})
+                    "cpu_baseline": {"value": (nr * (nr - 1) // 2) / tr_cpu, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                                     "sample": "oracle/similarity.py all-vs-all loop on the first %d of these frames (%d pairs): %.2f s"
+                                               % (nr, nr * (nr - 1) // 2, tr_cpu)}})
         del dr, rf, ri, ff, fi
     del xr
 

@@ -44,11 +44,18 @@ def test_bench_json_contract():
     assert abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4 / 1e3)) / d["value"] < 1e-6
     # the other rows of the hot path, each with its own roofline and CPU baseline, each checked against the oracle
     paths = {p["path"]: p for p in d["paths"]}
-    assert set(paths) == {"SDAV.transform", "SDAV.train_step (layer 0, 10 frames)", "SDAV similarity matrix",
+    assert set(paths) == {"SDAV.transform", "SDAV.transform (f16x2 split, tolerance mode)",
+                          "SDAV.train_step (layer 0, 10 frames)", "SDAV similarity matrix",
+                          "SDAV similarity matrix, real-frame statistics, N(0,1) weights",
+                          "SDAV similarity matrix, real-frame statistics, 1/sqrt(fan_in) weights",
                           "patch front-end (grey + Harris + 30 patches of 41x41)",
                           "LoopClosureDetector.query_and_insert (batches of 32 frames)",
                           "cosine similarity matrix (flattened SDAV descriptors)",
                           "cosine top-20 (flattened SDAV descriptors)", "CnnVtl.transform", "cnn_vtl distance matrix"}
+    assert paths["SDAV.transform (f16x2 split, tolerance mode)"]["rel_l2_vs_fp64_encoder_max"] < 1e-4
+    for name in ("N(0,1) weights", "1/sqrt(fan_in) weights"):
+        row = paths["SDAV similarity matrix, real-frame statistics, " + name]
+        assert row["equals_fp64_route_bit_for_bit"] is True and row["filter_took_the_call"] is True and row["stats"][1] == 0
     assert paths["SDAV.train_step (layer 0, 10 frames)"]["loss_rel_err_vs_oracle"] < 1e-9
     assert paths["patch front-end (grey + Harris + 30 patches of 41x41)"]["bit_exact_vs_oracle"] is True
     assert paths["LoopClosureDetector.query_and_insert (batches of 32 frames)"]["index_agreement_vs_oracle"] > 0.999
