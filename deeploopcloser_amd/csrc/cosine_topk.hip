@@ -701,11 +701,9 @@ struct FinishArgs {
     int rslack;
 };
 
-// The 256-thread forms are meant to sit beside a resident score-GEMM workgroup (2 x 200 VGPRs per
-// SIMD): 5 waves per SIMD caps them at 96 VGPRs.
+// (the body of the two finish_topk_kernel forms below)
 template <typename Tag, int THREADS, int RS_UNROLL, int MODE>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 5 : 1)))
-void finish_topk_kernel(FinishArgs a) {
+__device__ __forceinline__ void finish_topk_body(const FinishArgs& a) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     constexpr int FIN_WAVES = THREADS / 64;
     constexpr int FIN_THREADS = THREADS;      // shadows the namespace constant inside this kernel
@@ -936,7 +934,10 @@ void finish_topk_kernel(FinishArgs a) {
         const char* rows[GROUP];
 #pragma unroll
         for (int r = 0; r < GROUP; ++r) {
-            ids[r] = s * GROUP + r < m3 ? crow[s * GROUP + r] : -1;
+            // (every lane reads the same LDS word: through readfirstlane the ids, and the row pointers behind them, live in
+            // scalar registers -- sixteen vector registers fewer, which the 96-register cooperative forms did not have: the
+            // re-score form of the sharded protocol spilled two)
+            ids[r] = __builtin_amdgcn_readfirstlane(s * GROUP + r < m3 ? crow[s * GROUP + r] : -1);
             any |= ids[r] >= 0;
             rows[r] = a.DB + (long long)(ids[r] < 0 ? 0 : ids[r]) * a.lddb_b;
         }
@@ -977,6 +978,19 @@ void finish_topk_kernel(FinishArgs a) {
             a.status[qi] = cert ? 0 : 1;
         }
     }
+}
+
+// The stand-alone form: 512 threads, four rows' worth of loads in flight per lane.
+template <typename Tag, int THREADS, int RS_UNROLL, int MODE>
+__global__ __launch_bounds__(THREADS) void finish_topk_kernel(FinishArgs a) {
+    finish_topk_body<Tag, THREADS, RS_UNROLL, MODE>(a);
+}
+// The 256-thread forms are meant to sit beside a resident score-GEMM workgroup: its two waves per SIMD hold 2 x 200 of the
+// SIMD's 512 registers, which leaves 112 for this kernel's one wave -- capped at 104 here.  (r03 capped it through
+// amdgpu_waves_per_eu(5) = 96 registers, which the re-score form of the sharded protocol missed by two: it spilled.)
+template <typename Tag, int RS_UNROLL, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void finish_topk_coop_kernel(FinishArgs a) {
+    finish_topk_body<Tag, 256, RS_UNROLL, MODE>(a);
 }
 
 // Exhaustive pass of the queries a selection could not certify (status[q] == 1; every other workgroup leaves at once).
@@ -1632,7 +1646,9 @@ int launch_finish(dlc_ctx* ctx, FinishArgs f, int64_t q, bool small_lds, hipStre
     f.tv_in_lds = MODE != FIN_RESCORE && !small_lds && (size_t)f.nh * 4 <= 96 * 1024;
     if (f.tv_in_lds) dsm += (size_t)f.nh * 4;
     dsm = dlc::align_up(dsm, 16);
-    auto fk = finish_topk_kernel<Tag, THREADS, RS_UNROLL, MODE>;
+    void (*fk)(FinishArgs);
+    if constexpr (THREADS == 256) fk = finish_topk_coop_kernel<Tag, RS_UNROLL, MODE>;
+    else fk = finish_topk_kernel<Tag, THREADS, RS_UNROLL, MODE>;
     if (dsm > 48 * 1024)
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm));
     hipLaunchKernelGGL(fk, dim3((unsigned)q, (unsigned)(MODE == FIN_RESCORE && f.gparts > 1 ? f.gparts : 1)), dim3(THREADS),
