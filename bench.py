@@ -74,6 +74,8 @@ def parse():
                     help="one stream, no overlap of a batch's selection / all-gather with the next batch's GEMM")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-paths", action="store_true", help="skip the `paths` entries (configs[1] / configs[2] rows)")
+    ap.add_argument("--no-shard-emulation", action="store_true",
+                    help="skip `multi_gpu_emulation` (one rank's step of a 2 / 4 / 8-GPU run, emulated on this GPU)")
     ap.add_argument("--path-frames", type=int, default=1063, help="frames of the `paths` entries (outdoor_kennedylong: 1063)")
     return ap.parse_args()
 
@@ -606,6 +608,72 @@ def bench_paths(eng, n_frames):
     return out
 
 
+def bench_shard_emulation(eng, dlc, rows, queries, k, want_idx, steps=100):
+    """What ONE rank of an R-GPU run does per query batch, on this one GPU: MatchPipeline's sharded protocol (score pass,
+    group selection, all-gather #1, filtered fp64 re-score, all-gather #2, certifying merge; three batches in flight, two
+    streams) over rank 0's shard of the resident database.  The whole database is on this GPU, so the OTHER ranks'
+    contributions are real: their group maxima and -- filtered against everybody's maxima, as the protocol has it -- their
+    packed top-k parts are computed once, before anything is timed, from their shards; the two all-gathers are then device
+    copies of this rank's fresh part next to those.  NO RCCL, no other GPU: the GPU-side floor of a rank's step, i.e. an upper
+    bound of what R GPUs reach (every rank in lockstep); the merged result must equal the one-GPU result (want_idx)."""
+    out = []
+    n, nq, d = rows.shape[0], queries.shape[0], queries.shape[1]
+    kg = eng.groups_per_query(k)
+    for parts in (2, 4, 8):
+        bounds = [dlc.shard_bounds(n, parts, r) for r in range(parts)]
+        gmx, ids = [], []
+        for lo, hi in bounds:                                   # step 1 of every rank: its kg best groups
+            ws = torch.empty(eng.topk_workspace_bytes(nq, hi - lo, d, k), dtype=torch.uint8, device=eng.device)
+            gi = torch.empty((nq, kg), dtype=torch.int32, device=eng.device)
+            gm = torch.empty((nq, kg + 1), dtype=torch.float32, device=eng.device)
+            eng.score_groups(queries, rows[lo:hi], k, ws)
+            eng.select_groups(queries, rows[lo:hi], k, ws, gi, gm)
+            gmx.append(gm); ids.append(gi)
+            del ws
+        all_max = torch.stack(gmx)                              # what all-gather #1 delivers
+        packs = []
+        for r, (lo, hi) in enumerate(bounds):                   # step 2 of every rank: its filtered fp64 part, packed
+            pack = torch.empty(nq * k * 16, dtype=torch.uint8, device=eng.device)
+            p_idx = pack[:nq * k * 8].view(torch.int64).view(nq, k)
+            p_s64 = pack[nq * k * 8:].view(torch.float64).view(nq, k)
+            eng.rescore_topk(queries, rows[lo:hi], k, ids[r], gmx[r], p_s64, p_idx, all_max=all_max, row_offset=lo)
+            packs.append(pack)
+        others_max = all_max[1:].reshape(parts - 1, -1).clone()
+        others_pack = torch.stack(packs[1:])
+        torch.cuda.synchronize()
+
+        def fake_all_gather(out_t, inp, group=None, others_max=others_max, others_pack=others_pack, parts=parts):
+            o = out_t.view(parts, -1)
+            o[0].copy_(inp.reshape(-1))
+            o[1:].copy_(others_max if inp.dtype == torch.float32 else others_pack)
+
+        db = dlc.KeyframeDatabase(rows[bounds[0][0]:bounds[0][1]], dtype=rows.dtype, stored=True)
+        pipe = dlc.MatchPipeline(db, k, depth=3)
+        pipe.world = parts                                     # the sharded branch of submit() / result()
+        pipe.all_gather = fake_all_gather
+        t = None
+        for _ in range(10):
+            t = pipe.submit(queries)
+        pipe.result(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t = pipe.submit(queries)
+            if t >= pipe.depth - 1:
+                pipe.result(t - (pipe.depth - 1))
+        s_e, i_e = pipe.result(t)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out.append({"ranks": parts, "rows_per_rank": int(bounds[0][1] - bounds[0][0]), "ms_per_batch_per_rank": ms,
+                    "projected_query_frames_per_s": nq / (ms * 1e-3), "resolved_batches": pipe.resolved_batches,
+                    "merged_result_equals_one_gpu": bool(torch.equal(i_e, want_idx)),
+                    "label": "EMULATED on one GPU: rank 0's MatchPipeline step over N / %d rows; the other ranks' parts are real "
+                             "(computed once from their shards), the two all-gathers are device copies -- no RCCL, no xGMI; an "
+                             "upper bound for %d GPUs" % (parts, parts)})
+        del pipe, db, packs, others_pack, all_max
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start the N rank processes (torch.distributed.run, one per
     GPU, rendezvous on 127.0.0.1) as CHILDREN of this process, which has not touched the GPU and never will; rank 0
@@ -652,7 +720,14 @@ def rccl_smoke(eng, dlc, db, pipe, queries, k, lo, world):
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) != 1:
         raise SystemExit("RCCL smoke: the pipelined sharded match differs from the plain all-gather + merge of per-shard top-k")
-    return {"backend": dist.get_backend(), "ranks": world, "first_collective_s": t_up,
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                           # (a gloo rehearsal on a box without the library)
+        rccl_version = None
+    if dist.get_rank() == 0:
+        print("[bench] collectives up: backend %s, RCCL %s, %d ranks, first all-reduce %.2f s, all-gather #1 / #2: %s us"
+              % (dist.get_backend(), rccl_version, world, t_up, coll_us), file=sys.stderr, flush=True)
+    return {"backend": dist.get_backend(), "rccl_version": rccl_version, "ranks": world, "first_collective_s": t_up,
             "pipeline_equals_plain_exchange": True, "collective_us": coll_us,
             "resolved_batches": pipe.resolved_batches}
 
@@ -671,10 +746,14 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # first contact must not hang the job: the rendezvous and every collective time out after 120 s, the failing rank
+        # exits non-zero and torch.distributed.run takes the others down with it
+        import datetime
+        tmo = datetime.timedelta(seconds=120)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
 
     import deeploopcloser_amd as dlc
     from deeploopcloser_amd.engine import torch_dtype
@@ -837,6 +916,11 @@ def main():
         out["topk_index_agreement_vs_oracle"] = agree
         out["topk_index_agreement_rows"] = ns
         out["topk_score_max_abs_err_vs_oracle"] = float(np.abs(s_gpu.cpu().numpy() - best_s).max())
+
+    # ---- what ONE rank of a 2 / 4 / 8-GPU run would do per batch, emulated on this GPU (no RCCL): driver-timed every
+    # round, since an 8-GPU node is not always at hand (rank 0, N=1 only; untimed above) ------------------------------
+    if rank == 0 and world == 1 and not args.no_shard_emulation and n >= 8 * 2048:
+        out["multi_gpu_emulation"] = bench_shard_emulation(eng, dlc, db.rows, queries, k, idx)
 
     # ---- the other rows of the hot path at configs[1] / configs[2] size (rank 0, N=1 only; untimed above) ----
     if rank == 0 and world == 1 and not args.no_paths:

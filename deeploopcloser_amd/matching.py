@@ -179,6 +179,9 @@ class MatchPipeline:
         self._slots = []
         self._count = 0
         self._nq = queries_per_batch
+        # the collective of the exchange (all_gather_into_tensor(out, inp, group=...)): torch.distributed's unless a caller
+        # installs another -- bench.py's one-GPU emulation of a rank's step puts device copies here
+        self.all_gather = dist.all_gather_into_tensor
         self.resolved_batches = 0          # batches that needed the exhaustive round (sharded)
         self.dropped_batches = 0           # batches whose slot was reused before result() fetched them
         self.time_collectives = False      # record events around the two all-gathers of every batch (collective_us())
@@ -246,14 +249,14 @@ class MatchPipeline:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.time_collectives else None
                 if ev:
                     ev[0].record(self.s_select)
-                dist.all_gather_into_tensor(s["g_max"].view(-1, s["g_max"].shape[-1]), s["grp_max"], group=self.group)
+                self.all_gather(s["g_max"].view(-1, s["g_max"].shape[-1]), s["grp_max"], group=self.group)
                 if ev:
                     ev[1].record(self.s_select)
                 eng.rescore_topk(q, rows, self.k, s["grp_ids"], s["grp_max"], s["p_s64"], s["p_idx"], bound=s["bound"],
                                  all_max=s["g_max"], row_offset=self.db.row_offset, coop=True, stream=self.s_select)
                 if ev:
                     ev[2].record(self.s_select)
-                dist.all_gather_into_tensor(s["g_pack"].view(-1), s["pack"], group=self.group)
+                self.all_gather(s["g_pack"].view(-1), s["pack"], group=self.group)
                 if ev:
                     ev[3].record(self.s_select)
                     self._coll_events.append(ev)
@@ -274,7 +277,7 @@ class MatchPipeline:
             lower = s["m_s64"][:, k - 1].contiguous()
             eng.exhaustive_topk(q, s["rows"], k, s["ws"], lower, s["tau"], s["status"], s["p_s64"], s["p_idx"],
                                 row_offset=self.db.row_offset, stream=self.s_select)
-            dist.all_gather_into_tensor(s["g_pack"].view(-1), s["pack"], group=self.group)
+            self.all_gather(s["g_pack"].view(-1), s["pack"], group=self.group)
             eng.topk_merge_packed(s["g_pack"], q.shape[0], k, out=(s["scores"], s["idx"]), scores_f64=s["m_s64"])
             s["done"].record(self.s_select)
         s["done"].synchronize()

@@ -42,6 +42,11 @@ def test_bench_json_contract():
     assert c["value_f32"] > 0 and c["arithmetic"] == "f64"
     assert d["recall_at_1"] == 1.0 and d["topk_index_agreement_vs_oracle"] == 1.0
     assert abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4 / 1e3)) / d["value"] < 1e-6
+    # one rank's step of a 2 / 4 / 8-GPU run, emulated on this GPU with the other ranks' real parts: the merged result is the
+    # one-GPU result
+    emu = d["multi_gpu_emulation"]
+    assert [e["ranks"] for e in emu] == [2, 4, 8]
+    assert all(e["merged_result_equals_one_gpu"] is True and e["ms_per_batch_per_rank"] > 0 and "EMULATED" in e["label"] for e in emu)
     # the other rows of the hot path, each with its own roofline and CPU baseline, each checked against the oracle
     paths = {p["path"]: p for p in d["paths"]}
     assert set(paths) == {"SDAV.transform", "SDAV.transform (f16x2 split, tolerance mode)",
