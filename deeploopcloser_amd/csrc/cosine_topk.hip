@@ -5,16 +5,19 @@
 //      The score tile never leaves the accumulators: the epilogue keeps, per
 //      query, the maximum of every aligned block of 8 database rows
 //      ("group", gmax) and of every 128 rows ("half tile", tmax).  The
-//      database is streamed from HBM exactly once.
+//      database is streamed from HBM exactly once.  These fp32 scores only CHOOSE CANDIDATES.
 //   2. finish_topk_kernel  one workgroup per query:
 //      a. the kg = k + SLACK half tiles with the largest tmax, then the kg groups
 //         with the largest gmax inside them.  Every member of the exact top-k
 //         lies in one of those groups (the k-th largest group maximum is a
 //         lower bound of the k-th largest score);
-//      b. exact fp32 dot products for the 8 rows of each selected group (a
+//      b. fp64 re-score of the 8 rows of each selected group (rescore8_f64: the fp64 sum of the exact products of the
+//         stored elements in one fixed order -- THE score of a (query, row) pair in every plan, shard and batch; a
 //         gather of kg*8 rows per query);
-//      c. top-k of the kg*8 candidates, score descending, ties toward the
-//         lower database index.
+//      c. top-k of the kg*8 candidates on the fp64 key round(s * 2^40), descending, ties toward the lower database
+//         index; and the certificate: the result is exact when the k-th fp64 score clears the best fp32 score left
+//         behind by more than the score pass's error bound tau;
+//   3. exhaustive_topk_kernel  the queries that failed the certificate (every other workgroup leaves at once).
 // dlc_topk_merge() is step 2c on an all-gather of per-shard results.
 //
 // MFMA operand roles: A = database rows, B = queries, so that in the 16x16 C/D

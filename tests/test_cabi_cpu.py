@@ -54,7 +54,7 @@ def test_host_only_entry_points(lib):
     assert lib.dlc_sdav_encode_workspace_bytes(300, dims, 5, _lib.DLC_F64) >= 2 * 300 * 2500 * 8
     assert lib.dlc_sdav_similarity_workspace_bytes(20, 30, 2500, 0, 0) > 0
     # the similarity's two forms (include/dlc.h): the int8 arg-min filter at the reference's shape -- quantised panels twice,
-    # int32 product block, 4.6 GB -- and the fp64 Gram form (transpose + fp64 block, 8.7 GB) for P > 32 or on request
+    # the arg-mins the product kernel emits, 0.9 GB -- and the fp64 Gram form (transpose + fp64 block, 8.7 GB) for P > 32 or on request
     w_i8 = lib.dlc_sdav_similarity_workspace_bytes(1063, 30, 2500, 0, 0)
     w_f64 = lib.dlc_sdav_similarity_workspace_bytes(1063, 30, 2500, _lib.DLC_SIM_FORCE_F64, 0)
     assert 0.8e9 < w_i8 < 1.0e9 and 8.5e9 < w_f64 < 9.0e9          # r03: the int32 product block (4 GB) and the second panel are gone
