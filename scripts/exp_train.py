@@ -3,6 +3,9 @@ latency mode (split-K scratch)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if len(sys.argv) > 1:                      # another build of the library (A/B)
+    import deeploopcloser_amd._lib as L
+    L.LIB_PATH = os.path.abspath(sys.argv[1])
 import deeploopcloser_amd as dlc
 eng = dlc.default_engine()
 g = torch.Generator(device=eng.device); g.manual_seed(0)
