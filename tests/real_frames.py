@@ -37,3 +37,28 @@ def tiled_patches(dlc, n_frames):
         have += t.shape[0]
         c += 1
     return torch.cat(tiles)[:n_frames]
+
+
+def tiled_bgr_frames(dlc, n_frames):
+    """[n_frames, 192, 240, 3] float64 on the device, as create_distance_matrix.py:23 feeds CnnVtl (cv2.imread order: BGR,
+    uint8 values): the 20 real frames, then copies -- copies 0 and 1 exact, later ones with a handful of pixel values moved
+    by +-1 (clamped to 0..255), every seventh one also with a blanked 32 x 32 block."""
+    import torch
+    base = np.stack([dlc.read_ppm(p)[:, :, ::-1] for p in frame_paths()]).astype(np.float64)      # [20, 192, 240, 3]
+    x = torch.from_numpy(np.ascontiguousarray(base)).to("cuda")
+    rng = np.random.RandomState(18)
+    tiles, have, c = [x], x.shape[0], 0
+    while have < n_frames:
+        t = x.clone()
+        if c >= 2:
+            for f in range(x.shape[0]):
+                for _ in range(3 + c % 7):
+                    t[f, rng.randint(192), rng.randint(240), rng.randint(3)] += 1.0 if rng.rand() < 0.5 else -1.0
+            t.clamp_(0.0, 255.0)
+        if c >= 4 and c % 7 == 3:
+            y0, x0 = rng.randint(160), rng.randint(208)
+            t[:, y0:y0 + 32, x0:x0 + 32] = 0.0
+        tiles.append(t)
+        have += t.shape[0]
+        c += 1
+    return torch.cat(tiles)[:n_frames]

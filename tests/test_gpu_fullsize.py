@@ -411,6 +411,56 @@ def test_cnn_vtl_transform_kennedylong_multi_chunk(dlc):
         assert m[a, b] == odist.calculate_distance(dn[a], dn[b])
 
 
+def test_config2_and_config3_on_tiled_real_frames(dlc):
+    """configs[1] (cosine over the flattened SDAV descriptors) and configs[2] (cnn_vtl) at the reference's full size on
+    REAL-image statistics: the 20 real frames tiled to 1063 (exact copies, copies with pixels moved by one step, blanked
+    blocks).  cnn_vtl: every int8 byte of sampled frames == the oracle, exact copies give identical descriptors, the
+    1063 x 1063 distance matrix is symmetric with a zero diagonal, zero between exact copies, == the oracle on sampled
+    pairs.  Cosine: the top-20 of every frame over the 75 008-wide place descriptors == the oracle's, all 21 260 slots
+    (scores crowd: a frame, its copies and near copies), the exact copies tie and go by index.  (A frame's best match
+    need not be itself: rows are unit vectors ROUNDED to bf16, and a near copy whose rounded row is a hair longer scores
+    higher -- the oracle, which works on the stored rows, agrees.)"""
+    import real_frames
+    from oracle import cnn_vtl as ocnn, cosine as ocos, distance as odist
+    eng = dlc.default_engine()
+    frames = real_frames.tiled_bgr_frames(dlc, N_FRAMES)
+    net = dlc.CnnVtl(input_shape=[N_FRAMES, 192, 240, 3], seed=5, mask_seed=9)
+    d = net.transform_tensor(frames)
+    assert d.shape == (N_FRAMES, net.columns.size) and d.dtype == torch.int8
+    ws, bs = ocnn.init_weights(5)
+    cols = ocnn.column_indices(net.layer_sizes, 99.59, seed=9)
+    pick = [0, 19, 20, 41, 77, 500, 1062]
+    assert np.array_equal(d[pick].cpu().numpy(), ocnn.transform(frames[pick].cpu().numpy(), ws, bs, cols))
+    assert torch.equal(d[:20], d[20:40]) and torch.equal(d[:20], d[40:60])          # copies 0 and 1 are exact
+    m = dlc.DistanceCalculator.distance_matrix(d)
+    dn = d.cpu().numpy()
+    assert np.array_equal(m, m.T) and np.all(np.diag(m) == 0)
+    assert np.all(m[np.arange(20), np.arange(20) + 20] == 0) and np.all(m[np.arange(20), np.arange(20) + 40] == 0)
+    rng = np.random.RandomState(4)
+    for _ in range(40):
+        a, b = rng.randint(0, N_FRAMES, 2)
+        assert m[a, b] == odist.calculate_distance(dn[a], dn[b])
+    del frames, d, net
+
+    xs = real_frames.tiled_patches(dlc, N_FRAMES)
+    h = dlc.SDAV(seed=2).transform_tensor(xs)
+    db = dlc.KeyframeDatabase(h.reshape(N_FRAMES, 30 * 2500), dtype="bf16", center=True)
+    rows = db.rows
+    top = eng.match_topk(rows, rows, 20, details=True)
+    rh = rows.float().cpu().numpy().astype(np.float64)
+    es, ei = ocos.topk_from_scores(ocos.scores(rh, rh), 20)
+    resolved = int((top.status == 2).sum())
+    print("config-2 top-20 on tiled real frames: %d of %d queries resolved by the exhaustive pass" % (resolved, N_FRAMES))
+    assert np.array_equal(top.idx.cpu().numpy(), ei)                               # identical indices, all 21 260 slots
+    assert np.abs(top.scores_f64.cpu().numpy() - es).max() < 1e-12
+    # frame f and its exact copies f + 20, f + 40 are the same stored row: they tie in every other frame's list and go by index
+    ti = top.idx.cpu().numpy()
+    for f in range(20):
+        for q in (100 + f, 500 + f):
+            pos = [int(np.nonzero(ti[q] == r)[0][0]) for r in (f, f + 20, f + 40) if (ti[q] == r).any()]
+            assert pos == sorted(pos)
+
+
 def test_cosine_matrix_config2_dense_full(dlc, descriptors):
     """configs[1]: the FULL 1063 x 1063 cosine matrix over the flattened 75 000-d SDAV place descriptors
     (stored width 75 008, split-K) against the fp64 oracle on sampled rows, its symmetry and unit diagonal,
