@@ -12,7 +12,9 @@ OURS = ("score_gemm_kernel", "finish_topk_kernel", "merge_topk_kernel", "l2_norm
         "pair_score_kernel", "pair_score_tile_kernel", "transpose_f64_kernel", "splitk_groups_kernel", "splitk_dense_kernel", "maxpool_kernel", "row_minmax_kernel",
         "quant_gather_kernel", "row_stats_kernel", "gram_i8_kernel", "pair_score_amin_kernel", "gram_blocks_kernel", "sim_rows_kernel",
         "sim_range_kernel", "sim_pairwise_program_kernel", "exhaustive_topk_kernel", "score_gemv_kernel", "stream_argmin_kernel",
-        "stream_score_kernel", "random_mask_kernel", "xent_grad_kernel", "hidden_grad_kernel", "sgd_kernel")
+        "stream_score_kernel", "random_mask_kernel", "xent_grad_kernel", "hidden_grad_kernel", "sgd_kernel",
+        "gemm_split_f16_kernel", "sp_split_rows_kernel", "sp_split_weights_kernel", "sim_colrange_kernel", "sim_sample_kernel",
+        "sim_keys_init_kernel", "topk_rows_f64_kernel", "finish_topk_coop_kernel", "merge_topk_kernel", "keep_older_kernel")
 
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 stats = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
@@ -21,7 +23,13 @@ with open(stats) as f, open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), 
         if i == 0 or any(k in line for k in OURS):
             g.write(line)
 
-summary = {"tag": tag, "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes, --no-paths)] -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe",
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+    dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "deeploopcloser_amd", "bench.py"], text=True).strip())
+except Exception:
+    commit, dirty = None, None
+summary = {"tag": tag, "commit": commit, "tree_dirty_when_summarised": dirty, "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes, --no-paths)] -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe",
            "kernels": {}}
 HEADLINE = "score_gemm_kernel<dlc_bf16_tag, 0, false>"      # the 1 M-row launch of the timed loop (GROUPS epilogue, unmasked)
 for row in csv.DictReader(open(stats)):
