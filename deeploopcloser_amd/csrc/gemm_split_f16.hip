@@ -1,7 +1,7 @@
 // SDAV.transform in a TOLERANCE mode on the 16-bit MFMA (dlc_sdav_encode_split; SDAV.py:126-163,293-302;
 // TensorflowWrapper.py:57-78: five times sigmoid(h . W + b)).  The fp64 encoder (gemm_dma_f64.hip) stays the parity mode
 // and the default; this one trades bit parity for the matrix cores' 16-bit rate under north_star's own tolerance
-// ("descriptor L2 within 1e-4"): measured relative L2 <= 2e-5 with the reference's N(0,1) weights, 8e-8 with 1/sqrt(fan_in)
+// ("descriptor L2 within 1e-4"): measured relative L2 <= 2.1e-5 with the reference's N(0,1) weights, 2e-7 with 1/sqrt(fan_in)
 // weights (tests/test_gpu_parity.py; the NumPy emulation that chose the form: scripts/emul_split_encoder.py).
 //
 // Arithmetic.  Every operand is TWO fp16 pieces of a power-of-two multiple of its value,
@@ -12,9 +12,11 @@
 // at the same MFMA rate per product.  The products of two fp16 values are exact in fp32; what is left is the fp32
 // accumulation over K = 2500 (1.7e-5 of the descriptor norm through five saturating layers) and the fp32 sigmoid.
 //
-// Kernel.  The three products are ONE plain GEMM over K' = 3 K: K tiles 0 .. nk-1 pair (h1, W1), nk .. 2nk-1 (h1, W2),
-// 2nk .. 3nk-1 (h2, W1) -- only the DMA's base pointers know.  Main loop = the cosine match's score GEMM
-// (cosine_topk.hip: 256 x 256 tile, BK = 64, 8 waves of 128 x 64, LDS-DMA rings, snake order of eight mini-phases per K
+// Kernel.  The three products are ONE plain GEMM over K' = 3 K: K tile 3 t pairs (h1, W1) at k-tile t, 3 t + 1 (h1, W2),
+// 3 t + 2 (h2, W1) -- only the DMA's base pointers know; a piece's k-tile is read again one or two K tiles after its first
+// use, out of L2 (segment by segment -- all of (h1, W1), then all of (h1, W2), ... -- every re-read went back over the
+// fabric: 4 % slower, at 1.5e-5 instead of 2.1e-5 of error: the small products then reach the accumulator last).
+// Main loop = the cosine match's score GEMM (cosine_topk.hip: 256 x 256 tile, BK = 64, 8 waves of 128 x 64, LDS-DMA rings, snake order of eight mini-phases per K
 // tile), with the roles turned: MFMA A operand = 256 weight columns (fragment rows permuted so that a lane's sixteen
 // accumulators of a half are sixteen CONSECUTIVE output columns n), B operand = 256 activation rows (a lane holds ONE
 // row m).  The epilogue therefore writes, per lane, runs of sixteen consecutive outputs of one row: bias + sigmoid in fp32,
@@ -142,12 +144,12 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
             }
         }
     }
-    // this wave's two piece bases, and the K-tile segment (0: h1 W1, 1: h1 W2, 2: h2 W1) that takes its second piece
+    // this wave's two piece bases, and the segment of a k-tile's three products (0: h1 W1, 1: h1 W2, 2: h2 W1) that takes its second piece
     const char* base0 = sp_uniform_ptr(is_a ? p.W[0] + (long long)tile_n * SP_BM * p.ldw_b : p.X[0] + tile_m * SP_BN * p.ldx_b);
     const char* base1 = sp_uniform_ptr(is_a ? p.W[1] + (long long)tile_n * SP_BM * p.ldw_b : p.X[1] + tile_m * SP_BN * p.ldx_b);
     const int seg1 = is_a ? 1 : 2;
     const unsigned lds_stage = lds_base + (unsigned)(32 * ridx) * 128 + (is_a ? 0u : (unsigned)SP_B_RING);
-    const int nk = p.nk, nk3 = 3 * p.nk;
+    const int nk3 = 3 * p.nk;
 
     // ---- fragment read offsets (bytes inside a half)
     const int i = lane & 15;
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
 #define SP_ISSUE(POS, H, t2)                                                                                     \
     do {                                                                                                         \
         const int kk_ = (t2) < nk3 ? (t2) : nk3 - 1;                                                             \
-        const int seg_ = (kk_ >= nk ? 1 : 0) + (kk_ >= 2 * nk ? 1 : 0);                                          \
-        const char* src_ = (seg_ == seg1 ? base1 : base0) + (long long)(kk_ - seg_ * nk) * 128;                  \
+        const int kt_ = kk_ / 3, seg_ = kk_ - 3 * kt_;                                                           \
+        const char* src_ = (seg_ == seg1 ? base1 : base0) + (long long)kt_ * 128;                                \
         sp_dma4(voff[H], src_, lds_stage + (POS) + (H) * SP_HALF);                                               \
     } while (0)
 #define SP_ISSUE_A(POS, H, t2) do { if (is_a) SP_ISSUE(POS, H, t2); } while (0)

@@ -29,7 +29,7 @@ try:
     dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "deeploopcloser_amd", "bench.py"], text=True).strip())
 except Exception:
     commit, dirty = None, None
-summary = {"tag": tag, "commit": commit, "tree_dirty_when_summarised": dirty, "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes, --no-paths)] -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe",
+summary = {"tag": tag, "commit": commit, "tree_dirty_when_summarised": dirty, "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes, --no-paths)] -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe --no-shard-emulation",
            "kernels": {}}
 HEADLINE = "score_gemm_kernel<dlc_bf16_tag, 0, false>"      # the 1 M-row launch of the timed loop (GROUPS epilogue, unmasked)
 for row in csv.DictReader(open(stats)):

@@ -518,7 +518,7 @@ def test_sdav_transform_split_mode_within_north_star_tolerance(dlc, scale):
         worst = max(worst, l2.max())
         one = net.transform(x[3:4])
         assert np.array_equal(one, h[90:120])                          # batch invariance (rows are independent)
-    assert worst < (3e-5 if scale == "reference" else 1e-6)            # what the form delivers, with margin
+    assert worst < (4e-5 if scale == "reference" else 1e-6)            # what the form delivers (2.1e-5 / 1.8e-7), with margin
 
 
 def test_sdav_encode_split_odd_shapes(eng):
