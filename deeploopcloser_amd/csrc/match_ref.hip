@@ -7,7 +7,7 @@
 //     loop of src/sdav/create_similarity_matrix.py:29-38): patch-to-patch
 //     distances from one fp64 MFMA Gram GEMM (||a||^2+||b||^2-2a.b), then one
 //     wave per frame pair for argmin / weighted distance / log-sum; or, for up to 32 patches per frame, the arg-min
-//     from exact integer products of 21-bit fixed-point descriptors with a direct fp64 evaluation wherever their
+//     from exact integer products of column-centred 24-bit fixed-point descriptors with a direct fp64 evaluation wherever their
 //     error bound cannot separate the candidates (gram_i8.hip).
 #include <cstdlib>
 #include <cstring>
@@ -586,9 +586,9 @@ __global__ __launch_bounds__(256) void pair_score_tile_kernel(const double* __re
 }
 
 // The filter form (gram_i8.hip): the int8 product kernel has decided, for every row patch a and every later frame j, which
-// patch b of frame j is nearest -- exact integer products of the descriptors' 21-bit fixed-point values, acc 2^-14 <=
-// u_a . u_b <= acc 2^-14 + E, arg-min of |u_b|^2 - 2 acc 2^-14 -- and left in abi / acand [nfp, rp] the index and, where
-// the runner-up lay within 2 E, the set of patches inside that window.  This kernel turns them into scores: undecided sets
+// patch b of frame j is nearest -- exact integer products of the column-centred descriptors' 24-bit fixed-point values v,
+// |2 v_a . v_b - acc 2^-15| <= E, arg-min of |v_b|^2 - acc 2^-15 -- and left in abi / acand [nfp, rp] the index and, where
+// the runner-up lay within 2 E (dlc_sim_window), the set of patches inside that window.  This kernel turns them into scores: undecided sets
 // lose the copies of an earlier member (equal content hashes: the same distance, a later index) and what is left is
 // evaluated directly -- |x_b - x_a| in fp64 from the descriptors, square roots compared as the reference compares them
 // (np.argmin of np.linalg.norm, first minimum: direct_argmin_wave) -- then the P terms of the pair and their sum.

@@ -683,7 +683,7 @@ def test_similarity_tiny_descriptors_follow_the_reference(dlc, monkeypatch):
 
 
 def test_similarity_filter_equals_fp64_gram_route(eng, monkeypatch):
-    """The two routes of dlc_sdav_similarity_matrix -- exact integer products of 21-bit fixed-point descriptors that
+    """The two routes of dlc_sdav_similarity_matrix -- exact integer products of column-centred 24-bit fixed-point descriptors that
     decide the arg-min (with a direct fp64 evaluation where their error bound cannot), and the fp64 Gram matrix --
     give the same matrix bit for bit: uniform, normal (negative values, range far from [0, 1]), saturated sigmoid
     outputs, duplicated patches (exact ties: first index), constant data, ragged sizes."""
