@@ -815,6 +815,26 @@ def main():
     gemm_ms = eng.profile_gemm_ms(min(args.steps, 256))
     eng.set_profiling(False)
 
+    # ---- the step's second stage on its own (N=1, untimed above): selection + fp64 re-score + certificate (+ the early-exit
+    # launch of the exhaustive pass), HIP events around dlc_cosine_select_topk behind a score pass into the same workspace
+    finish_ms = None
+    if world == 1 and pipe is None:
+        qs = db.prepare_queries(queries)
+        ws2 = torch.empty(eng.topk_workspace_bytes(nq, db.rows.shape[0], d, k), dtype=torch.uint8, device=eng.device)
+        o_s = torch.empty((nq, k), dtype=torch.float32, device=eng.device)
+        o_i = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
+        tms = []
+        for _ in range(12):
+            eng.score_groups(qs, db.rows, k, ws2)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            eng.select_topk(qs, db.rows, k, ws2, o_s, o_i, row_offset=lo)
+            e1.record()
+            torch.cuda.synchronize()
+            tms.append(e0.elapsed_time(e1))
+        finish_ms = float(np.mean(tms[2:]))
+        del ws2, o_s, o_i
+
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=eng.device)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -849,6 +869,8 @@ def main():
                        "db_rows": n, "dim": d, "queries_per_step": nq, "k": k, "rows_per_gpu": shard_rows,
                        "pipelined": pipe is not None},
             "recall_at_1": recall1,
+            # the step = score GEMM (roofline.kernel_ms) + this: selection, fp64 re-score of the candidates, certificate
+            "finish_ms": finish_ms, "step_minus_gemm_ms": ms_per_step - (float(np.mean(gemm_ms)) if gemm_ms else float("nan")),
             # digests of the timed result (the same database and queries whatever --gpus is): equal across rank counts
             "topk_idx_sha256": idx_sha, "topk_scores_sha256": scores_sha,
             "rccl_ranks": world if world > 1 else None, "rccl_smoke": smoke,
