@@ -221,8 +221,10 @@ def bench_paths(eng, n_frames):
     """The rows of the hot path other than the headline match, at BASELINE configs[1] / configs[2] size, each
     with the roofline of its dominant kernel and the CPU oracle timed on a bounded sample of the same input
     (the reference's Python cannot travel to this box; oracle/ restates it, `kind: port`)."""
+    import gc
     import deeploopcloser_amd as dlc
     from oracle import sdav as osdav, similarity as osim, distance as odist, cnn_vtl as ocnn, cosine as ocos
+    gc.collect()                                                         # (what the headline part left behind goes now, not inside a timed row)
     N, P, K0, H = n_frames, 30, 1681, 2500
     cores = blas_threads()
     out = []
@@ -293,11 +295,16 @@ def bench_paths(eng, n_frames):
             # the steps as SDAV.fit / fit_dataset run them: one captured HIP graph replayed per step, masks redrawn in place
             tnet.train_steps(0, xb, 5)
             torch.cuda.synchronize()
-            steps_t = 50
-            t0 = time.perf_counter()
-            tnet.train_steps(0, xb, steps_t)
-            torch.cuda.synchronize()
-            step_ms = (time.perf_counter() - t0) / steps_t * 1e3
+            # the fastest of five runs of 10 steps: a step is 0.5 ms, and one host pause inside a single long run -- Python's
+            # cyclic collector freeing what earlier rows left behind took 76 ms once -- would be booked as step time
+            steps_t = 10
+            step_ms = None
+            for _ in range(5):
+                t0 = time.perf_counter()
+                tnet.train_steps(0, xb, steps_t)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps_t * 1e3
+                step_ms = dt if step_ms is None or dt < step_ms else step_ms
             t0 = time.perf_counter()
             for _ in range(20):
                 tnet.train_step(0, xb, masks)                             # ... and one eager call per step (19 launches each)
@@ -802,9 +809,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
     for _ in range(args.warmup):
         step()
     eng.set_profiling(True)
+    gc.collect()                                             # no cyclic collection inside the timed region
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
