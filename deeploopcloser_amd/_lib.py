@@ -66,6 +66,9 @@ SIGNATURES = {
     "dlc_sdav_stream_init": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _dbl, _dbl, _vp, _vp]),
     "dlc_sdav_stream_append": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     "dlc_sdav_stream_query": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _vp, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp]),
+    "dlc_sdav_stream_query_batch_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dlc_sdav_stream_query_batch": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _dbl, _dbl, _vp, _i64, _vp,
+                                           _vp, _sz, _vp]),
     "dlc_cnnvtl_distance_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dlc_l2_normalize_rows": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
     "dlc_cosine_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),

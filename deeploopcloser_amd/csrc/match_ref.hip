@@ -785,8 +785,11 @@ __global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restri
                                                             const double* __restrict__ desc, const double* __restrict__ nu2,
                                                             const unsigned long long* __restrict__ rowhash,
                                                             unsigned long long* __restrict__ keys, long long f, int P, int H,
-                                                            unsigned char* __restrict__ bi_out, const int2* __restrict__ prog) {
+                                                            unsigned char* __restrict__ bi_out, long long bi_pitch,
+                                                            const int2* __restrict__ prog) {
     __shared__ double stacks[4][8 * PF_STACK_DEPTH];
+    f += blockIdx.y;                                               // a batch: query y is frame f + y, its verdicts row y of bi_out
+    bi_out += (long long)blockIdx.y * bi_pitch;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, quad = lane >> 4, an = lane & 15;
     const long long rows_old = f * P;                              // database patches: rows 0 .. rows_old - 1
     const long long gd0 = ((long long)blockIdx.x * 4 + w) * SR_G;
@@ -918,13 +921,16 @@ __global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restri
 // order (32-lane xor tree), so the row equals the matrix call's column f bit for bit.
 __global__ __launch_bounds__(256) void stream_score_kernel(const double* __restrict__ desc, const double* __restrict__ proj,
                                                            const double* __restrict__ score,
-                                                           const unsigned char* __restrict__ bi_in,
+                                                           const unsigned char* __restrict__ bi_in, long long bi_pitch,
                                                            unsigned long long* __restrict__ keys, long long f, int P, int H,
-                                                           double ca, double cb, double* __restrict__ row,
+                                                           double ca, double cb, double* __restrict__ row, long long ld_row,
                                                            long long* __restrict__ stats) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jj = lane >> 5, a = lane & 31;
     const long long j = ((long long)blockIdx.x * 4 + w) * 2 + jj;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                  // this query's count of direct evaluations: handed over and
+    f += blockIdx.y;                                            // a batch: query y is frame f + y, row y of the output
+    bi_in += (long long)blockIdx.y * bi_pitch;
+    row += (long long)blockIdx.y * ld_row;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // the call's count of direct evaluations: handed over and
         if (stats) { stats[0] = (long long)keys[4]; stats[1] = keys[2] ? 1 : 0; }
         keys[4] = 0ull;                                         // reset for the next query (no memset launch in front of it)
     }
@@ -1346,6 +1352,33 @@ extern "C" int dlc_sdav_stream_append(dlc_ctx* ctx, void* state, size_t state_by
                                          g_first, g_last - g_first, (hipStream_t)stream);
 }
 
+static int stream_query_impl(dlc_ctx* ctx, const char* what, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                             const double* desc, int64_t f, int64_t nq, const double* score, double a, double b, double* rows_out,
+                             int64_t ld_rows, int64_t* stats, unsigned char* bi, int64_t bi_pitch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const StreamWs w = stream_ws(capacity, P, H);
+    char* ws = (char*)state;
+    unsigned long long* keys = (unsigned long long*)(ws + w.keys);
+    const int64_t f_last = f + nq - 1;
+    if (f_last == 0) {                                          // (one query, frame 0: nothing older)
+        if (stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
+        return DLC_OK;
+    }
+    const long long kp = (long long)dlc::align_up((size_t)H, (size_t)256);
+    const long long gpitch = 3 * kp * 16;
+    const long long groups = dlc::cdiv(f_last * P, (int64_t)16);          // of the newest query; an older one's extra blocks leave at once
+    hipLaunchKernelGGL(stream_argmin_kernel, dim3((unsigned)dlc::cdiv(groups, (long long)(4 * SR_G)), (unsigned)nq), dim3(256), 0, st,
+                       (const char*)(ws + w.panel), gpitch, (int)(kp / 64), desc, (const double*)(ws + w.nu2),
+                       (const unsigned long long*)(ws + w.rowhash), keys, (long long)f, (int)P, (int)H, bi, (long long)bi_pitch,
+                       (const int2*)(ws + w.prog));
+    DLC_LAUNCH_CHECK(ctx, "stream_argmin_kernel");
+    hipLaunchKernelGGL(stream_score_kernel, dim3((unsigned)dlc::cdiv(f_last, (int64_t)8), (unsigned)nq), dim3(256), 0, st, desc,
+                       (const double*)(ws + w.proj), score, (const unsigned char*)bi, (long long)bi_pitch, keys, (long long)f, (int)P,
+                       (int)H, a, b, rows_out, (long long)ld_rows, (long long*)stats);
+    DLC_LAUNCH_CHECK(ctx, what);
+    return DLC_OK;
+}
+
 extern "C" int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
                                      const double* desc, int64_t f, const double* score, double a, double b, double* row_out,
                                      int64_t* stats, void* stream) {
@@ -1355,27 +1388,33 @@ extern "C" int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_byt
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_query: bad argument");
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    hipStream_t st = (hipStream_t)stream;
     const StreamWs w = stream_ws(capacity, P, H);
-    char* ws = (char*)state;
-    unsigned long long* keys = (unsigned long long*)(ws + w.keys);
-    if (f == 0) {
-        if (stats) DLC_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 16, st));
-        return DLC_OK;
-    }
-    const long long kp = (long long)dlc::align_up((size_t)H, (size_t)256);
-    const long long gpitch = 3 * kp * 16;
-    const long long groups = dlc::cdiv(f * P, (int64_t)16);
-    hipLaunchKernelGGL(stream_argmin_kernel, dim3((unsigned)dlc::cdiv(groups, (long long)(4 * SR_G))), dim3(256), 0, st,
-                       (const char*)(ws + w.panel), gpitch, (int)(kp / 64), desc, (const double*)(ws + w.nu2),
-                       (const unsigned long long*)(ws + w.rowhash), keys, (long long)f, (int)P, (int)H,
-                       (unsigned char*)(ws + w.bi), (const int2*)(ws + w.prog));
-    DLC_LAUNCH_CHECK(ctx, "stream_argmin_kernel");
-    hipLaunchKernelGGL(stream_score_kernel, dim3((unsigned)dlc::cdiv(f, (int64_t)8)), dim3(256), 0, st, desc,
-                       (const double*)(ws + w.proj), score, (const unsigned char*)(ws + w.bi), keys, (long long)f, (int)P,
-                       (int)H, a, b, row_out, (long long*)stats);
-    DLC_LAUNCH_CHECK(ctx, "stream_score_kernel");
-    return DLC_OK;
+    return stream_query_impl(ctx, "stream_score_kernel", state, state_bytes, capacity, P, H, desc, f, 1, score, a, b, row_out, 0, stats,
+                             (unsigned char*)((char*)state + w.bi), 0, stream);
+}
+
+extern "C" size_t dlc_sdav_stream_query_batch_workspace_bytes(int64_t capacity, int64_t P, int64_t n_queries) {
+    if (capacity < 1 || P < 1 || n_queries < 1) return 0;
+    return (size_t)n_queries * dlc::align_up((size_t)capacity * (size_t)P, 256);
+}
+
+extern "C" int dlc_sdav_stream_query_batch(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                                           const double* desc, int64_t f_first, int64_t n_queries, const double* score, double a,
+                                           double b, double* rows_out, int64_t ld_rows, int64_t* stats, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    int rc = stream_check(ctx, "sdav_stream_query_batch", state, state_bytes, capacity, P, H);
+    if (rc != DLC_OK) return rc;
+    if (!desc || !score || !rows_out || f_first < 0 || n_queries < 1 || n_queries > 65535 || f_first + n_queries > capacity ||
+        ld_rows < f_first + n_queries - 1)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_query_batch: bad argument (frames [%lld, %lld) of capacity %lld, ld_rows %lld)",
+                         (long long)f_first, (long long)(f_first + n_queries), (long long)capacity, (long long)ld_rows);
+    const size_t need = dlc_sdav_stream_query_batch_workspace_bytes(capacity, P, n_queries);
+    if (!workspace || workspace_bytes < need)
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "sdav_stream_query_batch: workspace %zu < %zu bytes", workspace_bytes, need);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    return stream_query_impl(ctx, "stream_score_kernel", state, state_bytes, capacity, P, H, desc, f_first, n_queries, score, a, b, rows_out,
+                             ld_rows, stats, (unsigned char*)workspace, (int64_t)dlc::align_up((size_t)capacity * (size_t)P, 256), stream);
 }
 
 extern "C" int dlc_topk_rows_f64(dlc_ctx* ctx, const double* scores, int64_t rows, int64_t ld, int64_t limit0, int64_t limit_step,

@@ -589,6 +589,24 @@ class Engine:
                                                     float(a), float(b), _ptr(out), _ptr(stats), self._stream()))
         return out
 
+    def sdav_stream_query_batch(self, state, desc, f_first, n_queries, score, a=10.0, b=-10.0, out=None, stats=None):
+        """Rows of the resident frames f_first .. f_first + n_queries - 1 against the frames older than each, in one pair of
+        launches: out [n_queries, ld >= f_first + n_queries - 1] fp64, row q valid in its first f_first + q entries."""
+        cap, p, h = desc.shape
+        ld = max(1, int(f_first) + int(n_queries) - 1)
+        if out is None:
+            out = torch.empty((int(n_queries), ld), dtype=torch.float64, device=self.device)
+        else:
+            self._check_out("out", out, (int(n_queries), out.shape[1]), torch.float64)
+        if stats is not None:
+            self._check_out("stats", stats, (2,), torch.int64)
+        need = self.lib.dlc_sdav_stream_query_batch_workspace_bytes(cap, p, int(n_queries))
+        ws = self.workspace("stream_batch", need)
+        self._check(self.lib.dlc_sdav_stream_query_batch(self.ctx, _ptr(state), state.numel(), cap, p, h, _ptr(desc), int(f_first),
+                                                          int(n_queries), _ptr(score), float(a), float(b), _ptr(out), out.shape[1],
+                                                          _ptr(stats), _ptr(ws), ws.numel(), self._stream()))
+        return out
+
     def topk_rows_f64(self, scores, limit0, limit_step, k):
         """(scores [rows, k] fp64, idx [rows, k] int64) of the k best of the first limit0 + r * limit_step entries of row r of
         scores [rows, ld] (fp64): score descending, ties -> the lower index, NaN never; (-inf, -1) where fewer."""

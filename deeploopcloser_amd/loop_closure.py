@@ -133,10 +133,12 @@ class SdavLoopClosureDetector:
             x = x.unsqueeze(0)
         b = x.shape[0]
         first = st.append(x)                                          # all B frames become resident: one quantisation launch
-        rows = torch.empty((b, first + b), dtype=torch.float64, device=eng.device)
-        for r in range(b):                                            # frame first + r against every older frame: rows[r, :first + r]
-            if first + r > 0:
-                st.query(first + r, out=rows[r, :first + r])
+        if first + b - 1 == 0:                                        # the very first frame alone: nothing older
+            return (torch.full((b, self.k), float("-inf"), dtype=torch.float64, device=eng.device),
+                    torch.full((b, self.k), -1, dtype=torch.int64, device=eng.device))
+        # frame first + r against every older frame, all B of them in one pair of launches (dlc_sdav_stream_query_batch):
+        # rows[r, :first + r]
+        rows = st.query_batch(first, b)
         # the k best of the frames old enough -- one launch for the batch (dlc_topk_rows_f64: score descending, ties ->
         # the older frame; a poisoned stream's NaN rows yield nothing here and loops() raises)
         return eng.topk_rows_f64(rows, first - self.exclusion, 1, self.k)

@@ -137,6 +137,14 @@ class SimilarityStream:
             raise ValueError("query: out must be a contiguous float64 tensor of %d entries" % f)
         return self.engine.sdav_stream_query(self.state, self.desc, f, self.score, self.a, self.b, out=out, stats=self.stats)
 
+    def query_batch(self, first, count):
+        """Device tensor [count, first + count - 1]: row q = query(first + q) in its first `first + q` entries (the rest of a
+        row is unspecified) -- the resident frames first .. first + count - 1 scored in ONE pair of launches."""
+        first, count = int(first), int(count)
+        if count < 1 or first < 0 or first + count > self._n:
+            raise ValueError("frames %d .. %d are not all resident (0..%d)" % (first, first + count - 1, self._n - 1))
+        return self.engine.sdav_stream_query_batch(self.state, self.desc, first, count, self.score, self.a, self.b, stats=self.stats)
+
     def query_and_insert(self, frame):
         """One new frame [P, H]: it becomes resident and its row against all older frames comes back (device, fp64)."""
         self.append(frame)

@@ -368,6 +368,18 @@ int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t
                           const double* desc, int64_t f, const double* score, double a, double b, double* row_out,
                           int64_t* stats, void* stream);
 /*
+ * The same for n_queries consecutive resident frames f_first .. f_first + n_queries - 1 in ONE pair of launches (a batch
+ * of frames that arrived together: each still sees only the frames older than itself): row q of rows_out [n_queries,
+ * ld_rows] receives entries 0 .. f_first + q - 1 (the rest of the row is left alone; ld_rows >= f_first + n_queries - 1),
+ * each equal to what dlc_sdav_stream_query writes for that frame, bit for bit.  stats[0]: the direct evaluations of the whole
+ * batch.  workspace: dlc_sdav_stream_query_batch_workspace_bytes (the queries' nearest-patch verdicts), 256-byte aligned.
+ */
+size_t dlc_sdav_stream_query_batch_workspace_bytes(int64_t capacity, int64_t P, int64_t n_queries);
+int dlc_sdav_stream_query_batch(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                                const double* desc, int64_t f_first, int64_t n_queries, const double* score, double a,
+                                double b, double* rows_out, int64_t ld_rows, int64_t* stats, void* workspace,
+                                size_t workspace_bytes, void* stream);
+/*
  * The k best entries of every row of an fp64 score matrix scores [rows, ld] -- the loop-closure candidates of a batch of
  * streamed frames (rows of dlc_sdav_stream_query): row r offers its first min(ld, limit0 + r * limit_step) entries (none
  * when that is <= 0); order: score descending, ties -> the lower index (the older frame); a NaN is never taken.

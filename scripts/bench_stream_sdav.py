@@ -26,6 +26,16 @@ for f in (n - 1, n // 2):
     mb = f * 30 * 7680 / 1e6
     print("query of frame %d against %d older frames: %.1f us per query (%.0f MB of panel: %.2f TB/s), direct evaluations %d"
           % (f, f, us, mb, mb / us, int(st.stats[0])))
+for cnt in (8, 32):                        # a batch of frames that arrived together: one pair of launches
+    st.query_batch(n - cnt, cnt); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        st.query_batch(n - cnt, cnt)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print("batch of %d queries (frames %d .. %d): %.1f us per batch = %.1f us per query, direct evaluations %d"
+          % (cnt, n - cnt, n - 1, us, us / cnt, int(st.stats[0])))
 t0 = time.perf_counter()
 st2 = dlc.SimilarityStream(score, capacity=n)
 for f in range(64):

@@ -276,4 +276,16 @@ def test_topk_rows_f64_and_batched_detector():
     s2, i2 = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     assert torch.equal(i1, i2) and torch.equal(s1, s2)
     assert int(i1[9, 0]) == 2 and bool(torch.isinf(s1[9, 0]))       # the repeated frame finds its first sighting
+    # dlc_sdav_stream_query_batch: rows of several resident frames in one pair of launches == one query each, bit for bit
+    st = bat.stream
+    for first, count in ((0, 1), (0, 5), (1, 1), (7, 13), (n - 3, 3), (0, n)):
+        rows = st.query_batch(first, count)
+        assert rows.shape == (count, max(1, first + count - 1))
+        for q in range(count):
+            f = first + q
+            want = st.query(f)
+            assert torch.equal(torch.nan_to_num(rows[q, :f], posinf=1e300), torch.nan_to_num(want, posinf=1e300)), (first, count, q)
+            assert torch.equal(rows[q, :f].isinf(), want.isinf())
+    with pytest.raises(ValueError):
+        st.query_batch(n - 1, 2)
     assert one.loops(s1, i1, 0) == bat.loops(s2, i2, 0)
