@@ -450,6 +450,52 @@ def bench_paths(eng, n_frames):
     del mf, mi, sub, ref, dsn
     out[-1]["direct_evaluations"] = sim_direct(desc)[0]
 
+    # ---- f-4 with the REFERENCE's similarity: frames arriving in batches, each scored against every older resident frame
+    # (SimilarityCalculator.similarity_score per pair; create_similarity_matrix.py:34-38 as a robot would run it) ----------
+    sb, sk, sex = 32, 5, 30
+    def sdav_stream():
+        det_ = dlc.SdavLoopClosureDetector(score_s, patches=P, width=H, k=sk, exclusion=sex, capacity=N)
+        outs_ = [det_.query_and_insert(desc[lo:lo + sb]) for lo in range(0, N, sb)]
+        return det_, torch.cat([o[0] for o in outs_]), torch.cat([o[1] for o in outs_])
+    score_s = eng.distinctive_score(desc, 0.5, 0.2)
+    ss_ms, _, _, (sdet, sds, sdi) = _timed_path(eng, sdav_stream, reps=2)
+    # every row of the stream is the matrix call's column: the detector's ranking of it against a stable sort of that column
+    mcol = eng.sdav_similarity_matrix(desc, score_s, 10.0, -10.0, want_int64=False)[0].cpu().numpy()
+    agree, checked = 0, 0
+    for f_ in range(0, N, max(1, N // 40)):
+        nsee = f_ - sex
+        if nsee <= 0:
+            continue
+        col = mcol[:nsee, f_]
+        order = np.lexsort((np.arange(nsee), -col))[:sk]
+        got_ = sdi[f_, :len(order)].cpu().numpy()
+        agree += int(np.array_equal(got_, order)); checked += 1
+    nsm = min(N, 10)
+    dsm = desc[:nsm].cpu().numpy()
+    scm = score_s.cpu().numpy()
+    t0 = time.perf_counter()
+    for f_ in range(1, nsm):
+        for j_ in range(f_):
+            with np.errstate(divide="ignore"):
+                np.sum(10 - 10 * np.log(osim.weighted_distances(dsm[j_], dsm[f_], osim.match_features(dsm[j_], dsm[f_]), scm)))
+    t_cpu = time.perf_counter() - t0
+    panel_bytes = float(N) * N / 2 * P * 3 * 2560 / 2                     # two frames of a batch share one stream of the older frames' fixed-point panel
+    out.append({"path": "SdavLoopClosureDetector.query_and_insert (batches of %d frames)" % sb,
+                "reference": "src/sdav/similarity/SimilarityCalculator.py:12-49 per arriving frame (src/sdav/create_similarity_matrix.py:34-38)",
+                "frames": N, "dtype": "f64", "k": sk, "value": (N * (N - 1) / 2.0) / (ss_ms * 1e-3), "unit": "frame-pairs/s", "ms": ss_ms,
+                "frames_per_s": N / (ss_ms * 1e-3),
+                "roofline": {"bound": "hbm", "achieved": panel_bytes / (ss_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": panel_bytes / (ss_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": "stream_argmin_kernel<2> + stream_score_kernel (one pair of launches per batch; two frames per pass "
+                                       "over the older frames' int8 panel) + the quantisation of the batch + topk_rows_f64_kernel",
+                             "kernel_ms": ss_ms, "call_ms": ss_ms, "algorithmic_bytes_per_call": panel_bytes},
+                "cpu_baseline": {"value": (nsm * (nsm - 1) // 2) / t_cpu, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                                 "sample": "oracle/similarity.py similarity_score terms for every frame of the first %d against its older "
+                                           "frames (%d pairs): %.2f s" % (nsm, nsm * (nsm - 1) // 2, t_cpu)},
+                "ranking_equals_matrix_columns": agree == checked, "frames_checked": checked,
+                "stream_poisoned": int(sdet.stream.stats[1])})
+    del sdet, sds, sdi, mcol, dsm
+
     # ---- M1/M2 on real-image statistics: the repo's 20 real frames (tests/golden) tiled to N, through the GPU front-end and
     # SDAV.transform with the reference's N(0,1) initialiser (real images saturate it) and with 1/sqrt(fan_in) weights
     # (every descriptor column within 1e-3 of its own mean, the means spread over [0.15, 0.88]: low contrast) -------------

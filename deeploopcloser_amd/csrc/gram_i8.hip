@@ -785,7 +785,7 @@ int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, in
 
 size_t sim_stream_panel_bytes(int64_t rows, int64_t H) {
     const size_t kp = dlc::align_up((size_t)H, (size_t)GI_KPAD);
-    return (size_t)(dlc::cdiv(rows, (int64_t)16) + 4) * 3 * kp * 16;      // whole groups + the query's three-group window past the end
+    return (size_t)(dlc::cdiv(rows, (int64_t)16) + 8) * 3 * kp * 16;      // whole groups + the queries' five-group window past the end
 }
 
 // |x|^2, dot(score, x) and the content hash of every patch row (the fp64 Gram form; the filter's prepare computes the same

@@ -781,33 +781,43 @@ __device__ __forceinline__ void sr_merge(int& best, int& bidx, int& second, int 
     if (take) { best = ob; bidx = oi; }
 }
 
+// NQ: query frames per pass over the database panel.  NQ = 1 is the single query (two register rings four k-steps deep: the
+// latency form).  NQ = 2 scores TWO consecutive frames per pass -- their 2 P patches lie in five consecutive groups of the
+// panel -- so a batch of frames that arrived together streams the older frames' panel once per pair instead of once per
+// frame (a batch of 32 one frame per pass: 47 us per query, all of it the 245 MB panel at 5.2 TB/s).  Query y of pass
+// blockIdx.y is frame f + blockIdx.y * NQ + y (< f_end); its verdicts go to row blockIdx.y * NQ + y of bi_out.
+template <int NQ>
 __global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restrict__ X, long long gpitch, int n64,
                                                             const double* __restrict__ desc, const double* __restrict__ nu2,
                                                             const unsigned long long* __restrict__ rowhash,
-                                                            unsigned long long* __restrict__ keys, long long f, int P, int H,
-                                                            unsigned char* __restrict__ bi_out, long long bi_pitch,
+                                                            unsigned long long* __restrict__ keys, long long f, long long f_end, int P,
+                                                            int H, unsigned char* __restrict__ bi_out, long long bi_pitch,
                                                             const int2* __restrict__ prog) {
+    constexpr int NG = 2 * NQ + 1;                                 // query-side groups: NQ * P + 15 patches at most
+    constexpr int DEPTH = NQ == 1 ? 4 : 2;                         // k-steps in flight (registers: rings of DEPTH buffers)
     __shared__ double stacks[4][8 * PF_STACK_DEPTH];
-    f += blockIdx.y;                                               // a batch: query y is frame f + y, its verdicts row y of bi_out
-    bi_out += (long long)blockIdx.y * bi_pitch;
+    f += (long long)blockIdx.y * NQ;                               // the pass's first query frame
+    bi_out += (long long)blockIdx.y * NQ * bi_pitch;
+    const int nv = (int)(f_end - f < NQ ? f_end - f : NQ);         // query frames of this pass (>= 1)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, quad = lane >> 4, an = lane & 15;
-    const long long rows_old = f * P;                              // database patches: rows 0 .. rows_old - 1
+    const long long rows_q0 = f * P;                               // first patch of the pass's first query frame
+    const long long rows_last = (f + nv - 1) * P;                  // database patches of its LAST query: rows 0 .. rows_last - 1
     const long long gd0 = ((long long)blockIdx.x * 4 + w) * SR_G;
     // (the count of direct evaluations, keys[4], is zero: the stream's creation and every query's last kernel leave it so)
-    if (gd0 * 16 >= rows_old) return;                              // (whole wave)
-    const long long gq0 = rows_old / 16;                           // frame f's patches lie in groups gq0 .. gq0 + 2
-    const int boff = (int)(rows_old - gq0 * 16);
+    if (gd0 * 16 >= rows_last) return;                             // (whole wave)
+    const long long gq0 = rows_q0 / 16;                            // the query frames' patches lie in groups gq0 .. gq0 + NG - 1
+    const int boff0 = (int)(rows_q0 - gq0 * 16);
     const char* xq = X + gq0 * gpitch + lane * 16;
     const char* xd = X + gd0 * gpitch + lane * 16;
-    sr_v4i c2[3][SR_G], c3[3][SR_G], c4[3][SR_G];
+    sr_v4i c2[NG][SR_G], c3[NG][SR_G], c4[NG][SR_G];
 #pragma unroll
-    for (int jq = 0; jq < 3; ++jq)
+    for (int jq = 0; jq < NG; ++jq)
 #pragma unroll
         for (int ig = 0; ig < SR_G; ++ig) { c2[jq][ig] = sr_v4i{0, 0, 0, 0}; c3[jq][ig] = sr_v4i{0, 0, 0, 0}; c4[jq][ig] = sr_v4i{0, 0, 0, 0}; }
-    // The database fragments come from HBM (a wave's 6 KiB per k-step, read once, non-temporal), the query's from L2
-    // (9 KiB per k-step, the same for every wave); both are fetched THREE k-steps ahead through a ring of four register
-    // buffers -- one k-step ahead, a wave finished a k-step per memory round trip: 25 us for the K loop alone.
-    sr_v4i q[4][3][3], d[4][3][SR_G];                              // [ring buffer][slice][group]
+    // The database fragments come from HBM (a wave's 6 KiB per k-step, read once, non-temporal), the queries' from L2
+    // (3 KiB per group and k-step, the same for every wave); both are fetched DEPTH - 1 k-steps ahead through rings of
+    // register buffers -- one k-step ahead, a wave finished a k-step per memory round trip: 25 us for the K loop alone.
+    sr_v4i q[DEPTH][3][NG], d[DEPTH][3][SR_G];                     // [ring buffer][slice][group]
     auto fetch = [&](int buf, int t) {
 #pragma unroll
         for (int s_ = 0; s_ < 3; ++s_) {
@@ -815,11 +825,11 @@ __global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restri
 #pragma unroll
             for (int ig = 0; ig < SR_G; ++ig) d[buf][s_][ig] = __builtin_nontemporal_load((const sr_v4i*)(xd + ig * gpitch + ko));
 #pragma unroll
-            for (int jq = 0; jq < 3; ++jq) q[buf][s_][jq] = *(const sr_v4i*)(xq + jq * gpitch + ko);
+            for (int jq = 0; jq < NG; ++jq) q[buf][s_][jq] = *(const sr_v4i*)(xq + jq * gpitch + ko);
         }
     };
 #define SR_STEP(B)                                                                                                        \
-    _Pragma("unroll") for (int jq = 0; jq < 3; ++jq)                                                                      \
+    _Pragma("unroll") for (int jq = 0; jq < NG; ++jq)                                                                     \
         _Pragma("unroll") for (int ig = 0; ig < SR_G; ++ig) {                                                             \
             c2[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][0][jq], d[B][0][ig], c2[jq][ig], 0, 0, 0);            \
             c3[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][1][jq], d[B][0][ig], c3[jq][ig], 0, 0, 0);            \
@@ -828,90 +838,95 @@ __global__ __launch_bounds__(256) void stream_argmin_kernel(const char* __restri
             c4[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][1][jq], d[B][1][ig], c4[jq][ig], 0, 0, 0);            \
             c4[jq][ig] = __builtin_amdgcn_mfma_i32_16x16x64_i8(q[B][0][jq], d[B][2][ig], c4[jq][ig], 0, 0, 0);            \
         }
-    fetch(0, 0); fetch(1, 1); fetch(2, 2);                         // n64 >= 4
-    for (int t = 0; t < n64; t += 4) {                             // n64 is a multiple of 4
-        if (t + 3 < n64) fetch(3, t + 3);
-        SR_STEP(0)
-        if (t + 4 < n64) fetch(0, t + 4);
-        SR_STEP(1)
-        if (t + 5 < n64) fetch(1, t + 5);
-        SR_STEP(2)
-        if (t + 6 < n64) fetch(2, t + 6);
-        SR_STEP(3)
+#pragma unroll
+    for (int i = 0; i < DEPTH - 1; ++i) fetch(i, i);               // n64 >= 4 > DEPTH - 1
+    for (int t = 0; t < n64; t += DEPTH) {                         // k-step s lives in ring buffer s % DEPTH
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            if (t + i + DEPTH - 1 < n64) fetch((i + DEPTH - 1) % DEPTH, t + i + DEPTH - 1);
+            if (t + i < n64) { SR_STEP(i) }
+        }
     }
 #undef SR_STEP
-    // D[m][n] of MFMA (jq, ig): m = query-side patch jq * 16 + quad * 4 + v (b = that - boff), n = database patch an of group ig
+    // D[m][n] of MFMA (jq, ig): m = query-side patch jq * 16 + quad * 4 + v (patch b = that - boff of its frame), n = database
+    // patch an of group ig
     const long long window = dlc_gemm::dlc_sim_window(keys, H);
     const int prog_len = (int)keys[5];
-    int nbv[3][4];                                                 // |v_b|^2 of this lane's twelve query patches, units of 2^-15
-#pragma unroll
-    for (int jq = 0; jq < 3; ++jq)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int b = jq * 16 + quad * 4 + v - boff;
-            nbv[jq][v] = (b >= 0 && b < P) ? (int)llrint(nu2[rows_old + b] * 32768.0) : 0;
-        }
     unsigned long long directs = 0;
 #pragma unroll
-    for (int ig = 0; ig < SR_G; ++ig) {
-        const long long a = (gd0 + ig) * 16 + an;
-        const bool a_ok = a < rows_old;
-        int best = 0x7fffffff, second = 0x7fffffff, bidx = 0x7fffffff;
-        int d2v[3][4];
+    for (int y = 0; y < NQ; ++y) {
+        if (y >= nv) break;                                        // (uniform)
+        const long long rows_old = rows_q0 + (long long)y * P;     // query frame f + y: database patches 0 .. rows_old - 1
+        const int boff = boff0 + y * P;
+        int nbv[NG][4];                                            // |v_b|^2 of this lane's query-side patches that belong to frame y, units of 2^-15
 #pragma unroll
-        for (int jq = 0; jq < 3; ++jq) {
-            const sr_v4i acc = c2[jq][ig] + ((c3[jq][ig] + (c4[jq][ig] >> 8)) >> 8);
+        for (int jq = 0; jq < NG; ++jq)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int b = jq * 16 + quad * 4 + v - boff;
-                d2v[jq][v] = nbv[jq][v] - acc[v];
-                if (b >= 0 && b < P) sr_merge(best, bidx, second, d2v[jq][v], b, 0x7fffffff);
+                nbv[jq][v] = (b >= 0 && b < P) ? (int)llrint(nu2[rows_old + b] * 32768.0) : 0;
             }
-        }
 #pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {                       // the four quads hold the rest of patch a's row
-            const int ob = __shfl_xor(best, o), oi = __shfl_xor(bidx, o), os = __shfl_xor(second, o);
-            sr_merge(best, bidx, second, ob, oi, os);
-        }
-        int bi = bidx < P ? bidx : 0;
-        unsigned cand = 0;
-        if ((long long)second - best <= window) {
+        for (int ig = 0; ig < SR_G; ++ig) {
+            const long long a = (gd0 + ig) * 16 + an;
+            const bool a_ok = a < rows_old;
+            int best = 0x7fffffff, second = 0x7fffffff, bidx = 0x7fffffff;
+            int d2v[NG][4];
 #pragma unroll
-            for (int jq = 0; jq < 3; ++jq)
+            for (int jq = 0; jq < NG; ++jq) {
+                const sr_v4i acc = c2[jq][ig] + ((c3[jq][ig] + (c4[jq][ig] >> 8)) >> 8);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int b = jq * 16 + quad * 4 + v - boff;
-                    if (b >= 0 && b < P && (long long)d2v[jq][v] - best <= window) cand |= 1u << b;
+                    d2v[jq][v] = nbv[jq][v] - acc[v];
+                    if (b >= 0 && b < P) sr_merge(best, bidx, second, d2v[jq][v], b, 0x7fffffff);
                 }
-        }
-        cand |= (unsigned)__shfl_xor((int)cand, 16);
-        cand |= (unsigned)__shfl_xor((int)cand, 32);
-        if (cand & (cand - 1)) {
-            // a copy of an earlier candidate (equal content hashes) has that candidate's distance and a later index
-            const unsigned long long* hb = rowhash + 2 * rows_old;
-            unsigned kept = 0;
-            for (unsigned m = cand; m; m &= m - 1) {
-                const int b = __ffs((int)m) - 1;
-                bool copy = false;
-                for (unsigned k2 = kept; k2; k2 &= k2 - 1) {
-                    const int e = __ffs((int)k2) - 1;
-                    copy |= hb[2 * e] == hb[2 * b] && hb[2 * e + 1] == hb[2 * b + 1];
-                }
-                if (!copy) kept |= 1u << b;
             }
-            cand = kept;
-            if (!(cand & (cand - 1))) { bi = __ffs((int)cand) - 1; cand = 0; }
-        } else cand = 0;
-        for (unsigned long long todo = __ballot(cand != 0 && quad == 0 && a_ok); todo; todo &= todo - 1) {
-            const int src = __ffsll((long long)todo) - 1;
-            const unsigned cm = (unsigned)__shfl((int)cand, src);
-            const long long a_s = (gd0 + ig) * 16 + (src & 15);
-            const int ebi = direct_argmin_wave(desc + a_s * H, desc + rows_old * H, (unsigned long long)cm, P, H, lane, prog,
-                                               prog_len, stacks[w]);
-            if (lane == src) bi = ebi;
-            if (lane == 0) ++directs;
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {                   // the four quads hold the rest of patch a's row
+                const int ob = __shfl_xor(best, o), oi = __shfl_xor(bidx, o), os = __shfl_xor(second, o);
+                sr_merge(best, bidx, second, ob, oi, os);
+            }
+            int bi = bidx < P ? bidx : 0;
+            unsigned cand = 0;
+            if ((long long)second - best <= window) {
+#pragma unroll
+                for (int jq = 0; jq < NG; ++jq)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int b = jq * 16 + quad * 4 + v - boff;
+                        if (b >= 0 && b < P && (long long)d2v[jq][v] - best <= window) cand |= 1u << b;
+                    }
+            }
+            cand |= (unsigned)__shfl_xor((int)cand, 16);
+            cand |= (unsigned)__shfl_xor((int)cand, 32);
+            if (cand & (cand - 1)) {
+                // a copy of an earlier candidate (equal content hashes) has that candidate's distance and a later index
+                const unsigned long long* hb = rowhash + 2 * rows_old;
+                unsigned kept = 0;
+                for (unsigned m = cand; m; m &= m - 1) {
+                    const int b = __ffs((int)m) - 1;
+                    bool copy = false;
+                    for (unsigned k2 = kept; k2; k2 &= k2 - 1) {
+                        const int e = __ffs((int)k2) - 1;
+                        copy |= hb[2 * e] == hb[2 * b] && hb[2 * e + 1] == hb[2 * b + 1];
+                    }
+                    if (!copy) kept |= 1u << b;
+                }
+                cand = kept;
+                if (!(cand & (cand - 1))) { bi = __ffs((int)cand) - 1; cand = 0; }
+            } else cand = 0;
+            for (unsigned long long todo = __ballot(cand != 0 && quad == 0 && a_ok); todo; todo &= todo - 1) {
+                const int src = __ffsll((long long)todo) - 1;
+                const unsigned cm = (unsigned)__shfl((int)cand, src);
+                const long long a_s = (gd0 + ig) * 16 + (src & 15);
+                const int ebi = direct_argmin_wave(desc + a_s * H, desc + rows_old * H, (unsigned long long)cm, P, H, lane, prog,
+                                                   prog_len, stacks[w]);
+                if (lane == src) bi = ebi;
+                if (lane == 0) ++directs;
+            }
+            if (quad == 0 && a_ok) bi_out[(long long)y * bi_pitch + a] = (unsigned char)bi;
         }
-        if (quad == 0 && a_ok) bi_out[a] = (unsigned char)bi;
     }
     if (lane == 0 && directs) atomicAdd(&keys[4], directs);
 }
@@ -1367,10 +1382,15 @@ static int stream_query_impl(dlc_ctx* ctx, const char* what, void* state, size_t
     const long long kp = (long long)dlc::align_up((size_t)H, (size_t)256);
     const long long gpitch = 3 * kp * 16;
     const long long groups = dlc::cdiv(f_last * P, (int64_t)16);          // of the newest query; an older one's extra blocks leave at once
-    hipLaunchKernelGGL(stream_argmin_kernel, dim3((unsigned)dlc::cdiv(groups, (long long)(4 * SR_G)), (unsigned)nq), dim3(256), 0, st,
-                       (const char*)(ws + w.panel), gpitch, (int)(kp / 64), desc, (const double*)(ws + w.nu2),
-                       (const unsigned long long*)(ws + w.rowhash), keys, (long long)f, (int)P, (int)H, bi, (long long)bi_pitch,
-                       (const int2*)(ws + w.prog));
+    const dim3 agrid((unsigned)dlc::cdiv(groups, (long long)(4 * SR_G)), (unsigned)(nq == 1 ? 1 : dlc::cdiv(nq, (int64_t)2)));
+    if (nq == 1)
+        hipLaunchKernelGGL(stream_argmin_kernel<1>, agrid, dim3(256), 0, st, (const char*)(ws + w.panel), gpitch, (int)(kp / 64), desc,
+                           (const double*)(ws + w.nu2), (const unsigned long long*)(ws + w.rowhash), keys, (long long)f,
+                           (long long)(f + nq), (int)P, (int)H, bi, (long long)bi_pitch, (const int2*)(ws + w.prog));
+    else                                                        // a batch: two query frames per pass over the panel
+        hipLaunchKernelGGL(stream_argmin_kernel<2>, agrid, dim3(256), 0, st, (const char*)(ws + w.panel), gpitch, (int)(kp / 64), desc,
+                           (const double*)(ws + w.nu2), (const unsigned long long*)(ws + w.rowhash), keys, (long long)f,
+                           (long long)(f + nq), (int)P, (int)H, bi, (long long)bi_pitch, (const int2*)(ws + w.prog));
     DLC_LAUNCH_CHECK(ctx, "stream_argmin_kernel");
     hipLaunchKernelGGL(stream_score_kernel, dim3((unsigned)dlc::cdiv(f_last, (int64_t)8), (unsigned)nq), dim3(256), 0, st, desc,
                        (const double*)(ws + w.proj), score, (const unsigned char*)bi, (long long)bi_pitch, keys, (long long)f, (int)P,

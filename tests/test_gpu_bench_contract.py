@@ -55,6 +55,7 @@ def test_bench_json_contract():
                           "SDAV similarity matrix, real-frame statistics, 1/sqrt(fan_in) weights",
                           "patch front-end (grey + Harris + 30 patches of 41x41)",
                           "LoopClosureDetector.query_and_insert (batches of 32 frames)",
+                          "SdavLoopClosureDetector.query_and_insert (batches of 32 frames)",
                           "cosine similarity matrix (flattened SDAV descriptors)",
                           "cosine top-20 (flattened SDAV descriptors)", "CnnVtl.transform", "cnn_vtl distance matrix"}
     assert paths["SDAV.transform (f16x2 split, tolerance mode)"]["rel_l2_vs_fp64_encoder_max"] < 1e-4
@@ -64,6 +65,7 @@ def test_bench_json_contract():
     assert paths["SDAV.train_step (layer 0, 10 frames)"]["loss_rel_err_vs_oracle"] < 1e-9
     assert paths["patch front-end (grey + Harris + 30 patches of 41x41)"]["bit_exact_vs_oracle"] is True
     assert paths["LoopClosureDetector.query_and_insert (batches of 32 frames)"]["index_agreement_vs_oracle"] > 0.999
+    assert paths["SdavLoopClosureDetector.query_and_insert (batches of 32 frames)"]["stream_poisoned"] == 0
     for p in d["paths"]:
         pr, pc = p["roofline"], p["cpu_baseline"]
         assert p["frames"] == (10 if "train_step" in p["path"] else 24) and p["value"] > 0 and p["ms"] > 0 and p["reference"]
