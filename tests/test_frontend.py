@@ -112,6 +112,24 @@ def test_drivers_and_database_file(tmp_path):
 
 
 @pytest.mark.gpu
+def test_rgb_to_gray_odd_sizes_and_unaligned_views():
+    """The grey kernel handles four pixels per thread from whole dwords: pixel counts that are not multiples of four
+    (the tail) and buffers that do not start on a dword (the byte path) give the same bytes as the oracle."""
+    import deeploopcloser_amd as dlc
+    eng = dlc.default_engine()
+    rng = np.random.RandomState(12)
+    for h, w in [(1, 1), (3, 5), (7, 9), (64, 66), (33, 127)]:
+        rgb = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        want = opatch.bgr2gray_opencv(rgb)
+        assert np.array_equal(eng.rgb_to_gray(torch.from_numpy(rgb).cuda()).cpu().numpy(), want), (h, w)
+        flat = torch.zeros((h * w * 3 + 3,), dtype=torch.uint8, device=eng.device)
+        flat[3:] = torch.from_numpy(rgb).cuda().reshape(-1)                   # a view one pixel (3 bytes) into the buffer
+        view = flat[3:].view(h, w, 3)
+        assert view.data_ptr() % 4 != 0 and view.is_contiguous()
+        assert np.array_equal(eng.rgb_to_gray(view).cpu().numpy(), want), (h, w)
+
+
+@pytest.mark.gpu
 def test_harris_keypoints_bit_exact_vs_oracle():
     """The build's detector (stand-in for SURF) is integer arithmetic: points, responses and counts
     equal the oracle's exactly -- reference frames, noise, a symmetric pattern full of ties, flat."""
@@ -129,8 +147,13 @@ def test_harris_keypoints_bit_exact_vs_oracle():
     sq = np.zeros((192, 240), dtype=np.uint8)
     sq[50:90, 60:140] = 180                                                   # 4 corners only: count < n
     frames.append(sq)
+    dots = np.zeros((192, 240), dtype=np.uint8)
+    for a in range(6):
+        for b in range(8):                                                    # one blob per 32 x 32 tile of the kernel: the
+            dots[14 + 32 * a:18 + 32 * a, 14 + 32 * b:18 + 32 * b] = 40 + 4 * (a * 8 + b)   # lists' first slots hold everything
+    frames.append(dots)
     g = torch.from_numpy(np.stack(frames)).to(eng.device)
-    for n in (30, 7):
+    for n in (30, 7, 200):
         pts, resp, cnt = eng.harris_keypoints(g, n)
         for f, img in enumerate(frames):
             ep, er, ec = okp.key_points(img, n)
@@ -148,7 +171,7 @@ def test_frontend_fuzz_odd_image_sizes():
     from oracle import keypoints as okp
     eng = dlc.default_engine()
     rng = np.random.RandomState(31)
-    for h, w, n in [(7, 7, 3), (8, 300, 5), (41, 41, 30), (100, 57, 30), (193, 241, 64)]:
+    for h, w, n in [(7, 7, 3), (8, 300, 5), (41, 41, 30), (100, 57, 30), (193, 241, 64), (96, 160, 300), (80, 72, 700)]:
         imgs = rng.randint(0, 256, (3, h, w)).astype(np.uint8)
         pts, resp, cnt = eng.harris_keypoints(torch.from_numpy(imgs).to(eng.device), n)
         for f in range(3):
