@@ -379,7 +379,7 @@ def bench_paths(eng, n_frames):
                 "dtype": "bf16", "k": kl, "value": N / (lc_ms * 1e-3), "unit": "frames/s", "ms": lc_ms,
                 "roofline": {"bound": "hbm", "achieved": lc_bytes / (lc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": lc_bytes / (lc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "l2_normalize into the store + top-(k+B-1) match per batch (%d launches of a few microseconds of work: launch-bound at this database size)" % (-(-N // bl)),
+                             "kernel": "per batch: l2_normalize into the store + one age-limited top-k match (dlc_cosine_topk_older: split-K score pass, group maxima, selection + fp64 re-score, early-exit launch) -- %d batches of five launches of 4-18 us each: latency-bound at this database size" % (-(-N // bl)),
                              "kernel_ms": lc_ms, "call_ms": lc_ms, "algorithmic_bytes_per_call": lc_bytes},
                 "cpu_baseline": {"value": nl / t_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/loop_closure.py per-frame fp64 loop over the first %d stored rows: %.2f s" % (nl, t_cpu)},

@@ -16,7 +16,7 @@ DLC_BF16, DLC_F16, DLC_F32, DLC_F64, DLC_I8 = 0, 1, 2, 3, 4
 DLC_ACT_NONE, DLC_ACT_SIGMOID, DLC_ACT_RELU = 0, 1, 2
 DLC_B_KN, DLC_B_NK = 0, 1
 DLC_MAX_K = 128
-DLC_ABI_VERSION = 6          # include/dlc.h; load() refuses a library built from another header
+DLC_ABI_VERSION = 7          # include/dlc.h; load() refuses a library built from another header
 DLC_SELECT_COOP = 1
 DLC_SIM_FORCE_F64, DLC_SIM_NO_HOST_SYNC = 1, 2
 
@@ -74,6 +74,8 @@ SIGNATURES = {
     "dlc_cosine_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
     "dlc_cosine_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz,
                               _vp]),
+    "dlc_cosine_topk_older": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
+                                    _sz, _vp]),
     "dlc_cosine_score_error_bound": (_dbl, [_i64, _i64, _i64, _int]),
     "dlc_cosine_score_groups": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _vp, _sz, _vp]),
     "dlc_cosine_select_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp,

@@ -702,7 +702,15 @@ struct FinishArgs {
     const float* dense_S;         // small-database plan: the fp32 score matrix [q, ld_s] is in the workspace, so the
     long long ld_s;               // candidates are ROWS: the k + rslack best fp32 scores of the selected groups
     int rslack;
+    int limited;                  // 1: query qi may only see rows < limit0 + qi (the streaming detector's batches); the group and
+    long long limit0;             // half-tile maxima of the score pass stay upper bounds of what it may see
 };
+// rows / groups / half tiles query qi may see
+__device__ __forceinline__ long long visible_rows(long long n, int limited, long long limit0, int qi) {
+    if (!limited) return n;
+    const long long lim = limit0 + qi;
+    return lim < 0 ? 0 : (lim < n ? lim : n);
+}
 
 // (the body of the two finish_topk_kernel forms below)
 template <typename Tag, int THREADS, int RS_UNROLL, int MODE>
@@ -712,7 +720,26 @@ __device__ __forceinline__ void finish_topk_body(const FinishArgs& a) {
     constexpr int FIN_THREADS = THREADS;      // shadows the namespace constant inside this kernel
     constexpr int GPH = GROUPS_PER_HALF;
     const int kg = a.kg, k = a.k;
-    const long long n = a.n;
+    const long long n = visible_rows(a.n, a.limited, a.limit0, (int)blockIdx.x);
+    const long long ng = a.limited ? (n + GROUP - 1) / GROUP : a.ng;
+    if (n <= 0) {                                               // (only with a limit) nothing this query may see: an empty list
+        if constexpr (MODE == FIN_GROUPS) {
+            for (int e = threadIdx.x; e <= kg; e += THREADS) {
+                if (e < kg) a.grp_ids[(long long)blockIdx.x * kg + e] = -1;
+                a.grp_max[(long long)blockIdx.x * (kg + 1) + e] = -INFINITY;
+            }
+        } else {
+            const long long oq = (long long)blockIdx.y * a.nq + blockIdx.x;
+            for (int e = threadIdx.x; e < k; e += THREADS) {
+                if (a.out_s) a.out_s[oq * k + e] = -INFINITY;
+                a.out_s64[oq * k + e] = -INFINITY;
+                a.out_i[oq * k + e] = -1;
+            }
+            if (MODE == FIN_FUSED && threadIdx.x == 0) a.status[blockIdx.x] = 0;
+            if (MODE == FIN_RESCORE && a.bound_out && blockIdx.y == 0 && threadIdx.x == 0) a.bound_out[blockIdx.x] = -INFINITY;
+        }
+        return;
+    }
     unsigned long long* ckey = (unsigned long long*)dsm;                       // [kg * GPH] packed fp32 keys
     long long* ck64 = (long long*)(dsm + (size_t)kg * GPH * 8);                // [kg * GROUP] fp64 ordering keys
     double* cs64 = (double*)(dsm + (size_t)kg * (GPH * 8 + GROUP * 8));        // [kg * GROUP] fp64 scores
@@ -736,7 +763,7 @@ __device__ __forceinline__ void finish_topk_body(const FinishArgs& a) {
     // Each wave extracts the kt best of its slice by repeated wave arg-max (DPP, no barrier);
     // the FIN_WAVES * kt survivors are ranked together.  What a wave has left after its kt extractions
     // (misc[w]) and the survivor of rank kt bound every half tile that is not selected.
-    const int nh = a.nh;
+    const int nh = a.limited ? (int)((n + HALF - 1) / HALF) : a.nh;
     const int kt = min(kg, nh);
     {
         const int chunk = (nh + FIN_WAVES - 1) / FIN_WAVES;
@@ -813,7 +840,16 @@ __device__ __forceinline__ void finish_topk_body(const FinishArgs& a) {
     for (int e = tid; e < m2; e += FIN_THREADS) {
         const int ht = sel[e / GPH];
         const long long g = (long long)ht * GPH + (e % GPH);
-        ckey[e] = (ht >= 0 && g < a.ng) ? pack_key(a.gmax[(long long)qi * a.ldg + g], (unsigned)g) : 0ull;
+        float gm = (ht >= 0 && g < ng) ? a.gmax[(long long)qi * a.ldg + g] : 0.0f;
+        if (a.limited && a.dense_S && ht >= 0 && g == ng - 1 && (n & (GROUP - 1))) {
+            // the one group a limit cuts through: its maximum over the rows the query may see, from the score matrix of the
+            // small-database plan (the score pass's maximum counts up to 7 rows it may not see; as the k-th largest group
+            // maximum such a number prunes groups that hold top-k rows -- safe, the certificate then fails, but that was
+            // an exhaustive pass for one or two queries of every batch of 32)
+            gm = -INFINITY;
+            for (long long row = g * GROUP; row < n; ++row) gm = fmaxf(gm, a.dense_S[(long long)qi * a.ld_s + row]);
+        }
+        ckey[e] = (ht >= 0 && g < ng) ? pack_key(gm, (unsigned)g) : 0ull;
     }
     __syncthreads();
     kg2 = min(kg, m2);
@@ -838,7 +874,9 @@ __device__ __forceinline__ void finish_topk_body(const FinishArgs& a) {
     if (tid < kg2) {
         const int c = sel2[tid];
         int g = c < 0 ? -1 : (int)key_id(ckey[c]);
-        if (tid >= k && g >= 0 && sel2[k - 1] >= 0) {
+        // (with a limit and no score matrix the group the limit cuts through has an inflated maximum, u' may be that
+        // number, and "k groups hold a row the query may see with a score >= u'" no longer holds: nothing is pruned then)
+        if (tid >= k && g >= 0 && sel2[k - 1] >= 0 && !(a.limited && !a.dense_S)) {
             const double uk = (double)key_f32((unsigned)(ckey[sel2[k - 1]] >> 32));
             if ((double)key_f32((unsigned)(ckey[c] >> 32)) < uk - 2.0 * a.tau) g = -2;          // pruned (after the reads below)
         }
@@ -1010,6 +1048,7 @@ struct ExhaustiveArgs {
     float* out_s; double* out_s64; long long* out_i;     // [q, k]; out_s / out_s64 may be null
     int* status;
     double tau;
+    int limited; long long limit0;                           // as in FinishArgs
 };
 constexpr int EXH_BATCH = 64;                               // groups per re-score batch
 constexpr int EXH_POOL = EXH_BATCH * GROUP + DLC_MAX_K;     // running top-k in front of the batch's rows
@@ -1025,12 +1064,14 @@ __global__ __launch_bounds__(FIN_THREADS) void exhaustive_topk_kernel(Exhaustive
     __shared__ int wcnt[FIN_THREADS / 64];
     __shared__ int sel[DLC_MAX_K];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = a.k;
+    const long long n_vis = visible_rows(a.n, a.limited, a.limit0, qi);
+    const long long ng_vis = a.limited ? (n_vis + GROUP - 1) / GROUP : a.ng;
     double theta = a.lower[(long long)qi * a.lower_stride] - a.tau;      // -inf - tau = -inf: everything qualifies
     int cnt = 0;                                                         // rows in the running top-k (pool[0 .. cnt))
     const char* qrow = a.Q + (long long)qi * a.ldq_b;
-    for (long long c0 = 0; c0 < a.ng; c0 += FIN_THREADS) {
+    for (long long c0 = 0; c0 < ng_vis; c0 += FIN_THREADS) {
         const long long g = c0 + tid;
-        const bool qual = g < a.ng && (double)a.gmax[(long long)qi * a.ldg + g] >= theta;
+        const bool qual = g < ng_vis && (double)a.gmax[(long long)qi * a.ldg + g] >= theta;
         const unsigned long long bal = __ballot(qual);
         if (lane == 0) wcnt[w] = __popcll(bal);
         __syncthreads();
@@ -1054,7 +1095,7 @@ __global__ __launch_bounds__(FIN_THREADS) void exhaustive_topk_kernel(Exhaustive
 #pragma unroll
                 for (int r = 0; r < GROUP; ++r)
                     if (lane == r) {
-                        const bool ok = row0 + r < a.n;
+                        const bool ok = row0 + r < n_vis;
                         ps[cnt + s * GROUP + r] = ok ? acc[r] : -INFINITY;
                         pk[cnt + s * GROUP + r] = ok ? f64_key(acc[r]) : KEY64_EMPTY;
                         pid[cnt + s * GROUP + r] = (int)(row0 + r);
@@ -1680,6 +1721,7 @@ int run_exhaustive(dlc_ctx* ctx, int dtype, const FinishArgs& f, int64_t q, cons
     e.lower = lower; e.lower_stride = lower_stride;
     e.out_s = out_s; e.out_s64 = out_s64; e.out_i = (long long*)out_i;
     e.status = status; e.tau = f.tau;
+    e.limited = f.limited; e.limit0 = f.limit0;
     if (dtype == DLC_BF16)
         hipLaunchKernelGGL(exhaustive_topk_kernel<dlc_bf16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, e);
     else
@@ -1704,9 +1746,10 @@ int launch_merge(dlc_ctx* ctx, const double* scores, int64_t score_part_stride, 
 // Stage 2 of a match from a filled workspace: selection, fp64 re-score, final top-k, certification, exhaustive pass.
 int run_finish(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
                float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status, void* workspace, int flags,
-               hipStream_t st) {
+               hipStream_t st, int limited = 0, int64_t limit0 = 0) {
     char* ws = (char*)workspace;
     FinishArgs f = finish_args(mc, k, n, d, q, row_offset);
+    f.limited = limited; f.limit0 = limit0;
     int* status = out_status ? out_status : (int*)(ws + mc.w.status);
     double* s64 = out_scores_f64 ? out_scores_f64 : (double*)(ws + mc.w.s64);
     int rc;
@@ -1754,6 +1797,23 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
     if (rc != DLC_OK) return rc;
     return run_finish(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_scores_f64, out_idx, out_status, workspace, 0,
                       (hipStream_t)stream);
+}
+
+extern "C" int dlc_cosine_topk_older(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
+                                     int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, int64_t limit0,
+                                     float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk_older: null output");
+    MatchCall mc;
+    int rc = prepare_match(ctx, "cosine_topk_older", dtype, Q, q, ldq, DB, n, lddb, d, k, workspace, workspace_bytes, &mc);
+    if (rc != DLC_OK) return rc;
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    rc = run_score(ctx, dtype, mc, (hipStream_t)stream);
+    if (rc != DLC_OK) return rc;
+    return run_finish(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_scores_f64, out_idx, out_status, workspace, 0,
+                      (hipStream_t)stream, 1, limit0);
 }
 
 extern "C" int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,

@@ -45,10 +45,13 @@ __global__ __launch_bounds__(256) void extract_patches_kernel(const unsigned cha
     const int x0 = window_lo(cx, H, ps / 2), y0 = window_lo(cy, W, ps / 2);
     const unsigned char* img = gray + frame * (long long)H * W;
     T* o = out + fp * (long long)ps * ps;
-    const int step_x = 256 / ps, step_y = 256 - step_x * ps;           // e += 256 without a division per element
+    __shared__ T by255[256];                                           // the 256 quotients once, not a division per element
+    by255[threadIdx.x] = (T)threadIdx.x / (T)255.0;
+    __syncthreads();
+    const int step_x = 256 / ps, step_y = 256 - step_x * ps;           // e += 256 without an integer division per element
     int dx = threadIdx.x / ps, dy = threadIdx.x - dx * ps;
     for (int e = threadIdx.x; e < ps * ps; e += 256) {
-        o[e] = (T)img[(long long)(x0 + dx) * W + (y0 + dy)] / (T)255.0;
+        o[e] = by255[img[(long long)(x0 + dx) * W + (y0 + dy)]];
         dx += step_x; dy += step_y;
         if (dy >= ps) { dy -= ps; ++dx; }
     }
@@ -202,9 +205,17 @@ __global__ __launch_bounds__(256) void harris_candidates_kernel(const uint8_t* _
     __builtin_amdgcn_s_barrier();
     if (threadIdx.x == 0) lcount[tile_id] = nkeep < HT_CAP ? nkeep : HT_CAP;
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_max_step(long long& v) {
+    const int lo = (int)(unsigned)v, hi = (int)((unsigned long long)v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    const long long ov = (long long)(((unsigned long long)ohi << 32) | olo);
+    v = ov > v ? ov : v;
+}
 // The n strongest candidates of a frame, strongest first (ties: the lower pixel index).  One workgroup per frame, one
 // thread per list slot: thread t looks at entry t of every tile's list and keeps its three best in registers; a round's
-// winner comes from shuffles inside a wave and the four waves' winners through LDS; the winner's owner moves its next
+// winner comes from DPP steps inside a wave and the four waves' winners through LDS; the winner's owner moves its next
 // one up.  Only an owner whose three are used up while it has more entries goes back to memory (its wave fetches them,
 // one tile per lane: those that come after the round's winner in the order, everything before it has been a winner).
 // Nothing is stored to memory inside a round -- the winners wait in LDS and go out 256 at a time: hipcc holds a wave
@@ -273,21 +284,28 @@ __global__ __launch_bounds__(HT_CAP) void harris_select_kernel(const long long* 
     }
     left -= (v1 > 0) + (v2 > 0) + (v3 > 0);
     for (int j = 0; j < n; ++j) {
-        long long v = v1;
-        int i = i1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const long long ov = __shfl_xor(v, o);
-            const int oi = __shfl_xor(i, o);
-            if (better(ov, oi, v, i)) { v = ov; i = oi; }
+        // the wave's largest response by DPP steps (no LDS round trip per step as with ds_bpermute): a scan inside the
+        // rows of 16 lanes, then rows 0 -> 1, 2 -> 3 and lanes 0..31 -> 32..63; lane 63 holds the maximum.  Lanes
+        // without a source take 0, which no response is below.
+        long long m = v1;
+        dpp_max_step<0x111, 0xf>(m); dpp_max_step<0x112, 0xf>(m); dpp_max_step<0x114, 0xf>(m); dpp_max_step<0x118, 0xf>(m);
+        dpp_max_step<0x142, 0xa>(m); dpp_max_step<0x143, 0xc>(m);
+        const unsigned mlo = __builtin_amdgcn_readlane((unsigned)m, 63);
+        const unsigned mhi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)m >> 32), 63);
+        const long long wave_v = (long long)(((unsigned long long)mhi << 32) | mlo);
+        int wave_i = 0x7fffffff;                               // the lowest pixel among the lanes that hold it (scalar)
+        for (unsigned long long tied = __ballot(v1 == wave_v && wave_v > 0); tied; tied &= tied - 1) {
+            const int x = __builtin_amdgcn_readlane(i1, __ffsll((long long)tied) - 1);
+            wave_i = x < wave_i ? x : wave_i;
         }
-        if (lane == 0) { sv[j & 1][w] = v; si[j & 1][w] = i; }
+        if (lane == 0) { sv[j & 1][w] = wave_v; si[j & 1][w] = wave_i; }
         __syncthreads();
-        v = sv[j & 1][lane & 3]; i = si[j & 1][lane & 3];
+        long long v = sv[j & 1][0];
+        int i = si[j & 1][0];
 #pragma unroll
-        for (int o = 2; o > 0; o >>= 1) {
-            const long long ov = __shfl_xor(v, o);
-            const int oi = __shfl_xor(i, o);
+        for (int o = 1; o < 4; ++o) {
+            const long long ov = sv[j & 1][o];
+            const int oi = si[j & 1][o];
             if (better(ov, oi, v, i)) { v = ov; i = oi; }
         }
         const long long wv = v;

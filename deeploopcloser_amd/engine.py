@@ -673,11 +673,12 @@ class Engine:
         if q.stride(1) != 1 or db.stride(1) != 1:
             raise ValueError("stored descriptor rows must be contiguous")
 
-    def match_topk(self, q, db, k, row_offset=0, out=None, details=False):
+    def match_topk(self, q, db, k, row_offset=0, out=None, details=False, older_than=None):
         """Top-k cosine match of stored queries q [Q,d] against stored db [N,d].
         Returns (scores [Q,k] float32, idx [Q,k] int64 with row_offset added); with details=True a
         TopK(scores, idx, scores_f64, status): the fp64 scores the order was decided on and, per query,
-        0 = certified by the selection, 2 = resolved by the exhaustive pass (include/dlc.h)."""
+        0 = certified by the selection, 2 = resolved by the exhaustive pass (include/dlc.h).
+        older_than = L: query i only sees db rows below L + i (dlc_cosine_topk_older; (-inf, -1) where it sees fewer than k)."""
         self._check_stored(q, db)
         nq, d = q.shape
         n = db.shape[0]
@@ -693,9 +694,15 @@ class Engine:
             idx = self._check_out("out[1] (idx)", out[1], (nq, k), torch.int64)
         s64 = torch.empty((nq, k), dtype=torch.float64, device=self.device) if details else None
         status = torch.empty((nq,), dtype=torch.int32, device=self.device) if details else None
-        self._check(self.lib.dlc_cosine_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
-                                              db.stride(0), d, k, row_offset, _ptr(scores), _ptr(s64), _ptr(idx),
-                                              _ptr(status), _ptr(ws), ws.numel(), self._stream()))
+        if older_than is None:
+            self._check(self.lib.dlc_cosine_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
+                                                  db.stride(0), d, k, row_offset, _ptr(scores), _ptr(s64), _ptr(idx),
+                                                  _ptr(status), _ptr(ws), ws.numel(), self._stream()))
+        else:
+            self._check(self.lib.dlc_cosine_topk_older(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
+                                                        db.stride(0), d, k, row_offset, int(older_than), _ptr(scores),
+                                                        _ptr(s64), _ptr(idx), _ptr(status), _ptr(ws), ws.numel(),
+                                                        self._stream()))
         return TopK(scores, idx, s64, status) if details else (scores, idx)
 
     def topk_workspace_bytes(self, nq, n, d, k):

@@ -56,8 +56,8 @@ class LoopClosureDetector:
 
     @property
     def max_batch(self):
-        """Largest number of frames one engine call can take (k + B - 1 <= DLC_MAX_K)."""
-        return L.DLC_MAX_K - self.k + 1
+        """Largest number of frames one engine call takes (one 256-query tile of the score pass)."""
+        return 256
 
     def query_and_insert(self, descriptors):
         """The next B frames' descriptors [B, dim] (ids len(self) .. len(self)+B-1) ->
@@ -75,6 +75,8 @@ class LoopClosureDetector:
             dev = self.db.engine.device
             return (torch.empty((0, self.k), dtype=torch.float32, device=dev),
                     torch.empty((0, self.k), dtype=torch.int64, device=dev))
+        if len(out_s) == 1:                                  # (torch.cat of one tensor is a copy: two launches per batch)
+            return out_s[0], out_i[0]
         return torch.cat(out_s), torch.cat(out_i)
 
     def _step(self, x):
@@ -88,8 +90,9 @@ class LoopClosureDetector:
         if n_search <= 0:
             return (torch.full((b, k), float("-inf"), dtype=torch.float32, device=dev),
                     torch.full((b, k), -1, dtype=torch.int64, device=dev))
-        s, i = db.engine.match_topk(q, db.rows[:n_search], min(k + b - 1, L.DLC_MAX_K))
-        return db.engine.topk_keep_older(s, i, g0 - self.exclusion, k)      # one kernel; first_k_eligible is its torch form
+        # one score pass over what the newest frame may see; frame j of the batch keeps to the rows below g0 - exclusion + j
+        # (dlc_cosine_topk_older -- the lists of a k + b - 1 match followed by dlc_topk_keep_older / first_k_eligible)
+        return db.engine.match_topk(q, db.rows[:n_search], k, older_than=g0 - self.exclusion)
 
     def loops(self, scores, ids, first_id):
         """[(frame id, matched key-frame id, score)] of the candidates at or above the threshold."""

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DLC_ABI_VERSION 6
+#define DLC_ABI_VERSION 7
 
 typedef struct dlc_ctx dlc_ctx;
 
@@ -444,6 +444,18 @@ int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t l
                     const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
                     float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
                     void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * The same match with an age limit per query (the streaming loop-closure query, SURVEY 8f-4, for a batch of frames that
+ * were appended to the database together): query i only sees rows 0 .. min(n, limit0 + i) - 1 (local rows, before
+ * row_offset); a query that sees nothing gets (-inf, -1) and status 0.  One score pass over the n rows serves the whole
+ * batch -- its group maxima remain upper bounds of what a query may see, which is all the selection and the certificate
+ * need; rows a query may not see are never re-scored.  Same workspace, plans, ordering rule and status values as
+ * dlc_cosine_topk; the lists equal dlc_cosine_topk with k + q - 1 candidates followed by dlc_topk_keep_older.
+ */
+int dlc_cosine_topk_older(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
+                          const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, int64_t limit0,
+                          float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /*
  * tau of the plan dlc_cosine_topk takes for this shape: |fp32 score of the score pass - fp64 score|
  * <= tau for rows of norm <= 1.005.  (s MFMA / v_dot2 accumulation steps of at most 2^-23 *

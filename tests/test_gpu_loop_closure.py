@@ -129,6 +129,39 @@ def test_keep_older_kernel_equals_torch_form(dlc):
         assert torch.equal(gi, wi) and torch.equal(gs, ws), (b, kk, k, limit0)
 
 
+def test_match_with_age_limit_equals_wide_match_then_keep_older(dlc):
+    """dlc_cosine_topk_older (query i sees rows below limit0 + i) == dlc_cosine_topk with k + q - 1 candidates followed by
+    dlc_topk_keep_older, index for index and score bit for score bit, on every plan of the match: the small-database plan,
+    the one-pass plan, few queries with long rows (re-score spread over workgroups + merge); limits that leave some queries
+    nothing, limits past the database, limits inside a group of 8 rows; databases full of exact copies (ties)."""
+    eng = dlc.default_engine()
+    g = torch.Generator(device=eng.device); g.manual_seed(11)
+    cases = [(32, 700, 192, 5, 650, 0), (32, 700, 192, 5, -10, 0), (7, 100, 64, 3, 97, 0), (5, 300, 33024, 4, 283, 0),
+             (64, 70000, 128, 8, 69950, 0), (32, 500, 64, 6, 470, 50), (40, 333, 256, 20, 1000, 0), (3, 9, 64, 2, 1, 3),
+             (16, 700, 192, 5, -40, 0), (32, 70000, 128, 5, 300, 0)]
+    for (q, n, d, k, limit0, distinct) in cases:
+        x = torch.randn((n, d), generator=g, device=eng.device, dtype=torch.float32)
+        if distinct:
+            x = x[torch.randint(0, distinct, (n,), generator=g, device=eng.device)]
+        db = eng.normalize(x, torch.bfloat16, False)
+        qs = eng.normalize(x[torch.randint(0, n, (q,), generator=g, device=eng.device)] +
+                           0.2 * torch.randn((q, d), generator=g, device=eng.device, dtype=torch.float32), torch.bfloat16, False)
+        # the two-step form: the rows the NEWEST query may see, k + q - 1 candidates (at most q - 1 of them too recent for a
+        # query), then every query's first k that are old enough
+        n_newest = max(0, min(n, limit0 + q - 1))
+        if n_newest > 0:
+            ws, wi = eng.match_topk(qs, db[:n_newest], min(k + q - 1, 128))
+            ws, wi = eng.topk_keep_older(ws, wi, limit0, k)
+        else:
+            ws = torch.full((q, k), float("-inf"), dtype=torch.float32, device=eng.device)
+            wi = torch.full((q, k), -1, dtype=torch.int64, device=eng.device)
+        got = eng.match_topk(qs, db, k, older_than=limit0, details=True)
+        assert torch.equal(got.idx, wi), (q, n, d, k, limit0)
+        assert torch.equal(got.scores, ws), (q, n, d, k, limit0)
+        assert int(got.status.max()) in (0, 2)
+        with_off = eng.match_topk(qs, db, k, row_offset=1000, older_than=limit0)
+        assert torch.equal(with_off[1], torch.where(wi >= 0, wi + 1000, wi)), (q, n, d, k, limit0)
+
 
 # ---------------------------------------------------------------------------------- reference-semantics streaming query
 def test_similarity_stream_rows_equal_matrix_columns():
