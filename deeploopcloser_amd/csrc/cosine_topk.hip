@@ -664,6 +664,38 @@ __device__ __forceinline__ void rescore8_f64(const char* qrow, const char* const
     }
 }
 
+// One row of rescore8_f64: the same pieces per lane in the same order, the same butterfly -- the same value.
+template <typename Tag>
+__device__ __forceinline__ double rescore1_f64(const char* qrow, const char* row, int d, int lane) {
+    constexpr int U = 4;
+    double acc = 0.0;
+    for (int d0 = lane * 8; d0 < d; d0 += 512 * U) {
+        uint4 qv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int dd = d0 + u * 512;
+            const bool ok = dd < d;
+            qv[u] = ok ? *(const uint4*)(qrow + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
+            rv[u] = ok ? *(const uint4*)(row + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned qw[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
+            const unsigned w4[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = fma((double)Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu)),
+                          (double)Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc);
+                acc = fma((double)Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16)),
+                          (double)Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    return acc;
+}
+
 // One workgroup per query: half-tile selection -> group selection -> fp64 re-score of the candidates' rows ->
 // final top-k -> certification.
 // THREADS / RS_UNROLL pick the footprint: (512, 4) is the fastest stand-alone form; (256, 1) stays under 96 VGPRs
@@ -967,8 +999,21 @@ __device__ __forceinline__ void finish_topk_body(const FinishArgs& a) {
     }
     __syncthreads();
 
-    // ---- fp64 re-score: wave w takes candidates 8w .. 8w + 7, then 8 (w + FIN_WAVES) ...
+    // ---- fp64 re-score: wave w takes candidates 8w .. 8w + 7, then 8 (w + FIN_WAVES) ... (a group's 8 rows are
+    // neighbours in memory).  The small-database plan's candidates are k + rslack single ROWS: they are dealt round the
+    // waves instead, one row at a time (wave w: candidates w, w + FIN_WAVES, ...) -- nine rows of 8 KB were one wave's
+    // 8 rows and a second wave's one.  Same value either way (rescore1_f64).
     const char* qrow = a.Q + (long long)qi * a.ldq_b;
+    if (MODE == FIN_FUSED && a.dense_S != nullptr) {                   // (only the fused form runs the small-database plan)
+        for (int ci = w; ci < m3; ci += FIN_WAVES) {
+            const int id = __builtin_amdgcn_readfirstlane(crow[ci]);
+            const double sc = id < 0 ? 0.0 : rescore1_f64<Tag>(qrow, a.DB + (long long)id * a.lddb_b, a.d, lane);
+            if (lane == 0) {
+                cs64[ci] = id < 0 ? -INFINITY : sc;
+                ck64[ci] = id < 0 ? KEY64_EMPTY : f64_key(sc);
+            }
+        }
+    } else
     for (int s = w; s * GROUP < m3; s += FIN_WAVES) {
         int ids[GROUP];
         bool any = false;
@@ -2023,11 +2068,14 @@ extern "C" int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* sr
     if (dst_dtype != DLC_BF16 && dst_dtype != DLC_F16)
         return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "l2_normalize_rows: dtype pair %d -> %d", src_dtype, dst_dtype);
     unsigned short* o = (unsigned short*)dst;
-    // one-pass register form: rows of <= 64 (a wave per row) or <= 256 threads x 16 vectors of 16 bytes
+    // one-pass register form: rows of <= 64 threads x 4 (a wave per row) or <= 256 threads x 16 vectors of 16 bytes
     // whose vectors can be loaded / stored aligned; anything else takes the multi-pass kernel
     const int vw = src_dtype == DLC_F32 ? 4 : 2;
     const bool aligned = ((uintptr_t)src & 15) == 0 && (lds % vw) == 0 && ((uintptr_t)dst & 7) == 0;
-    const int64_t cap_wave = 64 * 16 * vw, cap_block = 256 * 16 * vw;
+    // (a wave per row up to 4 vectors per lane: with 16 -- rows of 4096 floats -- a lane's 64 fp64 accumulations and 64 fp64
+    // scalings made a batch of 32 rows an 8 us launch; the choice depends on the row length alone, so that a row's stored
+    // bits do not depend on how many rows are normalised with it)
+    const int64_t cap_wave = 64 * 4 * vw, cap_block = 256 * 16 * vw;
 #define DLC_NORM_REGS(SRC, TAG, TPR)                                                                              \
     hipLaunchKernelGGL((l2_normalize_regs_kernel<SRC, TAG, TPR, 16>), dim3((unsigned)(TPR == 64 ? dlc::cdiv(n, 4) : n)), \
                        dim3(256), 0, st, (const SRC*)src, (long long)lds, (long long)n, (int)d, center, o, (long long)ldd)
