@@ -664,36 +664,57 @@ __device__ __forceinline__ void rescore8_f64(const char* qrow, const char* const
     }
 }
 
-// One row of rescore8_f64: the same pieces per lane in the same order, the same butterfly -- the same value.
-template <typename Tag>
-__device__ __forceinline__ double rescore1_f64(const char* qrow, const char* row, int d, int lane) {
-    constexpr int U = 4;
-    double acc = 0.0;
+// R rows of rescore8_f64 (R = 1, 2), U pieces of every row and of the query in flight per lane: the same pieces per lane
+// in the same order, the same butterfly -- the same values.
+template <typename Tag, int R, int U>
+__device__ __forceinline__ void rescore_rows_f64(const char* qrow, const char* const (&rows)[R], int d, int lane,
+                                                 double (&acc)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
     for (int d0 = lane * 8; d0 < d; d0 += 512 * U) {
-        uint4 qv[U], rv[U];
+        uint4 qv[U], rv[U][R];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int dd = d0 + u * 512;
             const bool ok = dd < d;
             qv[u] = ok ? *(const uint4*)(qrow + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
-            rv[u] = ok ? *(const uint4*)(row + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) rv[u][r] = ok ? *(const uint4*)(rows[r] + (long long)dd * 2) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned qw[4] = {qv[u].x, qv[u].y, qv[u].z, qv[u].w};
-            const unsigned w4[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+            double qd[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc = fma((double)Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu)),
-                          (double)Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc);
-                acc = fma((double)Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16)),
-                          (double)Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc);
+                qd[2 * e] = (double)Mfma16<Tag>::to_f32((unsigned short)(qw[e] & 0xffffu));
+                qd[2 * e + 1] = (double)Mfma16<Tag>::to_f32((unsigned short)(qw[e] >> 16));
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned w4[4] = {rv[u][r].x, rv[u][r].y, rv[u][r].z, rv[u][r].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[r] = fma(qd[2 * e], (double)Mfma16<Tag>::to_f32((unsigned short)(w4[e] & 0xffffu)), acc[r]);
+                    acc[r] = fma(qd[2 * e + 1], (double)Mfma16<Tag>::to_f32((unsigned short)(w4[e] >> 16)), acc[r]);
+                }
             }
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    return acc;
+    for (int r = 0; r < R; ++r) {
+        double v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        acc[r] = v;
+    }
+}
+template <typename Tag>
+__device__ __forceinline__ double rescore1_f64(const char* qrow, const char* row, int d, int lane) {
+    const char* const rows[1] = {row};
+    double acc[1];
+    rescore_rows_f64<Tag, 1, 4>(qrow, rows, d, lane, acc);
+    return acc[0];
 }
 
 // One workgroup per query: half-tile selection -> group selection -> fp64 re-score of the candidates' rows ->
@@ -1077,6 +1098,172 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(FinishArgs a) {
 template <typename Tag, int RS_UNROLL, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void finish_topk_coop_kernel(FinishArgs a) {
     finish_topk_body<Tag, 256, RS_UNROLL, MODE>(a);
+}
+
+// The small-database plan in ONE launch per match (databases of <= 16384 rows, k + rslack < SMALL_KT_MAX): a workgroup
+// per query sums the split-K partial scores of its row itself (thread t: the groups t, t + 512, ... of 8 rows; fp64 sum
+// of the chunks rounded once, exactly splitk_groups_kernel's arithmetic, so the same tau holds), keeps the 32 scores in
+// registers, extracts the k + rslack + 1 best ROWS (each wave the best of its slice by repeated DPP arg-max, the
+// 8 x (k + rslack + 1) survivors ranked together), re-scores k + rslack of them in fp64 (dealt round the waves) and
+// certifies against the one left behind.  The group maxima are written for the exhaustive pass only.  With the
+// hierarchical kernel this plan was three launches (partials, splitk_groups_kernel, finish_topk_kernel: half-tile
+// selection, group selection, row selection) -- 34 us of a 32-frame batch's 45 in the streaming detector.
+struct SmallArgs {
+    const float* P; long long ldp; long long qstride; int nsplit;
+    float* gmax; long long ldg;
+    const char* Q; long long ldq_b; const char* DB; long long lddb_b;
+    long long n; int d; int k; int m3max; long long row_offset;
+    float* out_s; double* out_s64; long long* out_i; int* status; double tau;
+    int limited; long long limit0;
+};
+constexpr int SMALL_KT_MAX = 40;
+constexpr int SMALL_GPT = 4;                                  // groups per thread: 512 x 4 x 8 = 16384 rows
+
+template <typename Tag>
+__global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
+    __shared__ unsigned long long ckey[(FIN_THREADS / 64) * SMALL_KT_MAX];
+    __shared__ long long ck64[SMALL_KT_MAX];
+    __shared__ double cs64[SMALL_KT_MAX];
+    __shared__ int crow[SMALL_KT_MAX];
+    __shared__ int sel[SMALL_KT_MAX + 1];
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = a.k;
+    const long long n = visible_rows(a.n, a.limited, a.limit0, qi);
+    for (int e = tid; e < k; e += FIN_THREADS) {             // defaults for slots past the candidates
+        if (a.out_s) a.out_s[(long long)qi * k + e] = -INFINITY;
+        a.out_s64[(long long)qi * k + e] = -INFINITY;
+        a.out_i[(long long)qi * k + e] = -1;
+    }
+    for (int e = tid; e <= SMALL_KT_MAX; e += FIN_THREADS) sel[e] = -1;
+    if (n <= 0) {                                              // (only with a limit) nothing this query may see
+        if (tid == 0) a.status[qi] = 0;
+        return;
+    }
+    // ---- scores of this thread's groups: fp64 sum of the chunk partials, rounded once; keys of the rows it may see
+    const long long ng_all = (a.n + GROUP - 1) / GROUP;
+    unsigned vk[SMALL_GPT][GROUP];
+#pragma unroll
+    for (int j = 0; j < SMALL_GPT; ++j) {
+        const long long g = tid + (long long)FIN_THREADS * j;
+#pragma unroll
+        for (int r = 0; r < GROUP; ++r) vk[j][r] = 0u;
+        if (g < ng_all) {
+            f64x4_t a64 = {0., 0., 0., 0.}, b64 = {0., 0., 0., 0.};
+            const float* src = a.P + (long long)qi * a.ldp + g * GROUP;
+            for (int c0 = 0; c0 < a.nsplit; c0 += 16) {      // sixteen chunks' loads in flight, summed in chunk order
+                f32x4_t pa[16], pb[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float* sp = src + (long long)(c0 + u < a.nsplit ? c0 + u : c0) * a.qstride;
+                    pa[u] = *(const f32x4_t*)(sp);
+                    pb[u] = *(const f32x4_t*)(sp + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (c0 + u < a.nsplit) {
+                        a64 += __builtin_convertvector(pa[u], f64x4_t);
+                        b64 += __builtin_convertvector(pb[u], f64x4_t);
+                    }
+            }
+            const f32x4_t lo = __builtin_convertvector(a64, f32x4_t), hi = __builtin_convertvector(b64, f32x4_t);
+            a.gmax[(long long)qi * a.ldg + g] =
+                fmaxf(fmaxf(fmaxf(lo[0], lo[1]), fmaxf(lo[2], lo[3])), fmaxf(fmaxf(hi[0], hi[1]), fmaxf(hi[2], hi[3])));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                vk[j][r] = g * GROUP + r < n ? f32_key(lo[r]) : 0u;
+                vk[j][r + 4] = g * GROUP + r + 4 < n ? f32_key(hi[r]) : 0u;
+            }
+        }
+    }
+    // ---- the kt = k + rslack + 1 best rows: every wave hands in the kt best of its lanes' rows
+    const int m3 = (int)(n < (long long)a.m3max ? n : (long long)a.m3max);
+    const int kt = (int)(n < (long long)(m3 + 1) ? n : (long long)(m3 + 1));
+    unsigned bh = 0u, bl = 0u;                                 // this lane's best key (score, ~row); 0, 0 = none
+    unsigned gh[SMALL_GPT], gl[SMALL_GPT];                     // ... and the best of each of its groups
+    auto rescan_group = [&](int j) {                           // (j is a constant after unrolling)
+        gh[j] = 0u; gl[j] = 0u;
+#pragma unroll
+        for (int r = 0; r < GROUP; ++r)                        // rows ascending: the first maximum is the lowest row
+            if (vk[j][r] > gh[j]) { gh[j] = vk[j][r]; gl[j] = ~(unsigned)((tid + FIN_THREADS * j) * GROUP + r); }
+    };
+    auto combine = [&]() {
+        bh = 0u; bl = 0u;
+#pragma unroll
+        for (int j = 0; j < SMALL_GPT; ++j)
+            if (gh[j] > bh) { bh = gh[j]; bl = gl[j]; }
+    };
+#pragma unroll
+    for (int j = 0; j < SMALL_GPT; ++j) rescan_group(j);
+    combine();
+    for (int it = 0; it < kt; ++it) {
+        const unsigned mh = wave_max_u32(bh);
+        const unsigned ml = wave_max_u32(bh == mh ? bl : 0u);
+        if (lane == 0) ckey[w * kt + it] = mh == 0u ? 0ull : (((unsigned long long)mh << 32) | ml);
+        if (mh != 0u && bh == mh && bl == ml) {                // the owner retires it and finds its next best
+            const unsigned row = ~ml;
+#pragma unroll
+            for (int j = 0; j < SMALL_GPT; ++j)
+                if ((row >> 3) == (unsigned)(tid + FIN_THREADS * j)) {
+#pragma unroll
+                    for (int r = 0; r < GROUP; ++r)
+                        if ((row & 7u) == (unsigned)r) vk[j][r] = 0u;
+                    rescan_group(j);
+                }
+            combine();
+        }
+    }
+    __syncthreads();
+    rank_select(ckey, (FIN_THREADS / 64) * kt, kt, sel);
+    __syncthreads();
+    // the best row left behind bounds every row that is not re-scored (0 = every row the query may see is a candidate)
+    const unsigned bkey = (kt > m3 && sel[m3] >= 0) ? (unsigned)(ckey[sel[m3]] >> 32) : 0u;
+    if (tid < m3) crow[tid] = sel[tid] < 0 ? -1 : (int)key_id(ckey[sel[tid]]);
+    __syncthreads();
+    // ---- fp64 re-score, final top-k (fp64 key descending, ties -> lower row), certificate
+    // (candidates dealt round the waves, a wave's two at a time with eight pieces of each in flight: these are dependent
+    // round trips to memory, and with k + rslack = 9 one wave has two rows)
+    const char* qrow = a.Q + (long long)qi * a.ldq_b;
+    constexpr int NW = FIN_THREADS / 64;
+    int ci = w;
+    for (; ci + NW < m3; ci += 2 * NW) {
+        const int id0 = __builtin_amdgcn_readfirstlane(crow[ci]), id1 = __builtin_amdgcn_readfirstlane(crow[ci + NW]);
+        const char* const rows[2] = {a.DB + (long long)(id0 < 0 ? 0 : id0) * a.lddb_b,
+                                     a.DB + (long long)(id1 < 0 ? 0 : id1) * a.lddb_b};
+        double sc[2];
+        rescore_rows_f64<Tag, 2, 8>(qrow, rows, a.d, lane, sc);
+        if (lane == 0) {
+            cs64[ci] = id0 < 0 ? -INFINITY : sc[0];
+            ck64[ci] = id0 < 0 ? KEY64_EMPTY : f64_key(sc[0]);
+            cs64[ci + NW] = id1 < 0 ? -INFINITY : sc[1];
+            ck64[ci + NW] = id1 < 0 ? KEY64_EMPTY : f64_key(sc[1]);
+        }
+    }
+    if (ci < m3) {
+        const int id = __builtin_amdgcn_readfirstlane(crow[ci]);
+        const char* const rows[1] = {a.DB + (long long)(id < 0 ? 0 : id) * a.lddb_b};
+        double sc[1];
+        rescore_rows_f64<Tag, 1, 8>(qrow, rows, a.d, lane, sc);
+        if (lane == 0) {
+            cs64[ci] = id < 0 ? -INFINITY : sc[0];
+            ck64[ci] = id < 0 ? KEY64_EMPTY : f64_key(sc[0]);
+        }
+    }
+    for (int e = tid; e <= SMALL_KT_MAX; e += FIN_THREADS) sel[e] = -1;
+    __syncthreads();
+    rank_select64(ck64, crow, m3, k, sel);
+    __syncthreads();
+    for (int e = tid; e < k; e += FIN_THREADS) {
+        const int c = sel[e];
+        if (c >= 0) {
+            if (a.out_s) a.out_s[(long long)qi * k + e] = (float)cs64[c];
+            a.out_s64[(long long)qi * k + e] = cs64[c];
+            a.out_i[(long long)qi * k + e] = (long long)crow[c] + a.row_offset;
+        }
+    }
+    if (tid == 0) {
+        const int c = sel[k - 1];
+        const bool cert = bkey == 0u || (c >= 0 && cs64[c] > (double)key_f32(bkey) + a.tau);
+        a.status[qi] = cert ? 0 : 1;
+    }
 }
 
 // Exhaustive pass of the queries a selection could not certify (status[q] == 1; every other workgroup leaves at once).
@@ -1645,12 +1832,13 @@ int launch_gemv(dlc_ctx* ctx, const GemmArgs& a, hipStream_t st) {
 // keep: the top-k call's small-database plan -- score tile(s) to the workspace even when K is not split,
 // group maxima from the reducing pass, the summed scores kept in chunk 0.
 template <typename Tag>
-int launch_scores(dlc_ctx* ctx, const GemmArgs& a, bool dense, hipStream_t st, bool keep = false) {
+int launch_scores(dlc_ctx* ctx, const GemmArgs& a, bool dense, hipStream_t st, bool keep = false, bool partials_only = false) {
     if (!dense && !keep && use_gemv(a)) return launch_gemv<Tag>(ctx, a, st);
     if (a.nsplit <= 1 && !keep)
         return dense ? launch_gemm<Tag, GEMM_DENSE>(ctx, a, st) : launch_gemm<Tag, GEMM_GROUPS>(ctx, a, st);
     int rc = launch_gemm<Tag, GEMM_PARTIAL>(ctx, a, st);
     if (rc != DLC_OK) return rc;
+    if (partials_only) return DLC_OK;                        // small_topk_kernel sums the chunks itself
     if (dense) {
         dim3 grid((unsigned)a.q, (unsigned)dlc::cdiv(a.n, (int64_t)1024));
         hipLaunchKernelGGL(splitk_dense_kernel, grid, dim3(256), 0, st, a.P, a.ldp, a.q, a.nsplit, a.S, a.lds, a.n);
@@ -1702,11 +1890,16 @@ int prepare_match(dlc_ctx* ctx, const char* what, int dtype, const void* Q, int6
     return DLC_OK;
 }
 
-int run_score(dlc_ctx* ctx, int dtype, MatchCall& mc, hipStream_t st) {
+// The small-database plan as one selection launch (small_topk_kernel) instead of the reducing pass + the hierarchical kernel.
+inline bool small_direct(const MatchCall& mc, int k) {
+    return mc.w.dense && mc.a.n <= (int64_t)FIN_THREADS * SMALL_GPT * GROUP && k + DENSE_ROW_SLACK + 1 <= SMALL_KT_MAX;
+}
+
+int run_score(dlc_ctx* ctx, int dtype, MatchCall& mc, hipStream_t st, bool partials_only = false) {
     const int slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[slot], st));
-    int rc = (dtype == DLC_BF16) ? launch_scores<dlc_bf16_tag>(ctx, mc.a, false, st, mc.w.dense)
-                                 : launch_scores<dlc_f16_tag>(ctx, mc.a, false, st, mc.w.dense);
+    int rc = (dtype == DLC_BF16) ? launch_scores<dlc_bf16_tag>(ctx, mc.a, false, st, mc.w.dense, partials_only)
+                                 : launch_scores<dlc_f16_tag>(ctx, mc.a, false, st, mc.w.dense, partials_only);
     if (rc != DLC_OK) return rc;
     if (ctx->profiling) {
         DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[slot], st));
@@ -1791,14 +1984,27 @@ int launch_merge(dlc_ctx* ctx, const double* scores, int64_t score_part_stride, 
 // Stage 2 of a match from a filled workspace: selection, fp64 re-score, final top-k, certification, exhaustive pass.
 int run_finish(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
                float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status, void* workspace, int flags,
-               hipStream_t st, int limited = 0, int64_t limit0 = 0) {
+               hipStream_t st, int limited = 0, int64_t limit0 = 0, bool direct = false) {
     char* ws = (char*)workspace;
     FinishArgs f = finish_args(mc, k, n, d, q, row_offset);
     f.limited = limited; f.limit0 = limit0;
     int* status = out_status ? out_status : (int*)(ws + mc.w.status);
     double* s64 = out_scores_f64 ? out_scores_f64 : (double*)(ws + mc.w.s64);
     int rc;
-    if (mc.w.rparts <= 1) {
+    if (direct) {
+        SmallArgs sa{};
+        sa.P = mc.a.P; sa.ldp = mc.a.ldp; sa.qstride = (long long)q * mc.a.ldp; sa.nsplit = mc.a.nsplit;
+        sa.gmax = mc.a.gmax; sa.ldg = mc.a.ldg;
+        sa.Q = f.Q; sa.ldq_b = f.ldq_b; sa.DB = f.DB; sa.lddb_b = f.lddb_b;
+        sa.n = n; sa.d = (int)d; sa.k = k; sa.m3max = k + DENSE_ROW_SLACK; sa.row_offset = row_offset;
+        sa.out_s = out_scores; sa.out_s64 = s64; sa.out_i = (long long*)out_idx; sa.status = status; sa.tau = mc.w.tau;
+        sa.limited = limited; sa.limit0 = limit0;
+        if (dtype == DLC_BF16)
+            hipLaunchKernelGGL(small_topk_kernel<dlc_bf16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, sa);
+        else
+            hipLaunchKernelGGL(small_topk_kernel<dlc_f16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, sa);
+        DLC_LAUNCH_CHECK(ctx, "small_topk_kernel");
+    } else if (mc.w.rparts <= 1) {
         f.out_s = out_scores; f.out_s64 = s64; f.out_i = (long long*)out_idx; f.status = status;
         if (mc.w.dense) { f.dense_S = mc.a.P; f.ld_s = mc.a.ldp; f.rslack = DENSE_ROW_SLACK; }
         rc = run_select<FIN_FUSED>(ctx, dtype, f, q, flags, st);
@@ -1838,10 +2044,11 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
     if (rc != DLC_OK) return rc;
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    rc = run_score(ctx, dtype, mc, (hipStream_t)stream);
+    const bool direct = small_direct(mc, k);
+    rc = run_score(ctx, dtype, mc, (hipStream_t)stream, direct);
     if (rc != DLC_OK) return rc;
     return run_finish(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_scores_f64, out_idx, out_status, workspace, 0,
-                      (hipStream_t)stream);
+                      (hipStream_t)stream, 0, 0, direct);
 }
 
 extern "C" int dlc_cosine_topk_older(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
@@ -1855,10 +2062,11 @@ extern "C" int dlc_cosine_topk_older(dlc_ctx* ctx, int dtype, const void* Q, int
     if (rc != DLC_OK) return rc;
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    rc = run_score(ctx, dtype, mc, (hipStream_t)stream);
+    const bool direct = small_direct(mc, k);
+    rc = run_score(ctx, dtype, mc, (hipStream_t)stream, direct);
     if (rc != DLC_OK) return rc;
     return run_finish(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_scores_f64, out_idx, out_status, workspace, 0,
-                      (hipStream_t)stream, 1, limit0);
+                      (hipStream_t)stream, 1, limit0, direct);
 }
 
 extern "C" int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,

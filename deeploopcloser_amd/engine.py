@@ -50,6 +50,7 @@ class Engine:
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self._dev_index = self.device.index
         ctx = C.c_void_p()
         rc = self.lib.dlc_create(self.device.index, C.byref(ctx))
         if rc != L.DLC_OK:
@@ -96,8 +97,13 @@ class Engine:
     def _check(self, rc):
         L.raise_for_status(self.lib, self.ctx, rc)
 
+    def _raw_stream(self):
+        """The current stream's handle as an int (torch._C._cuda_getCurrentRawStream: a tenth of the cost of building a
+        torch.cuda.Stream object, which three calls per batch of a streaming detector made a quarter of its host time)."""
+        return torch._C._cuda_getCurrentRawStream(self._dev_index)
+
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(self._raw_stream())
 
     WORKSPACE_STREAMS = 4      # per name: the workspaces of at most this many streams are kept (least recently used out)
 
@@ -107,12 +113,13 @@ class Engine:
         does not grow memory without bound: per name the WORKSPACE_STREAMS most recently used streams keep theirs, an
         evicted one is released once its stream has finished with it (the caching allocator's record_stream)."""
         nbytes = max(int(nbytes), 256)
-        stream = torch.cuda.current_stream(self.device)
-        k = (key, stream.cuda_stream)
+        k = (key, self._raw_stream())
         t = self._ws.pop(k, None)
         if t is None or t.numel() < nbytes:
             t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._ws[k] = t                                   # (re-)inserted last: dicts keep insertion order
+        if len(self._ws) <= self.WORKSPACE_STREAMS:       # (cannot hold more than that many of one name)
+            return t
         same = [kk for kk in self._ws if kk[0] == key]
         for kk in same[:max(0, len(same) - self.WORKSPACE_STREAMS)]:
             old = self._ws.pop(kk)
