@@ -1221,9 +1221,31 @@ __global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
     // ---- fp64 re-score, final top-k (fp64 key descending, ties -> lower row), certificate
     // (candidates dealt round the waves, a wave's two at a time with eight pieces of each in flight: these are dependent
     // round trips to memory, and with k + rslack = 9 one wave has two rows)
+    // Long rows (>= 32 KB) are bandwidth, not latency: there a wave takes eight candidates at a time and reads the query
+    // once for them (1063 queries x 24 rows of 150 KB: dealt in pairs every wave read the query again, +18 % time).
     const char* qrow = a.Q + (long long)qi * a.ldq_b;
     constexpr int NW = FIN_THREADS / 64;
     int ci = w;
+    if (a.d >= 16384) {
+        ci = m3;                                               // (nothing left for the dealt form below)
+        for (int s8 = w; s8 * GROUP < m3; s8 += NW) {
+            int ids[GROUP];
+            const char* rows[GROUP];
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r) {
+                ids[r] = __builtin_amdgcn_readfirstlane(s8 * GROUP + r < m3 ? crow[s8 * GROUP + r] : -1);
+                rows[r] = a.DB + (long long)(ids[r] < 0 ? 0 : ids[r]) * a.lddb_b;
+            }
+            double acc[GROUP];
+            rescore8_f64<Tag, 4>(qrow, rows, a.d, lane, acc);
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r)
+                if (lane == r && s8 * GROUP + r < m3) {
+                    cs64[s8 * GROUP + r] = ids[r] < 0 ? -INFINITY : acc[r];
+                    ck64[s8 * GROUP + r] = ids[r] < 0 ? KEY64_EMPTY : f64_key(acc[r]);
+                }
+        }
+    }
     for (; ci + NW < m3; ci += 2 * NW) {
         const int id0 = __builtin_amdgcn_readfirstlane(crow[ci]), id1 = __builtin_amdgcn_readfirstlane(crow[ci + NW]);
         const char* const rows[2] = {a.DB + (long long)(id0 < 0 ? 0 : id0) * a.lddb_b,
