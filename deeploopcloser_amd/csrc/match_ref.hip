@@ -47,8 +47,13 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __re
                                                               long long ldd, long long kchunk,
                                                               unsigned long long* __restrict__ out) {
     if (blockIdx.x < blockIdx.y) return;                  // below the diagonal: the mirror of another tile
+    // staged per operand word, once: x' = x ^ m(x) and s(x) (popabs4's mask and carry-in).  For w = a ^ b the sign bytes are
+    // s(w) = s(a) ^ s(b) and m(w) = m(a) ^ m(b), so |w| = (a' ^ b') + (s(a) ^ s(b)): an xor, a v_xad_u32 and the counting add
+    // per word pair instead of six instructions (the kernel is VALU-issue-bound: 1.15 G word pairs at 1063 frames).
     __shared__ unsigned As[DT][DCH / 4 + 1];
     __shared__ unsigned Bs[DT][DCH / 4 + 1];
+    __shared__ unsigned Asg[DT][DCH / 4 + 1];
+    __shared__ unsigned Bsg[DT][DCH / 4 + 1];
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const long long i0 = (long long)blockIdx.y * DT, j0 = (long long)blockIdx.x * DT;
@@ -63,40 +68,56 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __re
     const bool a_ok = i0 + lrow < n, b_ok = j0 + lrow < n;
     const int8_t* arow = desc + (a_ok ? i0 + lrow : 0) * ldd;
     const int8_t* brow = desc + (b_ok ? j0 + lrow : 0) * ldd;
-    for (long long k0 = k_lo; k0 < k_hi; k0 += DCH) {
+    // a step's words are fetched into registers while the step before is being counted (a workgroup has only ~13 steps
+    // at 1063 frames and two or three workgroups share a CU: the fetch latency was in the open)
+    unsigned va[4], vb[4];
+    auto fetch = [&](long long k0) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            unsigned va = 0, vb = 0;
+            va[w] = 0; vb[w] = 0;
             const long long k = k0 + (lw0 + w) * 4;
             if constexpr (WORDS) {
                 if (k < k_hi) {
                     const long long left = k_hi - k;
                     const unsigned mask = left >= 4 ? 0xffffffffu : ((1u << (8 * (int)left)) - 1u);
-                    if (a_ok) va = *(const unsigned*)(arow + k) & mask;
-                    if (b_ok) vb = *(const unsigned*)(brow + k) & mask;
+                    if (a_ok) va[w] = *(const unsigned*)(arow + k) & mask;
+                    if (b_ok) vb[w] = *(const unsigned*)(brow + k) & mask;
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (k + e < k_hi) {
-                        if (a_ok) va |= ((unsigned)(unsigned char)arow[k + e]) << (8 * e);
-                        if (b_ok) vb |= ((unsigned)(unsigned char)brow[k + e]) << (8 * e);
+                        if (a_ok) va[w] |= ((unsigned)(unsigned char)arow[k + e]) << (8 * e);
+                        if (b_ok) vb[w] |= ((unsigned)(unsigned char)brow[k + e]) << (8 * e);
                     }
                 }
             }
-            As[lrow][lw0 + w] = va;
-            Bs[lrow][lw0 + w] = vb;
+        }
+    };
+    fetch(k_lo);
+    for (long long k0 = k_lo; k0 < k_hi; k0 += DCH) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned sa = (va[w] >> 7) & 0x01010101u, sb = (vb[w] >> 7) & 0x01010101u;
+            As[lrow][lw0 + w] = va[w] ^ ((sa << 8) - sa);
+            Bs[lrow][lw0 + w] = vb[w] ^ ((sb << 8) - sb);
+            Asg[lrow][lw0 + w] = sa;
+            Bsg[lrow][lw0 + w] = sb;
         }
         __syncthreads();
+        if (k0 + DCH < k_hi) fetch(k0 + DCH);
 #pragma unroll
         for (int w = 0; w < DCH / 4; ++w) {
-            unsigned a[4], b[4];
+            unsigned a[4], b[4], sa[4], sb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = As[ty * 4 + r][w]; b[r] = Bs[tx * 4 + r][w]; }
+            for (int r = 0; r < 4; ++r) {
+                a[r] = As[ty * 4 + r][w]; b[r] = Bs[tx * 4 + r][w];
+                sa[r] = Asg[ty * 4 + r][w]; sb[r] = Bsg[tx * 4 + r][w];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] += popabs4(a[r] ^ b[c]);
+                for (int c = 0; c < 4; ++c) acc[r][c] += __popc((a[r] ^ b[c]) + (sa[r] ^ sb[c]));
         }
         __syncthreads();
     }
