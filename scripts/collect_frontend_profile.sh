@@ -10,5 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 S="python3 $R/scripts/prof_frontend.py"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o fe -- $S > $OUT/stats.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -o fe -- $S > $OUT/pmc_sq.log 2>&1
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mem -o fe -- $S > $OUT/pmc_mem.log 2>&1
+# (FETCH_SIZE and WRITE_SIZE in one pass: "Request exceeds the capabilities of the hardware to collect")
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch -o fe -- $S > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o fe -- $S > $OUT/pmc_write.log 2>&1
 ls $OUT

@@ -25,7 +25,7 @@ for row in csv.DictReader(open(os.path.join(src, "stats", "fe_kernel_stats.csv")
     if m:
         out["kernels"][m.group(0)] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
                                      "min_us": float(row["MinNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3}
-for sub in ("pmc_sq", "pmc_mem"):
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     path = os.path.join(src, sub, "fe_counter_collection.csv")
     if not os.path.exists(path):
         continue
@@ -48,7 +48,11 @@ if "SQ_INSTS_VALU" in p and "avg_us" in k:
     k["note"] = "VALU issue time of the kernel's instruction count against its measured duration: the kernel is VALU-bound"
 for name, kk in out["kernels"].items():
     p = kk.get("pmc_per_dispatch", {})
-    if "FETCH_SIZE" in p:                                   # rocprofv3 on gfx950: KiB, the 64-B requests counted as 32 B -> x2
+    if "FETCH_SIZE" in p:
+        # MI355X_MICROARCH.md "HBM": FETCH_SIZE (KiB) reports 1/2 of a wide coalesced stream on gfx950 -> x2.  The Harris
+        # kernel's reads are 44-byte row segments of a tile (1.56 x the image by the halo, one or two 64-B lines each): its
+        # raw figure already is ~2.8 x the 49 MB image, so both are kept
+        kk["fetch_size_raw_bytes_per_dispatch"] = p["FETCH_SIZE"] * 1024
         kk["hbm_read_bytes_per_dispatch"] = p["FETCH_SIZE"] * 1024 * 2
     if "WRITE_SIZE" in p:
         kk["hbm_write_bytes_per_dispatch"] = p["WRITE_SIZE"] * 1024
