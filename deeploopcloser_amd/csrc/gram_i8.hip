@@ -69,6 +69,10 @@ struct GramI8Args {
     int kp, H, P, fpu;
     int tiles_m, tiles_n, nsm, nsn, nsup;
     const int2* blk;                                // [nsup] (block row, block column) of the wanted blocks, row by row
+    // a STRIP of the triangle (the streaming form's batches, gram_argmin_i8_strip): only the column tiles tn_lo .. tn_hi are
+    // wanted, and abi / acand hold the column frames from fj_base on (row fj - fj_base).  The whole triangle: 0, INT_MAX, 0.
+    int tn_lo, tn_hi;
+    long long fj_base;
 };
 
 // The triangle's wanted blocks.  Block row si (GI_BR tiles of rows) wants the block columns from the one that holds the
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     const int2 blk = p.blk[want];
     const int si = blk.x, sj = blk.y;
     const int tile_m = si * GI_BR + (local >> 3), tile_n = sj * GI_BC + (local & 7);
-    if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+    if (tile_m >= p.tiles_m || tile_n >= p.tiles_n || tile_n < p.tn_lo || tile_n > p.tn_hi) return;
     const long long m0 = (long long)tile_m * GI_T, n0 = (long long)tile_n * GI_T;
     // the tile's last frame must lie behind its first row's frame, and its first frame must exist
     if ((long long)(2 * tile_n + 2) * p.fpu - 1 <= m0 / p.P || (long long)2 * tile_n * p.fpu >= p.nframes) return;
@@ -408,8 +412,8 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
             cand &= pmask;
             if ((cand & (cand - 1)) == 0) cand = 0;                      // P = 1, or a window wider than the padding's distance
         }
-        p.abi[fj * p.rp + a] = (unsigned char)bi;
-        p.acand[fj * p.rp + a] = cand;                                  // 0 = decided (one patch inside the window)
+        p.abi[(fj - p.fj_base) * p.rp + a] = (unsigned char)bi;
+        p.acand[(fj - p.fj_base) * p.rp + a] = cand;                    // 0 = decided (one patch inside the window)
     }
 }
 
@@ -774,11 +778,12 @@ int sim_stream_init(dlc_ctx* ctx, unsigned long long* keys, double* cc, void* pr
 // (a group shared with older rows is rewritten with the same values)
 int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, int64_t H, const double* score,
                         unsigned long long* keys, const double* cc, char* X, double* nu2, double* proj,
-                        unsigned long long* rowhash, int64_t g_first, int64_t g_count, hipStream_t st) {
+                        unsigned long long* rowhash, int64_t g_first, int64_t g_count, int64_t P, int* nbp, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     if (g_count < 1) return DLC_OK;
+    // nbp: |v|^2 of every patch in the product kernel's unit layout (the batched query's strip takes the patches as columns)
     hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)g_count), dim3(256), 0, st, desc, (long long)rows_total, (int)H, kp, score,
-                       keys, cc, X, (double*)nullptr, nu2, proj, rowhash, (long long)g_first, 1, 1, (int*)nullptr);
+                       keys, cc, X, (double*)nullptr, nu2, proj, rowhash, (long long)g_first, (int)P, sim_frames_per_unit(P), nbp);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
 }
@@ -812,6 +817,7 @@ int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X,
     a.gpitch = 3ll * kp * 16; a.kp = kp; a.H = (int)H; a.P = (int)P; a.fpu = sim_frames_per_unit(P);
     a.X = X; a.zrow = (int64_t)dlc::align_up((size_t)(N * P), 16); a.nbp = nbp; a.keys = keys; a.abi = abi; a.acand = acand;
     a.nfp = sim_col_frames(N, P); a.rp = sim_argmin_pitch(N, P); a.nrows = N * P; a.nframes = N;
+    a.tn_lo = 0; a.tn_hi = 0x7fffffff; a.fj_base = 0;
     a.tiles_m = (int)dlc::cdiv((N - 1) * P, (int64_t)GI_T);              // the last frame's patches have no later frame
     a.tiles_n = (int)sim_col_tiles(N, P);
     if (a.tiles_m < 1) return DLC_OK;
@@ -842,6 +848,62 @@ int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X,
         DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[prof_slot], st));
         ctx->prof_calls++;
     }
+    return DLC_OK;
+}
+
+// ---- a strip of the triangle: the column frames f_first .. f_last against every older row patch ----------------------
+// (the streaming form's batches: the frames of a batch are the strip's columns, the resident panel its rows -- the SAME
+// kernel, so a batch of 32 frames costs its share of the matrix call instead of 16 passes over the panel.)
+// blk: every block row against the block columns sj_lo .. sj_hi.  One workgroup of 256 threads.
+__global__ void gram_strip_blocks_kernel(int nsm, int sj_lo, int sj_hi, int2* blk) {
+    const int ncol = sj_hi - sj_lo + 1;
+    for (int e = threadIdx.x; e < nsm * ncol; e += blockDim.x) blk[e] = make_int2(e / ncol, sj_lo + e % ncol);
+}
+
+// frames of the strip's abi / acand (whole block columns) and the bytes of its block table
+int64_t gram_strip_frames(int64_t f_first, int64_t f_last, int64_t P) {
+    const int64_t fpb = (int64_t)GI_BC * 2 * sim_frames_per_unit(P);     // frames per block column
+    return (f_last / fpb - f_first / fpb + 1) * fpb;
+}
+size_t gram_strip_blocks_bytes(int64_t f_first, int64_t f_last, int64_t P) {
+    const int64_t fpb = (int64_t)GI_BC * 2 * sim_frames_per_unit(P);
+    const int64_t nsm = dlc::cdiv(dlc::cdiv(f_last * P, (int64_t)GI_T), (int64_t)GI_BR);
+    return (size_t)std::max<int64_t>(nsm, 1) * (size_t)(f_last / fpb - f_first / fpb + 1) * 8;
+}
+
+// X: a panel whose rows are frame-major patches (frame f's patch p = row f P + p) with an all-zero group at row `zrow`,
+// nbp in unit layout over the same frame numbering.  abi / acand: [gram_strip_frames, rp]; the entry of (column frame fj,
+// row patch a) is row fj - *fj_base_out.  Written: f_first <= fj <= f_last (and the other frames of their tiles), a < fj P.
+int gram_argmin_i8_strip(dlc_ctx* ctx, int64_t f_first, int64_t f_last, int64_t P, int64_t H, const char* X, int64_t zrow,
+                         const int* nbp, const unsigned long long* keys, unsigned char* abi, unsigned* acand, int64_t rp,
+                         int64_t* fj_base_out, void* blocks, hipStream_t st) {
+    const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
+    const int64_t N = f_last + 1;
+    GramI8Args a;
+    a.gpitch = 3ll * kp * 16; a.kp = kp; a.H = (int)H; a.P = (int)P; a.fpu = sim_frames_per_unit(P);
+    a.X = X; a.zrow = zrow; a.nbp = nbp; a.keys = keys; a.abi = abi; a.acand = acand;
+    a.nfp = 0; a.rp = rp; a.nrows = N * P; a.nframes = N;
+    a.tiles_m = (int)dlc::cdiv(f_last * P, (int64_t)GI_T);                // rows of the frames older than the newest
+    a.tiles_n = (int)sim_col_tiles(N, P);
+    a.tn_lo = (int)(f_first / a.fpu / 2); a.tn_hi = (int)(f_last / a.fpu / 2);
+    const int sj_lo = a.tn_lo / GI_BC, sj_hi = a.tn_hi / GI_BC;
+    a.fj_base = (int64_t)sj_lo * GI_BC * 2 * a.fpu;
+    *fj_base_out = a.fj_base;
+    if (a.tiles_m < 1) return DLC_OK;
+    a.nsm = (a.tiles_m + GI_BR - 1) / GI_BR;
+    a.nsn = (a.tiles_n + GI_BC - 1) / GI_BC;
+    a.nsup = a.nsm * (sj_hi - sj_lo + 1);
+    a.blk = (const int2*)blocks;
+    hipLaunchKernelGGL(gram_strip_blocks_kernel, dim3(1), dim3(256), 0, st, a.nsm, sj_lo, sj_hi, (int2*)blocks);
+    DLC_LAUNCH_CHECK(ctx, "gram_strip_blocks_kernel");
+    const size_t lds = (size_t)GI_NSTAGE * GI_STAGE;
+    if (!(ctx->func_attr_set & (1ull << DLC_ATTR_GRAM_I8))) {
+        DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gram_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->func_attr_set |= 1ull << DLC_ATTR_GRAM_I8;
+    }
+    const unsigned grid = (unsigned)(((a.nsup + 7) / 8) * 8 * 32);
+    hipLaunchKernelGGL(gram_i8_kernel, dim3(grid), dim3(256), lds, st, a);
+    DLC_LAUNCH_CHECK(ctx, "gram_i8_kernel");
     return DLC_OK;
 }
 

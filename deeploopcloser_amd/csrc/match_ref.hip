@@ -981,6 +981,62 @@ __global__ __launch_bounds__(256) void stream_score_kernel(const double* __restr
     if (pair_ok && a == 0) row[j] = keys[2] ? __longlong_as_double(0x7ff8000000000000ll) : term;
 }
 
+// The batched query through the matrix call's product kernel (gram_argmin_i8_strip: the batch's frames are a strip of
+// columns): its verdicts abi / acand [strip frame, rp] -> the final arg-mins bi_out [query, bi_pitch] that
+// stream_score_kernel reads, as stream_argmin_kernel leaves them.  Undecided sets are treated as pair_score_amin_kernel
+// treats them: copies of an earlier member dropped (equal content hashes), what is left evaluated directly in fp64
+// (direct_argmin_wave).  Lane = one older patch; a wave that has to evaluate holds up nobody else.
+__global__ __launch_bounds__(256) void strip_resolve_kernel(const double* __restrict__ desc, const unsigned char* __restrict__ abi,
+                                                            const unsigned* __restrict__ acand, long long rp, long long fj_base,
+                                                            const unsigned long long* __restrict__ rowhash,
+                                                            unsigned long long* __restrict__ keys, long long f_first, int P, int H,
+                                                            const int2* __restrict__ prog, unsigned char* __restrict__ bi_out,
+                                                            long long bi_pitch) {
+    extern __shared__ double rs_lds_all[];                  // the summation program's value stacks, 8 per wave
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const long long fj = f_first + blockIdx.y;
+    const long long ra = (long long)blockIdx.x * 256 + tid;
+    const bool live = ra < fj * P;
+    if (keys[2]) {                                          // poisoned stream: the product kernel left at once; rows come back NaN
+        if (live) bi_out[(long long)blockIdx.y * bi_pitch + ra] = 0;
+        return;
+    }
+    const int prog_len = (int)keys[5];
+    int bi = 0;
+    unsigned cand = 0;
+    if (live) {
+        bi = abi[(fj - fj_base) * rp + ra];
+        cand = acand[(fj - fj_base) * rp + ra];
+        if (cand) {
+            const unsigned long long* hbj = rowhash + 2 * (fj * P);
+            unsigned kept = 0;
+            for (unsigned m = cand; m; m &= m - 1) {
+                const int b = __ffs((int)m) - 1;
+                bool copy = false;
+                for (unsigned k2 = kept; k2; k2 &= k2 - 1) {
+                    const int e = __ffs((int)k2) - 1;
+                    copy |= hbj[2 * e] == hbj[2 * b] && hbj[2 * e + 1] == hbj[2 * b + 1];
+                }
+                if (!copy) kept |= 1u << b;
+            }
+            cand = kept;
+            if (!(cand & (cand - 1))) { bi = __ffs((int)cand) - 1; cand = 0; }           // one patch left: decided
+        }
+    }
+    unsigned long long directs = 0;
+    for (unsigned long long todo = __ballot(cand != 0); todo; todo &= todo - 1) {
+        const int src = __ffsll((long long)todo) - 1;
+        const unsigned cm = (unsigned)__shfl((int)cand, src);
+        const long long ra_s = (long long)blockIdx.x * 256 + w * 64 + src;
+        const int ebi = direct_argmin_wave(desc + ra_s * H, desc + fj * P * H, (unsigned long long)cm, P, H, lane, prog, prog_len,
+                                           rs_lds_all + (size_t)w * 8 * PF_STACK_DEPTH);
+        if (lane == src) bi = ebi;
+        if (lane == 0) ++directs;
+    }
+    if (live) bi_out[(long long)blockIdx.y * bi_pitch + ra] = (unsigned char)bi;
+    if (lane == 0 && directs) atomicAdd(&keys[4], directs);
+}
+
 // The k best entries of every row of an fp64 score matrix (the loop-closure candidates of a batch of streamed frames,
 // loop_closure.py: SdavLoopClosureDetector): row r offers its first limit0 + r * limit_step entries; order: score
 // descending, ties -> the lower index (the older frame); a NaN is never taken.  One workgroup per row, k rounds of
@@ -1030,7 +1086,9 @@ __global__ __launch_bounds__(256) void topk_rows_f64_kernel(const double* __rest
 }
 
 struct StreamWs {
-    size_t keys, prog, cc, nu2, proj, rowhash, bi, panel, total;
+    size_t keys, prog, cc, nu2, proj, rowhash, bi, nbp, panel, total;
+    long long zrow;            // an all-zero group of the panel (the last of the eight spare ones behind the capacity's rows)
+    size_t panel_groups;
 };
 StreamWs stream_ws(int64_t capacity, int64_t P, int64_t H) {
     StreamWs w;
@@ -1043,7 +1101,10 @@ StreamWs stream_ws(int64_t capacity, int64_t P, int64_t H) {
     w.proj = o; o += dlc::align_up(rows * 16, 256);               // double-double projections
     w.rowhash = o; o += dlc::align_up(rows * 16, 256);
     w.bi = o; o += dlc::align_up(rows, 256);
+    w.nbp = o; o += dlc::align_up((size_t)dlc_gemm::sim_col_rows(capacity, P) * 4, 256);   // |v|^2 in the product kernel's unit layout
     w.panel = o; o += dlc::align_up(dlc_gemm::sim_stream_panel_bytes(rows, H), 256);
+    w.panel_groups = (size_t)dlc::cdiv((int64_t)rows, (int64_t)16) + 8;
+    w.zrow = (long long)(w.panel_groups - 1) * 16;
     w.total = o;
     return w;
 }
@@ -1365,6 +1426,10 @@ extern "C" int dlc_sdav_stream_init(dlc_ctx* ctx, void* state, size_t state_byte
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     const StreamWs w = stream_ws(capacity, P, H);
     char* ws = (char*)state;
+    // the batched query's strip (gram_argmin_i8_strip) gathers padding columns from a zero group and reads |v|^2 = 0 for them
+    const size_t gbytes = 3 * dlc::align_up((size_t)H, (size_t)256) * 16;
+    DLC_HIP_CHECK(ctx, hipMemsetAsync(ws + w.panel + (w.panel_groups - 8) * gbytes, 0, 8 * gbytes, (hipStream_t)stream));
+    DLC_HIP_CHECK(ctx, hipMemsetAsync(ws + w.nbp, 0, (size_t)dlc_gemm::sim_col_rows(capacity, P) * 4, (hipStream_t)stream));
     return dlc_gemm::sim_stream_init(ctx, (unsigned long long*)(ws + w.keys), (double*)(ws + w.cc), ws + w.prog, H, lo, hi,
                                      col_centre, (hipStream_t)stream);
 }
@@ -1385,12 +1450,36 @@ extern "C" int dlc_sdav_stream_append(dlc_ctx* ctx, void* state, size_t state_by
     return dlc_gemm::sim_stream_quantise(ctx, desc, n_total * P, H, score, (unsigned long long*)(ws + w.keys),
                                          (const double*)(ws + w.cc), ws + w.panel,
                                          (double*)(ws + w.nu2), (double*)(ws + w.proj), (unsigned long long*)(ws + w.rowhash),
-                                         g_first, g_last - g_first, (hipStream_t)stream);
+                                         g_first, g_last - g_first, P, (int*)(ws + w.nbp), (hipStream_t)stream);
+}
+
+// A batch's workspace: the arg-mins [nq, pitch] | the strip's verdicts abi [frames, pitch] and acand [frames, pitch] | its block
+// table.  frames: the whole block columns a batch of nq frames can touch, wherever it starts.
+struct BatchWs {
+    size_t bi, abi, acand, blk, total;
+    long long pitch;
+};
+constexpr int64_t STRIP_MIN_QUERIES = 8;                      // smaller batches: two query frames per pass over the panel
+static BatchWs batch_ws(int64_t capacity, int64_t P, int64_t nq) {
+    BatchWs w;
+    w.pitch = (long long)dlc::align_up((size_t)capacity * (size_t)P, 256);
+    size_t o = 0;
+    w.bi = o; o += (size_t)nq * (size_t)w.pitch;
+    w.abi = w.acand = w.blk = o;
+    if (nq >= STRIP_MIN_QUERIES) {
+        const int64_t frames = dlc_gemm::gram_strip_frames(0, nq - 1, P) + dlc_gemm::gram_strip_frames(0, 0, P);
+        w.abi = o; o += (size_t)frames * (size_t)w.pitch;
+        w.acand = o; o += (size_t)frames * (size_t)w.pitch * 4;
+        w.blk = o; o += dlc::align_up(2 * dlc_gemm::gram_strip_blocks_bytes(0, capacity - 1, P) / 1 + 256, 256);
+    }
+    w.total = o;
+    return w;
 }
 
 static int stream_query_impl(dlc_ctx* ctx, const char* what, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
                              const double* desc, int64_t f, int64_t nq, const double* score, double a, double b, double* rows_out,
-                             int64_t ld_rows, int64_t* stats, unsigned char* bi, int64_t bi_pitch, void* stream) {
+                             int64_t ld_rows, int64_t* stats, unsigned char* bi, int64_t bi_pitch, void* stream,
+                             char* batch_base = nullptr, const BatchWs* bw = nullptr) {
     hipStream_t st = (hipStream_t)stream;
     const StreamWs w = stream_ws(capacity, P, H);
     char* ws = (char*)state;
@@ -1402,6 +1491,28 @@ static int stream_query_impl(dlc_ctx* ctx, const char* what, void* state, size_t
     }
     const long long kp = (long long)dlc::align_up((size_t)H, (size_t)256);
     const long long gpitch = 3 * kp * 16;
+    if (bw && nq >= STRIP_MIN_QUERIES && dlc_gemm::sim_filter_fits(capacity, P, H)) {
+        // the batch as a strip of the all-vs-all call: ONE launch of the product kernel (columns: the batch's frames, rows:
+        // every older patch of the resident panel) + the resolution of its undecided cells + the scores.  At 32 frames
+        // against 1062 older ones the two-frames-per-pass form streams the 245 MB panel 16 times (1.07 ms); the strip is
+        // 8 of the matrix call's 266 column tiles.
+        unsigned char* abi = (unsigned char*)(batch_base + bw->abi);
+        unsigned* acand = (unsigned*)(batch_base + bw->acand);
+        int64_t fj_base = 0;
+        int rc = dlc_gemm::gram_argmin_i8_strip(ctx, f, f_last, P, H, (const char*)(ws + w.panel), w.zrow, (const int*)(ws + w.nbp), keys,
+                                                abi, acand, bw->pitch, &fj_base, batch_base + bw->blk, st);
+        if (rc != DLC_OK) return rc;
+        hipLaunchKernelGGL(strip_resolve_kernel, dim3((unsigned)dlc::cdiv(f_last * P, (int64_t)256), (unsigned)nq), dim3(256), PF_STACK_BYTES,
+                           st, desc, (const unsigned char*)abi, (const unsigned*)acand, (long long)bw->pitch, (long long)fj_base,
+                           (const unsigned long long*)(ws + w.rowhash), keys, (long long)f, (int)P, (int)H, (const int2*)(ws + w.prog), bi,
+                           (long long)bi_pitch);
+        DLC_LAUNCH_CHECK(ctx, "strip_resolve_kernel");
+        hipLaunchKernelGGL(stream_score_kernel, dim3((unsigned)dlc::cdiv(f_last, (int64_t)8), (unsigned)nq), dim3(256), 0, st, desc,
+                           (const double*)(ws + w.proj), score, (const unsigned char*)bi, (long long)bi_pitch, keys, (long long)f, (int)P,
+                           (int)H, a, b, rows_out, (long long)ld_rows, (long long*)stats);
+        DLC_LAUNCH_CHECK(ctx, what);
+        return DLC_OK;
+    }
     const long long groups = dlc::cdiv(f_last * P, (int64_t)16);          // of the newest query; an older one's extra blocks leave at once
     const dim3 agrid((unsigned)dlc::cdiv(groups, (long long)(4 * SR_G)), (unsigned)(nq == 1 ? 1 : dlc::cdiv(nq, (int64_t)2)));
     if (nq == 1)
@@ -1435,8 +1546,8 @@ extern "C" int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_byt
 }
 
 extern "C" size_t dlc_sdav_stream_query_batch_workspace_bytes(int64_t capacity, int64_t P, int64_t n_queries) {
-    if (capacity < 1 || P < 1 || n_queries < 1) return 0;
-    return (size_t)n_queries * dlc::align_up((size_t)capacity * (size_t)P, 256);
+    if (capacity < 1 || P < 1 || P > 32 || n_queries < 1) return 0;
+    return batch_ws(capacity, P, n_queries).total;
 }
 
 extern "C" int dlc_sdav_stream_query_batch(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
@@ -1454,8 +1565,10 @@ extern "C" int dlc_sdav_stream_query_batch(dlc_ctx* ctx, void* state, size_t sta
         return dlc::fail(ctx, DLC_ERR_WORKSPACE, "sdav_stream_query_batch: workspace %zu < %zu bytes", workspace_bytes, need);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    if ((uintptr_t)workspace & 255) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_query_batch: workspace must be 256-byte aligned");
+    const BatchWs bw = batch_ws(capacity, P, n_queries);
     return stream_query_impl(ctx, "stream_score_kernel", state, state_bytes, capacity, P, H, desc, f_first, n_queries, score, a, b, rows_out,
-                             ld_rows, stats, (unsigned char*)workspace, (int64_t)dlc::align_up((size_t)capacity * (size_t)P, 256), stream);
+                             ld_rows, stats, (unsigned char*)workspace + bw.bi, bw.pitch, stream, (char*)workspace, &bw);
 }
 
 extern "C" int dlc_topk_rows_f64(dlc_ctx* ctx, const double* scores, int64_t rows, int64_t ld, int64_t limit0, int64_t limit_step,

@@ -322,3 +322,37 @@ def test_topk_rows_f64_and_batched_detector():
     with pytest.raises(ValueError):
         st.query_batch(n - 1, 2)
     assert one.loops(s1, i1, 0) == bat.loops(s2, i2, 0)
+
+
+def test_batched_stream_query_as_a_strip_of_the_matrix_call():
+    """Batches of 8 frames and more go through the all-vs-all call's product kernel (dlc_sdav_stream_query_batch: the
+    batch's frames are a strip of its columns): rows == single queries == the matrix call's columns, bit for bit -- for
+    batches that start anywhere in a block of 32 frames and span one, two or three of them, with copies of patches and of
+    frames (exact ties, +inf scores), near-copies one ulp apart, and a stream that has grown past its first capacity."""
+    import deeploopcloser_amd as dlc
+    eng = dlc.default_engine()
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(21)
+    n, p, h = 150, 30, 250
+    ds = torch.sigmoid(6.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+    ds[70] = ds[11]                                                  # a frame seen twice
+    ds[71, 4] = ds[71, 3]                                            # a patch twice in one frame
+    ds[90, 7] = torch.nextafter(ds[90, 6], torch.ones_like(ds[90, 6]))   # one ulp apart
+    ds[120:124, 5] = ds[40, 5]                                       # one patch in several frames
+    score = eng.distinctive_score(ds, 0.5, 0.2)
+    want = eng.sdav_similarity_matrix(ds, score, 10.0, -10.0, want_int64=False)[0]
+    st = dlc.SimilarityStream(score, patches=p, width=h, capacity=16)
+    st.append(ds[:100])
+    st.append(ds[100:])
+    stats_total = 0
+    for first, count in ((0, 8), (0, 32), (5, 8), (31, 9), (37, 64), (96, 32), (64, 86), (142, 8), (1, 149)):
+        rows = st.query_batch(first, count)
+        stats_total += int(st.stats[0])
+        for q in range(count):
+            f = first + q
+            got, col = rows[q, :f], want[:f, f]
+            assert torch.equal(got.isinf(), col.isinf()), (first, count, q)
+            assert torch.equal(torch.nan_to_num(got, posinf=1e300), torch.nan_to_num(col, posinf=1e300)), (first, count, q)
+    assert bool(torch.isinf(want[11, 70])) and stats_total > 0       # the copies went through the direct evaluation
+    one = st.query(77)
+    assert torch.equal(torch.nan_to_num(one, posinf=1e300), torch.nan_to_num(want[:77, 77], posinf=1e300))
