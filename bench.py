@@ -479,16 +479,17 @@ def bench_paths(eng, n_frames):
             with np.errstate(divide="ignore"):
                 np.sum(10 - 10 * np.log(osim.weighted_distances(dsm[j_], dsm[f_], osim.match_features(dsm[j_], dsm[f_]), scm)))
     t_cpu = time.perf_counter() - t0
-    panel_bytes = float(N) * N / 2 * P * 3 * 2560 / 2                     # two frames of a batch share one stream of the older frames' fixed-point panel
+    # every (older frame, new frame) pair's patch products once: the matrix call's int8 work (i8_ops above), spread over the batches
     out.append({"path": "SdavLoopClosureDetector.query_and_insert (batches of %d frames)" % sb,
                 "reference": "src/sdav/similarity/SimilarityCalculator.py:12-49 per arriving frame (src/sdav/create_similarity_matrix.py:34-38)",
                 "frames": N, "dtype": "f64", "k": sk, "value": (N * (N - 1) / 2.0) / (ss_ms * 1e-3), "unit": "frame-pairs/s", "ms": ss_ms,
                 "frames_per_s": N / (ss_ms * 1e-3),
-                "roofline": {"bound": "hbm", "achieved": panel_bytes / (ss_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": panel_bytes / (ss_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "stream_argmin_kernel<2> + stream_score_kernel (one pair of launches per batch; two frames per pass "
-                                       "over the older frames' int8 panel) + the quantisation of the batch + topk_rows_f64_kernel",
-                             "kernel_ms": ss_ms, "call_ms": ss_ms, "algorithmic_bytes_per_call": panel_bytes},
+                "roofline": {"bound": "mfma", "achieved": i8_ops / (ss_ms * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                             "frac": i8_ops / (ss_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": None,
+                             "kernel": "per batch: the quantisation of the batch into the resident panel, gram_i8_kernel on the strip "
+                                       "(columns: the batch's frames, rows: every older patch) + strip_resolve_kernel + stream_score_kernel + "
+                                       "topk_rows_f64_kernel -- the all-vs-all call's products, one strip of column tiles per batch",
+                             "kernel_ms": ss_ms, "call_ms": ss_ms, "algorithmic_ops_per_call": i8_ops},
                 "cpu_baseline": {"value": (nsm * (nsm - 1) // 2) / t_cpu, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/similarity.py similarity_score terms for every frame of the first %d against its older "
                                            "frames (%d pairs): %.2f s" % (nsm, nsm * (nsm - 1) // 2, t_cpu)},

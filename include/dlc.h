@@ -368,11 +368,16 @@ int dlc_sdav_stream_query(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t
                           const double* desc, int64_t f, const double* score, double a, double b, double* row_out,
                           int64_t* stats, void* stream);
 /*
- * The same for n_queries consecutive resident frames f_first .. f_first + n_queries - 1 in ONE pair of launches (a batch
+ * The same for n_queries consecutive resident frames f_first .. f_first + n_queries - 1 in one set of launches (a batch
  * of frames that arrived together: each still sees only the frames older than itself): row q of rows_out [n_queries,
  * ld_rows] receives entries 0 .. f_first + q - 1 (the rest of the row is left alone; ld_rows >= f_first + n_queries - 1),
  * each equal to what dlc_sdav_stream_query writes for that frame, bit for bit.  stats[0]: the direct evaluations of the whole
- * batch.  workspace: dlc_sdav_stream_query_batch_workspace_bytes (the queries' nearest-patch verdicts), 256-byte aligned.
+ * batch.  workspace: dlc_sdav_stream_query_batch_workspace_bytes, 256-byte aligned.
+ * Fewer than 8 frames: two query frames per pass over the panel.  8 and more: the batch is a STRIP of the all-vs-all
+ * call -- its frames are the columns, every older patch of the resident panel a row, of ONE launch of the int8 product
+ * kernel dlc_sdav_similarity_matrix runs (the panel holds the patches in that kernel's operand order; |v|^2 is kept in its
+ * column layout), whose undecided cells are then resolved as that call resolves them.  The workspace holds the queries'
+ * nearest-patch verdicts and, for such batches, the strip's verdict arrays.
  */
 size_t dlc_sdav_stream_query_batch_workspace_bytes(int64_t capacity, int64_t P, int64_t n_queries);
 int dlc_sdav_stream_query_batch(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
