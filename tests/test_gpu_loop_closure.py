@@ -356,3 +356,18 @@ def test_batched_stream_query_as_a_strip_of_the_matrix_call():
     assert bool(torch.isinf(want[11, 70])) and stats_total > 0       # the copies went through the direct evaluation
     one = st.query(77)
     assert torch.equal(torch.nan_to_num(one, posinf=1e300), torch.nan_to_num(want[:77, 77], posinf=1e300))
+    # other patch counts: 7 patches = nine frames per 64-column unit, 16 = four, 32 = two (no padding columns)
+    for p2, h2, n2 in ((7, 96, 90), (16, 130, 70), (32, 64, 45)):
+        d2 = torch.sigmoid(5.0 * torch.randn((n2, p2, h2), generator=g, device=eng.device, dtype=torch.float64))
+        d2[n2 // 2] = d2[3]
+        sc2 = eng.distinctive_score(d2, 0.5, 0.2)
+        w2 = eng.sdav_similarity_matrix(d2, sc2, 10.0, -10.0, want_int64=False)[0]
+        s2 = dlc.SimilarityStream(sc2, patches=p2, width=h2, capacity=n2)
+        s2.append(d2)
+        for first, count in ((0, n2), (11, min(40, n2 - 11)), (n2 - 9, 9)):
+            rows = s2.query_batch(first, count)
+            for q in range(count):
+                f = first + q
+                got, col = rows[q, :f], w2[:f, f]
+                assert torch.equal(got.isinf(), col.isinf()), (p2, first, count, q)
+                assert torch.equal(torch.nan_to_num(got, posinf=1e300), torch.nan_to_num(col, posinf=1e300)), (p2, first, count, q)
