@@ -14,7 +14,9 @@ with open(os.path.join(src, "stats", "sim_kernel_stats.csv")) as f, open(os.path
     for i, line in enumerate(f):
         if i == 0 or any(k in line for k in KERNELS):
             g.write(line)
-out = {"tag": tag, "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes)] -- python3 scripts/prof_similarity.py",
+import subprocess
+out = {"tag": tag, "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip(),
+       "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes)] -- python3 scripts/prof_similarity.py",
        "kernels": {}}
 for row in csv.DictReader(open(os.path.join(src, "stats", "sim_kernel_stats.csv"))):
     for k in KERNELS:

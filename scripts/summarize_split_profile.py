@@ -12,7 +12,9 @@ with open(os.path.join(src, "stats", "sp_kernel_stats.csv")) as f, open(os.path.
     for i, line in enumerate(f):
         if i == 0 or any(k in line for k in KERNELS):
             g.write(line)
-out = {"tag": tag, "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes)] -- python3 scripts/prof_sdav_split.py",
+import subprocess
+out = {"tag": tag, "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip(),
+       "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes)] -- python3 scripts/prof_sdav_split.py",
        "workload": "SDAV.transform(dtype='f16x2') of 1063 frames: 4 launches of gemm_split_f16_kernel<false> + 1 of <true> per call",
        "kernels": {}}
 for row in csv.DictReader(open(os.path.join(src, "stats", "sp_kernel_stats.csv"))):
