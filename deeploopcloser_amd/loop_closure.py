@@ -9,9 +9,11 @@ top-k path and reports the candidates whose cosine score reaches `threshold`.
 
     python -m deeploopcloser_amd.loop_closure DATASET_DIR --network cnn_vtl --k 5 --threshold 0.9
 
-Batching never changes a result: a batch of B frames is matched against the longest prefix any
-of its frames may see, with k+B-1 candidates per frame, and each frame then keeps its first k
-candidates that are old enough (at most B-1 of the extra rows are too recent for it).
+Batching never changes a result: a batch of B frames is matched in one call against the longest
+prefix any of its frames may see, each frame keeping to the key-frames old enough for IT inside the
+selection (dlc_cosine_topk_older).  The same lists come from a match with k+B-1 candidates per frame
+followed by each frame's first k candidates that are old enough (first_k_eligible below, the form
+the engine call is tested against: at most B-1 of the extra rows are too recent for a frame).
 """
 import argparse
 import contextlib
