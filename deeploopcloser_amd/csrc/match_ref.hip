@@ -142,17 +142,24 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __re
 // then the distinctive score exp(-(avg-mu)^2 / (2 sigma^2)) (:25-27).
 //
 // The row-ordered fp64 add chain of a column IS the specification (bit parity with NumPy), the
-// serial LOAD chain is not: a workgroup owns DS_COLS = 16 columns (one 128-byte segment of every
-// row) and all of its 256 threads fetch -- 16 lane groups x DS_U rows each = a batch of 256 rows =
-// 32 KiB, and TWO batches ahead (two register sets): 64 KiB in flight per workgroup, 157 workgroups
-// at H = 2500 -- while the first 16 lanes add the batch that has landed out of LDS in row order.  One
+// serial LOAD chain is not: a workgroup owns DS_COLS = 8 columns (one 64-byte segment of every
+// row) and all of its 256 threads fetch -- 32 lane groups x DS_U rows each = a batch of 512 rows =
+// 32 KiB, and TWO batches ahead (two register sets): 64 KiB in flight per workgroup, 313 workgroups
+// at H = 2500 (16 columns per workgroup were 157 -- fewer than the chip has CUs: 0.38 ms; 8: 0.33; 4 columns
+// or smaller batches: slower; measured r04, scripts/exp/ds_variants.sh) -- while the first 8 lanes add
+// the batch that has landed out of LDS in row order.  One
 // barrier per batch (double-buffered LDS).  With one batch ahead a batch took as long as its loads
 // (3.2 us, the add chain 1 us): 2 TB/s.  (512 threads and one batch of 64 KiB ahead: slower still --
 // the same latency per batch, twice the batch.)  HBM-bound (rows*H*8 bytes read once) down to the
 // latency of the add chain itself (rows x one v_add_f64).
-constexpr int DS_COLS = 16;               // columns per workgroup
-constexpr int DS_U = 16;                  // rows per thread and batch
-constexpr int DS_ROWS = 16 * DS_U;        // rows per batch
+#ifndef DLC_DS_COLS
+#define DLC_DS_COLS 8
+#define DLC_DS_U 16
+#endif
+constexpr int DS_COLS = DLC_DS_COLS;      // columns per workgroup
+constexpr int DS_U = DLC_DS_U;            // rows per thread and batch
+constexpr int DS_G = 256 / DS_COLS;       // lane groups: rows fetched side by side
+constexpr int DS_ROWS = DS_G * DS_U;      // rows per batch
 // range (may be null): the pass sees every element once, so it also leaves what the similarity's filter form needs to know
 // about the dataset -- every COLUMN's minimum and maximum as ordered keys, and whether it holds a NaN / infinity: the layout
 // of gram_i8.hip's sim_colrange_kernel, 3 + 2 H words -- and dlc_sdav_similarity_matrix then skips its own pass over the
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
     __shared__ double buf[2][DS_ROWS][DS_COLS];
     double lo = INFINITY, hi = -INFINITY;
     bool bad = false;
-    const int tid = threadIdx.x, c = tid & 15, g = tid >> 4;
+    const int tid = threadIdx.x, c = tid % DS_COLS, g = tid / DS_COLS;
     const int col = blockIdx.x * DS_COLS + c;
     const bool col_ok = col < H;
     const double* src = desc + (col_ok ? col : 0);
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
     auto fetch = [&](double (&v)[DS_U], long long r0) {
 #pragma unroll
         for (int u = 0; u < DS_U; ++u) {
-            const long long r = r0 + u * 16 + g;
+            const long long r = r0 + u * DS_G + g;
             v[u] = (col_ok && r < rows) ? src[r * H] : 0.0;
         }
     };
@@ -182,11 +189,11 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
     // one batch: its values (landed by now) into LDS, the fetch of the batch two ahead into the same registers, the add
     auto batch = [&](double (&v)[DS_U], int b, long long r0) {
 #pragma unroll
-        for (int u = 0; u < DS_U; ++u) buf[b][u * 16 + g][c] = v[u];
+        for (int u = 0; u < DS_U; ++u) buf[b][u * DS_G + g][c] = v[u];
         if (range) {                                           // (here, where the loads have landed -- not where they are issued)
 #pragma unroll
             for (int u = 0; u < DS_U; ++u)
-                if (col_ok && r0 + u * 16 + g < rows) { bad |= !(fabs(v[u]) < INFINITY); lo = fmin(lo, v[u]); hi = fmax(hi, v[u]); }
+                if (col_ok && r0 + u * DS_G + g < rows) { bad |= !(fabs(v[u]) < INFINITY); lo = fmin(lo, v[u]); hi = fmax(hi, v[u]); }
         }
         __syncthreads();
         if (r0 + 2 * DS_ROWS < rows) fetch(v, r0 + 2 * DS_ROWS);
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
         __syncthreads();
         if (tid < DS_COLS && col_ok) {
             double l = buf[0][0][c], h = buf[1][0][c];
-            for (int q = 1; q < 16; ++q) { l = fmin(l, buf[0][q][c]); h = fmax(h, buf[1][q][c]); }
+            for (int q = 1; q < DS_G; ++q) { l = fmin(l, buf[0][q][c]); h = fmax(h, buf[1][q][c]); }
             range[3 + col] = dlc_f64_key(l);
             range[3 + H + col] = dlc_f64_key(h);
         }
