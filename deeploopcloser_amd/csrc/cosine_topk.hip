@@ -1100,12 +1100,117 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void f
     finish_topk_body<Tag, 256, RS_UNROLL, MODE>(a);
 }
 
+// Exhaustive pass of the queries a selection could not certify (status[q] == 1; every other workgroup leaves at once).
+// L = the k-th fp64 score found so far (lower[q * lower_stride]; -inf: fewer than k rows found) is a lower bound of
+// the true k-th score, so every top-k row has an fp32 score >= L - tau and lies in a group whose maximum is >= L - tau:
+// all such groups are re-scored in fp64, 64 groups at a time, against a running top-k (L only rises on the way).
+// The result REPLACES the query's top-k; status becomes 2.  In the degenerate case (all scores within tau of each
+// other) this is an fp64 brute force over the shard for that query -- slow, finite and exact.
+struct ExhaustiveArgs {
+    const float* gmax; long long ldg; long long ng;
+    const char* Q; long long ldq_b; const char* DB; long long lddb_b;
+    long long n; int d; int k; long long row_offset;
+    const double* lower; long long lower_stride;
+    float* out_s; double* out_s64; long long* out_i;     // [q, k]; out_s / out_s64 may be null
+    int* status;
+    double tau;
+    int limited; long long limit0;                           // as in FinishArgs
+};
+constexpr int EXH_BATCH = 64;                               // groups per re-score batch
+constexpr int EXH_POOL = EXH_BATCH * GROUP + DLC_MAX_K;     // running top-k in front of the batch's rows
+
+// (the body: also the tail of small_topk_kernel, whose workgroup carries on with it when its own selection did not certify
+// -- no second launch behind every small-database match to find out that nothing is left to do)
+template <typename Tag>
+__device__ __forceinline__ void exhaustive_topk_body(const ExhaustiveArgs& a, double lower) {
+    const int qi = blockIdx.x;
+    __shared__ long long pk[EXH_POOL];
+    __shared__ double ps[EXH_POOL];
+    __shared__ int pid[EXH_POOL];
+    __shared__ int qlist[FIN_THREADS];
+    __shared__ int wcnt[FIN_THREADS / 64];
+    __shared__ int sel[DLC_MAX_K];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = a.k;
+    const long long n_vis = visible_rows(a.n, a.limited, a.limit0, qi);
+    const long long ng_vis = a.limited ? (n_vis + GROUP - 1) / GROUP : a.ng;
+    double theta = lower - a.tau;                                        // -inf - tau = -inf: everything qualifies
+    int cnt = 0;                                                         // rows in the running top-k (pool[0 .. cnt))
+    const char* qrow = a.Q + (long long)qi * a.ldq_b;
+    for (long long c0 = 0; c0 < ng_vis; c0 += FIN_THREADS) {
+        const long long g = c0 + tid;
+        const bool qual = g < ng_vis && (double)a.gmax[(long long)qi * a.ldg + g] >= theta;
+        const unsigned long long bal = __ballot(qual);
+        if (lane == 0) wcnt[w] = __popcll(bal);
+        __syncthreads();
+        int base = 0, nqual = 0;
+#pragma unroll
+        for (int ww = 0; ww < FIN_THREADS / 64; ++ww) {
+            base += ww < w ? wcnt[ww] : 0;
+            nqual += wcnt[ww];
+        }
+        if (qual) qlist[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)g;
+        __syncthreads();
+        for (int b0 = 0; b0 < nqual; b0 += EXH_BATCH) {
+            const int nb = min(EXH_BATCH, nqual - b0);
+            for (int s = w; s < nb; s += FIN_THREADS / 64) {
+                const long long row0 = (long long)qlist[b0 + s] * GROUP;
+                const char* rows[GROUP];
+#pragma unroll
+                for (int r = 0; r < GROUP; ++r) rows[r] = a.DB + (row0 + r < a.n ? row0 + r : a.n - 1) * a.lddb_b;
+                double acc[GROUP];
+                rescore8_f64<Tag, 4>(qrow, rows, a.d, lane, acc);
+#pragma unroll
+                for (int r = 0; r < GROUP; ++r)
+                    if (lane == r) {
+                        const bool ok = row0 + r < n_vis;
+                        ps[cnt + s * GROUP + r] = ok ? acc[r] : -INFINITY;
+                        pk[cnt + s * GROUP + r] = ok ? f64_key(acc[r]) : KEY64_EMPTY;
+                        pid[cnt + s * GROUP + r] = (int)(row0 + r);
+                    }
+            }
+            for (int e = tid; e < k; e += FIN_THREADS) sel[e] = -1;
+            __syncthreads();
+            const int m = cnt + nb * GROUP;
+            rank_select64(pk, pid, m, k, sel);
+            __syncthreads();
+            // compact the winners to the front of the pool (through registers: k <= 128 < FIN_THREADS)
+            long long tk = KEY64_EMPTY; double ts = -INFINITY; int ti = -1;
+            if (tid < k && sel[tid] >= 0) { const int c = sel[tid]; tk = pk[c]; ts = ps[c]; ti = pid[c]; }
+            const unsigned long long have = __ballot(tid < k && sel[tid] >= 0);
+            if (lane == 0) wcnt[w] = __popcll(have);
+            __syncthreads();
+            if (tid < k) { pk[tid] = tk; ps[tid] = ts; pid[tid] = ti; }
+            cnt = 0;
+#pragma unroll
+            for (int ww = 0; ww < FIN_THREADS / 64; ++ww) cnt += wcnt[ww];
+            __syncthreads();
+            if (cnt == k && ps[k - 1] - a.tau > theta) theta = ps[k - 1] - a.tau;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < k; e += FIN_THREADS) {
+        const bool ok = e < cnt;
+        if (a.out_s) a.out_s[(long long)qi * k + e] = ok ? (float)ps[e] : -INFINITY;
+        if (a.out_s64) a.out_s64[(long long)qi * k + e] = ok ? ps[e] : -INFINITY;
+        a.out_i[(long long)qi * k + e] = ok ? (long long)pid[e] + a.row_offset : -1;
+    }
+    if (tid == 0) a.status[qi] = 2;
+}
+
+template <typename Tag>
+__global__ __launch_bounds__(FIN_THREADS) void exhaustive_topk_kernel(ExhaustiveArgs a) {
+    const int qi = blockIdx.x;
+    if (a.status[qi] != 1) return;
+    exhaustive_topk_body<Tag>(a, a.lower[(long long)qi * a.lower_stride]);
+}
+
 // The small-database plan in ONE launch per match (databases of <= 16384 rows, k + rslack < SMALL_KT_MAX): a workgroup
 // per query sums the split-K partial scores of its row itself (thread t: the groups t, t + 512, ... of 8 rows; fp64 sum
 // of the chunks rounded once, exactly splitk_groups_kernel's arithmetic, so the same tau holds), keeps the 32 scores in
 // registers, extracts the k + rslack + 1 best ROWS (each wave the best of its slice by repeated DPP arg-max, the
 // 8 x (k + rslack + 1) survivors ranked together), re-scores k + rslack of them in fp64 (dealt round the waves) and
-// certifies against the one left behind.  The group maxima are written for the exhaustive pass only.  With the
+// certifies against the one left behind -- and, where that fails, carries on with the exhaustive pass (the group maxima are
+// written for it only).  With the
 // hierarchical kernel this plan was three launches (partials, splitk_groups_kernel, finish_topk_kernel: half-tile
 // selection, group selection, row selection) -- 34 us of a 32-frame batch's 45 in the streaming detector.
 struct SmallArgs {
@@ -1281,107 +1386,25 @@ __global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
             a.out_i[(long long)qi * k + e] = (long long)crow[c] + a.row_offset;
         }
     }
-    if (tid == 0) {
-        const int c = sel[k - 1];
-        const bool cert = bkey == 0u || (c >= 0 && cs64[c] > (double)key_f32(bkey) + a.tau);
-        a.status[qi] = cert ? 0 : 1;
+    // certified: nothing was left behind, or the k-th fp64 score clears everything left behind by more than tau (uniform:
+    // every thread reads the same LDS words).  Otherwise this workgroup runs the exhaustive pass itself.
+    const int ck = sel[k - 1];
+    const double kth = ck >= 0 ? cs64[ck] : -INFINITY;
+    const bool cert = bkey == 0u || (ck >= 0 && kth > (double)key_f32(bkey) + a.tau);
+    if (cert) {
+        if (tid == 0) a.status[qi] = 0;
+        return;
     }
-}
-
-// Exhaustive pass of the queries a selection could not certify (status[q] == 1; every other workgroup leaves at once).
-// L = the k-th fp64 score found so far (lower[q * lower_stride]; -inf: fewer than k rows found) is a lower bound of
-// the true k-th score, so every top-k row has an fp32 score >= L - tau and lies in a group whose maximum is >= L - tau:
-// all such groups are re-scored in fp64, 64 groups at a time, against a running top-k (L only rises on the way).
-// The result REPLACES the query's top-k; status becomes 2.  In the degenerate case (all scores within tau of each
-// other) this is an fp64 brute force over the shard for that query -- slow, finite and exact.
-struct ExhaustiveArgs {
-    const float* gmax; long long ldg; long long ng;
-    const char* Q; long long ldq_b; const char* DB; long long lddb_b;
-    long long n; int d; int k; long long row_offset;
-    const double* lower; long long lower_stride;
-    float* out_s; double* out_s64; long long* out_i;     // [q, k]; out_s / out_s64 may be null
-    int* status;
-    double tau;
-    int limited; long long limit0;                           // as in FinishArgs
-};
-constexpr int EXH_BATCH = 64;                               // groups per re-score batch
-constexpr int EXH_POOL = EXH_BATCH * GROUP + DLC_MAX_K;     // running top-k in front of the batch's rows
-
-template <typename Tag>
-__global__ __launch_bounds__(FIN_THREADS) void exhaustive_topk_kernel(ExhaustiveArgs a) {
-    const int qi = blockIdx.x;
-    if (a.status[qi] != 1) return;
-    __shared__ long long pk[EXH_POOL];
-    __shared__ double ps[EXH_POOL];
-    __shared__ int pid[EXH_POOL];
-    __shared__ int qlist[FIN_THREADS];
-    __shared__ int wcnt[FIN_THREADS / 64];
-    __shared__ int sel[DLC_MAX_K];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = a.k;
-    const long long n_vis = visible_rows(a.n, a.limited, a.limit0, qi);
-    const long long ng_vis = a.limited ? (n_vis + GROUP - 1) / GROUP : a.ng;
-    double theta = a.lower[(long long)qi * a.lower_stride] - a.tau;      // -inf - tau = -inf: everything qualifies
-    int cnt = 0;                                                         // rows in the running top-k (pool[0 .. cnt))
-    const char* qrow = a.Q + (long long)qi * a.ldq_b;
-    for (long long c0 = 0; c0 < ng_vis; c0 += FIN_THREADS) {
-        const long long g = c0 + tid;
-        const bool qual = g < ng_vis && (double)a.gmax[(long long)qi * a.ldg + g] >= theta;
-        const unsigned long long bal = __ballot(qual);
-        if (lane == 0) wcnt[w] = __popcll(bal);
-        __syncthreads();
-        int base = 0, nqual = 0;
-#pragma unroll
-        for (int ww = 0; ww < FIN_THREADS / 64; ++ww) {
-            base += ww < w ? wcnt[ww] : 0;
-            nqual += wcnt[ww];
-        }
-        if (qual) qlist[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)g;
-        __syncthreads();
-        for (int b0 = 0; b0 < nqual; b0 += EXH_BATCH) {
-            const int nb = min(EXH_BATCH, nqual - b0);
-            for (int s = w; s < nb; s += FIN_THREADS / 64) {
-                const long long row0 = (long long)qlist[b0 + s] * GROUP;
-                const char* rows[GROUP];
-#pragma unroll
-                for (int r = 0; r < GROUP; ++r) rows[r] = a.DB + (row0 + r < a.n ? row0 + r : a.n - 1) * a.lddb_b;
-                double acc[GROUP];
-                rescore8_f64<Tag, 4>(qrow, rows, a.d, lane, acc);
-#pragma unroll
-                for (int r = 0; r < GROUP; ++r)
-                    if (lane == r) {
-                        const bool ok = row0 + r < n_vis;
-                        ps[cnt + s * GROUP + r] = ok ? acc[r] : -INFINITY;
-                        pk[cnt + s * GROUP + r] = ok ? f64_key(acc[r]) : KEY64_EMPTY;
-                        pid[cnt + s * GROUP + r] = (int)(row0 + r);
-                    }
-            }
-            for (int e = tid; e < k; e += FIN_THREADS) sel[e] = -1;
-            __syncthreads();
-            const int m = cnt + nb * GROUP;
-            rank_select64(pk, pid, m, k, sel);
-            __syncthreads();
-            // compact the winners to the front of the pool (through registers: k <= 128 < FIN_THREADS)
-            long long tk = KEY64_EMPTY; double ts = -INFINITY; int ti = -1;
-            if (tid < k && sel[tid] >= 0) { const int c = sel[tid]; tk = pk[c]; ts = ps[c]; ti = pid[c]; }
-            const unsigned long long have = __ballot(tid < k && sel[tid] >= 0);
-            if (lane == 0) wcnt[w] = __popcll(have);
-            __syncthreads();
-            if (tid < k) { pk[tid] = tk; ps[tid] = ts; pid[tid] = ti; }
-            cnt = 0;
-#pragma unroll
-            for (int ww = 0; ww < FIN_THREADS / 64; ++ww) cnt += wcnt[ww];
-            __syncthreads();
-            if (cnt == k && ps[k - 1] - a.tau > theta) theta = ps[k - 1] - a.tau;
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < k; e += FIN_THREADS) {
-        const bool ok = e < cnt;
-        if (a.out_s) a.out_s[(long long)qi * k + e] = ok ? (float)ps[e] : -INFINITY;
-        if (a.out_s64) a.out_s64[(long long)qi * k + e] = ok ? ps[e] : -INFINITY;
-        a.out_i[(long long)qi * k + e] = ok ? (long long)pid[e] + a.row_offset : -1;
-    }
-    if (tid == 0) a.status[qi] = 2;
+    __syncthreads();                                           // the group maxima and the lists above are written; LDS is re-used
+    ExhaustiveArgs e;
+    e.gmax = a.gmax; e.ldg = a.ldg; e.ng = ng_all;
+    e.Q = a.Q; e.ldq_b = a.ldq_b; e.DB = a.DB; e.lddb_b = a.lddb_b;
+    e.n = a.n; e.d = a.d; e.k = k; e.row_offset = a.row_offset;
+    e.lower = nullptr; e.lower_stride = 0;
+    e.out_s = a.out_s; e.out_s64 = a.out_s64; e.out_i = a.out_i;
+    e.status = a.status; e.tau = a.tau;
+    e.limited = a.limited; e.limit0 = a.limit0;
+    exhaustive_topk_body<Tag>(e, kth);
 }
 
 // Global top-k from [parts, q, k] per-shard results (the all-gather layout); idx < 0 = empty slot.
@@ -2045,6 +2068,7 @@ int run_finish(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, i
         rc = launch_merge(ctx, ps, q * k, pi, q * k, mc.w.rparts, q, k, pb, mc.w.tau, out_scores, s64, out_idx, status, st);
         if (rc != DLC_OK) return rc;
     }
+    if (direct) return DLC_OK;                                  // small_topk_kernel runs the exhaustive pass of its own queries
     return run_exhaustive(ctx, dtype, f, q, s64 + (k - 1), k, out_scores, s64, out_idx, status, st);
 }
 
