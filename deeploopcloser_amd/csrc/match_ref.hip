@@ -24,14 +24,10 @@ namespace {
 // ---------------------------------------------------------------------------
 // cnn_vtl distance
 // ---------------------------------------------------------------------------
-// popcount(|x|) for the four signed bytes of w:  |x| = (x ^ m) + s with m = 0xFF
-// and s = 1 for negative bytes (~x <= 127, so the +1 never carries out of a byte;
-// -128 -> 128 -> 1 bit, as bin(-128) has).
-__device__ __forceinline__ int popabs4(unsigned w) {
-    const unsigned s = (w >> 7) & 0x01010101u;
-    const unsigned m = (s << 8) - s;   // 0xFF in every negative byte
-    return __popc((w ^ m) + s);
-}
+// popcount(|x|) for the four signed bytes of a word w:  |x| = (x ^ m) + s with m = 0xFF and s = 1 for negative bytes
+// (~x <= 127, so the +1 never carries out of a byte; -128 -> 128 -> 1 bit, as bin(-128) has):
+//     s = (w >> 7) & 0x01010101,  m = (s << 8) - s,  popcount((w ^ m) + s).
+// The kernel below stages x ^ m(x) and s(x) per OPERAND word (see there).
 
 constexpr int DT = 64;      // output tile (frames x frames)
 constexpr int DCH = 64;     // descriptor bytes per step (16 words)
@@ -47,7 +43,7 @@ __global__ __launch_bounds__(256) void distance_matrix_kernel(const int8_t* __re
                                                               long long ldd, long long kchunk,
                                                               unsigned long long* __restrict__ out) {
     if (blockIdx.x < blockIdx.y) return;                  // below the diagonal: the mirror of another tile
-    // staged per operand word, once: x' = x ^ m(x) and s(x) (popabs4's mask and carry-in).  For w = a ^ b the sign bytes are
+    // staged per operand word, once: x' = x ^ m(x) and s(x) (the mask and the carry-in above).  For w = a ^ b the sign bytes are
     // s(w) = s(a) ^ s(b) and m(w) = m(a) ^ m(b), so |w| = (a' ^ b') + (s(a) ^ s(b)): an xor, a v_xad_u32 and the counting add
     // per word pair instead of six instructions (the kernel is VALU-issue-bound: 1.15 G word pairs at 1063 frames).
     __shared__ unsigned As[DT][DCH / 4 + 1];
@@ -1477,7 +1473,7 @@ static BatchWs batch_ws(int64_t capacity, int64_t P, int64_t nq) {
         const int64_t frames = dlc_gemm::gram_strip_frames(0, nq - 1, P) + dlc_gemm::gram_strip_frames(0, 0, P);
         w.abi = o; o += (size_t)frames * (size_t)w.pitch;
         w.acand = o; o += (size_t)frames * (size_t)w.pitch * 4;
-        w.blk = o; o += dlc::align_up(2 * dlc_gemm::gram_strip_blocks_bytes(0, capacity - 1, P) / 1 + 256, 256);
+        w.blk = o; o += dlc::align_up(dlc_gemm::gram_strip_blocks_bytes(0, capacity - 1, P), 256);   // (every block column: an upper bound)
     }
     w.total = o;
     return w;
