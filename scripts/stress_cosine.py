@@ -18,7 +18,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 eng = dlc.default_engine()
 rng = np.random.RandomState(seed)
 g = torch.Generator(device=eng.device); g.manual_seed(seed)
-t0, cnt, exhaustive, crowded = time.time(), 0, 0, 0
+t0, cnt, exhaustive, crowded, limited = time.time(), 0, 0, 0, 0
 while time.time() - t0 < budget:
     n = int(rng.choice([rng.randint(1, 300), rng.randint(300, 20000), rng.randint(20000, 120000)]))
     d = int(rng.choice([rng.randint(1, 200), 64 * rng.randint(1, 20), rng.randint(200, 3000)]))
@@ -66,6 +66,25 @@ while time.time() - t0 < budget:
         m = eng.topk_merge(torch.stack(ps), torch.stack(pi), details=True)
         assert torch.equal(m.idx, top.idx) and torch.equal(m.scores_f64, top.scores_f64) and torch.equal(m.scores, top.scores), \
             ("sharded", n, d, q, k, parts)
+    if rng.rand() < 0.4:
+        # the age-limited match (dlc_cosine_topk_older): query i sees the rows below limit0 + i only
+        limit0 = int(rng.choice([rng.randint(-q, n + 1), n - q, rng.randint(0, 20), n + 5]))
+        old = eng.match_topk(qs, db, k, details=True, older_than=limit0)
+        lim = (limit0 + torch.arange(q, device=eng.device)).clamp(0, n)
+        hidden = torch.arange(n, device=eng.device).unsqueeze(0) >= lim.unsqueeze(1)
+        mkey = torch.where(hidden, torch.full_like(key, float("-inf")), key)
+        morder = torch.sort(-mkey, dim=1, stable=True).indices[:, :kk]
+        seen = torch.gather(~hidden, 1, morder)
+        want_i = torch.where(seen, morder, torch.full_like(morder, -1))
+        assert torch.equal(old.idx[:, :kk], want_i), ("older: indices", n, d, q, k, dtype, limit0)
+        assert bool((old.idx[:, kk:] == -1).all())
+        want_s = torch.where(seen, torch.gather(full, 1, morder), torch.full_like(want, float("-inf")))
+        got_s = old.scores_f64[:, :kk]
+        assert torch.equal(got_s.isinf(), want_s.isinf()) and float(torch.nan_to_num(got_s - want_s, nan=0.0).abs().max()) < 1e-12, \
+            ("older: scores", n, d, q, k, limit0)
+        assert set(old.status.cpu().tolist()) <= {0, 2}
+        limited += 1
     cnt += 1
 torch.cuda.synchronize()
-print("cosine top-k: %d random cases exact (%d crowded; %d queries resolved by the exhaustive pass)" % (cnt, crowded, exhaustive), flush=True)
+print("cosine top-k: %d random cases exact (%d crowded; %d queries resolved by the exhaustive pass; %d cases also with an age limit per query)"
+      % (cnt, crowded, exhaustive, limited), flush=True)
