@@ -73,6 +73,7 @@ struct GramI8Args {
     // wanted, and abi / acand hold the column frames from fj_base on (row fj - fj_base).  The whole triangle: 0, INT_MAX, 0.
     int tn_lo, tn_hi;
     long long fj_base;
+    int strip_cols, sj_lo;                          // > 0: a strip -- no table, block `want` is (want / strip_cols, sj_lo + want % strip_cols)
 };
 
 // The triangle's wanted blocks.  Block row si (GI_BR tiles of rows) wants the block columns from the one that holds the
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(256) void gram_i8_kernel(const GramI8Args p) {
     const int xcd = id & 7, slot = id >> 3, local = slot & 31;
     const int want = (slot >> 5) * 8 + xcd;           // index among the wanted blocks: p.blk (gram_blocks_kernel) names it
     if (want >= p.nsup) return;
-    const int2 blk = p.blk[want];
+    // the triangle's blocks come from the table; a strip's are every block row x its strip_cols block columns from sj_lo on
+    const int2 blk = p.strip_cols ? make_int2(want / p.strip_cols, p.sj_lo + want % p.strip_cols) : p.blk[want];
     const int si = blk.x, sj = blk.y;
     const int tile_m = si * GI_BR + (local >> 3), tile_n = sj * GI_BC + (local & 7);
     if (tile_m >= p.tiles_m || tile_n >= p.tiles_n || tile_n < p.tn_lo || tile_n > p.tn_hi) return;
@@ -817,7 +819,7 @@ int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X,
     a.gpitch = 3ll * kp * 16; a.kp = kp; a.H = (int)H; a.P = (int)P; a.fpu = sim_frames_per_unit(P);
     a.X = X; a.zrow = (int64_t)dlc::align_up((size_t)(N * P), 16); a.nbp = nbp; a.keys = keys; a.abi = abi; a.acand = acand;
     a.nfp = sim_col_frames(N, P); a.rp = sim_argmin_pitch(N, P); a.nrows = N * P; a.nframes = N;
-    a.tn_lo = 0; a.tn_hi = 0x7fffffff; a.fj_base = 0;
+    a.tn_lo = 0; a.tn_hi = 0x7fffffff; a.fj_base = 0; a.strip_cols = 0; a.sj_lo = 0;
     a.tiles_m = (int)dlc::cdiv((N - 1) * P, (int64_t)GI_T);              // the last frame's patches have no later frame
     a.tiles_n = (int)sim_col_tiles(N, P);
     if (a.tiles_m < 1) return DLC_OK;
@@ -854,21 +856,10 @@ int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X,
 // ---- a strip of the triangle: the column frames f_first .. f_last against every older row patch ----------------------
 // (the streaming form's batches: the frames of a batch are the strip's columns, the resident panel its rows -- the SAME
 // kernel, so a batch of 32 frames costs its share of the matrix call instead of 16 passes over the panel.)
-// blk: every block row against the block columns sj_lo .. sj_hi.  One workgroup of 256 threads.
-__global__ void gram_strip_blocks_kernel(int nsm, int sj_lo, int sj_hi, int2* blk) {
-    const int ncol = sj_hi - sj_lo + 1;
-    for (int e = threadIdx.x; e < nsm * ncol; e += blockDim.x) blk[e] = make_int2(e / ncol, sj_lo + e % ncol);
-}
-
-// frames of the strip's abi / acand (whole block columns) and the bytes of its block table
+// frames of the strip's abi / acand (whole block columns)
 int64_t gram_strip_frames(int64_t f_first, int64_t f_last, int64_t P) {
     const int64_t fpb = (int64_t)GI_BC * 2 * sim_frames_per_unit(P);     // frames per block column
     return (f_last / fpb - f_first / fpb + 1) * fpb;
-}
-size_t gram_strip_blocks_bytes(int64_t f_first, int64_t f_last, int64_t P) {
-    const int64_t fpb = (int64_t)GI_BC * 2 * sim_frames_per_unit(P);
-    const int64_t nsm = dlc::cdiv(dlc::cdiv(f_last * P, (int64_t)GI_T), (int64_t)GI_BR);
-    return (size_t)std::max<int64_t>(nsm, 1) * (size_t)(f_last / fpb - f_first / fpb + 1) * 8;
 }
 
 // X: a panel whose rows are frame-major patches (frame f's patch p = row f P + p) with an all-zero group at row `zrow`,
@@ -876,7 +867,7 @@ size_t gram_strip_blocks_bytes(int64_t f_first, int64_t f_last, int64_t P) {
 // row patch a) is row fj - *fj_base_out.  Written: f_first <= fj <= f_last (and the other frames of their tiles), a < fj P.
 int gram_argmin_i8_strip(dlc_ctx* ctx, int64_t f_first, int64_t f_last, int64_t P, int64_t H, const char* X, int64_t zrow,
                          const int* nbp, const unsigned long long* keys, unsigned char* abi, unsigned* acand, int64_t rp,
-                         int64_t* fj_base_out, void* blocks, hipStream_t st) {
+                         int64_t* fj_base_out, hipStream_t st) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     const int64_t N = f_last + 1;
     GramI8Args a;
@@ -893,9 +884,7 @@ int gram_argmin_i8_strip(dlc_ctx* ctx, int64_t f_first, int64_t f_last, int64_t 
     a.nsm = (a.tiles_m + GI_BR - 1) / GI_BR;
     a.nsn = (a.tiles_n + GI_BC - 1) / GI_BC;
     a.nsup = a.nsm * (sj_hi - sj_lo + 1);
-    a.blk = (const int2*)blocks;
-    hipLaunchKernelGGL(gram_strip_blocks_kernel, dim3(1), dim3(256), 0, st, a.nsm, sj_lo, sj_hi, (int2*)blocks);
-    DLC_LAUNCH_CHECK(ctx, "gram_strip_blocks_kernel");
+    a.blk = nullptr; a.strip_cols = sj_hi - sj_lo + 1; a.sj_lo = sj_lo;
     const size_t lds = (size_t)GI_NSTAGE * GI_STAGE;
     if (!(ctx->func_attr_set & (1ull << DLC_ATTR_GRAM_I8))) {
         DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gram_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1456,10 +1456,10 @@ extern "C" int dlc_sdav_stream_append(dlc_ctx* ctx, void* state, size_t state_by
                                          g_first, g_last - g_first, P, (int*)(ws + w.nbp), (hipStream_t)stream);
 }
 
-// A batch's workspace: the arg-mins [nq, pitch] | the strip's verdicts abi [frames, pitch] and acand [frames, pitch] | its block
-// table.  frames: the whole block columns a batch of nq frames can touch, wherever it starts.
+// A batch's workspace: the arg-mins [nq, pitch] | the strip's verdicts abi [frames, pitch] and acand [frames, pitch].
+// frames: the whole block columns a batch of nq frames can touch, wherever it starts.
 struct BatchWs {
-    size_t bi, abi, acand, blk, total;
+    size_t bi, abi, acand, total;
     long long pitch;
 };
 constexpr int64_t STRIP_MIN_QUERIES = 8;                      // smaller batches: two query frames per pass over the panel
@@ -1468,12 +1468,11 @@ static BatchWs batch_ws(int64_t capacity, int64_t P, int64_t nq) {
     w.pitch = (long long)dlc::align_up((size_t)capacity * (size_t)P, 256);
     size_t o = 0;
     w.bi = o; o += (size_t)nq * (size_t)w.pitch;
-    w.abi = w.acand = w.blk = o;
+    w.abi = w.acand = o;
     if (nq >= STRIP_MIN_QUERIES) {
         const int64_t frames = dlc_gemm::gram_strip_frames(0, nq - 1, P) + dlc_gemm::gram_strip_frames(0, 0, P);
         w.abi = o; o += (size_t)frames * (size_t)w.pitch;
         w.acand = o; o += (size_t)frames * (size_t)w.pitch * 4;
-        w.blk = o; o += dlc::align_up(dlc_gemm::gram_strip_blocks_bytes(0, capacity - 1, P), 256);   // (every block column: an upper bound)
     }
     w.total = o;
     return w;
@@ -1503,7 +1502,7 @@ static int stream_query_impl(dlc_ctx* ctx, const char* what, void* state, size_t
         unsigned* acand = (unsigned*)(batch_base + bw->acand);
         int64_t fj_base = 0;
         int rc = dlc_gemm::gram_argmin_i8_strip(ctx, f, f_last, P, H, (const char*)(ws + w.panel), w.zrow, (const int*)(ws + w.nbp), keys,
-                                                abi, acand, bw->pitch, &fj_base, batch_base + bw->blk, st);
+                                                abi, acand, bw->pitch, &fj_base, st);
         if (rc != DLC_OK) return rc;
         hipLaunchKernelGGL(strip_resolve_kernel, dim3((unsigned)dlc::cdiv(f_last * P, (int64_t)256), (unsigned)nq), dim3(256), PF_STACK_BYTES,
                            st, desc, (const unsigned char*)abi, (const unsigned*)acand, (long long)bw->pitch, (long long)fj_base,
