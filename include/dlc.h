@@ -441,7 +441,9 @@ int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* src, int64_t 
  * Plans (picked from the shape; the workspace size reflects them): one score pass for databases of
  * >= 256 tiles of 256 rows; split-K partial score tiles + a reducing pass (chunks summed in fp64)
  * for few rows with long descriptors; for <= 32 queries with long rows the re-score is spread over
- * one workgroup per selected group and merged.  Results are identical across plans.
+ * one workgroup per selected group and merged; against <= 16384 rows (k <= 35) one selection launch
+ * sums the partial scores, picks the candidate ROWS, re-scores and certifies (and runs the exhaustive
+ * pass of its own uncertified queries).  Results are identical across plans.
  */
 #define DLC_MAX_K 128
 size_t dlc_cosine_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int k);
