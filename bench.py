@@ -367,6 +367,12 @@ def bench_paths(eng, n_frames):
         outs = [det.query_and_insert(xs_l[lo:lo + bl]) for lo in range(0, N, bl)]
         return det, torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     lc_ms, _, _, (det, ls, li) = _timed_path(eng, stream)
+
+    def stream_single():                                          # the robot's case: frames arrive one at a time
+        det_ = dlc.LoopClosureDetector(Dl, k=kl, threshold=0.5, exclusion=excl, capacity=max(64, N))
+        outs_ = [det_.query_and_insert(xs_l[lo:lo + 1]) for lo in range(N)]
+        return torch.cat([o[1] for o in outs_])
+    lc1_ms, _, _, li1 = _timed_path(eng, stream_single, reps=2)
     nl = min(N, 200)
     rows_l = det.db.rows[:nl].float().cpu().numpy().astype(np.float64)
     t0 = time.perf_counter()
@@ -379,12 +385,14 @@ def bench_paths(eng, n_frames):
                 "dtype": "bf16", "k": kl, "value": N / (lc_ms * 1e-3), "unit": "frames/s", "ms": lc_ms,
                 "roofline": {"bound": "hbm", "achieved": lc_bytes / (lc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": lc_bytes / (lc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "per batch: l2_normalize into the store + one age-limited top-k match (dlc_cosine_topk_older: split-K score pass, group maxima, selection + fp64 re-score, early-exit launch) -- %d batches of five launches of 4-18 us each: latency-bound at this database size" % (-(-N // bl)),
+                             "kernel": "per batch: l2_normalize into the store + one age-limited top-k match (dlc_cosine_topk_older: the split-K score pass, then small_topk_kernel -- partial sums, row selection, fp64 re-score, certificate) -- %d batches of three launches of 6-15 us each: latency-bound at this database size" % (-(-N // bl)),
                              "kernel_ms": lc_ms, "call_ms": lc_ms, "algorithmic_bytes_per_call": lc_bytes},
                 "cpu_baseline": {"value": nl / t_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/loop_closure.py per-frame fp64 loop over the first %d stored rows: %.2f s" % (nl, t_cpu)},
-                "index_agreement_vs_oracle": lc_agree})
-    del xs_l, det, ls, li
+                "index_agreement_vs_oracle": lc_agree,
+                "one_frame_at_a_time": {"ms": lc1_ms, "us_per_frame": lc1_ms * 1e3 / N, "frames_per_s": N / (lc1_ms * 1e-3),
+                                        "same_lists_as_batched": bool(torch.equal(li1, li))}})
+    del xs_l, det, ls, li, li1
 
     # ---- M1/M2: SDAV similarity matrix (SimilarityCalculator.py:12-49 + create_similarity_matrix.py:29-38) ----
     desc = h.reshape(N, P, H)
@@ -459,6 +467,12 @@ def bench_paths(eng, n_frames):
         return det_, torch.cat([o[0] for o in outs_]), torch.cat([o[1] for o in outs_])
     score_s = eng.distinctive_score(desc, 0.5, 0.2)
     ss_ms, _, _, (sdet, sds, sdi) = _timed_path(eng, sdav_stream, reps=2)
+
+    def sdav_stream_single():                                     # one frame at a time: the single-query kernels
+        det_ = dlc.SdavLoopClosureDetector(score_s, patches=P, width=H, k=sk, exclusion=sex, capacity=N)
+        outs_ = [det_.query_and_insert(desc[lo:lo + 1]) for lo in range(N)]
+        return torch.cat([o[1] for o in outs_])
+    ss1_ms, _, _, sdi1 = _timed_path(eng, sdav_stream_single, reps=1)
     # every row of the stream is the matrix call's column: the detector's ranking of it against a stable sort of that column
     mcol = eng.sdav_similarity_matrix(desc, score_s, 10.0, -10.0, want_int64=False)[0].cpu().numpy()
     agree, checked = 0, 0
@@ -494,8 +508,10 @@ def bench_paths(eng, n_frames):
                                  "sample": "oracle/similarity.py similarity_score terms for every frame of the first %d against its older "
                                            "frames (%d pairs): %.2f s" % (nsm, nsm * (nsm - 1) // 2, t_cpu)},
                 "ranking_equals_matrix_columns": agree == checked, "frames_checked": checked,
-                "stream_poisoned": int(sdet.stream.stats[1])})
-    del sdet, sds, sdi, mcol, dsm
+                "stream_poisoned": int(sdet.stream.stats[1]),
+                "one_frame_at_a_time": {"ms": ss1_ms, "us_per_frame": ss1_ms * 1e3 / N, "frames_per_s": N / (ss1_ms * 1e-3),
+                                        "same_lists_as_batched": bool(torch.equal(sdi1, sdi))}})
+    del sdet, sds, sdi, sdi1, mcol, dsm
 
     # ---- M1/M2 on real-image statistics: the repo's 20 real frames (tests/golden) tiled to N, through the GPU front-end and
     # SDAV.transform with the reference's N(0,1) initialiser (real images saturate it) and with 1/sqrt(fan_in) weights
