@@ -1730,8 +1730,12 @@ inline bool gemv_shape(int64_t q, int64_t nk) {
 // (24 rows per query at k = 20 instead of 192).
 constexpr int64_t DENSE_MAX_ROWS = 16384;
 constexpr int DENSE_ROW_SLACK = 4;
+// (a handful of queries otherwise take the bandwidth kernel and the hierarchical selection: right for a database that
+// has to be streamed from HBM, three dependent launches of 13 + 29 + 5 us for a frame against 1000 resident key-frames --
+// up to DENSE_GEMV_BYTES of database they take this plan too: 11 + 9 us)
+constexpr int64_t DENSE_GEMV_BYTES = 32ll << 20;
 inline bool dense_plan(int64_t q, int64_t n, int64_t d) {
-    return n <= DENSE_MAX_ROWS && !gemv_shape(q, d / BK);
+    return n <= DENSE_MAX_ROWS && (!gemv_shape(q, d / BK) || n * d * 2 <= DENSE_GEMV_BYTES);
 }
 
 // One workgroup per query gathers kg * 8 rows: with a handful of queries and long rows (1 query x

@@ -441,7 +441,8 @@ int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* src, int64_t 
  * Plans (picked from the shape; the workspace size reflects them): one score pass for databases of
  * >= 256 tiles of 256 rows; split-K partial score tiles + a reducing pass (chunks summed in fp64)
  * for few rows with long descriptors; for <= 32 queries with long rows the re-score is spread over
- * one workgroup per selected group and merged; against <= 16384 rows (k <= 35) one selection launch
+ * one workgroup per selected group and merged; against <= 16384 rows (k <= 35; with <= 4 queries: up to
+ * 32 MB of database, beyond that the bandwidth kernel streams it) one selection launch
  * sums the partial scores, picks the candidate ROWS, re-scores and certifies (and runs the exhaustive
  * pass of its own uncertified queries).  Results are identical across plans.
  */
