@@ -559,16 +559,17 @@ __device__ __forceinline__ dd_t dd_add(dd_t x, dd_t y) {
 //   QUANT (the filter): sum |v| (its largest value into keys[3], an ordered key), |v|^2, and the three signed digits of
 //   the 24-bit fixed-point value, 16 bytes of each per lane at lane * 16 of that (group, slice, k-step) block -- 1 KiB per
 //   store instruction.  Rows past the last one and k >= H are zeros there and take no part in the sums.
+constexpr int SR_WAVES = 8;                // waves of a workgroup: the k-steps of a group's 16 rows are dealt round them
 template <bool QUANT>
-__global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict__ desc, long long rows, int H, int kp,
+__global__ __launch_bounds__(64 * SR_WAVES) void sim_rows_kernel(const double* __restrict__ desc, long long rows, int H, int kp,
                                                        const double* __restrict__ score, unsigned long long* keys,
                                                        const double* __restrict__ cc,
                                                        char* __restrict__ X, double* __restrict__ nrm2,
                                                        double* __restrict__ nu2, double* __restrict__ proj,
                                                        unsigned long long* __restrict__ rowhash, long long g0, int P, int fpu,
                                                        int* __restrict__ nbp) {
-    __shared__ double red[4][16][5];
-    __shared__ unsigned long long redh[4][16][2];
+    __shared__ double red[SR_WAVES][16][5];
+    __shared__ unsigned long long redh[SR_WAVES][16][2];
     unsigned long long h1 = 0, h2 = 0;
     const long long g = g0 + blockIdx.x;          // (g0 > 0: the groups a stream's new frames touch)
     bool outside = false;                         // a value outside the digits' range: only possible with a FIXED range (streams)
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
     char* xg = X + g * (3ll * nks * 1024) + lane * 16;
     double n2 = 0.0, su = 0.0, s2 = 0.0;
     dd_t pr = {0.0, 0.0};
-    for (int ks = w; ks < nks; ks += 4) {
+    for (int ks = w; ks < nks; ks += SR_WAVES) {
         const int k0 = ks * 64 + chunk * 16;
         unsigned w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0}, w3[4] = {0, 0, 0, 0};
         auto put = [&](int e, double v, double sc, double c) {
@@ -651,11 +652,15 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
     if (w == 0 && chunk == 0 && row_ok) {
         double t[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) t[c] = ((red[0][rr][c] + red[1][rr][c]) + red[2][rr][c]) + red[3][rr][c];
+        for (int c = 0; c < 4; ++c) {
+            t[c] = red[0][rr][c];
+#pragma unroll
+            for (int ww = 1; ww < SR_WAVES; ++ww) t[c] += red[ww][rr][c];
+        }
         if (nrm2) nrm2[r] = t[0];
         dd_t pt = {red[0][rr][1], red[0][rr][4]};
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) { const dd_t o = {red[ww][rr][1], red[ww][rr][4]}; pt = dd_add(pt, o); }
+        for (int ww = 1; ww < SR_WAVES; ++ww) { const dd_t o = {red[ww][rr][1], red[ww][rr][4]}; pt = dd_add(pt, o); }
         {                                                                // normalised: hi = the sum rounded to fp64, lo = the rest
 #pragma clang fp contract(off)
             const double hi = pt.hi + pt.lo;
@@ -668,8 +673,11 @@ __global__ __launch_bounds__(256) void sim_rows_kernel(const double* __restrict_
             if (nbp) { const long long f = r / P; nbp[(f / fpu) * 64 + (f % fpu) * P + (r - f * P)] = (int)llrint(t[3] * 32768.0); }
         }
         if (rowhash) {
-            rowhash[2 * r] = redh[0][rr][0] + redh[1][rr][0] + redh[2][rr][0] + redh[3][rr][0];
-            rowhash[2 * r + 1] = redh[0][rr][1] + redh[1][rr][1] + redh[2][rr][1] + redh[3][rr][1];
+            unsigned long long ha = 0, hb = 0;
+#pragma unroll
+            for (int ww = 0; ww < SR_WAVES; ++ww) { ha += redh[ww][rr][0]; hb += redh[ww][rr][1]; }
+            rowhash[2 * r] = ha;
+            rowhash[2 * r + 1] = hb;
         }
     }
 }
@@ -751,7 +759,7 @@ int sim_filter_prepare(dlc_ctx* ctx, const double* desc, int64_t N, int64_t P, i
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, keys + 5);
     DLC_LAUNCH_CHECK(ctx, "sim_keys_init_kernel");
     DLC_HIP_CHECK(ctx, hipMemsetAsync(nbp, 0, (size_t)sim_col_rows(N, P) * 4, st));
-    hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(256), 0, st, desc, (long long)rows,
+    hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)(sim_panel_rows(rows) / 16)), dim3(64 * SR_WAVES), 0, st, desc, (long long)rows,
                        (int)H, kp, score, keys, (const double*)cc, X, (double*)nullptr, nu2, proj, rowhash, 0ll, (int)P,
                        sim_frames_per_unit(P), nbp);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
@@ -784,7 +792,7 @@ int sim_stream_quantise(dlc_ctx* ctx, const double* desc, int64_t rows_total, in
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     if (g_count < 1) return DLC_OK;
     // nbp: |v|^2 of every patch in the product kernel's unit layout (the batched query's strip takes the patches as columns)
-    hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)g_count), dim3(256), 0, st, desc, (long long)rows_total, (int)H, kp, score,
+    hipLaunchKernelGGL(sim_rows_kernel<true>, dim3((unsigned)g_count), dim3(64 * SR_WAVES), 0, st, desc, (long long)rows_total, (int)H, kp, score,
                        keys, cc, X, (double*)nullptr, nu2, proj, rowhash, (long long)g_first, (int)P, sim_frames_per_unit(P), nbp);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
     return DLC_OK;
@@ -803,7 +811,7 @@ size_t sim_pairwise_program_bytes(int64_t H) { return dlc::align_up((size_t)(H /
 int sim_row_sums(dlc_ctx* ctx, const double* desc, int64_t rows, int64_t H, const double* score, double* nrm2, double* proj,
                  unsigned long long* rowhash, void* prog, unsigned long long* prog_len, hipStream_t st) {
     hipLaunchKernelGGL(sim_pairwise_program_kernel, dim3(1), dim3(64), 0, st, (int)H, (int2*)prog, prog_len);
-    hipLaunchKernelGGL(sim_rows_kernel<false>, dim3((unsigned)dlc::cdiv(rows, (int64_t)16)), dim3(256), 0, st, desc, (long long)rows,
+    hipLaunchKernelGGL(sim_rows_kernel<false>, dim3((unsigned)dlc::cdiv(rows, (int64_t)16)), dim3(64 * SR_WAVES), 0, st, desc, (long long)rows,
                        (int)H, 0, score, (unsigned long long*)nullptr, (const double*)nullptr, (char*)nullptr, nrm2, (double*)nullptr, proj,
                        rowhash, 0ll, 1, 1, (int*)nullptr);
     DLC_LAUNCH_CHECK(ctx, "sim_rows_kernel");
