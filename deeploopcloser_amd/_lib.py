@@ -16,7 +16,7 @@ DLC_BF16, DLC_F16, DLC_F32, DLC_F64, DLC_I8 = 0, 1, 2, 3, 4
 DLC_ACT_NONE, DLC_ACT_SIGMOID, DLC_ACT_RELU = 0, 1, 2
 DLC_B_KN, DLC_B_NK = 0, 1
 DLC_MAX_K = 128
-DLC_ABI_VERSION = 7          # include/dlc.h; load() refuses a library built from another header
+DLC_ABI_VERSION = 8          # include/dlc.h; load() refuses a library built from another header
 DLC_SELECT_COOP = 1
 DLC_SIM_FORCE_F64, DLC_SIM_NO_HOST_SYNC = 1, 2
 
@@ -61,7 +61,7 @@ SIGNATURES = {
     "dlc_sdav_similarity_workspace_bytes": (_sz, [_i64, _i64, _i64, _int, _i64]),
     "dlc_sdav_similarity_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _int, _i64, _vp, _vp, _vp,
                                          _vp, _sz, _vp]),
-    "dlc_topk_rows_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
+    "dlc_topk_rows_f64": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
     "dlc_sdav_stream_state_bytes": (_sz, [_i64, _i64, _i64]),
     "dlc_sdav_stream_init": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _dbl, _dbl, _vp, _vp]),
     "dlc_sdav_stream_append": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
@@ -72,22 +72,25 @@ SIGNATURES = {
     "dlc_cnnvtl_distance_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dlc_l2_normalize_rows": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
     "dlc_cosine_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
-    "dlc_cosine_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp, _sz,
+    "dlc_cosine_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                               _vp]),
+    "dlc_max_row_norm": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "dlc_cosine_tau_scale": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "dlc_cosine_topk_older": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
-                                    _sz, _vp]),
+                                    _vp, _sz, _vp]),
     "dlc_cosine_score_error_bound": (_dbl, [_i64, _i64, _i64, _int]),
+    "dlc_cosine_score_error_bound_any_plan": (_dbl, [_i64]),
     "dlc_cosine_score_groups": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _vp, _sz, _vp]),
-    "dlc_cosine_select_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp,
+    "dlc_cosine_select_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _sz, _int, _vp]),
     "dlc_cosine_groups_per_query": (_int, [_int]),
     "dlc_cosine_select_groups": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _vp, _sz, _vp, _vp, _int,
                                        _vp]),
     "dlc_cosine_rescore_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp, _int,
-                                      _vp, _vp, _vp, _int, _vp]),
+                                      _vp, _vp, _vp, _vp, _int, _vp]),
     "dlc_cosine_exhaustive_topk": (_int, [_vp, _int, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _int, _i64, _vp, _i64, _dbl,
-                                         _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "dlc_topk_merge_strided": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _i64, _int, _vp, _dbl, _vp, _vp, _vp, _vp, _vp]),
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dlc_topk_merge_strided": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _i64, _int, _vp, _dbl, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dlc_topk_merge": (_int, [_vp, _vp, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp]),
     "dlc_topk_keep_older": (_int, [_vp, _vp, _vp, _i64, _int, _i64, _int, _vp, _vp, _vp]),
     "dlc_cosine_scores_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -732,6 +732,13 @@ __device__ __forceinline__ double rescore1_f64(const char* qrow, const char* row
 //                  maxima anywhere is out.  Each shard then re-scores ~kg/parts groups per query instead of kg, and
 //                  writes to bound_out[q] the largest fp32 score a row outside the surviving groups of ALL shards
 //                  can have (the same value on every shard): the merge certifies against it.
+// tau of query qi: the plan's bound for operands of norm <= 1.005, times the query's scale where the caller supplied one
+// (dlc_cosine_tau_scale).  tau = +inf is legal everywhere below: nothing is pruned, nothing certifies, the exhaustive
+// pass takes every group.
+__device__ __forceinline__ double scaled_tau(double tau, const float* __restrict__ tau_scale, int qi) {
+    return tau_scale ? tau * (double)tau_scale[qi] : tau;
+}
+
 enum { FIN_FUSED = 0, FIN_GROUPS = 1, FIN_RESCORE = 2 };
 struct FinishArgs {
     float* tmax; long long ldt; int nh; int tv_in_lds;
@@ -743,7 +750,9 @@ struct FinishArgs {
     double* out_s64;              // [q, k] fp64, never null inside the kernels (the workspace lends one)
     long long* out_i;             // [q, k]
     int* status;                  // FIN_FUSED: [q] 0 = certified, 1 = the exhaustive pass has to run
-    double tau;                   // error bound of the score pass's fp32 scores against the fp64 re-score
+    double tau;                   // error bound of the score pass's fp32 scores against the fp64 re-score (rows of norm <= 1.005)
+    const float* tau_scale;       // [q] or null: query qi certifies with tau * tau_scale[qi] (dlc_cosine_tau_scale: operands
+                                  // of any norm; inf = certify nothing, the exhaustive pass decides)
     int* grp_ids;                 // [q, kg]
     float* grp_max;               // [q, kg + 1]
     const float* all_max;         // [parts, q, kg + 1] or null
@@ -773,6 +782,7 @@ __device__ __forceinline__ void finish_topk_body(const FinishArgs& a) {
     constexpr int FIN_THREADS = THREADS;      // shadows the namespace constant inside this kernel
     constexpr int GPH = GROUPS_PER_HALF;
     const int kg = a.kg, k = a.k;
+    const double tau = scaled_tau(a.tau, a.tau_scale, (int)blockIdx.x);
     const long long n = visible_rows(a.n, a.limited, a.limit0, (int)blockIdx.x);
     const long long ng = a.limited ? (n + GROUP - 1) / GROUP : a.ng;
     if (n <= 0) {                                               // (only with a limit) nothing this query may see: an empty list
@@ -931,7 +941,7 @@ __device__ __forceinline__ void finish_topk_body(const FinishArgs& a) {
         // number, and "k groups hold a row the query may see with a score >= u'" no longer holds: nothing is pruned then)
         if (tid >= k && g >= 0 && sel2[k - 1] >= 0 && !(a.limited && !a.dense_S)) {
             const double uk = (double)key_f32((unsigned)(ckey[sel2[k - 1]] >> 32));
-            if ((double)key_f32((unsigned)(ckey[c] >> 32)) < uk - 2.0 * a.tau) g = -2;          // pruned (after the reads below)
+            if ((double)key_f32((unsigned)(ckey[c] >> 32)) < uk - 2.0 * tau) g = -2;          // pruned (after the reads below)
         }
         misc[9] = 0u;                                       // (benign: every writer stores the same value)
         crow[tid] = g;                                      // staged: sel2 / ckey are still being read by the other threads
@@ -1081,7 +1091,7 @@ __device__ __forceinline__ void finish_topk_body(const FinishArgs& a) {
         // certified: nothing was left behind, or the k-th fp64 score clears everything left behind by more than tau
         if (tid == 0) {
             const int c = sel[k - 1];
-            const bool cert = bkey == 0u || (c >= 0 && cs64[c] > (double)key_f32(bkey) + a.tau);
+            const bool cert = bkey == 0u || (c >= 0 && cs64[c] > (double)key_f32(bkey) + tau);
             a.status[qi] = cert ? 0 : 1;
         }
     }
@@ -1093,8 +1103,9 @@ __global__ __launch_bounds__(THREADS) void finish_topk_kernel(FinishArgs a) {
     finish_topk_body<Tag, THREADS, RS_UNROLL, MODE>(a);
 }
 // The 256-thread forms are meant to sit beside a resident score-GEMM workgroup: its two waves per SIMD hold 2 x 200 of the
-// SIMD's 512 registers, which leaves 112 for this kernel's one wave -- capped at 104 here.  (r03 capped it through
-// amdgpu_waves_per_eu(5) = 96 registers, which the re-score form of the sharded protocol missed by two: it spilled.)
+// SIMD's 512 registers, which leaves 112 for this kernel's one wave.  The cap is amdgpu_waves_per_eu(5) = 96 registers;
+// the three forms take 95 / 52 / 94 and no scratch (r03's re-score form missed 96 by two and spilled; its row pointers now
+// live in scalar registers).  `make` fails if any kernel of the library has a private segment: csrc/check_scratch.py.
 template <typename Tag, int RS_UNROLL, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void finish_topk_coop_kernel(FinishArgs a) {
     finish_topk_body<Tag, 256, RS_UNROLL, MODE>(a);
@@ -1114,6 +1125,7 @@ struct ExhaustiveArgs {
     float* out_s; double* out_s64; long long* out_i;     // [q, k]; out_s / out_s64 may be null
     int* status;
     double tau;
+    const float* tau_scale;                                  // as in FinishArgs
     int limited; long long limit0;                           // as in FinishArgs
 };
 constexpr int EXH_BATCH = 64;                               // groups per re-score batch
@@ -1133,7 +1145,8 @@ __device__ __forceinline__ void exhaustive_topk_body(const ExhaustiveArgs& a, do
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, k = a.k;
     const long long n_vis = visible_rows(a.n, a.limited, a.limit0, qi);
     const long long ng_vis = a.limited ? (n_vis + GROUP - 1) / GROUP : a.ng;
-    double theta = lower - a.tau;                                        // -inf - tau = -inf: everything qualifies
+    const double tau = scaled_tau(a.tau, a.tau_scale, qi);
+    double theta = lower - tau;                                          // -inf - tau = -inf: everything qualifies
     int cnt = 0;                                                         // rows in the running top-k (pool[0 .. cnt))
     const char* qrow = a.Q + (long long)qi * a.ldq_b;
     for (long long c0 = 0; c0 < ng_vis; c0 += FIN_THREADS) {
@@ -1184,7 +1197,7 @@ __device__ __forceinline__ void exhaustive_topk_body(const ExhaustiveArgs& a, do
 #pragma unroll
             for (int ww = 0; ww < FIN_THREADS / 64; ++ww) cnt += wcnt[ww];
             __syncthreads();
-            if (cnt == k && ps[k - 1] - a.tau > theta) theta = ps[k - 1] - a.tau;
+            if (cnt == k && ps[k - 1] - tau > theta) theta = ps[k - 1] - tau;
         }
         __syncthreads();
     }
@@ -1219,6 +1232,7 @@ struct SmallArgs {
     const char* Q; long long ldq_b; const char* DB; long long lddb_b;
     long long n; int d; int k; int m3max; long long row_offset;
     float* out_s; double* out_s64; long long* out_i; int* status; double tau;
+    const float* tau_scale;                                   // as in FinishArgs
     int limited; long long limit0;
 };
 constexpr int SMALL_KT_MAX = 40;
@@ -1390,7 +1404,7 @@ __global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
     // every thread reads the same LDS words).  Otherwise this workgroup runs the exhaustive pass itself.
     const int ck = sel[k - 1];
     const double kth = ck >= 0 ? cs64[ck] : -INFINITY;
-    const bool cert = bkey == 0u || (ck >= 0 && kth > (double)key_f32(bkey) + a.tau);
+    const bool cert = bkey == 0u || (ck >= 0 && kth > (double)key_f32(bkey) + scaled_tau(a.tau, a.tau_scale, qi));
     if (cert) {
         if (tid == 0) a.status[qi] = 0;
         return;
@@ -1402,7 +1416,7 @@ __global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
     e.n = a.n; e.d = a.d; e.k = k; e.row_offset = a.row_offset;
     e.lower = nullptr; e.lower_stride = 0;
     e.out_s = a.out_s; e.out_s64 = a.out_s64; e.out_i = a.out_i;
-    e.status = a.status; e.tau = a.tau;
+    e.status = a.status; e.tau = a.tau; e.tau_scale = a.tau_scale;
     e.limited = a.limited; e.limit0 = a.limit0;
     exhaustive_topk_body<Tag>(e, kth);
 }
@@ -1417,6 +1431,7 @@ __global__ __launch_bounds__(FIN_THREADS) void merge_topk_kernel(const double* _
                                                                  const long long* __restrict__ pidx,
                                                                  long long i_stride, int parts, long long nq, int k,
                                                                  const float* __restrict__ bound, double tau,
+                                                                 const float* __restrict__ tau_scale,
                                                                  float* __restrict__ out_s,
                                                                  double* __restrict__ out_s64,
                                                                  long long* __restrict__ out_i,
@@ -1463,7 +1478,7 @@ __global__ __launch_bounds__(FIN_THREADS) void merge_topk_kernel(const double* _
         __syncthreads();
         if (tid == 0) {
             const float b = bound ? bound[qi] : -INFINITY;
-            status[qi] = (b == -INFINITY || (have_kth && kth > (double)b + tau)) ? 0 : 1;
+            status[qi] = (b == -INFINITY || (have_kth && kth > (double)b + scaled_tau(tau, tau_scale, qi))) ? 0 : 1;
         }
     }
 }
@@ -2007,7 +2022,7 @@ int run_exhaustive(dlc_ctx* ctx, int dtype, const FinishArgs& f, int64_t q, cons
     e.n = f.n; e.d = f.d; e.k = f.k; e.row_offset = f.row_offset;
     e.lower = lower; e.lower_stride = lower_stride;
     e.out_s = out_s; e.out_s64 = out_s64; e.out_i = (long long*)out_i;
-    e.status = status; e.tau = f.tau;
+    e.status = status; e.tau = f.tau; e.tau_scale = f.tau_scale;
     e.limited = f.limited; e.limit0 = f.limit0;
     if (dtype == DLC_BF16)
         hipLaunchKernelGGL(exhaustive_topk_kernel<dlc_bf16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, e);
@@ -2018,14 +2033,14 @@ int run_exhaustive(dlc_ctx* ctx, int dtype, const FinishArgs& f, int64_t q, cons
 }
 
 int launch_merge(dlc_ctx* ctx, const double* scores, int64_t score_part_stride, const int64_t* idx, int64_t idx_part_stride,
-                 int parts, int64_t q, int k, const float* bound, double tau, float* out_scores, double* out_scores_f64,
-                 int64_t* out_idx, int* status, hipStream_t st) {
+                 int parts, int64_t q, int k, const float* bound, double tau, const float* tau_scale, float* out_scores,
+                 double* out_scores_f64, int64_t* out_idx, int* status, hipStream_t st) {
     const size_t m = (size_t)parts * k;
     const size_t dsm = m * 24;
     if (dsm > 48 * 1024) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "topk_merge: parts*k=%zu too large (max 2048)", m);
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)q), dim3(FIN_THREADS), dsm, st, scores, (long long)score_part_stride,
-                       (const long long*)idx, (long long)idx_part_stride, parts, (long long)q, k, bound, tau, out_scores,
-                       out_scores_f64, (long long*)out_idx, status);
+                       (const long long*)idx, (long long)idx_part_stride, parts, (long long)q, k, bound, tau, tau_scale,
+                       out_scores, out_scores_f64, (long long*)out_idx, status);
     DLC_LAUNCH_CHECK(ctx, "merge_topk_kernel");
     return DLC_OK;
 }
@@ -2033,10 +2048,10 @@ int launch_merge(dlc_ctx* ctx, const double* scores, int64_t score_part_stride, 
 // Stage 2 of a match from a filled workspace: selection, fp64 re-score, final top-k, certification, exhaustive pass.
 int run_finish(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, int64_t d, int64_t q, int64_t row_offset,
                float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status, void* workspace, int flags,
-               hipStream_t st, int limited = 0, int64_t limit0 = 0, bool direct = false) {
+               const float* tau_scale, hipStream_t st, int limited = 0, int64_t limit0 = 0, bool direct = false) {
     char* ws = (char*)workspace;
     FinishArgs f = finish_args(mc, k, n, d, q, row_offset);
-    f.limited = limited; f.limit0 = limit0;
+    f.limited = limited; f.limit0 = limit0; f.tau_scale = tau_scale;
     int* status = out_status ? out_status : (int*)(ws + mc.w.status);
     double* s64 = out_scores_f64 ? out_scores_f64 : (double*)(ws + mc.w.s64);
     int rc;
@@ -2047,7 +2062,7 @@ int run_finish(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, i
         sa.Q = f.Q; sa.ldq_b = f.ldq_b; sa.DB = f.DB; sa.lddb_b = f.lddb_b;
         sa.n = n; sa.d = (int)d; sa.k = k; sa.m3max = k + DENSE_ROW_SLACK; sa.row_offset = row_offset;
         sa.out_s = out_scores; sa.out_s64 = s64; sa.out_i = (long long*)out_idx; sa.status = status; sa.tau = mc.w.tau;
-        sa.limited = limited; sa.limit0 = limit0;
+        sa.tau_scale = tau_scale; sa.limited = limited; sa.limit0 = limit0;
         if (dtype == DLC_BF16)
             hipLaunchKernelGGL(small_topk_kernel<dlc_bf16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, sa);
         else
@@ -2069,7 +2084,7 @@ int run_finish(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, i
         f.gparts = mc.w.rparts; f.out_s = nullptr; f.out_s64 = ps; f.out_i = (long long*)pi; f.bound_out = pb;
         rc = run_select<FIN_RESCORE>(ctx, dtype, f, q, DLC_SELECT_COOP, st);
         if (rc != DLC_OK) return rc;
-        rc = launch_merge(ctx, ps, q * k, pi, q * k, mc.w.rparts, q, k, pb, mc.w.tau, out_scores, s64, out_idx, status, st);
+        rc = launch_merge(ctx, ps, q * k, pi, q * k, mc.w.rparts, q, k, pb, mc.w.tau, tau_scale, out_scores, s64, out_idx, status, st);
         if (rc != DLC_OK) return rc;
     }
     if (direct) return DLC_OK;                                  // small_topk_kernel runs the exhaustive pass of its own queries
@@ -2085,8 +2100,8 @@ extern "C" double dlc_cosine_score_error_bound(int64_t q, int64_t n, int64_t d, 
 
 extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
                                int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, float* out_scores,
-                               double* out_scores_f64, int64_t* out_idx, int32_t* out_status, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               double* out_scores_f64, int64_t* out_idx, int32_t* out_status, const float* tau_scale,
+                               void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk: null output");
     MatchCall mc;
@@ -2098,13 +2113,13 @@ extern "C" int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q
     rc = run_score(ctx, dtype, mc, (hipStream_t)stream, direct);
     if (rc != DLC_OK) return rc;
     return run_finish(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_scores_f64, out_idx, out_status, workspace, 0,
-                      (hipStream_t)stream, 0, 0, direct);
+                      tau_scale, (hipStream_t)stream, 0, 0, direct);
 }
 
 extern "C" int dlc_cosine_topk_older(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
                                      int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, int64_t limit0,
                                      float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+                                     const float* tau_scale, void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_topk_older: null output");
     MatchCall mc;
@@ -2116,7 +2131,7 @@ extern "C" int dlc_cosine_topk_older(dlc_ctx* ctx, int dtype, const void* Q, int
     rc = run_score(ctx, dtype, mc, (hipStream_t)stream, direct);
     if (rc != DLC_OK) return rc;
     return run_finish(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_scores_f64, out_idx, out_status, workspace, 0,
-                      (hipStream_t)stream, 1, limit0, direct);
+                      tau_scale, (hipStream_t)stream, 1, limit0, direct);
 }
 
 extern "C" int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
@@ -2133,8 +2148,9 @@ extern "C" int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, i
 
 extern "C" int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
                                       int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, float* out_scores,
-                                      double* out_scores_f64, int64_t* out_idx, int32_t* out_status, void* workspace,
-                                      size_t workspace_bytes, int flags, void* stream) {
+                                      double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
+                                      const float* tau_scale, void* workspace, size_t workspace_bytes, int flags,
+                                      void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!out_scores || !out_idx) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_select_topk: null output");
     MatchCall mc;
@@ -2143,7 +2159,7 @@ extern "C" int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, in
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     return run_finish(ctx, dtype, mc, k, n, d, q, row_offset, out_scores, out_scores_f64, out_idx, out_status, workspace, flags,
-                      (hipStream_t)stream);
+                      tau_scale, (hipStream_t)stream);
 }
 
 extern "C" int dlc_cosine_groups_per_query(int k) { return (k < 1 || k > DLC_MAX_K) ? 0 : k + SLACK; }
@@ -2184,8 +2200,8 @@ int operands_only(dlc_ctx* ctx, const char* what, int dtype, const void* Q, int6
 extern "C" int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
                                        int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
                                        const int32_t* group_ids, const float* group_max, const float* all_group_max,
-                                       int parts, double* out_scores_f64, int64_t* out_idx, float* out_bound, int flags,
-                                       void* stream) {
+                                       int parts, double* out_scores_f64, int64_t* out_idx, float* out_bound,
+                                       const float* tau_scale, int flags, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!out_scores_f64 || !out_idx || !group_ids || !group_max || parts < 0 || (parts > 0 && !all_group_max))
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_rescore_topk: bad argument");
@@ -2198,13 +2214,14 @@ extern "C" int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, i
     f.grp_ids = const_cast<int32_t*>(group_ids); f.grp_max = const_cast<float*>(group_max);
     f.all_max = all_group_max; f.parts = parts;
     f.out_s = nullptr; f.out_s64 = out_scores_f64; f.out_i = (long long*)out_idx; f.bound_out = out_bound;
+    f.tau_scale = tau_scale;
     return run_select<FIN_RESCORE>(ctx, dtype, f, q, flags, (hipStream_t)stream);
 }
 
 extern "C" int dlc_cosine_exhaustive_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, const void* DB,
                                           int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
-                                          const double* lower, int64_t lower_stride, double tau, int32_t* status,
-                                          float* out_scores, double* out_scores_f64, int64_t* out_idx, void* workspace,
+                                          const double* lower, int64_t lower_stride, double tau,
+                                          const float* tau_scale, int32_t* status, float* out_scores, double* out_scores_f64, int64_t* out_idx, void* workspace,
                                           size_t workspace_bytes, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!lower || lower_stride < 0 || !status || !out_idx || !(tau >= 0.0))
@@ -2215,7 +2232,7 @@ extern "C" int dlc_cosine_exhaustive_topk(dlc_ctx* ctx, int dtype, const void* Q
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     FinishArgs f = finish_args(mc, k, n, d, q, row_offset);
-    f.tau = tau;
+    f.tau = tau; f.tau_scale = tau_scale;
     return run_exhaustive(ctx, dtype, f, q, lower, lower_stride, out_scores, out_scores_f64, out_idx, status, (hipStream_t)stream);
 }
 
@@ -2263,22 +2280,22 @@ extern "C" int dlc_topk_keep_older(dlc_ctx* ctx, const float* scores, const int6
 
 extern "C" int dlc_topk_merge_strided(dlc_ctx* ctx, const double* scores_f64, int64_t score_part_stride, const int64_t* idx,
                                       int64_t idx_part_stride, int parts, int64_t q, int k, const float* bound, double tau,
-                                      float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
-                                      void* stream) {
+                                      const float* tau_scale, float* out_scores, double* out_scores_f64, int64_t* out_idx,
+                                      int32_t* out_status, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!scores_f64 || !idx || !out_idx || parts < 1 || q < 1 || k < 1 || k > DLC_MAX_K ||
         score_part_stride < q * k || idx_part_stride < q * k || !(tau >= 0.0))
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "topk_merge: bad argument");
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    return launch_merge(ctx, scores_f64, score_part_stride, idx, idx_part_stride, parts, q, k, bound, tau, out_scores,
-                        out_scores_f64, out_idx, out_status, (hipStream_t)stream);
+    return launch_merge(ctx, scores_f64, score_part_stride, idx, idx_part_stride, parts, q, k, bound, tau, tau_scale,
+                        out_scores, out_scores_f64, out_idx, out_status, (hipStream_t)stream);
 }
 
 extern "C" int dlc_topk_merge(dlc_ctx* ctx, const double* scores_f64, const int64_t* idx, int parts, int64_t q, int k,
                               float* out_scores, double* out_scores_f64, int64_t* out_idx, void* stream) {
-    return dlc_topk_merge_strided(ctx, scores_f64, q * k, idx, q * k, parts, q, k, nullptr, 0.0, out_scores, out_scores_f64,
-                                  out_idx, nullptr, stream);
+    return dlc_topk_merge_strided(ctx, scores_f64, q * k, idx, q * k, parts, q, k, nullptr, 0.0, nullptr, out_scores,
+                                  out_scores_f64, out_idx, nullptr, stream);
 }
 
 extern "C" size_t dlc_cosine_scores_workspace_bytes(int64_t q, int64_t n, int64_t d) {
@@ -2354,4 +2371,118 @@ extern "C" int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* sr
 #undef DLC_NORM
     DLC_LAUNCH_CHECK(ctx, "l2_normalize_kernel");
     return DLC_OK;
+}
+
+// ---- operands of any norm: the certificate's tau follows the data --------------------------------------------------------
+// tau of the plans above is stated for |q| |x| <= 1.01 (rows dlc_l2_normalize_rows wrote).  The score pass's error is
+// linear in the product of the norms (every MFMA / v_dot2 step errs by at most eps * (|accumulator| + sum |products|) and
+// partial sums are bounded by |q| |x|), so for other operands query qi certifies with tau * tau_scale[qi],
+// tau_scale[qi] = max(1, |q_qi| * R / 1.01), R >= every database row's norm (of EVERY shard, when sharded).
+namespace {
+// fp32 norm of a stored row, rounded UP (one wave; the sum of squares of a lane's chain + a butterfly errs by < 1e-4
+// relative for rows up to 2^20 elements; 1.001 covers it and the square root); non-finite -> +inf
+template <typename Tag>
+__device__ __forceinline__ float row_norm_up(const char* __restrict__ row, int d, int lane) {
+    float acc = 0.f;
+    for (int c = lane * 8; c < d; c += 512) {
+        const u32x4_t v = *(const u32x4_t*)(row + (long long)c * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float lo, hi;
+            if constexpr (__is_same(Tag, dlc_bf16_tag)) {
+                lo = __uint_as_float(v[j] << 16);
+                hi = __uint_as_float(v[j] & 0xffff0000u);
+            } else {
+                lo = dlc_f16_bits_to_f32((unsigned short)(v[j] & 0xffffu));
+                hi = dlc_f16_bits_to_f32((unsigned short)(v[j] >> 16));
+            }
+            acc = fmaf(lo, lo, acc);
+            acc = fmaf(hi, hi, acc);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    const float nrm = sqrtf(acc) * 1.001f;
+    return (nrm <= 3.0e38f) ? nrm : INFINITY;
+}
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void max_row_norm_kernel(const char* __restrict__ rows, long long ld_b, long long n, int d,
+                                                           float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    float best = 0.f;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (long long)gridDim.x * 4)
+        best = fmaxf(best, row_norm_up<Tag>(rows + r * ld_b, d, lane));
+    // non-negative floats (and +inf) order like their bit patterns
+    if (lane == 0) atomicMax((unsigned*)out, __float_as_uint(best));
+}
+
+template <typename Tag>
+__global__ __launch_bounds__(256) void tau_scale_kernel(const char* __restrict__ Q, long long ldq_b, long long q, int d,
+                                                        const float* __restrict__ db_max_norm, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long qi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= q) return;
+    const float nq = row_norm_up<Tag>(Q + qi * ldq_b, d, lane);
+    const float R = db_max_norm ? *db_max_norm : 1.005f;
+    // 0 * inf (an all-zero query against a poisoned database) must not come out as "certified with tau": NaN -> +inf
+    const float prod = nq * R * (1.0f / 1.01f) * 1.000001f;
+    const float s = (prod <= 3.0e38f) ? fmaxf(prod, 1.0f) : INFINITY;
+    if (lane == 0) out[qi] = s;
+}
+
+int check_rows(dlc_ctx* ctx, const char* what, int dtype, const void* rows, int64_t n, int64_t ld, int64_t d) {
+    if (!ctx) return DLC_ERR_BAD_ARG;
+    if (dtype != DLC_BF16 && dtype != DLC_F16)
+        return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "%s: dtype %d (need DLC_BF16 or DLC_F16)", what, dtype);
+    if (!rows || n < 1 || d < 1) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "%s: null/empty operand", what);
+    if (d % 8 != 0 || ld < d || (ld % 8) || ((uintptr_t)rows & 15))
+        return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "%s: rows must be 16-byte aligned, d and the stride multiples of 8 elements", what);
+    if (d > 0x7ffffff0ll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "%s: d too large", what);
+    return DLC_OK;
+}
+}  // namespace
+
+extern "C" int dlc_max_row_norm(dlc_ctx* ctx, int dtype, const void* rows, int64_t n, int64_t ld, int64_t d,
+                                float* max_norm, void* stream) {
+    int rc = check_rows(ctx, "max_row_norm", dtype, rows, n, ld, d);
+    if (rc != DLC_OK) return rc;
+    if (!max_norm) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "max_row_norm: null output");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    const unsigned grid = (unsigned)std::min<int64_t>(dlc::cdiv(n, 4), 256 * 16);
+    if (dtype == DLC_BF16)
+        hipLaunchKernelGGL(max_row_norm_kernel<dlc_bf16_tag>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)rows,
+                           (long long)ld * 2, (long long)n, (int)d, max_norm);
+    else
+        hipLaunchKernelGGL(max_row_norm_kernel<dlc_f16_tag>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)rows,
+                           (long long)ld * 2, (long long)n, (int)d, max_norm);
+    DLC_LAUNCH_CHECK(ctx, "max_row_norm_kernel");
+    return DLC_OK;
+}
+
+extern "C" int dlc_cosine_tau_scale(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, int64_t d,
+                                    const float* db_max_norm, float* tau_scale, void* stream) {
+    int rc = check_rows(ctx, "cosine_tau_scale", dtype, Q, q, ldq, d);
+    if (rc != DLC_OK) return rc;
+    if (!tau_scale) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "cosine_tau_scale: null output");
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    const unsigned grid = (unsigned)dlc::cdiv(q, 4);
+    if (dtype == DLC_BF16)
+        hipLaunchKernelGGL(tau_scale_kernel<dlc_bf16_tag>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)Q,
+                           (long long)ldq * 2, (long long)q, (int)d, db_max_norm, tau_scale);
+    else
+        hipLaunchKernelGGL(tau_scale_kernel<dlc_f16_tag>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)Q,
+                           (long long)ldq * 2, (long long)q, (int)d, db_max_norm, tau_scale);
+    DLC_LAUNCH_CHECK(ctx, "tau_scale_kernel");
+    return DLC_OK;
+}
+
+extern "C" double dlc_cosine_score_error_bound_any_plan(int64_t d) {
+    if (d < BK) return 0.0;
+    const double nk = (double)(d / BK);
+    // the unsplit MFMA pass (2 k-slices per K tile of 64) or the bandwidth kernel's lane chain: split-K chunks are shorter
+    const double steps = std::max(2.0 * nk + 2.0, nk * 0.5 + 8.0);
+    return SCORE_STEP_EPS * 1.01 * steps + 3.7e-12;
 }

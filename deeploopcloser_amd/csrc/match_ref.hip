@@ -1046,10 +1046,18 @@ __global__ __launch_bounds__(256) void strip_resolve_kernel(const double* __rest
 // "the best entry after the last one taken" -- rows of a few thousand scores, k a handful: microseconds.
 __global__ __launch_bounds__(256) void topk_rows_f64_kernel(const double* __restrict__ scores, long long ld, long long limit0,
                                                             long long limit_step, int k, double* __restrict__ out_s,
-                                                            long long* __restrict__ out_i) {
+                                                            long long* __restrict__ out_i,
+                                                            const long long* __restrict__ poison) {
     __shared__ unsigned long long red_k[4];
     __shared__ long long red_i[4];
     const long long r = blockIdx.x;
+    if (poison && *poison != 0) {                                // the caller's "these scores mean nothing" word: say so in the
+        for (int t = threadIdx.x; t < k; t += 256) {             // output itself (NaN, -1), not with an empty list
+            out_s[r * k + t] = __longlong_as_double(0x7ff8000000000000ll);
+            out_i[r * k + t] = -1;
+        }
+        return;
+    }
     long long n = limit0 + r * limit_step;
     if (n > ld) n = ld;
     const double* row = scores + r * ld;
@@ -1574,14 +1582,14 @@ extern "C" int dlc_sdav_stream_query_batch(dlc_ctx* ctx, void* state, size_t sta
 }
 
 extern "C" int dlc_topk_rows_f64(dlc_ctx* ctx, const double* scores, int64_t rows, int64_t ld, int64_t limit0, int64_t limit_step,
-                                 int k, double* out_scores, int64_t* out_idx, void* stream) {
+                                 int k, double* out_scores, int64_t* out_idx, const int64_t* poison, void* stream) {
     if (!ctx) return DLC_ERR_BAD_ARG;
     if (!scores || !out_scores || !out_idx || rows < 1 || ld < 1 || k < 1 || k > DLC_MAX_K || rows > 0x7fffffffll)
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "topk_rows_f64: bad argument");
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     hipLaunchKernelGGL(topk_rows_f64_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, scores, (long long)ld,
-                       (long long)limit0, (long long)limit_step, k, out_scores, (long long*)out_idx);
+                       (long long)limit0, (long long)limit_step, k, out_scores, (long long*)out_idx, (const long long*)poison);
     DLC_LAUNCH_CHECK(ctx, "topk_rows_f64_kernel");
     return DLC_OK;
 }

@@ -26,6 +26,9 @@ K_STEP = 64   # the score GEMM's K step: stored descriptor rows are padded to a 
 TopK = collections.namedtuple("TopK", "scores idx scores_f64 status")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def torch_dtype(name):
     if isinstance(name, torch.dtype):
         return name
@@ -100,7 +103,9 @@ class Engine:
     def _raw_stream(self):
         """The current stream's handle as an int (torch._C._cuda_getCurrentRawStream: a tenth of the cost of building a
         torch.cuda.Stream object, which three calls per batch of a streaming detector made a quarter of its host time)."""
-        return torch._C._cuda_getCurrentRawStream(self._dev_index)
+        if _RAW_STREAM is not None:
+            return _RAW_STREAM(self._dev_index)
+        return torch.cuda.current_stream(self.device).cuda_stream      # (a torch build without the private fast path)
 
     def _stream(self):
         return C.c_void_p(self._raw_stream())
@@ -614,15 +619,18 @@ class Engine:
                                                           _ptr(stats), _ptr(ws), ws.numel(), self._stream()))
         return out
 
-    def topk_rows_f64(self, scores, limit0, limit_step, k):
+    def topk_rows_f64(self, scores, limit0, limit_step, k, poison=None):
         """(scores [rows, k] fp64, idx [rows, k] int64) of the k best of the first limit0 + r * limit_step entries of row r of
-        scores [rows, ld] (fp64): score descending, ties -> the lower index, NaN never; (-inf, -1) where fewer."""
+        scores [rows, ld] (fp64): score descending, ties -> the lower index, NaN never; (-inf, -1) where fewer.
+        poison: a device int64 [1] read by the kernel; non-zero -> every slot (NaN, -1)."""
         self._check_out("scores", scores, tuple(scores.shape), torch.float64)
+        if poison is not None:
+            self._check_out("poison", poison, (1,), torch.int64)
         rows, ld = scores.shape
         o_s = torch.empty((rows, k), dtype=torch.float64, device=self.device)
         o_i = torch.empty((rows, k), dtype=torch.int64, device=self.device)
         self._check(self.lib.dlc_topk_rows_f64(self.ctx, _ptr(scores), rows, ld, int(limit0), int(limit_step), int(k), _ptr(o_s),
-                                                _ptr(o_i), self._stream()))
+                                                _ptr(o_i), _ptr(poison), self._stream()))
         return o_s, o_i
 
     def cnnvtl_distance_matrix(self, desc, d=None, out=None):
@@ -665,11 +673,50 @@ class Engine:
             out = torch.empty((n, ldd), dtype=dt, device=self.device)
         elif out.shape != (n, ldd) or out.dtype != dt or not out.is_contiguous() or out.device != self.device:
             raise ValueError("normalize: out must be a contiguous [%d, %d] %s tensor on %s" % (n, ldd, dt, self.device))
-        if n == 0:
-            return out
-        self._check(self.lib.dlc_l2_normalize_rows(self.ctx, _TORCH_TO_DLC[x.dtype], _ptr(x), n, d, x.stride(0),
-                                                    1 if center else 0, _TORCH_TO_DLC[dt], _ptr(out), ldd,
-                                                    self._stream()))
+        if n > 0:
+            self._check(self.lib.dlc_l2_normalize_rows(self.ctx, _TORCH_TO_DLC[x.dtype], _ptr(x), n, d, x.stride(0),
+                                                        1 if center else 0, _TORCH_TO_DLC[dt], _ptr(out), ldd,
+                                                        self._stream()))
+        # the mark unit_rows() looks for: THIS tensor object, at this version, holds rows of norm <= 1.005.  A view or a copy
+        # does not carry it and an in-place torch write outdates it -- then the match measures the norms instead of trusting
+        out._dlc_unit_rows = out._version
+        return out
+
+    @staticmethod
+    def unit_rows(t):
+        """True when t is a tensor normalize() wrote and nothing has written to it since: its rows are what the cosine
+        certificate's static tau is derived for (include/dlc.h, NORMS)."""
+        return getattr(t, "_dlc_unit_rows", None) == t._version
+
+    def max_row_norm(self, rows, out=None):
+        """Device float [1]: max(out, the largest L2 norm of the stored rows [n, d]) rounded up (dlc_max_row_norm); out
+        starts at 0 when not given.  What a database of rows normalize() did NOT write owes the certificate."""
+        if rows.dim() != 2 or rows.dtype not in (torch.bfloat16, torch.float16) or rows.stride(1) != 1:
+            raise ValueError("max_row_norm: stored rows [n, d] (bf16 / fp16, contiguous rows)")
+        if out is None:
+            out = torch.zeros((1,), dtype=torch.float32, device=self.device)
+        else:
+            self._check_out("out", out, (1,), torch.float32)
+        if rows.shape[0] > 0:
+            self._check(self.lib.dlc_max_row_norm(self.ctx, _TORCH_TO_DLC[rows.dtype], _ptr(rows), rows.shape[0],
+                                                   rows.stride(0), rows.shape[1], _ptr(out), self._stream()))
+        return out
+
+    def cosine_tau_scale(self, q, db_max_norm=None, out=None, stream=None):
+        """[Q] floats: what query i's certificate multiplies tau by, max(1, |q_i| R / 1.01) with R = db_max_norm (a device
+        float [1] from max_row_norm; None: the database rows are normalize()'s) -- dlc_cosine_tau_scale."""
+        if q.dim() != 2 or q.dtype not in (torch.bfloat16, torch.float16) or q.stride(1) != 1:
+            raise ValueError("cosine_tau_scale: stored queries [Q, d] (bf16 / fp16, contiguous rows)")
+        if out is None:
+            out = torch.empty((q.shape[0],), dtype=torch.float32, device=self.device)
+        else:
+            self._check_out("out", out, (q.shape[0],), torch.float32)
+        if db_max_norm is not None:
+            self._check_out("db_max_norm", db_max_norm, (1,), torch.float32)
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        if q.shape[0] > 0:
+            self._check(self.lib.dlc_cosine_tau_scale(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
+                                                       q.shape[1], _ptr(db_max_norm), _ptr(out), st))
         return out
 
     def _check_stored(self, q, db):
@@ -680,14 +727,18 @@ class Engine:
         if q.stride(1) != 1 or db.stride(1) != 1:
             raise ValueError("stored descriptor rows must be contiguous")
 
-    def match_topk(self, q, db, k, row_offset=0, out=None, details=False, older_than=None):
+    def match_topk(self, q, db, k, row_offset=0, out=None, details=False, older_than=None, tau_scale=None):
         """Top-k cosine match of stored queries q [Q,d] against stored db [N,d].
         Returns (scores [Q,k] float32, idx [Q,k] int64 with row_offset added); with details=True a
         TopK(scores, idx, scores_f64, status): the fp64 scores the order was decided on and, per query,
         0 = certified by the selection, 2 = resolved by the exhaustive pass (include/dlc.h).
-        older_than = L: query i only sees db rows below L + i (dlc_cosine_topk_older; (-inf, -1) where it sees fewer than k)."""
+        older_than = L: query i only sees db rows below L + i (dlc_cosine_topk_older; (-inf, -1) where it sees fewer than k).
+        tau_scale: None states that q and db are normalize()'s rows; otherwise cosine_tau_scale(q, max_row_norm(db))
+        (KeyframeDatabase.match_topk keeps track of that by itself)."""
         self._check_stored(q, db)
         nq, d = q.shape
+        if tau_scale is not None:
+            self._check_out("tau_scale", tau_scale, (nq,), torch.float32)
         n = db.shape[0]
         need = self.lib.dlc_cosine_topk_workspace_bytes(nq, n, d, k)
         if need == 0:
@@ -704,12 +755,12 @@ class Engine:
         if older_than is None:
             self._check(self.lib.dlc_cosine_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
                                                   db.stride(0), d, k, row_offset, _ptr(scores), _ptr(s64), _ptr(idx),
-                                                  _ptr(status), _ptr(ws), ws.numel(), self._stream()))
+                                                  _ptr(status), _ptr(tau_scale), _ptr(ws), ws.numel(), self._stream()))
         else:
             self._check(self.lib.dlc_cosine_topk_older(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db), n,
                                                         db.stride(0), d, k, row_offset, int(older_than), _ptr(scores),
-                                                        _ptr(s64), _ptr(idx), _ptr(status), _ptr(ws), ws.numel(),
-                                                        self._stream()))
+                                                        _ptr(s64), _ptr(idx), _ptr(status), _ptr(tau_scale), _ptr(ws),
+                                                        ws.numel(), self._stream()))
         return TopK(scores, idx, s64, status) if details else (scores, idx)
 
     def topk_workspace_bytes(self, nq, n, d, k):
@@ -722,6 +773,11 @@ class Engine:
         """tau of the plan a [nq, d] x [n, d] top-k match takes: |fp32 score of the score pass - fp64 score| <= tau."""
         return float(self.lib.dlc_cosine_score_error_bound(nq, n, d, k))
 
+    def score_error_bound_any_plan(self, d):
+        """The largest tau any plan has for descriptors of (stored) width d: what a sharded merge certifies with -- the same
+        number on every rank, whatever plan its shard's size picks."""
+        return float(self.lib.dlc_cosine_score_error_bound_any_plan(d))
+
     def score_groups(self, q, db, k, ws, stream=None):
         """Stage 1 of match_topk (the MFMA score GEMM) into the caller's workspace tensor."""
         self._check_stored(q, db)
@@ -731,7 +787,8 @@ class Engine:
                                                       _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, _ptr(ws),
                                                       ws.numel(), st))
 
-    def select_topk(self, q, db, k, ws, scores, idx, row_offset=0, coop=False, stream=None, scores_f64=None, status=None):
+    def select_topk(self, q, db, k, ws, scores, idx, row_offset=0, coop=False, stream=None, scores_f64=None, status=None,
+                    tau_scale=None):
         """Stage 2 of match_topk (selection, fp64 re-score, final top-k, certificate, exhaustive pass) from the workspace."""
         self._check_stored(q, db)
         self._check_ws(ws)
@@ -744,8 +801,9 @@ class Engine:
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         self._check(self.lib.dlc_cosine_select_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
                                                      _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, row_offset,
-                                                     _ptr(scores), _ptr(scores_f64), _ptr(idx), _ptr(status), _ptr(ws),
-                                                     ws.numel(), L.DLC_SELECT_COOP if coop else 0, st))
+                                                     _ptr(scores), _ptr(scores_f64), _ptr(idx), _ptr(status),
+                                                     _ptr(tau_scale), _ptr(ws), ws.numel(),
+                                                     L.DLC_SELECT_COOP if coop else 0, st))
 
     def _check_ws(self, ws):
         if not isinstance(ws, torch.Tensor) or ws.dtype != torch.uint8 or not ws.is_contiguous() or ws.device != self.device:
@@ -772,7 +830,7 @@ class Engine:
                                                        L.DLC_SELECT_COOP if coop else 0, st))
 
     def rescore_topk(self, q, db, k, grp_ids, grp_max, scores_f64, idx, bound=None, all_max=None, row_offset=0, coop=False,
-                     stream=None):
+                     stream=None, tau_scale=None):
         """Stage 2b: fp64 re-score of the listed groups (filtered against all shards' maxima when all_max
         [parts, Q, kg+1] is given): the shard's part of the top-k (fp64 scores, rows) and bound [Q] = the best fp32
         score any row outside the surviving groups of all shards can have."""
@@ -791,9 +849,11 @@ class Engine:
         self._check(self.lib.dlc_cosine_rescore_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), q.shape[0], q.stride(0),
                                                       _ptr(db), db.shape[0], db.stride(0), q.shape[1], k, row_offset,
                                                       _ptr(grp_ids), _ptr(grp_max), _ptr(all_max), parts, _ptr(scores_f64),
-                                                      _ptr(idx), _ptr(bound), L.DLC_SELECT_COOP if coop else 0, st))
+                                                      _ptr(idx), _ptr(bound), _ptr(tau_scale),
+                                                      L.DLC_SELECT_COOP if coop else 0, st))
 
-    def exhaustive_topk(self, q, db, k, ws, lower, tau, status, scores_f64, idx, scores=None, row_offset=0, stream=None):
+    def exhaustive_topk(self, q, db, k, ws, lower, tau, status, scores_f64, idx, scores=None, row_offset=0, stream=None,
+                        tau_scale=None):
         """The exhaustive pass of the sharded protocol for the queries with status == 1: lower [Q] fp64 = the k-th score
         found so far; this shard's exact top-k over every group whose maximum (in `ws`, the workspace of the score
         pass) is >= lower - tau replaces scores_f64 / idx (and scores) of those queries; their status becomes 2."""
@@ -809,10 +869,10 @@ class Engine:
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
         self._check(self.lib.dlc_cosine_exhaustive_topk(self.ctx, _TORCH_TO_DLC[q.dtype], _ptr(q), nq, q.stride(0), _ptr(db),
                                                          db.shape[0], db.stride(0), q.shape[1], k, row_offset, _ptr(lower), 1,
-                                                         float(tau), _ptr(status), _ptr(scores), _ptr(scores_f64), _ptr(idx),
-                                                         _ptr(ws), ws.numel(), st))
+                                                         float(tau), _ptr(tau_scale), _ptr(status), _ptr(scores),
+                                                         _ptr(scores_f64), _ptr(idx), _ptr(ws), ws.numel(), st))
 
-    def topk_merge_packed(self, gathered, nq, k, out, bound=None, tau=0.0, scores_f64=None, status=None):
+    def topk_merge_packed(self, gathered, nq, k, out, bound=None, tau=0.0, scores_f64=None, status=None, tau_scale=None):
         """Merge an all-gather of packed per-shard results: gathered is uint8 [parts, nq*k*16], each part = int64 idx
         [nq,k] followed by float64 scores [nq,k].  With bound [nq] / tau the merge certifies into status [nq]."""
         parts = gathered.shape[0]
@@ -828,7 +888,8 @@ class Engine:
             self._check_out("status", status, (nq,), torch.int32)
         self._check(self.lib.dlc_topk_merge_strided(self.ctx, C.c_void_p(base + nq * k * 8), nq * k * 2,
                                                      C.c_void_p(base), nq * k * 2, parts, nq, k, _ptr(bound), float(tau),
-                                                     _ptr(o_s), _ptr(scores_f64), _ptr(o_i), _ptr(status), self._stream()))
+                                                     _ptr(tau_scale), _ptr(o_s), _ptr(scores_f64), _ptr(o_i), _ptr(status),
+                                                     self._stream()))
         return o_s, o_i
 
     def topk_keep_older(self, scores, idx, limit0, k):

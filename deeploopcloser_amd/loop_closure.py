@@ -130,7 +130,10 @@ class SdavLoopClosureDetector:
 
     def query_and_insert(self, frames):
         """frames [B, P, H] (ids len(self) .. + B - 1) -> (scores [B, k] float64, ids [B, k] int64) on the device, best first,
-        (-inf, -1) where fewer than k frames are old enough; the frames are resident afterwards."""
+        (-inf, -1) where fewer than k frames are old enough; the frames are resident afterwards.  A POISONED stream (a value
+        outside its fixed range or a NaN was appended, now or earlier: `poisoned`, SimilarityStream.stats[1]) returns
+        (NaN, -1) in every slot -- "these scores mean nothing", visible in the tensors themselves without a host read;
+        loops() raises."""
         st = self.stream
         eng = st.engine
         x = eng.to_device(frames, torch.float64)
@@ -139,14 +142,21 @@ class SdavLoopClosureDetector:
         b = x.shape[0]
         first = st.append(x)                                          # all B frames become resident: one quantisation launch
         if first + b - 1 == 0:                                        # the very first frame alone: nothing older
-            return (torch.full((b, self.k), float("-inf"), dtype=torch.float64, device=eng.device),
+            none = torch.full((b, self.k), float("-inf"), dtype=torch.float64, device=eng.device)
+            return (torch.where(self.poisoned != 0, float("nan"), none),
                     torch.full((b, self.k), -1, dtype=torch.int64, device=eng.device))
         # frame first + r against every older frame, all B of them in one pair of launches (dlc_sdav_stream_query_batch):
         # rows[r, :first + r]
         rows = st.query_batch(first, b)
         # the k best of the frames old enough -- one launch for the batch (dlc_topk_rows_f64: score descending, ties ->
-        # the older frame; a poisoned stream's NaN rows yield nothing here and loops() raises)
-        return eng.topk_rows_f64(rows, first - self.exclusion, 1, self.k)
+        # the older frame; the kernel reads the stream's poison word and answers (NaN, -1) everywhere when it is set)
+        return eng.topk_rows_f64(rows, first - self.exclusion, 1, self.k, poison=self.poisoned)
+
+    @property
+    def poisoned(self):
+        """Device int64 [1] (a view of SimilarityStream.stats): non-zero once a descriptor value outside the stream's fixed
+        range (or a NaN / infinity) has been appended.  No host synchronisation to look at it on the device."""
+        return self.stream.stats[1:2]
 
     def _check_poison(self):
         if int(self.stream.stats[1]) != 0:

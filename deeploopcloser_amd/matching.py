@@ -30,19 +30,33 @@ class KeyframeDatabase:
     The rows live in a capacity-reserved buffer so that a running loop-closure session can
     append() key-frames without re-uploading the shard: `rows` is the view of the first
     len(db) rows, growth doubles the reservation (sized against 288 GB of HBM, a 4096-d bf16
-    key-frame is 8 KiB)."""
+    key-frame is 8 KiB).
+
+    Norms.  The top-k's certificate (include/dlc.h, NORMS) is derived for rows of norm <= 1.005 -- what the engine's own
+    normaliser writes.  Rows handed over with stored=True (a loaded shard, descriptors stored by another tool, a slice of
+    anything) are not taken on trust: one reduction at construction measures their largest norm (`norm_bound`, a device
+    float, never read by the host) and every match of this database then certifies with tau scaled by |q| * norm_bound
+    (dlc_cosine_tau_scale) -- the result is the exact fp64 top-k whatever the rows' norms.  The same goes for queries that
+    arrive already stored (bf16 / fp16) from anywhere but normalize().  norm_bound is None when every row is the normaliser's."""
 
     def __init__(self, descriptors, dtype="bf16", center=False, row_offset=0, device=None, stored=False,
-                 capacity=None):
+                 capacity=None, _norm_bound=None):
         self.engine = default_engine(device)
         self.dtype = torch_dtype(dtype)
         self.center = center
         self.row_offset = int(row_offset)
+        self.norm_bound = None
         if stored:
             d = descriptors.to(self.engine.device)
             if d.dtype != self.dtype:
                 raise ValueError("stored descriptors have dtype %s, expected %s" % (d.dtype, self.dtype))
             rows = d
+            if _norm_bound is not None:                      # prefix(): the parent's verdict holds for its first rows
+                self.norm_bound = _norm_bound[0]
+            elif d.shape[0] > 0 and not self.engine.unit_rows(d):
+                # starts at 1.005, not 0: rows append() normalises later are covered by the same number
+                self.norm_bound = self.engine.max_row_norm(
+                    d, out=torch.full((1,), 1.005, dtype=torch.float32, device=self.engine.device))
         else:
             rows = self.engine.normalize(self._as_float(descriptors), self.dtype, center)
         self._n = rows.shape[0]
@@ -107,7 +121,7 @@ class KeyframeDatabase:
         if not 0 <= n <= self._n:
             raise ValueError("prefix: n=%d outside 0..%d" % (n, self._n))
         return KeyframeDatabase(self._store[:n], dtype=self.dtype, center=self.center, row_offset=self.row_offset,
-                                device=self.engine.device, stored=True)
+                                device=self.engine.device, stored=True, _norm_bound=(self.norm_bound,))
 
     # ---- on-disk format: one .npz per shard ---------------------------------
     def save(self, path):
@@ -132,9 +146,16 @@ class KeyframeDatabase:
             return x
         return self.engine.normalize(self._as_float(x), self.dtype, self.center)
 
-    def match_topk(self, queries, k, out=None):
+    def tau_scale(self, q, out=None, stream=None):
+        """What the certificate of stored queries q against this database multiplies tau by ([Q] device floats), or None
+        when q and every row are the normaliser's (norm <= 1.005: the static tau is the bound)."""
+        if self.norm_bound is None and self.engine.unit_rows(q):
+            return None
+        return self.engine.cosine_tau_scale(q, self.norm_bound, out=out, stream=stream)
+
+    def match_topk(self, queries, k, out=None, details=False):
         q = self.prepare_queries(queries)
-        return self.engine.match_topk(q, self.rows, k, self.row_offset, out=out)
+        return self.engine.match_topk(q, self.rows, k, self.row_offset, out=out, details=details, tau_scale=self.tau_scale(q))
 
     def match(self, queries):
         return self.engine.cosine_scores(self.prepare_queries(queries), self.rows)
@@ -164,8 +185,9 @@ class MatchPipeline:
     a ticket, result(ticket) waits for that batch only.  A result must be fetched before `depth`
     further batches are submitted (its buffers are then reused), and all ranks must call submit() /
     result() in the same order (they carry collectives).  A batch whose ticket is never fetched is DROPPED when its
-    slot comes round again -- the exhaustive round of an uncertified batch runs only inside result() -- and counted in
-    `dropped_batches`; (scores, idx) of result() alias the slot's buffers until then.
+    slot comes round again and counted in `dropped_batches` -- unless its merge did not certify it (the exhaustive round
+    of such a batch runs only inside result()): submit() then raises RuntimeError on every rank rather than overwrite an
+    unverified list; (scores, idx) of result() alias the slot's buffers until then.
     """
 
     def __init__(self, db, k, depth=2, group=None, queries_per_batch=None):
@@ -182,6 +204,14 @@ class MatchPipeline:
         # the collective of the exchange (all_gather_into_tensor(out, inp, group=...)): torch.distributed's unless a caller
         # installs another -- bench.py's one-GPU emulation of a rank's step puts device copies here
         self.all_gather = dist.all_gather_into_tensor
+        # sharded: every rank certifies with the norm bound of the WHOLE database (ranks whose rows are the normaliser's
+        # contribute 1.005) -- one 4-byte all-reduce here, never read by the host
+        self._norm_bound = db.norm_bound
+        if self.world > 1:
+            r = db.norm_bound.clone() if db.norm_bound is not None else \
+                torch.full((1,), 1.005, dtype=torch.float32, device=dev)
+            dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
+            self._norm_bound = r
         self.resolved_batches = 0          # batches that needed the exhaustive round (sharded)
         self.dropped_batches = 0           # batches whose slot was reused before result() fetched them
         self.time_collectives = False      # record events around the two all-gathers of every batch (collective_us())
@@ -201,7 +231,7 @@ class MatchPipeline:
                  "scores": torch.empty((nq, k), dtype=torch.float32, device=dev),
                  "idx": torch.empty((nq, k), dtype=torch.int64, device=dev),
                  "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "fetched": True, "q": None,
-                 "rows": None}
+                 "rows": None, "ts_buf": torch.empty((nq,), dtype=torch.float32, device=dev), "ts": None}
             if self.world > 1:
                 kg = eng.groups_per_query(k)
                 nb = nq * k * 16                           # packed part: int64 rows [nq,k] | float64 scores [nq,k]
@@ -216,8 +246,10 @@ class MatchPipeline:
                 s["m_s64"] = torch.empty((nq, k), dtype=torch.float64, device=dev)
                 s["status"] = torch.empty((nq,), dtype=torch.int32, device=dev)
                 s["flag"] = torch.zeros((nq,), dtype=torch.int32).pin_memory()       # the merge's per-query status, on the host
-                # every shard's score pass errs by at most its plan's tau; the unsplit plan's is the largest
-                s["tau"] = max(eng.score_error_bound(nq, len(self.db), d, k), eng.score_error_bound(nq, 1 << 30, d, k))
+                # every shard's score pass errs by at most its plan's tau; the merge certifies with the largest tau ANY plan
+                # has for this width -- the same number on every rank whatever plan its shard's size picked (a rank on the
+                # bandwidth kernel's plan next to one on the MFMA plan must not certify with the smaller of the two)
+                s["tau"] = eng.score_error_bound_any_plan(d)
             self._slots[i] = s
         return s
 
@@ -229,9 +261,19 @@ class MatchPipeline:
         s = self._slot(i, q.shape[0], q.shape[1])
         main = torch.cuda.current_stream(eng.device)
         if s["busy"]:
-            main.wait_event(s["done"])          # the workspace / outputs of this slot are free again
             if not s["fetched"]:
-                self.dropped_batches += 1       # (its exhaustive round, if it needed one, never ran: nobody asked for the result)
+                # nobody asked for that batch's result.  If the merge certified it, dropping it loses nothing; if it did NOT
+                # (sharded: the exhaustive round runs inside result() only), the buffers hold an unverified list that this
+                # submit is about to overwrite -- say so instead of counting: the flags are identical on every rank, so
+                # every rank raises here, before any collective of the new batch
+                s["done"].synchronize()
+                if self.world > 1 and bool(s["flag"].any()):
+                    raise RuntimeError("MatchPipeline.submit: batch %d was never fetched and its merge did not certify %d "
+                                       "quer%s -- call result(ticket) within `depth` submissions (the exhaustive round runs "
+                                       "there)" % (self._count - self.depth, int((s["flag"] != 0).sum()),
+                                                   "y" if int((s["flag"] != 0).sum()) == 1 else "ies"))
+                self.dropped_batches += 1
+            main.wait_event(s["done"])          # the workspace / outputs of this slot are free again
         s["q"] = q                              # keep the stored queries alive until the batch is done
         # ... and the database rows: append() may replace the store (reserve) while this batch's
         # selection / re-score still gathers rows from the old one on the second stream
@@ -240,9 +282,14 @@ class MatchPipeline:
         s["scored"].record(main)
         self.s_select.wait_event(s["scored"])
         with torch.cuda.stream(self.s_select):
+            # operands that are not the normaliser's: tau follows |q| * (the database's largest row norm)
+            if self.world == 1 and self._norm_bound is None and eng.unit_rows(q):
+                ts = s["ts"] = None
+            else:
+                ts = s["ts"] = eng.cosine_tau_scale(q, self._norm_bound, out=s["ts_buf"], stream=self.s_select)
             if self.world == 1:
                 eng.select_topk(q, rows, self.k, s["ws"], s["scores"], s["idx"],
-                                row_offset=self.db.row_offset, coop=True, stream=self.s_select)
+                                row_offset=self.db.row_offset, coop=True, stream=self.s_select, tau_scale=ts)
             else:
                 eng.select_groups(q, rows, self.k, s["ws"], s["grp_ids"], s["grp_max"], coop=True,
                                   stream=self.s_select)
@@ -253,7 +300,8 @@ class MatchPipeline:
                 if ev:
                     ev[1].record(self.s_select)
                 eng.rescore_topk(q, rows, self.k, s["grp_ids"], s["grp_max"], s["p_s64"], s["p_idx"], bound=s["bound"],
-                                 all_max=s["g_max"], row_offset=self.db.row_offset, coop=True, stream=self.s_select)
+                                 all_max=s["g_max"], row_offset=self.db.row_offset, coop=True, stream=self.s_select,
+                                 tau_scale=ts)
                 if ev:
                     ev[2].record(self.s_select)
                 self.all_gather(s["g_pack"].view(-1), s["pack"], group=self.group)
@@ -261,7 +309,7 @@ class MatchPipeline:
                     ev[3].record(self.s_select)
                     self._coll_events.append(ev)
                 eng.topk_merge_packed(s["g_pack"], q.shape[0], self.k, out=(s["scores"], s["idx"]), bound=s["bound"],
-                                      tau=s["tau"], scores_f64=s["m_s64"], status=s["status"])
+                                      tau=s["tau"], scores_f64=s["m_s64"], status=s["status"], tau_scale=ts)
                 s["flag"].copy_(s["status"], non_blocking=True)
             s["done"].record(self.s_select)
         s["busy"] = True
@@ -276,7 +324,7 @@ class MatchPipeline:
         with torch.cuda.stream(self.s_select):
             lower = s["m_s64"][:, k - 1].contiguous()
             eng.exhaustive_topk(q, s["rows"], k, s["ws"], lower, s["tau"], s["status"], s["p_s64"], s["p_idx"],
-                                row_offset=self.db.row_offset, stream=self.s_select)
+                                row_offset=self.db.row_offset, stream=self.s_select, tau_scale=s["ts"])
             self.all_gather(s["g_pack"].view(-1), s["pack"], group=self.group)
             eng.topk_merge_packed(s["g_pack"], q.shape[0], k, out=(s["scores"], s["idx"]), scores_f64=s["m_s64"])
             s["done"].record(self.s_select)

@@ -51,7 +51,12 @@ class SDAV:
         # dlc_sdav_encode_split); training always runs the fp64 kernels
         self.mode = "f16x2" if dtype == "f16x2" else "exact"
         self.dtype = {"float64": torch.float64, "float32": torch.float32, "f16x2": torch.float64}[dtype]
-        self._panels = None                         # the tolerance mode's prepared weights, rebuilt when the weights change
+        # the tolerance mode's prepared weights, keyed on (where the weights live, _weights_gen).  The training kernels
+        # update the weights in place through raw pointers -- neither data_ptr() nor torch's version counter moves -- so
+        # every entry that can change a weight steps _weights_gen itself (SDAV.py:232-240,293-302: transform always sees the
+        # current variables)
+        self._panels = None
+        self._weights_gen = 0
         dims = [self.input_shape[1]] + list(self.hidden_units)
         self._weights, self._biases = _init_weights(dims, seed, self.dtype, self.engine.device, weight_scale)
         self._biases_dec = [torch.zeros(k, dtype=self.dtype, device=self.engine.device) for k in dims[:-1]]   # :193-217
@@ -98,6 +103,13 @@ class SDAV:
             ws.append(w)
             bs.append(b)
         self._weights, self._biases = ws, bs
+        self._weights_changed()
+
+    def _weights_changed(self):
+        """Called by everything that writes a weight (set_weights / load_weights, train_step, train_steps -- eager and
+        graph replay -- and through them fit / fit_dataset): the f16x2 panels of the old values must not be used again."""
+        self._weights_gen += 1
+        self._panels = None
 
     def get_weights(self):
         return [w.cpu().numpy() for w in self._weights], [b.cpu().numpy() for b in self._biases]
@@ -128,7 +140,7 @@ class SDAV:
             return torch.empty((0, self.hidden_units[-1]), dtype=self.dtype, device=self.engine.device)
         x2 = x.reshape(x.shape[0] * x.shape[1], x.shape[2])      # flat_batch, TensorflowWrapper.py:13-15
         if self.mode == "f16x2":
-            sig = tuple((w.data_ptr(), w._version) for w in self._weights)
+            sig = (self._weights_gen,) + tuple((w.data_ptr(), w._version) for w in self._weights)
             if self._panels is None or self._panels[0] != sig:
                 self._panels = (sig, self.engine.sdav_split_panels(self._weights))
             dims = [self.input_shape[1]] + list(self.hidden_units)
@@ -178,6 +190,7 @@ class SDAV:
                                     self._biases, self._biases_dec[layer_n], self.sparse_level, self.sparse_penalty,
                                     self.consecutive_penalty, self.learning_rate, loss_out=loss)
         self.global_step += 1
+        self._weights_changed()
         return loss
 
     def _fill_mask(self, m, layer_n):
@@ -247,6 +260,7 @@ class SDAV:
             else:
                 one_step()
         self.global_step += n_steps
+        self._weights_changed()
         return g["loss"]
 
     def get_dataset(self, file_pattern: str, key_points_fn=None):

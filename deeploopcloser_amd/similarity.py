@@ -10,16 +10,33 @@ from .engine import default_engine
 class SimilarityCalculator:
     def __init__(self, dataset: np.ndarray, mu=0.5, sigma=0.2, a=10, b=-10, device=None):
         self.mu, self.sigma, self.a, self.b = mu, sigma, a, b
-        self.dataset = dataset
         self.engine = default_engine(device)
+        self._pair = None
+        self.dataset = dataset
+
+    @property
+    def dataset(self):
+        return self._dataset
+
+    @dataset.setter
+    def dataset(self, dataset):
+        """The reference reads self.dataset (and mu / sigma) on EVERY similarity_score call (:13-14); here the average
+        response and the distinctive score are hoisted out of the pair loop, so assigning the public attribute
+        re-hoists them: `calc.dataset = other` scores against `other` from the next call on, as upstream."""
         ds = self.engine.to_device(dataset, torch.float64)
         if ds.dim() != 3:
             raise ValueError("dataset must be [N, P, H]")
-        self._dataset_dev = ds
-        # hoisted: the reference recomputes these for every pair (:13-14)
+        self._dataset, self._dataset_dev = dataset, ds
+        self._pair = None                                     # the pair buffers are sized by the dataset's width
         # ... and what that pass learned about the dataset's range serves similarity_matrix() over the same tensor
-        self._score, self._range = self.engine.distinctive_score(ds, mu, sigma, with_range=True)
-        self._pair = None
+        self._score, self._range = self.engine.distinctive_score(ds, self.mu, self.sigma, with_range=True)
+        self._hoisted = (self.mu, self.sigma)
+
+    def _current_score(self):
+        if self._hoisted != (self.mu, self.sigma):            # mu / sigma are public attributes too (:25-27)
+            self._score, self._range = self.engine.distinctive_score(self._dataset_dev, self.mu, self.sigma, with_range=True)
+            self._hoisted = (self.mu, self.sigma)
+        return self._score
 
     def similarity_score(self, h1, h2):
         """similarity_score(h1, h2) (:12-17): python float, +inf when a matched pair is identical.
@@ -43,13 +60,14 @@ class SimilarityCalculator:
         buf["host_np"][0] = a
         buf["host_np"][1] = b
         buf["dev"].copy_(buf["host"], non_blocking=True)
-        out, _ = self.engine.sdav_similarity_matrix(buf["dev"], self._score, self.a, self.b, want_int64=False,
+        score = self._current_score()
+        out, _ = self.engine.sdav_similarity_matrix(buf["dev"], score, self.a, self.b, want_int64=False,
                                                     no_host_sync=True, stats=buf["stats"])
         buf["res"][:1].copy_(out.view(-1)[1:2], non_blocking=True)
         buf["res"][1:].copy_(buf["stats"].to(torch.float64), non_blocking=True)
         torch.cuda.current_stream(self.engine.device).synchronize()
         if buf["res"][2].item() != 0.0:            # a NaN / infinity in the pair: the fp64 form reproduces NumPy's handling
-            out, _ = self.engine.sdav_similarity_matrix(buf["dev"], self._score, self.a, self.b, want_int64=False, force_f64=True)
+            out, _ = self.engine.sdav_similarity_matrix(buf["dev"], score, self.a, self.b, want_int64=False, force_f64=True)
             return float(out[0, 1].item())
         return float(buf["res"][0].item())
 
@@ -57,7 +75,7 @@ class SimilarityCalculator:
         """create_similarity_matrix.py:29-38: scores for i<j mirrored, diagonal -1.
         as_int64=True returns the reference's int64 matrix (truncated scores)."""
         d = self._dataset_dev if descriptors is None else self.engine.to_device(descriptors, torch.float64)
-        f, i = self.engine.sdav_similarity_matrix(d, self._score, self.a, self.b, want_int64=as_int64,
+        f, i = self.engine.sdav_similarity_matrix(d, self._current_score(), self.a, self.b, want_int64=as_int64,
                                                   range=self._range if descriptors is None else None)
         return (i if as_int64 else f).cpu().numpy()
 

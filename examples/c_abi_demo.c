@@ -40,8 +40,9 @@ int main(void) {
     const size_t need = dlc_cosine_topk_workspace_bytes(Q, N, D, K);
     CHECK_HIP(hipMalloc(&ws, need));
     const char* queries = (const char*)rows + (size_t)500 * D * 2;        /* rows 500 and 501 as the queries */
-    /* fp64 scores and the per-query certificate are optional outputs: NULL, NULL */
-    CHECK_DLC(dlc_cosine_topk(ctx, DLC_BF16, queries, Q, D, rows, N, D, D, K, 0, scores, NULL, idx, NULL, ws, need, NULL));
+    /* fp64 scores and the per-query certificate are optional outputs: NULL, NULL; tau_scale NULL: every row is
+       dlc_l2_normalize_rows' output (rows from elsewhere: dlc_max_row_norm + dlc_cosine_tau_scale) */
+    CHECK_DLC(dlc_cosine_topk(ctx, DLC_BF16, queries, Q, D, rows, N, D, D, K, 0, scores, NULL, idx, NULL, NULL, ws, need, NULL));
     CHECK_HIP(hipDeviceSynchronize());
 
     float hs[Q * K]; int64_t hi[Q * K];

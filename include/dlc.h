@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DLC_ABI_VERSION 7
+#define DLC_ABI_VERSION 8
 
 typedef struct dlc_ctx dlc_ctx;
 
@@ -389,9 +389,12 @@ int dlc_sdav_stream_query_batch(dlc_ctx* ctx, void* state, size_t state_bytes, i
  * streamed frames (rows of dlc_sdav_stream_query): row r offers its first min(ld, limit0 + r * limit_step) entries (none
  * when that is <= 0); order: score descending, ties -> the lower index (the older frame); a NaN is never taken.
  * out_scores / out_idx [rows, k]: (-inf, -1) where a row offers fewer than k.  1 <= k <= DLC_MAX_K.
+ * poison (device, may be NULL): one int64 read on the device -- non-zero (stats[1] of a dlc_sdav_stream_* whose range was
+ * violated: every row of it is NaN) turns every slot into (NaN, -1), so that a caller who only looks at the lists sees
+ * "these scores mean nothing" rather than "no candidates".
  */
 int dlc_topk_rows_f64(dlc_ctx* ctx, const double* scores, int64_t rows, int64_t ld, int64_t limit0, int64_t limit_step,
-                      int k, double* out_scores, int64_t* out_idx, void* stream);
+                      int k, double* out_scores, int64_t* out_idx, const int64_t* poison, void* stream);
 /*
  * All-vs-all cnn_vtl distance: DistanceCalculator.calculate_distance
  * (src/cnn_vtl/similarity/DistanceCalculator.py:4-12) = sum_k popcount(|a_k ^ b_k|)
@@ -412,9 +415,19 @@ int dlc_l2_normalize_rows(dlc_ctx* ctx, int src_dtype, const void* src, int64_t 
                           int center, int dst_dtype, void* dst, int64_t ldd, void* stream);
 /*
  * Top-k cosine match of q query rows against n database rows of width d
- * (both stored normalised in `dtype` = DLC_BF16 / DLC_F16 -- row norms <= 1.005, what
- * dlc_l2_normalize_rows writes; row strides ldq / lddb in elements, d a multiple of 64, rows
- * 16-byte aligned).
+ * (both stored in `dtype` = DLC_BF16 / DLC_F16; row strides ldq / lddb in elements, d a multiple of
+ * 64, rows 16-byte aligned).
+ *
+ * NORMS.  tau_scale = NULL states that every query and database row is what dlc_l2_normalize_rows
+ * wrote (norm <= 1.005): the certificate's tau below is derived for |q| |x| <= 1.01.  Rows from anywhere
+ * else (descriptors stored by another tool, a saved shard, un-normalised vectors) need
+ * tau_scale = the [q] floats of dlc_cosine_tau_scale(Q, the database's largest row norm from
+ * dlc_max_row_norm): query i then certifies with tau * tau_scale[i] -- the score pass's error is linear in
+ * |q| |x| -- and the result is the exact fp64 top-k for operands of ANY norm (elements finite,
+ * |q| |x| < 2^21 so that the ordering key below does not saturate).  A scale of +inf (a non-finite norm)
+ * certifies nothing: that query is decided by the exhaustive pass.  Every call of the staged / sharded
+ * forms below takes the same array; all shards must use the bound of the WHOLE database (the maximum
+ * over the shards' dlc_max_row_norm).
  *
  * THE SCORE of a (query, row) pair is one number, whatever call, plan, shard or batch computes it:
  * the fp64 sum of the exact products of the stored elements (bf16 / fp16 products are exact in
@@ -451,7 +464,19 @@ size_t dlc_cosine_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int k);
 int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
                     const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
                     float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    const float* tau_scale, void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * The two reductions behind tau_scale (rows as the match takes them: 16-byte aligned, d and the stride multiples of 8).
+ *   dlc_max_row_norm      *max_norm (ONE device float the caller zeroed before the first call) = max(*max_norm, the
+ *                         largest L2 norm of rows [n, d], fp32, rounded up; +inf when an element is not finite).
+ *                         Call it once per shard at load time and again for appended rows; sharded: all-reduce(MAX).
+ *   dlc_cosine_tau_scale  tau_scale[i] = max(1, |Q_i| * R / 1.01), R = *db_max_norm (a device float; NULL = 1.005: the
+ *                         database is dlc_l2_normalize_rows' output and only the queries are foreign).
+ */
+int dlc_max_row_norm(dlc_ctx* ctx, int dtype, const void* rows, int64_t n, int64_t ld, int64_t d, float* max_norm,
+                     void* stream);
+int dlc_cosine_tau_scale(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq, int64_t d,
+                         const float* db_max_norm, float* tau_scale, void* stream);
 /*
  * The same match with an age limit per query (the streaming loop-closure query, SURVEY 8f-4, for a batch of frames that
  * were appended to the database together): query i only sees rows 0 .. min(n, limit0 + i) - 1 (local rows, before
@@ -463,15 +488,19 @@ int dlc_cosine_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t l
 int dlc_cosine_topk_older(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
                           const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset, int64_t limit0,
                           float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          const float* tau_scale, void* workspace, size_t workspace_bytes, void* stream);
 /*
  * tau of the plan dlc_cosine_topk takes for this shape: |fp32 score of the score pass - fp64 score|
- * <= tau for rows of norm <= 1.005.  (s MFMA / v_dot2 accumulation steps of at most 2^-23 *
+ * <= tau for rows of norm <= 1.005 (times tau_scale[i] for any other operands, see NORMS above).  (s MFMA / v_dot2 accumulation steps of at most 2^-23 *
  * (|accumulator| + sum |products|) each, partial sums <= |q| |x| <= 1.01: tau = 2^-23 * 1.01 *
  * (s + 2) + 2^-38; s = 2 * (K tiles of 64 per split-K chunk).  4096-d one pass: 1.6e-5.)
- * A caller that merges shards of different shapes certifies with the largest of their taus.
+ * A caller that merges shards of different shapes certifies with the largest of their taus:
+ * dlc_cosine_score_error_bound_any_plan(d) is the largest tau ANY plan has for descriptors of width d (the unsplit
+ * MFMA pass, or the bandwidth kernel's chain for very short rows) -- the same number on every rank whatever its shard's
+ * size or plan, which is what a sharded merge must certify with.
  */
 double dlc_cosine_score_error_bound(int64_t q, int64_t n, int64_t d, int k);
+double dlc_cosine_score_error_bound_any_plan(int64_t d);
 /*
  * The two stages of dlc_cosine_topk as separate calls, for callers that pipeline batches
  * over two streams (stage 2 of batch i overlapping stage 1 of batch i+1, each batch with its
@@ -490,7 +519,7 @@ int dlc_cosine_score_groups(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, i
 int dlc_cosine_select_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
                            const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
                            float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
-                           void* workspace, size_t workspace_bytes, int flags, void* stream);
+                           const float* tau_scale, void* workspace, size_t workspace_bytes, int flags, void* stream);
 /*
  * Stage 2 split once more, for a database sharded over several GPUs.  Each shard would
  * otherwise re-score its own kg = dlc_cosine_groups_per_query(k) best groups per query, whatever
@@ -528,11 +557,12 @@ int dlc_cosine_rescore_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, i
                             const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
                             const int32_t* group_ids, const float* group_max,
                             const float* all_group_max, int parts,
-                            double* out_scores_f64, int64_t* out_idx, float* out_bound, int flags, void* stream);
+                            double* out_scores_f64, int64_t* out_idx, float* out_bound, const float* tau_scale,
+                            int flags, void* stream);
 int dlc_cosine_exhaustive_topk(dlc_ctx* ctx, int dtype, const void* Q, int64_t q, int64_t ldq,
                                const void* DB, int64_t n, int64_t lddb, int64_t d, int k, int64_t row_offset,
-                               const double* lower, int64_t lower_stride, double tau, int32_t* status,
-                               float* out_scores, double* out_scores_f64, int64_t* out_idx,
+                               const double* lower, int64_t lower_stride, double tau, const float* tau_scale,
+                               int32_t* status, float* out_scores, double* out_scores_f64, int64_t* out_idx,
                                void* workspace, size_t workspace_bytes, void* stream);
 /*
  * Streaming loop-closure queries: a batch of B new frames is matched in one dlc_cosine_topk call with
@@ -551,10 +581,11 @@ int dlc_topk_merge(dlc_ctx* ctx, const double* scores_f64, const int64_t* idx, i
                    float* out_scores, double* out_scores_f64, int64_t* out_idx, void* stream);
 /* Same with explicit distances (in elements) between consecutive parts, for results that were
  * gathered as one packed buffer per shard, and with the certificate of the sharded protocol above:
- * bound [q] (may be NULL: nothing left behind) and tau -> out_status[q] (may be NULL).  parts * k <= 2048. */
+ * bound [q] (may be NULL: nothing left behind), tau and tau_scale [q] (may be NULL: 1) -> out_status[q] (may be
+ * NULL).  parts * k <= 2048. */
 int dlc_topk_merge_strided(dlc_ctx* ctx, const double* scores_f64, int64_t score_part_stride,
                            const int64_t* idx, int64_t idx_part_stride, int parts, int64_t q, int k,
-                           const float* bound, double tau,
+                           const float* bound, double tau, const float* tau_scale,
                            float* out_scores, double* out_scores_f64, int64_t* out_idx, int32_t* out_status,
                            void* stream);
 /*

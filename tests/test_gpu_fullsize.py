@@ -290,7 +290,10 @@ def test_cosine_config4_shape_properties(dlc):
 @pytest.mark.parametrize("n", [3_000_000, 3_400_000])
 def test_select_kernel_large_shard_paths(dlc, n):
     """nh = n/128 half-tile maxima: 94 KB of LDS at 3.0 M rows (needs the >48 KB attribute), in-place
-    global path beyond 96 KB at 3.4 M rows.  Narrow descriptors keep it cheap; result vs torch."""
+    global path beyond 96 KB at 3.4 M rows.  Narrow descriptors keep it cheap; result vs torch.
+    The rows are N(0,1) vectors of norm ~8 (one of norm ~32), NOT the normaliser's output: the certificate's norm
+    precondition (include/dlc.h, NORMS) is met by the database measuring them (stored=True -> norm_bound -> tau_scale), not
+    by margin."""
     eng = dlc.default_engine()
     g = torch.Generator(device="cuda")
     g.manual_seed(n)
@@ -298,12 +301,14 @@ def test_select_kernel_large_shard_paths(dlc, n):
     q = torch.randn((8, 64), generator=g, device="cuda").to(torch.bfloat16)
     db[n - 1] = q[0] * 4                       # the very last row must be found
     db[12345] = db[n - 7]                      # an exact tie far apart
-    s, i = eng.match_topk(q, db, 5)
+    kdb = dlc.KeyframeDatabase(db, stored=True)
+    assert float(kdb.norm_bound) >= float(db[n - 1].double().norm()) and float(kdb.tau_scale(q).min()) > 30.0
+    s, i = kdb.match_topk(q, 5)
     ref = q.double() @ db.double().T                                    # [8, n] fp64 on the GPU (plumbing: checker only)
     rs, ri = torch.sort(ref, dim=1, descending=True, stable=True)
     assert torch.equal(i, ri[:, :5]) and float((s.double() - rs[:, :5]).abs().max()) < 1e-4
     assert int(i[0, 0]) == n - 1
-    p = dlc.MatchPipeline(dlc.KeyframeDatabase(db, stored=True), 5)     # cooperative kernel: always the global path
+    p = dlc.MatchPipeline(kdb, 5)                                       # cooperative kernel: always the global path
     s2, i2 = p.result(p.submit(q))
     assert torch.equal(i2, i) and torch.equal(s2, s)
 

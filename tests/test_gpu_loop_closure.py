@@ -265,8 +265,8 @@ def test_similarity_stream_vs_oracle_on_real_frames_and_poison():
     bad[4, 7] = 1.25                                              # outside (0, 1): the fixed-point bound does not cover it
     row = det.stream.query_and_insert(bad)
     assert bool(row.isnan().all()) and int(det.stream.stats[1]) == 1
-    s, i = det.query_and_insert(h[5])                             # ... and the detector refuses to report loops from it
-    assert int(i.max()) == -1
+    s, i = det.query_and_insert(h[5])                             # ... and the detector's lists say so themselves: (NaN, -1)
+    assert int(i.max()) == -1 and bool(s.isnan().all()) and int(det.poisoned) == 1
     with pytest.raises(RuntimeError, match="outside the stream's fixed range"):
         det.loops(s, i, len(det) - 1)
 
@@ -283,8 +283,11 @@ def test_topk_rows_f64_and_batched_detector():
     sc[:, ::5] = sc[:, 1::5][:, :sc[:, ::5].shape[1]]              # exact ties
     sc[3, :] = 2.5                                                  # a whole row of ties
     sc[4, 10:900] = float("nan"); sc[5, :] = float("nan"); sc[6, 17] = float("inf"); sc[7, 3] = float("-inf")
+    clean = torch.zeros(1, dtype=torch.int64, device=eng.device)
+    s, i = eng.topk_rows_f64(sc, ld, 0, k, poison=clean + 3)       # the poison word: (NaN, -1) everywhere
+    assert bool(s.isnan().all()) and bool((i == -1).all())
     for limit0, step in ((ld, 0), (-3, 1), (4, 40), (0, 0)):
-        s, i = eng.topk_rows_f64(sc, limit0, step, k)
+        s, i = eng.topk_rows_f64(sc, limit0, step, k, poison=clean if step else None)
         for r in range(rows):
             n = max(0, min(ld, limit0 + r * step))
             v = sc[r, :n].cpu().numpy()

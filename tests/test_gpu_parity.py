@@ -216,6 +216,131 @@ def test_cosine_topk_crowded_scores_take_the_exhaustive_pass(eng):
                 assert torch.equal(i2, top.idx) and torch.equal(s2, top.scores)
 
 
+def _ladder_database(n, d, dtype, seed, rungs=40, scale=8.0):
+    """Stored rows built on the HOST (what a saved shard or another tool hands over): unit rows, `rungs` copies of row 17
+    in `rungs` distinct 8-row groups, copy j lowered by j steps of a few ulps in ONE element of about 0.012 -- fp64 scores
+    against row 17 of s_0 - j g with g = 7e-7 -- then everything times `scale` (a power of two: exact in bf16 / fp16,
+    scores times scale^2).  Returns (rows [n, d] as torch CPU tensor of `dtype`, where [rungs], g)."""
+    rng = np.random.RandomState(seed)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    x = rng.standard_normal((n, d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    st = torch.from_numpy(x).to(tdt)
+    bits = st.view(torch.int16)
+    mant_bits, step = (7, 1) if dtype == "bf16" else (10, 8)
+    base = bits[17].clone()
+    # an element of row 17 in the binade [2^-7, 2^-6) whose mantissa leaves room for rungs * step ulps below it
+    vals = st[17].double().abs()
+    mant = (base.to(torch.int32) & ((1 << mant_bits) - 1))
+    ok = (vals >= 2.0 ** -7) & (vals < 2.0 ** -6) & (mant >= rungs * step + (1 << mant_bits) // 8)
+    e = int(torch.nonzero(ok)[0])
+    where = np.sort(rng.choice(np.arange(3, n // 8), rungs, replace=False)) * 8 + rng.randint(0, 8, rungs)
+    where[0] = 17                                            # rung 0 is row 17 itself
+    for j, r in enumerate(where.tolist()):
+        bits[r] = base
+        bits[r, e] = base[e] - j * step                     # magnitude down by j * step ulps (sign bit untouched)
+    g = step * 2.0 ** (-7 - mant_bits) * float(vals[e])
+    return (st.double() * scale).to(tdt), where, g * scale * scale
+
+
+@pytest.mark.parametrize("n,d,dtype", [(4096, 4096, "bf16"), (40000, 4096, "bf16"), (40000, 4096, "f16")])
+def test_cosine_certificate_follows_operand_norms(eng, dlc, n, d, dtype):
+    """Rows of norm 8 (queries too: scores x 64, the score pass's fp32 error x 64).  A ladder of 40 near-copies of the query
+    row in 40 groups, fp64 scores 4.6e-5 apart (x 64 of 7e-7): the k-th (20th) score clears the best row left behind
+    (the 25th) by 2.3e-4 -- MORE than the static tau (1.6e-5, derived for norms <= 1.005: include/dlc.h NORMS), LESS than
+    what the score pass can err by on these operands (tau x 64).  The static tau would certify on margin; the database
+    measures its rows' norms (stored=True), the certificate follows them, the query goes through the exhaustive pass
+    (status 2) and the list is the fp64 oracle's index for index -- small-database plan (4096 rows), standard plan, fp16;
+    one-shot call, two-stream pipeline and the sharded protocol (4 shards, every entry point that takes tau_scale)."""
+    from oracle import cosine as ocos
+    k, nq = 20, 6
+    rows_h, where, g = _ladder_database(n, d, dtype, seed=n + d)
+    db = dlc.KeyframeDatabase(rows_h, dtype=dtype, stored=True)
+    assert db.norm_bound is not None and 8.0 <= float(db.norm_bound) <= 8.1
+    q = db.rows[torch.tensor([17, 100, 101, 102, 103, 104], device=eng.device)].clone()
+    ts = db.tau_scale(q)
+    tau = eng.score_error_bound(nq, n, d, k)
+    assert ts.shape == (nq,) and 63.0 < float(ts.min()) and float(ts.max()) < 65.0
+    es, ei = ocos.cosine_topk(q.double().cpu().numpy(), rows_h.double().numpy(), k)
+    assert ei[0].tolist() == where[:k].tolist()                              # the ladder's first 20 rungs, in order
+    gap = es[0, k - 1] - float(q[0].double() @ db.rows[int(where[k + 4])].double())
+    assert tau < 0.7 * gap and gap < 0.5 * tau * float(ts[0])               # the window the test is about (see above)
+    top = db.match_topk(q, k, details=True)
+    torch.cuda.synchronize()
+    assert int(top.status[0]) == 2 and set(top.status.cpu().tolist()) <= {0, 2}
+    assert np.array_equal(top.idx.cpu().numpy(), ei)
+    assert np.abs(top.scores_f64.cpu().numpy() - es).max() < 64 * 1e-12
+    assert np.abs(top.scores.cpu().numpy() - es).max() < 64 * 1.2e-7
+    # what the static tau does with the same operands: certifies the ladder query on its margin (the precondition the
+    # header used to state and nothing checked)
+    raw = eng.match_topk(q, db.rows, k, details=True)
+    assert int(raw.status[0]) == 0
+    # unit rows through the same path: scale 1, nothing changes
+    unit = dlc.KeyframeDatabase((rows_h.double() / 8).to(rows_h.dtype), dtype=dtype, stored=True)
+    assert 1.0 <= float(unit.norm_bound) <= 1.01
+    qu = unit.rows[torch.tensor([17, 100], device=eng.device)].clone()
+    assert float(unit.tau_scale(qu).max()) <= 1.01
+    assert eng.unit_rows(eng.normalize(qu.float(), dtype)) and not eng.unit_rows(qu) and unit.tau_scale(
+        eng.normalize(qu.float(), dtype)) is not None                        # the ROWS are foreign, whatever the queries are
+    own = dlc.KeyframeDatabase(rows_h.float(), dtype=dtype)                  # normalised here: trusted, no scale
+    assert own.norm_bound is None and own.tau_scale(own.prepare_queries(qu.float())) is None
+    # the two-stream pipeline on one GPU
+    pipe = dlc.MatchPipeline(db, k)
+    s2, i2 = pipe.result(pipe.submit(q))
+    assert torch.equal(i2, top.idx) and torch.equal(s2, top.scores)
+    # the sharded protocol with 4 shards: select groups, exchange maxima, filtered re-score, certifying merge, exhaustive round
+    parts, kg = 4, eng.groups_per_query(k)
+    tau_any = eng.score_error_bound_any_plan(d)
+    assert tau_any >= tau
+    ids, mx, wss, shards = [], [], [], [dlc.shard_bounds(n, parts, r) for r in range(parts)]
+    for lo, hi in shards:
+        ws = torch.empty(eng.topk_workspace_bytes(nq, hi - lo, d, k), dtype=torch.uint8, device=eng.device)
+        gi = torch.empty((nq, kg), dtype=torch.int32, device=eng.device)
+        gm = torch.empty((nq, kg + 1), dtype=torch.float32, device=eng.device)
+        eng.score_groups(q, db.rows[lo:hi], k, ws)
+        eng.select_groups(q, db.rows[lo:hi], k, ws, gi, gm)
+        ids.append(gi), mx.append(gm), wss.append(ws)
+    all_max = torch.stack(mx)
+    gathered = torch.empty((parts, nq * k * 16), dtype=torch.uint8, device=eng.device)
+    bound = torch.empty((nq,), dtype=torch.float32, device=eng.device)
+    for r, (lo, hi) in enumerate(shards):
+        eng.rescore_topk(q, db.rows[lo:hi], k, ids[r], mx[r], gathered[r, nq * k * 8:].view(torch.float64).view(nq, k),
+                         gathered[r, :nq * k * 8].view(torch.int64).view(nq, k), bound=bound, all_max=all_max, row_offset=lo,
+                         tau_scale=ts)
+    o_s = torch.empty((nq, k), dtype=torch.float32, device=eng.device)
+    o_i = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
+    o_64 = torch.empty((nq, k), dtype=torch.float64, device=eng.device)
+    status = torch.full((nq,), -1, dtype=torch.int32, device=eng.device)
+    eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i), bound=bound, tau=tau_any, scores_f64=o_64, status=status, tau_scale=ts)
+    assert int(status[0]) == 1 and torch.equal(status == 0, o_64[:, k - 1] > bound.double() + tau_any * ts.double())
+    static = torch.full((nq,), -1, dtype=torch.int32, device=eng.device)
+    eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i), bound=bound, tau=tau_any, scores_f64=o_64, status=static)
+    assert int(static[0]) == 0                                               # (again: the static tau's verdict)
+    lower = o_64[:, k - 1].contiguous()
+    for r, (lo, hi) in enumerate(shards):
+        st = status.clone()
+        eng.exhaustive_topk(q, db.rows[lo:hi], k, wss[r], lower, tau_any, st, gathered[r, nq * k * 8:].view(torch.float64).view(nq, k),
+                            gathered[r, :nq * k * 8].view(torch.int64).view(nq, k), row_offset=lo, tau_scale=ts)
+        assert int(st[0]) == 2
+    eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i), scores_f64=o_64)
+    assert torch.equal(o_i, top.idx) and torch.equal(o_64, top.scores_f64)
+    # a non-finite element: the scale is +inf, nothing certifies, the exhaustive pass decides (finite queries still exact)
+    poisoned = db.rows.clone()
+    poisoned[5, 3] = float("inf")
+    pdb = dlc.KeyframeDatabase(poisoned, dtype=dtype, stored=True)
+    assert bool(torch.isinf(pdb.norm_bound).all()) and bool(torch.isinf(pdb.tau_scale(q)).all())
+
+
+def test_any_plan_error_bound_covers_every_plan(eng):
+    """dlc_cosine_score_error_bound_any_plan(d) -- what a sharded merge certifies with -- is at least the tau of whatever
+    plan a shard's shape picks: the bandwidth kernel (q <= 4), the small-database plan, split-K, the one-pass MFMA plan."""
+    for d in (64, 128, 256, 1024, 4096, 16384, 75008):
+        any_plan = eng.score_error_bound_any_plan(d)
+        for nq in (1, 2, 4, 5, 32, 256):
+            for n in (8, 1000, 16384, 16385, 125_000, 1_000_000, 1 << 30):
+                assert eng.score_error_bound(nq, n, d, 20) <= any_plan, (nq, n, d)
+
+
 def test_score_error_bound_holds(eng):
     """dlc_cosine_score_error_bound is what the certificate of every selection rests on: |fp32 score of the score pass -
     fp64 score| <= tau.  Checked on every element of dense MFMA score matrices (one pass and split-K) for random,
@@ -521,6 +646,50 @@ def test_sdav_transform_split_mode_within_north_star_tolerance(dlc, scale):
     assert worst < (4e-5 if scale == "reference" else 1e-6)            # what the form delivers (2.1e-5 / 1.8e-7), with margin
 
 
+@pytest.mark.parametrize("how", ["train_step", "train_steps_graph", "fit"])
+def test_sdav_split_mode_sees_trained_weights(dlc, how):
+    """transform -> train -> transform in the tolerance mode (SDAV.py:232-240,293-302: transform always sees the current
+    variables).  The training kernels update the weights in place through raw pointers -- neither data_ptr() nor torch's
+    version counter moves -- so the fp16 panels are keyed on the network's own weights generation (the cache
+    used to return descriptors of the PRE-training weights).  After training: a fresh network given the trained weights
+    returns the same descriptors bit for bit, they differ from the ones before, and they are within 1e-4 relative L2 of
+    the fp64 oracle on the trained weights."""
+    from oracle import sdav as osdav
+    rng = np.random.RandomState(17)
+    net = dlc.SDAV(seed=13, dtype="f16x2", weight_scale="fan_in")
+    x = rng.uniform(0, 1, size=(6, 30, 1681))
+    xb = rng.uniform(0, 1, size=(4, 30, 1681))
+    h0 = net.transform(x)
+    if how == "train_step":
+        for _ in range(3):
+            net.train_step(0, xb)
+    elif how == "train_steps_graph":
+        with net.engine.latency_mode():
+            net.train_steps(1, xb, 5)                                   # one eager step, then graph replays
+            h_mid = net.transform(x)
+            net.train_steps(1, xb, 4)                                   # replays only: the cached graph
+        assert not np.array_equal(h_mid, net.transform(x))
+    else:
+        net.epochs = 3
+        net.fit(xb)
+    h1 = net.transform(x)
+    ws, bs = net.get_weights()
+    fresh = dlc.SDAV(seed=99, dtype="f16x2")
+    fresh.set_weights(ws, bs)
+    assert np.array_equal(fresh.transform(x), h1)
+    assert not np.array_equal(h1, h0)
+    ref = osdav.transform(x, ws, bs)
+    l2 = np.linalg.norm(h1 - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert l2.max() < 1e-4
+    l2_stale = np.linalg.norm(h0 - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert l2_stale.max() > 10 * l2.max()                               # the test can tell stale from fresh
+    # set_weights on the same object: new tensors that the caching allocator may place where the old ones lived
+    net.set_weights([w * 0.5 for w in ws], bs)
+    ref2 = osdav.transform(x, [w * 0.5 for w in ws], bs)
+    h2 = net.transform(x)
+    assert (np.linalg.norm(h2 - ref2, axis=1) / np.linalg.norm(ref2, axis=1)).max() < 1e-4
+
+
 def test_sdav_encode_split_odd_shapes(eng):
     """dlc_sdav_encode_split on widths that are no multiple of anything (K tails, ragged last tiles, one layer, a single
     row) against a float64 torch chain: relative error of every output below 1e-5; re-preparing after a weight change."""
@@ -623,6 +792,34 @@ def test_similarity_vs_reference_fixture(dlc, golden, name):
     for (i, j) in [(0, 1), (1, 0), (2, 3)]:
         got = calc.similarity_score(ds[i], ds[j])
         assert (np.isinf(want[i, j]) and got == want[i, j]) or abs(got - want[i, j]) <= 1e-9 * abs(want[i, j])
+
+
+def test_similarity_calculator_rereads_its_public_attributes(dlc):
+    """The reference reads self.dataset, self.mu, self.sigma on every similarity_score call
+    (SimilarityCalculator.py:13-14,25-27); the drop-in hoists the distinctive score, so assigning any of them must
+    re-hoist it -- also when the new dataset has another width (the pair buffers follow)."""
+    from oracle import similarity as osim
+    rng = np.random.RandomState(31)
+    ds_a = rng.uniform(0, 1, size=(5, 30, 96))
+    ds_b = rng.uniform(0, 1, size=(7, 30, 96)) ** 3
+    ds_c = rng.uniform(0, 1, size=(4, 12, 40))
+    calc = dlc.SimilarityCalculator(ds_a)
+    close = lambda got, want: abs(got - want) <= 1e-9 * abs(want)
+    assert close(calc.similarity_score(ds_a[0], ds_a[1]), osim.similarity_score(ds_a, ds_a[0], ds_a[1]))
+    calc.dataset = ds_b
+    assert calc.dataset is ds_b
+    want_b = osim.similarity_score(ds_b, ds_a[0], ds_a[1])
+    assert not close(osim.similarity_score(ds_a, ds_a[0], ds_a[1]), want_b)
+    assert close(calc.similarity_score(ds_a[0], ds_a[1]), want_b)
+    ref = osim.similarity_matrix_f64(ds_b)
+    got = calc.similarity_matrix(as_int64=False)
+    assert np.abs(got - ref).max() < 1e-9 * np.abs(ref).max()
+    calc.mu, calc.sigma = 0.3, 0.1
+    assert close(calc.similarity_score(ds_b[2], ds_b[5]), osim.similarity_score(ds_b, ds_b[2], ds_b[5], mu=0.3, sigma=0.1))
+    calc.dataset = ds_c
+    assert close(calc.similarity_score(ds_c[0], ds_c[3]), osim.similarity_score(ds_c, ds_c[0], ds_c[3], mu=0.3, sigma=0.1))
+    with pytest.raises(ValueError):
+        calc.dataset = ds_c[0]
 
 
 def test_similarity_matrix_vs_oracle_larger(dlc):
@@ -1164,7 +1361,8 @@ def test_group_exchange_protocol_equals_unsharded(eng, dlc, n):
     o_i = torch.empty((nq, k), dtype=torch.int64, device=eng.device)
     o_64 = torch.empty((nq, k), dtype=torch.float64, device=eng.device)
     status = torch.full((nq,), -1, dtype=torch.int32, device=eng.device)
-    tau = max(eng.score_error_bound(nq, hi - lo, d, k) for lo, hi in shards)
+    tau = eng.score_error_bound_any_plan(d)                    # what MatchPipeline certifies with: plan-independent
+    assert tau >= max(eng.score_error_bound(nq, hi - lo, d, k) for lo, hi in shards)
     eng.topk_merge_packed(gathered, nq, k, out=(o_s, o_i), bound=bounds[0], tau=tau, scores_f64=o_64, status=status)
     assert torch.equal(o_i, want.idx) and torch.equal(o_s, want.scores) and torch.equal(o_64, want.scores_f64)
     assert int(status.min()) >= 0 and int(status.max()) <= 1
@@ -1296,13 +1494,13 @@ def test_row_stride_bound_and_buffer_validation(eng, dlc):
     big = (1 << 32) // (2 * 255) // 8 * 8 + 8                       # elements: 255 rows x 2 bytes >= 4 GiB
     for ldq, lddb in ((64, big), (big, 64)):
         rc = eng.lib.dlc_cosine_topk(eng.ctx, L.DLC_BF16, C.c_void_p(q.data_ptr()), 4, ldq, C.c_void_p(q.data_ptr()), 1, lddb,
-                                     64, 2, 0, C.c_void_p(s.data_ptr()), None, C.c_void_p(i.data_ptr()), None,
+                                     64, 2, 0, C.c_void_p(s.data_ptr()), None, C.c_void_p(i.data_ptr()), None, None,
                                      C.c_void_p(ws.data_ptr()), ws.numel(), None)
         assert rc == L.DLC_ERR_BAD_SHAPE and b"stride" in eng.lib.dlc_last_error(eng.ctx)
     ok = (1 << 32) // (2 * 255) // 8 * 8 - 64                       # just below the bound: accepted (one row: the stride is unused)
     rc = eng.lib.dlc_cosine_topk(eng.ctx, L.DLC_BF16, C.c_void_p(q.data_ptr()), 1, ok, C.c_void_p(q.data_ptr()), 1, ok, 64, 1, 0,
-                                 C.c_void_p(s.data_ptr()), None, C.c_void_p(i.data_ptr()), None, C.c_void_p(ws.data_ptr()),
-                                 ws.numel(), None)
+                                 C.c_void_p(s.data_ptr()), None, C.c_void_p(i.data_ptr()), None, None,
+                                 C.c_void_p(ws.data_ptr()), ws.numel(), None)
     torch.cuda.synchronize()
     assert rc == L.DLC_OK
     for bad in ((s[:, :1], i), (s, i.to(torch.int32)), (s.t().contiguous().t(), i), (s.cpu(), i)):
