@@ -284,6 +284,40 @@ class Engine:
         self._s_out.synchronize()                     # the result is complete in host memory
         return state["out"]
 
+    def for_each_chunk(self, x, chunk, consume):
+        """The upload half of run_chunked for results that STAY on the device: x [N, ...] (numpy, pageable) is cut into
+        chunks of `chunk` items, the upload of chunk c+1 (copy stream, pinned staging ring) overlaps consume(device
+        chunk, lo, hi) of chunk c on the current stream.  consume must be done with its chunk in stream order (it may keep
+        results, not the chunk: the two buffers are reused).  Returns when everything has been SUBMITTED; the current
+        stream is ordered behind the last upload."""
+        x = np.ascontiguousarray(x)
+        n = x.shape[0]
+        dev = self.device
+        dt = self._torch_dtype_of(x)
+        if dt is None:
+            raise ValueError("for_each_chunk: unsupported array dtype %s" % x.dtype)
+        if not hasattr(self, "_s_in"):
+            self._s_in, self._s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        chunk = max(1, min(int(chunk), n))
+        bufs = [torch.empty((chunk,) + tuple(x.shape[1:]), dtype=dt, device=dev) for _ in range(2 if n > chunk else 1)]
+        self._s_in.wait_stream(cur)                 # the buffers' memory may still be in use by earlier work of this stream
+        free_ev = [None, None]
+        for c, lo in enumerate(range(0, n, chunk)):
+            hi = min(lo + chunk, n)
+            b = c % len(bufs)
+            if free_ev[b] is not None:
+                self._s_in.wait_event(free_ev[b])     # chunk c-2's kernels have read this buffer
+            self.upload(x[lo:hi], out=bufs[b][:hi - lo], stream=self._s_in)
+            up = torch.cuda.Event()
+            up.record(self._s_in)
+            cur.wait_event(up)
+            consume(bufs[b][:hi - lo], lo, hi)
+            free_ev[b] = torch.cuda.Event()
+            free_ev[b].record(cur)
+        for b_ in bufs:
+            b_.record_stream(cur)
+
     # ---- dense layers -----------------------------------------------------------
     def gemm_bias_act(self, a, b, bias=None, act=L.DLC_ACT_NONE, blayout=L.DLC_B_KN, out=None):
         """out[M,N] = act(a[M,K] . b + bias) in a's dtype (float64 / float32)."""

@@ -20,6 +20,7 @@ import contextlib
 import glob
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -181,28 +182,29 @@ def _frame_files(dataset_path, pattern):
 
 
 def describe_sdav(files, network=None, key_points_fn=None):
-    """Frames -> one [30*2500] place descriptor per frame (patches -> SDAV.transform, flattened)."""
-    from .input import CvInputParser, read_ppm
+    """Frames -> one [30*2500] place descriptor per frame (patches -> SDAV.transform, flattened), a DEVICE tensor: the
+    uint8 frames go up once, grey / key-points / patches / encoder run back to back in HBM (pipeline.py)."""
+    from . import pipeline
+    from .input import read_ppm
     from .sdav import SDAV
     network = network or SDAV()
     p = network.input_shape[0]
-    parser = CvInputParser(p, int(round(np.sqrt(network.input_shape[1]))))
     frames = [read_ppm(f) for f in files]
+    kp = None
     if key_points_fn:
-        x = np.stack([parser.parse(fr, key_points_fn(fr.shape[:2])) for fr in frames])
-    else:                                                    # grey, Harris key-points, patches: all on the GPU
-        x = parser.parse_batch(np.stack(frames))
-    h = network.transform(x)
-    return h.reshape(len(files), p * h.shape[1])
+        kp = pipeline.key_point_array([key_points_fn(fr.shape[:2]) for fr in frames], p, network.engine)
+    desc = pipeline.sdav_descriptors_from_frames(np.stack(frames), network, key_points=kp)
+    return desc.view(len(files), -1)
 
 
 def describe_cnn_vtl(files, network=None):
-    """Frames -> CnnVtl int8 descriptors [B, D'] (as float for the cosine engine)."""
+    """Frames -> CnnVtl int8 descriptors [B, D'] as float32 for the cosine engine, a DEVICE tensor (pipeline.py)."""
+    from . import pipeline
     from .cnn_vtl import CnnVtl
     from .input import read_ppm
     frames = np.stack([read_ppm(f)[..., ::-1] for f in files])           # BGR, as create_distance_matrix.py:23
     network = network or CnnVtl(input_shape=[len(files)] + list(frames.shape[1:]))
-    return network.transform(frames).astype(np.float32)
+    return pipeline.cnn_vtl_descriptors_from_frames(frames, network).to(torch.float32)
 
 
 def main(argv=None):
@@ -244,19 +246,25 @@ def _stream(args, files):
             net.load_alexnet_npy(args.weights)
         describe = lambda fs: describe_cnn_vtl(fs, net)
     det = None
+    lat = []                                                     # wall-clock per step: file read -> descriptors -> match -> candidates on the host
     for lo in range(0, len(files), args.batch):
         chunk = files[lo:lo + args.batch]
+        t0 = time.perf_counter()
         desc = describe(chunk)
         if det is None:
             det = LoopClosureDetector(desc.shape[1], k=args.k, threshold=args.threshold, exclusion=args.exclusion,
                                       dtype=args.dtype, center=True, capacity=max(4096, len(files)))
         s, i = det.query_and_insert(desc)
-        for frame, match, score in det.loops(s, i, lo):
+        found = det.loops(s, i, lo)                              # (the one host read of the step)
+        lat.append(((time.perf_counter() - t0) * 1e3, len(chunk)))
+        for frame, match, score in found:
             print("loop\t%d\t%s\t%d\t%s\t%.4f" % (frame, os.path.basename(files[frame]), match,
                                                  os.path.basename(files[match]), score))
     print("frames\t%d\tkey-frames\t%d" % (len(files), len(det)), file=sys.stderr)
+    # the first step pays one-time costs (the library's first launches, workspaces, the database's reservation): reported apart
+    steady = lat[1:] if len(lat) > 1 else lat
+    ms = np.array([m for m, _ in steady])
+    per_frame = float(ms.sum() / max(1, sum(c for _, c in steady)))
+    print("latency\tbatch\t%d\tsteps\t%d\tfirst_step_ms\t%.2f\tms_per_step_median\t%.3f\tms_per_step_max\t%.3f\tms_per_frame\t%.3f"
+          % (args.batch, len(lat), lat[0][0], float(np.median(ms)), float(ms.max()), per_frame), file=sys.stderr)
     return 0
-
-
-if __name__ == "__main__":
-    sys.exit(main())

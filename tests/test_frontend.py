@@ -112,6 +112,91 @@ def test_drivers_and_database_file(tmp_path):
 
 
 @pytest.mark.gpu
+def test_end_to_end_pipelines_equal_the_staged_calls(tmp_path):
+    """BASELINE configs[1] / configs[2] as one device-resident path (deeploopcloser_amd/pipeline.py; the reference's scripts
+    src/sdav/create_similarity_matrix.py:23-38 and src/cnn_vtl/create_distance_matrix.py:14-36): frames in, matrix out, no
+    host hop between the stages.  On the 20 real frames tiled to 47 (three upload chunks of 16): the matrices equal, bit for
+    bit, what the staged calls (parser -> transform -> matrix, each through NumPy) give; host frames == resident frames;
+    caller-supplied key-points == the per-frame parse; the fp64 similarity equals the oracle's on the first frames."""
+    import deeploopcloser_amd as dlc
+    from deeploopcloser_amd import pipeline, drivers
+    from oracle import similarity as osim
+    import real_frames
+    paths = real_frames.frame_paths()
+    base = np.stack([dlc.read_ppm(p) for p in paths])                          # [20, 192, 240, 3] uint8 RGB
+    rng = np.random.RandomState(3)
+    frames = np.concatenate([base, base[::-1], base[:7]])                      # 47 frames
+    noise = rng.randint(0, 40, size=frames[20:].shape)
+    frames[20:] = np.clip(frames[20:].astype(np.int64) + noise - 20, 0, 255).astype(np.uint8)
+    n = frames.shape[0]
+    net = dlc.SDAV(seed=4, weight_scale="fan_in")
+    parser = dlc.CvInputParser(30, 41)
+    # staged, through the host between every stage (what drivers.py did before)
+    x = np.stack([parser.parse(fr) for fr in frames])
+    h = net.transform(x)
+    want = dlc.SimilarityCalculator(h.reshape(n, 30, 2500)).similarity_matrix()
+    t = []
+    got = pipeline.sdav_similarity_matrix_from_frames(frames, net, parser, chunk_frames=16, timings=t)
+    assert got.dtype == np.int64 and np.array_equal(got, want)
+    ms = pipeline.stage_ms(t)
+    assert set(ms) == {"front-end (grey, key-points, patches)", "SDAV.transform",
+                       "similarity matrix (distinctive score + all-vs-all)", "download of the matrix"} and all(v > 0 for v in ms.values())
+    res = pipeline.sdav_similarity_matrix_from_frames(torch.from_numpy(frames).cuda(), net, device_result=True)
+    assert res.is_cuda and np.array_equal(res.cpu().numpy(), want)
+    f64 = pipeline.sdav_similarity_matrix_from_frames(frames, net, as_int64=False)
+    ref = osim.similarity_matrix_f64(h.reshape(n, 30, 2500)[:6])
+    fin = np.isfinite(ref)
+    assert np.abs(f64[:6, :6][fin] - ref[fin]).max() <= 1e-9 * np.abs(ref[fin]).max()
+    # the tolerance mode's encoder in the same pipeline: its own staged result
+    net16 = dlc.SDAV(seed=4, weight_scale="fan_in", dtype="f16x2")
+    want16 = dlc.SimilarityCalculator(net16.transform(x).reshape(n, 30, 2500)).similarity_matrix()
+    assert np.array_equal(pipeline.sdav_similarity_matrix_from_frames(frames, net16, chunk_frames=20), want16)
+    # caller-supplied key-points (the reference's SURF slot): per-frame parse == the batched gather
+    kps = [dlc.grid_key_points(fr.shape[:2], 30) for fr in frames[:5]]
+    xk = np.stack([parser.parse(fr, kp) for fr, kp in zip(frames[:5], kps)])
+    wantk = dlc.SimilarityCalculator(net.transform(xk).reshape(5, 30, 2500)).similarity_matrix()
+    gotk = pipeline.sdav_similarity_matrix_from_frames(frames[:5], net, parser, key_points=pipeline.key_point_array(kps, 30, net.engine))
+    assert np.array_equal(gotk, wantk)
+    with pytest.raises(ValueError, match="key-points"):
+        pipeline.key_point_array([kps[0][:7]], 30, net.engine)
+    # configs[2]
+    bgr = np.ascontiguousarray(frames[..., ::-1])
+    cnn = dlc.CnnVtl(input_shape=[n, 192, 240, 3], seed=3, mask_seed=4)
+    d8 = cnn.transform(bgr)
+    wantd = dlc.DistanceCalculator.distance_matrix(d8)
+    t = []
+    gotd = pipeline.cnn_vtl_distance_matrix_from_frames(bgr, cnn, chunk_frames=16, timings=t)
+    assert gotd.dtype == np.int64 and np.array_equal(gotd, wantd) and set(pipeline.stage_ms(t)) == {
+        "CnnVtl.transform", "distance matrix", "download of the matrix"}
+    assert np.array_equal(pipeline.cnn_vtl_distance_matrix_from_frames(torch.from_numpy(bgr).cuda(), cnn, device_result=True).cpu().numpy(), wantd)
+    assert np.array_equal(pipeline.cnn_vtl_descriptors_from_frames(bgr.astype(np.float64), cnn).cpu().numpy(), d8)
+    # the drivers are these pipelines behind a directory listing (also with a key-point function)
+    frames_dir = os.path.join(GOLDEN, "frames")
+    files = sorted(os.listdir(frames_dir))
+    three = np.stack([dlc.read_ppm(os.path.join(frames_dir, f)) for f in files])
+    sim = drivers.create_similarity_matrix(frames_dir, network=net)
+    assert np.array_equal(sim, pipeline.sdav_similarity_matrix_from_frames(three, net))
+    simk = drivers.create_similarity_matrix(frames_dir, network=net, key_points_fn=lambda shape: dlc.grid_key_points(shape, 30))
+    xg = np.stack([parser.parse(fr, dlc.grid_key_points(fr.shape[:2], 30)) for fr in three])
+    assert np.array_equal(simk, dlc.SimilarityCalculator(net.transform(xg).reshape(3, 30, 2500)).similarity_matrix())
+
+
+@pytest.mark.gpu
+def test_cli_reports_per_frame_latency(capsys):
+    """The streaming CLI one frame at a time: candidates on stdout, the step latency (file -> descriptors -> match ->
+    candidates on the host) on stderr."""
+    from deeploopcloser_amd import loop_closure
+    rc = loop_closure.main([os.path.join(GOLDEN, "datasets_test"), "--network", "cnn_vtl", "--k", "1", "--exclusion", "0",
+                            "--threshold", "-1", "--batch", "1"])
+    cap = capsys.readouterr()
+    assert rc == 0 and len(cap.out.strip().splitlines()) == 16              # 17 frames: all but the first find an older one
+    line = [l for l in cap.err.splitlines() if l.startswith("latency\t")]
+    assert len(line) == 1
+    f = line[0].split("\t")
+    assert f[1:5] == ["batch", "1", "steps", "17"] and float(f[f.index("ms_per_frame") + 1]) > 0.0
+
+
+@pytest.mark.gpu
 def test_rgb_to_gray_odd_sizes_and_unaligned_views():
     """The grey kernel handles four pixels per thread from whole dwords: pixel counts that are not multiples of four
     (the tail) and buffers that do not start on a dword (the byte path) give the same bytes as the oracle."""

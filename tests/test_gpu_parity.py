@@ -216,10 +216,10 @@ def test_cosine_topk_crowded_scores_take_the_exhaustive_pass(eng):
                 assert torch.equal(i2, top.idx) and torch.equal(s2, top.scores)
 
 
-def _ladder_database(n, d, dtype, seed, rungs=40, scale=8.0):
+def _ladder_database(n, d, dtype, seed, g_unit, rungs=40, scale=8.0):
     """Stored rows built on the HOST (what a saved shard or another tool hands over): unit rows, `rungs` copies of row 17
-    in `rungs` distinct 8-row groups, copy j lowered by j steps of a few ulps in ONE element of about 0.012 -- fp64 scores
-    against row 17 of s_0 - j g with g = 7e-7 -- then everything times `scale` (a power of two: exact in bf16 / fp16,
+    in `rungs` distinct 8-row groups, copy j lowered by j steps of a few ulps in ONE element -- picked from the binade that
+    makes the fp64 scores against row 17 s_0 - j g with g within a factor 2 of g_unit -- then everything times `scale` (a power of two: exact in bf16 / fp16,
     scores times scale^2).  Returns (rows [n, d] as torch CPU tensor of `dtype`, where [rungs], g)."""
     rng = np.random.RandomState(seed)
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
@@ -229,42 +229,44 @@ def _ladder_database(n, d, dtype, seed, rungs=40, scale=8.0):
     bits = st.view(torch.int16)
     mant_bits, step = (7, 1) if dtype == "bf16" else (10, 8)
     base = bits[17].clone()
-    # an element of row 17 in the binade [2^-7, 2^-6) whose mantissa leaves room for rungs * step ulps below it
+    # g = step * ulp * |x_e| = step * 2^(-b - mant_bits) * |x_e| with |x_e| in [2^-b, 2^-b+1): the binade b for g_unit, and an
+    # element of row 17 in it whose mantissa leaves room for rungs * step ulps below it
+    b = int(round((-np.log2(g_unit / (1.5 * step)) - mant_bits) / 2))
     vals = st[17].double().abs()
     mant = (base.to(torch.int32) & ((1 << mant_bits) - 1))
-    ok = (vals >= 2.0 ** -7) & (vals < 2.0 ** -6) & (mant >= rungs * step + (1 << mant_bits) // 8)
+    ok = (vals >= 2.0 ** -b) & (vals < 2.0 ** (1 - b)) & (mant >= rungs * step + (1 << mant_bits) // 8)
     e = int(torch.nonzero(ok)[0])
     where = np.sort(rng.choice(np.arange(3, n // 8), rungs, replace=False)) * 8 + rng.randint(0, 8, rungs)
     where[0] = 17                                            # rung 0 is row 17 itself
     for j, r in enumerate(where.tolist()):
         bits[r] = base
         bits[r, e] = base[e] - j * step                     # magnitude down by j * step ulps (sign bit untouched)
-    g = step * 2.0 ** (-7 - mant_bits) * float(vals[e])
+    g = step * 2.0 ** (-b - mant_bits) * float(vals[e])
     return (st.double() * scale).to(tdt), where, g * scale * scale
 
 
 @pytest.mark.parametrize("n,d,dtype", [(4096, 4096, "bf16"), (40000, 4096, "bf16"), (40000, 4096, "f16")])
 def test_cosine_certificate_follows_operand_norms(eng, dlc, n, d, dtype):
     """Rows of norm 8 (queries too: scores x 64, the score pass's fp32 error x 64).  A ladder of 40 near-copies of the query
-    row in 40 groups, fp64 scores 4.6e-5 apart (x 64 of 7e-7): the k-th (20th) score clears the best row left behind
-    (the 25th) by 2.3e-4 -- MORE than the static tau (1.6e-5, derived for norms <= 1.005: include/dlc.h NORMS), LESS than
-    what the score pass can err by on these operands (tau x 64).  The static tau would certify on margin; the database
+    row in 40 groups, fp64 scores ~3 tau apart (tau of the shape's plan: 1.6e-5 one-pass, 1.2e-6 split-K): the k-th (20th)
+    score clears the best row left behind (the 25th) by ~15 tau -- MORE than the static tau (derived for norms <= 1.005:
+    include/dlc.h NORMS), LESS than what the score pass can err by on these operands (tau x 64).  The static tau would certify on margin; the database
     measures its rows' norms (stored=True), the certificate follows them, the query goes through the exhaustive pass
     (status 2) and the list is the fp64 oracle's index for index -- small-database plan (4096 rows), standard plan, fp16;
     one-shot call, two-stream pipeline and the sharded protocol (4 shards, every entry point that takes tau_scale)."""
     from oracle import cosine as ocos
     k, nq = 20, 6
-    rows_h, where, g = _ladder_database(n, d, dtype, seed=n + d)
+    tau = eng.score_error_bound(nq, n, d, k)
+    rows_h, where, g = _ladder_database(n, d, dtype, seed=n + d, g_unit=tau / 20)
     db = dlc.KeyframeDatabase(rows_h, dtype=dtype, stored=True)
     assert db.norm_bound is not None and 8.0 <= float(db.norm_bound) <= 8.1
     q = db.rows[torch.tensor([17, 100, 101, 102, 103, 104], device=eng.device)].clone()
     ts = db.tau_scale(q)
-    tau = eng.score_error_bound(nq, n, d, k)
     assert ts.shape == (nq,) and 63.0 < float(ts.min()) and float(ts.max()) < 65.0
     es, ei = ocos.cosine_topk(q.double().cpu().numpy(), rows_h.double().numpy(), k)
     assert ei[0].tolist() == where[:k].tolist()                              # the ladder's first 20 rungs, in order
     gap = es[0, k - 1] - float(q[0].double() @ db.rows[int(where[k + 4])].double())
-    assert tau < 0.7 * gap and gap < 0.5 * tau * float(ts[0])               # the window the test is about (see above)
+    assert 2 * tau < gap < 0.5 * tau * float(ts[0])                         # the window the test is about (see above)
     top = db.match_topk(q, k, details=True)
     torch.cuda.synchronize()
     assert int(top.status[0]) == 2 and set(top.status.cpu().tolist()) <= {0, 2}
