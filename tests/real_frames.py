@@ -62,3 +62,27 @@ def tiled_bgr_frames(dlc, n_frames):
         have += t.shape[0]
         c += 1
     return torch.cat(tiles)[:n_frames]
+
+
+def tiled_u8_frames(dlc, n_frames):
+    """[n_frames, 192, 240, 3] uint8 RGB on the HOST -- what a script reads from disk before anything runs
+    (create_similarity_matrix.py:23-26, create_distance_matrix.py:20-25; cv2.imread's BGR is this array's [..., ::-1]):
+    the 20 real frames, then copies -- copies 0 and 1 exact, later ones with a handful of pixel values moved by +-1,
+    every seventh one also with a blanked 32 x 32 block."""
+    base = np.stack([dlc.read_ppm(p) for p in frame_paths()])                                      # [20, 192, 240, 3]
+    rng = np.random.RandomState(28)
+    tiles, have, c = [base], base.shape[0], 0
+    while have < n_frames:
+        t = base.astype(np.int16)
+        if c >= 2:
+            for f in range(base.shape[0]):
+                for _ in range(3 + c % 7):
+                    t[f, rng.randint(192), rng.randint(240), rng.randint(3)] += 1 if rng.rand() < 0.5 else -1
+            np.clip(t, 0, 255, out=t)
+        if c >= 4 and c % 7 == 3:
+            y0, x0 = rng.randint(160), rng.randint(208)
+            t[:, y0:y0 + 32, x0:x0 + 32] = 0
+        tiles.append(t.astype(np.uint8))
+        have += base.shape[0]
+        c += 1
+    return np.ascontiguousarray(np.concatenate(tiles)[:n_frames])

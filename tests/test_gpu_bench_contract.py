@@ -57,7 +57,29 @@ def test_bench_json_contract():
                           "LoopClosureDetector.query_and_insert (batches of 32 frames)",
                           "SdavLoopClosureDetector.query_and_insert (batches of 32 frames)",
                           "cosine similarity matrix (flattened SDAV descriptors)",
-                          "cosine top-20 (flattened SDAV descriptors)", "CnnVtl.transform", "cnn_vtl distance matrix"}
+                          "cosine top-20 (flattened SDAV descriptors)", "CnnVtl.transform", "cnn_vtl distance matrix",
+                          "configs[1] end to end: 24 frames -> patches -> SDAV -> similarity matrix, fp64 encoder (parity mode)",
+                          "configs[1] end to end: 24 frames -> patches -> SDAV -> similarity matrix, f16x2 encoder (tolerance mode)",
+                          "configs[2] end to end: 24 frames -> CnnVtl -> distance matrix",
+                          "configs[0] end to end: 20 real frames -> patches -> SDAV -> 20 x 20 cosine matrix"}
+    # BASELINE configs[1] / configs[2] as one device-resident path each: the matrix of the composed call is the staged calls'
+    for name in [n_ for n_ in paths if n_.startswith(("configs[1]", "configs[2]"))]:
+        row = paths[name]
+        assert row["equals_staged_calls_bit_for_bit"] is True and row["device_resident_ms"] > 0 and row["host_to_host_ms"] > 0
+        assert abs(sum(row["stage_ms_device_resident"].values()) - row["device_resident_ms"]) < 0.5 * row["device_resident_ms"] + 1.0
+    assert paths["configs[2] end to end: 24 frames -> CnnVtl -> distance matrix"]["bit_exact_vs_oracle_on_the_sample"] is True
+    assert paths["configs[1] end to end: 24 frames -> patches -> SDAV -> similarity matrix, fp64 encoder (parity mode)"][
+        "matrix_agreement_with_oracle_on_the_sample"] > 0.99
+    assert paths["configs[0] end to end: 20 real frames -> patches -> SDAV -> 20 x 20 cosine matrix"]["max_abs_err_vs_oracle"] < 2e-3
+    # BASELINE configs[3] / configs[4]: a timed one-GPU row each + rank 0's step of the 8-GPU form, merged result == one-shot result
+    cfg = {c_["config"]: c_ for c_ in d["baseline_configs"]}
+    assert set(cfg) == {3, 4} and cfg[3]["dtype"] == "bf16" and cfg[4]["dtype"] == "f16" and cfg[4]["db_rows"] == 30000
+    for c_ in cfg.values():
+        assert c_["value"] > 0 and c_["ms_per_step"] > 0 and c_["recall_at_1_of_planted_rows_in_this_db"] == 1.0
+        assert 0 < c_["roofline"]["frac"] < 1 and c_["roofline"]["kernel_ms"] <= c_["ms_per_step"] * 1.001
+        e8 = c_["eight_gpu_emulation"]
+        assert e8["ranks"] == 8 and e8["merged_result_equals_one_gpu"] is True and "EMULATED" in e8["label"]
+    assert d["roofline"]["frac_of_measured_copy"] > d["roofline"]["frac"]
     assert paths["SDAV.transform (f16x2 split, tolerance mode)"]["rel_l2_vs_fp64_encoder_max"] < 1e-4
     for name in ("N(0,1) weights", "1/sqrt(fan_in) weights"):
         row = paths["SDAV similarity matrix, real-frame statistics, " + name]
@@ -68,7 +90,8 @@ def test_bench_json_contract():
     assert paths["SdavLoopClosureDetector.query_and_insert (batches of 32 frames)"]["stream_poisoned"] == 0
     for p in d["paths"]:
         pr, pc = p["roofline"], p["cpu_baseline"]
-        assert p["frames"] == (10 if "train_step" in p["path"] else 24) and p["value"] > 0 and p["ms"] > 0 and p["reference"]
+        assert p["frames"] == (10 if "train_step" in p["path"] else 20 if p["path"].startswith("configs[0]") else 24)
+        assert p["value"] > 0 and p["ms"] > 0 and p["reference"]
         assert pr["bound"] in ("hbm", "mfma") and pr["achieved"] > 0 and abs(pr["frac"] - pr["achieved"] / pr["peak"]) < 1e-9
         assert pr["kernel_ms"] > 0 and pr["kernel_ms"] <= pr["call_ms"] * 1.001 and "traffic" in pr
         assert pc["kind"] == "port" and pc["value"] > 0 and pc["cores"] >= 1 and pc["unit"] == p["unit"] and pc["sample"]
@@ -119,3 +142,24 @@ def test_bench_launches_its_own_ranks():
         assert got["n_gpus"] == ranks and got["rccl_smoke"]["pipeline_equals_plain_exchange"] is True
         assert got["recall_at_1"] == 1.0
         assert got["topk_idx_sha256"] == one["topk_idx_sha256"] and got["topk_scores_sha256"] == one["topk_scores_sha256"]
+
+
+def test_sharded_exhaustive_round_across_processes():
+    """`bench.py --crowded`: query 0's planted row copied to kg * 8 + 1 places spread over every shard -- its k-th score
+    ties with a row every selection leaves behind, so NO merge can certify it.  One rank resolves it inside its one-shot
+    call; two real processes (gloo, sharing the GPU) must take MatchPipeline._resolve -- the exhaustive pass on every rank,
+    a third all-gather, a merge -- for every batch, agree on the flags (nobody hangs in a collective the other skipped),
+    drop nothing and return exactly the one-rank lists."""
+    common = ["--steps", "5", "--warmup", "2", "--rows", "40000", "--no-cpu-baseline", "--no-power-probe", "--no-paths",
+              "--no-shard-emulation", "--crowded"]
+    one = run_bench(["--gpus", "1"] + common)
+    port = 29900 + os.getpid() % 90
+    two = run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
+                    launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port)])
+    assert one["config"]["crowded"] is True and two["config"]["crowded"] is True and two["n_gpus"] == 2
+    p = two["pipeline"]
+    assert p["resolved_batches"] >= 5 and p["dropped_batches"] == 0            # every timed batch went through the round
+    assert two["rccl_smoke"]["pipeline_equals_plain_exchange"] is True and two["rccl_smoke"]["resolved_batches"] == 3
+    assert two["topk_idx_sha256"] == one["topk_idx_sha256"] and two["topk_scores_sha256"] == one["topk_scores_sha256"]
+    assert one["recall_at_1"] == 1.0 and two["recall_at_1"] == 1.0
