@@ -12,16 +12,29 @@
 // at the same MFMA rate per product.  The products of two fp16 values are exact in fp32; what is left is the fp32
 // accumulation over K = 2500 (1.7e-5 of the descriptor norm through five saturating layers) and the fp32 sigmoid.
 //
-// Kernel.  The three products are ONE plain GEMM over K' = 3 K: K tile 3 t pairs (h1, W1) at k-tile t, 3 t + 1 (h1, W2),
-// 3 t + 2 (h2, W1) -- only the DMA's base pointers know; a piece's k-tile is read again one or two K tiles after its first
-// use, out of L2 (segment by segment -- all of (h1, W1), then all of (h1, W2), ... -- every re-read went back over the
-// fabric: 4 % slower, at 1.5e-5 instead of 2.1e-5 of error: the small products then reach the accumulator last).
-// Main loop = the cosine match's score GEMM (cosine_topk.hip: 256 x 256 tile, BK = 64, 8 waves of 128 x 64, LDS-DMA rings, snake order of eight mini-phases per K
-// tile), with the roles turned: MFMA A operand = 256 weight columns (fragment rows permuted so that a lane's sixteen
-// accumulators of a half are sixteen CONSECUTIVE output columns n), B operand = 256 activation rows (a lane holds ONE
-// row m).  The epilogue therefore writes, per lane, runs of sixteen consecutive outputs of one row: bias + sigmoid in fp32,
-// then either the next layer's two fp16 pieces (32 bytes each) or, for the last layer, sixteen fp64 values.  The
-// activations never exist as fp64 between the layers.
+// Kernel.  The three products of a k-slice share ONE set of operands (r04 ran them as one plain GEMM over K' = 3 K: six
+// operand tiles staged and six sets of fragments read per 64-deep k-tile, where four are distinct -- DMA issue and LDS
+// fragment reads were worth 17 % of the kernel each, docs/LAB.md 10.2).  Per 32-deep k-slice (one MFMA of K) the four
+// tiles W1, W2 (256 weight columns), h1, h2 (256 activation rows) are staged once (64 KiB by LDS-DMA), each wave reads its
+// fragments of the four once (W1, W2: 8 x 16 B per lane; h1, h2: 4 x 16 B) and issues 96 MFMAs from registers:
+//   P1 = h1 . W1,  P2 = h2 . W1,  P3 = h1 . W2       (8 x 4 tiles of 16 x 16 each, v_mfma_f32_16x16x32_f16)
+// with ONE workgroup barrier per slice (r04: four per 64 MFMAs): after P2 every wave has read the whole stage, its refill
+// (slice s + 2) is issued behind the barrier and lands during P3 (s), P1, P2 (s + 1); the fragments of W1, h1 (s + 1) are
+// read during P3 (s), h2 during P1, W2 during P2 -- 96 fragment registers, two LDS stages (128 KiB).
+//
+// Operand format ("K32-major", private to this file -- both operands are written by kernels here): element (row r, k) of a
+// piece lives at byte ((k / 32) * rows_pad + r) * 64 + (k % 32) * 2, so that the 256 rows x 32 k of one tile and slice are
+// ONE contiguous 16 KiB block: sixteen LDS-DMA wave-instructions of 1 KiB, every one a fully coalesced read (a row-major
+// operand would hand each of them sixteen half lines).  The LDS image is that block with the four 16-byte slots of a row
+// XOR-ed by 2 * bit 3 of the row (on the DMA's per-lane source offset; the destination is lane-linear), which makes the
+// fragment reads -- lane (i, kq) takes slot kq of row i of a 16-row block, ds_read_b128 -- conflict-free in each of the
+// instruction's four 16-lane groups.
+// Roles: MFMA A operand = 256 weight columns; the weight panel's rows are PERMUTED inside every 64 (column 16 g + 4 t + r
+// sits at row 16 t + 4 g + r) so that sixteen consecutive panel rows are one A fragment whose accumulators are, per lane,
+// sixteen CONSECUTIVE output columns.  B operand = 256 activation rows (a lane holds ONE row m).  The epilogue therefore
+// writes, per lane, runs of sixteen consecutive outputs of one row: bias + sigmoid in fp32, then either the next layer's
+// two fp16 pieces (32 bytes each, K32-major) or, for the last layer, sixteen fp64 values.  The activations never exist as
+// fp64 between the layers.
 // Both operands are re-read (neither is a once-only stream): an XCD's 32 resident workgroups take one br x bc block of
 // tiles, so that br + bc operand panels feed br * bc tiles out of that XCD's L2.
 #include "gemm_internal.h"
@@ -32,26 +45,26 @@ namespace {
 constexpr int SP_BM = 256;                     // weight columns per tile (MFMA A operand)
 constexpr int SP_BN = 256;                     // activation rows per tile (MFMA B operand)
 constexpr int SP_THREADS = 512;
-constexpr int SP_TILE = 256 * 64 * 2;          // one operand's K tile: 256 rows x 128 B = 32 KiB
-constexpr int SP_HALF = 128 * 128;             // a half tile of 128 rows
-constexpr int SP_STAGES = 2;
-constexpr int SP_B_RING = SP_STAGES * SP_TILE;
-constexpr int SP_LDS = 2 * SP_STAGES * SP_TILE;            // 128 KiB
+constexpr int SP_KS = 32;                      // k per slice: one v_mfma_f32_16x16x32_f16
+constexpr int SP_ROWB = SP_KS * 2;             // 64 bytes of a row per slice
+constexpr int SP_OP = 256 * SP_ROWB;           // one operand tile of one slice: 16 KiB, contiguous in memory and in LDS
+constexpr int SP_STAGE = 4 * SP_OP;            // W1 | W2 | h1 | h2
+constexpr int SP_LDS = 2 * SP_STAGE;           // 128 KiB
 constexpr int SP_X_SHIFT = 11;                 // activations are carried as h * 2^11
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct SplitArgs {
-    const char* W[2];           // weight pieces, TRANSPOSED: [Np, ldw] fp16, row n = column n of W (rows >= N, k >= K: zeros)
-    const char* X[2];           // activation pieces [M, ldx] fp16
-    long long ldw_b, ldx_b;     // row strides in bytes
+    const char* W[2];           // weight pieces, K32-major: [K/32][Np rows (permuted inside 64s)][32] fp16 (rows >= N, k >= K: zeros)
+    const char* X[2];           // activation pieces, K32-major: [slices][Mp rows][32] fp16
+    long long wslice_b, xslice_b;   // bytes from one k-slice to the next: Np * 64, Mp * 64
     long long M;                // activation rows
     int N;                      // output columns
-    int nk;                     // K tiles of 64 per piece
+    int ns;                     // k-slices of 32
     const double* bias;         // [N] or null
     const float* wscale;        // device: 2^s of this layer's weights
-    char* O[2];                 // next layer's pieces [M, ldo] fp16 (null for the last layer) ...
-    long long ldo_b;
+    char* O[2];                 // next layer's pieces, K32-major with oslice_b per slice (null for the last layer) ...
+    long long oslice_b;
     double* C;                  // ... whose output is fp64 [M, ldc]
     long long ldc;
     int br, bc;                 // an XCD's block: br tiles of activation rows x bc tiles of weight columns, br * bc <= 32
@@ -60,10 +73,7 @@ struct SplitArgs {
     int tiles_n;                // weight column tiles
 };
 
-__device__ __forceinline__ int swz_a(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }
-__device__ __forceinline__ int swz_b(int r) { return (r >> 1) & 7; }
-
-// Four LDS-DMA wave-instructions (4 x 1 KiB: 32 rows of one half tile); inline asm so that hipcc does not count them in
+// Four LDS-DMA wave-instructions (4 x 1 KiB, consecutive in LDS); inline asm so that hipcc does not count them in
 // vmcnt, M0 saved and restored (cosine_topk.hip: dma4).
 __device__ __forceinline__ void sp_dma4(const unsigned (&voff)[4], const char* sbase, unsigned lds0) {
     unsigned keep;
@@ -85,6 +95,23 @@ __device__ __forceinline__ void sp_dma4(const unsigned (&voff)[4], const char* s
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase), "s"(lds0)
+        : "memory", "scc");
+}
+// ... and two of them (2 x 1 KiB)
+__device__ __forceinline__ void sp_dma2(unsigned v0, unsigned v1, const char* sbase, unsigned lds0) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, %4, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "v"(v1), "s"(sbase), "s"(lds0)
         : "memory", "scc");
 }
 __device__ __forceinline__ const char* sp_uniform_ptr(const char* p) {
@@ -124,139 +151,103 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
     }
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem_sp;
 
-    // ---- DMA roles: waves 0-3 stage the weight (A) halves, waves 4-7 the activation (B) halves
-    const bool is_a = wid < 4;
-    const int ridx = wid & 3;                               // this wave stages rows 32*ridx .. +31 of a half
-    unsigned voff[2][4];                                    // [half][dma]: byte offset of this lane's 16 B
+    // ---- DMA roles: wave w stages half (w & 1) of operand w >> 1 (0 W1, 1 W2, 2 h1, 3 h2): 8 KiB = 8 pieces per slice
+    const int op = wid >> 1;
+    unsigned voff[4];                                       // this lane's 16 B inside pieces 0 .. 3 (pieces 4 .. 7: base + 4 KiB)
     {
-        const int slot = lane & 7;
-        const long long brows = p.M - tile_m * SP_BN;       // valid activation rows in this tile (>= 1)
+        const int row = lane >> 2, slot = lane & 3;         // a piece = 16 rows x 4 slots; LDS slot s of row r holds source slot s ^ 2 * bit3(r)
+        const unsigned in_piece = (unsigned)(row * SP_ROWB + ((slot ^ (((row >> 3) & 1) << 1)) << 4));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = 32 * ridx + 8 * j + (lane >> 3);  // row inside the half
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const long long ar = (r >> 6) * 128 + h * 64 + (r & 63);         // (the weight panels hold whole tiles)
-                long long br = (r >> 5) * 64 + h * 32 + (r & 31);
-                if (br > brows - 1) br = brows - 1;
-                voff[h][j] = is_a ? (unsigned)(ar * p.ldw_b + ((slot ^ swz_a(r)) << 4))
-                                  : (unsigned)(br * p.ldx_b + ((slot ^ swz_b(r)) << 4));
-            }
-        }
+        for (int j = 0; j < 4; ++j) voff[j] = in_piece + (unsigned)j * 1024u;
     }
-    // this wave's two piece bases, and the segment of a k-tile's three products (0: h1 W1, 1: h1 W2, 2: h2 W1) that takes its second piece
-    const char* base0 = sp_uniform_ptr(is_a ? p.W[0] + (long long)tile_n * SP_BM * p.ldw_b : p.X[0] + tile_m * SP_BN * p.ldx_b);
-    const char* base1 = sp_uniform_ptr(is_a ? p.W[1] + (long long)tile_n * SP_BM * p.ldw_b : p.X[1] + tile_m * SP_BN * p.ldx_b);
-    const int seg1 = is_a ? 1 : 2;
-    const unsigned lds_stage = lds_base + (unsigned)(32 * ridx) * 128 + (is_a ? 0u : (unsigned)SP_B_RING);
-    const int nk3 = 3 * p.nk;
+    const long long slice_b = op < 2 ? p.wslice_b : p.xslice_b;
+    const char* src = sp_uniform_ptr((op < 2 ? p.W[op] + (long long)tile_n * SP_BM * SP_ROWB
+                                             : p.X[op - 2] + tile_m * SP_BN * SP_ROWB) + (wid & 1) * (SP_OP / 2));
+    const unsigned lds_stage = lds_base + (unsigned)op * SP_OP + (unsigned)(wid & 1) * (SP_OP / 2);
+    const int ns = p.ns;
 
-    // ---- fragment read offsets (bytes inside a half)
+    // ---- fragment read addresses: lane (i, kq) -> row i, slot kq ^ 2 * bit3(i) of a 16-row block
     const int i = lane & 15;
     const int kq = lane >> 4;
-    const int fa = ((i >> 1) & 1) | ((i >> 2) << 1);
-    const int fb = (i >> 1) & 7;
     typedef const __attribute__((address_space(3))) u32x4_t* lds_u4p;
     typedef const __attribute__((address_space(3))) char* lds_cp;
     const lds_cp lbase = (lds_cp)(lptr_t)smem_sp;
-    const unsigned rdA0_l = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((0 + kq) ^ fa) << 4);   // + tt*512
-    const unsigned rdA1_l = (wr * 64 + 16 * (i >> 2) + (i & 3)) * 128 + (((4 + kq) ^ fa) << 4);
-    const unsigned rdB0_l = SP_B_RING + (wc * 32 + i) * 128 + (((0 + kq) ^ fb) << 4);             // + c*2048
-    const unsigned rdB1_l = SP_B_RING + (wc * 32 + i) * 128 + (((4 + kq) ^ fb) << 4);
-    unsigned aoff = 0, boff = 0;
-    unsigned rdA0 = rdA0_l, rdA1 = rdA1_l, rdB0 = rdB0_l, rdB1 = rdB1_l;
+    const unsigned rd_l = (unsigned)(i * SP_ROWB + ((kq ^ (((i >> 3) & 1) << 1)) << 4));
+    const unsigned rdA = rd_l + (unsigned)wr * (SP_OP / 2);                       // W1 of stage 0 (+ SP_OP: W2), fragment T at + T KiB
+    const unsigned rdB = rd_l + 2u * SP_OP + (unsigned)wc * (SP_OP / 4);          // h1 of stage 0 (+ SP_OP: h2), fragment c at + c KiB
 
     f32x4_t acc[8][4];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    u32x4_t faX[4], faY[4], fbX[2], fbY[2];
+    u32x4_t fW1[8], fW2[8], fhA[4], fhB[4];
 
-#define SP_READ_A(DST, RD, OFF) _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) DST[tt] = *(lds_u4p)(lbase + (RD) + (OFF) + tt * 512)
-#define SP_READ_B(DST, RD, OFF) _Pragma("unroll") for (int c = 0; c < 2; ++c) DST[c] = *(lds_u4p)(lbase + (RD) + (OFF) + c * 2048)
-#define SP_MFMA(FA, FB, AH, BH)                                                                                  \
+#define SP_READ_W(DST, ST, WHICH) _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) DST[tt] = *(lds_u4p)(lbase + rdA + (ST) * SP_STAGE + (WHICH) * SP_OP + tt * 1024)
+#define SP_READ_H(DST, ST, WHICH) _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = *(lds_u4p)(lbase + rdB + (ST) * SP_STAGE + (WHICH) * SP_OP + c * 1024)
+    // tiles T0 .. T0 + NT - 1 of one product (NT x 4 MFMAs)
+#define SP_MFMA(FA, FB, T0, NT)                                                                                  \
     do {                                                                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                           \
-        _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) _Pragma("unroll") for (int c = 0; c < 2; ++c)           \
-            acc[(AH) * 4 + tt][(BH) * 2 + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                           \
-                __builtin_bit_cast(f16x8_t, FA[tt]), __builtin_bit_cast(f16x8_t, FB[c]), acc[(AH) * 4 + tt][(BH) * 2 + c], 0, 0, 0); \
+        _Pragma("unroll") for (int tt = (T0); tt < (T0) + (NT); ++tt) _Pragma("unroll") for (int c = 0; c < 4; ++c) \
+            acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                                 \
+                __builtin_bit_cast(f16x8_t, FA[tt]), __builtin_bit_cast(f16x8_t, FB[c]), acc[tt][c], 0, 0, 0);   \
         __builtin_amdgcn_s_setprio(0);                                                                           \
     } while (0)
-#define SP_RELEASE() SP_WAIT_LGKM0(); sp_barrier()
-    // DMA of half H of K tile t2 into ring position POS (past the end: clamped -- the redundant DMA lands in a dead half
-    // and keeps the vmcnt bookkeeping uniform).  The K tile's segment picks the piece.
-#define SP_ISSUE(POS, H, t2)                                                                                     \
+    // this wave's pieces 2 Q, 2 Q + 1 of slice S2 into stage ST (past the end: clamped -- the redundant DMA lands in a dead
+    // stage and keeps the vmcnt bookkeeping uniform)
+#define SP_ISSUE2(ST, S2, Q)                                                                                     \
     do {                                                                                                         \
-        const int kk_ = (t2) < nk3 ? (t2) : nk3 - 1;                                                             \
-        const int kt_ = kk_ / 3, seg_ = kk_ - 3 * kt_;                                                           \
-        const char* src_ = (seg_ == seg1 ? base1 : base0) + (long long)kt_ * 128;                                \
-        sp_dma4(voff[H], src_, lds_stage + (POS) + (H) * SP_HALF);                                               \
+        const int ss_ = (S2) < ns ? (S2) : ns - 1;                                                               \
+        sp_dma2(voff[(2 * (Q)) & 3], voff[(2 * (Q) + 1) & 3], src + (long long)ss_ * slice_b + ((Q) >> 1) * 4096,  \
+                lds_stage + (ST) * SP_STAGE + ((Q) >> 1) * 4096 + ((Q) & 1) * 2048);                             \
     } while (0)
-#define SP_ISSUE_A(POS, H, t2) do { if (is_a) SP_ISSUE(POS, H, t2); } while (0)
-#define SP_ISSUE_B(POS, H, t2) do { if (!is_a) SP_ISSUE(POS, H, t2); } while (0)
+#define SP_ISSUE8(ST, S2) do { SP_ISSUE2(ST, S2, 0); SP_ISSUE2(ST, S2, 1); SP_ISSUE2(ST, S2, 2); SP_ISSUE2(ST, S2, 3); } while (0)
 
-    // ---- prologue: K tiles 0 and 1 of both operands issued (per-tile order A1, A0 / B0, B1, as the steady state issues them)
-#pragma unroll
-    for (int s_ = 0; s_ < SP_STAGES; ++s_) {
-        SP_ISSUE_A(s_ * SP_TILE, 1, s_);
-        SP_ISSUE_A(s_ * SP_TILE, 0, s_);
-    }
-    SP_ISSUE_B(0 * SP_TILE, 0, 0);
-    SP_ISSUE_B(0 * SP_TILE, 1, 0);
-    SP_ISSUE_B(1 * SP_TILE, 0, 1);
-    SP_ISSUE_B(1 * SP_TILE, 1, 1);
-    SP_WAIT_VMCNT(8);                                          // K tile 0 landed (this wave's share)
+    // One slice (stage ST), entered with W1 and HCUR = h1 of this slice in registers; leaves W1 and HNXT = h1 of the next.
+#define SP_STEP(ST, S, HCUR, HNXT)                                                                               \
+    do {                                                                                                         \
+        SP_READ_H(HNXT, ST, 1);                                    /* h2 (s) */                                   \
+        SP_MFMA(fW1, HCUR, 0, 8);                                  /* P1 = h1 . W1 */                            \
+        SP_READ_W(fW2, ST, 1);                                     /* W2 (s) */                                   \
+        SP_MFMA(fW1, HNXT, 0, 8);                                  /* P2 = h2 . W1 */                            \
+        SP_WAIT_VMCNT(0);                                          /* this wave's share of slice s + 1 landed */  \
+        SP_WAIT_LGKM0();                                           /* ... and its reads of stage ST are done */    \
+        sp_barrier();                                              /* stage ST is free; slice s + 1 is visible */ \
+        SP_READ_W(fW1, (ST) ^ 1, 0);                               /* W1, h1 (s + 1) */                           \
+        SP_READ_H(HNXT, (ST) ^ 1, 0);                                                                            \
+        SP_ISSUE2(ST, (S) + 2, 0);                                                                               \
+        SP_MFMA(fW2, HCUR, 0, 2);                                  /* P3 = h1 . W2, the refill issued between */ \
+        SP_ISSUE2(ST, (S) + 2, 1);                                                                               \
+        SP_MFMA(fW2, HCUR, 2, 2);                                                                                \
+        SP_ISSUE2(ST, (S) + 2, 2);                                                                               \
+        SP_MFMA(fW2, HCUR, 4, 2);                                                                                \
+        SP_ISSUE2(ST, (S) + 2, 3);                                                                               \
+        SP_MFMA(fW2, HCUR, 6, 2);                                                                                \
+    } while (0)
+
+    // ---- prologue: slices 0 and 1 issued; slice 0 landed and visible; W1, h1 (0) read
+    SP_ISSUE8(0, 0);
+    SP_ISSUE8(1, 1);
+    SP_WAIT_VMCNT(8);
     sp_barrier();
-    SP_READ_A(faX, rdA0, 0);
-    SP_READ_B(fbX, rdB0, 0);
-
-    // One K tile = 8 mini-phases of 8 MFMAs (cosine_topk.hip: the same schedule):
-    //   m1 (A0,B0,k0) m2 (A0,B1,k0) m3 (A1,B1,k0) m4 (A1,B0,k0)  m5 (A1,B0,k1) m6 (A1,B1,k1) m7 (A0,B1,k1) m8 (A0,B0,k1)
-    // A half is dead once its k1 slice has been read (A1 after m3, B0 after m4, B1 after m5, A0 after m6): a barrier
-    // there, then the DMA that refills it with K tile t + 2.
-    for (int t = 0; t < nk3; ++t) {
-        SP_READ_B(fbY, rdB0, SP_HALF);
-        SP_MFMA(faX, fbX, 0, 0);                                   // m1
-        SP_READ_A(faY, rdA0, SP_HALF);
-        SP_MFMA(faX, fbY, 0, 1);                                   // m2
-        SP_READ_A(faX, rdA1, SP_HALF);
-        SP_MFMA(faY, fbY, 1, 1);                                   // m3
-        SP_RELEASE();                                              // A1 read by everyone
-        SP_READ_B(fbY, rdB1, 0);
-        SP_ISSUE_A(aoff, 1, t + SP_STAGES);
-        SP_MFMA(faY, fbX, 1, 0);                                   // m4
-        SP_RELEASE();                                              // B0
-        SP_READ_B(fbX, rdB1, SP_HALF);
-        SP_ISSUE_B(boff, 0, t + 2);
-        SP_MFMA(faX, fbY, 1, 0);                                   // m5
-        SP_RELEASE();                                              // B1
-        SP_READ_A(faY, rdA1, 0);
-        SP_ISSUE_B(boff, 1, t + 2);
-        SP_MFMA(faX, fbX, 1, 1);                                   // m6
-        if (is_a) SP_WAIT_VMCNT(4); else SP_WAIT_VMCNT(8);         // K tile t+1 landed (this wave's share)
-        SP_RELEASE();                                              // A0; and t+1 visible to all
-        SP_ISSUE_A(aoff, 0, t + SP_STAGES);
-        aoff ^= SP_TILE;
-        boff ^= SP_TILE;
-        rdA0 = rdA0_l + aoff; rdA1 = rdA1_l + aoff; rdB0 = rdB0_l + boff; rdB1 = rdB1_l + boff;
-        SP_READ_A(faX, rdA0, 0);
-        SP_MFMA(faY, fbX, 0, 1);                                   // m7
-        SP_READ_B(fbX, rdB0, 0);
-        SP_MFMA(faY, fbY, 0, 0);                                   // m8
+    SP_READ_W(fW1, 0, 0);
+    SP_READ_H(fhA, 0, 0);
+    for (int s = 0; s < ns; s += 2) {
+        SP_STEP(0, s, fhA, fhB);
+        if (s + 1 < ns) SP_STEP(1, s + 1, fhB, fhA);
     }
     SP_WAIT_VMCNT(0);    // the clamped tail DMAs must not outlive the workgroup's LDS
     SP_WAIT_LGKM0();
-#undef SP_ISSUE_A
-#undef SP_ISSUE_B
-#undef SP_ISSUE
-#undef SP_READ_A
-#undef SP_READ_B
+#undef SP_STEP
+#undef SP_ISSUE8
+#undef SP_ISSUE2
+#undef SP_READ_W
+#undef SP_READ_H
 #undef SP_MFMA
-#undef SP_RELEASE
 
     // ---- epilogue.  C/D layout: column = lane & 15 -> activation row, row = 4 * (lane >> 4) + reg -> weight column; with
-    // the permuted A rows, acc[th * 4 + tt][c][r] is output (m, n0 + 4 tt + r): sixteen consecutive columns per (c, th).
+    // the permuted panel rows, acc[th * 4 + tt][c][r] is output (m, n0 + 4 tt + r): sixteen consecutive columns per (c, th).
     const int lg = lane >> 4;
     const float inv = 1.0f / ((float)(1 << SP_X_SHIFT) * p.wscale[0]);        // a power of two: exact
     const float xs = (float)(1 << SP_X_SHIFT);
@@ -299,8 +290,10 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
                     w1[j >> 1] = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
                     w2[j >> 1] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
                 }
-                char* o1 = p.O[0] + m * p.ldo_b + (long long)n0 * 2;
-                char* o2 = p.O[1] + m * p.ldo_b + (long long)n0 * 2;
+                // K32-major: columns n0 .. n0 + 15 are half of row m's 64 bytes in slice n0 / 32
+                const long long o = (long long)(n0 >> 5) * p.oslice_b + m * SP_ROWB + (n0 & 16) * 2;
+                char* o1 = p.O[0] + o;
+                char* o2 = p.O[1] + o;
                 *(uint4*)o1 = make_uint4(w1[0], w1[1], w1[2], w1[3]);
                 *(uint4*)(o1 + 16) = make_uint4(w1[4], w1[5], w1[6], w1[7]);
                 *(uint4*)o2 = make_uint4(w2[0], w2[1], w2[2], w2[3]);
@@ -329,10 +322,16 @@ __global__ void sp_scale_kernel(const unsigned long long* amax, float* wscale) {
     s = s > 100 ? 100 : (s < -100 ? -100 : s);
     *wscale = (float)ldexp(1.0, s);
 }
-// W [K, N] fp64 -> its two fp16 pieces transposed, [Np, ldw] each (k contiguous), zeros past K / N: 64 x 64 tiles through LDS
+// panel row of weight column n: inside every 64 columns, column 16 g + 4 t + r sits at row 16 t + 4 g + r (the kernel's header)
+__device__ __forceinline__ long long sp_panel_row(long long n) {
+    const int c = (int)(n & 63);
+    return (n & ~63ll) | (long long)((((c >> 2) & 3) << 4) | ((c >> 4) << 2) | (c & 3));
+}
+// W [K, N] fp64 -> its two fp16 pieces, K32-major [kp / 32][Np rows][32] (k contiguous inside a row's 64 bytes), zeros past
+// K / N: 64 x 64 tiles through LDS
 __global__ __launch_bounds__(256) void sp_split_weights_kernel(const double* __restrict__ w, long long K, long long N, const float* wscale,
                                                                unsigned short* __restrict__ p1, unsigned short* __restrict__ p2,
-                                                               long long ldw) {
+                                                               long long np) {
     __shared__ float t1[64][65], t2[64][65];
     const long long n0 = (long long)blockIdx.x * 64, k0 = (long long)blockIdx.y * 64;
     const double sc = (double)wscale[0];
@@ -347,23 +346,26 @@ __global__ __launch_bounds__(256) void sp_split_weights_kernel(const double* __r
     }
     __syncthreads();
     for (int nn = ty; nn < 64; nn += 4) {
-        const long long o = (n0 + nn) * ldw + k0 + tx;
+        const long long k = k0 + tx;
+        const long long o = ((k >> 5) * np + sp_panel_row(n0 + nn)) * SP_KS + (k & 31);
         p1[o] = __builtin_bit_cast(unsigned short, (_Float16)t1[tx][nn]);
         p2[o] = __builtin_bit_cast(unsigned short, (_Float16)t2[tx][nn]);
     }
 }
-// x [rows, K] fp64 -> the two fp16 pieces of x 2^11, [rows, ldx] each, zeros past K
-__global__ __launch_bounds__(256) void sp_split_rows_kernel(const double* __restrict__ x, long long rows, long long K,
+// x [rows, K] fp64 -> the two fp16 pieces of x 2^11, K32-major [kp / 32][mp rows][32], zeros past K (rows past `rows` are
+// never read into a stored output and stay unwritten)
+__global__ __launch_bounds__(256) void sp_split_rows_kernel(const double* __restrict__ x, long long rows, long long K, long long kp,
                                                             unsigned short* __restrict__ p1, unsigned short* __restrict__ p2,
-                                                            long long ldx) {
-    const long long total = rows * ldx;
+                                                            long long mp) {
+    const long long total = rows * kp;
     const double sc = (double)(1 << SP_X_SHIFT);
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long r = e / ldx, k = e - r * ldx;
+        const long long r = e / kp, k = e - r * kp;
         const double v = k < K ? x[r * K + k] * sc : 0.0;
         const _Float16 a = (_Float16)v;
-        p1[e] = __builtin_bit_cast(unsigned short, a);
-        p2[e] = __builtin_bit_cast(unsigned short, (_Float16)(v - (double)a));
+        const long long o = ((k >> 5) * mp + r) * SP_KS + (k & 31);
+        p1[o] = __builtin_bit_cast(unsigned short, a);
+        p2[o] = __builtin_bit_cast(unsigned short, (_Float16)(v - (double)a));
     }
 }
 
@@ -374,7 +376,7 @@ struct PanelLayout {
 PanelLayout panel_layout(int64_t K, int64_t N) {
     PanelLayout L;
     L.np = (long long)dlc::align_up((size_t)N, (size_t)SP_BM);
-    L.kp = (long long)dlc::align_up((size_t)K, 64);
+    L.kp = (long long)dlc::align_up((size_t)K, 64);           // (whole 64 x 64 tiles of the preparation kernel; the GEMM walks align(K, 32))
     L.scale = 0; L.amax = 8;
     L.p1 = 256;
     L.p2 = L.p1 + dlc::align_up((size_t)L.np * L.kp * 2, 256);
@@ -401,34 +403,37 @@ int split_prepare(dlc_ctx* ctx, int n_layers, const int64_t* dims, const double*
         hipLaunchKernelGGL(sp_scale_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)(base + L.amax), (float*)(base + L.scale));
         hipLaunchKernelGGL(sp_split_weights_kernel, dim3((unsigned)(L.np / 64), (unsigned)(L.kp / 64)), dim3(256), 0, st, W[l],
                            (long long)dims[l], (long long)dims[l + 1], (const float*)(base + L.scale), (unsigned short*)(base + L.p1),
-                           (unsigned short*)(base + L.p2), L.kp);
+                           (unsigned short*)(base + L.p2), L.np);
         DLC_LAUNCH_CHECK(ctx, "sp_split_weights_kernel");
         off += L.total;
     }
     return DLC_OK;
 }
 
-// the activation pieces' row pitch (elements) for a layer input of width K: whole output tiles of the layer before
-static long long split_pitch(int64_t K) { return (long long)dlc::align_up((size_t)K, (size_t)SP_BM); }
+// the k-slices an activation piece holds for a layer input of width K: whole 256-column output tiles of the layer before
+static long long split_slices(int64_t K) { return (long long)dlc::align_up((size_t)K, (size_t)SP_BM) / SP_KS; }
+// ... and its rows: whole 256-row tiles (the GEMM stages full tiles; rows past the last are never stored)
+static long long split_rows_pad(int64_t rows) { return (long long)dlc::align_up((size_t)rows, (size_t)SP_BN); }
 
 size_t split_encode_workspace_bytes(int64_t rows, const int64_t* dims, int n_layers) {
-    long long wmax = 0;
-    for (int l = 0; l < n_layers; ++l) wmax = split_pitch(dims[l]) > wmax ? split_pitch(dims[l]) : wmax;
-    return 4 * dlc::align_up((size_t)rows * (size_t)wmax * 2, 256);          // two ping-pong buffers of two pieces
+    long long smax = 0;
+    for (int l = 0; l < n_layers; ++l) smax = split_slices(dims[l]) > smax ? split_slices(dims[l]) : smax;
+    return 4 * dlc::align_up((size_t)split_rows_pad(rows) * (size_t)smax * SP_ROWB, 256);          // two ping-pong buffers of two pieces
 }
 
 int split_encode(dlc_ctx* ctx, int64_t rows, int n_layers, const int64_t* dims, const double* x, const char* panels,
                  const double* const* b, double* out, char* ws, hipStream_t st) {
-    long long wmax = 0;
-    for (int l = 0; l < n_layers; ++l) wmax = split_pitch(dims[l]) > wmax ? split_pitch(dims[l]) : wmax;
-    const size_t piece = dlc::align_up((size_t)rows * (size_t)wmax * 2, 256);
+    long long smax = 0;
+    for (int l = 0; l < n_layers; ++l) smax = split_slices(dims[l]) > smax ? split_slices(dims[l]) : smax;
+    const long long mp = split_rows_pad(rows);
+    const size_t piece = dlc::align_up((size_t)mp * (size_t)smax * SP_ROWB, 256);
     char* buf[2][2] = {{ws, ws + piece}, {ws + 2 * piece, ws + 3 * piece}};
     {
-        const long long ldx = split_pitch(dims[0]);
-        long long blocks = dlc::cdiv(rows * ldx, (int64_t)256);
+        const long long kp = (long long)dlc::align_up((size_t)dims[0], (size_t)SP_KS);
+        long long blocks = dlc::cdiv(rows * kp, (int64_t)256);
         if (blocks > 256 * 32) blocks = 256 * 32;
-        hipLaunchKernelGGL(sp_split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (long long)rows, (long long)dims[0],
-                           (unsigned short*)buf[0][0], (unsigned short*)buf[0][1], ldx);
+        hipLaunchKernelGGL(sp_split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (long long)rows, (long long)dims[0], kp,
+                           (unsigned short*)buf[0][0], (unsigned short*)buf[0][1], mp);
         DLC_LAUNCH_CHECK(ctx, "sp_split_rows_kernel");
     }
     if (!(ctx->func_attr_set & (1ull << DLC_ATTR_SPLIT_F16))) {
@@ -441,14 +446,14 @@ int split_encode(dlc_ctx* ctx, int64_t rows, int n_layers, const int64_t* dims, 
         const PanelLayout L = panel_layout(dims[l], dims[l + 1]);
         const char* base = panels + off;
         SplitArgs a;
-        a.W[0] = base + L.p1; a.W[1] = base + L.p2; a.ldw_b = L.kp * 2;
-        a.X[0] = buf[l & 1][0]; a.X[1] = buf[l & 1][1]; a.ldx_b = split_pitch(dims[l]) * 2;
-        a.M = rows; a.N = (int)dims[l + 1]; a.nk = (int)(L.kp / 64);
+        a.W[0] = base + L.p1; a.W[1] = base + L.p2; a.wslice_b = L.np * SP_ROWB;
+        a.X[0] = buf[l & 1][0]; a.X[1] = buf[l & 1][1]; a.xslice_b = mp * SP_ROWB;
+        a.M = rows; a.N = (int)dims[l + 1]; a.ns = (int)dlc::cdiv(dims[l], (int64_t)SP_KS);
         a.bias = b ? b[l] : nullptr;
         a.wscale = (const float*)(base + L.scale);
         const bool fin = l == n_layers - 1;
         a.O[0] = fin ? nullptr : buf[(l + 1) & 1][0]; a.O[1] = fin ? nullptr : buf[(l + 1) & 1][1];
-        a.ldo_b = fin ? 0 : split_pitch(dims[l + 1]) * 2;
+        a.oslice_b = fin ? 0 : mp * SP_ROWB;
         a.C = fin ? out : nullptr; a.ldc = dims[l + 1];
         a.tiles_m = dlc::cdiv(rows, (int64_t)SP_BN);
         a.tiles_n = (int)(L.np / SP_BM);
@@ -525,10 +530,6 @@ extern "C" int dlc_sdav_encode_split(dlc_ctx* ctx, int64_t rows, int n_layers, c
         return dlc::fail(ctx, DLC_ERR_WORKSPACE, "sdav_encode_split: workspace %zu < %zu bytes", workspace_bytes, need);
     if (((uintptr_t)workspace & 255) || ((uintptr_t)panels & 255))
         return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_encode_split: workspace and panels must be 256-byte aligned");
-    // per-lane DMA offsets are 32-bit: 256 rows of the widest operand
-    for (int l = 0; l < n_layers; ++l)
-        if ((long long)dlc::align_up((size_t)dims[l], 256) * 2 * 256 > 0x7fffffffll)
-            return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_encode_split: dims[%d] too wide", l);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     return dlc_gemm::split_encode(ctx, rows, n_layers, dims, x, (const char*)panels, b, out, (char*)workspace, (hipStream_t)stream);
