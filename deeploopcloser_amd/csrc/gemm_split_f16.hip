@@ -18,9 +18,14 @@
 // tiles W1, W2 (256 weight columns), h1, h2 (256 activation rows) are staged once (64 KiB by LDS-DMA), each wave reads its
 // fragments of the four once (W1, W2: 8 x 16 B per lane; h1, h2: 4 x 16 B) and issues 96 MFMAs from registers:
 //   P1 = h1 . W1,  P2 = h2 . W1,  P3 = h1 . W2       (8 x 4 tiles of 16 x 16 each, v_mfma_f32_16x16x32_f16)
-// with ONE workgroup barrier per slice (r04: four per 64 MFMAs): after P2 every wave has read the whole stage, its refill
-// (slice s + 2) is issued behind the barrier and lands during P3 (s), P1, P2 (s + 1); the fragments of W1, h1 (s + 1) are
-// read during P3 (s), h2 during P1, W2 during P2 -- 96 fragment registers, two LDS stages (128 KiB).
+// with ONE workgroup barrier per slice (r04: four per 64 MFMAs), behind P1: by then every wave holds all four fragment
+// sets of the slice (W1, h1 were read during P3 of the slice before, h2 and W2 between P1's MFMAs) and the slice's LDS is
+// dead.  The LDS is a ring of 2 1/2 slices, all 160 KiB: two slots for (W2, h2) pairs, three for (W1, h1) pairs.  Behind the
+// barrier of slice s the loaders issue (W2, h2) of slice s + 2 -- wanted one period later -- and then (W1, h1) of slice
+// s + 3, which has TWO periods to land: the wait in front of a barrier leaves the youngest (W1, h1) pair in flight, so the
+// L2 -> LDS stream never drains (with two whole-slice stages every refill had to be issued behind one barrier and land in
+// front of the next: 64 KiB take ~2900 cycles round trip on a CU, the slice's MFMAs 3072 -- the period was their sum's
+// better part, 3900 cycles; in-kernel stamps, docs/LAB.md 11.3).
 //
 // Operand format ("K32-major", private to this file -- both operands are written by kernels here): element (row r, k) of a
 // piece lives at byte ((k / 32) * rows_pad + r) * 64 + (k % 32) * 2, so that the 256 rows x 32 k of one tile and slice are
@@ -48,8 +53,10 @@ constexpr int SP_THREADS = 512;
 constexpr int SP_KS = 32;                      // k per slice: one v_mfma_f32_16x16x32_f16
 constexpr int SP_ROWB = SP_KS * 2;             // 64 bytes of a row per slice
 constexpr int SP_OP = 256 * SP_ROWB;           // one operand tile of one slice: 16 KiB, contiguous in memory and in LDS
-constexpr int SP_STAGE = 4 * SP_OP;            // W1 | W2 | h1 | h2
-constexpr int SP_LDS = 2 * SP_STAGE;           // 128 KiB
+constexpr int SP_PAIR_B = 2 * SP_OP;           // a slot: one weight tile + one activation tile of a slice, 32 KiB
+constexpr int SP_RING_B = 0;                   // (W2, h2) slots 0, 1
+constexpr int SP_RING_A = 2 * SP_PAIR_B;       // (W1, h1) slots 0, 1, 2
+constexpr int SP_LDS = 5 * SP_PAIR_B;          // 160 KiB: all of a CU's LDS
 constexpr int SP_X_SHIFT = 11;                 // activations are carried as h * 2^11
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -73,45 +80,45 @@ struct SplitArgs {
     int tiles_n;                // weight column tiles
 };
 
-// Four LDS-DMA wave-instructions (4 x 1 KiB, consecutive in LDS); inline asm so that hipcc does not count them in
-// vmcnt, M0 saved and restored (cosine_topk.hip: dma4).
-__device__ __forceinline__ void sp_dma4(const unsigned (&voff)[4], const char* sbase, unsigned lds0) {
+// LDS-DMA wave-instructions of 1 KiB each: inline asm so that hipcc does not count them in vmcnt, M0 saved and restored
+// (cosine_topk.hip: dma4).  The instruction's immediate offset is
+// added to the global address AND to the LDS address (M0 + offset + 16 * lane), and a run is laid out alike on both
+// sides: one address register and one M0 value serve every piece of it.
+// Four pieces (a 4 KiB run) in one statement, SKIPPED by a wave whose `on` is 0: the jump is inside the statement, so that
+// the compiler sees straight-line code (a C-level `if` around the statement -- basic blocks inside the k loop -- cost the
+// register allocator its footing at 252 of 256 registers: spills).
+__device__ __forceinline__ void sp_dma4(unsigned on, unsigned voff, const char* sbase, unsigned lds0) {
     unsigned keep;
     asm volatile(
+        "s_cmp_eq_u32 %4, 0\n\t"
+        "s_cbranch_scc1 .Lsp_skip_%=\n\t"
         "s_nop 4\n\t"
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %6\n\t"
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %5\n\t"
-        "s_add_u32 m0, %6, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %5\n\t"
-        "s_add_u32 m0, %6, 0x800\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %5\n\t"
-        "s_add_u32 m0, %6, 0xc00\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, %5\n\t"
-        "s_mov_b32 m0, %0"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        "s_mov_b32 m0, %0\n"
+        ".Lsp_skip_%=:"
         : "=&s"(keep)
-        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase), "s"(lds0)
+        : "v"(voff), "s"(sbase), "s"(lds0), "s"(on)
         : "memory", "scc");
 }
-// ... and two of them (2 x 1 KiB)
-__device__ __forceinline__ void sp_dma2(unsigned v0, unsigned v1, const char* sbase, unsigned lds0) {
-    unsigned keep;
+// s_waitcnt vmcnt(N0) for a wave whose `sel` is 0, vmcnt(N1) otherwise -- the choice inside the statement (see sp_dma4)
+template <int N0, int N1>
+__device__ __forceinline__ void sp_wait_vmcnt_by(unsigned sel) {
     asm volatile(
-        "s_nop 4\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "s_add_u32 m0, %4, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %3\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(v0), "v"(v1), "s"(sbase), "s"(lds0)
+        "s_cmp_eq_u32 %0, 0\n\t"
+        "s_cbranch_scc1 .Lsp_w0_%=\n\t"
+        "s_waitcnt vmcnt(%2)\n\t"
+        "s_branch .Lsp_w1_%=\n"
+        ".Lsp_w0_%=:\n\t"
+        "s_waitcnt vmcnt(%1)\n"
+        ".Lsp_w1_%=:"
+        :
+        : "s"(sel), "n"(N0), "n"(N1)
         : "memory", "scc");
 }
 __device__ __forceinline__ const char* sp_uniform_ptr(const char* p) {
@@ -151,19 +158,26 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
     }
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem_sp;
 
-    // ---- DMA roles: wave w stages half (w & 1) of operand w >> 1 (0 W1, 1 W2, 2 h1, 3 h2): 8 KiB = 8 pieces per slice
-    const int op = wid >> 1;
-    unsigned voff[4];                                       // this lane's 16 B inside pieces 0 .. 3 (pieces 4 .. 7: base + 4 KiB)
+    // ---- DMA roles.  A piece costs its wave ~100 cycles of issue, 64 pieces a slice: all eight waves carry eight each, the
+    // two waves of a SIMD (w and w + 4) in ANTIPHASE.  Waves 0-3 ("early") stage the (W2, h2) pairs -- wanted within one
+    // period -- right behind the barrier, between P2's first MFMAs; waves 4-7 ("late") stage the (W1, h1) pairs, which have
+    // two periods, between P3's: while one wave of a SIMD is inside its DMA statements (no matrix instruction for hundreds
+    // of cycles) the matrix pipe has the other's.  Wave w stages half (w & 1) of the weight tile (w & 2 == 0) or of the
+    // activation tile of its class: eight pieces a slice.
+    const unsigned late = __builtin_amdgcn_readfirstlane(wid >> 2);            // 0: (W2, h2) loader, 1: (W1, h1) loader
+    const unsigned early = late ^ 1u;
+    const int lw = wid & 3;
+    unsigned voff;                                          // this lane's 16 B inside a piece
     {
         const int row = lane >> 2, slot = lane & 3;         // a piece = 16 rows x 4 slots; LDS slot s of row r holds source slot s ^ 2 * bit3(r)
-        const unsigned in_piece = (unsigned)(row * SP_ROWB + ((slot ^ (((row >> 3) & 1) << 1)) << 4));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) voff[j] = in_piece + (unsigned)j * 1024u;
+        voff = (unsigned)(row * SP_ROWB + ((slot ^ (((row >> 3) & 1) << 1)) << 4));
     }
-    const long long slice_b = op < 2 ? p.wslice_b : p.xslice_b;
-    const char* src = sp_uniform_ptr((op < 2 ? p.W[op] + (long long)tile_n * SP_BM * SP_ROWB
-                                             : p.X[op - 2] + tile_m * SP_BN * SP_ROWB) + (wid & 1) * (SP_OP / 2));
-    const unsigned lds_stage = lds_base + (unsigned)op * SP_OP + (unsigned)(wid & 1) * (SP_OP / 2);
+    const long long slice_b = lw < 2 ? p.wslice_b : p.xslice_b;
+    const long long tile_off = (lw < 2 ? (long long)tile_n * SP_BM * SP_ROWB : tile_m * SP_BN * SP_ROWB) + (lw & 1) * (SP_OP / 2);
+    const int piece_sel = late ? 0 : 1;                     // late waves stage the first pieces (W1 / h1), early ones the second
+    const char* src = sp_uniform_ptr((lw < 2 ? p.W[piece_sel] : p.X[piece_sel]) + tile_off);
+    const unsigned lds_mine = lds_base + (late ? (unsigned)SP_RING_A : (unsigned)SP_RING_B) + (unsigned)(lw >> 1) * SP_OP +
+                              (unsigned)(lw & 1) * (SP_OP / 2);                // inside slot 0 of this wave's ring
     const int ns = p.ns;
 
     // ---- fragment read addresses: lane (i, kq) -> row i, slot kq ^ 2 * bit3(i) of a 16-row block
@@ -173,8 +187,11 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
     typedef const __attribute__((address_space(3))) char* lds_cp;
     const lds_cp lbase = (lds_cp)(lptr_t)smem_sp;
     const unsigned rd_l = (unsigned)(i * SP_ROWB + ((kq ^ (((i >> 3) & 1) << 1)) << 4));
-    const unsigned rdA = rd_l + (unsigned)wr * (SP_OP / 2);                       // W1 of stage 0 (+ SP_OP: W2), fragment T at + T KiB
-    const unsigned rdB = rd_l + 2u * SP_OP + (unsigned)wc * (SP_OP / 4);          // h1 of stage 0 (+ SP_OP: h2), fragment c at + c KiB
+    const unsigned rdW = rd_l + (unsigned)wr * (SP_OP / 2);                      // weight fragment T at + T KiB inside a slot
+    const unsigned rdH = rd_l + (unsigned)SP_OP + (unsigned)wc * (SP_OP / 4);    // activation fragment c at + c KiB
+    unsigned sb = 0;          // byte offset of the (W2, h2) slot of the current slice: s % 2
+    unsigned sa_next = SP_PAIR_B;   // ... of the (W1, h1) slot of slice s + 1: (s + 1) % 3
+    unsigned sa_free = 0;           // ... of slice s's own (W1, h1) slot, refilled with slice s + 3: s % 3
 
     f32x4_t acc[8][4];
 #pragma unroll
@@ -183,65 +200,84 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
         for (int c = 0; c < 4; ++c) acc[t][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     u32x4_t fW1[8], fW2[8], fhA[4], fhB[4];
 
-#define SP_READ_W(DST, ST, WHICH) _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) DST[tt] = *(lds_u4p)(lbase + rdA + (ST) * SP_STAGE + (WHICH) * SP_OP + tt * 1024)
-#define SP_READ_H(DST, ST, WHICH) _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = *(lds_u4p)(lbase + rdB + (ST) * SP_STAGE + (WHICH) * SP_OP + c * 1024)
-    // tiles T0 .. T0 + NT - 1 of one product (NT x 4 MFMAs)
-#define SP_MFMA(FA, FB, T0, NT)                                                                                  \
+#define SP_READ_W(DST, BASE) _Pragma("unroll") for (int tt = 0; tt < 8; ++tt) DST[tt] = *(lds_u4p)(lbase + (BASE) + rdW + tt * 1024)
+#define SP_READ_H(DST, BASE) _Pragma("unroll") for (int c = 0; c < 4; ++c) DST[c] = *(lds_u4p)(lbase + (BASE) + rdH + c * 1024)
+    // MFMAs E0 .. E0 + NE - 1 of one product, in the order e -> (tile e / 4, row block e % 4)
+#define SP_MFMA(FA, FB, E0, NE)                                                                                  \
     do {                                                                                                         \
-        __builtin_amdgcn_s_setprio(1);                                                                           \
-        _Pragma("unroll") for (int tt = (T0); tt < (T0) + (NT); ++tt) _Pragma("unroll") for (int c = 0; c < 4; ++c) \
-            acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                                 \
-                __builtin_bit_cast(f16x8_t, FA[tt]), __builtin_bit_cast(f16x8_t, FB[c]), acc[tt][c], 0, 0, 0);   \
-        __builtin_amdgcn_s_setprio(0);                                                                           \
+        _Pragma("unroll") for (int e = (E0); e < (E0) + (NE); ++e)                                               \
+            acc[e >> 2][e & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                         \
+                __builtin_bit_cast(f16x8_t, FA[e >> 2]), __builtin_bit_cast(f16x8_t, FB[e & 3]), acc[e >> 2][e & 3], 0, 0, 0); \
     } while (0)
-    // this wave's pieces 2 Q, 2 Q + 1 of slice S2 into stage ST (past the end: clamped -- the redundant DMA lands in a dead
-    // stage and keeps the vmcnt bookkeeping uniform)
-#define SP_ISSUE2(ST, S2, Q)                                                                                     \
+    // "N times one MFMA, then one LDS read" for the scheduler: the fragment reads ride in the issue slots an MFMA leaves
+    // (it holds the SIMD's vector issue for 8 of its 16 cycles), not in a block of their own with the matrix pipe idle
+#define SP_PAIR(N) _Pragma("unroll") for (int z_ = 0; z_ < (N); ++z_) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#define SP_ONLY_MFMA(N) __builtin_amdgcn_sched_group_barrier(0x008, (N), 0)
+    // pieces 4 Q .. 4 Q + 3 (Q = 0, 1) of slice S2's pair into the slot at byte SLOT of this wave's ring, issued by the
+    // waves whose ON is set (past the end: clamped -- the redundant DMA lands in a dead slot and keeps the vmcnt
+    // bookkeeping uniform); the other waves jump over the statement
+#define SP_ISSUE4(ON, SLOT, S2, Q)                                                                               \
     do {                                                                                                         \
         const int ss_ = (S2) < ns ? (S2) : ns - 1;                                                               \
-        sp_dma2(voff[(2 * (Q)) & 3], voff[(2 * (Q) + 1) & 3], src + (long long)ss_ * slice_b + ((Q) >> 1) * 4096,  \
-                lds_stage + (ST) * SP_STAGE + ((Q) >> 1) * 4096 + ((Q) & 1) * 2048);                             \
+        sp_dma4(ON, voff, src + (long long)ss_ * slice_b + (Q) * 4096, lds_mine + (SLOT) + (Q) * 4096);          \
     } while (0)
-#define SP_ISSUE8(ST, S2) do { SP_ISSUE2(ST, S2, 0); SP_ISSUE2(ST, S2, 1); SP_ISSUE2(ST, S2, 2); SP_ISSUE2(ST, S2, 3); } while (0)
 
-    // One slice (stage ST), entered with W1 and HCUR = h1 of this slice in registers; leaves W1 and HNXT = h1 of the next.
-#define SP_STEP(ST, S, HCUR, HNXT)                                                                               \
+    // One slice, entered with W1 and HCUR = h1 of it in registers; leaves W1 and HNXT = h1 of the next.
+#define SP_STEP(S, HCUR, HNXT)                                                                                   \
     do {                                                                                                         \
-        SP_READ_H(HNXT, ST, 1);                                    /* h2 (s) */                                   \
-        SP_MFMA(fW1, HCUR, 0, 8);                                  /* P1 = h1 . W1 */                            \
-        SP_READ_W(fW2, ST, 1);                                     /* W2 (s) */                                   \
-        SP_MFMA(fW1, HNXT, 0, 8);                                  /* P2 = h2 . W1 */                            \
-        SP_WAIT_VMCNT(0);                                          /* this wave's share of slice s + 1 landed */  \
-        SP_WAIT_LGKM0();                                           /* ... and its reads of stage ST are done */    \
-        sp_barrier();                                              /* stage ST is free; slice s + 1 is visible */ \
-        SP_READ_W(fW1, (ST) ^ 1, 0);                               /* W1, h1 (s + 1) */                           \
-        SP_READ_H(HNXT, (ST) ^ 1, 0);                                                                            \
-        SP_ISSUE2(ST, (S) + 2, 0);                                                                               \
-        SP_MFMA(fW2, HCUR, 0, 2);                                  /* P3 = h1 . W2, the refill issued between */ \
-        SP_ISSUE2(ST, (S) + 2, 1);                                                                               \
-        SP_MFMA(fW2, HCUR, 2, 2);                                                                                \
-        SP_ISSUE2(ST, (S) + 2, 2);                                                                               \
-        SP_MFMA(fW2, HCUR, 4, 2);                                                                                \
-        SP_ISSUE2(ST, (S) + 2, 3);                                                                               \
-        SP_MFMA(fW2, HCUR, 6, 2);                                                                                \
+        SP_READ_H(HNXT, SP_RING_B + sb);                           /* h2 (s) */                                   \
+        SP_READ_W(fW2, SP_RING_B + sb);                            /* W2 (s) */                                   \
+        SP_MFMA(fW1, HCUR, 0, 32);                                 /* P1 = h1 . W1, the twelve reads between */   \
+        SP_PAIR(12); SP_ONLY_MFMA(20);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        sp_wait_vmcnt_by<0, 8>(late);                              /* early: (W2, h2) of s + 1 landed; late: all but its youngest (W1, h1) pair */ \
+        SP_WAIT_LGKM0();                                           /* this wave's reads of slice s are done */     \
+        sp_barrier();                                              /* slice s is dead; slice s + 1 is visible */  \
+        SP_ISSUE4(early, sb, (S) + 2, 0);                          /* (W2, h2) of s + 2: wanted in one period */  \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        SP_MFMA(fW1, HNXT, 0, 4);                                  /* P2 = h2 . W1 */                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        SP_ISSUE4(early, sb, (S) + 2, 1);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        SP_MFMA(fW1, HNXT, 4, 28);                                                                               \
+        SP_READ_H(HNXT, SP_RING_A + sa_next);                      /* h1, W1 (s + 1) */                           \
+        SP_READ_W(fW1, SP_RING_A + sa_next);                                                                     \
+        SP_MFMA(fW2, HCUR, 0, 12);                                 /* P3 = h1 . W2 */                            \
+        SP_ONLY_MFMA(28); SP_PAIR(12);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        SP_ISSUE4(late, sa_free, (S) + 3, 0);                      /* (W1, h1) of s + 3: two periods to land */  \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        SP_MFMA(fW2, HCUR, 12, 4);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        SP_ISSUE4(late, sa_free, (S) + 3, 1);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        SP_MFMA(fW2, HCUR, 16, 16);                                                                              \
+        sb ^= SP_PAIR_B;                                                                                         \
+        sa_free = sa_next;                                                                                       \
+        sa_next = sa_next == 2 * SP_PAIR_B ? 0u : sa_next + SP_PAIR_B;                                           \
     } while (0)
 
-    // ---- prologue: slices 0 and 1 issued; slice 0 landed and visible; W1, h1 (0) read
-    SP_ISSUE8(0, 0);
-    SP_ISSUE8(1, 1);
-    SP_WAIT_VMCNT(8);
+    // ---- prologue: early waves issue (W2, h2) of slices 0, 1; late waves (W1, h1) of slices 0, 1, 2; slice 0 landed and
+    // visible; W1, h1 (0) read
+    SP_ISSUE4(early, 0, 0, 0); SP_ISSUE4(early, 0, 0, 1);
+    SP_ISSUE4(early, SP_PAIR_B, 1, 0); SP_ISSUE4(early, SP_PAIR_B, 1, 1);
+    SP_ISSUE4(late, 0, 0, 0); SP_ISSUE4(late, 0, 0, 1);
+    SP_ISSUE4(late, SP_PAIR_B, 1, 0); SP_ISSUE4(late, SP_PAIR_B, 1, 1);
+    SP_ISSUE4(late, 2 * SP_PAIR_B, 2, 0); SP_ISSUE4(late, 2 * SP_PAIR_B, 2, 1);
+    sp_wait_vmcnt_by<8, 16>(late);                             // slice 0 landed (this wave's share)
     sp_barrier();
-    SP_READ_W(fW1, 0, 0);
-    SP_READ_H(fhA, 0, 0);
+    SP_READ_W(fW1, SP_RING_A + 0);
+    SP_READ_H(fhA, SP_RING_A + 0);
     for (int s = 0; s < ns; s += 2) {
-        SP_STEP(0, s, fhA, fhB);
-        if (s + 1 < ns) SP_STEP(1, s + 1, fhB, fhA);
+        SP_STEP(s, fhA, fhB);
+        if (s + 1 < ns) SP_STEP(s + 1, fhB, fhA);
     }
     SP_WAIT_VMCNT(0);    // the clamped tail DMAs must not outlive the workgroup's LDS
     SP_WAIT_LGKM0();
 #undef SP_STEP
-#undef SP_ISSUE8
-#undef SP_ISSUE2
+#undef SP_ISSUE4
+#undef SP_PAIR
+#undef SP_ONLY_MFMA
 #undef SP_READ_W
 #undef SP_READ_H
 #undef SP_MFMA
@@ -251,12 +287,29 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
     const int lg = lane >> 4;
     const float inv = 1.0f / ((float)(1 << SP_X_SHIFT) * p.wscale[0]);        // a power of two: exact
     const float xs = (float)(1 << SP_X_SHIFT);
+    // the tile's 256 biases through LDS (the ring is dead): ONE global load per thread; a lane's sixteen then come as four
+    // 16-byte LDS reads (read straight from memory they were 32 dependent 8-byte loads per lane: a tenth of a tile's time)
+    {
+        sp_barrier();                                          // every wave is past its last fragment read
+        float* bl = (float*)smem_sp;
+        if (tid < SP_BM) {
+            const int n = tile_n * SP_BM + tid;
+            bl[tid] = (p.bias && n < p.N) ? (float)p.bias[n] : 0.0f;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int th = 0; th < 2; ++th) {
         const int n0 = tile_n * SP_BM + wr * 128 + th * 64 + 16 * lg;
         float bv[16];
+        {
+            const float4* b4 = (const float4*)((const float*)smem_sp + wr * 128 + th * 64 + 16 * lg);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bv[j] = (p.bias && n0 + j < p.N) ? (float)p.bias[n0 + j] : 0.0f;
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = b4[j];
+                bv[4 * j] = v.x; bv[4 * j + 1] = v.y; bv[4 * j + 2] = v.z; bv[4 * j + 3] = v.w;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const long long m = tile_m * SP_BN + wc * 64 + c * 16 + i;
