@@ -38,6 +38,11 @@ extern "C" int dlc_create(int device, dlc_ctx** out) {
             return DLC_ERR_HIP;
         }
     }
+    c->host_lock = new (std::nothrow) std::mutex;
+    if (!c->host_lock) {
+        delete c;
+        return DLC_ERR_HIP;
+    }
     if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess ||
         hipHostMalloc((void**)&c->host_flag, 64, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_flag, hipEventDisableTiming) != hipSuccess) {
@@ -64,6 +69,7 @@ extern "C" int dlc_destroy(dlc_ctx* ctx) {
             dlc::staging_free(ctx->staging);
         }
     }
+    delete ctx->host_lock;
     delete ctx;
     return DLC_OK;
 }

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 
 #include "../../include/dlc.h"
 
@@ -24,6 +25,7 @@ struct dlc_ctx {
     unsigned long long func_attr_set;
     void* zero_page;                            // 4 KiB of zeros in device memory (source of masked LDS-DMA pieces)
     dlc_host_staging* staging;                  // created by the first dlc_host_to_device / dlc_device_to_host
+    std::mutex* host_lock;                      // serialises the staged transfers, the ring's creation and its teardown
     int host_threads;                           // host copy threads of the staging (0 = min(16, hardware threads))
     unsigned long long* host_flag;              // 64 page-locked bytes: the one word dlc_sdav_similarity_matrix reads back
     hipEvent_t ev_flag;                         // ... and the event behind its copy
