@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void xent_grad_kernel(const double* __restrict
         if (dlab) dlab[r * cols + c] = -logsm * inv_rows;
     }
     cd = block_sum(cd, red);
-    if (threadIdx.x == 0) acc[r] = cd * inv_rows;             // cd_part[r]: summed in order by finalize_loss_kernel
+    if (threadIdx.x == 0) acc[r] = cd * inv_rows;             // cd_part[r]: summed in order by update_kernel's last workgroup
 }
 
 constexpr int FN_MAX_SLICES = 64;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void frame_norm_kernel(const double* __restric
                                                          double* __restrict__ acc) {
     // Per frame t: its share of the sparsity term and the squared distance to frame t + 1 (the consecutive-frame term).
     // A frame is cut into gridDim.y slices (one workgroup per frame walked 75 000 elements alone: 97 us of a 790 us
-    // step); slice y leaves its part in nrm_part[t * 64 + y] and frame_norm_finish_kernel adds the parts IN ORDER and takes
+    // step); slice y leaves its part in nrm_part[t * 64 + y]; hidden_grad_kernel and update_kernel add the parts IN ORDER and take
     // the roots: nrm feeds the consecutive-frame gradient, so the SGD trajectory is the same bits run after run (an
     // atomicAdd here made it depend on the order the workgroups finished).
     __shared__ double red[4];
@@ -214,45 +214,21 @@ __global__ __launch_bounds__(256) void frame_norm_kernel(const double* __restric
         nrm_part[(long long)t * FN_MAX_SLICES + blockIdx.y] = s2;
     }
 }
-__global__ void frame_norm_finish_kernel(int batch, int slices, const double* __restrict__ nrm_part,
-                                         const double* __restrict__ l1_part, double* __restrict__ nrm,
-                                         double* __restrict__ acc) {
-    // one thread per frame adds its slices in slice order, thread 0 then the frames in frame order: a fixed tree
-    __shared__ double fn2[256], fl1[256];
-    if (blockIdx.x != 0) return;
-    for (int t0 = 0; t0 < batch; t0 += 256) {           // (batches of more than 256 frames: in rounds, still in order)
-        const int t = t0 + threadIdx.x;
-        double n2 = 0.0, l1 = 0.0;
-        if (t < batch)
-            for (int y = 0; y < slices; ++y) {
-                n2 += nrm_part[(long long)t * FN_MAX_SLICES + y];
-                l1 += l1_part[(long long)t * FN_MAX_SLICES + y];
-            }
-        fn2[threadIdx.x] = n2; fl1[threadIdx.x] = l1;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s = t0 == 0 ? 0.0 : acc[2], l = t0 == 0 ? 0.0 : acc[1];
-            for (int u = 0; u < 256 && t0 + u < batch; ++u) {
-                l += fl1[u];
-                if (t0 + u + 1 < batch) {
-                    const double n = sqrt(fn2[u]);
-                    nrm[t0 + u] = n;
-                    s += n / (double)(batch - 1);
-                }
-            }
-            acc[1] = l;
-            acc[2] = s;
-        }
-        __syncthreads();
-    }
-}
-
 // dh += sparse_penalty*sign(h - s)/cs_den + consecutive term;  dz1 = dh * h(1-h)
+// nrm[f] = sqrt of frame f's squared distance to frame f + 1: the slices' parts added in slice order (every workgroup adds
+// the same parts in the same order: the same bits, and no launch of its own for a few hundred additions)
 __global__ __launch_bounds__(256) void hidden_grad_kernel(const double* __restrict__ h, const double* __restrict__ dh_in,
-                                                          const double* __restrict__ nrm, int batch,
+                                                          const double* __restrict__ nrm_part, int slices, int batch,
                                                           long long frame_elems, double cs_den, double sparse_level,
                                                           double sparse_penalty, double consecutive_penalty,
                                                           double* __restrict__ dz1) {
+    extern __shared__ double nrm[];                            // [batch - 1]
+    for (int t = threadIdx.x; t + 1 < batch; t += 256) {
+        double n2 = 0.0;
+        for (int y = 0; y < slices; ++y) n2 += nrm_part[(long long)t * FN_MAX_SLICES + y];
+        nrm[t] = sqrt(n2);
+    }
+    __syncthreads();
     const long long total = (long long)batch * frame_elems;
     const double ccs = consecutive_penalty / (double)(batch - 1), sps = sparse_penalty / cs_den;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -285,8 +261,10 @@ __global__ __launch_bounds__(256) void backprop_input_kernel(const double* __res
 // out[c * ldo + r] = in[r, c]  (ldo >= rows: two transposes side by side make the K-stacked operand of the fused
 // weight-gradient product)
 __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, long long rows, long long cols,
-                                                        double* __restrict__ out, long long ldo) {
+                                                        double* __restrict__ out, long long ldo,
+                                                        const double* __restrict__ in2 = nullptr, double* __restrict__ out2 = nullptr) {
     __shared__ double tile[32][33];
+    if (blockIdx.z == 1) { in = in2; out = out2; }             // (a second matrix of the same shape in the same launch)
     const long long r0 = (long long)blockIdx.y * 32, c0 = (long long)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
     for (int i = ty; i < 32; i += 8)
@@ -296,11 +274,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
         if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * ldo + r0 + tx] = tile[tx][i];
 }
 
-// out[c] = sum_r in[r, c]   (rows are few hundred: one thread per column, coalesced across columns)
+// out[c] = sum_r in[r, c]: 32 columns x 8 row groups per workgroup, the groups' partial sums combined in group order (kept
+// for the encoder biases of layers more than two below the trained one, whose dz1 buffer is reused before the step's end)
 __global__ __launch_bounds__(256) void colsum_kernel(const double* __restrict__ in, long long rows, long long cols,
                                                      double* __restrict__ out) {
-    // out[c] = sum over rows of in[r, c]: 32 columns x 8 row groups per workgroup, the groups' partial sums combined in
-    // group order (one thread per column walking all 300 rows: 76 us, twice per step)
     __shared__ double part[8][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const long long c = (long long)blockIdx.x * 32 + cl;
@@ -319,26 +296,80 @@ __global__ __launch_bounds__(256) void colsum_kernel(const double* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void sgd_kernel(double* __restrict__ p, const double* __restrict__ g1,
-                                                  const double* __restrict__ g2, long long n, double lr) {
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256)
-        p[e] -= lr * (g2 ? g1[e] + g2[e] : g1[e]);
-}
-
-// {loss, cd, cs, cc}; cd = the rows' cross-entropies added in row order by one workgroup (a fixed tree: the reported loss is
-// the same bits run after run, like the parameters)
-__global__ __launch_bounds__(256) void finalize_loss_kernel(const double* __restrict__ cd_part, long long rows,
-                                                            const double* __restrict__ acc, double sparse_penalty,
-                                                            double consecutive_penalty, double* __restrict__ loss_out) {
+// Everything behind the last product of a step in ONE launch (r04: two column-sum kernels, five SGD kernels and the loss
+// kernel -- eight launches of microseconds each): workgroups [0, w_blocks) walk the weight matrices (p -= lr g), the next
+// ones take 32 bias columns each (the column sum of their gradient rows, 8 row groups combined in group order, then the
+// update), the last one adds the loss's parts in their fixed order.  Same arithmetic, same order, same bits as the
+// separate kernels.
+constexpr int UP_MAX = 8;
+struct UpdateArgs {
+    int n_w;                                    // weight matrices
+    double* w[UP_MAX]; const double* gw[UP_MAX]; long long w_n[UP_MAX]; long long w_blk0[UP_MAX + 1];   // block ranges
+    int n_b;                                    // bias vectors
+    double* b[UP_MAX + 1]; const double* gb_rows[UP_MAX + 1]; long long b_cols[UP_MAX + 1]; long long b_blk0[UP_MAX + 2];
+    long long b_rows[UP_MAX + 1];               // gradient rows to add up (1: gb_rows is the gradient itself)
+    long long rows;
+    double lr;
+    // loss
+    const double* cd_part; const double* nrm_part; const double* l1_part; int batch, slices;
+    double sparse_penalty, consecutive_penalty; double* loss_out;
+};
+__global__ __launch_bounds__(256) void update_kernel(UpdateArgs a) {
+    __shared__ double part[8][33];
     __shared__ double red[4];
+    const long long blk = blockIdx.x;
+    if (blk < a.w_blk0[a.n_w]) {
+        int m = 0;
+        while (blk >= a.w_blk0[m + 1]) ++m;
+        const long long nb = a.w_blk0[m + 1] - a.w_blk0[m];
+        double* __restrict__ p = a.w[m];
+        const double* __restrict__ g = a.gw[m];
+        for (long long e = (blk - a.w_blk0[m]) * 256 + threadIdx.x; e < a.w_n[m]; e += nb * 256) p[e] -= a.lr * g[e];
+        return;
+    }
+    if (blk < a.b_blk0[a.n_b]) {
+        int m = 0;
+        while (blk >= a.b_blk0[m + 1]) ++m;
+        const long long cols = a.b_cols[m];
+        const double* __restrict__ in = a.gb_rows[m];
+        const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+        const long long c = (blk - a.b_blk0[m]) * 32 + cl;
+        double s = 0.0;
+        if (c < cols) {
+#pragma unroll 4
+            for (long long r = rg; r < a.b_rows[m]; r += 8) s += in[r * cols + c];
+        }
+        part[rg][cl] = s;
+        __syncthreads();
+        if (rg == 0 && c < cols) {
+            double t = part[0][cl];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) t += part[g][cl];
+            a.b[m][c] -= a.lr * t;
+        }
+        return;
+    }
+    // {loss, cd, cs, cc}: the rows' cross-entropies added in row order, the frames' sparsity / consecutive-frame parts in
+    // slice then frame order (a fixed tree: the reported loss is the same bits run after run, like the parameters)
+    if (!a.loss_out) return;
     double cd = 0.0;
-    for (long long r = threadIdx.x; r < rows; r += 256) cd += cd_part[r];
+    for (long long r = threadIdx.x; r < a.rows; r += 256) cd += a.cd_part[r];
     cd = block_sum(cd, red);
     if (threadIdx.x == 0) {
-        loss_out[0] = cd + sparse_penalty * acc[1] + consecutive_penalty * acc[2];
-        loss_out[1] = cd;
-        loss_out[2] = acc[1];
-        loss_out[3] = acc[2];
+        double cs = 0.0, cc = 0.0;
+        for (int t = 0; t < a.batch; ++t) {
+            double n2 = 0.0, l1 = 0.0;
+            for (int y = 0; y < a.slices; ++y) {
+                n2 += a.nrm_part[(long long)t * FN_MAX_SLICES + y];
+                l1 += a.l1_part[(long long)t * FN_MAX_SLICES + y];
+            }
+            cs += l1;
+            if (t + 1 < a.batch) cc += sqrt(n2) / (double)(a.batch - 1);
+        }
+        a.loss_out[0] = cd + a.sparse_penalty * cs + a.consecutive_penalty * cc;
+        a.loss_out[1] = cd;
+        a.loss_out[2] = cs;
+        a.loss_out[3] = cc;
     }
 }
 
@@ -443,29 +474,28 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
                        layer > 0 ? P(w.dlab) : (double*)nullptr, P(w.cd_part));
     // tf.norm(h - s, axis=1, ord=1) + reduce_mean (SDAV.py:174): h is [B,P,N] at layer 0, [B*P,N] afterwards
     const double cs_den = layer == 0 ? (double)batch * (double)N : (double)rows;
+    int fn_slices = 1;
     {
         long long slices = dlc::cdiv((long long)patches * N, (long long)256 * 16);      // >= 16 elements per thread
         if (slices > FN_MAX_SLICES) slices = FN_MAX_SLICES;
         hipLaunchKernelGGL(frame_norm_kernel, dim3((unsigned)batch, (unsigned)slices), dim3(256), 0, st, h, (int)batch,
                            (long long)patches * N, sparse_level, cs_den, P(w.nrm_part), P(w.l1_part));
-        hipLaunchKernelGGL(frame_norm_finish_kernel, dim3(1), dim3(256), 0, st, (int)batch, (int)slices, P(w.nrm_part),
-                           P(w.l1_part), P(w.nrm), P(w.acc));
+        fn_slices = (int)slices;
     }
     GEMM(DLC_B_KN, DLC_ACT_NONE, rows, N, K, P(w.dz2), K, W[layer], N, nullptr, P(w.dh), N);      // dh = dz2 W
     double* dz1 = P(w.h[layer]) + rows * N;                   // right behind h
-    hipLaunchKernelGGL(hidden_grad_kernel, dim3(grid_for(rows * N)), dim3(256), 0, st, h, P(w.dh), P(w.nrm), (int)batch,
-                       (long long)patches * N, cs_den, sparse_level, sparse_penalty, consecutive_penalty, dz1);
+    if ((size_t)batch * 8 > 48 * 1024) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_train_step: batch too large");
+    hipLaunchKernelGGL(hidden_grad_kernel, dim3(grid_for(rows * N)), dim3(256), (size_t)batch * 8, st, h, P(w.dh), P(w.nrm_part),
+                       fn_slices, (int)batch, (long long)patches * N, cs_den, sparse_level, sparse_penalty, consecutive_penalty, dz1);
     // The tied weight's two gradients in ONE product (they were two of 1681 x 300 x 2500, each too short a K loop to run
     // well: 80 us apiece): d/dW = dz2^T h (decoder use) + x~^T dz1 (encoder use) = [dz2^T | x~^T] . [h ; dz1], K = 2 rows.
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0, st,
-                       P(w.dz2), rows, K, P(w.tr), 2 * rows);
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0, st,
-                       P(w.xt[layer]), rows, K, P(w.tr) + rows, 2 * rows);
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32), 2), dim3(256), 0, st,
+                       P(w.dz2), rows, K, P(w.tr), 2 * rows, (const double*)P(w.xt[layer]), P(w.tr) + rows);
     GEMM(DLC_B_KN, DLC_ACT_NONE, K, N, 2 * rows, P(w.tr), 2 * rows, h, N, nullptr, P(w.gw[layer]), N);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)dlc::cdiv(K, 32)), dim3(256), 0, st, P(w.dz2), rows, K, P(w.gbd));
 
     // ---- backward through the encoders layer .. 0
     double* spare[2] = {P(w.dz1a), P(w.dz1b)};
+    const double* dz1_of[8] = {};                       // the rows whose column sums are layer l's encoder-bias gradient
     int which = 0;
     for (int l = layer; l >= 0; --l) {
         const long long Kl = dims[l], Nl = dims[l + 1];
@@ -474,7 +504,8 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
                                st, P(w.xt[l]), rows, Kl, P(w.tr), rows);
             GEMM(DLC_B_KN, DLC_ACT_NONE, Kl, Nl, rows, P(w.tr), rows, dz1, Nl, nullptr, P(w.gw[l]), Nl);   // x~^T dz1
         }
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)dlc::cdiv(Nl, 32)), dim3(256), 0, st, dz1, rows, Nl, P(w.gbe[l]));
+        if (layer - l <= 2) dz1_of[l] = dz1;            // (behind h, dz1a, dz1b: alive until the update kernel)
+        else hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)dlc::cdiv(Nl, 32)), dim3(256), 0, st, dz1, rows, Nl, P(w.gbe[l]));
         if (l == 0) break;
         GEMM(DLC_B_NK, DLC_ACT_NONE, rows, Kl, Nl, dz1, Nl, W[l], Nl, nullptr, P(w.dxt), Kl);          // dz1 W^T
         hipLaunchKernelGGL(backprop_input_kernel, dim3(grid_for(rows * Kl)), dim3(256), 0, st, P(w.dxt),
@@ -484,18 +515,35 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
         which ^= 1;
     }
 
-    // ---- plain gradient descent on everything the loss reached (SDAV.py:223-226)
-    for (int l = 0; l <= layer; ++l) {
-        hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(dims[l] * dims[l + 1])), dim3(256), 0, st, W[l], P(w.gw[l]),
-                           (const double*)nullptr, (long long)(dims[l] * dims[l + 1]), learning_rate);
-        hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(dims[l + 1])), dim3(256), 0, st, b_enc[l], P(w.gbe[l]),
-                           (const double*)nullptr, (long long)dims[l + 1], learning_rate);
+    // ---- plain gradient descent on everything the loss reached (SDAV.py:223-226), the bias gradients' column sums and the
+    // loss: one launch
+    {
+        UpdateArgs u{};
+        u.n_w = layer + 1;
+        long long blk = 0;
+        for (int l = 0; l <= layer; ++l) {
+            u.w[l] = W[l]; u.gw[l] = P(w.gw[l]); u.w_n[l] = dims[l] * dims[l + 1];
+            u.w_blk0[l] = blk;
+            blk += grid_for(u.w_n[l]);
+        }
+        u.w_blk0[layer + 1] = blk;
+        u.n_b = layer + 2;
+        for (int l = 0; l <= layer; ++l) {
+            u.b[l] = b_enc[l]; u.b_cols[l] = dims[l + 1];
+            if (dz1_of[l]) { u.gb_rows[l] = dz1_of[l]; u.b_rows[l] = rows; }
+            else { u.gb_rows[l] = P(w.gbe[l]); u.b_rows[l] = 1; }
+            u.b_blk0[l] = blk;
+            blk += dlc::cdiv(dims[l + 1], (int64_t)32);
+        }
+        u.b[layer + 1] = b_dec; u.gb_rows[layer + 1] = P(w.dz2); u.b_rows[layer + 1] = rows; u.b_cols[layer + 1] = K;
+        u.b_blk0[layer + 1] = blk;
+        blk += dlc::cdiv(K, (int64_t)32);
+        u.b_blk0[layer + 2] = blk;
+        u.rows = rows; u.lr = learning_rate;
+        u.cd_part = P(w.cd_part); u.nrm_part = P(w.nrm_part); u.l1_part = P(w.l1_part); u.batch = (int)batch; u.slices = fn_slices;
+        u.sparse_penalty = sparse_penalty; u.consecutive_penalty = consecutive_penalty; u.loss_out = loss_out;
+        hipLaunchKernelGGL(update_kernel, dim3((unsigned)(blk + 1)), dim3(256), 0, st, u);
     }
-    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(K)), dim3(256), 0, st, b_dec, P(w.gbd), (const double*)nullptr, K,
-                       learning_rate);
-    if (loss_out)
-        hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(256), 0, st, P(w.cd_part), (long long)rows, P(w.acc),
-                           sparse_penalty, consecutive_penalty, loss_out);
 #undef GEMM
     DLC_LAUNCH_CHECK(ctx, "sdav_train_step kernels");
     return DLC_OK;
