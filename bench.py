@@ -322,8 +322,9 @@ def bench_paths(eng, n_frames):
                     "frames": B, "dtype": "f64", "value": 1e3 / step_ms, "unit": "steps/s", "ms": step_ms,
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
-                                 "kernel": "five fp64 GEMMs of 300 x 1681 x 2500 (split-K, as SDAV.fit runs them) + 14 small kernels per step, "
-                                           "captured once as a HIP graph and replayed (SDAV.train_steps), masks redrawn in place per step",
+                                 "kernel": "five fp64 GEMMs of 300 x 1681 x 2500 (split-K, as SDAV.fit runs them) + 7 small kernels per step (r04: 14; "
+                                           "the column sums, every SGD update and the loss are one launch), captured once as a HIP graph "
+                                           "and replayed (SDAV.train_steps), masks redrawn in place per step",
                                  "kernel_ms": step_ms, "call_ms": step_ms, "algorithmic_flops_per_call": tflops,
                                  "eager_ms_per_step": eager_ms},
                     "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "steps/s", "cores": cores, "kind": "port",

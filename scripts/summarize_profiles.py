@@ -14,7 +14,7 @@ OURS = ("score_gemm_kernel", "finish_topk_kernel", "merge_topk_kernel", "l2_norm
         "sim_range_kernel", "sim_pairwise_program_kernel", "exhaustive_topk_kernel", "score_gemv_kernel", "stream_argmin_kernel",
         "stream_score_kernel", "random_mask_kernel", "xent_grad_kernel", "hidden_grad_kernel", "sgd_kernel",
         "gemm_split_f16_kernel", "sp_split_rows_kernel", "sp_split_weights_kernel", "sim_colrange_kernel", "sim_sample_kernel",
-        "sim_keys_init_kernel", "topk_rows_f64_kernel", "finish_topk_coop_kernel", "merge_topk_kernel", "keep_older_kernel")
+        "sim_keys_init_kernel", "topk_rows_f64_kernel", "update_kernel", "max_row_norm_kernel", "tau_scale_kernel", "small_topk_kernel", "frame_norm_kernel", "colsum_kernel", "finish_topk_coop_kernel", "merge_topk_kernel", "keep_older_kernel")
 
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 stats = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
@@ -29,7 +29,7 @@ try:
     dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "deeploopcloser_amd", "bench.py"], text=True).strip())
 except Exception:
     commit, dirty = None, None
-summary = {"tag": tag, "commit": commit, "tree_dirty_when_summarised": dirty, "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes, --no-paths)] -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe --no-shard-emulation",
+summary = {"tag": tag, "commit": commit, "tree_dirty_when_summarised": dirty, "command": "rocprofv3 --kernel-trace [--stats | --pmc ... (separate passes, --no-paths)] -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe --no-shard-emulation --no-configs",
            "kernels": {}}
 HEADLINE = "score_gemm_kernel<dlc_bf16_tag, 0, false>"      # the 1 M-row launch of the timed loop (GROUPS epilogue, unmasked)
 for row in csv.DictReader(open(stats)):
