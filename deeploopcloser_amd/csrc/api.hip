@@ -46,6 +46,7 @@ extern "C" int dlc_create(int device, dlc_ctx** out) {
     if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess ||
         hipHostMalloc((void**)&c->host_flag, 64, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_flag, hipEventDisableTiming) != hipSuccess) {
+        delete c->host_lock;
         delete c;
         return DLC_ERR_HIP;
     }

@@ -333,6 +333,50 @@ def test_cosine_certificate_follows_operand_norms(eng, dlc, n, d, dtype):
     assert bool(torch.isinf(pdb.norm_bound).all()) and bool(torch.isinf(pdb.tau_scale(q)).all())
 
 
+def test_pipeline_refuses_to_overwrite_an_unverified_batch(eng, dlc):
+    """MatchPipeline.submit on a slot whose batch was never fetched: dropping a certified batch loses nothing (counted in
+    dropped_batches); a batch whose sharded merge did NOT certify has its exhaustive round pending inside result() -- submit
+    raises instead of overwriting the unverified lists (it used to count and carry on).  One process, the
+    sharded branch switched on with a second, empty 'rank' (as bench.py's emulation does)."""
+    rng = np.random.RandomState(5)
+    n, d, k = 30000, 256, 8
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[rng.choice(n, 200, replace=False)] = x[3]                      # 201 copies of row 3: more ties than any selection holds
+    db = dlc.KeyframeDatabase(x, dtype="bf16")
+    kg = eng.groups_per_query(k)
+
+    def lonely_all_gather(out_t, inp, group=None):                   # rank 1 has nothing: -inf maxima, empty lists
+        o = out_t.view(2, -1)
+        o[0].copy_(inp.reshape(-1))
+        if inp.dtype == torch.float32:
+            o[1].fill_(float("-inf"))
+        else:
+            nq = inp.numel() // (k * 16)
+            o[1][:nq * k * 8].view(torch.int64).fill_(-1)
+            o[1][nq * k * 8:].view(torch.float64).fill_(float("-inf"))
+
+    def pipe_of():
+        p = dlc.MatchPipeline(db, k, depth=1)
+        p.world = 2
+        p.all_gather = lonely_all_gather
+        return p
+    clean = db.prepare_queries(x[100:104])
+    crowded = db.prepare_queries(x[[3, 100]])
+    p = pipe_of()
+    p.submit(clean); p.submit(clean)                                 # certified, never fetched: dropped, counted
+    assert p.dropped_batches == 1
+    s_, i_ = p.result(1)
+    assert i_[:, 0].cpu().tolist() == [100, 101, 102, 103]
+    p = pipe_of()
+    t = p.submit(crowded)
+    with pytest.raises(RuntimeError, match="never fetched and its merge did not certify 1 query"):
+        p.submit(crowded)
+    s_, i_ = p.result(t)                                             # the round still runs where it belongs
+    assert p.resolved_batches == 1
+    want = eng.match_topk(crowded, db.rows, k)
+    assert torch.equal(i_, want[1]) and torch.equal(s_, want[0])
+
+
 def test_any_plan_error_bound_covers_every_plan(eng):
     """dlc_cosine_score_error_bound_any_plan(d) -- what a sharded merge certifies with -- is at least the tau of whatever
     plan a shard's shape picks: the bandwidth kernel (q <= 4), the small-database plan, split-K, the one-pass MFMA plan."""
