@@ -284,12 +284,13 @@ class Engine:
         self._s_out.synchronize()                     # the result is complete in host memory
         return state["out"]
 
-    def for_each_chunk(self, x, chunk, consume):
+    def for_each_chunk(self, x, chunk, consume, first=None):
         """The upload half of run_chunked for results that STAY on the device: x [N, ...] (numpy, pageable) is cut into
         chunks of `chunk` items, the upload of chunk c+1 (copy stream, pinned staging ring) overlaps consume(device
         chunk, lo, hi) of chunk c on the current stream.  consume must be done with its chunk in stream order (it may keep
-        results, not the chunk: the two buffers are reused).  Returns when everything has been SUBMITTED; the current
-        stream is ordered behind the last upload."""
+        results, not the chunk: the two buffers are reused).  first: items of the first chunk (default `chunk`) -- nothing
+        overlaps ITS upload, so a short first chunk starts the kernels sooner.  Returns when everything has been
+        SUBMITTED; the current stream is ordered behind the last upload."""
         x = np.ascontiguousarray(x)
         n = x.shape[0]
         dev = self.device
@@ -300,11 +301,13 @@ class Engine:
             self._s_in, self._s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         chunk = max(1, min(int(chunk), n))
-        bufs = [torch.empty((chunk,) + tuple(x.shape[1:]), dtype=dt, device=dev) for _ in range(2 if n > chunk else 1)]
+        first = chunk if first is None else max(1, min(int(first), chunk))
+        bufs = [torch.empty((chunk,) + tuple(x.shape[1:]), dtype=dt, device=dev) for _ in range(2 if n > first else 1)]
         self._s_in.wait_stream(cur)                 # the buffers' memory may still be in use by earlier work of this stream
         free_ev = [None, None]
-        for c, lo in enumerate(range(0, n, chunk)):
-            hi = min(lo + chunk, n)
+        starts = [0] + list(range(first, n, chunk))
+        for c, lo in enumerate(starts):
+            hi = min(lo + (first if c == 0 else chunk), n)
             b = c % len(bufs)
             if free_ev[b] is not None:
                 self._s_in.wait_event(free_ev[b])     # chunk c-2's kernels have read this buffer

@@ -16,6 +16,9 @@ from .input import CvInputParser, _centres
 
 
 RESIDENT_CHUNK_FRAMES = 2048
+FIRST_CHUNK_FRAMES = None        # frames of the first upload chunk (None: like the others).  The first upload overlaps nothing, but a
+                                 # short first chunk did not pay: its kernels fill a fraction of the chip (scripts/exp_first_chunk.py:
+                                 # 39.1 / 16.8 / 32.6 ms host to host with None, 39.4-40.5 / 16.8-17.5 / 32.2-32.8 with 16 .. 128 frames)
 
 
 def _mark(timings, name, stream):
@@ -100,7 +103,7 @@ def sdav_descriptors_from_frames(frames, network, parser=None, key_points=None, 
         if a.dtype != np.uint8:
             a = a.astype(np.uint8)
         n_chunks = max(1, -(-n // max(1, int(chunk_frames))))
-        eng.for_each_chunk(a, -(-n // n_chunks), consume)
+        eng.for_each_chunk(a, -(-n // n_chunks), consume, first=FIRST_CHUNK_FRAMES)
     return desc
 
 
@@ -149,7 +152,7 @@ def cnn_vtl_descriptors_from_frames(frames, network, chunk_frames=None, timings=
         a = a.astype(np.float64)
     cf = int(chunk_frames or max(1, network.frame_chunk // 4))
     n_chunks = max(1, -(-n // cf))
-    eng.for_each_chunk(a, -(-n // n_chunks), consume)
+    eng.for_each_chunk(a, -(-n // n_chunks), consume, first=FIRST_CHUNK_FRAMES)
     return out
 
 
