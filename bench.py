@@ -231,6 +231,7 @@ def bench_paths(eng, n_frames):
     import deeploopcloser_amd as dlc
     from oracle import sdav as osdav, similarity as osim, distance as odist, cnn_vtl as ocnn, cosine as ocos
     gc.collect()                                                         # (what the headline part left behind goes now, not inside a timed row)
+    torch.cuda.empty_cache()                                             # (... and the allocator's cached 8 GB blocks of the config rows)
     N, P, K0, H = n_frames, 30, 1681, 2500
     cores = blas_threads()
     out = []
@@ -1261,7 +1262,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_power_probe:
         out["roofline"]["power_probe"] = power_probe(step, seconds=2.5)
 
-    # ---- CPU baseline + index agreement on a bounded sample (rank 0, N=1 only) ----------------
+    # ---- what ONE rank of a 2 / 4 / 8-GPU run would do per batch, emulated on this GPU (no RCCL): driver-timed every
+    # round, since an 8-GPU node is not always at hand (rank 0, N=1 only; untimed above) ------------------------------
+    if rank == 0 and world == 1 and not args.no_shard_emulation and n >= 8 * 2048:
+        out["multi_gpu_emulation"] = bench_shard_emulation(eng, dlc, db.rows, queries, k, idx)
+
+    # ---- BASELINE configs[3] and configs[4] on this one GPU, each a timed row of its own, and one rank's step of their
+    # 8-GPU form (rank 0, N=1 only; untimed above) -------------------------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_configs and not args.crowded:
+        out["baseline_configs"] = bench_configs(eng, dlc, args, db.rows, queries, planted, noise, sigma, planted_rows)
+
+    # ---- the other rows of the hot path at configs[1] / configs[2] size (rank 0, N=1 only; untimed above) ----
+    if rank == 0 and world == 1 and not args.no_paths:
+        del rows, planted, noise
+        out["paths"] = bench_paths(eng, args.path_frames)
+
+    # ---- CPU baseline + index agreement on a bounded sample (rank 0, N=1 only).  LAST: its BLAS / torch thread pools keep
+    # spinning for a while and took 10 ms out of the host-to-host rows above when it ran in front of them ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cosine as ocos
         ns = min(args.cpu_sample_rows, n)
@@ -1322,21 +1339,6 @@ def main():
         out["topk_index_agreement_vs_oracle"] = agree
         out["topk_index_agreement_rows"] = ns
         out["topk_score_max_abs_err_vs_oracle"] = float(np.abs(s_gpu.cpu().numpy() - best_s).max())
-
-    # ---- what ONE rank of a 2 / 4 / 8-GPU run would do per batch, emulated on this GPU (no RCCL): driver-timed every
-    # round, since an 8-GPU node is not always at hand (rank 0, N=1 only; untimed above) ------------------------------
-    if rank == 0 and world == 1 and not args.no_shard_emulation and n >= 8 * 2048:
-        out["multi_gpu_emulation"] = bench_shard_emulation(eng, dlc, db.rows, queries, k, idx)
-
-    # ---- BASELINE configs[3] and configs[4] on this one GPU, each a timed row of its own, and one rank's step of their
-    # 8-GPU form (rank 0, N=1 only; untimed above) -------------------------------------------------------------------
-    if rank == 0 and world == 1 and not args.no_configs and not args.crowded:
-        out["baseline_configs"] = bench_configs(eng, dlc, args, db.rows, queries, planted, noise, sigma, planted_rows)
-
-    # ---- the other rows of the hot path at configs[1] / configs[2] size (rank 0, N=1 only; untimed above) ----
-    if rank == 0 and world == 1 and not args.no_paths:
-        del rows, planted, noise
-        out["paths"] = bench_paths(eng, args.path_frames)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

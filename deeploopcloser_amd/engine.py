@@ -61,6 +61,14 @@ class Engine:
         self.ctx = ctx
         self._ws = {}
         self._scratch = None
+        # The copy streams of run_chunked / for_each_chunk, created NOW and touched once: the HIP runtime deals its few
+        # hardware queues (4 by default) to streams in the order they come to life, and two streams on one queue run one
+        # after the other.  Created lazily -- behind whatever streams the application had made by then (a MatchPipeline per
+        # database, ...) -- an upload stream landed on the compute stream's queue and upload, kernels and download of
+        # SDAV.transform(ndarray) stopped overlapping: 47 ms instead of 36 (docs/LAB.md 11.6; GPU_MAX_HW_QUEUES=8 hid it).
+        self._s_in, self._s_out = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
+        for st in (self._s_in, self._s_out):
+            torch.cuda.Event().record(st)
 
     def set_scratch(self, nbytes=SCRATCH_BYTES):
         """Latency mode: lend the context `nbytes` of HBM for the split-K form of the dense GEMMs
@@ -237,8 +245,6 @@ class Engine:
         dt = self._torch_dtype_of(x)
         if dt is None:
             raise ValueError("run_chunked: unsupported array dtype %s" % x.dtype)
-        if not hasattr(self, "_s_in"):
-            self._s_in, self._s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         chunk = max(1, min(int(chunk), n))
         bufs = [torch.empty((chunk,) + tuple(x.shape[1:]), dtype=dt, device=dev) for _ in range(2 if n > chunk else 1)]
@@ -297,8 +303,6 @@ class Engine:
         dt = self._torch_dtype_of(x)
         if dt is None:
             raise ValueError("for_each_chunk: unsupported array dtype %s" % x.dtype)
-        if not hasattr(self, "_s_in"):
-            self._s_in, self._s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
         chunk = max(1, min(int(chunk), n))
         first = chunk if first is None else max(1, min(int(first), chunk))
