@@ -67,7 +67,8 @@ class Engine:
         # database, ...) -- an upload stream landed on the compute stream's queue and upload, kernels and download of
         # SDAV.transform(ndarray) stopped overlapping: 47 ms instead of 36 (docs/LAB.md 11.6; GPU_MAX_HW_QUEUES=8 hid it).
         self._s_in, self._s_out = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
-        for st in (self._s_in, self._s_out):
+        self.side_stream = torch.cuda.Stream(device=self.device)     # MatchPipeline's second stream (selection / exchange beside the next GEMM)
+        for st in (self._s_in, self._s_out, self.side_stream):
             torch.cuda.Event().record(st)
 
     def set_scratch(self, nbytes=SCRATCH_BYTES):

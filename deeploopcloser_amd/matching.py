@@ -195,7 +195,9 @@ class MatchPipeline:
         self.db, self.k, self.depth = db, int(k), int(depth)
         self.engine = db.engine
         dev = self.engine.device
-        self.s_select = torch.cuda.Stream(device=dev)
+        # the engine's side stream, made when the engine was: a stream created here, behind whatever streams the application
+        # has made by now, may share a hardware queue with the submitting stream and overlap nothing (engine.py)
+        self.s_select = self.engine.side_stream
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._slots = []
