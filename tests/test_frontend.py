@@ -183,6 +183,46 @@ def test_end_to_end_pipelines_equal_the_staged_calls(tmp_path):
 
 
 @pytest.mark.gpu
+def test_pipeline_edge_cases():
+    """pipeline.py on the inputs either side of the usual one: no frames, one frame, grey frames, a chunk larger than the
+    batch, a first chunk shorter than the others (Engine.for_each_chunk), resident float64 frames for CnnVtl."""
+    import deeploopcloser_amd as dlc
+    from deeploopcloser_amd import pipeline
+    import real_frames
+    eng = dlc.default_engine()
+    frames = np.stack([dlc.read_ppm(p) for p in real_frames.frame_paths()[:9]])
+    net = dlc.SDAV(seed=2, weight_scale="fan_in")
+    parser = dlc.CvInputParser(30, 41)
+    want = pipeline.sdav_descriptors_from_frames(torch.from_numpy(frames).cuda(), net, parser)
+    assert want.shape == (9, 30, 2500) and want.is_cuda
+    assert pipeline.sdav_descriptors_from_frames(frames[:0], net, parser).shape == (0, 30, 2500)
+    assert torch.equal(pipeline.sdav_descriptors_from_frames(frames[:1], net, parser), want[:1])
+    for chunk, first in ((100, None), (4, None), (4, 1), (2, 2), (5, 3)):
+        pipeline.FIRST_CHUNK_FRAMES = first
+        try:
+            assert torch.equal(pipeline.sdav_descriptors_from_frames(frames, net, parser, chunk_frames=chunk), want), (chunk, first)
+        finally:
+            pipeline.FIRST_CHUNK_FRAMES = None
+    # grey frames in == the grey conversion of the colour frames in
+    gray = eng.rgb_to_gray(torch.from_numpy(frames).cuda()).cpu().numpy()
+    assert torch.equal(pipeline.sdav_descriptors_from_frames(gray, net, parser), want)
+    # the chunk walker itself: every item visited once, in order, whatever the chunking
+    x = np.arange(23 * 5, dtype=np.int32).reshape(23, 5)
+    for chunk, first in ((23, None), (7, None), (7, 2), (1, None), (50, 3)):
+        seen = []
+        eng.for_each_chunk(x, chunk, lambda dev, lo, hi: seen.append((lo, hi, dev.clone())), first=first)
+        torch.cuda.synchronize()
+        assert [s_[0] for s_ in seen] == [0] + [s_[1] for s_ in seen[:-1]] and seen[-1][1] == 23
+        assert np.array_equal(torch.cat([s_[2] for s_ in seen]).cpu().numpy(), x)
+    cnn = dlc.CnnVtl(input_shape=[9, 192, 240, 3], seed=3, mask_seed=4)
+    bgr = np.ascontiguousarray(frames[..., ::-1])
+    d8 = pipeline.cnn_vtl_descriptors_from_frames(bgr, cnn)
+    assert torch.equal(pipeline.cnn_vtl_descriptors_from_frames(torch.from_numpy(bgr).cuda().to(torch.float64), cnn), d8)
+    assert pipeline.cnn_vtl_descriptors_from_frames(bgr[:0], cnn).shape == (0, cnn.columns.size)
+    assert pipeline.cnn_vtl_distance_matrix_from_frames(bgr[:1], cnn).tolist() == [[0]]
+
+
+@pytest.mark.gpu
 def test_cli_reports_per_frame_latency(capsys):
     """The streaming CLI one frame at a time: candidates on stdout, the step latency (file -> descriptors -> match ->
     candidates on the host) on stderr."""
