@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
 }
 
 // out[c] = sum_r in[r, c]: 32 columns x 8 row groups per workgroup, the groups' partial sums combined in group order (kept
-// for the encoder biases of layers more than two below the trained one, whose dz1 buffer is reused before the step's end)
+// for the encoder biases of the layers between 1 and the trained one, whose dz1 buffer is reused before the step's end)
 __global__ __launch_bounds__(256) void colsum_kernel(const double* __restrict__ in, long long rows, long long cols,
                                                      double* __restrict__ out) {
     __shared__ double part[8][33];
@@ -504,7 +504,9 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
                                st, P(w.xt[l]), rows, Kl, P(w.tr), rows);
             GEMM(DLC_B_KN, DLC_ACT_NONE, Kl, Nl, rows, P(w.tr), rows, dz1, Nl, nullptr, P(w.gw[l]), Nl);   // x~^T dz1
         }
-        if (layer - l <= 2) dz1_of[l] = dz1;            // (behind h, dz1a, dz1b: alive until the update kernel)
+        // dz1 of the trained layer lives behind h, the deeper ones alternate between two buffers: at the step's end only the
+        // trained layer's and the last two written (layers 1 and 0) are still there; the others are summed now
+        if (l == layer || l <= 1) dz1_of[l] = dz1;
         else hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)dlc::cdiv(Nl, 32)), dim3(256), 0, st, dz1, rows, Nl, P(w.gbe[l]));
         if (l == 0) break;
         GEMM(DLC_B_NK, DLC_ACT_NONE, rows, Kl, Nl, dz1, Nl, W[l], Nl, nullptr, P(w.dxt), Kl);          // dz1 W^T

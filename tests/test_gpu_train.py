@@ -18,14 +18,17 @@ def close(a, b, rel=1e-9):
     return np.abs(a - b).max() <= rel * max(1.0, np.abs(b).max())
 
 
-@pytest.mark.parametrize("layer", [0, 1, 2])
+@pytest.mark.parametrize("layer", [0, 1, 2, 3, 4])
 def test_train_step_small_vs_oracle(layer):
+    """One SGD step of layer `layer` of a small five-layer network against oracle/sdav_train.py: loss parts and every
+    parameter the loss reaches.  Layers 3 and 4 take the step's other route for the encoder biases of layers 2 .. layer - 1
+    (their dz1 buffer is reused before the update kernel runs: a column-sum launch of their own)."""
     import deeploopcloser_amd as dlc
     from oracle import sdav_train as ot
     from oracle.tensor_ops import corruption_mask
     eng = dlc.default_engine()
     rng = np.random.RandomState(layer)
-    batch, patches, dims = 4, 5, (37, 21, 21, 21)
+    batch, patches, dims = 4, 5, (37, 21, 21, 21, 21, 21)
     x = rng.uniform(0, 1, size=(batch, patches, dims[0]))
     ws = [rng.standard_normal((a, b)) * 0.4 for a, b in zip(dims[:-1], dims[1:])]
     bes = [rng.standard_normal(b) * 0.1 for b in dims[1:]]
