@@ -40,8 +40,13 @@
 // writes, per lane, runs of sixteen consecutive outputs of one row: bias + sigmoid in fp32, then either the next layer's
 // two fp16 pieces (32 bytes each, K32-major) or, for the last layer, sixteen fp64 values.  The activations never exist as
 // fp64 between the layers.
-// Both operands are re-read (neither is a once-only stream): an XCD's 32 resident workgroups take one br x bc block of
-// tiles, so that br + bc operand panels feed br * bc tiles out of that XCD's L2.
+// Both operands are re-read (neither is a once-only stream).  Tile order: the tiles in "super-rows" of four activation row
+// tiles, column by column inside a super-row, cut into EIGHT CONTIGUOUS RANGES, one per XCD (workgroup ids go round-robin
+// to the XCDs; an XCD starts its ids in order, one workgroup per CU): the 32 tiles an XCD runs at a time are 4 rows x 8
+// columns of tiles -- 12 operand panels out of that XCD's L2 -- and every XCD gets its 1 / 8 of the tiles to within one.
+// (r04 .. the first r05 form dealt whole blocks of 6 x 5 tiles to the XCDs: 1250 tiles = 42 blocks = SIX rounds on two of
+// the XCDs where 1250 / 256 = 4.9 fit in five -- a sixth of the kernel's time, found through the in-kernel stamps: the k
+// loop accounted for 140 of a tile's 186 us.)
 #include "gemm_internal.h"
 
 namespace dlc_gemm {
@@ -58,6 +63,7 @@ constexpr int SP_RING_B = 0;                   // (W2, h2) slots 0, 1
 constexpr int SP_RING_A = 2 * SP_PAIR_B;       // (W1, h1) slots 0, 1, 2
 constexpr int SP_LDS = 5 * SP_PAIR_B;          // 160 KiB: all of a CU's LDS
 constexpr int SP_X_SHIFT = 11;                 // activations are carried as h * 2^11
+constexpr int SP_SUPER = 4;                    // activation row tiles per super-row of the tile order
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -74,10 +80,9 @@ struct SplitArgs {
     long long oslice_b;
     double* C;                  // ... whose output is fp64 [M, ldc]
     long long ldc;
-    int br, bc;                 // an XCD's block: br tiles of activation rows x bc tiles of weight columns, br * bc <= 32
-    long long nbr, nblocks;
     long long tiles_m;          // activation row tiles
     int tiles_n;                // weight column tiles
+    long long per_xcd, extra;   // tiles per XCD: per_xcd (+ 1 for the first `extra` XCDs), in the order of the file header
 };
 
 // LDS-DMA wave-instructions of 1 KiB each: inline asm so that hipcc does not count them in vmcnt, M0 saved and restored
@@ -143,18 +148,24 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2;   // weight-column half (128 columns)
     const int wc = wid & 3;    // activation-row block (64 rows)
-    // workgroup -> tile: ids go round-robin to the 8 XCDs; 32 consecutive ids of an XCD take one br x bc block
+    // workgroup -> tile: ids go round-robin to the 8 XCDs; XCD x walks its own contiguous range of the tile order
     long long tile_m;
     int tile_n;
     {
         const long long id = blockIdx.x;
-        const long long l = id >> 3;
-        const long long blk = (l >> 5) * 8 + (id & 7);
-        const int i = (int)(l & 31);
-        if (blk >= p.nblocks || i >= p.br * p.bc) return;
-        tile_m = (blk % p.nbr) * p.br + (i % p.br);
-        tile_n = (int)(blk / p.nbr) * p.bc + (i / p.br);
-        if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
+        const long long x = id & 7, l = id >> 3;
+        if (l >= p.per_xcd + (x < p.extra ? 1 : 0)) return;
+        const long long t = x * p.per_xcd + (x < p.extra ? x : p.extra) + l;
+        const long long full = (p.tiles_m / SP_SUPER) * SP_SUPER * p.tiles_n;       // tiles in whole super-rows
+        if (t < full) {
+            const long long w = t % ((long long)SP_SUPER * p.tiles_n);
+            tile_m = t / ((long long)SP_SUPER * p.tiles_n) * SP_SUPER + w % SP_SUPER;
+            tile_n = (int)(w / SP_SUPER);
+        } else {
+            const long long rr = p.tiles_m % SP_SUPER, w = t - full;
+            tile_m = p.tiles_m / SP_SUPER * SP_SUPER + w % rr;
+            tile_n = (int)(w / rr);
+        }
     }
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem_sp;
 
@@ -510,21 +521,9 @@ int split_encode(dlc_ctx* ctx, int64_t rows, int n_layers, const int64_t* dims, 
         a.C = fin ? out : nullptr; a.ldc = dims[l + 1];
         a.tiles_m = dlc::cdiv(rows, (int64_t)SP_BN);
         a.tiles_n = (int)(L.np / SP_BM);
-        // an XCD's block of <= 32 tiles: the shape with the fewest operand panels per computed tile, idle slots counted
-        int best_br = 1, best_bc = 1;
-        double best = 1e30;
-        for (int bc = 1; bc <= 32 && bc <= a.tiles_n; ++bc) {
-            int br = 32 / bc;
-            if ((long long)br > a.tiles_m) br = (int)a.tiles_m;
-            const double cover = (double)(dlc::cdiv((int64_t)a.tiles_n, (int64_t)bc) * bc) / a.tiles_n *
-                                 (double)(dlc::cdiv(a.tiles_m, (int64_t)br) * br) / (double)a.tiles_m;
-            const double cost = (double)(br + bc) / (br * bc) * cover * (32.0 / (br * bc));
-            if (cost < best) { best = cost; best_br = br; best_bc = bc; }
-        }
-        a.br = best_br; a.bc = best_bc;
-        a.nbr = dlc::cdiv(a.tiles_m, (int64_t)a.br);
-        a.nblocks = a.nbr * dlc::cdiv((int64_t)a.tiles_n, (int64_t)a.bc);
-        const long long nwg = dlc::cdiv(a.nblocks, (int64_t)8) * 8 * 32;
+        const long long tiles = a.tiles_m * a.tiles_n;
+        a.per_xcd = tiles / 8; a.extra = tiles % 8;
+        const long long nwg = (a.per_xcd + (a.extra ? 1 : 0)) * 8;
         if (nwg > 0x7fffffffll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_encode_split: too many tiles");
         const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
         if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
