@@ -23,6 +23,12 @@ ws = [t for k, t in eng._ws.items() if k[0] == "sdav_split"][0]
 mp, M = 32000, 31890
 piece0 = ws[:mp * 80 * 64].view(torch.int64).reshape(80, mp, 8)          # [slice][row][64 bytes]
 d = piece0[:23, M:M + 110].reshape(-1, 2)[:125 * 10 * 8].cpu().numpy()     # 4 entries of 16 bytes per row, 110 rows per slice
+if "epistamp" in sys.argv[1]:
+    e = piece0[23:46, M:M + 110].reshape(-1, 2)[:125 * 10 * 8].cpu().numpy()[:, 0].astype(np.float64)
+    c0 = d[:, 0].astype(np.float64)
+    print("%%-30s %%-9s k loop %%.0f cycles per wave (median), loop end -> kernel end %%.0f cycles (median; max %%.0f) = %%.1f %%%% of the loop"
+          %% (os.path.basename(sys.argv[1]), sys.argv[2], np.median(c0[c0 > 0]), np.median(e[e > 0]), e.max(), 100 * np.median(e[e > 0]) / np.median(c0[c0 > 0])), flush=True)
+    sys.exit(0)
 cyc, ticks = d[:, 0].astype(np.float64), d[:, 1].astype(np.float64)
 ok = ticks > 0
 if "barstamp" in sys.argv[1]:

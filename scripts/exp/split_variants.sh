@@ -30,10 +30,13 @@ P = {
                "        { const unsigned long long b0_ = __builtin_amdgcn_s_memtime(); sp_barrier(); bar_ += __builtin_amdgcn_s_memtime() - b0_; } \\\n"),
               ("    f32x4_t acc[8][4];\n", "    unsigned long long bar_ = 0;\n    f32x4_t acc[8][4];\n"),
               ("d_[1] = (long long)(sr1_ - sr0_); }", "d_[1] = (long long)bar_; }")],
+ # cycles from the end of the k loop to the end of the kernel (bias staging, sigmoid, re-split, stores), per wave
+ "epistamp": [("    const unsigned long long st1_ = __builtin_amdgcn_s_memtime(), sr1_ = __builtin_amdgcn_s_memrealtime();", "    const unsigned long long st1_ = __builtin_amdgcn_s_memtime(), sr1_ = __builtin_amdgcn_s_memrealtime();\n    const long long ix_e_ = (tile_m * p.tiles_n + tile_n) * 8 + wid;"),
+              ("                *(uint4*)(o2 + 16) = make_uint4(w2[4], w2[5], w2[6], w2[7]);\n            }\n        }\n    }\n}", "                *(uint4*)(o2 + 16) = make_uint4(w2[4], w2[5], w2[6], w2[7]);\n            }\n        }\n    }\n    if (!FINAL && lane == 0 && p.M == 31890) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); long long* d_ = (long long*)(p.O[0] + (23 + ix_e_ / 440) * p.oslice_b + (p.M + (ix_e_ % 440) / 4) * 64 + (ix_e_ % 4) * 16); d_[0] = (long long)(__builtin_amdgcn_s_memtime() - st1_); d_[1] = 0; }\n}")],
  "noepi": [("            if (m >= p.M) continue;\n            float hv[16];", "            if (m >= p.M || p.ns > 1) continue;\n            float hv[16];")],
  # in-kernel stamps of the k loop of the HIDDEN layers (shader cycles and 100 MHz ticks per wave), stored where nothing else
  # is: rows >= M of the output piece (440 entries of 16 bytes per k-slice); the epilogue stays (the MFMAs must stay alive)
- "stamp": [("    // ---- prologue: (W1, h1) of slices 0, 1, 2", "    const unsigned long long st0_ = __builtin_amdgcn_s_memtime(), sr0_ = __builtin_amdgcn_s_memrealtime();\n    // ---- prologue: (W1, h1) of slices 0, 1, 2"),
+ "stamp": [("    // ---- prologue: early waves issue (W2, h2)", "    const unsigned long long st0_ = __builtin_amdgcn_s_memtime(), sr0_ = __builtin_amdgcn_s_memrealtime();\n    // ---- prologue: early waves issue (W2, h2)"),
            ("    SP_WAIT_VMCNT(0);    // the clamped tail DMAs must not outlive the workgroup's LDS\n    SP_WAIT_LGKM0();",
             "    SP_WAIT_VMCNT(0);    // the clamped tail DMAs must not outlive the workgroup's LDS\n    SP_WAIT_LGKM0();\n    const unsigned long long st1_ = __builtin_amdgcn_s_memtime(), sr1_ = __builtin_amdgcn_s_memrealtime();"),
            ("    const int lg = lane >> 4;\n    const float inv", "    if (!FINAL && lane == 0 && p.M == 31890) { const long long ix_ = (tile_m * p.tiles_n + tile_n) * 8 + wid; long long* d_ = (long long*)(p.O[0] + (ix_ / 440) * p.oslice_b + (p.M + (ix_ % 440) / 4) * 64 + (ix_ % 4) * 16); d_[0] = (long long)(st1_ - st0_); d_[1] = (long long)(sr1_ - sr0_); }\n    const int lg = lane >> 4;\n    const float inv")],
@@ -49,6 +52,5 @@ PY
     (cd $T/$name && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-function *.hip -o $R/var_build/lib_split_$name.so)
     echo built var_build/lib_split_$name.so
 }
-build barstamp "stamp,barstamp" &
-build barstamp_nodma_nolds "nodma,nolds,stamp,barstamp" &
+build epistamp "stamp,epistamp" &
 wait
