@@ -62,6 +62,9 @@ constexpr int SP_PAIR_B = 2 * SP_OP;           // a slot: one weight tile + one 
 constexpr int SP_RING_B = 0;                   // (W2, h2) slots 0, 1
 constexpr int SP_RING_A = 2 * SP_PAIR_B;       // (W1, h1) slots 0, 1, 2
 constexpr int SP_LDS = 5 * SP_PAIR_B;          // 160 KiB: all of a CU's LDS
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 constexpr int SP_X_SHIFT = 11;                 // activations are carried as h * 2^11
 constexpr int SP_SUPER = 4;                    // activation row tiles per super-row of the tile order
 
@@ -268,6 +271,13 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
         sa_next = sa_next == 2 * SP_PAIR_B ? 0u : sa_next + SP_PAIR_B;                                           \
     } while (0)
 
+    // this thread's bias of the tile (threads 0 .. 255), folded for the epilogue's one fma (see there); fetched here, a
+    // register across the k loop, because behind the loop its miss was 2 000 cycles that every wave of the tile waited for
+    float bias_l = 0.0f;
+    if (tid < SP_BM) {
+        const int n = tile_n * SP_BM + tid;
+        bias_l = (float)(-1.4426950408889634 * ((p.bias && n < p.N) ? p.bias[n] : 0.0) - (FINAL ? 0.0 : (double)SP_X_SHIFT));
+    }
     // ---- prologue: early waves issue (W2, h2) of slices 0, 1; late waves (W1, h1) of slices 0, 1, 2; slice 0 landed and
     // visible; W1, h1 (0) read
     SP_ISSUE4(early, 0, 0, 0); SP_ISSUE4(early, 0, 0, 1);
@@ -296,22 +306,27 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
     // ---- epilogue.  C/D layout: column = lane & 15 -> activation row, row = 4 * (lane >> 4) + reg -> weight column; with
     // the permuted panel rows, acc[th * 4 + tt][c][r] is output (m, n0 + 4 tt + r): sixteen consecutive columns per (c, th).
     const int lg = lane >> 4;
-    const float inv = 1.0f / ((float)(1 << SP_X_SHIFT) * p.wscale[0]);        // a power of two: exact
-    const float xs = (float)(1 << SP_X_SHIFT);
+    // sigmoid(z) = 1 / (1 + 2^(-z log2 e)), z = acc * inv + b with inv = 1 / (2^11 * the weights' scale), a power of two.
+    // The constants are folded into the ONE fma in front of v_exp_f32: zl = acc * (-inv log2 e) + (-b log2 e); a hidden
+    // layer wants h * 2^11 = 1 / (2^-11 + 2^(zl - 11)), so its -11 rides in the staged bias too.  The reciprocal is
+    // v_rcp_f32 (1 ulp): `1.0f / x` and __frcp_rn are the IEEE division here -- ten instructions per element, 1280 per lane
+    // and tile, a third of the epilogue (the tolerance of this mode is 2^-15 of the descriptors, not the last bit).
+    const float ninv = -1.4426950408889634f / ((float)(1 << SP_X_SHIFT) * p.wscale[0]);
+    const float one = FINAL ? 1.0f : 1.0f / (float)(1 << SP_X_SHIFT);
     // the tile's 256 biases through LDS (the ring is dead): ONE global load per thread; a lane's sixteen then come as four
     // 16-byte LDS reads (read straight from memory they were 32 dependent 8-byte loads per lane: a tenth of a tile's time)
     {
         sp_barrier();                                          // every wave is past its last fragment read
         float* bl = (float*)smem_sp;
-        if (tid < SP_BM) {
-            const int n = tile_n * SP_BM + tid;
-            bl[tid] = (p.bias && n < p.N) ? (float)p.bias[n] : 0.0f;
-        }
+        if (tid < SP_BM) bl[tid] = bias_l;
         __syncthreads();
     }
+    constexpr int SP_TP = 68;                                 // floats per row of a wave's 64 x 64 block: 16 rows of float4 writes / a row of float2 reads each sweep the 64 banks once
+    float* tl = (float*)(smem_sp + 4096) + wid * 64 * SP_TP;  // (behind the biases; 8 waves x 17 KiB)
 #pragma unroll
     for (int th = 0; th < 2; ++th) {
         const int n0 = tile_n * SP_BM + wr * 128 + th * 64 + 16 * lg;
+        const bool whole = tile_n * SP_BM + wr * 128 + th * 64 + 64 <= p.N;      // all 64 columns of this wave's half exist
         float bv[16];
         {
             const float4* b4 = (const float4*)((const float*)smem_sp + wr * 128 + th * 64 + 16 * lg);
@@ -330,39 +345,73 @@ __global__ __launch_bounds__(SP_THREADS, 2) void gemm_split_f16_kernel(SplitArgs
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = fmaf(acc[th * 4 + tt][c][r], inv, bv[4 * tt + r]);
-                    hv[4 * tt + r] = __frcp_rn(1.0f + __expf(-z));                  // sigmoid (TensorflowWrapper.py:77-78)
+                    const float zl = fmaf(acc[th * 4 + tt][c][r], ninv, bv[4 * tt + r]);
+                    hv[4 * tt + r] = __builtin_amdgcn_rcpf(one + __builtin_amdgcn_exp2f(zl));   // sigmoid (TensorflowWrapper.py:77-78) [* 2^11]
                 }
             if constexpr (FINAL) {
-                double* dst = p.C + m * p.ldc + n0;
-                if (n0 + 16 <= p.N && ((p.ldc & 1) == 0)) {
+                // into the wave's LDS block, row (c, i), columns 16 lg .. + 15: the stores below want whole rows
+                float* row = tl + (c * 16 + i) * SP_TP + 16 * lg;
 #pragma unroll
-                    for (int j = 0; j < 16; j += 2) *(double2*)(dst + j) = make_double2((double)hv[j], (double)hv[j + 1]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (n0 + j < p.N) dst[j] = (double)hv[j];
-                }
+                for (int j = 0; j < 16; j += 4) *(float4*)(row + j) = make_float4(hv[j], hv[j + 1], hv[j + 2], hv[j + 3]);
             } else {
                 // the next layer's two pieces of h * 2^11; columns past N are zeros there (its weights' k rows past N too)
                 unsigned w1[8], w2[8];
+                if (!whole) {                                  // (wave-uniform: only the last column tile has such columns)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) hv[j] = n0 + j < p.N ? hv[j] : 0.0f;
+                }
 #pragma unroll
                 for (int j = 0; j < 16; j += 2) {
-                    const float v0 = n0 + j < p.N ? hv[j] * xs : 0.0f, v1 = n0 + j + 1 < p.N ? hv[j + 1] * xs : 0.0f;
-                    const _Float16 a0 = (_Float16)v0, a1 = (_Float16)v1;
-                    const _Float16 b0 = (_Float16)(v0 - (float)a0), b1 = (_Float16)(v1 - (float)a1);
-                    w1[j >> 1] = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
-                    w2[j >> 1] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+                    const f32x2_t v = {hv[j], hv[j + 1]};
+                    const f16x2_t a = __builtin_convertvector(v, f16x2_t);                 // v_cvt_pk_f16_f32
+                    const f16x2_t b = __builtin_convertvector(v - __builtin_convertvector(a, f32x2_t), f16x2_t);
+                    w1[j >> 1] = __builtin_bit_cast(unsigned, a);
+                    w2[j >> 1] = __builtin_bit_cast(unsigned, b);
                 }
-                // K32-major: columns n0 .. n0 + 15 are half of row m's 64 bytes in slice n0 / 32
-                const long long o = (long long)(n0 >> 5) * p.oslice_b + m * SP_ROWB + (n0 & 16) * 2;
+                // K32-major: columns n0 .. n0 + 15 are half of row m's 64 bytes in slice n0 / 32 -- the wave's 64 columns are two
+                // slices, lanes 0-31 hold the first one's.  Stored as they lie, an instruction wrote 16 of every row's 64 bytes
+                // in each slice; v_permlane32_swap trades the second 16 bytes of the lower lanes for the first 16 of the upper
+                // ones, and every instruction writes ONE slice: sixteen rows x 64 bytes = 1 KiB in a piece.
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(w1[e], w1[4 + e], false, false);
+                    const u32x2_t s2 = __builtin_amdgcn_permlane32_swap(w2[e], w2[4 + e], false, false);
+                    w1[e] = s1[0]; w1[4 + e] = s1[1];
+                    w2[e] = s2[0]; w2[4 + e] = s2[1];
+                }
+                const int nb = tile_n * SP_BM + wr * 128 + th * 64;                      // the wave's 64 columns: slices nb / 32, + 1
+                const long long o = (long long)(nb >> 5) * p.oslice_b + m * SP_ROWB + (lg & 1) * 32 + (lg >> 1) * 16;
                 char* o1 = p.O[0] + o;
                 char* o2 = p.O[1] + o;
                 *(uint4*)o1 = make_uint4(w1[0], w1[1], w1[2], w1[3]);
-                *(uint4*)(o1 + 16) = make_uint4(w1[4], w1[5], w1[6], w1[7]);
+                *(uint4*)(o1 + p.oslice_b) = make_uint4(w1[4], w1[5], w1[6], w1[7]);
                 *(uint4*)o2 = make_uint4(w2[0], w2[1], w2[2], w2[3]);
-                *(uint4*)(o2 + 16) = make_uint4(w2[4], w2[5], w2[6], w2[7]);
+                *(uint4*)(o2 + p.oslice_b) = make_uint4(w2[4], w2[5], w2[6], w2[7]);
             }
+        }
+        if constexpr (FINAL) {
+            // fp64 out, a ROW at a time: the wave's 64 rows x 64 columns come back from LDS with 32 lanes on one row's 512
+            // bytes, two rows per store instruction.  (Stored from the accumulators' layout every lane wrote 16 bytes of a
+            // different cache line: 64 lines per instruction, 0.14 ms of this layer's 0.99.)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int nb = tile_n * SP_BM + wr * 128 + th * 64, cj = 2 * (lane & 31);
+            const bool pairs = (p.ldc & 1) == 0 && ((unsigned long long)p.C & 15) == 0;
+#pragma unroll 4
+            for (int it = 0; it < 32; ++it) {
+                const int r = 2 * it + (lane >> 5);
+                const long long m = tile_m * SP_BN + wc * 64 + r;
+                const float2 v = *(const float2*)(tl + r * SP_TP + cj);
+                if (m >= p.M) continue;
+                double* dst = p.C + m * p.ldc + nb + cj;
+                if (pairs && nb + cj + 2 <= p.N) *(double2*)dst = make_double2((double)v.x, (double)v.y);
+                else {
+                    if (nb + cj < p.N) dst[0] = (double)v.x;
+                    if (nb + cj + 1 < p.N) dst[1] = (double)v.y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the next half's rows overwrite the block
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -39,7 +39,7 @@ P = {
  "stamp": [("    // ---- prologue: early waves issue (W2, h2)", "    const unsigned long long st0_ = __builtin_amdgcn_s_memtime(), sr0_ = __builtin_amdgcn_s_memrealtime();\n    // ---- prologue: early waves issue (W2, h2)"),
            ("    SP_WAIT_VMCNT(0);    // the clamped tail DMAs must not outlive the workgroup's LDS\n    SP_WAIT_LGKM0();",
             "    SP_WAIT_VMCNT(0);    // the clamped tail DMAs must not outlive the workgroup's LDS\n    SP_WAIT_LGKM0();\n    const unsigned long long st1_ = __builtin_amdgcn_s_memtime(), sr1_ = __builtin_amdgcn_s_memrealtime();"),
-           ("    const int lg = lane >> 4;\n    const float inv", "    if (!FINAL && lane == 0 && p.M == 31890) { const long long ix_ = (tile_m * p.tiles_n + tile_n) * 8 + wid; long long* d_ = (long long*)(p.O[0] + (ix_ / 440) * p.oslice_b + (p.M + (ix_ % 440) / 4) * 64 + (ix_ % 4) * 16); d_[0] = (long long)(st1_ - st0_); d_[1] = (long long)(sr1_ - sr0_); }\n    const int lg = lane >> 4;\n    const float inv")],
+           ("    const int lg = lane >> 4;\n    // sigmoid(z)", "    if (!FINAL && lane == 0 && p.M == 31890) { const long long ix_ = (tile_m * p.tiles_n + tile_n) * 8 + wid; long long* d_ = (long long*)(p.O[0] + (ix_ / 440) * p.oslice_b + (p.M + (ix_ % 440) / 4) * 64 + (ix_ % 4) * 16); d_[0] = (long long)(st1_ - st0_); d_[1] = (long long)(sr1_ - sr0_); }\n    const int lg = lane >> 4;\n    // sigmoid(z)")],
 }
 for n in names:
     if not n:
