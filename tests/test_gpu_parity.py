@@ -692,6 +692,34 @@ def test_sdav_transform_split_mode_within_north_star_tolerance(dlc, scale):
     assert worst < (4e-5 if scale == "reference" else 1e-6)            # what the form delivers (2.1e-5 / 1.8e-7), with margin
 
 
+@pytest.mark.parametrize("rows,dims", [(1, (37, 21)), (300, (37, 21, 19, 23)), (257, (1681, 250, 2)), (513, (64, 300, 257))])
+def test_sdav_split_mode_ragged_shapes(dlc, rows, dims):
+    """dlc_sdav_encode_split on shapes the drop-in class never asks for: odd widths (the fp64 output's pitch is odd: no
+    16-byte stores), widths that end inside a 16-column block, a 64-column half and a 256-column tile, a single layer, one
+    row, rows that end just behind a 256-row tile; no biases for one layer.  Against the fp64 chain in NumPy: relative L2
+    of every row within 1e-4, and every row the same when encoded alone (rows are independent)."""
+    eng = dlc.default_engine()
+    rng = np.random.RandomState(rows + len(dims))
+    n_layers = len(dims) - 1
+    ws = [rng.standard_normal((dims[l], dims[l + 1])) / np.sqrt(dims[l]) for l in range(n_layers)]
+    bs = [0.2 * rng.standard_normal(dims[l + 1]) if l != 1 else None for l in range(n_layers)]
+    x = rng.uniform(0, 1, size=(rows, dims[0]))
+    ref = x
+    for w, b in zip(ws, bs):
+        ref = 1.0 / (1.0 + np.exp(-(ref @ w + (0.0 if b is None else b))))
+    tw = [torch.from_numpy(w).to(eng.device) for w in ws]
+    tb = [None if b is None else torch.from_numpy(b).to(eng.device) for b in bs]
+    panels = eng.sdav_split_panels(tw)
+    tx = torch.from_numpy(x).to(eng.device)
+    h = eng.sdav_encode_split(tx, list(dims), panels, tb).cpu().numpy()
+    assert h.shape == ref.shape
+    l2 = np.linalg.norm(h - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert l2.max() < 1e-4, l2.max()
+    for r in sorted({0, rows // 2, rows - 1}):
+        one = eng.sdav_encode_split(tx[r:r + 1], list(dims), panels, tb).cpu().numpy()
+        assert np.array_equal(one[0], h[r])
+
+
 @pytest.mark.parametrize("how", ["train_step", "train_steps_graph", "fit"])
 def test_sdav_split_mode_sees_trained_weights(dlc, how):
     """transform -> train -> transform in the tolerance mode (SDAV.py:232-240,293-302: transform always sees the current
