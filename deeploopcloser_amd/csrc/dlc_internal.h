@@ -41,6 +41,7 @@ enum {
     DLC_ATTR_GRAM_I8 = 49,       // gram_i8_kernel
     DLC_ATTR_PAIR_FILTER = 50,   // pair_score_filter_kernel
     DLC_ATTR_SPLIT_F16 = 51,     // gemm_split_f16_kernel
+    DLC_ATTR_DS_DMA = 52,        // distinctive_score_dma_kernel
 };
 
 namespace dlc {

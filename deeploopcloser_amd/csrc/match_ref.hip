@@ -170,7 +170,12 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
     double lo = INFINITY, hi = -INFINITY;
     bool bad = false;
     const int tid = threadIdx.x, c = tid % DS_COLS, g = tid / DS_COLS;
-    const int col = blockIdx.x * DS_COLS + c;
+    // workgroup ids go round-robin to the 8 XCDs: XCD x takes the x-th CONTIGUOUS eighth of the column groups, so that the
+    // groups that share a cache line (and a DRAM page) run side by side under one L2 instead of on eight of them
+    const int groups = (H + DS_COLS - 1) / DS_COLS, per = (groups + 7) / 8;
+    const int grp = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (grp >= groups) return;
+    const int col = grp * DS_COLS + c;
     const bool col_ok = col < H;
     const double* src = desc + (col_ok ? col : 0);
     double va[DS_U], vb[DS_U];
@@ -228,6 +233,146 @@ __global__ __launch_bounds__(256) void distinctive_score_kernel(const double* __
             for (int q = 1; q < DS_G; ++q) { l = fmin(l, buf[0][q][c]); h = fmax(h, buf[1][q][c]); }
             range[3 + col] = dlc_f64_key(l);
             range[3 + H + col] = dlc_f64_key(h);
+        }
+    }
+}
+
+// The same pass with the loads as LDS-DMA (H even, 16-byte aligned rows; the form above stays for the rest).  What set the
+// pace of the form above was neither memory nor the add chain's own latency (a dependent v_add_f64 issues every 9 cycles,
+// scripts/micro/add_f64_chain.hip: 0.13 ms for 31 890 rows) but the LDS round trips hipcc left between the adds -- "read two
+// rows, wait for them, add them": 22 cycles a row, 0.34 ms, 1.9 TB/s however the columns were dealt.
+// Here a workgroup owns 16 columns (one 128-byte line of every row: 157 workgroups at H = 2500, one per CU -- two workgroups
+// on a CU put two chains on one SIMD: 8 columns per workgroup 0.27 ms); waves 1-3 fetch -- a batch of 384 rows = 48 KiB = 48
+// DMA instructions (eight rows x eight 16-byte pieces each), three batches in the ring (144 KiB, two in flight) -- and take
+// the extremes of what has landed (all of a batch's reads first, then the comparisons: one LDS round trip, not one per
+// value -- that alone was 0.29 -> 0.20 ms); wave 0 does nothing but the chain: sixteen lanes, one column each, 32 rows at a
+// time out of LDS into registers with the next 32 on their way.  One barrier per batch: "batch t has landed, batch t - 1 is
+// consumed".  0.19 ms = 3.4 TB/s (batches of 192 rows, six in the ring: 0.20).
+#ifndef DLC_DSD_COLS
+#define DLC_DSD_COLS 16
+#endif
+constexpr int DSD_RB = 384, DSD_NB = 3;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dsd_dma(unsigned voff, const char* sbase, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+#pragma clang diagnostic pop
+template <int DSD_C>
+__global__ __launch_bounds__(256) void distinctive_score_dma_kernel(const double* __restrict__ desc, long long rows, int H,
+                                                                    double mu, double sigma, double* __restrict__ score,
+                                                                    unsigned long long* __restrict__ range) {
+    extern __shared__ __attribute__((aligned(16))) char dsd_smem[];
+    constexpr int DSD_BB = DSD_RB * DSD_C * 8;                 // bytes of a batch
+    constexpr int PPR = DSD_C / 2, RPI = 64 / PPR;             // 16-byte pieces per row; rows per DMA instruction
+    constexpr int IPW = DSD_RB / RPI / 3;                      // DMA instructions per loader wave and batch
+    constexpr int NQ = 192 / DSD_C;                            // threads of waves 1-3 per column (the extremes)
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int groups = (H + DSD_C - 1) / DSD_C, per = (groups + 7) / 8;
+    const int grp = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);      // XCD x: the x-th contiguous eighth of the groups
+    if (grp >= groups) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col0 = grp * DSD_C;
+    const long long rowb = (long long)H * 8, nb = (rows + DSD_RB - 1) / DSD_RB;
+    const unsigned lds_base = (unsigned)(unsigned long long)(lds_ptr_t)dsd_smem;
+    // loader lanes: piece (16 bytes = two columns) lane & 7 of row lane >> 3 of an instruction's eight rows; a piece past
+    // the last column fetches piece 0 again (nobody reads it)
+    const unsigned pc16 = (unsigned)((col0 + (lane % PPR) * 2 < H ? (lane % PPR) : 0) * 16);
+    auto issue = [&](long long t, int slot) {                  // batch t (past the end: the last one again, into a dead slot)
+        const long long tc = t < nb ? t : nb - 1, r0 = tc * DSD_RB;
+        const long long last = rows - 1 - r0;                  // rows past the end re-read the last one
+        const unsigned long long a = (unsigned long long)(desc + r0 * H + col0);
+        const unsigned a_lo = __builtin_amdgcn_readfirstlane((unsigned)a), a_hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const char* base = (const char*)(((unsigned long long)a_hi << 32) | a_lo);      // (unsigned halves: the builtin returns int)
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)slot * DSD_BB + (unsigned)(w - 1) * IPW * 1024);
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const long long ri = ((w - 1) * IPW + j) * RPI + lane / PPR;
+            dsd_dma((unsigned)((ri < last ? ri : last) * rowb) + pc16, base, dst + j * 1024);
+        }
+    };
+    // extremes: thread (c, q) of waves 1-3 sees rows q, q + 12, .. of column c of every batch
+    const int rc = (tid - 64) % DSD_C, rq = (tid - 64) / DSD_C;
+    const bool rcol_ok = col0 + rc < H;
+    double lo = INFINITY, hi = -INFINITY, s = 0.0;
+    bool bad = false;
+    if (w > 0)
+        for (int t = 0; t < DSD_NB - 1; ++t) issue(t, t);
+    int slot = 0, free_slot = DSD_NB - 1;
+    for (long long t = 0; t < nb; ++t) {
+        if (w > 0) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(IPW * (DSD_NB - 2)) : "memory");    // this wave's pieces of batch t
+        __syncthreads();                                       // batch t is whole; batch t - 1 is consumed
+        const double* b = (const double*)(dsd_smem + slot * DSD_BB);
+        const long long r0 = t * DSD_RB;
+        const int m = rows - r0 < DSD_RB ? (int)(rows - r0) : DSD_RB;
+        if (w > 0) {
+            issue(t + DSD_NB - 1, free_slot);
+            if (range && rcol_ok) {
+                double v[DSD_RB / NQ];                         // all reads first: one LDS round trip, not one per value
+#pragma unroll
+                for (int u = 0; u < DSD_RB / NQ; ++u) v[u] = b[(rq + NQ * u) * DSD_C + rc];
+#pragma unroll
+                for (int u = 0; u < DSD_RB / NQ; ++u) {        // (rows past the end hold the last row again: no predicate)
+                    bad |= !(fabs(v[u]) < INFINITY); lo = fmin(lo, v[u]); hi = fmax(hi, v[u]);
+                }
+            }
+        } else if (lane < DSD_C) {
+            // the chain: 32 rows at a time out of LDS into registers, the NEXT 32 on their way while these are added (left
+            // to itself hipcc read two rows, waited for them, added them: an LDS round trip per pair, 40 cycles a row, and
+            // the chain -- not the memory -- set the pace of both forms of this pass)
+            if (m == DSD_RB) {
+                double va[32], vb[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) va[r] = b[r * DSD_C + lane];
+                // "two adds, then one LDS read (two rows)": a dependent v_add_f64 issues every 9 cycles (scripts/micro/
+                // add_f64_chain.hip), the reads of the next 32 rows ride in the gaps
+#define DSD_PAIRS _Pragma("unroll") for (int z_ = 0; z_ < 16; ++z_) { __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+                for (int blk = 0; blk < DSD_RB / 32; blk += 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) vb[r] = b[((blk + 1) * 32 + r) * DSD_C + lane];
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) s += va[r];
+                    DSD_PAIRS
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (blk + 2 < DSD_RB / 32) {
+#pragma unroll
+                        for (int r = 0; r < 32; ++r) va[r] = b[((blk + 2) * 32 + r) * DSD_C + lane];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) s += vb[r];
+                    if (blk + 2 < DSD_RB / 32) { DSD_PAIRS }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef DSD_PAIRS
+            } else {
+                for (int r = 0; r < m; ++r) s += b[r * DSD_C + lane];
+            }
+        }
+        free_slot = slot;
+        slot = slot == DSD_NB - 1 ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the redundant tail DMAs must not outlive the workgroup's LDS
+    __syncthreads();
+    if (w == 0 && lane < DSD_C && col0 + lane < H) {
+        const double avg = s / (double)rows;
+        const double e = -((avg - mu) * (avg - mu)) / (2.0 * sigma * sigma);
+        score[col0 + lane] = exp(e);
+    }
+    if (range) {
+        double* red = (double*)dsd_smem;                       // [2][NQ][DSD_C]
+        if (w > 0) { red[rq * DSD_C + rc] = lo; red[192 + rq * DSD_C + rc] = hi; }
+        const bool any_bad = __ballot(bad) != 0;
+        if (lane == 0 && any_bad) atomicOr(&range[2], 1ull);
+        __syncthreads();
+        if (w == 0 && lane < DSD_C && col0 + lane < H) {
+            double l = red[lane], h = red[192 + lane];
+            for (int q = 1; q < NQ; ++q) { l = fmin(l, red[q * DSD_C + lane]); h = fmax(h, red[192 + q * DSD_C + lane]); }
+            range[3 + col0 + lane] = dlc_f64_key(l);
+            range[3 + H + col0 + lane] = dlc_f64_key(h);
         }
     }
 }
@@ -1280,7 +1425,18 @@ extern "C" int dlc_sdav_distinctive_score(dlc_ctx* ctx, const double* dataset, i
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
     if (range) hipLaunchKernelGGL(range_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)range);
-    hipLaunchKernelGGL(distinctive_score_kernel, dim3((unsigned)dlc::cdiv(H, DS_COLS)), dim3(256), 0, (hipStream_t)stream,
+    if ((H & 1) == 0 && ((uintptr_t)dataset & 15) == 0 && (long long)DSD_RB * H * 8 < 0x7fffffffll) {
+        constexpr int C = DLC_DSD_COLS, lds = DSD_NB * DSD_RB * C * 8;
+        if (!(ctx->func_attr_set & (1ull << DLC_ATTR_DS_DMA))) {
+            DLC_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)distinctive_score_dma_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            ctx->func_attr_set |= 1ull << DLC_ATTR_DS_DMA;
+        }
+        hipLaunchKernelGGL(distinctive_score_dma_kernel<C>, dim3((unsigned)(dlc::cdiv(dlc::cdiv(H, (int64_t)C), (int64_t)8) * 8)), dim3(256),
+                           lds, (hipStream_t)stream, dataset, (long long)rows, (int)H, mu, sigma, score, (unsigned long long*)range);
+        DLC_LAUNCH_CHECK(ctx, "distinctive_score_dma_kernel");
+        return DLC_OK;
+    }
+    hipLaunchKernelGGL(distinctive_score_kernel, dim3((unsigned)(dlc::cdiv(dlc::cdiv(H, (int64_t)DS_COLS), (int64_t)8) * 8)), dim3(256), 0, (hipStream_t)stream,
                        dataset, (long long)rows, (int)H, mu, sigma, score, (unsigned long long*)range);
     DLC_LAUNCH_CHECK(ctx, "distinctive_score_kernel");
     return DLC_OK;

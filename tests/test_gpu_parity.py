@@ -1015,6 +1015,43 @@ def _low_contrast(shape, g, device, spread=1e-3):
     return means + spread * torch.randn(shape, generator=g, device=device, dtype=torch.float64)
 
 
+def _unkey(k):
+    """dlc_f64_key inverted (csrc/dlc_internal.h): ordered 64-bit keys -> doubles."""
+    k = k.astype(np.uint64)
+    top = (k >> np.uint64(63)).astype(bool)
+    u = np.where(top, k & np.uint64(0x7fffffffffffffff), ~k)
+    return u.view(np.float64)
+
+
+@pytest.mark.parametrize("rows,h", [(1000, 40), (193, 18), (192, 16), (5, 7), (391, 33), (2 * 192 + 1, 2500), (600, 2)])
+def test_distinctive_score_pass_is_the_row_ordered_chain(eng, rows, h):
+    """dlc_sdav_distinctive_score: the column mean is NumPy's row-by-row accumulation (SimilarityCalculator.py:20-23) --
+    made visible with columns of cancelling values (1e16, 1, -1e16, 3, ...: any other summation order changes the mean by
+    whole units) -- on both forms of the pass (the LDS-DMA one: even H; the register-staged one: odd H), at batch edges
+    (192 rows a batch), column counts that end inside a 16-column group; the columns' extremes and the NaN flag it leaves
+    for the similarity's filter are exact."""
+    from oracle import similarity as osim
+    rng = np.random.RandomState(rows * 7 + h)
+    x = rng.uniform(0.0, 1.0, size=(rows, h))
+    for c in range(h):                                                 # as many + 1e16 as - 1e16 in every column, anywhere
+        pos = rng.permutation(rows)[:2 * (rows // 10)]
+        x[pos[0::2], c], x[pos[1::2], c] = 1e16, -1e16
+    want_avg = np.cumsum(x, axis=0)[-1] / rows                          # cumsum IS the sequential chain
+    assert np.array_equal(want_avg, osim.average_response(x.reshape(rows, 1, h)))
+    mu, sigma = float(np.median(want_avg)), 0.3
+    want = np.exp(-((want_avg - mu) ** 2) / (2.0 * sigma * sigma))
+    score, r = eng.distinctive_score(torch.from_numpy(x).to(eng.device), mu, sigma, with_range=True)
+    np.testing.assert_allclose(score.cpu().numpy(), want, rtol=1e-12)
+    # a different order would show: the pairwise sum of the same column differs from the chain in most columns
+    assert (np.cumsum(x[::-1], axis=0)[-1] / rows != want_avg).mean() > 0.3 or rows < 16
+    words = r.cpu().numpy().view(np.uint64)
+    assert words[2] == 0
+    assert np.array_equal(_unkey(words[3:3 + h]), x.min(axis=0)) and np.array_equal(_unkey(words[3 + h:3 + 2 * h]), x.max(axis=0))
+    x[rows // 2, h - 1] = np.nan
+    _, r = eng.distinctive_score(torch.from_numpy(x).to(eng.device), mu, sigma, with_range=True)
+    assert r.cpu().numpy().view(np.uint64)[2] == 1
+
+
 def test_similarity_filter_low_contrast_columns(eng):
     """The filter quantises x - centre of the COLUMN (a per-column offset changes no distance): low-contrast descriptors,
     on which a global range left every arg-min inside the error window, are decided by the int8 products --
