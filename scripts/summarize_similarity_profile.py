@@ -8,7 +8,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_sim_" + tag)
 dst = os.path.join(root, "profiles")
 KERNELS = ("gram_i8_kernel", "pair_score_amin_kernel", "sim_rows_kernel", "sim_range_kernel", "sim_colrange_kernel",
-           "sim_keys_init_kernel", "sim_sample_kernel", "sim_pairwise_program_kernel", "distinctive_score_kernel",
+           "sim_keys_init_kernel", "sim_sample_kernel", "sim_pairwise_program_kernel", "distinctive_score_dma_kernel", "distinctive_score_kernel",
            "fill_diag_kernel", "gram_blocks_kernel", "sim_finish_kernel")
 with open(os.path.join(src, "stats", "sim_kernel_stats.csv")) as f, open(os.path.join(dst, tag + "_similarity_kernel_stats.csv"), "w") as g:
     for i, line in enumerate(f):
