@@ -32,7 +32,7 @@ P = {
               ("d_[1] = (long long)(sr1_ - sr0_); }", "d_[1] = (long long)bar_; }")],
  # cycles from the end of the k loop to the end of the kernel (bias staging, sigmoid, re-split, stores), per wave
  "epistamp": [("    const unsigned long long st1_ = __builtin_amdgcn_s_memtime(), sr1_ = __builtin_amdgcn_s_memrealtime();", "    const unsigned long long st1_ = __builtin_amdgcn_s_memtime(), sr1_ = __builtin_amdgcn_s_memrealtime();\n    const long long ix_e_ = (tile_m * p.tiles_n + tile_n) * 8 + wid;"),
-              ("                *(uint4*)(o2 + 16) = make_uint4(w2[4], w2[5], w2[6], w2[7]);\n            }\n        }\n    }\n}", "                *(uint4*)(o2 + 16) = make_uint4(w2[4], w2[5], w2[6], w2[7]);\n            }\n        }\n    }\n    if (!FINAL && lane == 0 && p.M == 31890) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); long long* d_ = (long long*)(p.O[0] + (23 + ix_e_ / 440) * p.oslice_b + (p.M + (ix_e_ % 440) / 4) * 64 + (ix_e_ % 4) * 16); d_[0] = (long long)(__builtin_amdgcn_s_memtime() - st1_); d_[1] = 0; }\n}")],
+              ("            __builtin_amdgcn_wave_barrier();\n        }\n    }\n}", "            __builtin_amdgcn_wave_barrier();\n        }\n    }\n    if (!FINAL && lane == 0 && p.M == 31890) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); long long* d_ = (long long*)(p.O[0] + (23 + ix_e_ / 440) * p.oslice_b + (p.M + (ix_e_ % 440) / 4) * 64 + (ix_e_ % 4) * 16); d_[0] = (long long)(__builtin_amdgcn_s_memtime() - st1_); d_[1] = 0; }\n}")],
  "noepi": [("            if (m >= p.M) continue;\n            float hv[16];", "            if (m >= p.M || p.ns > 1) continue;\n            float hv[16];")],
  # in-kernel stamps of the k loop of the HIDDEN layers (shader cycles and 100 MHz ticks per wave), stored where nothing else
  # is: rows >= M of the output piece (440 entries of 16 bytes per k-slice); the epilogue stays (the MFMAs must stay alive)
