@@ -43,7 +43,8 @@ struct DmaArgs {
     double* C; long long ldc;
     long long M, N, K;                          // K: the reduction length as the A operand has it (even)
     long long Kb;                               // ... and as B has it (<= K): B's k-rows Kb .. K-1 do not exist and read as zeros
-    int act;
+    int act;                                    // DLC_ACT_* of include/dlc.h, or ACT_AXPY: C += alpha * (A . B) (no bias)
+    double alpha;
     ConvGeom cv;
     long long m_base;                           // CONV: output pixel index of row 0 (a launch over the tail rows of a convolution)
     int cv_all_valid;                           // no tap of any output pixel falls outside the input (VALID, no padding)
@@ -261,6 +262,7 @@ __device__ __forceinline__ void dma_b2s(unsigned o0, unsigned o1, const char* ba
         : "memory", "scc");
 }
 
+constexpr int ACT_AXPY = 16;                      // internal: the product is added into C (the SGD step of a weight gradient)
 __device__ __forceinline__ double act_f64(double z, int act) {
     if (act == DLC_ACT_SIGMOID) return 1.0 / (1.0 + exp(-z));
     if (act == DLC_ACT_RELU) return z > 0.0 ? z : 0.0;
@@ -591,6 +593,38 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     // CONV with mm_keys: the minimum / maximum of every image's outputs is folded into ordered keys on the way out
     // (the CnnVtl descriptor's per-frame range, cnn_vtl.py:110-112: a separate pass over the five layers' outputs read
     // 4.9 GB again).  A wave's 64 rows (output pixels) touch at most two images -- the launcher checks OH * OW >= 64.
+    if (!CONV && p.act == ACT_AXPY) {
+        // C += alpha * acc: ALL of the lane's old values first, then the fmas and the stores (written as one expression per
+        // element, every element was load -> wait -> fma -> store: sixteen memory round trips in a row)
+        constexpr int JB = MI >= 4 ? 1 : (MI == 2 ? 2 : NJ);      // column groups per batch: 16 old values in registers at a time
+#pragma unroll
+        for (int j0 = 0; j0 < NJ; j0 += JB) {
+            double old[MI][JB][4];
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) {
+                const long long gn = n0 + (wc * NJ + j0 + jj) * 16 + fr;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long long gm = m0 + wr * (16 * MI) + i * 16 + fk + 4 * r;
+                        old[i][jj][r] = (j0 + jj < NJ && gn < p.N && gm < p.M) ? p.C[gm * p.ldc + gn] : 0.0;
+                    }
+            }
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) {
+                const long long gn = n0 + (wc * NJ + j0 + jj) * 16 + fr;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long long gm = m0 + wr * (16 * MI) + i * 16 + fk + 4 * r;
+                        if (j0 + jj < NJ && gn < p.N && gm < p.M) p.C[gm * p.ldc + gn] = fma(p.alpha, acc[i][j0 + jj < NJ ? j0 + jj : 0][r], old[i][jj][r]);
+                    }
+            }
+        }
+        return;
+    }
     double mn0 = INFINITY, mx0 = -INFINITY, mn1 = INFINITY, mx1 = -INFINITY;
     long long mm_img0 = 0, mm_bnd = 0;
     const bool fold = CONV && p.cv.mm_keys != nullptr;
@@ -666,7 +700,7 @@ int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
 // force_tm: 128 / 256 rows per tile; dry: only say whether the launch would be taken (DLC_OK / 1).
 static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                            const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
-                           const ConvGeom* cv, const TriSkip* tri, int64_t Kb, int64_t m_base, int force_tm, bool dry) {
+                           const ConvGeom* cv, const TriSkip* tri, int64_t Kb, int64_t m_base, int force_tm, bool dry, double alpha = 0.0) {
     if (Kb <= 0 || Kb > K) Kb = K;
     // 16-byte pieces: operand rows must start on 16-byte boundaries and K, N be even (a piece = 2 doubles)
     if (!ctx->zero_page || (K & 1) || (N & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 1)) return 1;
@@ -702,7 +736,7 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
     if (dry) return DLC_OK;
     DmaArgs a;
     a.A = (const char*)A; a.lda_b = lda * 8; a.B = (const char*)B; a.ldb_b = ldb * 8;
-    a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.Kb = Kb; a.act = act;
+    a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.Kb = Kb; a.act = act; a.alpha = alpha;
     a.cv = cv ? *cv : ConvGeom{};
     a.m_base = m_base;
     a.cv_all_valid = 0;
@@ -810,7 +844,7 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
 // Rows are independent and every form sums k in the same order: the same bits whichever is taken.
 int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                    const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
-                   const ConvGeom* cv, const TriSkip* tri, int64_t Kb) {
+                   const ConvGeom* cv, const TriSkip* tri, int64_t Kb, double alpha) {
     int tm = TM3;
     if (!tri && N > 96) {
         constexpr double HALF = 0.51;
@@ -827,11 +861,11 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
                 const double split = (double)dlc::cdiv(rm * tn_, (int64_t)256) + HALF * (double)dlc::cdiv(tt, (int64_t)256) + 0.05;
                 const double* a2 = cv ? A : A + m1 * lda;
                 if (split < whole4 - 0.15 && split < whole2 - 0.03 && split < quarter - 0.03 &&
-                    launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, true) == DLC_OK &&
-                    launch_dma_part(ctx, blayout, act, m2, N, K, a2, lda, B, ldb, bias, C + m1 * ldc, ldc, st, cv, tri, Kb, cv ? m1 : 0, TM3 / 2, true) == DLC_OK) {
-                    const int rc = launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, false);
+                    launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, true, alpha) == DLC_OK &&
+                    launch_dma_part(ctx, blayout, act, m2, N, K, a2, lda, B, ldb, bias, C + m1 * ldc, ldc, st, cv, tri, Kb, cv ? m1 : 0, TM3 / 2, true, alpha) == DLC_OK) {
+                    const int rc = launch_dma_part(ctx, blayout, act, m1, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, TM3, false, alpha);
                     if (rc != DLC_OK) return rc;
-                    return launch_dma_part(ctx, blayout, act, m2, N, K, a2, lda, B, ldb, bias, C + m1 * ldc, ldc, st, cv, tri, Kb, cv ? m1 : 0, TM3 / 2, false);
+                    return launch_dma_part(ctx, blayout, act, m2, N, K, a2, lda, B, ldb, bias, C + m1 * ldc, ldc, st, cv, tri, Kb, cv ? m1 : 0, TM3 / 2, false, alpha);
                 }
             }
         }
@@ -848,7 +882,14 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     }
     // the Gram blocks of the similarity: 64-row tiles for the same reason (similarity of 1063 frames 39.8 -> 39.0 ms)
     if (tri && N > 96 && dlc::cdiv(M, (int64_t)TM3) * dlc::cdiv(N, (int64_t)TN3) > 512) tm = TM3 / 4;
-    return launch_dma_part(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, tm, false);
+    return launch_dma_part(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, tm, false, alpha);
+}
+
+// C += alpha * (A . B) in the epilogue of the LDS-DMA kernel (the SGD step of a weight gradient: W -= lr * dW without dW
+// ever reaching memory -- SDAV.py:223-226).  DLC_OK, or 1 when the shape / alignment is not one the kernel handles.
+int gemm_axpy_dma_f64(dlc_ctx* ctx, int blayout, double alpha, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                      const double* B, int64_t ldb, double* C, int64_t ldc, hipStream_t st) {
+    return launch_dma_f64(ctx, blayout, ACT_AXPY, M, N, K, A, lda, B, ldb, nullptr, C, ldc, st, nullptr, nullptr, 0, alpha);
 }
 
 

@@ -28,7 +28,9 @@ struct TriSkip {
 // 1681 input columns, copied into rows of 1696): B's missing k-rows read as zeros.
 int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                    const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
-                   const ConvGeom* cv, const TriSkip* tri, int64_t Kb = 0);
+                   const ConvGeom* cv, const TriSkip* tri, int64_t Kb = 0, double alpha = 0.0);
+int gemm_axpy_dma_f64(dlc_ctx* ctx, int blayout, double alpha, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                      const double* B, int64_t ldb, double* C, int64_t ldc, hipStream_t st);
 
 // A zero-padded by the caller to lda = Kpad columns (columns K .. Kpad-1 are zeros): act(A[:, :K] . B + bias) with the
 // LDS-DMA kernel when it applies (it then walks Kpad), else the register-staged kernel on the first K columns.

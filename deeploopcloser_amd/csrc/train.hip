@@ -9,6 +9,8 @@
 namespace dlc_gemm {
 int gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A,
                   int64_t lda, const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st);
+int gemm_axpy_dma_f64(dlc_ctx* ctx, int blayout, double alpha, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                      const double* B, int64_t ldb, double* C, int64_t ldc, hipStream_t st);      // gemm_dma_f64.hip
 }
 
 namespace {
@@ -487,11 +489,18 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
     if ((size_t)batch * 8 > 48 * 1024) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_train_step: batch too large");
     hipLaunchKernelGGL(hidden_grad_kernel, dim3(grid_for(rows * N)), dim3(256), (size_t)batch * 8, st, h, P(w.dh), P(w.nrm_part),
                        fn_slices, (int)batch, (long long)patches * N, cs_den, sparse_level, sparse_penalty, consecutive_penalty, dz1);
-    // The tied weight's two gradients in ONE product (they were two of 1681 x 300 x 2500, each too short a K loop to run
-    // well: 80 us apiece): d/dW = dz2^T h (decoder use) + x~^T dz1 (encoder use) = [dz2^T | x~^T] . [h ; dz1], K = 2 rows.
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32), 2), dim3(256), 0, st,
-                       P(w.dz2), rows, K, P(w.tr), 2 * rows, (const double*)P(w.xt[layer]), P(w.tr) + rows);
-    GEMM(DLC_B_KN, DLC_ACT_NONE, K, N, 2 * rows, P(w.tr), 2 * rows, h, N, nullptr, P(w.gw[layer]), N);
+    // A layer's weight gradient and its SGD step in ONE launch where the LDS-DMA GEMM takes the shape: W += -lr * (A . B)
+    // in the product's epilogue (gemm_axpy_dma_f64) -- dW never reaches memory, and the update kernel's pass over W and dW
+    // (100 MB at layer 0: 25 us of a 0.5 ms step) is gone.  W[l] must be dead by then: every layer's product runs AFTER the
+    // last use of its weights (dz1 W^T on the way down), the same products on the same operands as before, in another
+    // order.  Where the kernel does not take the shape (odd widths) the gradient goes to w.gw[l] and update_kernel steps it.
+    bool stepped[8] = {};
+    auto weight_step = [&](int l, long long Kl, long long Nl, long long kk, const double* Bop) -> int {
+        int rc_ = dlc_gemm::gemm_axpy_dma_f64(ctx, DLC_B_KN, -learning_rate, Kl, Nl, kk, P(w.tr), kk, Bop, Nl, W[l], Nl, st);
+        if (rc_ == DLC_OK) { stepped[l] = true; return DLC_OK; }
+        if (rc_ != 1) return rc_;
+        return dlc_gemm::gemm_bias_act(ctx, DLC_F64, DLC_B_KN, DLC_ACT_NONE, Kl, Nl, kk, P(w.tr), kk, Bop, Nl, nullptr, P(w.gw[l]), Nl, st);
+    };
 
     // ---- backward through the encoders layer .. 0
     double* spare[2] = {P(w.dz1a), P(w.dz1b)};
@@ -499,36 +508,50 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
     int which = 0;
     for (int l = layer; l >= 0; --l) {
         const long long Kl = dims[l], Nl = dims[l + 1];
-        if (l < layer) {
-            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(Kl, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0,
-                               st, P(w.xt[l]), rows, Kl, P(w.tr), rows);
-            GEMM(DLC_B_KN, DLC_ACT_NONE, Kl, Nl, rows, P(w.tr), rows, dz1, Nl, nullptr, P(w.gw[l]), Nl);   // x~^T dz1
-        }
         // dz1 of the trained layer lives behind h, the deeper ones alternate between two buffers: at the step's end only the
         // trained layer's and the last two written (layers 1 and 0) are still there; the others are summed now
         if (l == layer || l <= 1) dz1_of[l] = dz1;
         else hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)dlc::cdiv(Nl, 32)), dim3(256), 0, st, dz1, rows, Nl, P(w.gbe[l]));
-        if (l == 0) break;
-        GEMM(DLC_B_NK, DLC_ACT_NONE, rows, Kl, Nl, dz1, Nl, W[l], Nl, nullptr, P(w.dxt), Kl);          // dz1 W^T
-        hipLaunchKernelGGL(backprop_input_kernel, dim3(grid_for(rows * Kl)), dim3(256), 0, st, P(w.dxt),
-                           l == layer ? P(w.dlab) : (const double*)nullptr, masks[l], P(w.h[l - 1]), rows, Pn, Kl,
-                           spare[which]);
-        dz1 = spare[which];
-        which ^= 1;
+        double* dz1_next = nullptr;
+        if (l > 0) {
+            GEMM(DLC_B_NK, DLC_ACT_NONE, rows, Kl, Nl, dz1, Nl, W[l], Nl, nullptr, P(w.dxt), Kl);          // dz1 W^T
+            hipLaunchKernelGGL(backprop_input_kernel, dim3(grid_for(rows * Kl)), dim3(256), 0, st, P(w.dxt),
+                               l == layer ? P(w.dlab) : (const double*)nullptr, masks[l], P(w.h[l - 1]), rows, Pn, Kl,
+                               spare[which]);
+            dz1_next = spare[which];
+            which ^= 1;
+        }
+        if (l == layer) {
+            // The tied weight's two gradients in ONE product (they were two of 1681 x 300 x 2500, each too short a K loop to
+            // run well: 80 us apiece): d/dW = dz2^T h (decoder use) + x~^T dz1 (encoder use) = [dz2^T | x~^T] . [h ; dz1],
+            // K = 2 rows (dz1 lies right behind h).
+            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32), 2), dim3(256), 0, st,
+                               P(w.dz2), rows, K, P(w.tr), 2 * rows, (const double*)P(w.xt[layer]), P(w.tr) + rows);
+            const int rc_ = weight_step(l, K, N, 2 * rows, h);
+            if (rc_ != DLC_OK) return rc_;
+        } else {
+            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(Kl, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0,
+                               st, P(w.xt[l]), rows, Kl, P(w.tr), rows);
+            const int rc_ = weight_step(l, Kl, Nl, rows, dz1);                                          // x~^T dz1
+            if (rc_ != DLC_OK) return rc_;
+        }
+        dz1 = dz1_next;
     }
 
     // ---- plain gradient descent on everything the loss reached (SDAV.py:223-226), the bias gradients' column sums and the
     // loss: one launch
     {
         UpdateArgs u{};
-        u.n_w = layer + 1;
+        u.n_w = 0;
         long long blk = 0;
         for (int l = 0; l <= layer; ++l) {
-            u.w[l] = W[l]; u.gw[l] = P(w.gw[l]); u.w_n[l] = dims[l] * dims[l + 1];
-            u.w_blk0[l] = blk;
-            blk += grid_for(u.w_n[l]);
+            if (stepped[l]) continue;                                // (its product's epilogue took the step)
+            const int m = u.n_w++;
+            u.w[m] = W[l]; u.gw[m] = P(w.gw[l]); u.w_n[m] = dims[l] * dims[l + 1];
+            u.w_blk0[m] = blk;
+            blk += grid_for(u.w_n[m]);
         }
-        u.w_blk0[layer + 1] = blk;
+        u.w_blk0[u.n_w] = blk;
         u.n_b = layer + 2;
         for (int l = 0; l <= layer; ++l) {
             u.b[l] = b_enc[l]; u.b_cols[l] = dims[l + 1];
