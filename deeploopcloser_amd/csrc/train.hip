@@ -58,11 +58,15 @@ __device__ __forceinline__ unsigned mask_key(unsigned s0, unsigned s1, unsigned 
 }
 
 constexpr int RM_THREADS = 1024;
-constexpr int RM_PER = 80;                   // keys a thread keeps in registers: n <= 81 920 draws every key once
+constexpr int RM_PER_MAX = 80;               // keys a thread keeps in registers: n <= 81 920 draws every key once
 #define IDX(j) ((long long)tid + (long long)(j) * RM_THREADS)
-template <bool CACHED>
+// RM_PER: keys per thread held in registers between the passes (0: none -- any n, every pass recomputes them).  A thread
+// computes, histograms and tests RM_PER keys whether n needs them or not: the launcher takes the smallest form that holds n
+// (the reference's 50 430 elements: 52 instead of 80 keys per thread in every pass of this one-workgroup kernel).
+template <int RM_PER>
 __global__ __launch_bounds__(RM_THREADS) void random_mask_kernel(double* __restrict__ mask, long long n, long long n_zeros,
                                                                  unsigned long long seed, unsigned long long counter) {
+    constexpr bool CACHED = RM_PER > 0;
     __shared__ unsigned hist[2048];
     __shared__ unsigned sel_bin, sel_below;
     __shared__ unsigned eq_cnt[RM_THREADS];
@@ -595,12 +599,15 @@ extern "C" int dlc_random_mask_f64(dlc_ctx* ctx, double* mask, int64_t n, int64_
     if (n > (1ll << 26)) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "random_mask: n=%lld too large (one workgroup walks the keys)", (long long)n);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    if (n <= (long long)RM_THREADS * RM_PER)
-        hipLaunchKernelGGL(random_mask_kernel<true>, dim3(1), dim3(RM_THREADS), 0, (hipStream_t)stream, mask, (long long)n,
-                           (long long)n_zeros, (unsigned long long)seed, (unsigned long long)counter);
-    else
-        hipLaunchKernelGGL(random_mask_kernel<false>, dim3(1), dim3(RM_THREADS), 0, (hipStream_t)stream, mask, (long long)n,
-                           (long long)n_zeros, (unsigned long long)seed, (unsigned long long)counter);
+#define DLC_RM_LAUNCH(PER)                                                                                        \
+    hipLaunchKernelGGL(random_mask_kernel<PER>, dim3(1), dim3(RM_THREADS), 0, (hipStream_t)stream, mask, (long long)n, \
+                       (long long)n_zeros, (unsigned long long)seed, (unsigned long long)counter)
+    if (n <= (long long)RM_THREADS * 8) DLC_RM_LAUNCH(8);
+    else if (n <= (long long)RM_THREADS * 24) DLC_RM_LAUNCH(24);
+    else if (n <= (long long)RM_THREADS * 52) DLC_RM_LAUNCH(52);
+    else if (n <= (long long)RM_THREADS * RM_PER_MAX) DLC_RM_LAUNCH(RM_PER_MAX);
+    else DLC_RM_LAUNCH(0);
+#undef DLC_RM_LAUNCH
     DLC_LAUNCH_CHECK(ctx, "random_mask_kernel");
     return DLC_OK;
 }
