@@ -227,38 +227,72 @@ class SDAV:
         if g is None or g["sig"] != sig:
             if len(self._step_graphs) > 8:
                 self._step_graphs.clear()
+            # TWO sets of masks, one graph over each: the next step's masks are drawn on a second stream while this step's
+            # graph runs (the draw is one workgroup's 32 us -- a fifteenth of the step when it ran in front of every replay)
             g = {"sig": sig, "x": torch.empty_like(x),
-                 "masks": [torch.empty(tuple(self.get_layer_input_shape(l)), dtype=torch.float64, device=eng.device)
-                           for l in range(layer_n + 1)],
+                 "masks": [[torch.empty(tuple(self.get_layer_input_shape(l)), dtype=torch.float64, device=eng.device)
+                            for l in range(layer_n + 1)] for _ in range(2)],
                  "loss": torch.zeros(4, dtype=torch.float64, device=eng.device), "graph": None,
-                 "ws": eng.train_workspace(layer_n, x.shape[0], x.shape[1], self._weights)}     # its own: the graph keeps pointing at it
+                 "drawn": [torch.cuda.Event(), torch.cuda.Event()], "used": [torch.cuda.Event(), torch.cuda.Event()],
+                 "ws": eng.train_workspace(layer_n, x.shape[0], x.shape[1], self._weights)}     # its own: the graphs keep pointing at it
             self._step_graphs[key] = g
         g["x"].copy_(x)
 
-        def one_step():
-            eng.sdav_train_step(layer_n, g["x"].reshape(-1, x.shape[2]), x.shape[0], x.shape[1], g["masks"], self._weights,
+        def one_step(b):
+            eng.sdav_train_step(layer_n, g["x"].reshape(-1, x.shape[2]), x.shape[0], x.shape[1], g["masks"][b], self._weights,
                                 self._biases, self._biases_dec[layer_n], self.sparse_level, self.sparse_penalty,
                                 self.consecutive_penalty, self.learning_rate, loss_out=g["loss"], ws=g["ws"])
+
+        main, side = torch.cuda.current_stream(eng.device), eng.side_stream
+        # ... where a step draws more than one mask (measured per step, replayed: layer 2 1.36 -> 1.26 ms, layer 4 2.18 ->
+        # 2.02; at layer 0 the two cross-stream waits per step cost more than its one draw hides, 0.469 -> 0.489: there the
+        # draw stays in front of the replay, on the caller's stream)
+        beside = layer_n >= 1
+
+        def draw(b, after=None):
+            """Step's masks into set b on the second stream, behind `after` (the last step that read that set)."""
+            if not beside:
+                for l, m in enumerate(g["masks"][b]):
+                    self._fill_mask(m, l)
+                return
+            if after is not None:
+                side.wait_event(after)
+            with torch.cuda.stream(side):
+                for l, m in enumerate(g["masks"][b]):
+                    self._fill_mask(m, l)
+                g["drawn"][b].record(side)
 
         done = 0
         if g["graph"] is None and n_steps >= 3:
             # one eager step first: kernel attributes and the allocator's pools exist before the capture
-            for l, m in enumerate(g["masks"]):
+            for l, m in enumerate(g["masks"][0]):
                 self._fill_mask(m, l)
-            one_step()
+            one_step(0)
             done = 1
             torch.cuda.synchronize(eng.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):                    # (a capture records the launches, it does not run them)
-                one_step()
-            g["graph"] = graph
-        for _ in range(done, n_steps):
-            for l, m in enumerate(g["masks"]):
-                self._fill_mask(m, l)
+            graphs = []
+            for b in range(2):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):                # (a capture records the launches, it does not run them)
+                    one_step(b)
+                graphs.append(graph)
+            g["graph"] = graphs
+        if done < n_steps:
+            start = torch.cuda.Event()
+            start.record(main)                               # (the sets' last readers are behind this point of the caller's stream)
+            draw(done % 2, start)
+        for i in range(done, n_steps):
+            b = i % 2
+            if beside:
+                main.wait_event(g["drawn"][b])
             if g["graph"] is not None:
-                g["graph"].replay()
+                g["graph"][b].replay()
             else:
-                one_step()
+                one_step(b)
+            if beside:
+                g["used"][b].record(main)
+            if i + 1 < n_steps:
+                draw(1 - b, g["used"][1 - b] if i > done else start)
         self.global_step += n_steps
         self._weights_changed()
         return g["loss"]
