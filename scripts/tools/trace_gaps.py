@@ -1,13 +1,13 @@
 """Timeline of a rocprofv3 kernel trace (…_kernel_trace.csv): per kernel name the count and mean duration, and the idle time of
 the device between consecutive kernels, grouped by the kernel that FOLLOWS the gap.   usage: trace_gaps.py trace.csv [last N kernels]"""
-import csv, sys, collections
+import csv, re, sys, collections
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 if len(sys.argv) > 2:
     rows = rows[-int(sys.argv[2]):]
 dur, gap, cnt = collections.defaultdict(float), collections.defaultdict(float), collections.Counter()
 prev_end = None
 for r in rows:
-    n = r["Kernel_Name"].split("(")[0].split("::")[-1][:40]
+    n = re.sub(r"\(anonymous namespace\)::|dlc_gemm::|void ", "", r["Kernel_Name"]).split("(")[0][:44]
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     dur[n] += e - s; cnt[n] += 1
     if prev_end is not None:
