@@ -37,9 +37,10 @@
 // Roles: MFMA A operand = 256 weight columns; the weight panel's rows are PERMUTED inside every 64 (column 16 g + 4 t + r
 // sits at row 16 t + 4 g + r) so that sixteen consecutive panel rows are one A fragment whose accumulators are, per lane,
 // sixteen CONSECUTIVE output columns.  B operand = 256 activation rows (a lane holds ONE row m).  The epilogue therefore
-// writes, per lane, runs of sixteen consecutive outputs of one row: bias + sigmoid in fp32, then either the next layer's
-// two fp16 pieces (32 bytes each, K32-major) or, for the last layer, sixteen fp64 values.  The activations never exist as
-// fp64 between the layers.
+// holds, per lane, runs of sixteen consecutive outputs of one row: bias + sigmoid in fp32 (one fma, v_exp_f32, v_rcp_f32 per
+// element), then either the next layer's two fp16 pieces (32 bytes each, K32-major; lanes l and l + 32 trade halves so that a
+// store instruction writes one whole slice: 1 KiB in a piece) or, for the last layer, fp64 values that leave through LDS a
+// row at a time.  The activations never exist as fp64 between the layers.
 // Both operands are re-read (neither is a once-only stream).  Tile order: the tiles in "super-rows" of four activation row
 // tiles, column by column inside a super-row, cut into EIGHT CONTIGUOUS RANGES, one per XCD (workgroup ids go round-robin
 // to the XCDs; an XCD starts its ids in order, one workgroup per CU): the 32 tiles an XCD runs at a time are 4 rows x 8
