@@ -1160,16 +1160,18 @@ def main():
         torch.cuda.synchronize()
 
     import gc
-    for _ in range(args.warmup):
+    gc.collect()                                             # no cyclic collection inside the timed region -- and none between
+    gc.disable()                                             # the warm-up and it: a collection here is tens of milliseconds of an
+    eng.set_profiling(True)                                  # idle GPU, and the first steps behind an idle stretch run at the
+    for _ in range(args.warmup):                             # clock the chip dropped to (docs/LAB.md 11.6)
         step()
-    eng.set_profiling(True)
-    gc.collect()                                             # no cyclic collection inside the timed region
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     fence()
     t1 = time.perf_counter()
+    gc.enable()
     scores, idx = res if pipe is None else pipe.result(last[0])
     gemm_ms = eng.profile_gemm_ms(min(args.steps, 256))
     eng.set_profiling(False)
