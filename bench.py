@@ -181,10 +181,12 @@ def synth_shard(eng, n_total, dim, lo, hi, dtype, planted_rows, chunk=32768):
     return rows, planted
 
 
-def _timed_path(eng, fn, reps=3):
-    """fn() on the current stream: (wall ms of the whole call from stream events, summed ms of its dense-GEMM
-    launches from the HIP events the library records around each of them, number of launches, result) of
-    the fastest of `reps` calls after one warm-up."""
+def _timed_path(eng, fn, reps=3, inner=3):
+    """fn() on the current stream: (wall ms of a call from stream events, summed ms of its dense-GEMM launches from the
+    HIP events the library records around each of them, number of launches, result) -- per call, as the MEAN over `inner`
+    calls back to back, of the fastest of `reps` such runs after one warm-up.  (One call between two synchronisations
+    measured the clock the chip idles down to between them as much as the kernels: the tolerance-mode encoder read 4.5
+    ms a call that way and 4.25 in any loop, docs/LAB.md 11.5b.)"""
     fn()
     torch.cuda.synchronize()
     best = None
@@ -192,12 +194,15 @@ def _timed_path(eng, fn, reps=3):
         eng.set_profiling(True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = fn()
+        for _ in range(inner):
+            r = fn()
         e1.record()
         torch.cuda.synchronize()
         k = eng.profile_gemm_ms(256)
         eng.set_profiling(False)
-        cur = (e0.elapsed_time(e1), float(np.sum(k)) if k else None, len(k), r)
+        whole = len(k) % inner == 0 and len(k) < 256              # (a ring that wrapped cannot be split by call)
+        cur = (e0.elapsed_time(e1) / inner, (float(np.sum(k)) / inner if whole else None) if k else None,
+               len(k) // inner if whole else 0, r)
         if best is None or cur[0] < best[0]:
             best = cur
     return best
