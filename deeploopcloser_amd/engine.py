@@ -366,8 +366,17 @@ class Engine:
                                            a2.stride(0), _ptr(bias), _ptr(out), out.stride(0), self._stream()))
         return out.reshape(a.shape)
 
-    def sdav_encode(self, x2d, weights, biases):
-        """sigmoid chain on x2d [rows, K0]; weights[l] is [dims[l], dims[l+1]]."""
+    def _encode_out(self, out, rows, cols, dt, what):
+        """The caller's result tensor for an encode ([rows, cols], contiguous, on this device), or a new one."""
+        if out is None:
+            return torch.empty((rows, cols), dtype=dt, device=self.device)
+        if out.dtype != dt or tuple(out.shape) != (rows, cols) or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("%s: out must be a contiguous %s [%d, %d] tensor on %s" % (what, dt, rows, cols, self.device))
+        return out
+
+    def sdav_encode(self, x2d, weights, biases, out=None):
+        """sigmoid chain on x2d [rows, K0]; weights[l] is [dims[l], dims[l+1]].  out: where the result goes (a caller that
+        collects the chunks of a sequence hands its slice: no copy behind the call)."""
         dt = x2d.dtype
         if dt not in (torch.float64, torch.float32):
             raise ValueError("sdav_encode: float64 or float32")
@@ -383,7 +392,7 @@ class Engine:
         b_c = (C.c_void_p * n_layers)(*[(b.data_ptr() if b is not None else 0) for b in biases])
         need = self.lib.dlc_sdav_encode_workspace_bytes(rows, dims_c, n_layers, _TORCH_TO_DLC[dt])
         ws = self.workspace("sdav", need)
-        out = torch.empty((rows, dims[-1]), dtype=dt, device=self.device)
+        out = self._encode_out(out, rows, dims[-1], dt, "sdav_encode")
         self._check(self.lib.dlc_sdav_encode(self.ctx, _TORCH_TO_DLC[dt], rows, n_layers, dims_c, _ptr(x2d), w_c, b_c,
                                               _ptr(out), _ptr(ws), ws.numel(), self._stream()))
         return out
@@ -403,7 +412,7 @@ class Engine:
         self._check(self.lib.dlc_sdav_split_prepare(self.ctx, n_layers, dims_c, w_c, _ptr(panels), panels.numel(), self._stream()))
         return panels
 
-    def sdav_encode_split(self, x2d, dims, panels, biases):
+    def sdav_encode_split(self, x2d, dims, panels, biases, out=None):
         """The sigmoid chain on x2d [rows, dims[0]] (fp64) in the tolerance mode (three fp16 MFMA products per layer,
         include/dlc.h: dlc_sdav_encode_split) -> fp64 [rows, dims[-1]]."""
         if x2d.dtype != torch.float64 or x2d.dim() != 2 or x2d.shape[1] != dims[0]:
@@ -415,7 +424,7 @@ class Engine:
         b_c = (C.c_void_p * n_layers)(*[(b.data_ptr() if b is not None else 0) for b in biases])
         need = self.lib.dlc_sdav_encode_split_workspace_bytes(rows, dims_c, n_layers)
         ws = self.workspace("sdav_split", need)
-        out = torch.empty((rows, dims[-1]), dtype=torch.float64, device=self.device)
+        out = self._encode_out(out, rows, dims[-1], torch.float64, "sdav_encode_split")
         self._check(self.lib.dlc_sdav_encode_split(self.ctx, rows, n_layers, dims_c, _ptr(x2d), _ptr(panels), b_c, _ptr(out),
                                                     _ptr(ws), ws.numel(), self._stream()))
         return out

@@ -130,22 +130,23 @@ class SDAV:
                  global_step=np.array(self.global_step))
 
     # ---- encode ---------------------------------------------------------------------
-    def transform_tensor(self, x):
-        """x: [B,30,1681] on any device -> torch tensor [B*30, 2500] on the GPU."""
+    def transform_tensor(self, x, out=None):
+        """x: [B,30,1681] on any device -> torch tensor [B*30, 2500] on the GPU (out: the caller's contiguous tensor of that
+        shape and the network's dtype to write it into)."""
         x = self.engine.to_device(x, self.dtype)
         if x.dim() != 3 or list(x.shape[1:]) != list(self.input_shape):
             raise ValueError("expected input of shape [B, %d, %d], got %s" %
                              (self.input_shape[0], self.input_shape[1], tuple(x.shape)))
         if x.shape[0] == 0:
-            return torch.empty((0, self.hidden_units[-1]), dtype=self.dtype, device=self.engine.device)
+            return out if out is not None else torch.empty((0, self.hidden_units[-1]), dtype=self.dtype, device=self.engine.device)
         x2 = x.reshape(x.shape[0] * x.shape[1], x.shape[2])      # flat_batch, TensorflowWrapper.py:13-15
         if self.mode == "f16x2":
             sig = (self._weights_gen,) + tuple((w.data_ptr(), w._version) for w in self._weights)
             if self._panels is None or self._panels[0] != sig:
                 self._panels = (sig, self.engine.sdav_split_panels(self._weights))
             dims = [self.input_shape[1]] + list(self.hidden_units)
-            return self.engine.sdav_encode_split(x2, dims, self._panels[1], self._biases)
-        return self.engine.sdav_encode(x2, self._weights, self._biases)
+            return self.engine.sdav_encode_split(x2, dims, self._panels[1], self._biases, out=out)
+        return self.engine.sdav_encode(x2, self._weights, self._biases, out=out)
 
     def transform(self, x, chunk_frames=256):
         """SDAV.transform (SDAV.py:293-302): numpy in, numpy FLAT [B*30, 2500] float64 out.
