@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(const double* __restrict
 
 // random_mask (TensorflowWrapper.py:148-156): EXACTLY n_zeros zeros among n ones, every subset equally likely (the
 // reference concatenates zeros and ones and tf.random.shuffle's them).  Element i draws the 32-bit key
-// hash(seed, counter, i); the n_zeros smallest (key, index) pairs become the zeros -- found by one workgroup with a
-// three-pass radix select over the keys (11 + 11 + 10 bits, histograms in LDS; keys are recomputed, never stored) and a
-// fourth pass that writes the mask; equal keys at the threshold go by index (thread t owns a contiguous index range, so
-// a prefix sum over the threads orders them).  ~5 us for the 50 430 elements of the reference's first layer, where a
-// device randperm (a sort) took 83 us of a 470 us training step.
+// hash(seed, counter, i); the n_zeros smallest (key, index) pairs become the zeros -- found by one workgroup: a select
+// over the keys in a window around the expected threshold (the kernel's short way), or a three-pass radix select over all
+// keys (11 + 11 + 10 bits, histograms in LDS), and a last pass that writes the mask; keys are recomputed, never stored;
+// equal keys at the threshold go by index (a prefix sum over the threads orders them).  25 us for the 50 430 elements of
+// the reference's first layer (rocprofv3), where a device randperm (a sort) took 83 us of a 470 us training step.
 __device__ __forceinline__ unsigned mask_key(unsigned s0, unsigned s1, unsigned i) {
     // two rounds of murmur3's 32-bit finaliser over (index, seed, counter): 32-bit multiplies only (the 64-bit mix this
     // replaced cost ~250 cycles a key, and the kernel is one workgroup)
@@ -58,29 +58,96 @@ __device__ __forceinline__ unsigned mask_key(unsigned s0, unsigned s1, unsigned 
 }
 
 constexpr int RM_THREADS = 1024;
-constexpr int RM_PER_MAX = 80;               // keys a thread keeps in registers: n <= 81 920 draws every key once
 #define IDX(j) ((long long)tid + (long long)(j) * RM_THREADS)
-// RM_PER: keys per thread held in registers between the passes (0: none -- any n, every pass recomputes them).  A thread
-// computes, histograms and tests RM_PER keys whether n needs them or not: the launcher takes the smallest form that holds n
-// (the reference's 50 430 elements: 52 instead of 80 keys per thread in every pass of this one-workgroup kernel).
-template <int RM_PER>
+// (Forms that kept a thread's keys in registers between three histogram passes over ALL keys -- 80, then 52 keys per thread
+// -- were 38 and 32 us for the reference's 50 430 elements; this one is 25: what is left is the keys themselves, five 32-bit
+// multiplies each at a quarter of the vector rate, generated twice.)
 __global__ __launch_bounds__(RM_THREADS) void random_mask_kernel(double* __restrict__ mask, long long n, long long n_zeros,
                                                                  unsigned long long seed, unsigned long long counter) {
-    constexpr bool CACHED = RM_PER > 0;
     __shared__ unsigned hist[2048];
     __shared__ unsigned sel_bin, sel_below;
     __shared__ unsigned eq_cnt[RM_THREADS];
     const int tid = threadIdx.x;
     const unsigned s0 = (unsigned)seed ^ (unsigned)(counter >> 32) * 0x27d4eb2fu;
     const unsigned s1 = (unsigned)(seed >> 32) + (unsigned)counter * 0x165667b1u;
-    // thread t owns the indices t, t + 1024, ...: its keys stay in registers between the passes, and the mask is written
-    // in coalesced rows (a contiguous range per thread wrote 50 000 scattered doubles from one CU: 30 us)
-    unsigned keys[CACHED ? RM_PER : 1];
-    if constexpr (CACHED) {
-#pragma unroll
-        for (int j = 0; j < RM_PER; ++j) keys[j] = IDX(j) < n ? mask_key(s0, s1, (unsigned)IDX(j)) : 0u;
+    // thread t owns the indices t, t + 1024, ...: the mask is written in coalesced rows (a contiguous range per thread wrote
+    // 50 000 scattered doubles from one CU: 30 us); a key is recomputed wherever it is wanted
+    auto key_at = [&](int j) { return mask_key(s0, s1, (unsigned)IDX(j)); };
+    // The short way: the keys are uniform, so the n_zeros-th smallest lies within a few
+    // standard deviations of n_zeros / n * 2^32.  One pass over the keys counts those below a window of +- 8 sigma around
+    // that value and lists the ~16 sigma keys inside it (1 700 of the reference's 50 430); the radix select then runs over
+    // the LIST -- two keys per thread -- and a second pass over the keys writes the mask.  Two key generations and a list
+    // instead of one generation and three histogram passes of 50 LDS atomics per thread.  A window that does not hold the
+    // threshold (1e-15), a list that overflows, or equal keys AT the threshold (1e-5: which of them are zeros is then a
+    // matter of order) leave the decision to the general passes below; without ties both ways give the same mask.
+    {
+        constexpr int RM_CAP = 4096;
+        __shared__ unsigned l_len, l_below, l_eq;
+        __shared__ unsigned lkey[RM_CAP];
+        const double pz = (double)n_zeros / (double)n, sig = sqrt((double)n * pz * (1.0 - pz));
+        const double mid = pz * 4294967296.0, wid = (8.0 * sig + 4.0) * 4294967296.0 / (double)n;
+        if (n_zeros > 0 && n_zeros < n && mid - wid > 0.0 && mid + wid < 4294967295.0) {
+            const unsigned lo = (unsigned)(mid - wid), span = (unsigned)(mid + wid) - lo;
+            if (tid == 0) { l_len = 0; l_below = 0; l_eq = 0; }
+            __syncthreads();
+            unsigned below = 0;
+            for (int j = 0; IDX(j) < n; ++j) {
+                const unsigned k = key_at(j);
+                below += k < lo ? 1u : 0u;
+                if (k - lo <= span) {
+                    const unsigned slot = atomicAdd(&l_len, 1u);
+                    if (slot < (unsigned)RM_CAP) lkey[slot] = k - lo;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+            if ((tid & 63) == 0) atomicAdd(&l_below, below);
+            __syncthreads();
+            const unsigned len = l_len, nbelow = l_below;
+            if (len <= (unsigned)RM_CAP && (long long)nbelow < n_zeros && n_zeros <= (long long)nbelow + (long long)len) {
+                unsigned pre = 0, pm = 0;
+                long long wnt = n_zeros - (long long)nbelow;          // the wnt-th smallest offset of the list
+                for (int sh = 24; sh >= 0; sh -= 8) {                // four passes of eight bits, 256 bins: four a lane
+                    if (tid < 256) hist[tid] = 0;
+                    __syncthreads();
+                    for (unsigned e = tid; e < len; e += RM_THREADS)
+                        if ((lkey[e] & pm) == pre) atomicAdd(&hist[(lkey[e] >> sh) & 255u], 1u);
+                    __syncthreads();
+                    if (tid < 64) {
+                        const unsigned h0 = hist[tid * 4], h1 = hist[tid * 4 + 1], h2 = hist[tid * 4 + 2], h3 = hist[tid * 4 + 3];
+                        const unsigned sum = h0 + h1 + h2 + h3;
+                        unsigned inc = sum;
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const unsigned v = __shfl_up(inc, o);
+                            if (tid >= o) inc += v;
+                        }
+                        const unsigned exc = inc - sum;
+                        if ((long long)exc < wnt && wnt <= (long long)inc) {
+                            unsigned bl = exc, b = 0;
+                            if ((long long)(bl + h0) < wnt) { bl += h0; b = 1;
+                                if ((long long)(bl + h1) < wnt) { bl += h1; b = 2;
+                                    if ((long long)(bl + h2) < wnt) { bl += h2; b = 3; } } }
+                            sel_bin = (unsigned)tid * 4 + b; sel_below = bl;
+                        }
+                    }
+                    __syncthreads();
+                    pre |= sel_bin << sh;
+                    pm |= 255u << sh;
+                    wnt -= sel_below;
+                    __syncthreads();
+                }
+                // pre = the threshold's offset; wnt of the keys equal to it are zeros: all of them, unless keys collide there
+                for (unsigned e = tid; e < len; e += RM_THREADS)
+                    if (lkey[e] == pre) atomicAdd(&l_eq, 1u);
+                __syncthreads();
+                if ((long long)l_eq == wnt) {
+                    const unsigned thr = lo + pre;
+                    for (int j = 0; IDX(j) < n; ++j) mask[IDX(j)] = key_at(j) <= thr ? 0.0 : 1.0;
+                    return;
+                }
+            }
+            __syncthreads();
+        }
     }
-    auto key_at = [&](int j) { return CACHED ? keys[CACHED ? j : 0] : mask_key(s0, s1, (unsigned)IDX(j)); };
     unsigned prefix = 0, pmask = 0;          // the bits of the threshold key found so far, and which bits they are
     long long want = n_zeros;                // how many of the keys matching the prefix are still to be taken
     const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
@@ -88,15 +155,9 @@ __global__ __launch_bounds__(RM_THREADS) void random_mask_kernel(double* __restr
         const int nb = 1 << widths[pass];
         for (int b = tid; b < nb; b += RM_THREADS) hist[b] = 0;
         __syncthreads();
-        if constexpr (CACHED) {
-#pragma unroll
-            for (int j = 0; j < RM_PER; ++j)
-                if (IDX(j) < n && (keys[j] & pmask) == prefix) atomicAdd(&hist[(keys[j] >> shifts[pass]) & (nb - 1)], 1u);
-        } else {
-            for (int j = 0; IDX(j) < n; ++j) {
-                const unsigned k = key_at(j);
-                if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shifts[pass]) & (nb - 1)], 1u);
-            }
+        for (int j = 0; IDX(j) < n; ++j) {
+            const unsigned k = key_at(j);
+            if ((k & pmask) == prefix) atomicAdd(&hist[(k >> shifts[pass]) & (nb - 1)], 1u);
         }
         __syncthreads();
         if (tid < 64) {                      // the bin that holds the want-th smallest key: lane sums of nb / 64 bins, a
@@ -125,12 +186,7 @@ __global__ __launch_bounds__(RM_THREADS) void random_mask_kernel(double* __restr
     // keys < prefix: zeros; keys == prefix: the first `want` of them in (thread, j) order -- any fixed rule does: the keys are random
     const bool all = n_zeros >= n, none = n_zeros <= 0;
     unsigned mine = 0;
-    if constexpr (CACHED) {
-#pragma unroll
-        for (int j = 0; j < RM_PER; ++j) mine += (IDX(j) < n && keys[j] == prefix) ? 1u : 0u;
-    } else {
-        for (int j = 0; IDX(j) < n; ++j) mine += key_at(j) == prefix ? 1u : 0u;
-    }
+    for (int j = 0; IDX(j) < n; ++j) mine += key_at(j) == prefix ? 1u : 0u;
     eq_cnt[tid] = mine;
     __syncthreads();
     // exclusive prefix of the threads' counts (keys equal to the threshold are a handful: 32-bit keys rarely collide)
@@ -152,13 +208,7 @@ __global__ __launch_bounds__(RM_THREADS) void random_mask_kernel(double* __restr
         if (k == prefix) { zero = before < want; ++before; }
         mask[IDX(j)] = (all || (zero && !none)) ? 0.0 : 1.0;
     };
-    if constexpr (CACHED) {
-#pragma unroll
-        for (int j = 0; j < RM_PER; ++j)
-            if (IDX(j) < n) put(j, keys[j]);
-    } else {
-        for (int j = 0; IDX(j) < n; ++j) put(j, key_at(j));
-    }
+    for (int j = 0; IDX(j) < n; ++j) put(j, key_at(j));
 }
 #undef IDX
 
@@ -599,15 +649,8 @@ extern "C" int dlc_random_mask_f64(dlc_ctx* ctx, double* mask, int64_t n, int64_
     if (n > (1ll << 26)) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "random_mask: n=%lld too large (one workgroup walks the keys)", (long long)n);
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-#define DLC_RM_LAUNCH(PER)                                                                                        \
-    hipLaunchKernelGGL(random_mask_kernel<PER>, dim3(1), dim3(RM_THREADS), 0, (hipStream_t)stream, mask, (long long)n, \
-                       (long long)n_zeros, (unsigned long long)seed, (unsigned long long)counter)
-    if (n <= (long long)RM_THREADS * 8) DLC_RM_LAUNCH(8);
-    else if (n <= (long long)RM_THREADS * 24) DLC_RM_LAUNCH(24);
-    else if (n <= (long long)RM_THREADS * 52) DLC_RM_LAUNCH(52);
-    else if (n <= (long long)RM_THREADS * RM_PER_MAX) DLC_RM_LAUNCH(RM_PER_MAX);
-    else DLC_RM_LAUNCH(0);
-#undef DLC_RM_LAUNCH
+    hipLaunchKernelGGL(random_mask_kernel, dim3(1), dim3(RM_THREADS), 0, (hipStream_t)stream, mask, (long long)n,
+                       (long long)n_zeros, (unsigned long long)seed, (unsigned long long)counter);
     DLC_LAUNCH_CHECK(ctx, "random_mask_kernel");
     return DLC_OK;
 }

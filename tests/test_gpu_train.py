@@ -143,7 +143,8 @@ def test_random_mask_kernel_counts_and_uniformity():
     frequency (400 draws of 3000 elements at level 0.3: per-position frequency within 5 sigma of 0.3, mean exact)."""
     import deeploopcloser_amd as dlc
     eng = dlc.default_engine()
-    for n, nz in ((1, 0), (1, 1), (7, 3), (1024, 1024), (1025, 0), (50430, 15129), (75000, 22500), (200001, 1), (3000, 2999)):
+    for n, nz in ((1, 0), (1, 1), (7, 3), (1024, 1024), (1025, 0), (50430, 15129), (75000, 22500), (200001, 1), (3000, 2999),
+                  (300000, 90000), (1000000, 300000)):       # (the window's list holds the first, overflows on the second)
         m = torch.empty(n, dtype=torch.float64, device=eng.device)
         eng.random_mask(m, nz, seed=5, counter=n)
         assert int((m == 0).sum()) == nz and int((m == 1).sum()) == n - nz, (n, nz)
