@@ -34,6 +34,7 @@ Rank 0 prints ONE JSON line (the driver's contract) carrying also
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -79,6 +80,8 @@ def parse():
                     help="skip `multi_gpu_emulation` (one rank's step of a 2 / 4 / 8-GPU run, emulated on this GPU)")
     ap.add_argument("--path-frames", type=int, default=1063, help="frames of the `paths` entries (outdoor_kennedylong: 1063)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `baseline_configs` rows (configs[3], configs[4])")
+    ap.add_argument("--detail", default=None, help="where the full result goes (default: bench_detail.json beside this "
+                    "script, and gpurun_out/ when present); stdout carries one line under 4 KB")
     ap.add_argument("--crowded", action="store_true",
                     help="rehearsal of the sharded exhaustive round: the database row query 0 is planted on is copied to kg*8+1 "
                          "places spread over the whole database (every shard), so that query's k-th score ties with a row every "
@@ -116,19 +119,32 @@ def pmc_traffic(n, d, nq, dtype, world):
     return best
 
 
+def _smi(*flags):
+    import subprocess
+    return subprocess.run(["rocm-smi"] + list(flags), capture_output=True, text=True, timeout=10).stdout
+
+
+def _energy_uj():
+    """The package's accumulated-energy counter in microjoules (rocm-smi --showenergycounter), or None."""
+    try:
+        m = re.search(r"Accumulated Energy \(uJ\):\s*([0-9.]+)", _smi("--showenergycounter"))
+        return float(m.group(1)) if m else None
+    except Exception:
+        return None
+
+
 def power_probe(step, seconds=2.5):
     """Keep submitting steps for `seconds` while a thread samples `rocm-smi --showpower --showclocks`
-    (a child process); returns the median package power (W) and shader clock (MHz), or None."""
-    import re
-    import subprocess
+    (a child process); returns the median package power (W) and shader clock (MHz), the steps run and their
+    mean duration, and -- when the board exposes its energy accumulator -- the counter's joules per step over
+    the same stretch (the two reads sit outside the loop, behind a synchronise).  None if rocm-smi is missing."""
     import threading
     samples, stop = [], threading.Event()
 
     def sample():
         while not stop.is_set():
             try:
-                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True,
-                                     timeout=10).stdout
+                txt = _smi("--showpower", "--showclocks")
                 pw = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
                 sc = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", txt)
                 if pw and sc:
@@ -138,13 +154,21 @@ def power_probe(step, seconds=2.5):
             stop.wait(0.3)
 
     try:
+        for _ in range(50):                                  # the chip is under the load before the first counter read
+            step()
+        torch.cuda.synchronize()
+        e0 = _energy_uj()
         th = threading.Thread(target=sample, daemon=True)
         th.start()
+        steps = 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < seconds:
             for _ in range(50):
                 step()
+            steps += 50
             torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        e1 = _energy_uj()
         stop.set()
         th.join(timeout=15)
     except Exception:
@@ -152,8 +176,12 @@ def power_probe(step, seconds=2.5):
     if len(samples) < 2:
         return None
     good = samples[1:]                                   # the first sample may predate the load
-    return {"package_power_w": float(np.median([g[0] for g in good])), "sclk_mhz": float(np.median([g[1] for g in good])),
-            "samples": len(good), "source": "rocm-smi while the timed loop's step keeps running (untimed)"}
+    out = {"package_power_w": float(np.median([g[0] for g in good])), "sclk_mhz": float(np.median([g[1] for g in good])),
+           "samples": len(good), "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "source": "rocm-smi while the timed loop's step keeps running (untimed)"}
+    if e0 is not None and e1 is not None and e1 > e0:
+        out["energy_counter_j_per_step"] = (e1 - e0) * 1e-6 / steps
+    return out
 
 
 def synth_shard(eng, n_total, dim, lo, hi, dtype, planted_rows, chunk=32768):
@@ -1027,6 +1055,130 @@ def bench_configs(eng, dlc, args, rows_bf16, queries_bf16, planted, noise, sigma
     return out
 
 
+LINE_LIMIT = 4096            # the driver's parser lost round 5's 28 KB line: the line on stdout stays under this, always
+DETAIL_FILE = "bench_detail.json"
+
+_PATH_IDS = [                # (substring of a `paths` row's name, its key in the line's paths_summary), first match wins
+    ("f16x2 split", "sdav_encode_f16x2"), ("SDAV.transform", "sdav_encode_f64"), ("train_step", "sdav_train_step"),
+    ("patch front-end", "frontend"), ("SdavLoopClosureDetector", "stream_sdav"), ("LoopClosureDetector", "stream_cosine"),
+    ("real-frame statistics, N(0,1)", "sdav_sim_real_n01"), ("real-frame statistics, 1/sqrt", "sdav_sim_real_fanin"),
+    ("SDAV similarity matrix", "sdav_sim"), ("cosine similarity matrix", "cos_matrix_75k"), ("cosine top-", "cos_topk_75k"),
+    ("4096-wide", "sdav4096_encode_cos"),
+    ("CnnVtl.transform", "cnnvtl_encode"), ("cnn_vtl distance matrix", "cnnvtl_dist"),
+    ("configs[1] end to end", None), ("configs[2] end to end", "cfg2_e2e"), ("configs[0] end to end", "cfg0_e2e"),
+]
+
+
+def path_id(name):
+    for sub, key in _PATH_IDS:
+        if sub in name:
+            if key is None:
+                return "cfg1_e2e_f16x2" if "f16x2" in name else "cfg1_e2e_f64"
+            return key
+    import zlib                                                # an unlisted row: a short, distinct key from its name
+    return "%s_%04x" % (re.sub(r"[^a-z0-9]+", "_", name.lower())[:18], zlib.crc32(name.encode()) & 0xffff)
+
+
+def _r(x, digits=5):
+    """Numbers of the line carry `digits` significant digits (the sidecar keeps them all)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def compact_line(out, detail=DETAIL_FILE):
+    """The ONE line the driver parses, built from the full result `out` (which goes to the sidecar file whole): the
+    contract's keys, `roofline` (with the power probe and the energy per step), `cpu_baseline`, the index agreement, and
+    one [ms, roofline fraction, bound] triple per other row of the hot path.  Under LINE_LIMIT bytes whatever `out` holds:
+    the optional blocks are dropped, last first, if they do not fit."""
+    cfg = dict(out["config"])
+    cfg["workload"] = "%d x %d %s keyframe DB, Q=%d, top-%d cosine match, %d GPU(s)" % (
+        cfg.get("db_rows", 0), cfg.get("dim", 0), out["dtype"], cfg.get("queries_per_step", 0), cfg.get("k", 0), out["n_gpus"])
+    line = {k: _r(out[k], 7) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = cfg
+    line["recall_at_1"] = _r(out.get("recall_at_1"))
+    ro = out["roofline"]
+    r2 = {k: _r(ro.get(k), 6) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                                         "kernel_launches_timed", "algorithmic_bytes_per_launch", "mfma_frac",
+                                         "frac_of_measured_copy", "energy_j_per_step")}
+    if ro.get("traffic_source"):
+        r2["traffic_source"] = str(ro["traffic_source"]).split(" ")[0] + " (replayed PMC passes)"
+    pp = ro.get("power_probe")
+    if pp:
+        r2["power_probe"] = {k: _r(pp.get(k)) for k in ("package_power_w", "sclk_mhz", "samples", "energy_counter_j_per_step")}
+    line["roofline"] = r2
+    cb = out.get("cpu_baseline")
+    if cb:
+        c2 = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "arithmetic", "value_f32", "value_torch_f32_all_cores",
+                                         "host_cpus")}
+        c2["sample"] = cb.get("sample_short") or str(cb.get("sample", ""))[:160]
+        line["cpu_baseline"] = c2
+    for k in ("topk_index_agreement_vs_oracle", "topk_index_agreement_rows", "topk_score_max_abs_err_vs_oracle", "topk_idx_sha256"):
+        if k in out:
+            line[k] = _r(out[k])
+    optional = []                                             # (key, value), most dispensable LAST
+    if out.get("steady_state"):
+        optional.append(("steady_state", {"value": _r(out["steady_state"]["value"]), "ms_per_step": _r(out["steady_state"]["ms_per_step"])}))
+    if out.get("rccl_smoke"):
+        sm = out["rccl_smoke"]
+        optional.append(("rccl_smoke", {k: _r(sm.get(k)) for k in ("backend", "rccl_version", "ranks", "pipeline_equals_plain_exchange",
+                                                                   "first_collective_s")}))
+        if isinstance(sm.get("collective_us"), dict):
+            optional[-1][1]["collective_us"] = {k: _r(v, 4) for k, v in sm["collective_us"].items()}
+    if out.get("rccl_world1_smoke"):
+        optional.append(("rccl_world1_smoke", out["rccl_world1_smoke"]))
+    if out.get("pipeline"):
+        optional.append(("pipeline", out["pipeline"]))
+    if out.get("paths"):
+        optional.append(("paths_summary", {"_": "[ms, roofline frac, bound]",
+                                           **{path_id(p["path"]): [_r(p["ms"], 4), _r(p["roofline"]["frac"], 3), p["roofline"]["bound"]]
+                                              for p in out["paths"]}}))
+    if out.get("baseline_configs"):
+        optional.append(("configs_summary", {"_": "[ms, hbm frac, emulated 8-GPU q-f/s]",
+                                             **{"cfg%d" % c["config"]: [_r(c["ms_per_step"], 4), _r(c["roofline"]["frac"], 3),
+                                                                       _r((c.get("eight_gpu_emulation") or {}).get("projected_query_frames_per_s"), 4)]
+                                                for c in out["baseline_configs"]}}))
+    if out.get("multi_gpu_emulation"):
+        optional.append(("emulated_ranks_qfps", {"_": "EMULATED on one GPU, no RCCL",
+                                                 **{str(e["ranks"]): _r(e["projected_query_frames_per_s"], 4) for e in out["multi_gpu_emulation"]}}))
+    for k in ("finish_ms", "step_minus_gemm_ms"):
+        if out.get(k) is not None:
+            optional.append((k, _r(out[k], 4)))
+    line["detail"] = detail
+    for key, val in optional:
+        line[key] = val
+    txt = json.dumps(line, separators=(",", ":"))
+    while len(txt) >= LINE_LIMIT and optional:                  # cannot happen with today's rows; never print a line the
+        key, _ = optional.pop()                                 # driver cannot parse
+        line.pop(key, None)
+        line["dropped_for_size"] = line.get("dropped_for_size", []) + [key]
+        txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) >= LINE_LIMIT:
+        raise SystemExit("bench.py: the contract line is %d bytes" % len(txt))
+    return txt
+
+
+def write_detail(out, path=None):
+    """The full result -- every row of `paths`, `baseline_configs`, the emulation, the probes -- beside the script (and
+    under gpurun_out/ when that exists, which is what travels back from a GPU box).  Never on stdout or stderr."""
+    txt = json.dumps(out, indent=1)
+    targets = [path or os.path.join(ROOT, DETAIL_FILE)]
+    scratch = os.path.join(ROOT, "gpurun_out")
+    if path is None and os.path.isdir(scratch):
+        targets.append(os.path.join(scratch, DETAIL_FILE))
+    for t in targets:
+        try:
+            with open(t, "w") as f:
+                f.write(txt + "\n")
+        except OSError as e:                                     # a read-only checkout must not cost the line
+            print("[bench] could not write %s: %s" % (t, e), file=sys.stderr)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start the N rank processes (torch.distributed.run, one per
     GPU, rendezvous on 127.0.0.1) as CHILDREN of this process, which has not touched the GPU and never will; rank 0
@@ -1168,15 +1320,17 @@ def main():
     gc.collect()                                             # no cyclic collection inside the timed region -- and none between
     gc.disable()                                             # the warm-up and it: a collection here is tens of milliseconds of an
     eng.set_profiling(True)                                  # idle GPU, and the first steps behind an idle stretch run at the
-    for _ in range(args.warmup):                             # clock the chip dropped to (docs/LAB.md 11.6)
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    fence()
-    t1 = time.perf_counter()
-    gc.enable()
+    try:                                                     # clock the chip dropped to (docs/LAB.md 11.6)
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        fence()
+        t1 = time.perf_counter()
+    finally:
+        gc.enable()
     scores, idx = res if pipe is None else pipe.result(last[0])
     gemm_ms = eng.profile_gemm_ms(min(args.steps, 256))
     eng.set_profiling(False)
@@ -1267,7 +1421,10 @@ def main():
     # ---- package power / clock while the same loop runs on (untimed; rank 0, N=1 only): the score GEMM
     # sits on the board's power cap, which is what bounds it -------------------------
     if rank == 0 and world == 1 and not args.no_power_probe:
-        out["roofline"]["power_probe"] = power_probe(step, seconds=2.5)
+        pp = out["roofline"]["power_probe"] = power_probe(step, seconds=2.5)
+        # joules per step = the probe's median package power x the probe loop's own mean step (the same loop, the same
+        # operating point); the board's energy accumulator over the same stretch rides along in power_probe when it exists
+        out["roofline"]["energy_j_per_step"] = pp["package_power_w"] * pp["ms_per_step"] * 1e-3 if pp else None
         # ... and the same K steps timed once more, now that the chip has been under THIS load for 2.5 s: after any pause the
         # first ~25 launches of the score GEMM run ~5 % slower (2.05 ms against 1.96: scripts/exp_step_series.py), which is
         # where a `--warmup 5 --steps 20` run has its whole timed region.  `value` above stays the contract's number; this is
@@ -1350,6 +1507,8 @@ def main():
             "value_torch_f32_all_cores": nq / (t_torch * (n / ns32)), "torch_threads": ncpu,
             "host_cpus": os.cpu_count(), "kind": "port", "arithmetic": "f64",
             "value_f32": nq / (t32 * (n / ns32)),
+            "sample_short": "oracle/cosine.py fp64 NumPy matmul + exact top-%d, %d queries x %d of %d rows: %.1f s CPU%s"
+                            % (k, nq, ns, n, t_cpu, "" if ns == n else ", scaled linearly in rows"),
             "sample": "oracle/cosine.py (NumPy matmul on the BLAS pool of `cores` threads + exact top-k, blocks of %d rows) "
                       "on %d queries x %d of %d DB rows in fp64: %.1f s of CPU work%s; value_f32: the same in fp32 on the "
                       "first %d rows (%.1f s), scaled linearly in DB rows; value_torch_f32_all_cores: torch-CPU fp32 matmul + topk on "
@@ -1360,7 +1519,9 @@ def main():
         out["topk_score_max_abs_err_vs_oracle"] = float(np.abs(s_gpu.cpu().numpy() - best_s).max())
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        write_detail(out, args.detail)
+        sys.stderr.flush()
+        print(compact_line(out, os.path.basename(args.detail) if args.detail else DETAIL_FILE), flush=True)   # the LAST thing on stdout
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -67,7 +67,12 @@ class Engine:
         # database, ...) -- an upload stream landed on the compute stream's queue and upload, kernels and download of
         # SDAV.transform(ndarray) stopped overlapping: 47 ms instead of 36 (docs/LAB.md 11.6; GPU_MAX_HW_QUEUES=8 hid it).
         self._s_in, self._s_out = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
-        self.side_stream = torch.cuda.Stream(device=self.device)     # MatchPipeline's second stream (selection / exchange beside the next GEMM)
+        # ONE second stream per engine, shared by every MatchPipeline of the engine and by SDAV.train_steps' mask draws: the
+        # default four hardware queues are taken (caller's stream, upload, download, this one) and a fifth stream would
+        # share a queue with one of them.  Users of it are ordered among themselves (two pipelines' select / exchange /
+        # merge stages run one behind the other; results are the same, ordering is by events); an application that needs
+        # two pipelines overlapping independently gives each its own Engine (dlc_create is cheap) -- one per database.
+        self.side_stream = torch.cuda.Stream(device=self.device)
         for st in (self._s_in, self._s_out, self.side_stream):
             torch.cuda.Event().record(st)
 
@@ -148,6 +153,13 @@ class Engine:
             raise ValueError("%s must be a contiguous %s tensor of shape %s on %s" % (name, dtype, tuple(shape), self.device))
         return t
 
+    @staticmethod
+    def _wrote(t):
+        """The library has written (or is about to write) t through its raw pointer: torch must see that as the in-place
+        write it is -- the version counter t shares with its base and its views moves, and whatever was derived from the
+        old contents and keyed on the version (the unit_rows() mark) is outdated, as after any torch-side write."""
+        torch.autograd.graph.increment_version(t)
+
     def to_device(self, x, dtype=None):
         if isinstance(x, torch.Tensor):
             t = x.to(self.device)
@@ -184,6 +196,8 @@ class Engine:
         if out is None:
             with torch.cuda.stream(st):
                 out = torch.empty(a.shape, dtype=dt, device=self.device)
+        else:
+            self._wrote(out)
         if a.nbytes:
             self._check(self.lib.dlc_host_to_device(self.ctx, C.c_void_p(out.data_ptr()), C.c_void_p(a.ctypes.data), a.nbytes,
                                                      C.c_void_p(st.cuda_stream)))
@@ -729,7 +743,9 @@ class Engine:
                                                         1 if center else 0, _TORCH_TO_DLC[dt], _ptr(out), ldd,
                                                         self._stream()))
         # the mark unit_rows() looks for: THIS tensor object, at this version, holds rows of norm <= 1.005.  A view or a copy
-        # does not carry it and an in-place torch write outdates it -- then the match measures the norms instead of trusting
+        # does not carry it and an in-place write outdates it -- torch's own or the library's through a raw pointer
+        # (_wrote: upload(out=), this call) -- then the match measures the norms instead of trusting
+        self._wrote(out)
         out._dlc_unit_rows = out._version
         return out
 

@@ -190,6 +190,13 @@ def describe_sdav(files, network=None, key_points_fn=None):
     network = network or SDAV()
     p = network.input_shape[0]
     frames = [read_ppm(f) for f in files]
+    if any(fr.shape != frames[0].shape for fr in frames):
+        # a chunk of frames of several sizes (the reference parses them one by one, CvInputParser.py:30-33): each frame's
+        # patches are gathered on the device on its own, as drivers.create_similarity_matrix does
+        from .input import CvInputParser
+        parser = CvInputParser(p, int(round(np.sqrt(network.input_shape[1]))))
+        x = torch.stack([parser.parse_tensor(fr, key_points_fn(fr.shape[:2]) if key_points_fn else None) for fr in frames])
+        return network.transform_tensor(x).view(len(files), -1)
     kp = None
     if key_points_fn:
         kp = pipeline.key_point_array([key_points_fn(fr.shape[:2]) for fr in frames], p, network.engine)
@@ -268,3 +275,7 @@ def _stream(args, files):
     print("latency\tbatch\t%d\tsteps\t%d\tfirst_step_ms\t%.2f\tms_per_step_median\t%.3f\tms_per_step_max\t%.3f\tms_per_frame\t%.3f"
           % (args.batch, len(lat), lat[0][0], float(np.median(ms)), float(ms.max()), per_frame), file=sys.stderr)
     return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -13,19 +13,55 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def run_bench(extra, launcher=None, timeout=900):
-    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + extra
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
-    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+LINE_LIMIT = 4096                                                    # what the driver's parser is known to take
+
+
+def run_bench(extra, launcher=None, timeout=900, want_line=False):
+    """Runs bench.py; checks the stdout contract -- exactly ONE JSON line, the LAST thing on stdout, under 4 KB (round 5's
+    28 KB line was not parsed by the driver), with a short stderr -- and returns the full result from the sidecar file
+    (and the parsed line with want_line)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + extra + ["--detail", detail]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+        assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+        full = json.load(open(detail))
+    out_lines = res.stdout.splitlines()
+    lines = [l for l in out_lines if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]                       # exactly ONE JSON line
-    return json.loads(lines[0])
+    assert out_lines[-1] == lines[0]                                 # ... and nothing behind it
+    assert len(lines[0]) < LINE_LIMIT, len(lines[0])
+    assert len(res.stdout) + len(res.stderr) < 2 * LINE_LIMIT, (len(res.stdout), len(res.stderr))   # the driver keeps a tail
+    line = json.loads(lines[0])
+    for key in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[key] == full[key], key
+    assert abs(line["value"] - full["value"]) <= 1e-5 * full["value"]
+    assert abs(line["ms_per_step"] - full["ms_per_step"]) <= 1e-5 * full["ms_per_step"]
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) <= 1e-4 * full["roofline"]["frac"]
+    assert "dropped_for_size" not in line
+    return (full, line) if want_line else full
 
 
 def test_bench_json_contract():
-    d = run_bench(["--gpus", "1", "--steps", "4", "--warmup", "1", "--rows", "30000", "--cpu-sample-rows", "30000",
-                   "--no-power-probe", "--path-frames", "24"])
+    d, line = run_bench(["--gpus", "1", "--steps", "4", "--warmup", "1", "--rows", "30000", "--cpu-sample-rows", "30000",
+                         "--no-power-probe", "--path-frames", "24"], want_line=True)
+    # the line itself: the contract keys, roofline, cpu_baseline, the agreement, one triple per other row of the hot path
+    for key, typ in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
+                     ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict), ("paths_summary", dict)]:
+        assert isinstance(line[key], typ), key
+    assert line["vs_baseline"] is None and "workload" in line["config"] and "model" not in line["config"]
+    lr = line["roofline"]
+    assert lr["bound"] == "hbm" and lr["unit"] == "GB/s" and lr["peak"] == 8000.0 and lr["kernel"] == "score_gemm_kernel"
+    assert abs(lr["frac"] - lr["achieved"] / lr["peak"]) < 1e-4 and "traffic" in lr and lr["kernel_ms"] > 0
+    lc = line["cpu_baseline"]
+    assert lc["kind"] == "port" and lc["value"] > 0 and lc["cores"] >= 1 and lc["unit"] == line["unit"] and lc["sample"]
+    assert line["recall_at_1"] == 1.0 and line["topk_index_agreement_vs_oracle"] == 1.0
+    assert len(line["paths_summary"]) == len(d["paths"]) + 1
+    assert all(len(v) == 3 and v[0] > 0 and v[1] > 0 for k_, v in line["paths_summary"].items() if k_ != "_")
+    assert set(line["configs_summary"]) == {"_", "cfg3", "cfg4"} and set(line["emulated_ranks_qfps"]) == {"_", "2", "4", "8"}
     for key, typ in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
                      ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict), ("paths", list)]:

@@ -114,6 +114,29 @@ def test_cli_streams_the_reference_frames(dlc, capsys):
     assert rc == 0 and len(out) == 2
 
 
+def test_describe_sdav_takes_a_chunk_of_frames_of_several_sizes(dlc, tmp_path):
+    """The reference parses frames one by one (CvInputParser.py:30-33), so a dataset may mix sizes: a chunk of two sizes
+    gives, frame for frame, the descriptors each frame gets in a chunk of its own."""
+    import glob
+    import numpy as np
+    from deeploopcloser_amd import loop_closure
+    from deeploopcloser_amd.input import read_ppm
+    src = sorted(glob.glob(os.path.join(GOLDEN, "frames", "*.ppm")))[:2]
+    a, b = read_ppm(src[0]), read_ppm(src[1])[:160, :200]
+    files = []
+    for name, img in (("a.ppm", a), ("b.ppm", np.ascontiguousarray(b))):
+        f = str(tmp_path / name)
+        with open(f, "wb") as fh:
+            fh.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img.tobytes())
+        files.append(f)
+    net = dlc.SDAV()
+    both = loop_closure.describe_sdav(files, net)
+    one_a = loop_closure.describe_sdav(files[:1], net)
+    one_b = loop_closure.describe_sdav(files[1:], net)
+    assert tuple(both.shape) == (2, 30 * 2500)
+    assert torch.equal(both[0], one_a[0]) and torch.equal(both[1], one_b[0])
+
+
 def test_keep_older_kernel_equals_torch_form(dlc):
     """dlc_topk_keep_older == first_k_eligible (its torch form, tested on the CPU) on random candidate lists: empty
     slots, every candidate too recent, fewer candidates than k, more than 64 candidates per row."""

@@ -284,6 +284,14 @@ def test_cosine_certificate_follows_operand_norms(eng, dlc, n, d, dtype):
     assert float(unit.tau_scale(qu).max()) <= 1.01
     assert eng.unit_rows(eng.normalize(qu.float(), dtype)) and not eng.unit_rows(qu) and unit.tau_scale(
         eng.normalize(qu.float(), dtype)) is not None                        # the ROWS are foreign, whatever the queries are
+    # the mark is outdated by the library's own raw-pointer writes as by torch's: an upload into a normalised tensor (or a
+    # view of it) leaves rows of any norm behind
+    marked = eng.normalize(qu.float(), dtype)
+    assert eng.unit_rows(marked)
+    eng.upload(np.full(tuple(marked[:1].shape), 0x4040, dtype=np.int16), out=marked[:1].view(torch.int16))   # 3.0 / 2.125 everywhere
+    torch.cuda.synchronize()
+    assert float(marked[0].float().norm()) > 10
+    assert not eng.unit_rows(marked)
     own = dlc.KeyframeDatabase(rows_h.float(), dtype=dtype)                  # normalised here: trusted, no scale
     assert own.norm_bound is None and own.tau_scale(own.prepare_queries(qu.float())) is None
     # the two-stream pipeline on one GPU

@@ -154,3 +154,18 @@ def test_space_to_depth_kernel_rearrangement():
         assert wp.shape == (-(-k // s), -(-k // s), s * s * c, o)
         got = ocnn.conv2d_nhwc(xs, wp, b, 1, "VALID", True)
         assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-12
+
+
+def test_streaming_cli_runs_as_a_module():
+    """`python -m deeploopcloser_amd.loop_closure` is the documented streaming CLI (README, DESIGN, INTEGRATION): the module
+    must end in a __main__ guard -- without one the command prints nothing and exits 0."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, "-m", "deeploopcloser_amd.loop_closure", "--help"], capture_output=True, text=True,
+                         cwd=ROOT, timeout=300, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert res.returncode == 0 and "usage:" in res.stdout and "dataset_path" in res.stdout
+    res = subprocess.run([sys.executable, "-m", "deeploopcloser_amd.loop_closure"], capture_output=True, text=True,
+                         cwd=ROOT, timeout=300, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert res.returncode == 2 and "dataset_path" in res.stderr            # argparse's "required" error, not silence
