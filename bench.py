@@ -80,6 +80,9 @@ def parse():
                     help="skip `multi_gpu_emulation` (one rank's step of a 2 / 4 / 8-GPU run, emulated on this GPU)")
     ap.add_argument("--path-frames", type=int, default=1063, help="frames of the `paths` entries (outdoor_kennedylong: 1063)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `baseline_configs` rows (configs[3], configs[4])")
+    ap.add_argument("--no-rccl-smoke", action="store_true",
+                    help="N=1: skip the child process that brings RCCL up on this GPU (one-rank nccl group, the sharded "
+                         "protocol with its collectives forced through the library) after everything else has been measured")
     ap.add_argument("--detail", default=None, help="where the full result goes (default: bench_detail.json beside this "
                     "script, and gpurun_out/ when present); stdout carries one line under 4 KB")
     ap.add_argument("--crowded", action="store_true",
@@ -1179,6 +1182,32 @@ def write_detail(out, path=None):
             print("[bench] could not write %s: %s" % (t, e), file=sys.stderr)
 
 
+def rccl_world1_smoke(timeout=240):
+    """N = 1 only, after everything else: `python -m deeploopcloser_amd.dist --world1-smoke` as a CHILD process (a process
+    group of its own, a watchdog of its own: a hang in the library's bring-up costs this key, never the line) -- a one-rank
+    "nccl" group on this GPU, MatchPipeline with its collectives forced through librccl on the second stream, every batch
+    compared with the one-shot call bit for bit.  Returns the compact form for the line and the full dict."""
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        res = subprocess.run([sys.executable, "-m", "deeploopcloser_amd.dist", "--world1-smoke"], capture_output=True, text=True,
+                             timeout=timeout, cwd=ROOT, env=env)
+        rows = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        if res.returncode != 0 or not rows:
+            return {"ok": False, "error": ("exit %d: " % res.returncode) + (res.stderr.strip().splitlines() or ["no output"])[-1][:200]}, None
+        full = json.loads(rows[-1])
+    except Exception as e:                                      # (a time-out included)
+        return {"ok": False, "error": ("%s: %s" % (type(e).__name__, e))[:200]}, None
+    cu = full.get("pipeline_collective_us") or {}
+    short = {"ok": full["ok"], "backend": full["backend"], "rccl": full.get("rccl_version"), "world": full["world"],
+             "init_s": _r(full["init_s"], 3), "first_collective_s": _r(full["first_collective_s"], 3),
+             "allgather_us": [_r(cu.get("group_maxima"), 3), _r(cu.get("packed_topk"), 3)],
+             "equals_one_shot": full["pipeline_equals_one_shot"], "exhaustive_round_equals_one_shot": full["crowded_equals_one_shot"]}
+    return short, full
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start the N rank processes (torch.distributed.run, one per
     GPU, rendezvous on 127.0.0.1) as CHILDREN of this process, which has not touched the GPU and never will; rank 0
@@ -1517,6 +1546,9 @@ def main():
         out["topk_index_agreement_vs_oracle"] = agree
         out["topk_index_agreement_rows"] = ns
         out["topk_score_max_abs_err_vs_oracle"] = float(np.abs(s_gpu.cpu().numpy() - best_s).max())
+
+    if rank == 0 and world == 1 and not args.no_rccl_smoke:
+        out["rccl_world1_smoke"], out["rccl_world1_smoke_full"] = rccl_world1_smoke()
 
     if rank == 0:
         write_detail(out, args.detail)

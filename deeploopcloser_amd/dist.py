@@ -87,3 +87,103 @@ class ShardedKeyframeDatabase:
         if self.merge is not None:
             return self.merge(self._gather_s, self._gather_i, k)
         return merge_topk_torch(self._gather_s, self._gather_i, k)
+
+
+def world1_smoke(rows=131072, dim=4096, queries=256, k=20, backend="nccl", batches=6, device=0):
+    """RCCL first contact on ONE GPU: a one-rank process group on `backend` ("nccl" is RCCL on ROCm), then the sharded
+    protocol with every collective forced through the library (MatchPipeline(force_collectives=True): the norm all-reduce,
+    the all-gather of the group maxima and the all-gather of the packed parts, on the second stream beside the score
+    pass) -- each batch must equal the one-shot call on the same operands bit for bit; then the same with a crowded
+    database (a tie no merge can certify), which takes the exhaustive round and its third all-gather.  Returns a dict
+    (what bench.py puts in its line as `rccl_world1_smoke`).  Run it in a process of its own:
+    `python -m deeploopcloser_amd.dist --world1-smoke` prints the dict as one JSON line."""
+    import datetime
+    import os
+    import socket
+    import time
+    from .matching import KeyframeDatabase, MatchPipeline
+    from .engine import default_engine
+
+    torch.cuda.set_device(device)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    t0 = time.perf_counter()
+    kw = {"device_id": torch.device("cuda", device)} if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=0, world_size=1, timeout=datetime.timedelta(seconds=60), **kw)
+    t_init = time.perf_counter() - t0
+    try:
+        eng = default_engine(device)
+        t0 = time.perf_counter()
+        one = torch.ones(1, dtype=torch.int32, device=eng.device)
+        dist.all_reduce(one)
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t0
+        if int(one.item()) != 1:
+            raise RuntimeError("all-reduce over one rank gave %d" % int(one.item()))
+        g = torch.Generator(device=eng.device)
+        g.manual_seed(7)
+        stored = torch.empty((rows, eng.stored_width(dim)), dtype=torch.bfloat16, device=eng.device)
+        for lo in range(0, rows, 32768):
+            hi = min(rows, lo + 32768)
+            eng.normalize(torch.rand((hi - lo, dim), generator=g, device=eng.device), "bf16", center=True, out=stored[lo:hi])
+        pick = torch.randint(0, rows, (queries,), generator=g, device=eng.device)
+        # queries: stored rows moved a little (unit rows: a component is ~ 1 / sqrt(dim)) -- their neighbour stays the best row
+        near = stored[pick][:, :dim].float()
+        q = eng.normalize(near + (0.3 / dim ** 0.5) * torch.randn((queries, dim), generator=g, device=eng.device), "bf16")
+        out = {"backend": dist.get_backend(), "world": dist.get_world_size(), "init_s": t_init, "first_collective_s": t_first,
+               "db_rows": rows, "dim": dim, "queries": queries, "k": k}
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            out["rccl_version"] = None
+
+        def check(db, label):
+            want = db.match_topk(q, k, details=True)
+            pipe = MatchPipeline(db, k, depth=2, force_collectives=True)
+            pipe.time_collectives = True
+            same = True
+            for b in range(batches):
+                t = pipe.submit(q)
+                if t >= 1:
+                    s, i = pipe.result(t - 1)
+                    same = same and bool(torch.equal(i, want.idx) and torch.equal(s, want.scores))
+            s, i = pipe.result(batches - 1)
+            same = same and bool(torch.equal(i, want.idx) and torch.equal(s, want.scores))
+            out[label + "_equals_one_shot"] = same
+            out[label + "_collective_us"] = pipe.collective_us()
+            out[label + "_resolved_batches"] = pipe.resolved_batches
+            return same
+
+        ok = check(KeyframeDatabase(stored, dtype="bf16", stored=True), "pipeline")
+        # a tie no selection can certify: kg * 8 + 1 exact copies of query 0's row, spread over the database
+        copies = eng.groups_per_query(k) * 8 + 1
+        where = torch.linspace(0, rows - 1, copies, device=eng.device).long().unique()
+        stored[where] = stored[pick[0]]
+        ok = check(KeyframeDatabase(stored, dtype="bf16", stored=True), "crowded") and ok
+        ok = ok and out["crowded_resolved_batches"] == batches and out["pipeline_resolved_batches"] == 0
+        out["ok"] = bool(ok)
+        return out
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+    import sys
+    ap = argparse.ArgumentParser(description="multi-GPU helpers: --world1-smoke = RCCL first contact on one GPU")
+    ap.add_argument("--world1-smoke", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--rows", type=int, default=131072)
+    ap.add_argument("--dim", type=int, default=4096)
+    a = ap.parse_args()
+    if not a.world1_smoke:
+        ap.print_help()
+        sys.exit(2)
+    res = world1_smoke(rows=a.rows, dim=a.dim, backend=a.backend)
+    print(json.dumps(res), flush=True)
+    sys.exit(0 if res["ok"] else 1)

@@ -190,7 +190,7 @@ class MatchPipeline:
     unverified list; (scores, idx) of result() alias the slot's buffers until then.
     """
 
-    def __init__(self, db, k, depth=2, group=None, queries_per_batch=None):
+    def __init__(self, db, k, depth=2, group=None, queries_per_batch=None, force_collectives=False):
         import torch.distributed as dist
         self.db, self.k, self.depth = db, int(k), int(depth)
         self.engine = db.engine
@@ -200,6 +200,13 @@ class MatchPipeline:
         self.s_select = self.engine.side_stream
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collectives: run the SHARDED protocol -- both all-gathers, the norm all-reduce, the certifying merge --
+        # whatever the group's size.  A one-rank "nccl" group then takes every collective through librccl on the second
+        # stream beside the score pass: the library's bring-up and stream ordering rehearsed on a single GPU
+        # (python -m deeploopcloser_amd.dist --world1-smoke).  Needs an initialised process group.
+        if force_collectives and not dist.is_initialized():
+            raise ValueError("MatchPipeline(force_collectives=True) needs an initialised torch.distributed process group")
+        self.sharded = self.world > 1 or bool(force_collectives)
         self._slots = []
         self._count = 0
         self._nq = queries_per_batch
@@ -209,7 +216,7 @@ class MatchPipeline:
         # sharded: every rank certifies with the norm bound of the WHOLE database (ranks whose rows are the normaliser's
         # contribute 1.005) -- one 4-byte all-reduce here, never read by the host
         self._norm_bound = db.norm_bound
-        if self.world > 1:
+        if self.sharded:
             r = db.norm_bound.clone() if db.norm_bound is not None else \
                 torch.full((1,), 1.005, dtype=torch.float32, device=dev)
             dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
@@ -234,7 +241,7 @@ class MatchPipeline:
                  "idx": torch.empty((nq, k), dtype=torch.int64, device=dev),
                  "scored": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False, "fetched": True, "q": None,
                  "rows": None, "ts_buf": torch.empty((nq,), dtype=torch.float32, device=dev), "ts": None}
-            if self.world > 1:
+            if self.sharded:
                 kg = eng.groups_per_query(k)
                 nb = nq * k * 16                           # packed part: int64 rows [nq,k] | float64 scores [nq,k]
                 s["pack"] = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -269,7 +276,7 @@ class MatchPipeline:
                 # submit is about to overwrite -- say so instead of counting: the flags are identical on every rank, so
                 # every rank raises here, before any collective of the new batch
                 s["done"].synchronize()
-                if self.world > 1 and bool(s["flag"].any()):
+                if self.sharded and bool(s["flag"].any()):
                     raise RuntimeError("MatchPipeline.submit: batch %d was never fetched and its merge did not certify %d "
                                        "quer%s -- call result(ticket) within `depth` submissions (the exhaustive round runs "
                                        "there)" % (self._count - self.depth, int((s["flag"] != 0).sum()),
@@ -285,11 +292,11 @@ class MatchPipeline:
         self.s_select.wait_event(s["scored"])
         with torch.cuda.stream(self.s_select):
             # operands that are not the normaliser's: tau follows |q| * (the database's largest row norm)
-            if self.world == 1 and self._norm_bound is None and eng.unit_rows(q):
+            if not self.sharded and self._norm_bound is None and eng.unit_rows(q):
                 ts = s["ts"] = None
             else:
                 ts = s["ts"] = eng.cosine_tau_scale(q, self._norm_bound, out=s["ts_buf"], stream=self.s_select)
-            if self.world == 1:
+            if not self.sharded:
                 eng.select_topk(q, rows, self.k, s["ws"], s["scores"], s["idx"],
                                 row_offset=self.db.row_offset, coop=True, stream=self.s_select, tau_scale=ts)
             else:
@@ -340,7 +347,7 @@ class MatchPipeline:
         s = self._slots[ticket % self.depth]
         s["done"].synchronize()
         s["fetched"] = True
-        if self.world > 1 and bool(s["flag"].any()):
+        if self.sharded and bool(s["flag"].any()):
             s["flag"].zero_()
             self._resolve(s)
         return s["scores"], s["idx"]

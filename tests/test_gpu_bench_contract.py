@@ -61,6 +61,9 @@ def test_bench_json_contract():
     assert line["recall_at_1"] == 1.0 and line["topk_index_agreement_vs_oracle"] == 1.0
     assert len(line["paths_summary"]) == len(d["paths"]) + 1
     assert all(len(v) == 3 and v[0] > 0 and v[1] > 0 for k_, v in line["paths_summary"].items() if k_ != "_")
+    sm = line["rccl_world1_smoke"]
+    assert sm["ok"] is True and sm["backend"] == "nccl" and sm["world"] == 1 and sm["equals_one_shot"] is True
+    assert sm["exhaustive_round_equals_one_shot"] is True and min(sm["allgather_us"]) > 0
     assert set(line["configs_summary"]) == {"_", "cfg3", "cfg4"} and set(line["emulated_ranks_qfps"]) == {"_", "2", "4", "8"}
     for key, typ in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str),
@@ -147,7 +150,7 @@ def test_bench_two_ranks_equal_one_rank():
     with --backend gloo --share-gpu so that both ranks can use this box's single GPU: MatchPipeline's sharded
     protocol (group selection -> all-gather of the group maxima -> filtered re-score -> all-gather of the
     packed per-shard top-k -> merge) must give recall 1.0 and exactly the one-rank result."""
-    common = ["--steps", "6", "--warmup", "2", "--rows", "40000", "--no-cpu-baseline", "--no-power-probe", "--no-paths"]
+    common = ["--steps", "6", "--warmup", "2", "--rows", "40000", "--no-cpu-baseline", "--no-power-probe", "--no-paths", "--no-rccl-smoke"]
     one = run_bench(["--gpus", "1"] + common)
     port = 29600 + os.getpid() % 300
     two = run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
@@ -171,7 +174,7 @@ def test_bench_launches_its_own_ranks():
     command line would call it) starts its two rank processes itself, before it touches the GPU, relays rank 0's one
     JSON line and exit code, and gets the one-rank digests.  Four ranks on the one GPU as well (12 500-row shards: the
     small-database plan on every rank, another plan than the one-rank run's -- same digests)."""
-    common = ["--steps", "4", "--warmup", "1", "--rows", "50000", "--no-cpu-baseline", "--no-power-probe", "--no-paths"]
+    common = ["--steps", "4", "--warmup", "1", "--rows", "50000", "--no-cpu-baseline", "--no-power-probe", "--no-paths", "--no-rccl-smoke"]
     one = run_bench(["--gpus", "1"] + common)
     for ranks in (2, 4):
         got = run_bench(["--gpus", str(ranks), "--backend", "gloo", "--share-gpu"] + common)
@@ -187,7 +190,7 @@ def test_sharded_exhaustive_round_across_processes():
     a third all-gather, a merge -- for every batch, agree on the flags (nobody hangs in a collective the other skipped),
     drop nothing and return exactly the one-rank lists."""
     common = ["--steps", "5", "--warmup", "2", "--rows", "40000", "--no-cpu-baseline", "--no-power-probe", "--no-paths",
-              "--no-shard-emulation", "--crowded"]
+              "--no-shard-emulation", "--no-rccl-smoke", "--crowded"]
     one = run_bench(["--gpus", "1"] + common)
     port = 29900 + os.getpid() % 90
     two = run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu"] + common,
@@ -199,3 +202,21 @@ def test_sharded_exhaustive_round_across_processes():
     assert two["rccl_smoke"]["pipeline_equals_plain_exchange"] is True and two["rccl_smoke"]["resolved_batches"] == 3
     assert two["topk_idx_sha256"] == one["topk_idx_sha256"] and two["topk_scores_sha256"] == one["topk_scores_sha256"]
     assert one["recall_at_1"] == 1.0 and two["recall_at_1"] == 1.0
+
+
+def test_rccl_first_contact_on_one_gpu():
+    """`python -m deeploopcloser_amd.dist --world1-smoke` in a fresh process: a one-rank "nccl" (= RCCL) process group, the
+    sharded protocol with every collective forced through the library on the second stream (MatchPipeline(...,
+    force_collectives=True): norm all-reduce, both all-gathers, the certifying merge; and, on a crowded database, the
+    exhaustive round with its third all-gather) -- every batch equal to the one-shot call bit for bit.  What a first
+    `--gpus 8` run brings up, minus the other seven ranks."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    res = subprocess.run([sys.executable, "-m", "deeploopcloser_amd.dist", "--world1-smoke", "--rows", "65536"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] is True and d["backend"] == "nccl" and d["world"] == 1
+    assert d["pipeline_equals_one_shot"] is True and d["crowded_equals_one_shot"] is True
+    assert d["pipeline_resolved_batches"] == 0 and d["crowded_resolved_batches"] == 6
+    c = d["pipeline_collective_us"]
+    assert c["batches"] == 6 and c["group_maxima"] > 0 and c["packed_topk"] > 0

@@ -1638,6 +1638,25 @@ def test_row_stride_bound_and_buffer_validation(eng, dlc):
                           out=torch.zeros((4, 6), dtype=torch.float64, device=eng.device))
 
 
+def test_create_rejects_a_device_that_is_not_there(dlc):
+    """dlc_create(device, &ctx) on an index past the visible GPUs (what a mis-set LOCAL_RANK hands it) or a negative one:
+    DLC_ERR_BAD_ARG, a null context, no HIP state touched -- and the Python engine raises instead of keeping a half-made
+    handle.  The one-GPU half of the per-device path (the two-GPU half below needs a second GPU)."""
+    import ctypes as C
+    from deeploopcloser_amd import _lib as L
+    lib = L.load()
+    for bad in (torch.cuda.device_count(), torch.cuda.device_count() + 7, -1):
+        ctx = C.c_void_p(0xdead)
+        assert lib.dlc_create(bad, C.byref(ctx)) == L.DLC_ERR_BAD_ARG and not ctx.value
+    assert lib.dlc_create(0, None) == L.DLC_ERR_BAD_ARG
+    from deeploopcloser_amd.engine import Engine
+    with pytest.raises(L.DlcError):
+        Engine(torch.cuda.device_count())
+    # ... and the engine of device 0 is untouched by the refusals
+    e = dlc.default_engine(0)
+    assert float(e.normalize(torch.ones((2, 64), device=e.device), "bf16").float().norm(dim=1).max()) == pytest.approx(1.0, abs=1e-2)
+
+
 def test_two_contexts_two_devices(dlc):
     """One context per GPU: the kernels' dynamic-LDS limits are set per DEVICE (the flags live in the context), so a
     second context on another GPU of the same process runs the 128 KiB score GEMM too.  Needs two visible GPUs."""
