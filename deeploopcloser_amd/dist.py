@@ -162,7 +162,7 @@ def world1_smoke(rows=131072, dim=4096, queries=256, k=20, backend="nccl", batch
         # a tie no selection can certify: kg * 8 + 1 exact copies of query 0's row, spread over the database
         copies = eng.groups_per_query(k) * 8 + 1
         where = torch.linspace(0, rows - 1, copies, device=eng.device).long().unique()
-        stored[where] = stored[pick[0]]
+        stored[where] = stored[pick[0]].clone()
         ok = check(KeyframeDatabase(stored, dtype="bf16", stored=True), "crowded") and ok
         ok = ok and out["crowded_resolved_batches"] == batches and out["pipeline_resolved_batches"] == 0
         out["ok"] = bool(ok)

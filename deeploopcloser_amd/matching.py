@@ -206,7 +206,7 @@ class MatchPipeline:
         # (python -m deeploopcloser_amd.dist --world1-smoke).  Needs an initialised process group.
         if force_collectives and not dist.is_initialized():
             raise ValueError("MatchPipeline(force_collectives=True) needs an initialised torch.distributed process group")
-        self.sharded = self.world > 1 or bool(force_collectives)
+        self._force_collectives = bool(force_collectives)
         self._slots = []
         self._count = 0
         self._nq = queries_per_batch
@@ -225,6 +225,11 @@ class MatchPipeline:
         self.dropped_batches = 0           # batches whose slot was reused before result() fetched them
         self.time_collectives = False      # record events around the two all-gathers of every batch (collective_us())
         self._coll_events = []
+
+    @property
+    def sharded(self):
+        """The sharded protocol (group maxima -> all-gather -> filtered re-score -> all-gather -> certifying merge) runs."""
+        return self.world > 1 or self._force_collectives
 
     def _slot(self, i, nq, d):
         while len(self._slots) <= i:
