@@ -318,7 +318,54 @@ def bench_paths(eng, n_frames):
                              "algorithmic_flops_per_call": sflops, "fp64_equivalent_tflops": flops / (sk_ms * 1e-3) / 1e12},
                 "cpu_baseline": out[-1]["cpu_baseline"]})
     del net16, h16, l2
-    del ws, bs, xs, ref
+    del ws, bs, ref
+
+    # ---- SURVEY 8d config 2's optional variant, NOT the reference's network: hidden_units[-1] = 4096 -- north_star's
+    # "4096-d descriptors" at configs[1] size: encode (fp64, the same chain, last layer 2500 -> 4096), then every one of the
+    # N * 30 patch descriptors matched against all of them (cosine top-20, bf16, batches of 256 queries)
+    from oracle import cosine as ocos4
+    W4 = 4096
+    net4 = dlc.SDAV(seed=1, hidden_units=[H, H, H, H, W4])
+    e_ms, ek_ms, ek_n, h4 = _timed_path(eng, lambda: net4.transform_tensor(x), reps=2)
+    eflops = 2.0 * P * N * (K0 * H + 3 * H * H + H * W4)
+    db4 = dlc.KeyframeDatabase(h4, dtype="bf16", center=True)
+    q4 = db4.rows
+    nq4 = q4.shape[0]
+
+    def all_patches_top20():
+        r = None
+        for b0 in range(0, nq4, 256):
+            r = db4.match_topk(q4[b0:b0 + 256], 20)
+        return r
+    m_ms, _, _, _ = _timed_path(eng, all_patches_top20, reps=2, inner=1)
+    ws4, bs4 = net4.get_weights()
+    nb4 = min(N, 16)
+    t0 = time.perf_counter()
+    ref4 = osdav.transform(xs[:nb4], ws4, bs4)
+    t_cpu4 = time.perf_counter() - t0
+    err4 = float(np.abs(h4[:nb4 * P].cpu().numpy() - ref4).max())
+    nqs = min(64, nq4)
+    rows4_h = q4.float().cpu().numpy().astype(np.float64)
+    t0 = time.perf_counter()
+    es4, ei4 = ocos4.cosine_topk(rows4_h[:nqs], rows4_h, 20)
+    t_cos4 = time.perf_counter() - t0
+    top4 = db4.match_topk(q4[:nqs], 20)
+    tot4 = e_ms + m_ms
+    r4 = _mfma_f64_roofline(eflops, ek_ms, ek_n, tot4, "dominant stage: the encoder's five fp64 GEMMs (gemm_dma_f64_kernel); "
+                            "the match is score_gemm_kernel + finish per batch of 256 patch queries")
+    out.append({"path": "SDAV 4096-wide variant (non-reference): encode + cosine top-20 of all patch descriptors",
+                "reference": "NOT the reference's network (SDAV.py:31-32 fixes 5 x 2500): SURVEY 8d config 2's optional "
+                "hidden_units[-1] = 4096 variant, north_star's 4096-d descriptors", "frames": N, "dtype": "f64 encode, bf16 cosine",
+                "dim": W4, "k": 20, "value": N / (tot4 * 1e-3), "unit": "frames/s", "ms": tot4,
+                "stage_ms": {"SDAV.transform (last layer 4096 wide)": e_ms, "cosine top-20, %d x %d patch descriptors in batches of "
+                             "256" % (nq4, nq4): m_ms},
+                "patch_queries_per_s": nq4 / (m_ms * 1e-3), "roofline": r4,
+                "cpu_baseline": {"value": 1.0 / (t_cpu4 / nb4 + (t_cos4 / nqs) * P), "unit": "frames/s", "cores": cores, "kind": "port",
+                                 "sample": "oracle/sdav.py on the first %d frames (%.2f s) + oracle/cosine.py top-20 of the first %d "
+                                           "patch descriptors against all %d (%.2f s), per frame" % (nb4, t_cpu4, nqs, nq4, t_cos4)},
+                "max_abs_err_vs_oracle": err4,
+                "topk_index_agreement_vs_oracle": float((top4[1].cpu().numpy() == ei4).mean())})
+    del net4, h4, db4, q4, rows4_h, ws4, bs4, ref4, top4, xs
 
     # ---- f-2: one SDAV training step (sess.run(train_steps[0]), SDAV.py:262) on the reference's default batch -------
     from oracle import sdav_train as otrain
@@ -1062,11 +1109,11 @@ LINE_LIMIT = 4096            # the driver's parser lost round 5's 28 KB line: th
 DETAIL_FILE = "bench_detail.json"
 
 _PATH_IDS = [                # (substring of a `paths` row's name, its key in the line's paths_summary), first match wins
+    ("4096-wide", "sdav4096_encode_cos"),
     ("f16x2 split", "sdav_encode_f16x2"), ("SDAV.transform", "sdav_encode_f64"), ("train_step", "sdav_train_step"),
     ("patch front-end", "frontend"), ("SdavLoopClosureDetector", "stream_sdav"), ("LoopClosureDetector", "stream_cosine"),
     ("real-frame statistics, N(0,1)", "sdav_sim_real_n01"), ("real-frame statistics, 1/sqrt", "sdav_sim_real_fanin"),
     ("SDAV similarity matrix", "sdav_sim"), ("cosine similarity matrix", "cos_matrix_75k"), ("cosine top-", "cos_topk_75k"),
-    ("4096-wide", "sdav4096_encode_cos"),
     ("CnnVtl.transform", "cnnvtl_encode"), ("cnn_vtl distance matrix", "cnnvtl_dist"),
     ("configs[1] end to end", None), ("configs[2] end to end", "cfg2_e2e"), ("configs[0] end to end", "cfg0_e2e"),
 ]

@@ -40,10 +40,19 @@ def _init_weights(dims, seed, dtype, device, scale="reference"):
 
 
 class SDAV:
-    def __init__(self, verbosity=logging.WARNING, seed=0, dtype="float64", device=None, weight_scale="reference"):
+    def __init__(self, verbosity=logging.WARNING, seed=0, dtype="float64", device=None, weight_scale="reference",
+                 hidden_units=None):
         self.logger = logging.getLogger()
         self.logger.setLevel(verbosity)
         self._define_params()
+        if hidden_units is not None:
+            # NOT the reference's network (SDAV.py:31-32 fixes five layers of 2500): other widths for the same chain, e.g.
+            # [2500, 2500, 2500, 2500, 4096] -- the 4096-d patch descriptors BASELINE.json's north_star speaks of
+            # ("may be reported additionally, labelled non-reference")
+            hu = [int(h) for h in hidden_units]
+            if not hu or any(h <= 0 for h in hu):
+                raise ValueError("hidden_units: a non-empty list of positive layer widths")
+            self.hidden_units = hu
         self.losses = []
         self.engine = default_engine(device)
         # "f16x2": the tolerance mode -- parameters and results stay float64, transform() runs every layer as three fp16 MFMA

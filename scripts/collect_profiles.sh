@@ -8,8 +8,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel stats: the whole default workload (headline loop + the `paths` rows); PMC passes: the headline loop only
-S="python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe --no-shard-emulation --no-configs"
-B="python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe --no-shard-emulation --no-configs --no-paths"
+S="python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe --no-shard-emulation --no-configs --no-rccl-smoke"
+B="python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-power-probe --no-shard-emulation --no-configs --no-paths --no-rccl-smoke"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $S > $OUT/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1

@@ -89,6 +89,7 @@ def test_bench_json_contract():
     # the other rows of the hot path, each with its own roofline and CPU baseline, each checked against the oracle
     paths = {p["path"]: p for p in d["paths"]}
     assert set(paths) == {"SDAV.transform", "SDAV.transform (f16x2 split, tolerance mode)",
+                          "SDAV 4096-wide variant (non-reference): encode + cosine top-20 of all patch descriptors",
                           "SDAV.train_step (layer 0, 10 frames)", "SDAV similarity matrix",
                           "SDAV similarity matrix, real-frame statistics, N(0,1) weights",
                           "SDAV similarity matrix, real-frame statistics, 1/sqrt(fan_in) weights",
@@ -135,6 +136,8 @@ def test_bench_json_contract():
         assert pr["kernel_ms"] > 0 and pr["kernel_ms"] <= pr["call_ms"] * 1.001 and "traffic" in pr
         assert pc["kind"] == "port" and pc["value"] > 0 and pc["cores"] >= 1 and pc["unit"] == p["unit"] and pc["sample"]
     assert paths["SDAV.transform"]["max_abs_err_vs_oracle"] < 1e-9
+    wide = paths["SDAV 4096-wide variant (non-reference): encode + cosine top-20 of all patch descriptors"]
+    assert wide["max_abs_err_vs_oracle"] < 1e-9 and wide["topk_index_agreement_vs_oracle"] == 1.0 and wide["dim"] == 4096
     assert paths["SDAV similarity matrix"]["max_rel_err_vs_oracle"] < 1e-9
     assert paths["cosine similarity matrix (flattened SDAV descriptors)"]["max_abs_err_vs_oracle"] < 2e-5
     top = paths["cosine top-20 (flattened SDAV descriptors)"]

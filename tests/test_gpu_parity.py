@@ -659,6 +659,29 @@ def test_sdav_transform_vs_oracle(dlc, scale):
     assert l2.max() < 1e-10                                          # north_star: descriptor L2 within 1e-4
 
 
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-10), ("f16x2", 1e-4)])
+def test_sdav_other_widths_vs_oracle(dlc, dtype, tol):
+    """SDAV(hidden_units=[...]): the same chain with other layer widths (non-reference: SDAV.py:31-32 fixes 5 x 2500) --
+    a 4096-wide last layer for north_star's 4096-d descriptors, and a ragged stack -- against the oracle's forward."""
+    from oracle import sdav as osdav
+    rng = np.random.RandomState(21)
+    for hu in ([2500, 2500, 2500, 2500, 4096], [300, 77, 1000]):
+        net = dlc.SDAV(seed=5, dtype=dtype, weight_scale="fan_in", hidden_units=hu)
+        assert net.hidden_units == hu and net.get_layer_input_shape(len(hu) - 1) == [30, hu[-2]]
+        x = rng.uniform(0, 1, size=(4, 30, 1681))
+        h = net.transform(x)
+        ws, bs = net.get_weights()
+        assert [w.shape for w in ws] == [(k, n) for k, n in zip([1681] + hu[:-1], hu)]
+        ref = osdav.transform(x, ws, bs)
+        assert h.shape == (120, hu[-1]) and h.dtype == np.float64
+        l2 = np.linalg.norm(h - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        assert l2.max() < tol
+    with pytest.raises(ValueError):
+        dlc.SDAV(hidden_units=[])
+    with pytest.raises(ValueError):
+        dlc.SDAV(hidden_units=[2500, 0])
+
+
 def test_sdav_transform_fp32_mode_within_north_star_tolerance(dlc):
     from oracle import sdav as osdav
     rng = np.random.RandomState(6)
