@@ -1597,13 +1597,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_rccl_smoke:
         out["rccl_world1_smoke"], out["rccl_world1_smoke_full"] = rccl_world1_smoke()
 
-    if rank == 0:
-        write_detail(out, args.detail)
-        sys.stderr.flush()
-        print(compact_line(out, os.path.basename(args.detail) if args.detail else DETAIL_FILE), flush=True)   # the LAST thing on stdout
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    # the collectives come down FIRST (whatever the library prints on the way out must not follow the line), then rank 0
+    # writes the sidecar file and prints the ONE line: the last thing on stdout
+    try:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    finally:
+        if rank == 0:
+            write_detail(out, args.detail)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            print(compact_line(out, os.path.basename(args.detail) if args.detail else DETAIL_FILE), flush=True)
 
 
 if __name__ == "__main__":
