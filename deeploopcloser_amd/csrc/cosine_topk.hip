@@ -664,7 +664,7 @@ __device__ __forceinline__ void rescore8_f64(const char* qrow, const char* const
     }
 }
 
-// R rows of rescore8_f64 (R = 1, 2), U pieces of every row and of the query in flight per lane: the same pieces per lane
+// R rows of rescore8_f64 (R = 1, 2, 3), U pieces of every row and of the query in flight per lane: the same pieces per lane
 // in the same order, the same butterfly -- the same values.
 template <typename Tag, int R, int U>
 __device__ __forceinline__ void rescore_rows_f64(const char* qrow, const char* const (&rows)[R], int d, int lane,
@@ -1133,7 +1133,7 @@ constexpr int EXH_POOL = EXH_BATCH * GROUP + DLC_MAX_K;     // running top-k in 
 
 // (the body: also the tail of small_topk_kernel, whose workgroup carries on with it when its own selection did not certify
 // -- no second launch behind every small-database match to find out that nothing is left to do)
-template <typename Tag>
+template <typename Tag, int RS_UNROLL = 4>
 __device__ __forceinline__ void exhaustive_topk_body(const ExhaustiveArgs& a, double lower) {
     const int qi = blockIdx.x;
     __shared__ long long pk[EXH_POOL];
@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void exhaustive_topk_body(const ExhaustiveArgs& a, do
 #pragma unroll
                 for (int r = 0; r < GROUP; ++r) rows[r] = a.DB + (row0 + r < a.n ? row0 + r : a.n - 1) * a.lddb_b;
                 double acc[GROUP];
-                rescore8_f64<Tag, 4>(qrow, rows, a.d, lane, acc);
+                rescore8_f64<Tag, RS_UNROLL>(qrow, rows, a.d, lane, acc);
 #pragma unroll
                 for (int r = 0; r < GROUP; ++r)
                     if (lane == r) {
@@ -1238,8 +1238,12 @@ struct SmallArgs {
 constexpr int SMALL_KT_MAX = 40;
 constexpr int SMALL_GPT = 4;                                  // groups per thread: 512 x 4 x 8 = 16384 rows
 
-template <typename Tag>
-__global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
+// LONG: the instantiation for rows of 32 KB and more (configs[1]'s 75 008-d place descriptors), where the fp64 re-score is
+// the kernel (1.9 G conversions + fma for 1063 queries: 160 M vector instructions, 0.30 ms of issue alone on 256 CUs) and
+// two waves per SIMD waited on memory for 42 % of their cycles: fewer loads in flight per lane everywhere so that the
+// kernel fits 128 registers and TWO workgroups share a CU.
+template <typename Tag, bool LONG>
+__device__ __forceinline__ void small_topk_body(const SmallArgs& a) {
     __shared__ unsigned long long ckey[(FIN_THREADS / 64) * SMALL_KT_MAX];
     __shared__ long long ck64[SMALL_KT_MAX];
     __shared__ double cs64[SMALL_KT_MAX];
@@ -1268,16 +1272,17 @@ __global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
         if (g < ng_all) {
             f64x4_t a64 = {0., 0., 0., 0.}, b64 = {0., 0., 0., 0.};
             const float* src = a.P + (long long)qi * a.ldp + g * GROUP;
-            for (int c0 = 0; c0 < a.nsplit; c0 += 16) {      // sixteen chunks' loads in flight, summed in chunk order
-                f32x4_t pa[16], pb[16];
+            constexpr int PU = LONG ? 4 : 16;
+            for (int c0 = 0; c0 < a.nsplit; c0 += PU) {      // PU chunks' loads in flight, summed in chunk order
+                f32x4_t pa[PU], pb[PU];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < PU; ++u) {
                     const float* sp = src + (long long)(c0 + u < a.nsplit ? c0 + u : c0) * a.qstride;
                     pa[u] = *(const f32x4_t*)(sp);
                     pb[u] = *(const f32x4_t*)(sp + 4);
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < PU; ++u)
                     if (c0 + u < a.nsplit) {
                         a64 += __builtin_convertvector(pa[u], f64x4_t);
                         b64 += __builtin_convertvector(pb[u], f64x4_t);
@@ -1344,27 +1349,32 @@ __global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
     // once for them (1063 queries x 24 rows of 150 KB: dealt in pairs every wave read the query again, +18 % time).
     const char* qrow = a.Q + (long long)qi * a.ldq_b;
     constexpr int NW = FIN_THREADS / 64;
-    int ci = w;
-    if (a.d >= 16384) {
-        ci = m3;                                               // (nothing left for the dealt form below)
-        for (int s8 = w; s8 * GROUP < m3; s8 += NW) {
-            int ids[GROUP];
-            const char* rows[GROUP];
+    if constexpr (LONG) {
+        // THREE candidates per wave and pass: k + rslack = 24 candidates are one pass of all eight waves, the query read once
+        // per wave.  (Eight per wave -- r04 -- left five of the eight waves idle and each of the three busy ones alternating
+        // between 36 loads in flight and the 2 300 conversions + fma of a batch with nothing in flight: 0.57 ms for configs[1]'s
+        // 1063 queries at an L2 hit rate of 0.44 and 3.8 TB/s over the fabric -- latency, not bytes.  Pairs -- the form
+        // below -- take two passes for 24.)  A candidate's value is rescore8_f64's whatever the dealing: the same pieces
+        // per lane in the same order, the same butterfly.
+        for (int s3 = w; s3 * 3 < m3; s3 += NW) {
+            int ids[3];
+            const char* rows[3];
 #pragma unroll
-            for (int r = 0; r < GROUP; ++r) {
-                ids[r] = __builtin_amdgcn_readfirstlane(s8 * GROUP + r < m3 ? crow[s8 * GROUP + r] : -1);
+            for (int r = 0; r < 3; ++r) {
+                ids[r] = __builtin_amdgcn_readfirstlane(s3 * 3 + r < m3 ? crow[s3 * 3 + r] : -1);
                 rows[r] = a.DB + (long long)(ids[r] < 0 ? 0 : ids[r]) * a.lddb_b;
             }
-            double acc[GROUP];
-            rescore8_f64<Tag, 4>(qrow, rows, a.d, lane, acc);
+            double acc[3];
+            rescore_rows_f64<Tag, 3, 4>(qrow, rows, a.d, lane, acc);
 #pragma unroll
-            for (int r = 0; r < GROUP; ++r)
-                if (lane == r && s8 * GROUP + r < m3) {
-                    cs64[s8 * GROUP + r] = ids[r] < 0 ? -INFINITY : acc[r];
-                    ck64[s8 * GROUP + r] = ids[r] < 0 ? KEY64_EMPTY : f64_key(acc[r]);
+            for (int r = 0; r < 3; ++r)
+                if (lane == r && s3 * 3 + r < m3) {
+                    cs64[s3 * 3 + r] = ids[r] < 0 ? -INFINITY : acc[r];
+                    ck64[s3 * 3 + r] = ids[r] < 0 ? KEY64_EMPTY : f64_key(acc[r]);
                 }
         }
-    }
+    } else {
+    int ci = w;
     for (; ci + NW < m3; ci += 2 * NW) {
         const int id0 = __builtin_amdgcn_readfirstlane(crow[ci]), id1 = __builtin_amdgcn_readfirstlane(crow[ci + NW]);
         const char* const rows[2] = {a.DB + (long long)(id0 < 0 ? 0 : id0) * a.lddb_b,
@@ -1387,6 +1397,7 @@ __global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
             cs64[ci] = id < 0 ? -INFINITY : sc[0];
             ck64[ci] = id < 0 ? KEY64_EMPTY : f64_key(sc[0]);
         }
+    }
     }
     for (int e = tid; e <= SMALL_KT_MAX; e += FIN_THREADS) sel[e] = -1;
     __syncthreads();
@@ -1418,7 +1429,16 @@ __global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
     e.out_s = a.out_s; e.out_s64 = a.out_s64; e.out_i = a.out_i;
     e.status = a.status; e.tau = a.tau; e.tau_scale = a.tau_scale;
     e.limited = a.limited; e.limit0 = a.limit0;
-    exhaustive_topk_body<Tag>(e, kth);
+    exhaustive_topk_body<Tag, LONG ? 1 : 4>(e, kth);
+}
+
+template <typename Tag>
+__global__ __launch_bounds__(FIN_THREADS) void small_topk_kernel(SmallArgs a) {
+    small_topk_body<Tag, false>(a);
+}
+template <typename Tag>
+__global__ __launch_bounds__(FIN_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void small_topk_long_kernel(SmallArgs a) {
+    small_topk_body<Tag, true>(a);
 }
 
 // Global top-k from [parts, q, k] per-shard results (the all-gather layout); idx < 0 = empty slot.
@@ -2063,10 +2083,14 @@ int run_finish(dlc_ctx* ctx, int dtype, const MatchCall& mc, int k, int64_t n, i
         sa.n = n; sa.d = (int)d; sa.k = k; sa.m3max = k + DENSE_ROW_SLACK; sa.row_offset = row_offset;
         sa.out_s = out_scores; sa.out_s64 = s64; sa.out_i = (long long*)out_idx; sa.status = status; sa.tau = mc.w.tau;
         sa.tau_scale = tau_scale; sa.limited = limited; sa.limit0 = limit0;
-        if (dtype == DLC_BF16)
-            hipLaunchKernelGGL(small_topk_kernel<dlc_bf16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, sa);
-        else
-            hipLaunchKernelGGL(small_topk_kernel<dlc_f16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, sa);
+        const bool long_rows = d >= 16384;                      // (rows of 32 KB and more: the re-score IS the kernel there)
+        if (dtype == DLC_BF16) {
+            if (long_rows) hipLaunchKernelGGL(small_topk_long_kernel<dlc_bf16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, sa);
+            else hipLaunchKernelGGL(small_topk_kernel<dlc_bf16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, sa);
+        } else {
+            if (long_rows) hipLaunchKernelGGL(small_topk_long_kernel<dlc_f16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, sa);
+            else hipLaunchKernelGGL(small_topk_kernel<dlc_f16_tag>, dim3((unsigned)q), dim3(FIN_THREADS), 0, st, sa);
+        }
         DLC_LAUNCH_CHECK(ctx, "small_topk_kernel");
     } else if (mc.w.rparts <= 1) {
         f.out_s = out_scores; f.out_s64 = s64; f.out_i = (long long*)out_idx; f.status = status;

@@ -4,6 +4,9 @@ themselves (the bench's `cos_topk_75k` row), a few calls back to back.
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if len(sys.argv) > 3:                      # another build of the library
+    import deeploopcloser_amd._lib as L
+    L.LIB_PATH = os.path.abspath(sys.argv[3])
 import deeploopcloser_amd as dlc
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1063
@@ -23,4 +26,6 @@ for _ in range(calls):
     top = eng.match_topk(rows, rows, 20, details=True)
 e1.record()
 torch.cuda.synchronize()
-print("cosine top-20, %d x %d: %.3f ms per call, %d queries through the exhaustive pass" % (N, rows.shape[1], e0.elapsed_time(e1) / calls, int((top.status == 2).sum())), flush=True)
+import hashlib
+sha = hashlib.sha256(top.idx.cpu().numpy().tobytes() + top.scores_f64.cpu().numpy().tobytes()).hexdigest()[:16]
+print("cosine top-20, %d x %d: %.3f ms per call, %d queries through the exhaustive pass" % (N, rows.shape[1], e0.elapsed_time(e1) / calls, int((top.status == 2).sum())), "digest", sha, flush=True)
