@@ -332,10 +332,12 @@ def bench_paths(eng, n_frames):
     q4 = db4.rows
     nq4 = q4.shape[0]
 
-    def all_patches_top20():
+    QB4 = 4096                                                           # query rows per call: the score pass walks the database
+                                                                         # once per 256 of them, sixteen query blocks sharing
+    def all_patches_top20():                                             # every database tile out of one XCD's L2
         r = None
-        for b0 in range(0, nq4, 256):
-            r = db4.match_topk(q4[b0:b0 + 256], 20)
+        for b0 in range(0, nq4, QB4):
+            r = db4.match_topk(q4[b0:b0 + QB4], 20)
         return r
     m_ms, _, _, _ = _timed_path(eng, all_patches_top20, reps=2, inner=1)
     ws4, bs4 = net4.get_weights()
@@ -352,13 +354,13 @@ def bench_paths(eng, n_frames):
     top4 = db4.match_topk(q4[:nqs], 20)
     tot4 = e_ms + m_ms
     r4 = _mfma_f64_roofline(eflops, ek_ms, ek_n, tot4, "dominant stage: the encoder's five fp64 GEMMs (gemm_dma_f64_kernel); "
-                            "the match is score_gemm_kernel + finish per batch of 256 patch queries")
+                            "the match is score_gemm_kernel + finish_topk_kernel per call of 4096 patch queries")
     out.append({"path": "SDAV 4096-wide variant (non-reference): encode + cosine top-20 of all patch descriptors",
                 "reference": "NOT the reference's network (SDAV.py:31-32 fixes 5 x 2500): SURVEY 8d config 2's optional "
                 "hidden_units[-1] = 4096 variant, north_star's 4096-d descriptors", "frames": N, "dtype": "f64 encode, bf16 cosine",
                 "dim": W4, "k": 20, "value": N / (tot4 * 1e-3), "unit": "frames/s", "ms": tot4,
-                "stage_ms": {"SDAV.transform (last layer 4096 wide)": e_ms, "cosine top-20, %d x %d patch descriptors in batches of "
-                             "256" % (nq4, nq4): m_ms},
+                "stage_ms": {"SDAV.transform (last layer 4096 wide)": e_ms, "cosine top-20, %d x %d patch descriptors, %d queries per call"
+                             % (nq4, nq4, QB4): m_ms},
                 "patch_queries_per_s": nq4 / (m_ms * 1e-3), "roofline": r4,
                 "cpu_baseline": {"value": 1.0 / (t_cpu4 / nb4 + (t_cos4 / nqs) * P), "unit": "frames/s", "cores": cores, "kind": "port",
                                  "sample": "oracle/sdav.py on the first %d frames (%.2f s) + oracle/cosine.py top-20 of the first %d "
@@ -559,6 +561,21 @@ def bench_paths(eng, n_frames):
     score_s = eng.distinctive_score(desc, 0.5, 0.2)
     ss_ms, _, _, (sdet, sds, sdi) = _timed_path(eng, sdav_stream, reps=2)
 
+    def sdav_stream_piped():                                      # two batches in flight (submit / result, one ticket behind): a
+        det_ = dlc.SdavLoopClosureDetector(score_s, patches=P, width=H, k=sk, exclusion=sex, capacity=N)   # batch's small kernels
+        outs_, prev_ = [], None                                   # run beside its neighbours' product kernels on a second stream
+        for lo in range(0, N, sb):
+            t_ = det_.submit(desc[lo:lo + sb])
+            if prev_ is not None:
+                outs_.append(det_.result(prev_))
+            prev_ = t_
+        outs_.append(det_.result(prev_))
+        return torch.cat([o[0] for o in outs_]), torch.cat([o[1] for o in outs_])
+    sp_ms, _, _, (sps, spi) = _timed_path(eng, sdav_stream_piped, reps=2)
+    piped_same = bool(torch.equal(spi, sdi) and torch.equal(torch.nan_to_num(sps, posinf=1e300, neginf=-1e300),
+                                                            torch.nan_to_num(sds, posinf=1e300, neginf=-1e300)))
+    del sps, spi
+
     def sdav_stream_single():                                     # one frame at a time: the single-query kernels
         det_ = dlc.SdavLoopClosureDetector(score_s, patches=P, width=H, k=sk, exclusion=sex, capacity=N)
         outs_ = [det_.query_and_insert(desc[lo:lo + 1]) for lo in range(N)]
@@ -600,8 +617,23 @@ def bench_paths(eng, n_frames):
                                            "frames (%d pairs): %.2f s" % (nsm, nsm * (nsm - 1) // 2, t_cpu)},
                 "ranking_equals_matrix_columns": agree == checked, "frames_checked": checked,
                 "stream_poisoned": int(sdet.stream.stats[1]),
+                "two_batches_in_flight": {"ms": sp_ms, "frames_per_s": N / (sp_ms * 1e-3), "frac": i8_ops / (sp_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                                          "same_lists_as_batch_by_batch": piped_same,
+                                          "what": "SdavLoopClosureDetector.submit / result: copy + quantisation of batch b beside "
+                                                  "batch b - 1's product kernel, resolution + scores + ranking of b - 1 beside b's"},
                 "one_frame_at_a_time": {"ms": ss1_ms, "us_per_frame": ss1_ms * 1e3 / N, "frames_per_s": N / (ss1_ms * 1e-3),
                                         "same_lists_as_batched": bool(torch.equal(sdi1, sdi))}})
+    # ... and with two batches in flight, a row of its own (the same work, the same lists)
+    out.append({"path": "SdavLoopClosureDetector.submit / result (batches of %d frames, two in flight)" % sb,
+                "reference": out[-1]["reference"], "frames": N, "dtype": "f64", "k": sk,
+                "value": (N * (N - 1) / 2.0) / (sp_ms * 1e-3), "unit": "frame-pairs/s", "ms": sp_ms, "frames_per_s": N / (sp_ms * 1e-3),
+                "roofline": {"bound": "mfma", "achieved": i8_ops / (sp_ms * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                             "frac": i8_ops / (sp_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, "traffic": None,
+                             "kernel": "gram_i8_kernel on the strips, alone on the engine's second stream; a batch's copy + quantisation "
+                                       "and its neighbour's strip_resolve_kernel + stream_score_kernel + topk_rows_f64_kernel beside it "
+                                       "on the caller's stream", "kernel_ms": sp_ms, "call_ms": sp_ms, "algorithmic_ops_per_call": i8_ops},
+                "cpu_baseline": out[-1]["cpu_baseline"], "same_lists_as_batch_by_batch": piped_same,
+                "batch_by_batch_ms": ss_ms})
     del sdet, sds, sdi, sdi1, mcol, dsm
 
     # ---- M1/M2 on real-image statistics: the repo's 20 real frames (tests/golden) tiled to N, through the GPU front-end and
@@ -1111,7 +1143,7 @@ DETAIL_FILE = "bench_detail.json"
 _PATH_IDS = [                # (substring of a `paths` row's name, its key in the line's paths_summary), first match wins
     ("4096-wide", "sdav4096_encode_cos"),
     ("f16x2 split", "sdav_encode_f16x2"), ("SDAV.transform", "sdav_encode_f64"), ("train_step", "sdav_train_step"),
-    ("patch front-end", "frontend"), ("SdavLoopClosureDetector", "stream_sdav"), ("LoopClosureDetector", "stream_cosine"),
+    ("patch front-end", "frontend"), ("SdavLoopClosureDetector.submit", "stream_sdav_piped"), ("SdavLoopClosureDetector", "stream_sdav"), ("LoopClosureDetector", "stream_cosine"),
     ("real-frame statistics, N(0,1)", "sdav_sim_real_n01"), ("real-frame statistics, 1/sqrt", "sdav_sim_real_fanin"),
     ("SDAV similarity matrix", "sdav_sim"), ("cosine similarity matrix", "cos_matrix_75k"), ("cosine top-", "cos_topk_75k"),
     ("CnnVtl.transform", "cnnvtl_encode"), ("cnn_vtl distance matrix", "cnnvtl_dist"),

@@ -16,7 +16,7 @@ DLC_BF16, DLC_F16, DLC_F32, DLC_F64, DLC_I8 = 0, 1, 2, 3, 4
 DLC_ACT_NONE, DLC_ACT_SIGMOID, DLC_ACT_RELU = 0, 1, 2
 DLC_B_KN, DLC_B_NK = 0, 1
 DLC_MAX_K = 128
-DLC_ABI_VERSION = 8          # include/dlc.h; load() refuses a library built from another header
+DLC_ABI_VERSION = 9          # include/dlc.h; load() refuses a library built from another header
 DLC_SELECT_COOP = 1
 DLC_SIM_FORCE_F64, DLC_SIM_NO_HOST_SYNC = 1, 2
 
@@ -69,6 +69,8 @@ SIGNATURES = {
     "dlc_sdav_stream_query_batch_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dlc_sdav_stream_query_batch": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _dbl, _dbl, _vp, _i64, _vp,
                                            _vp, _sz, _vp]),
+    "dlc_sdav_stream_query_batch_staged": (_int, [_vp, _vp, _sz, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _dbl, _dbl, _vp, _i64,
+                                                  _vp, _vp, _sz, _int, _vp]),
     "dlc_cnnvtl_distance_matrix": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dlc_l2_normalize_rows": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _int, _int, _vp, _i64, _vp]),
     "dlc_cosine_topk_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),

@@ -63,7 +63,7 @@ size_t sim_stream_panel_bytes(int64_t rows, int64_t H);
 int64_t gram_strip_frames(int64_t f_first, int64_t f_last, int64_t P);
 int gram_argmin_i8_strip(dlc_ctx* ctx, int64_t f_first, int64_t f_last, int64_t P, int64_t H, const char* X, int64_t zrow,
                          const int* nbp, const unsigned long long* keys, unsigned char* abi, unsigned* acand, int64_t rp,
-                         int64_t* fj_base_out, hipStream_t st);
+                         int64_t* fj_base_out, hipStream_t st, bool launch = true);
 int gram_argmin_i8(dlc_ctx* ctx, int64_t N, int64_t P, int64_t H, const char* X, const int* nbp,
                    const unsigned long long* keys, unsigned char* abi, unsigned* acand, void* blocks, hipStream_t st);
 size_t gram_blocks_bytes(int64_t N, int64_t P);

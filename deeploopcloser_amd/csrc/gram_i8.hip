@@ -875,7 +875,7 @@ int64_t gram_strip_frames(int64_t f_first, int64_t f_last, int64_t P) {
 // row patch a) is row fj - *fj_base_out.  Written: f_first <= fj <= f_last (and the other frames of their tiles), a < fj P.
 int gram_argmin_i8_strip(dlc_ctx* ctx, int64_t f_first, int64_t f_last, int64_t P, int64_t H, const char* X, int64_t zrow,
                          const int* nbp, const unsigned long long* keys, unsigned char* abi, unsigned* acand, int64_t rp,
-                         int64_t* fj_base_out, hipStream_t st) {
+                         int64_t* fj_base_out, hipStream_t st, bool launch) {
     const int kp = (int)dlc::align_up((size_t)H, (size_t)GI_KPAD);
     const int64_t N = f_last + 1;
     GramI8Args a;
@@ -888,7 +888,7 @@ int gram_argmin_i8_strip(dlc_ctx* ctx, int64_t f_first, int64_t f_last, int64_t 
     const int sj_lo = a.tn_lo / GI_BC, sj_hi = a.tn_hi / GI_BC;
     a.fj_base = (int64_t)sj_lo * GI_BC * 2 * a.fpu;
     *fj_base_out = a.fj_base;
-    if (a.tiles_m < 1) return DLC_OK;
+    if (a.tiles_m < 1 || !launch) return DLC_OK;                          // (!launch: the caller only wants the strip's base)
     a.nsm = (a.tiles_m + GI_BR - 1) / GI_BR;
     a.nsn = (a.tiles_n + GI_BC - 1) / GI_BC;
     a.nsup = a.nsm * (sj_hi - sj_lo + 1);

@@ -1645,7 +1645,7 @@ static BatchWs batch_ws(int64_t capacity, int64_t P, int64_t nq) {
 static int stream_query_impl(dlc_ctx* ctx, const char* what, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
                              const double* desc, int64_t f, int64_t nq, const double* score, double a, double b, double* rows_out,
                              int64_t ld_rows, int64_t* stats, unsigned char* bi, int64_t bi_pitch, void* stream,
-                             char* batch_base = nullptr, const BatchWs* bw = nullptr) {
+                             char* batch_base = nullptr, const BatchWs* bw = nullptr, int stage = 0) {
     hipStream_t st = (hipStream_t)stream;
     const StreamWs w = stream_ws(capacity, P, H);
     char* ws = (char*)state;
@@ -1665,9 +1665,11 @@ static int stream_query_impl(dlc_ctx* ctx, const char* what, void* state, size_t
         unsigned char* abi = (unsigned char*)(batch_base + bw->abi);
         unsigned* acand = (unsigned*)(batch_base + bw->acand);
         int64_t fj_base = 0;
+        // (stage 2 -- the products were launched by an earlier stage-1 call on the same workspace: only the strip's base)
         int rc = dlc_gemm::gram_argmin_i8_strip(ctx, f, f_last, P, H, (const char*)(ws + w.panel), w.zrow, (const int*)(ws + w.nbp), keys,
-                                                abi, acand, bw->pitch, &fj_base, st);
+                                                abi, acand, bw->pitch, &fj_base, st, /*launch=*/stage != 2);
         if (rc != DLC_OK) return rc;
+        if (stage == 1) return DLC_OK;
         hipLaunchKernelGGL(strip_resolve_kernel, dim3((unsigned)dlc::cdiv(f_last * P, (int64_t)256), (unsigned)nq), dim3(256), PF_STACK_BYTES,
                            st, desc, (const unsigned char*)abi, (const unsigned*)acand, (long long)bw->pitch, (long long)fj_base,
                            (const unsigned long long*)(ws + w.rowhash), keys, (long long)f, (int)P, (int)H, (const int2*)(ws + w.prog), bi,
@@ -1735,6 +1737,32 @@ extern "C" int dlc_sdav_stream_query_batch(dlc_ctx* ctx, void* state, size_t sta
     const BatchWs bw = batch_ws(capacity, P, n_queries);
     return stream_query_impl(ctx, "stream_score_kernel", state, state_bytes, capacity, P, H, desc, f_first, n_queries, score, a, b, rows_out,
                              ld_rows, stats, (unsigned char*)workspace + bw.bi, bw.pitch, stream, (char*)workspace, &bw);
+}
+
+extern "C" int dlc_sdav_stream_query_batch_staged(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                                                  const double* desc, int64_t f_first, int64_t n_queries, const double* score, double a,
+                                                  double b, double* rows_out, int64_t ld_rows, int64_t* stats, void* workspace,
+                                                  size_t workspace_bytes, int stage, void* stream) {
+    int rc = stream_check(ctx, "sdav_stream_query_batch_staged", state, state_bytes, capacity, P, H);
+    if (rc != DLC_OK) return rc;
+    if (stage != 1 && stage != 2) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_query_batch_staged: stage must be 1 or 2");
+    if (!desc || !score || !rows_out || f_first < 0 || n_queries < 1 || n_queries > 65535 || f_first + n_queries > capacity ||
+        ld_rows < f_first + n_queries - 1)
+        return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_query_batch_staged: bad argument (frames [%lld, %lld) of capacity %lld, ld_rows %lld)",
+                         (long long)f_first, (long long)(f_first + n_queries), (long long)capacity, (long long)ld_rows);
+    if (n_queries < STRIP_MIN_QUERIES || !dlc_gemm::sim_filter_fits(capacity, P, H))
+        return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "sdav_stream_query_batch_staged: only the strip form (batches of %lld frames and more) "
+                         "has two stages", (long long)STRIP_MIN_QUERIES);
+    const size_t need = dlc_sdav_stream_query_batch_workspace_bytes(capacity, P, n_queries);
+    if (!workspace || workspace_bytes < need)
+        return dlc::fail(ctx, DLC_ERR_WORKSPACE, "sdav_stream_query_batch_staged: workspace %zu < %zu bytes", workspace_bytes, need);
+    dlc::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+    if ((uintptr_t)workspace & 255) return dlc::fail(ctx, DLC_ERR_BAD_ARG, "sdav_stream_query_batch_staged: workspace must be 256-byte aligned");
+    if (f_first + n_queries - 1 == 0) return DLC_OK;              // (frame 0 alone cannot be a strip; kept for symmetry)
+    const BatchWs bw = batch_ws(capacity, P, n_queries);
+    return stream_query_impl(ctx, "stream_score_kernel", state, state_bytes, capacity, P, H, desc, f_first, n_queries, score, a, b, rows_out,
+                             ld_rows, stats, (unsigned char*)workspace + bw.bi, bw.pitch, stream, (char*)workspace, &bw, stage);
 }
 
 extern "C" int dlc_topk_rows_f64(dlc_ctx* ctx, const double* scores, int64_t rows, int64_t ld, int64_t limit0, int64_t limit_step,

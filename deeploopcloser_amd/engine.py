@@ -684,6 +684,23 @@ class Engine:
                                                           _ptr(stats), _ptr(ws), ws.numel(), self._stream()))
         return out
 
+    def sdav_stream_query_batch_staged(self, state, desc, f_first, n_queries, score, stage, out, ws, a=10.0, b=-10.0, stats=None,
+                                       stream=None):
+        """One half of the strip form of sdav_stream_query_batch (include/dlc.h): stage 1 = the product kernel into the
+        caller's workspace ws, stage 2 = resolution + scores into out [n_queries, ld] -- for callers that run a batch's
+        stage 2 beside the next batch's stage 1 (loop_closure.SdavLoopClosureDetector.submit).  stream: a torch stream
+        (default: the current one)."""
+        cap, p, h = desc.shape
+        self._check_out("out", out, (int(n_queries), out.shape[1]), torch.float64)
+        if stats is not None:
+            self._check_out("stats", stats, (2,), torch.int64)
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self._stream()
+        self._check(self.lib.dlc_sdav_stream_query_batch_staged(self.ctx, _ptr(state), state.numel(), cap, p, h, _ptr(desc),
+                                                                 int(f_first), int(n_queries), _ptr(score), float(a), float(b),
+                                                                 _ptr(out), out.shape[1], _ptr(stats), _ptr(ws), ws.numel(),
+                                                                 int(stage), st))
+        return out
+
     def topk_rows_f64(self, scores, limit0, limit_step, k, poison=None):
         """(scores [rows, k] fp64, idx [rows, k] int64) of the k best of the first limit0 + r * limit_step entries of row r of
         scores [rows, ld] (fp64): score descending, ties -> the lower index, NaN never; (-inf, -1) where fewer.

@@ -153,6 +153,80 @@ class SdavLoopClosureDetector:
         # the older frame; the kernel reads the stream's poison word and answers (NaN, -1) everywhere when it is set)
         return eng.topk_rows_f64(rows, first - self.exclusion, 1, self.k, poison=self.poisoned)
 
+    # ---- two batches in flight ------------------------------------------------------------------------------------------
+    # query_and_insert runs a batch's six launches one behind the other: copy, quantisation, the strip's product kernel (200
+    # of the 275 us at 32 frames against 1063), resolution, scores, ranking.  Only the product kernel needs the whole chip.
+    # submit() / result() give it the engine's second stream to itself and keep the rest on the caller's: batch b's copy +
+    # quantisation run beside batch b - 1's products, batch b - 1's resolution + scores + ranking beside batch b's (what
+    # may run beside what: include/dlc.h, dlc_sdav_stream_query_batch_staged).  Everything the caller touches -- the frames
+    # going in, the lists coming out -- lives on the caller's stream; the second stream only ever carries product kernels.
+    # The lists are the lists query_and_insert returns, bit for bit.
+    PIPELINE_MIN_BATCH = 8                                            # below it there is no strip (include/dlc.h)
+
+    def submit(self, frames):
+        """frames [B, P, H] -> ticket.  The frames become resident; result(ticket) hands out (scores [B, k], ids [B, k]) --
+        to be fetched before the second submit() after this one (a slot's buffers are reused then).  Batches of fewer than
+        8 frames, the very first batch and a batch that makes the stream grow go through query_and_insert (no overlap)."""
+        st, eng = self.stream, self.stream.engine
+        x = eng.to_device(frames, torch.float64)
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        b, first = x.shape[0], len(st)
+        if not hasattr(self, "_slots"):
+            self._slots, self._pending, self._tickets = [{}, {}], None, 0
+        t = self._tickets
+        self._tickets += 1
+        main, side = torch.cuda.current_stream(eng.device), eng.side_stream
+        slot = self._slots[t % 2]
+        if b < self.PIPELINE_MIN_BATCH or first == 0 or first + b > st.capacity or x.dim() != 3:
+            self._flush()                                              # (a growing stream re-quantises everything: nothing in flight)
+            main.wait_stream(side)
+            slot.update({"ticket": t, "out": self.query_and_insert(x)})
+            return t
+        need = eng.lib.dlc_sdav_stream_query_batch_workspace_bytes(st.capacity, st.p, b)
+        if slot.get("ws") is None or slot["ws"].numel() < need:
+            slot["ws"] = torch.empty(int(need), dtype=torch.uint8, device=eng.device)
+        if slot.get("rows") is None or slot["rows"].shape[0] < b or slot["rows"].shape[1] < st.capacity:
+            slot["rows"] = torch.empty((b, st.capacity), dtype=torch.float64, device=eng.device)
+        st.append(x)                                                   # copy + quantisation: beside the previous batch's products
+        quantised = torch.cuda.Event()
+        quantised.record(main)                                         # (also behind the last use of this slot's buffers, two tickets ago)
+        side.wait_event(quantised)
+        rows = slot["rows"][:b]
+        eng.sdav_stream_query_batch_staged(st.state, st.desc, first, b, st.score, 1, rows, slot["ws"], st.a, st.b, stats=st.stats,
+                                           stream=side)
+        products = torch.cuda.Event()
+        products.record(side)
+        self._flush()                                                  # the previous batch's second half: beside this batch's products
+        slot.update({"ticket": t, "first": first, "b": b, "products": products, "out": None})
+        self._pending = t
+        return t
+
+    def _flush(self):
+        """The second half of the batch whose products are in flight -- resolution + scores + ranking, on the caller's stream
+        behind that batch's product kernel."""
+        if getattr(self, "_pending", None) is None:
+            return
+        st, eng = self.stream, self.stream.engine
+        slot = self._slots[self._pending % 2]
+        torch.cuda.current_stream(eng.device).wait_event(slot["products"])
+        rows = slot["rows"][:slot["b"]]
+        eng.sdav_stream_query_batch_staged(st.state, st.desc, slot["first"], slot["b"], st.score, 2, rows, slot["ws"], st.a, st.b,
+                                           stats=st.stats)
+        slot["out"] = eng.topk_rows_f64(rows, slot["first"] - self.exclusion, 1, self.k, poison=self.poisoned)
+        self._pending = None
+
+    def result(self, ticket):
+        """(scores [B, k] float64, ids [B, k] int64) of a submitted batch, in the current stream's order."""
+        if not hasattr(self, "_slots") or not self._tickets - 2 <= ticket < self._tickets:
+            raise ValueError("SdavLoopClosureDetector.result: ticket %r is not in flight" % (ticket,))
+        if self._pending == ticket:
+            self._flush()
+        slot = self._slots[ticket % 2]
+        if slot.get("ticket") != ticket or slot.get("out") is None:
+            raise ValueError("SdavLoopClosureDetector.result: ticket %r is not in flight" % (ticket,))
+        return slot["out"]
+
     @property
     def poisoned(self):
         """Device int64 [1] (a view of SimilarityStream.stats): non-zero once a descriptor value outside the stream's fixed

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DLC_ABI_VERSION 8
+#define DLC_ABI_VERSION 9
 
 typedef struct dlc_ctx dlc_ctx;
 
@@ -384,6 +384,23 @@ int dlc_sdav_stream_query_batch(dlc_ctx* ctx, void* state, size_t state_bytes, i
                                 const double* desc, int64_t f_first, int64_t n_queries, const double* score, double a,
                                 double b, double* rows_out, int64_t ld_rows, int64_t* stats, void* workspace,
                                 size_t workspace_bytes, void* stream);
+/*
+ * The strip form of dlc_sdav_stream_query_batch (n_queries >= 8) in its two halves, for callers that overlap batches on
+ * two streams (create_similarity_matrix.py:34-38, one arriving batch behind the other):
+ *   stage 1  the int8 product kernel of the strip (columns: the batch's frames; rows: every older patch of the panel) into
+ *            the workspace's verdict arrays -- on the stream the NEXT batch's stage 1 will follow on;
+ *   stage 2  resolution of the undecided cells + the scores into rows_out -- behind stage 1 of the SAME (f_first, n_queries,
+ *            workspace), on any stream ordered behind it; the batch's dlc_topk_rows_f64 follows it there.
+ * Stage 1 + stage 2 write exactly what the one call writes.  What may run BESIDE what: dlc_sdav_stream_append of the next
+ * batch beside this batch's stage 1 (it rewrites the panel group the two batches share with the same bytes, and only adds
+ * rows whose verdicts this strip never reads; the error bound it may raise only sends more cells to the direct evaluation:
+ * the rows do not change, stats[0] can), and this batch's stage 2 beside the next batch's stage 1 given a workspace of its
+ * own per batch in flight.  DLC_ERR_UNSUPPORTED for fewer than 8 frames (no strip: use the one call).
+ */
+int dlc_sdav_stream_query_batch_staged(dlc_ctx* ctx, void* state, size_t state_bytes, int64_t capacity, int64_t P, int64_t H,
+                                       const double* desc, int64_t f_first, int64_t n_queries, const double* score, double a,
+                                       double b, double* rows_out, int64_t ld_rows, int64_t* stats, void* workspace,
+                                       size_t workspace_bytes, int stage, void* stream);
 /*
  * The k best entries of every row of an fp64 score matrix scores [rows, ld] -- the loop-closure candidates of a batch of
  * streamed frames (rows of dlc_sdav_stream_query): row r offers its first min(ld, limit0 + r * limit_step) entries (none

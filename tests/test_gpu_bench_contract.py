@@ -96,6 +96,7 @@ def test_bench_json_contract():
                           "patch front-end (grey + Harris + 30 patches of 41x41)",
                           "LoopClosureDetector.query_and_insert (batches of 32 frames)",
                           "SdavLoopClosureDetector.query_and_insert (batches of 32 frames)",
+                          "SdavLoopClosureDetector.submit / result (batches of 32 frames, two in flight)",
                           "cosine similarity matrix (flattened SDAV descriptors)",
                           "cosine top-20 (flattened SDAV descriptors)", "CnnVtl.transform", "cnn_vtl distance matrix",
                           "configs[1] end to end: 24 frames -> patches -> SDAV -> similarity matrix, fp64 encoder (parity mode)",
@@ -128,6 +129,7 @@ def test_bench_json_contract():
     assert paths["patch front-end (grey + Harris + 30 patches of 41x41)"]["bit_exact_vs_oracle"] is True
     assert paths["LoopClosureDetector.query_and_insert (batches of 32 frames)"]["index_agreement_vs_oracle"] > 0.999
     assert paths["SdavLoopClosureDetector.query_and_insert (batches of 32 frames)"]["stream_poisoned"] == 0
+    assert paths["SdavLoopClosureDetector.submit / result (batches of 32 frames, two in flight)"]["same_lists_as_batch_by_batch"] is True
     for p in d["paths"]:
         pr, pc = p["roofline"], p["cpu_baseline"]
         assert p["frames"] == (10 if "train_step" in p["path"] else 20 if p["path"].startswith("configs[0]") else 24)

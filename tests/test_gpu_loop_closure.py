@@ -397,3 +397,59 @@ def test_batched_stream_query_as_a_strip_of_the_matrix_call():
                 got, col = rows[q, :f], w2[:f, f]
                 assert torch.equal(got.isinf(), col.isinf()), (p2, first, count, q)
                 assert torch.equal(torch.nan_to_num(got, posinf=1e300), torch.nan_to_num(col, posinf=1e300)), (p2, first, count, q)
+
+
+def test_detector_two_batches_in_flight_equals_batch_by_batch():
+    """SdavLoopClosureDetector.submit / result: a batch's copy + quantisation beside the previous batch's product kernel, its
+    resolution + scores + ranking beside the next batch's (two streams, dlc_sdav_stream_query_batch_staged) -- the lists are
+    query_and_insert's bit for bit, for batch sizes on both sides of the strip's threshold, a stream that grows under the
+    pipeline, copies of frames (ties, +inf scores), results fetched late (one ticket behind) and at once."""
+    import deeploopcloser_amd as dlc
+    eng = dlc.default_engine()
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(31)
+    n, p, h = 150, 30, 300
+    ds = torch.sigmoid(4.0 * torch.randn((n, p, h), generator=g, device=eng.device, dtype=torch.float64))
+    ds[40] = ds[7]
+    ds[41, 3] = ds[8, 11]
+    ds[120] = ds[119]
+    for sizes, late in (((32, 32, 32, 32, 22), True), ((9, 3, 40, 8, 1, 16, 33, 40), True), ((16, 16, 64, 54), False)):
+        plain = dlc.SdavLoopClosureDetector(ds, patches=p, width=h, k=4, exclusion=2, capacity=48)
+        piped = dlc.SdavLoopClosureDetector(ds, patches=p, width=h, k=4, exclusion=2, capacity=48)
+        want, got, f, prev = [], [], 0, None
+        for b in sizes:
+            chunk = ds[f:f + b]
+            want.append(plain.query_and_insert(chunk))
+            t = piped.submit(chunk)
+            if late:
+                if prev is not None:
+                    got.append(piped.result(prev))
+                prev = t
+            else:
+                got.append(piped.result(t))
+            f += b
+        if late:
+            got.append(piped.result(prev))
+        assert f == n and len(piped) == n
+        ws, wi = torch.cat([w[0] for w in want]), torch.cat([w[1] for w in want])
+        gs, gi = torch.cat([o[0] for o in got]), torch.cat([o[1] for o in got])
+        torch.cuda.synchronize()
+        assert torch.equal(wi, gi), sizes
+        assert torch.equal(torch.nan_to_num(ws, posinf=1e300, neginf=-1e300), torch.nan_to_num(gs, posinf=1e300, neginf=-1e300)), sizes
+        assert int(gi[40, 0]) == 7 and bool(torch.isinf(gs[40, 0]))
+        assert int(piped.stream.stats[1]) == 0
+    with pytest.raises(ValueError):
+        piped.result(0)                                               # long gone
+    # the two halves of the strip form through the engine: stage 1 + stage 2 == the one call
+    st = piped.stream
+    first, b = 100, 32
+    need = eng.lib.dlc_sdav_stream_query_batch_workspace_bytes(st.capacity, st.p, b)
+    ws_ = torch.empty(int(need), dtype=torch.uint8, device=eng.device)
+    rows = torch.zeros((b, st.capacity), dtype=torch.float64, device=eng.device)
+    eng.sdav_stream_query_batch_staged(st.state, st.desc, first, b, st.score, 1, rows, ws_, st.a, st.b)
+    eng.sdav_stream_query_batch_staged(st.state, st.desc, first, b, st.score, 2, rows, ws_, st.a, st.b)
+    one = st.query_batch(first, b)
+    for q in range(b):
+        assert torch.equal(torch.nan_to_num(rows[q, :first + q], posinf=1e300), torch.nan_to_num(one[q, :first + q], posinf=1e300))
+    with pytest.raises(Exception):
+        eng.sdav_stream_query_batch_staged(st.state, st.desc, first, 4, st.score, 1, rows[:4], ws_, st.a, st.b)   # no strip below 8
