@@ -531,3 +531,38 @@ def test_gemm_dma_every_element_repeated(dlc):
         got = eng.gemm_bias_act(p[:12800], p, None, act=L.DLC_ACT_NONE, blayout=L.DLC_B_NK)
         assert float((got - p[:12800] @ p.T).abs().max()) < 1e-10, rep
         del p, got
+
+
+@pytest.mark.parametrize("batch", [32, 50])
+def test_streaming_detector_kennedylong_two_batches_in_flight(dlc, descriptors, batch):
+    """configs[1]'s 1063 frames arriving in batches, with the REFERENCE's similarity (create_similarity_matrix.py:34-38 as a
+    robot runs it): SdavLoopClosureDetector.submit / result (the strip's product kernel alone on the second stream, the
+    small kernels of the neighbouring batches beside it) returns the lists of query_and_insert bit for bit, and both equal
+    a stable ranking of the all-vs-all call's columns on sampled frames."""
+    net, x, h = descriptors
+    eng = dlc.default_engine()
+    desc = h.reshape(N_FRAMES, 30, 2500)
+    score = eng.distinctive_score(desc, 0.5, 0.2)
+    k, excl = 5, 30
+    plain = dlc.SdavLoopClosureDetector(score, patches=30, width=2500, k=k, exclusion=excl, capacity=N_FRAMES)
+    piped = dlc.SdavLoopClosureDetector(score, patches=30, width=2500, k=k, exclusion=excl, capacity=N_FRAMES)
+    want, got, prev = [], [], None
+    for lo in range(0, N_FRAMES, batch):
+        want.append(plain.query_and_insert(desc[lo:lo + batch]))
+        t = piped.submit(desc[lo:lo + batch])
+        if prev is not None:
+            got.append(piped.result(prev))
+        prev = t
+    got.append(piped.result(prev))
+    ws, wi = torch.cat([w[0] for w in want]), torch.cat([w[1] for w in want])
+    gs, gi = torch.cat([o[0] for o in got]), torch.cat([o[1] for o in got])
+    torch.cuda.synchronize()
+    assert torch.equal(wi, gi)
+    assert torch.equal(torch.nan_to_num(ws, posinf=1e300, neginf=-1e300), torch.nan_to_num(gs, posinf=1e300, neginf=-1e300))
+    assert int(piped.stream.stats[1]) == 0 and len(piped) == N_FRAMES
+    col = eng.sdav_similarity_matrix(desc, score, 10.0, -10.0, want_int64=False)[0].cpu().numpy()
+    gi_h = gi.cpu().numpy()
+    for f in range(excl + 1, N_FRAMES, 37):
+        c = col[:f - excl, f]
+        order = np.lexsort((np.arange(len(c)), -c))[:k]
+        assert np.array_equal(gi_h[f, :len(order)], order), f
