@@ -435,6 +435,40 @@ int launch_kernel(dlc_ctx* ctx, const Args<T>& a, long long nwg, hipStream_t st)
     return DLC_OK;
 }
 
+// Few 64-row tiles and a long K (the training step's 300-row products, an encode of a few frames in latency mode): split-K
+// on the LDS-DMA kernel -- its K loop is the faster one, and 300 rows pad to 320 there instead of 384 -- then ONE reducing
+// pass that sums the chunks in chunk order and applies bias + activation.  A 64-row workgroup keeps a CU's fp64 matrix
+// pipes busy on its own, so a launch costs about (its MFMA work) / (the CUs it reaches): the chunk count is the one that
+// fills the 512 slots (two such workgroups per CU) once.  Needs the context's scratch (latency mode; the training step
+// lends it).  K: the reduction length as A has it (even), Kb <= K as B has it.  DLC_OK, 1 = not taken, < 0 = error.
+static int dma_splitk_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, int64_t Kb, const double* A,
+                          int64_t lda, const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st) {
+    if (!ctx->scratch || N <= 96) return 1;
+    const int64_t tiles = dlc::cdiv(M, (int64_t)64) * dlc::cdiv(N, (int64_t)128), nkt = dlc::cdiv(K, (int64_t)16);
+    if (tiles >= 256) return 1;
+    const int64_t fit = (int64_t)(ctx->scratch_bytes / ((size_t)M * (size_t)N * sizeof(double)));
+    const int64_t want = std::min<int64_t>(std::min<int64_t>(512 / tiles, nkt / 8), std::min<int64_t>(fit, 64));
+    if (want < 2) return 1;
+    const int64_t kchunk = dlc::cdiv(nkt, want) * 16, chunks = dlc::cdiv(K, kchunk);
+    if (chunks < 2) return 1;
+    double* part = (double*)ctx->scratch;
+    if (gemm_dma_f64_splitk(ctx, blayout, M, N, K, Kb, A, lda, B, ldb, part, kchunk, st, true) != DLC_OK) return 1;
+    const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
+    if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
+    const int rc = gemm_dma_f64_splitk(ctx, blayout, M, N, K, Kb, A, lda, B, ldb, part, kchunk, st, false);
+    if (rc != DLC_OK) return rc < 0 ? rc : dlc::fail(ctx, DLC_ERR_HIP, "gemm: the split-K launch was refused after its dry run");
+    if (ctx->profiling) {
+        DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_stop[prof_slot], st));
+        ctx->prof_calls++;
+    }
+    long long blocks = dlc::cdiv(M * N, (int64_t)256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(splitk_bias_act_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (const double*)part, (int)chunks, bias, C,
+                       (long long)ldc, (long long)M, (long long)N, act);
+    DLC_LAUNCH_CHECK(ctx, "splitk_bias_act_kernel");
+    return DLC_OK;
+}
+
 template <typename T>
 int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
            const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st,
@@ -448,6 +482,13 @@ int launch(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, 
     a.tri_col0 = tri ? tri->col0 : 0;
     a.tiles_m = dlc::cdiv(M, TM);
     a.tiles_n = dlc::cdiv(N, TN);
+    if constexpr (sizeof(T) == 8) {
+        if (!cv && !tri) {
+            const int rc_sk = dma_splitk_f64(ctx, blayout, act, M, N, K, K, (const double*)A, lda, (const double*)B, ldb,
+                                             (const double*)bias, (double*)C, ldc, st);
+            if (rc_sk <= 0) return rc_sk;
+        }
+    }
     const int chunks = plan_split<T>(ctx, M, N, K, &a.kchunk);
     if constexpr (sizeof(T) == 8) {
         // large aligned fp64 launches: the LDS-DMA kernel (gemm_dma_f64.hip); anything else stays here
@@ -530,6 +571,8 @@ int gram_upper_f64(dlc_ctx* ctx, int blayout, int64_t M, int64_t N, int64_t K, c
 
 int gemm_bias_act_padded_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, int64_t Kpad, const double* A,
                              const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st) {
+    const int rc_sk = dma_splitk_f64(ctx, DLC_B_KN, act, M, N, Kpad, K, A, Kpad, B, ldb, bias, C, ldc, st);
+    if (rc_sk <= 0) return rc_sk;
     const int rc = launch_dma_f64(ctx, DLC_B_KN, act, M, N, Kpad, A, Kpad, B, ldb, bias, C, ldc, st, nullptr, nullptr, K);
     if (rc <= 0) return rc;
     return launch<double>(ctx, DLC_B_KN, act, M, N, K, A, Kpad, B, ldb, bias, C, ldc, st);

@@ -49,6 +49,9 @@ struct DmaArgs {
     long long m_base;                           // CONV: output pixel index of row 0 (a launch over the tail rows of a convolution)
     int cv_all_valid;                           // no tap of any output pixel falls outside the input (VALID, no padding)
     const char* zero;                           // >= 128 bytes of zeros
+    long long kchunk;                           // > 0: split-K -- workgroup id = tile * nchunks + c sums k in [c * kchunk, (c + 1) * kchunk)
+    double* P;                                  // ... into its chunk's partial tile P[c][M][N] (no bias, no activation)
+    int nchunks;
     long long tiles_m, tiles_n, nbr, nblocks;
     int br, bc, lg_blk;                         // blocks of br x bc = 1 << lg_blk tiles
     int tri_p;
@@ -298,7 +301,19 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     const int wr = w >> 1, wc = w & 1;
     // ---- workgroup id -> tile: blocks of br x bc = 32 tiles, one block per XCD at a time (gemm_dense.hip, tile order)
     long long tile_m, tile_n;
-    {
+    int chunk = 0;
+    if (!CONV && p.kchunk > 0) {
+        // split-K launches are small (fewer tiles than CUs): no blocks, no holes -- the id counts (tile, chunk) pairs, chunk
+        // fastest, so that consecutive ids (dealt round-robin to XCDs and shader engines) are all real work.  (With the
+        // chunk in grid.y every slice repeated the block order's holes: 500 workgroups of 1280 ran on the SAME hundred
+        // CUs' worth of positions, and five chunks took as long as one pass.)
+        const long long wg = blockIdx.x;
+        chunk = (int)(wg % p.nchunks);
+        const long long t = wg / p.nchunks;
+        tile_m = t % p.tiles_m;
+        tile_n = t / p.tiles_m;
+        if (tile_n >= p.tiles_n) return;
+    } else {
         const long long wg = blockIdx.x;
         const long long l = wg >> 3;
         long long gb = (l >> p.lg_blk) * 8 + (wg & 7);
@@ -336,6 +351,22 @@ __global__ __launch_bounds__(NT3, 2) void gemm_dma_f64_kernel(DmaArgs p) {
     }
     const long long m0 = tile_m * TM, n0 = tile_n * TNJ;
     if (p.tri_p > 0 && (p.tri_col0 + n0 + TNJ - 1) / p.tri_p <= (p.tri_row0 + m0) / p.tri_p) return;
+    if constexpr (!CONV) {
+        // split-K (few tiles, long K: the training step's 300-row products, an encode of a few frames): this workgroup's
+        // K range is chunk blockIdx.y; from here on the kernel is the one-pass kernel on the shifted operands, writing the
+        // bare sums to the chunk's partial tile.  kchunk is a multiple of the K tile, so only the last chunk has a tail.
+        if (p.kchunk > 0) {
+            const long long k0 = (long long)chunk * p.kchunk;
+            p.A += k0 * 8;
+            p.B += BLAYOUT == DLC_B_NK ? k0 * 8 : k0 * p.ldb_b;
+            const long long kc = p.K - k0 < p.kchunk ? p.K - k0 : p.kchunk;
+            long long kb = p.Kb - k0;
+            kb = kb < 0 ? 0 : (kb > kc ? kc : kb);
+            p.K = kc; p.Kb = kb;
+            p.C = p.P + (long long)chunk * p.M * p.N;
+            p.ldc = p.N; p.act = DLC_ACT_NONE; p.bias = nullptr;
+        }
+    }
     const int nkt = (int)((p.K + TK3 - 1) / TK3);
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)smem3;
 
@@ -700,10 +731,12 @@ int launch_one(dlc_ctx* ctx, const DmaArgs& a, long long nwg, hipStream_t st) {
 // force_tm: 128 / 256 rows per tile; dry: only say whether the launch would be taken (DLC_OK / 1).
 static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                            const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st,
-                           const ConvGeom* cv, const TriSkip* tri, int64_t Kb, int64_t m_base, int force_tm, bool dry, double alpha = 0.0) {
+                           const ConvGeom* cv, const TriSkip* tri, int64_t Kb, int64_t m_base, int force_tm, bool dry, double alpha = 0.0,
+                           int64_t kchunk = 0, double* partials = nullptr) {
     if (Kb <= 0 || Kb > K) Kb = K;
     // 16-byte pieces: operand rows must start on 16-byte boundaries and K, N be even (a piece = 2 doubles)
-    if (!ctx->zero_page || (K & 1) || (N & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 1)) return 1;
+    // ([N,K] operands: B's rows are K long and C is stored element by element, so N may be odd there)
+    if (!ctx->zero_page || (K & 1) || ((N & 1) && blayout != DLC_B_NK) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || (ldb & 1)) return 1;
     if (Kb != K && blayout != DLC_B_KN) return 1;          // a shorter B is a [K,N] operand with fewer rows
     if (Kb < (dlc::cdiv(K, (int64_t)TK3) - 1) * TK3) return 1;   // ... whose missing rows all lie in the last K tile
     // per-lane source offsets inside a tile are 32-bit: 256 rows of A, 128 rows ([N,K]) or 16 k-rows ([K,N]) of B
@@ -751,6 +784,9 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
                          (int64_t)(cv->OW - 1) * cv->stride + cv->KW <= cv->W;
     }
     a.zero = (const char*)ctx->zero_page;
+    a.kchunk = kchunk; a.P = partials;
+    const int chunks = kchunk > 0 ? (int)dlc::cdiv(K, kchunk) : 1;
+    a.nchunks = chunks;
     a.tiles_m = tiles_m; a.tiles_n = tiles_n;
     a.tri_p = tri ? tri->p : 0; a.tri_row0 = tri ? tri->row0 : 0; a.tri_col0 = tri ? tri->col0 : 0;
     // block of 32 tiles (one XCD's 32 CUs): 4 row tiles x 8 column tiles = 1024 x 1024 outputs, narrower where the
@@ -808,7 +844,7 @@ static int launch_dma_part(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_
         for (long long c = 0; c < a.tri_nbc; ++c, tw.step(a)) a.nblocks += tw.count(a);
         if (a.nblocks == 0) return DLC_OK;                               // nothing wanted (the caller never reads this block)
     }
-    const long long nwg = (dlc::cdiv(a.nblocks, (int64_t)8) * 8) << a.lg_blk;
+    const long long nwg = kchunk > 0 ? tiles_m * tiles_n * chunks : (dlc::cdiv(a.nblocks, (int64_t)8) * 8) << a.lg_blk;
     if (nwg > 0x7fffffffll) return 1;
     const int prof_slot = (int)(ctx->prof_calls % DLC_PROFILE_RING);
     if (ctx->profiling) DLC_HIP_CHECK(ctx, hipEventRecord(ctx->ev_start[prof_slot], st));
@@ -883,6 +919,17 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
     // the Gram blocks of the similarity: 64-row tiles for the same reason (similarity of 1063 frames 39.8 -> 39.0 ms)
     if (tri && N > 96 && dlc::cdiv(M, (int64_t)TM3) * dlc::cdiv(N, (int64_t)TN3) > 512) tm = TM3 / 4;
     return launch_dma_part(ctx, blayout, act, M, N, K, A, lda, B, ldb, bias, C, ldc, st, cv, tri, Kb, 0, tm, false, alpha);
+}
+
+// Split-K on 64-row tiles (plain operands, no triangle): `chunks` chunks of kchunk (a multiple of the K tile) into the
+// partial tiles P[chunks][M][N]; the caller sums them in chunk order and applies bias + activation (splitk_reduce_f64,
+// gemm_dense.hip).  DLC_OK, or 1 when the shape / alignment is not one the kernel handles (dry: only say which).
+int gemm_dma_f64_splitk(dlc_ctx* ctx, int blayout, int64_t M, int64_t N, int64_t K, int64_t Kb, const double* A, int64_t lda,
+                        const double* B, int64_t ldb, double* partials, int64_t kchunk, hipStream_t st, bool dry) {
+    if (kchunk <= 0 || kchunk % TK3 != 0 || kchunk < 4 * TK3 || !partials) return 1;
+    if (N <= 96) return 1;                                   // (the 96-column form keeps the 256-row tile)
+    return launch_dma_part(ctx, blayout, DLC_ACT_NONE, M, N, K, A, lda, B, ldb, nullptr, partials, N, st, nullptr, nullptr, Kb, 0,
+                           TM3 / 4, dry, 0.0, kchunk, partials);
 }
 
 // C += alpha * (A . B) in the epilogue of the LDS-DMA kernel (the SGD step of a weight gradient: W -= lr * dW without dW

@@ -31,6 +31,9 @@ int launch_dma_f64(dlc_ctx* ctx, int blayout, int act, int64_t M, int64_t N, int
                    const ConvGeom* cv, const TriSkip* tri, int64_t Kb = 0, double alpha = 0.0);
 int gemm_axpy_dma_f64(dlc_ctx* ctx, int blayout, double alpha, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                       const double* B, int64_t ldb, double* C, int64_t ldc, hipStream_t st);
+// split-K on the kernel's 64-row tiles: chunks of kchunk (a multiple of 16) into partials[chunks][M][N] (gemm_dma_f64.hip)
+int gemm_dma_f64_splitk(dlc_ctx* ctx, int blayout, int64_t M, int64_t N, int64_t K, int64_t Kb, const double* A, int64_t lda,
+                        const double* B, int64_t ldb, double* partials, int64_t kchunk, hipStream_t st, bool dry);
 
 // A zero-padded by the caller to lda = Kpad columns (columns K .. Kpad-1 are zeros): act(A[:, :K] . B + bias) with the
 // LDS-DMA kernel when it applies (it then walks Kpad), else the register-staged kernel on the first K columns.

@@ -11,6 +11,10 @@ int gemm_bias_act(dlc_ctx* ctx, int dtype, int blayout, int act, int64_t M, int6
                   int64_t lda, const void* B, int64_t ldb, const void* bias, void* C, int64_t ldc, hipStream_t st);
 int gemm_axpy_dma_f64(dlc_ctx* ctx, int blayout, double alpha, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                       const double* B, int64_t ldb, double* C, int64_t ldc, hipStream_t st);      // gemm_dma_f64.hip
+// A zero-padded to lda = Kpad columns, B [K, N] (gemm_dense.hip): the LDS-DMA forms (split-K on 64-row tiles when the context
+// has scratch and the tiles are few) where they apply, else the register-staged kernel on the first K columns
+int gemm_bias_act_padded_f64(dlc_ctx* ctx, int act, int64_t M, int64_t N, int64_t K, int64_t Kpad, const double* A,
+                             const double* B, int64_t ldb, const double* bias, double* C, int64_t ldc, hipStream_t st);
 }
 
 namespace {
@@ -31,12 +35,15 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 }
 
 // x_tilde[r, c] = x[r, c] * mask[r % P, c]     (TensorWrapper.corrupt, TensorflowWrapper.py:34-38)
+// out has pitch ldo >= cols; its columns cols .. ldo - 1 are written as zeros (an odd width -- the 1681 pixels of a patch -- is
+// padded to an even pitch so that the LDS-DMA GEMM's 16-byte pieces start on 16-byte boundaries: even_pitch below)
 __global__ __launch_bounds__(256) void mask_rows_kernel(const double* __restrict__ x, const double* __restrict__ mask,
-                                                        long long rows, int P, long long cols, double* __restrict__ out) {
-    const long long total = rows * cols;
+                                                        long long rows, int P, long long cols, double* __restrict__ out,
+                                                        long long ldo) {
+    const long long total = rows * ldo;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long r = e / cols, c = e - r * cols;
-        out[e] = x[e] * mask[(r % P) * cols + c];
+        const long long r = e / ldo, c = e - r * ldo;
+        out[e] = c < cols ? x[r * cols + c] * mask[(r % P) * cols + c] : 0.0;
     }
 }
 
@@ -214,13 +221,14 @@ __global__ __launch_bounds__(RM_THREADS) void random_mask_kernel(double* __restr
 
 // softmax_cross_entropy_with_logits_v2(labels, logits = y) per row (SDAV.py:172), mean over rows.
 // dz2 = d(cd)/d(y) * y(1-y);  dlab (optional) = d(cd)/d(labels) = -log_softmax(y)/rows.
-__global__ __launch_bounds__(256) void xent_grad_kernel(const double* __restrict__ y, const double* __restrict__ lab,
-                                                        long long rows, int cols, double* __restrict__ dz2,
+// lab has pitch ldl, dz2 pitch ldz >= cols (its columns past cols are written as zeros: the A operand of dh = dz2 W).
+__global__ __launch_bounds__(256) void xent_grad_kernel(const double* __restrict__ y, const double* __restrict__ lab, long long ldl,
+                                                        long long rows, int cols, double* __restrict__ dz2, long long ldz,
                                                         double* __restrict__ dlab, double* __restrict__ acc) {
     __shared__ double red[4];
     const long long r = blockIdx.x;
     const double* yr = y + r * cols;
-    const double* lr = lab + r * cols;
+    const double* lr = lab + r * ldl;
     double mx = -INFINITY;
     for (int c = threadIdx.x; c < cols; c += 256) mx = fmax(mx, yr[c]);
     mx = block_max(mx, red);
@@ -235,9 +243,10 @@ __global__ __launch_bounds__(256) void xent_grad_kernel(const double* __restrict
         const double logsm = yv - mx - lse;
         cd -= lv * logsm;
         const double dy = (exp(logsm) * sl - lv) * inv_rows;
-        dz2[r * cols + c] = dy * yv * (1.0 - yv);
+        dz2[r * ldz + c] = dy * yv * (1.0 - yv);
         if (dlab) dlab[r * cols + c] = -logsm * inv_rows;
     }
+    for (long long c = cols + threadIdx.x; c < ldz; c += 256) dz2[r * ldz + c] = 0.0;
     cd = block_sum(cd, red);
     if (threadIdx.x == 0) acc[r] = cd * inv_rows;             // cd_part[r]: summed in order by update_kernel's last workgroup
 }
@@ -316,15 +325,16 @@ __global__ __launch_bounds__(256) void backprop_input_kernel(const double* __res
 
 // out[c * ldo + r] = in[r, c]  (ldo >= rows: two transposes side by side make the K-stacked operand of the fused
 // weight-gradient product)
-__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, long long rows, long long cols,
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ in, long long ldi, long long rows, long long cols,
                                                         double* __restrict__ out, long long ldo,
-                                                        const double* __restrict__ in2 = nullptr, double* __restrict__ out2 = nullptr) {
+                                                        const double* __restrict__ in2 = nullptr, long long ldi2 = 0,
+                                                        double* __restrict__ out2 = nullptr) {
     __shared__ double tile[32][33];
-    if (blockIdx.z == 1) { in = in2; out = out2; }             // (a second matrix of the same shape in the same launch)
+    if (blockIdx.z == 1) { in = in2; ldi = ldi2; out = out2; } // (a second matrix of the same shape in the same launch)
     const long long r0 = (long long)blockIdx.y * 32, c0 = (long long)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
     for (int i = ty; i < 32; i += 8)
-        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(r0 + i) * cols + c0 + tx];
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(r0 + i) * ldi + c0 + tx];
     __syncthreads();
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < cols && r0 + tx < rows) out[(c0 + i) * ldo + r0 + tx] = tile[tx][i];
@@ -364,6 +374,7 @@ struct UpdateArgs {
     int n_b;                                    // bias vectors
     double* b[UP_MAX + 1]; const double* gb_rows[UP_MAX + 1]; long long b_cols[UP_MAX + 1]; long long b_blk0[UP_MAX + 2];
     long long b_rows[UP_MAX + 1];               // gradient rows to add up (1: gb_rows is the gradient itself)
+    long long b_ld[UP_MAX + 1];                 // ... and their pitch
     long long rows;
     double lr;
     // loss
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateArgs a) {
         double s = 0.0;
         if (c < cols) {
 #pragma unroll 4
-            for (long long r = rg; r < a.b_rows[m]; r += 8) s += in[r * cols + c];
+            for (long long r = rg; r < a.b_rows[m]; r += 8) s += in[r * a.b_ld[m] + c];
         }
         part[rg][cl] = s;
         __syncthreads();
@@ -453,6 +464,8 @@ struct TrainWs {
     size_t y, dz2, dlab, dh, dz1a, dz1b, dxt, tr, gbd, nrm, nrm_part, l1_part, cd_part, acc, total;   // (gw2 is gone: one product makes both uses of the tied weight)
 };
 
+inline int64_t even_pitch(int64_t cols) { return cols + (cols & 1); }
+
 TrainWs train_ws(int64_t rows, int batch, const int64_t* dims, int layer) {
     TrainWs w;
     size_t o = 0;
@@ -460,7 +473,7 @@ TrainWs train_ws(int64_t rows, int batch, const int64_t* dims, int layer) {
     int64_t wmax = 0;
     for (int l = 0; l <= layer + 1; ++l) wmax = dims[l] > wmax ? dims[l] : wmax;
     for (int l = 0; l <= layer; ++l) {
-        w.xt[l] = take((size_t)rows * dims[l]);
+        w.xt[l] = take((size_t)rows * even_pitch(dims[l]));
         // behind the trained layer's h: the first dz1 (hidden_grad_kernel's output) -- [h ; dz1] is the K-stacked B operand
         // of the fused weight-gradient product
         w.h[l] = take((size_t)rows * dims[l + 1] * (l == layer ? 2 : 1));
@@ -468,7 +481,7 @@ TrainWs train_ws(int64_t rows, int batch, const int64_t* dims, int layer) {
         w.gbe[l] = take((size_t)dims[l + 1]);
     }
     w.y = take((size_t)rows * dims[layer]);
-    w.dz2 = take((size_t)rows * dims[layer]);
+    w.dz2 = take((size_t)rows * even_pitch(dims[layer]));
     w.dlab = take((size_t)rows * dims[layer]);
     w.dh = take((size_t)rows * wmax);
     w.dz1a = take((size_t)rows * wmax);
@@ -528,19 +541,25 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
     // ---- forward through layers 0..layer (old parameters everywhere)
     const double* cur = x;
     for (int l = 0; l <= layer; ++l) {
-        hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(rows * dims[l])), dim3(256), 0, st, cur, masks[l], rows, Pn,
-                           (long long)dims[l], P(w.xt[l]));
-        GEMM(DLC_B_KN, DLC_ACT_SIGMOID, rows, dims[l + 1], dims[l], P(w.xt[l]), dims[l], W[l], dims[l + 1], b_enc[l],
-             P(w.h[l]), dims[l + 1]);
+        const long long kp = even_pitch(dims[l]);                  // (1681 -> 1682: a zero column the weights have no row for)
+        hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(rows * kp)), dim3(256), 0, st, cur, masks[l], rows, Pn,
+                           (long long)dims[l], P(w.xt[l]), kp);
+        {
+            const int rc_ = dlc_gemm::gemm_bias_act_padded_f64(ctx, DLC_ACT_SIGMOID, rows, dims[l + 1], dims[l], kp, P(w.xt[l]), W[l],
+                                                              dims[l + 1], b_enc[l], P(w.h[l]), dims[l + 1], st);
+            if (rc_ != DLC_OK) return rc_;
+        }
         cur = P(w.h[l]);
     }
     const long long K = dims[layer], N = dims[layer + 1];
     const double* h = P(w.h[layer]);
     GEMM(DLC_B_NK, DLC_ACT_SIGMOID, rows, K, N, h, N, W[layer], N, b_dec, P(w.y), K);            // y = sigmoid(h W^T + b_d)
-    const double* labels = layer == 0 ? x : P(w.xt[layer]);
+    const long long Kp = even_pitch(K);                            // pitch of x~ and dz2 at the trained layer
+    const double* labels = layer == 0 ? x : P(w.xt[layer]);       // (x: the caller's, pitch K; x~ of a deeper layer: K is even there
+    const long long ld_labels = layer == 0 ? K : Kp;              //  or the pitch is Kp)
 
     // ---- loss pieces and the gradient at the trained layer
-    hipLaunchKernelGGL(xent_grad_kernel, dim3((unsigned)rows), dim3(256), 0, st, P(w.y), labels, rows, (int)K, P(w.dz2),
+    hipLaunchKernelGGL(xent_grad_kernel, dim3((unsigned)rows), dim3(256), 0, st, P(w.y), labels, ld_labels, rows, (int)K, P(w.dz2), Kp,
                        layer > 0 ? P(w.dlab) : (double*)nullptr, P(w.cd_part));
     // tf.norm(h - s, axis=1, ord=1) + reduce_mean (SDAV.py:174): h is [B,P,N] at layer 0, [B*P,N] afterwards
     const double cs_den = layer == 0 ? (double)batch * (double)N : (double)rows;
@@ -552,7 +571,10 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
                            (long long)patches * N, sparse_level, cs_den, P(w.nrm_part), P(w.l1_part));
         fn_slices = (int)slices;
     }
-    GEMM(DLC_B_KN, DLC_ACT_NONE, rows, N, K, P(w.dz2), K, W[layer], N, nullptr, P(w.dh), N);      // dh = dz2 W
+    {                                                                                             // dh = dz2 W
+        const int rc_ = dlc_gemm::gemm_bias_act_padded_f64(ctx, DLC_ACT_NONE, rows, N, K, Kp, P(w.dz2), W[layer], N, nullptr, P(w.dh), N, st);
+        if (rc_ != DLC_OK) return rc_;
+    }
     double* dz1 = P(w.h[layer]) + rows * N;                   // right behind h
     if ((size_t)batch * 8 > 48 * 1024) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "sdav_train_step: batch too large");
     hipLaunchKernelGGL(hidden_grad_kernel, dim3(grid_for(rows * N)), dim3(256), (size_t)batch * 8, st, h, P(w.dh), P(w.nrm_part),
@@ -594,12 +616,12 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
             // run well: 80 us apiece): d/dW = dz2^T h (decoder use) + x~^T dz1 (encoder use) = [dz2^T | x~^T] . [h ; dz1],
             // K = 2 rows (dz1 lies right behind h).
             hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(K, 32), (unsigned)dlc::cdiv(rows, 32), 2), dim3(256), 0, st,
-                               P(w.dz2), rows, K, P(w.tr), 2 * rows, (const double*)P(w.xt[layer]), P(w.tr) + rows);
+                               P(w.dz2), Kp, rows, K, P(w.tr), 2 * rows, (const double*)P(w.xt[layer]), Kp, P(w.tr) + rows);
             const int rc_ = weight_step(l, K, N, 2 * rows, h);
             if (rc_ != DLC_OK) return rc_;
         } else {
             hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)dlc::cdiv(Kl, 32), (unsigned)dlc::cdiv(rows, 32)), dim3(256), 0,
-                               st, P(w.xt[l]), rows, Kl, P(w.tr), rows);
+                               st, P(w.xt[l]), even_pitch(Kl), rows, Kl, P(w.tr), rows);
             const int rc_ = weight_step(l, Kl, Nl, rows, dz1);                                          // x~^T dz1
             if (rc_ != DLC_OK) return rc_;
         }
@@ -625,10 +647,12 @@ extern "C" int dlc_sdav_train_step(dlc_ctx* ctx, int layer, int64_t batch, int64
             u.b[l] = b_enc[l]; u.b_cols[l] = dims[l + 1];
             if (dz1_of[l]) { u.gb_rows[l] = dz1_of[l]; u.b_rows[l] = rows; }
             else { u.gb_rows[l] = P(w.gbe[l]); u.b_rows[l] = 1; }
+            u.b_ld[l] = dims[l + 1];
             u.b_blk0[l] = blk;
             blk += dlc::cdiv(dims[l + 1], (int64_t)32);
         }
         u.b[layer + 1] = b_dec; u.gb_rows[layer + 1] = P(w.dz2); u.b_rows[layer + 1] = rows; u.b_cols[layer + 1] = K;
+        u.b_ld[layer + 1] = Kp;
         u.b_blk0[layer + 1] = blk;
         blk += dlc::cdiv(K, (int64_t)32);
         u.b_blk0[layer + 2] = blk;
