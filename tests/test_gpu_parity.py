@@ -578,6 +578,37 @@ def test_gemm_split_k_latency_mode(eng, m, n, k, blayout):
     assert (split - one_pass).abs().max().item() < 1e-12
 
 
+@pytest.mark.parametrize("m,n,k,blayout", [(300, 2500, 2500, "kn"), (300, 1681, 2500, "nk"), (300, 2501, 2500, "nk"), (77, 130, 4096, "kn"),
+                                           (200, 256, 8190, "nk"), (1, 2500, 2502, "kn"), (255, 1000, 644, "kn"), (64, 128, 130, "kn"),
+                                           (320, 1024, 1682, "nk"), (129, 98, 5000, "kn")])
+def test_gemm_dma_split_k_shapes(eng, m, n, k, blayout):
+    """Few 64-row tiles and a long even K: split-K on the LDS-DMA kernel's 64-row tiles (r06: the training step's 300-row
+    products, an encode of a few frames) -- chunk tails (K % 16, K % chunk), an odd N for [N,K] operands, a single row, a K too
+    short to split (one pass), every activation: 1e-11 from NumPy's fp64 product, the same bits run after run, and within the
+    summation order of the one-pass result."""
+    from deeploopcloser_amd import _lib as L
+    from oracle import tensor_ops
+    rng = np.random.RandomState(m * 7 + n + k)
+    a = rng.standard_normal((m, k)) / np.sqrt(k)
+    b = rng.standard_normal((k, n)) if blayout == "kn" else rng.standard_normal((n, k))
+    bias = rng.standard_normal(n)
+    z = a @ (b if blayout == "kn" else b.T) + bias
+    ta, tb, tbias = (torch.from_numpy(np.ascontiguousarray(v)).to(eng.device) for v in (a, b, bias))
+    lay = L.DLC_B_KN if blayout == "kn" else L.DLC_B_NK
+    for act, fn in ((L.DLC_ACT_NONE, lambda v: v), (L.DLC_ACT_SIGMOID, tensor_ops.sigmoid), (L.DLC_ACT_RELU, lambda v: np.maximum(v, 0))):
+        one_pass = eng.gemm_bias_act(ta, tb, tbias, act=act, blayout=lay)
+        with eng.latency_mode():
+            split = eng.gemm_bias_act(ta, tb, tbias, act=act, blayout=lay)
+            again = eng.gemm_bias_act(ta, tb, tbias, act=act, blayout=lay)
+            nobias = eng.gemm_bias_act(ta, tb, None, act=L.DLC_ACT_NONE, blayout=lay)
+        ref = fn(z)
+        scale = max(1.0, np.abs(ref).max())
+        assert torch.equal(split, again)
+        assert np.abs(split.cpu().numpy() - ref).max() < 1e-11 * scale
+        assert np.abs(one_pass.cpu().numpy() - ref).max() < 1e-11 * scale
+        assert np.abs(nobias.cpu().numpy() - (z - bias)).max() < 1e-11 * scale
+
+
 def test_conv_and_gemm_fuzz_in_both_modes(eng):
     """Seeded random conv geometries (C % 8 == 0) and GEMM shapes, one-pass and split-K (scratch on):
     both within 1e-10 of the oracle; the split start (ky, kx, c) of every K chunk is exercised."""
