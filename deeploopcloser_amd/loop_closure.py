@@ -171,6 +171,8 @@ class SdavLoopClosureDetector:
         x = eng.to_device(frames, torch.float64)
         if x.dim() == 2:
             x = x.unsqueeze(0)
+        if x.dim() != 3 or x.shape[1] != st.p or x.shape[2] != st.h:       # (before a ticket is spent on it)
+            raise ValueError("frames must be [B, %d, %d]" % (st.p, st.h))
         b, first = x.shape[0], len(st)
         if not hasattr(self, "_slots"):
             self._slots, self._pending, self._tickets = [{}, {}], None, 0
@@ -178,7 +180,7 @@ class SdavLoopClosureDetector:
         self._tickets += 1
         main, side = torch.cuda.current_stream(eng.device), eng.side_stream
         slot = self._slots[t % 2]
-        if b < self.PIPELINE_MIN_BATCH or first == 0 or first + b > st.capacity or x.dim() != 3:
+        if b < self.PIPELINE_MIN_BATCH or first == 0 or first + b > st.capacity:
             self._flush()                                              # (a growing stream re-quantises everything: nothing in flight)
             main.wait_stream(side)
             slot.update({"ticket": t, "out": self.query_and_insert(x)})

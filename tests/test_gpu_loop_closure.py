@@ -440,6 +440,10 @@ def test_detector_two_batches_in_flight_equals_batch_by_batch():
         assert int(piped.stream.stats[1]) == 0
     with pytest.raises(ValueError):
         piped.result(0)                                               # long gone
+    before = piped._tickets
+    with pytest.raises(ValueError):
+        piped.submit(ds[:9, :, :7])                                   # a wrong width: refused before a ticket is spent
+    assert piped._tickets == before and len(piped) == n
     # the two halves of the strip form through the engine: stage 1 + stage 2 == the one call
     st = piped.stream
     first, b = 100, 32
