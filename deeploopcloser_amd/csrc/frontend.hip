@@ -35,25 +35,43 @@ __device__ __forceinline__ int window_lo(int c, int dim, int half) {
     return lo - back + fwd;
 }
 
+constexpr int EP_PATCHES = 1;                              // patches per workgroup (4: 140 us against 111 -- fewer workgroups, each a serial chain)
 template <typename T>
 __global__ __launch_bounds__(256) void extract_patches_kernel(const unsigned char* __restrict__ gray, int H, int W,
-                                                              const int* __restrict__ kp, int P, int ps,
+                                                              const int* __restrict__ kp, int P, int ps, long long n_patches,
                                                               T* __restrict__ out) {
-    const long long fp = blockIdx.x;                       // frame * P + patch
-    const long long frame = fp / P;
-    const int cx = kp[fp * 2], cy = kp[fp * 2 + 1];       // (x, y) = kp.pt rounded; x walks dim 0 (:111-119)
-    const int x0 = window_lo(cx, H, ps / 2), y0 = window_lo(cy, W, ps / 2);
-    const unsigned char* img = gray + frame * (long long)H * W;
-    T* o = out + fp * (long long)ps * ps;
     __shared__ T by255[256];                                           // the 256 quotients once, not a division per element
     by255[threadIdx.x] = (T)threadIdx.x / (T)255.0;
     __syncthreads();
     const int step_x = 256 / ps, step_y = 256 - step_x * ps;           // e += 256 without an integer division per element
-    int dx = threadIdx.x / ps, dy = threadIdx.x - dx * ps;
-    for (int e = threadIdx.x; e < ps * ps; e += 256) {
-        o[e] = by255[img[(long long)(x0 + dx) * W + (y0 + dy)]];
-        dx += step_x; dy += step_y;
-        if (dy >= ps) { dy -= ps; ++dx; }
+    const int total = ps * ps;
+    for (int pi = 0; pi < EP_PATCHES; ++pi) {
+        const long long fp = (long long)blockIdx.x * EP_PATCHES + pi;  // frame * P + patch
+        if (fp >= n_patches) return;
+        const long long frame = fp / P;
+        const int cx = kp[fp * 2], cy = kp[fp * 2 + 1];               // (x, y) = kp.pt rounded; x walks dim 0 (:111-119)
+        const int x0 = window_lo(cx, H, ps / 2), y0 = window_lo(cy, W, ps / 2);
+        const unsigned char* img = gray + frame * (long long)H * W;
+        T* o = out + fp * (long long)total;
+        int dx = threadIdx.x / ps, dy = threadIdx.x - dx * ps;
+        // eight elements of a thread at a time: all their byte loads first, then the table reads, then the stores (one
+        // element after the other was seven dependent round trips -- pixel, table, store -- per thread of a 41 x 41 patch)
+        for (int e0 = threadIdx.x; e0 < total; e0 += 8 * 256) {
+            unsigned char v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = e0 + u * 256 < total;
+                v[u] = ok ? img[(long long)(x0 + dx) * W + (y0 + dy)] : (unsigned char)0;
+                dx += step_x; dy += step_y;
+                if (dy >= ps) { dy -= ps; ++dx; }
+            }
+            T q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = by255[v[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * 256 < total) o[e0 + u * 256] = q[u];
+        }
     }
 }
 
@@ -415,13 +433,13 @@ extern "C" int dlc_extract_patches(dlc_ctx* ctx, const uint8_t* gray, int64_t fr
     if (frames * P > 0x7fffffffll) return dlc::fail(ctx, DLC_ERR_BAD_SHAPE, "extract_patches: too many patches");
     dlc::DeviceGuard guard(ctx->device);
     if (!guard.ok) return dlc::fail(ctx, DLC_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
-    dim3 grid((unsigned)(frames * P));
+    dim3 grid((unsigned)dlc::cdiv(frames * P, (int64_t)EP_PATCHES));
     if (out_dtype == DLC_F64)
         hipLaunchKernelGGL(extract_patches_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, gray, H, W,
-                           (const int*)key_points, P, patch_size, (double*)out);
+                           (const int*)key_points, P, patch_size, (long long)(frames * P), (double*)out);
     else if (out_dtype == DLC_F32)
         hipLaunchKernelGGL(extract_patches_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, gray, H, W,
-                           (const int*)key_points, P, patch_size, (float*)out);
+                           (const int*)key_points, P, patch_size, (long long)(frames * P), (float*)out);
     else
         return dlc::fail(ctx, DLC_ERR_UNSUPPORTED, "extract_patches: out dtype %d", out_dtype);
     DLC_LAUNCH_CHECK(ctx, "extract_patches_kernel");
