@@ -60,6 +60,34 @@ for case in range(cases):
         for q in range(cnt):
             assert same(rows[q, :first + q], want[:first + q, first + q]), ("resident", case, p, h, n, first, cnt, q)
         rows_checked += cnt
+    # r06: the detector with two batches in flight (submit / result: the strip's product kernel on a second stream, the small
+    # kernels of the neighbouring batches beside it) against the detector batch by batch -- the same lists bit for bit
+    k_, ex_ = int(rng.randint(1, 9)), int(rng.randint(0, 5))
+    cap_ = int(rng.choice([1, 8, n]))
+    plain = dlc.SdavLoopClosureDetector(score, patches=p, width=h, k=k_, exclusion=ex_, capacity=cap_)
+    piped = dlc.SdavLoopClosureDetector(score, patches=p, width=h, k=k_, exclusion=ex_, capacity=cap_)
+    f, prev, wl, gl = 0, None, [], []
+    late = rng.rand() < 0.7
+    while f < n:
+        b = int(min(n - f, rng.choice([1, 7, 8, 9, 16, 31, 32, 33, 64, rng.randint(1, 100)])))
+        wl.append(plain.query_and_insert(ds[f:f + b]))
+        t_ = piped.submit(ds[f:f + b])
+        if late:
+            if prev is not None:
+                gl.append(piped.result(prev))
+            prev = t_
+        else:
+            gl.append(piped.result(t_))
+        f += b
+    if late:
+        gl.append(piped.result(prev))
+    ws_, wi_ = torch.cat([w_[0] for w_ in wl]), torch.cat([w_[1] for w_ in wl])
+    gs_, gi_ = torch.cat([o_[0] for o_ in gl]), torch.cat([o_[1] for o_ in gl])
+    torch.cuda.synchronize()
+    assert torch.equal(wi_, gi_) and torch.equal(torch.nan_to_num(ws_, posinf=1e300, neginf=-1e300), torch.nan_to_num(gs_, posinf=1e300, neginf=-1e300)), \
+        ("pipelined detector", case, p, h, n, k_, ex_, cap_, late)
+    piped_rows = globals().get("piped_rows", 0) + n
 torch.cuda.synchronize()
+print("pipelined detector: %d frames' lists equal to the batch-by-batch detector's" % piped_rows, flush=True)
 print("streaming similarity: %d cases, %d rows bit-identical to the matrix call's columns (%d batches as strips; %d direct evaluations) in %.0f s"
       % (cases, rows_checked, strips, directs, time.time() - t0), flush=True)
